@@ -1,0 +1,146 @@
+/*
+ * ojf.h — C ABI of libojf.so, the MI355X (gfx950) implementation of the per-frame hot path of
+ * online joint depth fusion + semantics:  extract (ray gather)  ->  fusion net  ->  integrate
+ * (scatter).  This is the drop-in boundary: the reference itself has no native layer on this path
+ * (SURVEY.md §2.3), so every entry point below names the reference *Python* interface it replaces.
+ * INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; ojf_last_error() gives the message of the
+ *     calling thread's last failure.  Nothing throws, nothing aborts.
+ *   - "dev" pointers are device (HBM) addresses, "host" pointers are ordinary host memory read
+ *     before the call returns.  No torch types cross this boundary.
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream) and
+ *     is asynchronous; the library never synchronises the device on the hot path.
+ *   - volumes are [X,Y,Z] row-major (linear = (ix*Y + iy)*Z + iz, modules/integrator.py:57):
+ *     TSDF fp16, weights fp16, semantic ids u8, semantic scores fp16 (modules/database.py:60-76).
+ *   - camera: Kinv = inverse(float(K)) row-major f32[9] (modules/extractor.py:39,104),
+ *     E = first three rows of the float32 camera-to-world matrix, row-major f32[12]
+ *     (modules/extractor.py:40,57,115), origin f64[3] and resolution f64 (modules/database.py:57-58).
+ */
+#ifndef OJF_H
+#define OJF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *ojf_stream_t; /* hipStream_t */
+
+/* integrate modes */
+#define OJF_MODE_FAST 0   /* order-free fixed-point accumulation; deterministic; TSDF within 1 fp16 ulp */
+#define OJF_MODE_PARITY 1 /* per-voxel fp32 sums in the reference's entry order; bit-exact TSDF/weights */
+
+/* activation codes for ojf_conv2d */
+#define OJF_ACT_NONE 0
+#define OJF_ACT_RELU 1
+#define OJF_ACT_LEAKY 2 /* negative slope 0.01 (nn.LeakyReLU default, modules/model.py:12) */
+#define OJF_ACT_TANH 3
+
+const char *ojf_version(void);
+const char *ojf_last_error(void);
+/* number of visible HIP devices, or <0 with ojf_last_error() set (no GPU / no driver) */
+int ojf_device_count(void);
+
+/* ---- EXTRACT -------------------------------------------------------------------------------
+ * Replaces Extractor.forward (modules/extractor.py:24-79): compute_coordinates (:82-120),
+ * extract_values (:309-345), interpolation_weights (:533-593), trilinear_interpolation (:640-681).
+ * depth: dev f32[h*w], the UNFILTERED frame (modules/pipeline.py:202).
+ * out_values / out_weights: dev f32, element (pixel n, sample k) at [n*out_stride + k]; the
+ *   reference's fusion_values / fusion_weights are the out_stride == n_points case.
+ * pad_value: what out-of-volume corners read for TSDF (-0.1 in the reference, extractor.py:663).
+ * Optional debug outputs (NULL to skip) reproduce the other entries of the reference's dict:
+ *   dbg_indices i64[h*w,n_points,8,3], dbg_weights f64[h*w,n_points,8], dbg_points f64[h*w,n_points,3],
+ *   dbg_pcl f32[h*w,3]. */
+int ojf_extract(const float *depth_dev, const float *Kinv_host, const float *E_host,
+                const double *origin_host, double resolution, const uint16_t *tsdf_dev,
+                const uint16_t *weights_dev, int X, int Y, int Z, int h, int w, int n_points,
+                float pad_value, float *out_values_dev, float *out_weights_dev, int out_stride,
+                int64_t *dbg_indices_dev, double *dbg_weights_dev, double *dbg_points_dev,
+                float *dbg_pcl_dev, ojf_stream_t stream);
+
+/* ---- INTEGRATE -----------------------------------------------------------------------------
+ * Replaces Pipeline._prepare_volume_update (modules/pipeline.py:137-171) + Integrator.forward
+ * (modules/integrator.py:15-126).  Indices and corner weights are recomputed from depth and pose
+ * (bit-identical to ojf_extract) instead of being materialised.
+ * depth_filtered: dev f32[h*w] = where(mask, depth, 0) (pipeline.py:196); a pixel integrates iff != 0.
+ * est: dev f32, net output for (pixel n, sample k) at [n*est_stride + k]; clamped to +-trunc here.
+ * sem_ids u8[h*w] / sem_scores f32[h*w] / id_vol / score_vol: all four non-NULL to run the semantic
+ *   update (integrator.py:90-124, "test" mode); all NULL to skip it.
+ * workspace: dev memory of ojf_integrate_workspace_bytes(), prepared once by
+ *   ojf_integrate_workspace_init(); it is left clean by every call and may be shared by all
+ *   scenes of one grid size on one stream.
+ * stats_dev (optional, NULL to skip): dev u32[4] receiving {touched voxels, scatter entries, 0, 0}. */
+size_t ojf_integrate_workspace_bytes(int X, int Y, int Z, int h, int w, int n_tail, int mode);
+int ojf_integrate_workspace_init(void *workspace_dev, size_t workspace_bytes, int X, int Y, int Z,
+                                 int h, int w, int n_tail, int mode, ojf_stream_t stream);
+int ojf_integrate(const float *depth_filtered_dev, const float *Kinv_host, const float *E_host,
+                  const double *origin_host, double resolution, const float *est_dev,
+                  int est_stride, int n_points, int n_tail, float trunc, uint16_t *tsdf_dev,
+                  uint16_t *weights_dev, const uint8_t *sem_ids_dev, const float *sem_scores_dev,
+                  uint8_t *id_vol_dev, uint16_t *score_vol_dev, int X, int Y, int Z, int h, int w,
+                  int mode, void *workspace_dev, size_t workspace_bytes, uint32_t *stats_dev,
+                  ojf_stream_t stream);
+
+/* ---- FUSION NET ------------------------------------------------------------------------------
+ * Replaces FusionNet_v3.forward / FusionNet_v2.forward in eval mode (modules/model.py:164-283)
+ * together with Pipeline._prepare_fusion_input / _fusion (modules/pipeline.py:62-102).
+ * The host folds every BatchNorm into the preceding convolution and hands the folded layers over
+ * in the canonical order documented in DESIGN.md §"net layer order"; the library repacks them for
+ * the MFMA kernels and owns that copy plus the activation workspace (sized for h x w). */
+typedef struct ojf_net ojf_net;
+typedef struct ojf_conv_layer {
+    int c_in, c_out, ksize, dilation; /* square kernels, stride 1, padding = dilation*(ksize/2) */
+    const float *weight_host;         /* [c_out, c_in, ksize, ksize] fp32, BN folded */
+    const float *bias_host;           /* [c_out] fp32, BN folded */
+} ojf_conv_layer;
+
+/* version: 2 or 3 (FusionNet_v2 / FusionNet_v3).  n_points = 9, growth = growth_factor - 1 = 5 in
+ * every reference config (the YAML files under configs/fusion). */
+int ojf_net_create(ojf_net **out, int version, int n_points, int growth, int use_semantics,
+                   float output_scale, const ojf_conv_layer *layers_host, int n_layers, int h,
+                   int w);
+void ojf_net_destroy(ojf_net *net);
+/* number of folded conv layers ojf_net_create expects for this topology, <0 if unsupported */
+int ojf_net_layer_count(int version, int n_points, int growth, int use_semantics);
+/* Device pointer + pixel stride (floats) of the net's input rows: channel c of pixel n lives at
+ * base[n*stride + c]; channels [0,P) fusion_values, [P,2P) fusion_weights, [2P] depth frame.  With
+ * semantics (v3) a second row set holds [values | weights | (1+id)/n_classes] (model.py:274).
+ * ojf_extract can write straight into these (out_stride = stride). */
+int ojf_net_input(ojf_net *net, int head, float **base_dev, int *stride);
+/* Fills channel 2P of head 0 with the depth frame and, when the net uses semantics, head 1 with
+ * values | weights (copied from head 0) | (1+sem_id)/n_classes  (pipeline.py:90-96). */
+int ojf_net_prepare_input(ojf_net *net, const float *depth_dev, const uint8_t *sem_ids_dev,
+                          int n_classes, ojf_stream_t stream);
+/* Runs the net; est_dev receives output_scale*tanh(.) for (pixel n, sample k) at [n*est_stride+k]. */
+int ojf_net_forward(ojf_net *net, float *est_dev, int est_stride, ojf_stream_t stream);
+/* useful multiply-accumulates per pixel of this topology (padding excluded) */
+int64_t ojf_net_macs_per_pixel(const ojf_net *net);
+
+/* Stand-alone fused convolution on NHWC fp32 rows (the kernel the net is built from; exported so
+ * the parity tests can pin it layer by layer against torch.nn.functional.conv2d).
+ * in: [h*w, in_stride], channels [in_off, in_off+c_in); out likewise.  weight [c_out,c_in,k,k]. */
+int ojf_conv2d(const float *in_dev, int in_stride, int in_off, float *out_dev, int out_stride,
+               int out_off, const ojf_conv_layer *layer_host, int act, int h, int w,
+               ojf_stream_t stream);
+
+/* ---- VOLUME HELPERS (Database) -------------------------------------------------------------
+ * ojf_volume_fill_*: Database.reset (modules/database.py:351-370).
+ * ojf_volume_filter: Database.filter (:108-112): where weights < value: tsdf = init_value, weights = 0.
+ * ojf_volume_evaluate: utils/metrics.py:111-127 evaluation() on device: with mask = weights > 0 and
+ *   est/gt clipped to +-0.04, sums_dev f64[8] receives {n_mask, sum_sq_err, sum_abs_err,
+ *   n_intersection(est<0 & gt<0), n_union(est<0 | gt<0), n_sign_equal, 0, 0}. */
+int ojf_volume_fill_f16(uint16_t *vol_dev, size_t n, float value, ojf_stream_t stream);
+int ojf_volume_fill_u8(uint8_t *vol_dev, size_t n, uint8_t value, ojf_stream_t stream);
+int ojf_volume_filter(uint16_t *tsdf_dev, uint16_t *weights_dev, size_t n, float threshold,
+                      float init_value, ojf_stream_t stream);
+int ojf_volume_evaluate(const uint16_t *est_dev, const uint16_t *gt_dev, const uint16_t *weights_dev,
+                        size_t n, double *sums_dev, ojf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OJF_H */

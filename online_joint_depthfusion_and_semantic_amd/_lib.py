@@ -1,0 +1,104 @@
+"""ctypes binding of libojf.so (C ABI in include/ojf.h).
+
+There is NO fallback: if the shared library is missing, or a call is made without a GPU,
+this module raises.  The product path never routes through the CPU oracle.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libojf.so')
+
+MODE_FAST = 0
+MODE_PARITY = 1
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3
+
+
+class OjfError(RuntimeError):
+    pass
+
+
+class ConvLayer(ctypes.Structure):
+    _fields_ = [('c_in', ctypes.c_int), ('c_out', ctypes.c_int), ('ksize', ctypes.c_int),
+                ('dilation', ctypes.c_int), ('weight_host', ctypes.c_void_p),
+                ('bias_host', ctypes.c_void_p)]
+
+
+_c = ctypes
+_vp, _i, _f, _d, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_double, _c.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/ojf.h declares
+SIGNATURES = {
+    'ojf_version': (_c.c_char_p, []),
+    'ojf_last_error': (_c.c_char_p, []),
+    'ojf_device_count': (_i, []),
+    'ojf_extract': (_i, [_vp, _vp, _vp, _vp, _d, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i,
+                         _vp, _vp, _vp, _vp, _vp]),
+    'ojf_integrate_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    'ojf_integrate_workspace_init': (_i, [_vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'ojf_integrate': (_i, [_vp, _vp, _vp, _vp, _d, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp,
+                           _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
+    'ojf_net_create': (_i, [_c.POINTER(_vp), _i, _i, _i, _i, _f, _c.POINTER(ConvLayer), _i, _i, _i]),
+    'ojf_net_destroy': (None, [_vp]),
+    'ojf_net_layer_count': (_i, [_i, _i, _i, _i]),
+    'ojf_net_input': (_i, [_vp, _i, _c.POINTER(_vp), _c.POINTER(_i)]),
+    'ojf_net_prepare_input': (_i, [_vp, _vp, _vp, _i, _vp]),
+    'ojf_net_forward': (_i, [_vp, _vp, _i, _vp]),
+    'ojf_net_macs_per_pixel': (_c.c_int64, [_vp]),
+    'ojf_conv2d': (_i, [_vp, _i, _i, _vp, _i, _i, _c.POINTER(ConvLayer), _i, _i, _i, _vp]),
+    'ojf_volume_fill_f16': (_i, [_vp, _sz, _f, _vp]),
+    'ojf_volume_fill_u8': (_i, [_vp, _sz, _c.c_uint8, _vp]),
+    'ojf_volume_filter': (_i, [_vp, _vp, _sz, _f, _f, _vp]),
+    'ojf_volume_evaluate': (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
+}
+
+_LIB = None
+
+
+def load():
+    """Load libojf.so and bind every declared symbol.  Raises OjfError if the library is absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise OjfError('libojf.so not found at {}: build it with `python -c "import __graft_entry__ as g; '
+                       'g.build()"` or `make -C {}/csrc` (there is no CPU fallback)'.format(LIB_PATH, _HERE))
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise OjfError('{} failed (rc={}): {}'.format(what, rc, load().ojf_last_error().decode()))
+
+
+def require_gpu():
+    lib = load()
+    n = lib.ojf_device_count()
+    if n <= 0:
+        raise OjfError('no MI355X/HIP device visible: {} (the HIP path has no CPU fallback)'.format(
+            lib.ojf_last_error().decode()))
+    return n
+
+
+def ptr(t):
+    """Device/host address of a torch tensor or numpy array (None -> NULL)."""
+    if t is None:
+        return None
+    if isinstance(t, np.ndarray):
+        assert t.flags.c_contiguous
+        return t.ctypes.data
+    assert t.is_contiguous(), 'tensor handed to libojf must be contiguous'
+    return t.data_ptr()
+
+
+def stream_ptr(device=None):
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,130 @@
+// Shared host/device helpers of libojf (gfx950 only; no CUDA/portability layer by design).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/ojf.h"
+
+#define OJF_API extern "C" __attribute__((visibility("default")))
+
+namespace ojf {
+
+void set_error(const std::string &msg);
+int fail(const std::string &msg);
+int check_hip(hipError_t e, const char *what);
+
+#define OJF_HIP(call)                                  \
+    do {                                               \
+        int rc__ = ::ojf::check_hip((call), #call);    \
+        if (rc__) return rc__;                         \
+    } while (0)
+
+static inline hipStream_t as_stream(ojf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- camera + ray geometry ------------------------------------------------------------------
+// Passed by value as a kernel argument (lives in SGPRs / the kernarg segment).
+struct Camera {
+    float Ki[9];    // inverse intrinsics, row-major
+    float E[12];    // rows of the 3x4 camera-to-world matrix
+    double origin[3];
+    double res;
+    double eye_v[3];  // (E[:,3] - origin) / res, hoisted to the host: same IEEE f64 ops
+};
+
+Camera make_camera(const float *Ki, const float *E, const double *origin, double res);
+
+// fp16 bit pattern <-> fp32 (round-to-nearest-even on the way down, like torch .half())
+__device__ __forceinline__ float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+
+// One sample of one ray: everything the gather and the scatter need, bit-identical in both.
+// The rounding points are normative (oracle/ojf_oracle.c): compiled with
+// -ffp-contract=off, the only fused operations are the explicit fma calls below.
+struct RaySample {
+    int64_t fl[3];   // floor(p)
+    int nb[3];       // sign(centre - p) in {-1,0,1}
+    double a[3];     // |p - centre|
+    double p[3];
+};
+
+__device__ __forceinline__ void unproject(int r, int c, float z, const Camera &cam, float pw[3])
+{
+    // modules/extractor.py:112-117.  K^-1 @ p: every product and sum rounded separately;
+    // E @ [pc;1]: rounded first product, then a single-rounding fma chain (see the oracle).
+    const float u = (float)c * z;
+    const float v = (float)r * z;
+    float pc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float t0 = cam.Ki[3 * i + 0] * u, t1 = cam.Ki[3 * i + 1] * v, t2 = cam.Ki[3 * i + 2] * z;
+        pc[i] = (t0 + t1) + t2;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        pw[i] = __builtin_fmaf(cam.E[4 * i + 3], 1.0f,
+                               __builtin_fmaf(cam.E[4 * i + 2], pc[2],
+                                              __builtin_fmaf(cam.E[4 * i + 1], pc[1], cam.E[4 * i + 0] * pc[0])));
+}
+
+__device__ __forceinline__ void ray_frame(const float pw[3], const Camera &cam, double cv[3], double dir[3])
+{
+    // modules/extractor.py:314-318 (fp64 because origin is an fp64 tensor)
+    double d[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        cv[i] = ((double)pw[i] - cam.origin[i]) / cam.res;
+        d[i] = cv[i] - cam.eye_v[i];
+    }
+    const double ss = __builtin_fma(d[2], d[2], __builtin_fma(d[1], d[1], d[0] * d[0]));
+    double nrm = __builtin_sqrt(ss);
+    nrm = nrm < 1e-12 ? 1e-12 : nrm;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dir[i] = d[i] / nrm;
+}
+
+__device__ __forceinline__ void ray_sample(const double cv[3], const double dir[3], int k, int half, RaySample &s)
+{
+    // modules/extractor.py:327-331 (sample position), :535-555 (interpolation frame)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double p;
+        if (k == half)
+            p = cv[i];
+        else if (k > half)
+            p = cv[i] + (double)(k - half) * dir[i];
+        else
+            p = cv[i] - (double)(half - k) * dir[i];
+        const double fl = __builtin_floor(p);
+        const double ctr = fl + 0.5;
+        const double sg = ctr - p;
+        s.p[i] = p;
+        // keeps the int conversion defined for absurd or NaN depths; such samples are outside
+        // every volume in the reference as well (|idx| >> grid size, NaN -> INT64_MIN)
+        const double flc = (fl >= -4.0e15 && fl <= 4.0e15) ? fl : -4.0e15;
+        s.fl[i] = (int64_t)flc;
+        s.nb[i] = sg > 0.0 ? 1 : (sg < 0.0 ? -1 : 0);
+        s.a[i] = __builtin_fabs(p - ctr);
+    }
+}
+
+// corner q of the 2x2x2 stencil in the reference's order (i,j,k) = 000,001,...,111
+// (modules/extractor.py:560-586): index and fp64 weight, product evaluated left to right.
+__device__ __forceinline__ void corner(const RaySample &s, int q, int64_t idx[3], double &wq)
+{
+    const int bi = (q >> 2) & 1, bj = (q >> 1) & 1, bk = q & 1;
+    const double w1 = bi ? s.a[0] : 1.0 - s.a[0];
+    const double w2 = bj ? s.a[1] : 1.0 - s.a[1];
+    const double w3 = bk ? s.a[2] : 1.0 - s.a[2];
+    wq = w1 * w2 * w3;
+    idx[0] = s.fl[0] + (bi ? s.nb[0] : 0);
+    idx[1] = s.fl[1] + (bj ? s.nb[1] : 0);
+    idx[2] = s.fl[2] + (bk ? s.nb[2] : 0);
+}
+
+__device__ __forceinline__ bool in_volume(const int64_t idx[3], int X, int Y, int Z)
+{
+    return idx[0] >= 0 && idx[0] < X && idx[1] >= 0 && idx[1] < Y && idx[2] >= 0 && idx[2] < Z;
+}
+
+}  // namespace ojf

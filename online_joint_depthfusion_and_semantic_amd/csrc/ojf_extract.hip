@@ -1,0 +1,111 @@
+// EXTRACT: ray-cast gather of fp16 TSDF / weight voxels along unprojected depth rays with the
+// reference's 8-corner interpolation (modules/extractor.py:24-79, :640-681).
+//
+// Mapping: one lane per (sample k, pixel n), k-major, so the 64 lanes of a wave are 64 consecutive
+// pixels of one image row at the same ray offset: their stencils walk neighbouring voxels (the z
+// axis is contiguous in HBM) and the 16 fp16 loads per lane are all independent and in flight
+// together.  No LDS: the per-frame gather footprint (<= a few MB of 128-B lines) lives in L2/MALL.
+// HBM-bound integer/byte work by nature: ~0.1 flop per byte, the roofline is bandwidth.
+#include "ojf_common.h"
+
+namespace ojf {
+
+struct ExtractArgs {
+    const float *depth;
+    const uint16_t *tsdf;
+    const uint16_t *wgt;
+    float *out_values;
+    float *out_weights;
+    int64_t *dbg_idx;
+    double *dbg_w;
+    double *dbg_pts;
+    float *dbg_pcl;
+    int X, Y, Z, h, w, n_points, out_stride;
+    float pad_value;
+};
+
+__global__ __launch_bounds__(256) void extract_kernel(ExtractArgs a, Camera cam)
+{
+    const int N = a.h * a.w;
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= N * a.n_points) return;
+    const int k = item / N;
+    const int n = item - k * N;
+    const int r = n / a.w, c = n - r * a.w;
+    const int half = (a.n_points - 1) / 2;
+
+    float pw[3];
+    double cv[3], dir[3];
+    unproject(r, c, a.depth[n], cam, pw);
+    ray_frame(pw, cam, cv, dir);
+    RaySample s;
+    ray_sample(cv, dir, k, half, s);
+
+    // issue all 16 gathers before the first use
+    float val[8], wt[8];
+    double wq[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        int64_t idx[3];
+        corner(s, q, idx, wq[q]);
+        val[q] = a.pad_value;  // modules/extractor.py:663-664
+        wt[q] = 0.0f;
+        if (in_volume(idx, a.X, a.Y, a.Z)) {
+            const size_t lin = ((size_t)idx[0] * a.Y + (size_t)idx[1]) * a.Z + (size_t)idx[2];
+            val[q] = h2f(a.tsdf[lin]);
+            wt[q] = h2f(a.wgt[lin]);
+        }
+        if (a.dbg_idx) {
+            int64_t *o = a.dbg_idx + ((size_t)n * a.n_points + k) * 24 + 3 * q;
+            o[0] = idx[0]; o[1] = idx[1]; o[2] = idx[2];
+        }
+    }
+    // fp64 products, summed in corner order, rounded once to fp32 (extractor.py:673-681)
+    double sv = 0.0, sw = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        sv += (double)val[q] * wq[q];
+        sw += (double)wt[q] * wq[q];
+    }
+    a.out_values[(size_t)n * a.out_stride + k] = (float)sv;
+    a.out_weights[(size_t)n * a.out_stride + k] = (float)sw;
+
+    if (a.dbg_w) {
+        double *o = a.dbg_w + ((size_t)n * a.n_points + k) * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = wq[q];
+    }
+    if (a.dbg_pts) {
+        double *o = a.dbg_pts + ((size_t)n * a.n_points + k) * 3;
+        o[0] = s.p[0]; o[1] = s.p[1]; o[2] = s.p[2];
+    }
+    if (a.dbg_pcl && k == 0) {
+        float *o = a.dbg_pcl + (size_t)n * 3;
+        o[0] = pw[0]; o[1] = pw[1]; o[2] = pw[2];
+    }
+}
+
+}  // namespace ojf
+
+OJF_API int ojf_extract(const float *depth, const float *Ki, const float *E, const double *origin,
+                        double res, const uint16_t *tsdf, const uint16_t *wgt, int X, int Y, int Z,
+                        int h, int w, int n_points, float pad_value, float *out_values,
+                        float *out_weights, int out_stride, int64_t *dbg_idx, double *dbg_w,
+                        double *dbg_pts, float *dbg_pcl, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (!depth || !Ki || !E || !origin || !tsdf || !wgt || !out_values || !out_weights)
+        return fail("ojf_extract: null pointer argument");
+    if (X <= 0 || Y <= 0 || Z <= 0 || h <= 0 || w <= 0)
+        return fail("ojf_extract: non-positive volume or frame size");
+    if (n_points < 1 || (n_points & 1) == 0) return fail("ojf_extract: n_points must be odd and >= 1");
+    if (out_stride < n_points) return fail("ojf_extract: out_stride < n_points");
+    if ((int64_t)h * w * n_points > 0x7fffffffLL) return fail("ojf_extract: frame too large");
+    if (!(res > 0.0)) return fail("ojf_extract: resolution must be > 0");
+    ExtractArgs a{depth, tsdf, wgt, out_values, out_weights, dbg_idx, dbg_w, dbg_pts, dbg_pcl,
+                  X, Y, Z, h, w, n_points, out_stride, pad_value};
+    const Camera cam = make_camera(Ki, E, origin, res);
+    const int items = h * w * n_points;
+    hipLaunchKernelGGL(extract_kernel, dim3((items + 255) / 256), dim3(256), 0, as_stream(stream), a, cam);
+    return check_hip(hipGetLastError(), "ojf_extract launch");
+}

@@ -1,0 +1,178 @@
+// INTEGRATE: scatter of the per-ray TSDF updates back into the fp16 volumes
+// (modules/pipeline.py:137-171 + modules/integrator.py:15-126), without materialising the
+// reference's int64 index / fp64 weight tensors or its two dense fp32 caches.
+//
+// FAST mode (this file).  Colliding voxel writes (~16 entries per touched voxel) are resolved with
+// order-free integer arithmetic so that the result does not depend on scheduling:
+//   * sum(w) and sum(w*v) are accumulated as 2^-36 fixed point in 64-bit integers (integer adds
+//     are associative, so any combining order - in-wave, in-LDS, global atomics - gives the same
+//     bits); the total is rounded once to fp32 where the reference rounds after every add, which
+//     moves at most a handful of voxels per frame by one fp16 ulp;
+//   * the semantic "last writer wins" rule is an integer max over entry ids, i.e. exact.
+// Per-voxel accumulators live in a dense workspace that every call leaves zeroed: the finalize
+// pass walks the list of touched voxels, applies the running-mean update and clears its records.
+//
+// PARITY mode (ojf_integrate_parity.hip) reproduces the reference's sequential fp32 sums bit for bit.
+#include "ojf_integrate.h"
+
+namespace ojf {
+
+size_t fast_workspace_bytes(int X, int Y, int Z, int h, int w, int n_tail)
+{
+    const size_t nvox = (size_t)X * Y * Z;
+    const size_t entries = (size_t)h * w * n_tail * 8;
+    const size_t cap = entries < nvox ? entries : nvox;
+    return kHeaderBytes + nvox * sizeof(VoxelAcc) + cap * sizeof(unsigned int);
+}
+
+__global__ __launch_bounds__(256) void integrate_accumulate_kernel(IntegrateArgs a, Camera cam)
+{
+    const int N = a.h * a.w;
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= N * a.n_tail) return;
+    const int k = item / N;
+    const int n = item - k * N;
+    const float z = a.depth[n];
+    if (!(z != 0.0f)) return;  // modules/pipeline.py:145-146
+    const int r = n / a.w, c = n - r * a.w;
+
+    float pw[3];
+    double cv[3], dir[3];
+    unproject(r, c, z, cam, pw);
+    ray_frame(pw, cam, cv, dir);
+    RaySample s;
+    ray_sample(cv, dir, k, (a.n_points - 1) / 2, s);
+
+    float v = a.est[(size_t)n * a.est_stride + k];  // pipeline.py:153-156
+    v = v < -a.trunc ? -a.trunc : (v > a.trunc ? a.trunc : v);
+    const bool sem = a.id_vol != nullptr;
+    const uint8_t id_e = sem ? a.sem_ids[n] : 0;
+    const unsigned int e0 = ((unsigned int)n * a.n_tail + k) * 8u + 1u;
+    unsigned int n_in = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        int64_t idx[3];
+        double wq;
+        corner(s, q, idx, wq);
+        if (!in_volume(idx, a.X, a.Y, a.Z)) continue;  // integrator.py:48-53
+        const size_t lin = ((size_t)idx[0] * a.Y + (size_t)idx[1]) * a.Z + (size_t)idx[2];
+        const float we = (float)wq;  // integrator.py:45
+        const float ue = we * v;     // integrator.py:55
+        const long long xw = __double2ll_rn((double)we * kFixScale);
+        const long long xu = __double2ll_rn((double)ue * kFixScale);
+        VoxelAcc *rec = a.acc + lin;
+        const unsigned int prev = atomicMax(&rec->e_last, e0 + q);
+        if (prev == 0) a.touched[atomicAdd(&a.counters[0], 1u)] = (unsigned int)lin;
+        atomicAdd(&rec->w, (unsigned long long)xw);
+        atomicAdd(&rec->u, (unsigned long long)xu);
+        if (sem && a.id_vol[lin] != id_e) atomicMax(&rec->e_diff, e0 + q);  // integrator.py:105
+        ++n_in;
+    }
+    if (n_in) atomicAdd(&a.counters[1], n_in);
+}
+
+__global__ __launch_bounds__(256) void integrate_finalize_kernel(IntegrateArgs a)
+{
+    const unsigned int count = a.counters[0];
+    const unsigned int per_pixel = (unsigned int)a.n_tail * 8u;
+    const bool sem = a.id_vol != nullptr;
+    for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
+        const size_t lin = a.touched[t];
+        VoxelAcc *rec = a.acc + lin;
+        const VoxelAcc r = *rec;
+        rec->w = 0; rec->u = 0; rec->e_last = 0; rec->e_diff = 0;  // leave the workspace clean
+        const float W = (float)((double)(long long)r.w * kFixInv);
+        const float U = (float)((double)(long long)r.u * kFixInv);
+        const float w_old = h2f(a.wgt[lin]), v_old = h2f(a.tsdf[lin]);  // integrator.py:72-75
+        const float w_new = w_old + W;                                   // :77
+        const float num = w_old * v_old + U;                             // :82
+        a.wgt[lin] = f2h(w_new);                                         // :78,87
+        a.tsdf[lin] = f2h(num / w_new);                                  // :83,88
+        if (sem) {  // integrator.py:93-124 with "highest entry wins" for duplicates
+            const float s_old = h2f(a.score_vol[lin]);
+            const float s_last = a.sem_scores[(r.e_last - 1u) / per_pixel];
+            a.score_vol[lin] = f2h(s_last > s_old ? s_last : s_old);     // :113-114,124
+            if (r.e_diff) {                                               // :105,116-117,123
+                const unsigned int n_d = (r.e_diff - 1u) / per_pixel;
+                if (a.sem_scores[n_d] > s_old) a.id_vol[lin] = a.sem_ids[n_d];
+            }
+        }
+    }
+    if (a.stats && blockIdx.x == 0 && threadIdx.x == 0) {
+        a.stats[0] = count;
+        a.stats[1] = a.counters[1];
+        a.stats[2] = 0;
+        a.stats[3] = 0;
+    }
+}
+
+}  // namespace ojf
+
+OJF_API size_t ojf_integrate_workspace_bytes(int X, int Y, int Z, int h, int w, int n_tail, int mode)
+{
+    using namespace ojf;
+    if (X <= 0 || Y <= 0 || Z <= 0 || h <= 0 || w <= 0 || n_tail <= 0) return 0;
+    if (mode == OJF_MODE_FAST) return fast_workspace_bytes(X, Y, Z, h, w, n_tail);
+    if (mode == OJF_MODE_PARITY) return parity_workspace_bytes(X, Y, Z, h, w, n_tail);
+    return 0;
+}
+
+OJF_API int ojf_integrate_workspace_init(void *ws, size_t ws_bytes, int X, int Y, int Z, int h, int w,
+                                         int n_tail, int mode, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (!ws) return fail("ojf_integrate_workspace_init: null workspace");
+    const size_t need = ojf_integrate_workspace_bytes(X, Y, Z, h, w, n_tail, mode);
+    if (need == 0) return fail("ojf_integrate_workspace_init: bad sizes or mode");
+    if (ws_bytes < need) return fail("ojf_integrate_workspace_init: workspace too small");
+    // FAST: header + dense accumulators must start zeroed (every call restores that invariant)
+    const size_t zero_bytes = mode == OJF_MODE_FAST ? kHeaderBytes + (size_t)X * Y * Z * sizeof(VoxelAcc)
+                                                    : kHeaderBytes;
+    return check_hip(hipMemsetAsync(ws, 0, zero_bytes, as_stream(stream)), "workspace memset");
+}
+
+OJF_API int ojf_integrate(const float *depth_filtered, const float *Ki, const float *E, const double *origin,
+                          double res, const float *est, int est_stride, int n_points, int n_tail, float trunc,
+                          uint16_t *tsdf, uint16_t *wgt, const uint8_t *sem_ids, const float *sem_scores,
+                          uint8_t *id_vol, uint16_t *score_vol, int X, int Y, int Z, int h, int w, int mode,
+                          void *ws, size_t ws_bytes, uint32_t *stats, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (!depth_filtered || !Ki || !E || !origin || !est || !tsdf || !wgt || !ws)
+        return fail("ojf_integrate: null pointer argument");
+    if (X <= 0 || Y <= 0 || Z <= 0 || h <= 0 || w <= 0) return fail("ojf_integrate: non-positive size");
+    if (n_points < 1 || (n_points & 1) == 0) return fail("ojf_integrate: n_points must be odd and >= 1");
+    if (n_tail < 1 || n_tail > n_points) return fail("ojf_integrate: need 1 <= n_tail <= n_points");
+    if (est_stride < n_tail) return fail("ojf_integrate: est_stride < n_tail");
+    if (!(res > 0.0)) return fail("ojf_integrate: resolution must be > 0");
+    if ((uint64_t)X * Y * Z >= 0xffffffffull) return fail("ojf_integrate: volume has >= 2^32 voxels");
+    if ((uint64_t)h * w * n_tail * 8 >= 0xffffffffull) return fail("ojf_integrate: frame too large");
+    const int n_sem = (sem_ids != nullptr) + (sem_scores != nullptr) + (id_vol != nullptr) + (score_vol != nullptr);
+    if (n_sem != 0 && n_sem != 4)
+        return fail("ojf_integrate: sem_ids, sem_scores, id_vol, score_vol must be all set or all NULL");
+    const size_t need = ojf_integrate_workspace_bytes(X, Y, Z, h, w, n_tail, mode);
+    if (need == 0) return fail("ojf_integrate: unknown mode");
+    if (ws_bytes < need) return fail("ojf_integrate: workspace too small");
+
+    hipStream_t st = as_stream(stream);
+    char *base = static_cast<char *>(ws);
+    IntegrateArgs a;
+    a.depth = depth_filtered; a.est = est; a.tsdf = tsdf; a.wgt = wgt;
+    a.sem_ids = sem_ids; a.sem_scores = sem_scores; a.id_vol = id_vol; a.score_vol = score_vol;
+    a.counters = reinterpret_cast<unsigned int *>(base);
+    a.acc = nullptr; a.touched = nullptr; a.stats = stats;
+    a.X = X; a.Y = Y; a.Z = Z; a.h = h; a.w = w; a.n_points = n_points; a.n_tail = n_tail;
+    a.est_stride = est_stride; a.trunc = trunc;
+    const Camera cam = make_camera(Ki, E, origin, res);
+
+    OJF_HIP(hipMemsetAsync(a.counters, 0, kHeaderBytes, st));
+    if (mode == OJF_MODE_PARITY) return integrate_parity(a, cam, base + kHeaderBytes, ws_bytes - kHeaderBytes, st);
+
+    a.acc = reinterpret_cast<VoxelAcc *>(base + kHeaderBytes);
+    a.touched = reinterpret_cast<unsigned int *>(base + kHeaderBytes + (size_t)X * Y * Z * sizeof(VoxelAcc));
+    const int items = h * w * n_tail;
+    hipLaunchKernelGGL(integrate_accumulate_kernel, dim3((items + 255) / 256), dim3(256), 0, st, a, cam);
+    OJF_HIP(hipGetLastError());
+    hipLaunchKernelGGL(integrate_finalize_kernel, dim3(1024), dim3(256), 0, st, a);
+    return check_hip(hipGetLastError(), "ojf_integrate launch");
+}

@@ -1,0 +1,130 @@
+// Full-grid passes of the Database (modules/database.py:108-112, 351-370; utils/metrics.py:111-127).
+// Pure streaming kernels: 16-byte accesses per lane, grid-stride, bandwidth roofline.
+#include "ojf_common.h"
+
+namespace ojf {
+
+static inline int stream_grid(size_t work_items)
+{
+    size_t blocks = (work_items + 255) / 256;
+    if (blocks > 2048) blocks = 2048;  // 256 CUs x 8 resident blocks, grid-stride the rest
+    if (blocks == 0) blocks = 1;
+    return (int)blocks;
+}
+
+__global__ __launch_bounds__(256) void fill_u16_kernel(uint16_t *v, size_t n, uint16_t bits)
+{
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    const size_t head = ((16 - ((uintptr_t)v & 15)) & 15) / 2;  // elements before 16-B alignment
+    const size_t nh = head < n ? head : n;
+    if (tid < nh) v[tid] = bits;
+    const size_t nvec = (n - nh) / 8;
+    uint4 pat;
+    pat.x = pat.y = pat.z = pat.w = (uint32_t)bits | ((uint32_t)bits << 16);
+    uint4 *vv = reinterpret_cast<uint4 *>(v + nh);
+    for (size_t i = tid; i < nvec; i += step) vv[i] = pat;
+    const size_t tail0 = nh + nvec * 8;
+    if (tid < n - tail0) v[tail0 + tid] = bits;
+}
+
+__global__ __launch_bounds__(256) void filter_kernel(uint16_t *tsdf, uint16_t *wgt, size_t n, float thr,
+                                                      uint16_t init_bits)
+{
+    // Database.filter: volume[weights < value] = init ; weights[weights < value] = 0
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = tid; i < n; i += step) {
+        const float w = h2f(wgt[i]);
+        if (w < thr) {
+            tsdf[i] = init_bits;
+            wgt[i] = 0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void evaluate_kernel(const uint16_t *est, const uint16_t *gt,
+                                                        const uint16_t *wgt, size_t n, double *sums)
+{
+    // utils/metrics.py:111-127: nan_to_num, clip to +-0.04, masked mse / mad / occupancy iou / sign acc
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (size_t i = tid; i < n; i += step) {
+        if (!(h2f(wgt[i]) > 0.0f)) continue;
+        float e = h2f(est[i]), g = h2f(gt[i]);
+        e = (e != e) ? 0.0f : e;  // nan_to_num (infinities are clipped below)
+        g = (g != g) ? 0.0f : g;
+        e = fminf(fmaxf(e, -0.04f), 0.04f);
+        g = fminf(fmaxf(g, -0.04f), 0.04f);
+        const double d = (double)e - (double)g;
+        acc[0] += 1.0;
+        acc[1] += d * d;
+        acc[2] += fabs(d);
+        const bool eo = e < 0.0f, go = g < 0.0f;
+        acc[3] += (eo && go) ? 1.0 : 0.0;
+        acc[4] += (eo || go) ? 1.0 : 0.0;
+        acc[5] += (eo == go) ? 1.0 : 0.0;  // acc_fn: tp (both < 0) + tn (both >= 0)
+    }
+    __shared__ double red[6][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double v = acc[j];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[j][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const double v = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        atomicAdd(&sums[threadIdx.x], v);
+    }
+}
+
+}  // namespace ojf
+
+OJF_API int ojf_volume_fill_f16(uint16_t *vol, size_t n, float value, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (!vol && n) return fail("ojf_volume_fill_f16: null volume");
+    if (n == 0) return 0;
+    const _Float16 hv = (_Float16)value;
+    uint16_t bits;
+    __builtin_memcpy(&bits, &hv, 2);
+    hipLaunchKernelGGL(fill_u16_kernel, dim3(stream_grid(n / 8 + 16)), dim3(256), 0, as_stream(stream), vol, n, bits);
+    return check_hip(hipGetLastError(), "ojf_volume_fill_f16 launch");
+}
+
+OJF_API int ojf_volume_fill_u8(uint8_t *vol, size_t n, uint8_t value, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (!vol && n) return fail("ojf_volume_fill_u8: null volume");
+    if (n == 0) return 0;
+    return check_hip(hipMemsetAsync(vol, value, n, as_stream(stream)), "ojf_volume_fill_u8");
+}
+
+OJF_API int ojf_volume_filter(uint16_t *tsdf, uint16_t *wgt, size_t n, float threshold, float init_value,
+                              ojf_stream_t stream)
+{
+    using namespace ojf;
+    if ((!tsdf || !wgt) && n) return fail("ojf_volume_filter: null volume");
+    if (n == 0) return 0;
+    const _Float16 hv = (_Float16)init_value;
+    uint16_t bits;
+    __builtin_memcpy(&bits, &hv, 2);
+    hipLaunchKernelGGL(filter_kernel, dim3(stream_grid(n)), dim3(256), 0, as_stream(stream), tsdf, wgt, n,
+                       threshold, bits);
+    return check_hip(hipGetLastError(), "ojf_volume_filter launch");
+}
+
+OJF_API int ojf_volume_evaluate(const uint16_t *est, const uint16_t *gt, const uint16_t *wgt, size_t n,
+                                double *sums, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (!est || !gt || !wgt || !sums) return fail("ojf_volume_evaluate: null pointer argument");
+    OJF_HIP(hipMemsetAsync(sums, 0, 8 * sizeof(double), as_stream(stream)));
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(evaluate_kernel, dim3(stream_grid(n)), dim3(256), 0, as_stream(stream), est, gt, wgt, n,
+                       sums);
+    return check_hip(hipGetLastError(), "ojf_volume_evaluate launch");
+}

@@ -1,0 +1,108 @@
+"""HIP executor of the fusion net (ojf_net_* in include/ojf.h) fed from a torch parameter container.
+
+``FusionNetEngine`` folds the BatchNorms of a ``FusionNet_v2``/``FusionNet_v3`` module (running
+statistics, eval semantics), hands the folded layers to libojf, and exposes the device-side input
+rows so that ``ojf_extract`` writes its result directly where the first convolution reads it
+(no ``_prepare_fusion_input`` permute/copy: modules/pipeline.py:74-102).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .model import FusionNet_v2, FusionNet_v3, fold_layers
+
+
+def _layer_array(layers):
+    arr = (_lib.ConvLayer * len(layers))()
+    keep = []
+    for i, (w, b, k, d) in enumerate(layers):
+        w = np.ascontiguousarray(w, dtype=np.float32)
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        keep += [w, b]
+        arr[i].c_in, arr[i].c_out, arr[i].ksize, arr[i].dilation = w.shape[1], w.shape[0], k, d
+        arr[i].weight_host = w.ctypes.data
+        arr[i].bias_host = b.ctypes.data
+    return arr, keep
+
+
+class _DeviceRows:
+    """Exposes library-owned device memory to torch through the CUDA array interface."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {'shape': tuple(shape), 'typestr': '<f4', 'data': (int(ptr), False),
+                                         'version': 3, 'strides': None}
+
+
+class FusionNetEngine:
+    def __init__(self, net, h, w, device):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        if isinstance(net, FusionNet_v3):
+            version = 3
+        elif isinstance(net, FusionNet_v2):
+            version = 2
+        else:
+            raise TypeError('FusionNetEngine needs a FusionNet_v2 or FusionNet_v3 module')
+        self.device = torch.device(device)
+        self.h, self.w = h, w
+        self.n_points = net.n_points
+        self.use_semantics = bool(net.config.use_semantics)
+        layers = fold_layers(net)
+        arr, keep = _layer_array(layers)
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.lib.ojf_net_create(ctypes.byref(handle), version, net.n_points, net.gf,
+                                         int(self.use_semantics), float(net.scale), arr, len(layers), h, w)
+        _lib.check(rc, 'ojf_net_create')
+        self.handle = handle
+        base, stride = ctypes.c_void_p(), ctypes.c_int()
+        _lib.check(self.lib.ojf_net_input(self.handle, 0, ctypes.byref(base), ctypes.byref(stride)), 'ojf_net_input')
+        self.in_ptr, self.in_stride = base.value, stride.value
+        self.macs_per_pixel = int(self.lib.ojf_net_macs_per_pixel(self.handle))
+
+    def input_view(self, head=0):
+        """torch view [h*w, in_stride] of the net's input rows of ``head`` (memory owned by libojf)."""
+        base, stride = ctypes.c_void_p(), ctypes.c_int()
+        _lib.check(self.lib.ojf_net_input(self.handle, head, ctypes.byref(base), ctypes.byref(stride)), 'ojf_net_input')
+        return torch.as_tensor(_DeviceRows(base.value, (self.h * self.w, stride.value)), device=self.device)
+
+    def prepare_input(self, depth, sem_ids=None, n_classes=0):
+        assert depth.is_cuda and depth.dtype == torch.float32 and depth.is_contiguous()
+        if sem_ids is not None:
+            assert sem_ids.is_cuda and sem_ids.dtype == torch.uint8 and sem_ids.is_contiguous()
+        rc = self.lib.ojf_net_prepare_input(self.handle, _lib.ptr(depth), _lib.ptr(sem_ids), int(n_classes),
+                                            _lib.stream_ptr(self.device))
+        _lib.check(rc, 'ojf_net_prepare_input')
+
+    def forward(self, est):
+        """est: cuda f32 [h*w, stride>=n_points] receiving output_scale * tanh(.)"""
+        assert est.is_cuda and est.dtype == torch.float32 and est.is_contiguous()
+        rc = self.lib.ojf_net_forward(self.handle, _lib.ptr(est), est.shape[-1], _lib.stream_ptr(self.device))
+        _lib.check(rc, 'ojf_net_forward')
+        return est
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            torch.cuda.synchronize(self.device)
+            self.lib.ojf_net_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def conv2d_rows(x_rows, in_off, c_in, weight, bias, out_rows, out_off, h, w, dilation=1, act=_lib.ACT_NONE):
+    """Stand-alone HIP convolution on NHWC rows (ojf_conv2d); used by the layer-level parity tests."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    wgt = np.ascontiguousarray(weight, dtype=np.float32)
+    b = np.ascontiguousarray(bias, dtype=np.float32)
+    layer = _lib.ConvLayer(c_in, wgt.shape[0], wgt.shape[2], dilation, wgt.ctypes.data, b.ctypes.data)
+    rc = lib.ojf_conv2d(_lib.ptr(x_rows), x_rows.shape[-1], in_off, _lib.ptr(out_rows), out_rows.shape[-1], out_off,
+                        ctypes.byref(layer), act, h, w, _lib.stream_ptr(x_rows.device))
+    _lib.check(rc, 'ojf_conv2d')

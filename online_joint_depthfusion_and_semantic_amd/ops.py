@@ -1,0 +1,160 @@
+"""Thin torch-tensor front-end of the libojf C ABI (device pointers + current HIP stream).
+
+PyTorch is plumbing here: it owns the HBM allocations and the stream; all arithmetic of the hot
+path happens in the HIP kernels behind include/ojf.h.  Every function requires CUDA(HIP) tensors
+and raises if libojf.so or the GPU is missing.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import MODE_FAST, MODE_PARITY  # noqa: F401  (re-exported)
+
+
+def camera_arrays(intrinsics, extrinsics):
+    """Host-side camera preparation: (Kinv f32[9], E f32[12]) as numpy arrays.
+
+    Kinv follows the reference exactly: ``intrinsics.float().inverse()``
+    (modules/extractor.py:39,104); E is the first three rows of ``extrinsics.float()``
+    (extractor.py:40,115-117; ScanNet hands over 4x4 poses, Replica 3x4)."""
+    K = torch.as_tensor(intrinsics).detach().cpu().reshape(3, 3).float()
+    Ki = K.inverse().float().numpy().reshape(9).copy()
+    E = torch.as_tensor(extrinsics).detach().cpu().float()
+    E = E.reshape(-1, 4)[:3].contiguous().numpy().reshape(12).copy()
+    return Ki, E
+
+
+def _origin_array(origin):
+    if torch.is_tensor(origin):
+        origin = origin.detach().cpu().numpy()
+    return np.ascontiguousarray(np.asarray(origin, dtype=np.float64).reshape(3))
+
+
+def _vol16(t):
+    assert t.is_cuda and t.dtype == torch.float16 and t.is_contiguous() and t.dim() == 3
+    return t
+
+
+def extract(depth, Ki, E, origin, resolution, tsdf, weights, n_points=9, pad_value=-0.1,
+            out_values=None, out_weights=None, out_stride=None, debug=False):
+    """Gather along the depth rays.  depth: cuda f32 [h,w] (or [1,h,w]).  Returns a dict with
+    fusion_values / fusion_weights [h*w, n_points] (plus indices / weights / points / pcl when
+    ``debug``).  ``out_values``/``out_weights``/``out_stride`` let the caller place the result
+    inside a wider row buffer (the net's input rows)."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    depth = depth.reshape(depth.shape[-2], depth.shape[-1])
+    assert depth.is_cuda and depth.dtype == torch.float32 and depth.is_contiguous()
+    h, w = depth.shape
+    N = h * w
+    X, Y, Z = _vol16(tsdf).shape
+    assert _vol16(weights).shape == tsdf.shape
+    dev = depth.device
+    if out_values is None:
+        out_stride = n_points
+        out_values = torch.empty((N, n_points), dtype=torch.float32, device=dev)
+        out_weights = torch.empty((N, n_points), dtype=torch.float32, device=dev)
+    origin = _origin_array(origin)
+    dbg = {}
+    if debug:
+        dbg['indices'] = torch.empty((N, n_points, 8, 3), dtype=torch.int64, device=dev)
+        dbg['weights'] = torch.empty((N, n_points, 8), dtype=torch.float64, device=dev)
+        dbg['points'] = torch.empty((N, n_points, 3), dtype=torch.float64, device=dev)
+        dbg['pcl'] = torch.empty((N, 3), dtype=torch.float32, device=dev)
+    ov = out_values if isinstance(out_values, int) else _lib.ptr(out_values)  # raw device address allowed
+    ow = out_weights if isinstance(out_weights, int) else _lib.ptr(out_weights)
+    rc = lib.ojf_extract(_lib.ptr(depth), _lib.ptr(Ki), _lib.ptr(E), _lib.ptr(origin),
+                         float(resolution), _lib.ptr(tsdf), _lib.ptr(weights), X, Y, Z, h, w,
+                         n_points, float(pad_value), ov, ow,
+                         int(out_stride), _lib.ptr(dbg.get('indices')), _lib.ptr(dbg.get('weights')),
+                         _lib.ptr(dbg.get('points')), _lib.ptr(dbg.get('pcl')), _lib.stream_ptr(dev))
+    _lib.check(rc, 'ojf_extract')
+    out = dict(fusion_values=out_values, fusion_weights=out_weights)
+    out.update(dbg)
+    return out
+
+
+class IntegrateWorkspace:
+    """Device scratch of ojf_integrate for one (grid, frame size, mode); reusable across scenes."""
+
+    def __init__(self, shape, h, w, n_tail, mode, device):
+        _lib.require_gpu()
+        lib = _lib.load()
+        X, Y, Z = shape
+        self.key = (tuple(shape), h, w, n_tail, mode)
+        self.bytes = int(lib.ojf_integrate_workspace_bytes(X, Y, Z, h, w, n_tail, mode))
+        if self.bytes == 0:
+            raise _lib.OjfError('ojf_integrate_workspace_bytes: unsupported sizes/mode: ' +
+                                lib.ojf_last_error().decode())
+        self.buf = torch.empty(self.bytes, dtype=torch.uint8, device=device)
+        self.stats = torch.zeros(4, dtype=torch.int32, device=device)
+        rc = lib.ojf_integrate_workspace_init(_lib.ptr(self.buf), self.bytes, X, Y, Z, h, w, n_tail,
+                                              mode, _lib.stream_ptr(device))
+        _lib.check(rc, 'ojf_integrate_workspace_init')
+
+
+def integrate(depth_filtered, Ki, E, origin, resolution, est, tsdf, weights, workspace,
+              n_points=9, n_tail=7, trunc=0.1, est_stride=None, sem_ids=None, sem_scores=None,
+              id_vol=None, score_vol=None, mode=MODE_FAST):
+    """Scatter the clamped net output into the volumes, in place.  est: cuda f32 rows with
+    ``est_stride`` floats per pixel (default: est.shape[-1])."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    depth_filtered = depth_filtered.reshape(depth_filtered.shape[-2], depth_filtered.shape[-1])
+    assert depth_filtered.is_cuda and depth_filtered.dtype == torch.float32 and depth_filtered.is_contiguous()
+    h, w = depth_filtered.shape
+    X, Y, Z = _vol16(tsdf).shape
+    assert _vol16(weights).shape == tsdf.shape
+    assert est.is_cuda and est.dtype == torch.float32 and est.is_contiguous()
+    if est_stride is None:
+        est_stride = est.shape[-1]
+    if sem_ids is not None:
+        assert sem_ids.dtype == torch.uint8 and sem_ids.is_contiguous() and sem_ids.numel() == h * w
+        assert sem_scores.dtype == torch.float32 and sem_scores.is_contiguous() and sem_scores.numel() == h * w
+        assert id_vol.dtype == torch.uint8 and id_vol.is_contiguous() and id_vol.shape == tsdf.shape
+        assert score_vol.dtype == torch.float16 and score_vol.is_contiguous() and score_vol.shape == tsdf.shape
+    assert workspace.key == ((X, Y, Z), h, w, n_tail, mode), 'workspace built for another configuration'
+    origin = _origin_array(origin)
+    rc = lib.ojf_integrate(_lib.ptr(depth_filtered), _lib.ptr(Ki), _lib.ptr(E), _lib.ptr(origin),
+                           float(resolution), _lib.ptr(est), int(est_stride), n_points, n_tail,
+                           float(trunc), _lib.ptr(tsdf), _lib.ptr(weights), _lib.ptr(sem_ids),
+                           _lib.ptr(sem_scores), _lib.ptr(id_vol), _lib.ptr(score_vol), X, Y, Z, h, w,
+                           mode, _lib.ptr(workspace.buf), workspace.bytes, _lib.ptr(workspace.stats),
+                           _lib.stream_ptr(depth_filtered.device))
+    _lib.check(rc, 'ojf_integrate')
+
+
+def volume_fill(vol, value):
+    _lib.require_gpu()
+    lib = _lib.load()
+    assert vol.is_cuda and vol.is_contiguous()
+    if vol.dtype == torch.float16:
+        rc = lib.ojf_volume_fill_f16(_lib.ptr(vol), vol.numel(), float(value), _lib.stream_ptr(vol.device))
+    elif vol.dtype == torch.uint8:
+        rc = lib.ojf_volume_fill_u8(_lib.ptr(vol), vol.numel(), int(value), _lib.stream_ptr(vol.device))
+    else:
+        raise TypeError('volume_fill: fp16 or u8 volumes only')
+    _lib.check(rc, 'ojf_volume_fill')
+
+
+def volume_filter(tsdf, weights, threshold, init_value):
+    _lib.require_gpu()
+    lib = _lib.load()
+    rc = lib.ojf_volume_filter(_lib.ptr(_vol16(tsdf)), _lib.ptr(_vol16(weights)), tsdf.numel(),
+                               float(threshold), float(init_value), _lib.stream_ptr(tsdf.device))
+    _lib.check(rc, 'ojf_volume_filter')
+
+
+def volume_evaluate(est, gt, weights):
+    """utils/metrics.py:111-127 on device; returns dict(mse, mad, iou, acc) of python floats."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    sums = torch.zeros(8, dtype=torch.float64, device=est.device)
+    rc = lib.ojf_volume_evaluate(_lib.ptr(_vol16(est)), _lib.ptr(_vol16(gt)), _lib.ptr(_vol16(weights)),
+                                 est.numel(), _lib.ptr(sums), _lib.stream_ptr(est.device))
+    _lib.check(rc, 'ojf_volume_evaluate')
+    n, sq, ab, inter, union, same = sums[:6].tolist()
+    eps = 1.e-10
+    return {'mse': sq / (n + eps), 'mad': ab / (n + eps), 'iou': inter / (union + eps), 'acc': same / (n + eps)}

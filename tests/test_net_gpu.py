@@ -1,0 +1,96 @@
+"""-m gpu: the HIP fusion net (fp32 MFMA convolutions) against the fp32 torch-CPU reference of the
+same layers.  Stated tolerance: |tsdf_est difference| <= 1e-5 absolute."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from online_joint_depthfusion_and_semantic_amd import _lib, model
+from online_joint_depthfusion_and_semantic_amd.engine import FusionNetEngine, conv2d_rows
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+class NS:
+    def __init__(self, **k):
+        self.__dict__.update(k)
+
+
+def seeded_net(version, sem, h, w, seed=0):
+    cfg = NS(n_points=9, growth_factor=6, use_semantics=sem, output_scale=1.0, resx=w, resy=h)
+    torch.manual_seed(seed)
+    net = getattr(model, 'FusionNet_' + version)(cfg)
+    for m in net.modules():  # train_fusion.py:29-31 xavier init; randomised BN statistics
+        if isinstance(m, torch.nn.Conv2d):
+            torch.nn.init.xavier_normal_(m.weight)
+            m.bias.data.normal_(0, 0.05)
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.1)
+    return net.eval()
+
+
+@pytest.mark.parametrize('cin,cout,k,dil,act', [
+    (19, 19, 3, 1, _lib.ACT_LEAKY), (38, 19, 3, 1, _lib.ACT_LEAKY), (19, 19, 3, 3, _lib.ACT_RELU),
+    (19, 19, 3, 9, _lib.ACT_RELU), (19, 19, 3, 27, _lib.ACT_RELU), (114, 95, 1, 1, _lib.ACT_LEAKY),
+    (19, 114, 1, 1, _lib.ACT_RELU), (228, 19, 1, 1, _lib.ACT_NONE), (19, 9, 1, 1, _lib.ACT_TANH), (64, 48, 3, 2, _lib.ACT_NONE)])
+@pytest.mark.parametrize('h,w', [(24, 32), (37, 53)])
+def test_conv2d_layer(cuda, cin, cout, k, dil, act, h, w):
+    g = torch.Generator().manual_seed(cin * 1000 + cout + k + dil)
+    x = torch.randn(1, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x, wt, b, padding=dil * (k // 2), dilation=dil)
+    ref = {_lib.ACT_NONE: lambda t: t, _lib.ACT_RELU: F.relu, _lib.ACT_LEAKY: lambda t: F.leaky_relu(t, 0.01),
+           _lib.ACT_TANH: torch.tanh}[act](ref)
+    cin_p, cout_p = (cin + 3) // 4 * 4, (cout + 3) // 4 * 4
+    in_off, out_off = 4, 8  # embedded in wider rows, like the dense-growth buffers
+    xr = torch.full((h * w, cin_p + 8), 7.0)  # junk around the window must not leak in
+    xr[:, in_off:in_off + cin_p] = 0
+    xr[:, in_off:in_off + cin] = x[0].permute(1, 2, 0).reshape(h * w, cin)
+    xr = xr.to(cuda)
+    out = torch.full((h * w, cout_p + 12), -3.0, device=cuda)
+    conv2d_rows(xr, in_off, cin, wt.numpy(), b.numpy(), out, out_off, h, w, dilation=dil, act=act)
+    got = out.cpu()
+    assert torch.all(got[:, :out_off] == -3.0) and torch.all(got[:, out_off + cout_p:] == -3.0)
+    assert torch.all(got[:, out_off + cout:out_off + cout_p] == 0)  # pad channels carry zeros
+    y = got[:, out_off:out_off + cout].reshape(h, w, cout).permute(2, 0, 1)
+    assert float((y - ref[0]).abs().max()) <= TOL
+
+
+def _inputs(h, w, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    return dict(tsdf_values=(torch.rand(1, 9, h, w, generator=g) - 0.5) * 0.2,
+                tsdf_weights=torch.rand(1, 9, h, w, generator=g) * 4,
+                tsdf_frame=torch.rand(1, 1, h, w, generator=g) * 4,
+                sem_ids=torch.randint(0, 30, (h, w), generator=g, dtype=torch.uint8))
+
+
+@pytest.mark.parametrize('version,sem', [('v3', False), ('v3', True), ('v2', False), ('v2', True)])
+@pytest.mark.parametrize('h,w', [(24, 32), (60, 80), (120, 160)])
+def test_fusion_net_forward(cuda, version, sem, h, w):
+    net = seeded_net(version, sem, h, w)
+    x = _inputs(h, w)
+    x['semantic_frame'] = ((1 + x['sem_ids'].float()) / 30).view(1, 1, h, w)
+    with torch.no_grad():
+        ref = net(x)[0].permute(1, 2, 0).reshape(h * w, 9)
+    eng = FusionNetEngine(net, h, w, cuda)
+    rows = eng.input_view(0)
+    assert rows.shape == (h * w, eng.in_stride) and rows.data_ptr() == eng.in_ptr
+    rows[:, 0:9] = x['tsdf_values'][0].permute(1, 2, 0).reshape(h * w, 9).to(cuda)
+    rows[:, 9:18] = x['tsdf_weights'][0].permute(1, 2, 0).reshape(h * w, 9).to(cuda)
+    eng.prepare_input(x['tsdf_frame'].reshape(h, w).contiguous().to(cuda),
+                      x['sem_ids'].contiguous().to(cuda) if sem else None, 30)
+    for stride in (9, 12):
+        est = torch.full((h * w, stride), 5.0, device=cuda)
+        eng.forward(est)
+        got = est.cpu()
+        err = float((got[:, :9] - ref).abs().max())
+        assert err <= TOL, (version, sem, h, w, err)
+        if stride > 9:
+            assert torch.all(got[:, 9:] == 5.0)
+    assert eng.macs_per_pixel == (326876 if not sem else (508820 if version == 'v3' else None)) or version == 'v2'
+    eng.close()
