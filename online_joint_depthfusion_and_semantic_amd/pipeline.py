@@ -1,0 +1,198 @@
+"""Pipeline: per-frame orchestration with the reference's API (modules/pipeline.py:12-363).
+
+``fuse`` / ``fuse_training`` keep the reference's signatures, batch-dict keys and side effects on
+``Database``; the work is done by three HIP stages on the current stream with no host round trip
+in between:
+
+    ojf_extract  -> writes fusion_values / fusion_weights straight into the net's input rows
+    ojf_net_*    -> fp32-MFMA FusionNet (eval mode, BN folded)            [inference]
+                    torch autograd on the same device                     [training, needs grads]
+    ojf_integrate-> recomputes indices/weights, resolves colliding voxel writes, updates the
+                    fp16 volumes in place (and the semantic ids/scores in test mode)
+
+The reference's intermediate tensors (int64 indices [N,9,8,3], fp64 weights, NCHW permutes,
+fancy-index slices of valid pixels: pipeline.py:74-171) never exist here.
+"""
+import torch
+
+from . import ops
+from ._lib import MODE_FAST, MODE_PARITY
+from .engine import FusionNetEngine
+from .extractor import Extractor
+from .integrator import Integrator
+from .model import FusionNet_v2, FusionNet_v3
+
+
+class Pipeline(torch.nn.Module):
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.n_points = config.FUSION_MODEL.n_points
+        if config.DATA.semantics:
+            self.n_classes = config.SEMANTIC_2D_MODEL.n_classes
+        config.FUSION_MODEL.resx = config.DATA.resx  # pipeline.py:24-25
+        config.FUSION_MODEL.resy = config.DATA.resy
+
+        name = config.FUSION_MODEL.name
+        if name == 'v2':
+            self._fusion_network = FusionNet_v2(config.FUSION_MODEL)
+        elif name == 'v3':
+            self._fusion_network = FusionNet_v3(config.FUSION_MODEL)
+        else:  # the reference's v1 cannot even be constructed (model.py:58)
+            raise ValueError('FUSION_MODEL.name must be "v2" or "v3"')
+
+        if config.DATA.semantics and config.DATA.semantic_strategy == 'predict':
+            from .adapnet import AdapNet
+            self._semantic_2d_network = AdapNet(config.SEMANTIC_2D_MODEL)
+        else:
+            self._semantic_2d_network = None
+
+        self._extractor = Extractor(config)
+        self._integrator = Integrator(config)
+        mode = getattr(config.SETTINGS, 'integrate_mode', 'fast')
+        self._integrate_mode = MODE_PARITY if mode == 'parity' else MODE_FAST
+        self._engine = None
+        self._engine_key = None
+        self._workspaces = {}
+        self._est = None
+
+    # ---- cached device objects ----------------------------------------------------------------
+    def _weights_fingerprint(self):
+        net = self._fusion_network
+        return sum(t._version for t in list(net.parameters()) + list(net.buffers()))
+
+    def _get_engine(self, h, w, device):
+        key = (h, w, str(device), self._weights_fingerprint())
+        if self._engine is None or self._engine_key != key:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = FusionNetEngine(self._fusion_network, h, w, device)
+            self._engine_key = key
+            self._est = torch.empty((h * w, self.n_points), dtype=torch.float32, device=device)
+        return self._engine
+
+    def _get_workspace(self, shape, h, w, device):
+        key = (tuple(shape), h, w, self._integrate_mode)
+        if key not in self._workspaces:
+            self._workspaces[key] = ops.IntegrateWorkspace(shape, h, w, self.config.FUSION_MODEL.n_tail_points,
+                                                           self._integrate_mode, device)
+        return self._workspaces[key]
+
+    # ---- semantics front-end (pipeline.py:42-60, 181-193) --------------------------------------
+    def _segmentation(self, data):
+        inputs = {'image': (data['image'] / 255.0).to(self.device).float()}
+        in_ = self.config.DATA.input
+        if in_ != 'image':
+            inputs[in_] = data[in_].repeat(1, 3, 1, 1).to(self.device).float()
+        if self.config.SEMANTIC_2D_MODEL.stage == 1:
+            output = self._semantic_2d_network.forward(inputs[in_])
+        else:
+            output = self._semantic_2d_network.forward(inputs['image'], inputs[in_])
+        return torch.softmax(output[0], dim=1).permute(0, 2, 3, 1)
+
+    def _frame_semantics(self, batch):
+        if not self.config.DATA.semantics:
+            return None, None
+        strategy = self.config.DATA.semantic_strategy
+        if strategy == 'predict':
+            with torch.no_grad():
+                scores, sem_ids = self._segmentation(batch).max(dim=-1)
+        elif strategy == 'gt':
+            sem_ids = batch['semantic_gt']
+            scores = torch.ones_like(sem_ids, dtype=torch.float32)
+        else:
+            raise ValueError('Valid values for DATA.semantic_strategy are "gt" or "predict".')
+        h, w = sem_ids.shape[-2:]
+        sem_ids = sem_ids.to(self.device).to(torch.uint8).reshape(h * w).contiguous()
+        scores = scores.to(self.device).float().reshape(h * w).contiguous()
+        return sem_ids, scores
+
+    def _frames(self, batch):
+        frame = batch[self.config.DATA.input]
+        frame = frame.reshape(frame.shape[0], frame.shape[-2], frame.shape[-1])  # squeeze_(1) of [b,1,h,w]
+        if frame.shape[0] != 1:
+            raise ValueError('Pipeline: batch size 1 only (one scene per frame, pipeline.py:199)')
+        frame = frame.to(self.device).float().contiguous()
+        mask = batch['mask'].to(self.device).reshape(frame.shape)
+        filtered = torch.where(mask, frame, torch.zeros_like(frame))  # pipeline.py:196
+        return frame[0], filtered[0]
+
+    # ---- inference frame step (pipeline.py:173-248) ---------------------------------------------
+    def fuse(self, batch, database, device):
+        self.device = torch.device(device)
+        self._shape = batch['image'].shape
+        sem_ids, scores = self._frame_semantics(batch)
+        frame, filtered = self._frames(batch)
+        h, w = frame.shape
+
+        scene_id = batch['frame_id'][0].split('/')[0]
+        volume = database[scene_id]
+        tsdf, weights = volume['current'], volume['weights']
+        Ki, E = ops.camera_arrays(batch['intrinsics'][0], batch['extrinsics'][0])
+
+        eng = self._get_engine(h, w, self.device)
+        P = self.n_points
+        ops.extract(frame, Ki, E, volume['origin'], volume['resolution'], tsdf, weights, n_points=P,
+                    out_values=eng.in_ptr, out_weights=eng.in_ptr + 4 * P, out_stride=eng.in_stride)
+        use_sem = self.config.FUSION_MODEL.use_semantics
+        eng.prepare_input(frame, sem_ids if use_sem else None, self.n_classes if use_sem else 0)
+        eng.forward(self._est)
+
+        sem = bool(self.config.DATA.semantics)
+        ws = self._get_workspace(tsdf.shape, h, w, self.device)
+        ops.integrate(filtered, Ki, E, volume['origin'], volume['resolution'], self._est, tsdf, weights, ws,
+                      n_points=P, n_tail=self.config.FUSION_MODEL.n_tail_points,
+                      trunc=self.config.DATA.init_value,
+                      sem_ids=sem_ids if sem else None, sem_scores=scores if sem else None,
+                      id_vol=volume['ids_est'] if sem else None, score_vol=volume['scores'] if sem else None,
+                      mode=self._integrate_mode)
+
+        database.state[scene_id] = True  # volumes were updated in place (pipeline.py:239-244)
+        database.scenes_est[scene_id].volume = tsdf
+        database.fusion_weights[scene_id] = weights
+        return
+
+    # ---- training frame step (pipeline.py:251-363) -----------------------------------------------
+    def fuse_training(self, batch, database, device):
+        self.device = torch.device(device)
+        self._shape = batch['image'].shape
+        sem_ids, scores = self._frame_semantics(batch)
+        frame, filtered = self._frames(batch)
+        h, w = frame.shape
+        n, P = h * w, self.n_points
+
+        scene_id = batch['frame_id'][0].split('/')[0]
+        volume = database[scene_id]
+        tsdf, weights = volume['current'], volume['weights']
+        Ki, E = ops.camera_arrays(batch['intrinsics'][0], batch['extrinsics'][0])
+
+        cur = ops.extract(frame, Ki, E, volume['origin'], volume['resolution'], tsdf, weights, n_points=P)
+        gt = ops.extract(frame, Ki, E, volume['origin'], volume['resolution'], volume['gt'], weights, n_points=P)
+
+        def nchw(t):
+            return t.view(1, h, w, -1).permute(0, 3, 1, 2).contiguous()
+        inputs = {'tsdf_values': nchw(cur['fusion_values']), 'tsdf_weights': nchw(cur['fusion_weights']),
+                  'tsdf_frame': frame.view(1, 1, h, w)}
+        if self.config.FUSION_MODEL.use_semantics:
+            inputs['semantic_frame'] = ((1 + sem_ids.float()) / self.n_classes).view(1, 1, h, w)
+        tsdf_est = self._fusion_network.forward(inputs)  # autograd path (BN in train mode when .train())
+        tsdf_est = tsdf_est.permute(0, 2, 3, 1)[..., :P].reshape(1, n, P)
+
+        # pipeline.py:104-135
+        init = self.config.DATA.init_value
+        fw = torch.clamp_min(cur['fusion_weights'].view(1, n, P), 0)
+        tsdf_fused = (fw * cur['fusion_values'].view(1, n, P) + torch.clamp(tsdf_est, -init, init)) / (fw + 1)
+        valid = (filtered.reshape(n) != 0).nonzero()[:, 0]
+        output = {'tsdf_est': tsdf_est, 'tsdf_fused': tsdf_fused[:, valid, :],
+                  'tsdf_target': gt['fusion_values'].view(1, n, P)[:, valid, :]}
+
+        ws = self._get_workspace(tsdf.shape, h, w, self.device)
+        est_rows = tsdf_est.detach().reshape(n, P).contiguous()
+        ops.integrate(filtered, Ki, E, volume['origin'], volume['resolution'], est_rows, tsdf, weights, ws,
+                      n_points=P, n_tail=self.config.FUSION_MODEL.n_tail_points, trunc=init,
+                      mode=self._integrate_mode)  # test=False: no semantic update (pipeline.py:357)
+        database.state[scene_id] = True
+        database.scenes_est[scene_id].volume = tsdf
+        database.fusion_weights[scene_id] = weights
+        return output

@@ -58,3 +58,60 @@ def to_cuda(vols, dev):
 
 def make_stream(h, w, grid, n_frames=20, **kw):
     return SyntheticStream(h, w, grid, n_frames, **kw)
+
+
+# ---- whole-frame oracle: oracle.extract -> fp32 torch-CPU net -> oracle.integrate ---------------
+class NS(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def golden(name):
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', name))
+
+
+def net_from_golden(g, use_semantics, h, w, version='v3'):
+    import torch
+    from online_joint_depthfusion_and_semantic_amd import model
+    cfg = NS(n_points=9, growth_factor=6, use_semantics=use_semantics, output_scale=1.0, resx=w, resy=h)
+    net = getattr(model, 'FusionNet_' + version)(cfg)
+    state = {k[len('state_'):]: torch.from_numpy(g[k]) for k in g.files if k.startswith('state_')}
+    net.load_state_dict(state)
+    return net.eval()
+
+
+def oracle_net_est(net, fusion_values, fusion_weights, depth, sem_ids, n_classes, h, w):
+    """fp32 torch-CPU forward of the fusion net on [N,9] rows -> est [N,9]."""
+    import torch
+    def nchw(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).view(1, h, w, -1).permute(0, 3, 1, 2).contiguous()
+    x = dict(tsdf_values=nchw(fusion_values), tsdf_weights=nchw(fusion_weights),
+             tsdf_frame=torch.from_numpy(np.ascontiguousarray(depth)).view(1, 1, h, w))
+    if net.config.use_semantics:
+        x['semantic_frame'] = ((1 + torch.from_numpy(sem_ids.astype(np.float32))) / n_classes).view(1, 1, h, w)
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)  # golden-vector rule (SURVEY.md §8c): oneDNN conv results vary with threads at ulp level
+    try:
+        with torch.no_grad():
+            y = net(x)
+    finally:
+        torch.set_num_threads(nthreads)
+    return y[0].permute(1, 2, 0).reshape(h * w, -1)[:, :9].contiguous().numpy()
+
+
+def oracle_fuse(stream, i, vols, net, semantics, n_classes=30):
+    """One reference frame step on the CPU oracle; vols updated in place.  Returns est."""
+    f = stream.frame(i)
+    depth = f[stream.depth_key]
+    fd = np.where(f['mask'], depth, np.float32(0)).astype(np.float32)
+    Ki, E = oracle.camera_arrays(f['intrinsics'], f['extrinsics'])
+    ex = oracle.extract(depth, Ki, E, stream.origin, stream.resolution, vols['tsdf'], vols['wgt'])
+    est = oracle_net_est(net, ex['fusion_values'], ex['fusion_weights'], depth, f['semantic_gt'], n_classes,
+                         stream.h, stream.w)
+    kw = {}
+    if semantics:
+        kw = dict(sem_ids=f['semantic_gt'], sem_scores=np.ones_like(depth, dtype=np.float32),
+                  id_vol=vols['ids'], score_vol=vols['scores'])
+    oracle.integrate(fd, Ki, E, stream.origin, stream.resolution, est, vols['tsdf'], vols['wgt'], **kw)
+    return est

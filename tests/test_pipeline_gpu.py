@@ -1,0 +1,135 @@
+"""-m gpu: Pipeline.fuse / fuse_training (the drop-in boundary) on the HIP path against
+ (a) golden volumes produced by the reference's own Pipeline.fuse (tests/golden/make_golden.py),
+ (b) the CPU oracle frame step at config A, including the reference's volume metrics.
+Stated tolerances: semantic ids/scores and (parity mode) weights bit-exact; |dTSDF| <= 1.25e-4 (2 fp16 ulps)
+(the fp32-MFMA net differs from the CPU net by <= 1e-5 in tsdf_est, which can move the fp16
+rounding of U/W by one step, plus FAST mode's own single-ulp budget); metrics within 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+from online_joint_depthfusion_and_semantic_amd.config import default_config, database_config
+from online_joint_depthfusion_and_semantic_amd.database import Database
+from online_joint_depthfusion_and_semantic_amd.pipeline import Pipeline
+from online_joint_depthfusion_and_semantic_amd import metrics
+from helpers import (n_mismatch, f16_ulp_distance, golden, net_from_golden, oracle_fuse, fresh_volumes, make_stream)
+
+pytestmark = pytest.mark.gpu
+# 2 fp16 ulps at the top of the +-0.1 truncation band (ulp(0.0625..0.125) = 6.1e-5)
+TSDF_ABS_TOL = 1.25e-4
+
+
+def _setup(h, w, grid, sem, use_sem, mode, cuda, state=None):
+    cfg = default_config(h, w, semantics=sem, use_semantics=use_sem, integrate_mode=mode)
+    cfg.SETTINGS.device = str(cuda)
+    st = make_stream(h, w, grid)
+    db = Database(st, database_config(cfg))
+    pipe = Pipeline(cfg)
+    if state is not None:
+        pipe._fusion_network.load_state_dict(state)
+    pipe = pipe.to(cuda).eval()
+    return cfg, st, db, pipe
+
+
+def _batch(st, i, cuda, to_device=True):
+    b = st.batch(i)
+    if to_device:  # like utils/transform.to_device in the reference drivers
+        b = {k: (v.to(cuda) if torch.is_tensor(v) else v) for k, v in b.items()}
+    return b
+
+
+@pytest.mark.parametrize('mode', ['fast', 'parity'])
+@pytest.mark.parametrize('use_sem', [True, False])
+def test_fuse_matches_reference_pipeline_golden(cuda, use_sem, mode):
+    g = golden('pipeline_v3_%s_24x32_g32.npz' % ('sem' if use_sem else 'nosem'))
+    h, w, grid = 24, 32, 32
+    state = {k[len('state_'):]: torch.from_numpy(g[k]) for k in g.files if k.startswith('state_')}
+    cfg, st, db, pipe = _setup(h, w, grid, True, use_sem, mode, cuda, state)
+    with torch.no_grad():
+        for i in range(3):
+            pipe.fuse(_batch(st, i, cuda, to_device=(i % 2 == 0)), db, cuda)
+            s = st.scene
+            got = dict(tsdf=db.scenes_est[s].volume, wgt=db.fusion_weights[s], ids=db.ids_est[s].volume,
+                       scores=db.scores[s].volume)
+            got = {k: v.cpu().numpy() for k, v in got.items()}
+            assert n_mismatch(got['ids'], g['f%d_ids' % i]) == 0, i
+            assert n_mismatch(got['scores'], g['f%d_scores' % i]) == 0, i
+            wd = f16_ulp_distance(got['wgt'], g['f%d_wgt' % i])
+            assert wd.max() <= (0 if mode == 'parity' and i == 0 else 1), (i, int(wd.max()))
+            nan_eq = np.isnan(got['tsdf']) == np.isnan(g['f%d_tsdf' % i])
+            assert nan_eq.all()
+            td = np.nan_to_num(np.abs(got['tsdf'].astype(np.float32) - g['f%d_tsdf' % i].astype(np.float32)))
+            assert td.max() <= TSDF_ABS_TOL, (i, float(td.max()))
+            touched = int((g['f%d_wgt' % i] > 0).sum())
+            assert (td > 0).sum() <= 0.1 * touched, (i, int((td > 0).sum()), touched)
+    assert db.state[st.scene] is True
+
+
+def test_fuse_training_matches_reference_golden(cuda):
+    g = golden('pipeline_v3_nosem_24x32_g32.npz')
+    h, w, grid = 24, 32, 32
+    state = {k[len('state_'):]: torch.from_numpy(g[k]) for k in g.files if k.startswith('state_')}
+    cfg, st, db, pipe = _setup(h, w, grid, True, False, 'parity', cuda, state)
+    s = st.scene
+    # start from the reference's state after 3 frames, then one training frame (eval-mode BN like the fixture)
+    db.scenes_est[s].volume.copy_(torch.from_numpy(g['f2_tsdf']))
+    db.fusion_weights[s].copy_(torch.from_numpy(g['f2_wgt']))
+    out = pipe.fuse_training(_batch(st, 3, cuda), db, cuda)
+    assert out['tsdf_fused'].requires_grad
+    for k in ('tsdf_est', 'tsdf_fused', 'tsdf_target'):
+        a, b = out[k].detach()[0].cpu().numpy(), g['train_' + k]
+        assert a.shape == b.shape, (k, a.shape, b.shape)
+        assert np.abs(a - b).max() <= (0 if k == 'tsdf_target' else 2e-5), (k, float(np.abs(a - b).max()))
+    wd = f16_ulp_distance(db.fusion_weights[s].cpu().numpy(), g['train_wgt'])
+    assert wd.max() == 0
+    got = db.scenes_est[s].volume.cpu().numpy()
+    td = np.nan_to_num(np.abs(got.astype(np.float32) - g['train_tsdf'].astype(np.float32)))
+    assert td.max() <= TSDF_ABS_TOL
+    out['tsdf_fused'].sum().backward()  # gradients reach the net's parameters
+    assert any(p.grad is not None and p.grad.abs().sum() > 0 for p in pipe._fusion_network.parameters())
+
+
+@pytest.mark.parametrize('sem', [False, True])
+def test_stream_config_A_against_oracle(cuda, sem):
+    h, w, grid, frames = 120, 160, 64, 6
+    cfg, st, db, pipe = _setup(h, w, grid, sem, sem, 'fast', cuda)
+    torch.manual_seed(5)
+    for m in pipe._fusion_network.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            torch.nn.init.xavier_normal_(m.weight)
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    import copy
+    cpu_net = copy.deepcopy(pipe._fusion_network).cpu().eval()
+    vols = fresh_volumes(grid, True)
+    with torch.no_grad():
+        for i in range(frames):
+            pipe.fuse(_batch(st, i, cuda), db, cuda)
+            oracle_fuse(st, i, vols, cpu_net, sem)
+    s = st.scene
+    got_t, got_w = db.scenes_est[s].volume.cpu().numpy(), db.fusion_weights[s].cpu().numpy()
+    wd = f16_ulp_distance(got_w, vols['wgt'])
+    assert wd.max() <= 1
+    nan = np.isnan(got_t) | np.isnan(vols['tsdf'])
+    assert (np.isnan(got_t) == np.isnan(vols['tsdf'])).all()
+    td = np.where(nan, 0, np.abs(got_t.astype(np.float32) - vols['tsdf'].astype(np.float32)))
+    assert np.percentile(td[vols['wgt'] > 0], 99) <= 6.2e-5 and td.max() <= 2 * TSDF_ABS_TOL, float(td.max())
+    if sem:
+        assert n_mismatch(db.ids_est[s].volume.cpu().numpy(), vols['ids']) == 0
+        assert n_mismatch(db.scores[s].volume.cpu().numpy(), vols['scores']) == 0
+    # reference metrics (utils/metrics.py) on oracle volumes vs the on-device evaluate kernel
+    gt = db.scenes_gt[s].volume.cpu().numpy()
+    want = metrics.evaluation(vols['tsdf'], gt, vols['wgt'] > 0)
+    have = db.evaluate(mode='val')
+    for k in want:
+        assert abs(want[k] - have[k]) <= 1e-4 * max(1.0, abs(want[k])), (k, want[k], have[k])
+    # filter (outlier removal) on device == numpy semantics
+    db.filter(value=2.0)
+    low = vols['wgt'] < np.float16(2.0)
+    vols['tsdf'][low] = np.float16(0.1)
+    vols['wgt'][low] = 0
+    assert f16_ulp_distance(db.fusion_weights[s].cpu().numpy(), vols['wgt']).max() <= 1
+    db.reset(s)
+    assert float(db.fusion_weights[s].float().abs().sum()) == 0 and db.state[s] is False
+    assert torch.all(db.scenes_est[s].volume == torch.tensor(0.1, dtype=torch.float16))
