@@ -61,6 +61,10 @@ class FusionNetEngine:
         _lib.check(self.lib.ojf_net_input(self.handle, 0, ctypes.byref(base), ctypes.byref(stride)), 'ojf_net_input')
         self.in_ptr, self.in_stride = base.value, stride.value
         self.macs_per_pixel = int(self.lib.ojf_net_macs_per_pixel(self.handle))
+        heads = 2 if (version == 3 and self.use_semantics) else 1
+        n_vortex = heads + 1 if version == 3 else 2
+        # conv_mfma_kernel launches per forward: dense blocks, 14 per VortexPooling, prediction head
+        self.conv_launches = 2 * net.gf * heads + 14 * n_vortex + 2 * (net.gf - 1) + 3
 
     def input_view(self, head=0):
         """torch view [h*w, in_stride] of the net's input rows of ``head`` (memory owned by libojf)."""

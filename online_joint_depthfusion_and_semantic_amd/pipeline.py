@@ -56,6 +56,32 @@ class Pipeline(torch.nn.Module):
         self._engine_key = None
         self._workspaces = {}
         self._est = None
+        self.profile = False  # when True, fuse() brackets its three stages with HIP events
+        self._marks = []
+
+    # ---- live stage timing (HIP events on the launch stream; bench.py) ---------------------------
+    def _mark(self):
+        if self.profile:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream(self.device))
+            self._marks.append(e)
+
+    def reset_profile(self):
+        self._marks = []
+
+    def stage_times_ms(self):
+        """Mean milliseconds per frame of extract / net / integrate over the frames fused since
+        reset_profile() (4 events per frame)."""
+        torch.cuda.synchronize(self.device)
+        ev = self._marks
+        n = len(ev) // 4
+        if n == 0:
+            return {}
+        acc = [0.0, 0.0, 0.0]
+        for f in range(n):
+            for j in range(3):
+                acc[j] += ev[4 * f + j].elapsed_time(ev[4 * f + j + 1])
+        return {'extract': acc[0] / n, 'net': acc[1] / n, 'integrate': acc[2] / n}
 
     # ---- cached device objects ----------------------------------------------------------------
     def _weights_fingerprint(self):
@@ -133,11 +159,14 @@ class Pipeline(torch.nn.Module):
 
         eng = self._get_engine(h, w, self.device)
         P = self.n_points
+        self._mark()
         ops.extract(frame, Ki, E, volume['origin'], volume['resolution'], tsdf, weights, n_points=P,
                     out_values=eng.in_ptr, out_weights=eng.in_ptr + 4 * P, out_stride=eng.in_stride)
+        self._mark()
         use_sem = self.config.FUSION_MODEL.use_semantics
         eng.prepare_input(frame, sem_ids if use_sem else None, self.n_classes if use_sem else 0)
         eng.forward(self._est)
+        self._mark()
 
         sem = bool(self.config.DATA.semantics)
         ws = self._get_workspace(tsdf.shape, h, w, self.device)
@@ -147,6 +176,7 @@ class Pipeline(torch.nn.Module):
                       sem_ids=sem_ids if sem else None, sem_scores=scores if sem else None,
                       id_vol=volume['ids_est'] if sem else None, score_vol=volume['scores'] if sem else None,
                       mode=self._integrate_mode)
+        self._mark()
 
         database.state[scene_id] = True  # volumes were updated in place (pipeline.py:239-244)
         database.scenes_est[scene_id].volume = tsdf
