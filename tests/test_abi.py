@@ -1,0 +1,58 @@
+"""CPU: libojf.so loads without a GPU and exports exactly the symbols include/ojf.h declares;
+calls that need a device fail loudly instead of falling back to anything."""
+import os
+import re
+
+import pytest
+
+from online_joint_depthfusion_and_semantic_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, 'include', 'ojf.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(ojf_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.fail('libojf.so is not built: run `python -c "import __graft_entry__ as g; g.build()"`')
+    lib = _lib.load()
+    declared = header_symbols()
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(_lib.SIGNATURES) == declared  # the ctypes table and the header agree
+
+
+def test_version_and_error_strings():
+    lib = _lib.load()
+    assert lib.ojf_version().decode().startswith('ojf ')
+    assert isinstance(lib.ojf_last_error(), bytes)
+    assert lib.ojf_net_layer_count(3, 9, 5, 0) == 57
+    assert lib.ojf_net_layer_count(3, 9, 5, 1) == 85
+    assert lib.ojf_net_layer_count(2, 9, 5, 1) == 57
+    assert lib.ojf_net_layer_count(1, 9, 5, 0) < 0
+
+
+def test_no_silent_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is visible: the loud-failure path is for GPU-less hosts')
+    from online_joint_depthfusion_and_semantic_amd import ops
+    with pytest.raises(_lib.OjfError):
+        _lib.require_gpu()
+    with pytest.raises(_lib.OjfError):
+        ops.IntegrateWorkspace((8, 8, 8), 4, 4, 7, ops.MODE_FAST, 'cpu')
+
+
+def test_argument_validation_without_device():
+    lib = _lib.load()
+    # null pointers are rejected before any HIP call
+    assert lib.ojf_extract(None, None, None, None, 0.02, None, None, 8, 8, 8, 4, 4, 9, -0.1, None, None, 9,
+                           None, None, None, None, None) != 0
+    assert b'null' in lib.ojf_last_error()
+    assert lib.ojf_integrate_workspace_bytes(0, 8, 8, 4, 4, 7, 0) == 0
+    assert lib.ojf_integrate_workspace_bytes(8, 8, 8, 4, 4, 7, 0) == 256 + 512 * 24 + 512 * 4
