@@ -160,8 +160,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
 struct PoolArgs {
     const float *in;
     float *out;
-    const float *bias;  // optional: adds bias and applies ReLU (the branch's BN+ReLU after the 1x1)
-    int in_stride, in_off, out_stride, out_off, h, w, c4;
+    const float *bias;  // bias + ReLU (the branch's BN+ReLU after its 1x1) for the first act_c4 groups
+    int in_stride, in_off, out_stride, out_off, h, w, c4, act_c4;
 };
 
 // 3x3 average pool, stride 1, zero padding 1, count_include_pad (always / 9): nn.AvgPool2d(3,1,1)
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void avgpool3_kernel(const PoolArgs a)
                 s += *reinterpret_cast<const f32x4 *>(a.in + (size_t)(sy * a.w + sx) * a.in_stride + a.in_off + 4 * cg);
         }
     s = s / 9.0f;
-    if (a.bias) {
+    if (cg < a.act_c4) {
         const f32x4 b = *reinterpret_cast<const f32x4 *>(a.bias + 4 * cg);
         s += b;
 #pragma unroll
@@ -191,39 +191,50 @@ __global__ __launch_bounds__(256) void avgpool3_kernel(const PoolArgs a)
     *reinterpret_cast<f32x4 *>(a.out + (size_t)p * a.out_stride + a.out_off + 4 * cg) = s;
 }
 
-constexpr int kSumBlocks = 256;
+constexpr int kSumBlocks = 128;
 
-// per-channel partial sums over a strip of pixels (deterministic two-stage global average)
-__global__ __launch_bounds__(256) void colsum_kernel(const float *in, int stride, int off, int cphys, int npix, float *partial)
+// per-channel partial sums over a strip of pixels (deterministic two-stage global average):
+// thread (row r, float4 group cg) strides over the strip's pixels; rows are reduced in fixed order
+__global__ __launch_bounds__(256) void colsum_kernel(const float *in, int stride, int cphys, int npix, float *partial)
 {
-    const int c = threadIdx.x;
-    if (c >= cphys) return;
+    __shared__ f32x4 red[256];
+    const int ngrp = cphys >> 2;
+    const int rows = 256 / ngrp;
+    const int r = threadIdx.x / ngrp, cg = threadIdx.x - r * ngrp;
     const int per = (npix + gridDim.x - 1) / gridDim.x;
     const int p0 = blockIdx.x * per;
     const int p1 = min(npix, p0 + per);
-    float s = 0.0f;
-    for (int p = p0; p < p1; ++p) s += in[(size_t)p * stride + off + c];
-    partial[blockIdx.x * 256 + c] = s;
+    f32x4 s{0.f, 0.f, 0.f, 0.f};
+    if (r < rows)
+        for (int p = p0 + r; p < p1; p += rows) s += *reinterpret_cast<const f32x4 *>(in + (size_t)p * stride + 4 * cg);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (r == 0) {
+        for (int j = 1; j < rows; ++j) s += red[j * ngrp + cg];
+        *reinterpret_cast<f32x4 *>(partial + blockIdx.x * 256 + 4 * cg) = s;
+    }
 }
 
 // gave_pool branch (model.py:107-112) folded into the bias of the final 1x1 conv:
 //   mean -> 1x1 conv (+BN folded) -> g[c_out];  bias' = bias_final + W_final[:, gave columns] @ g
-__global__ __launch_bounds__(256) void gave_bias_kernel(const float *partial, int cphys, int npix, const float *Wg,
-                                                         const float *bg, const float *Wfg, const float *bf, int c_out,
+__global__ __launch_bounds__(256) void gave_bias_kernel(const float *partial, int cphys, int npix, const float *WgT,
+                                                         const float *bg, const float *WfgT, const float *bf, int c_out,
                                                          float *bias_out, int bias_len)
-{
+{   // WgT [cphys][c_out], WfgT [c_out(j)][c_out(o)]: lane o reads consecutive addresses
     __shared__ float mean[256];
     __shared__ float gv[256];
     const int t = threadIdx.x;
     if (t < cphys) {
         float s = 0.0f;
+#pragma unroll 8
         for (int b = 0; b < kSumBlocks; ++b) s += partial[b * 256 + t];
         mean[t] = s / (float)npix;
     }
     __syncthreads();
     if (t < c_out) {
         float s = bg[t];
-        for (int c = 0; c < cphys; ++c) s = __builtin_fmaf(Wg[(size_t)t * cphys + c], mean[c], s);
+#pragma unroll 8
+        for (int c = 0; c < cphys; ++c) s = __builtin_fmaf(WgT[(size_t)c * c_out + t], mean[c], s);
         gv[t] = s;
     }
     __syncthreads();
@@ -231,7 +242,8 @@ __global__ __launch_bounds__(256) void gave_bias_kernel(const float *partial, in
         float s = 0.0f;
         if (t < c_out) {
             s = bf[t];
-            for (int j = 0; j < c_out; ++j) s = __builtin_fmaf(Wfg[(size_t)t * c_out + j], gv[j], s);
+#pragma unroll 8
+            for (int j = 0; j < c_out; ++j) s = __builtin_fmaf(WfgT[(size_t)j * c_out + t], gv[j], s);
         }
         bias_out[t] = s;
     }
@@ -386,7 +398,8 @@ struct ojf_net {
     float *X[2] = {nullptr, nullptr};  // dense-growth buffers, (gf+1)*cs channels
     float *T = nullptr;                // cs
     float *Z = nullptr;                // 4*cs
-    float *Pa = nullptr, *Pb = nullptr, *U = nullptr, *V = nullptr;  // cs
+    float *Q1 = nullptr, *Q2 = nullptr, *Q3 = nullptr;  // pooled branch pre-activations: 3cs, 2cs, cs
+    float *U = nullptr, *V = nullptr;                    // cs
     float *CAT = nullptr;              // 4*os
     float *YY = nullptr;               // heads*os (vortex0 | vortex2 outputs)
     float *Y3 = nullptr;               // os
@@ -447,10 +460,10 @@ static int build_vortex(ojf_net *net, Vortex &v, const ojf_conv_layer *L, int c_
         b.add(lf, out, 5 * out, slot_map(4 * out, out, os), 0, false);
         if (finish(b, v.fin)) return -2;
         std::vector<float> Wg((size_t)out * c_in_phys, 0.0f), bg(out), Wfg((size_t)out * out), bf(out);
-        for (int o = 0; o < out; ++o) {
-            for (int ci = 0; ci < c_in; ++ci) Wg[(size_t)o * c_in_phys + in_map[ci]] = L[0].weight_host[(size_t)o * c_in + ci];
+        for (int o = 0; o < out; ++o) {  // stored transposed: [input][output]
+            for (int ci = 0; ci < c_in; ++ci) Wg[(size_t)in_map[ci] * out + o] = L[0].weight_host[(size_t)o * c_in + ci];
             bg[o] = L[0].bias_host[o];
-            for (int j = 0; j < out; ++j) Wfg[(size_t)o * out + j] = lf.weight_host[(size_t)o * 5 * out + j];
+            for (int j = 0; j < out; ++j) Wfg[(size_t)j * out + o] = lf.weight_host[(size_t)o * 5 * out + j];
             bf[o] = lf.bias_host[o];
         }
         if (upload(Wg, &v.Wg) || upload(bg, &v.bg) || upload(Wfg, &v.Wfg) || upload(bf, &v.bf)) return -2;
@@ -476,9 +489,9 @@ static void free_vortex(Vortex &v)
 }
 
 static int launch_pool(const float *in, int in_stride, int in_off, float *out, int out_stride, int out_off,
-                       const float *bias, int c4, int h, int w, hipStream_t st)
+                       const float *bias, int c4, int act_c4, int h, int w, hipStream_t st)
 {
-    PoolArgs a{in, out, bias, in_stride, in_off, out_stride, out_off, h, w, c4};
+    PoolArgs a{in, out, bias, in_stride, in_off, out_stride, out_off, h, w, c4, act_c4};
     const int items = h * w * c4;
     hipLaunchKernelGGL(avgpool3_kernel, dim3((items + 255) / 256), dim3(256), 0, st, a);
     return check_hip(hipGetLastError(), "avgpool3_kernel launch");
@@ -489,29 +502,24 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_stride, i
 {
     const int h = net->h, w = net->w, cs = net->cs, os = net->os, c4 = cs / 4;
     // global-average branch -> bias of the final conv
-    hipLaunchKernelGGL(colsum_kernel, dim3(kSumBlocks), dim3(256), 0, st, in + in_off, in_stride, 0, v.c_in_phys,
-                       net->npix, net->partial);
+    hipLaunchKernelGGL(colsum_kernel, dim3(kSumBlocks), dim3(256), 0, st, in + in_off, in_stride, v.c_in_phys, net->npix,
+                       net->partial);
     OJF_HIP(hipGetLastError());
     hipLaunchKernelGGL(gave_bias_kernel, dim3(1), dim3(256), 0, st, net->partial, v.c_in_phys, net->npix, v.Wg, v.bg,
                        v.Wfg, v.bf, net->pool_in, v.bias_final, v.fin.n_ot * 16);
     OJF_HIP(hipGetLastError());
     // branch entries: one GEMM, branch 0 gets bias + ReLU in the epilogue
     if (launch_conv(v.stacked, in, in_stride, in_off, net->Z, 4 * cs, 0, nullptr, OJF_ACT_RELU, cs, 1.0f, h, w, st)) return -2;
+    // pool pyramid on the pre-activations of branches 1..3 (one launch per level; the first cs
+    // channels of each level are that level's branch input and get its bias + ReLU):
+    //   Q1 = pool(Z[cs:4cs]) ; Q2 = pool(Q1[cs:3cs]) ; Q3 = pool(Q2[cs:2cs])
+    if (launch_pool(net->Z, 4 * cs, cs, net->Q1, 3 * cs, 0, v.pool_bias[1], 3 * c4, c4, h, w, st)) return -2;
+    if (launch_pool(net->Q1, 3 * cs, cs, net->Q2, 2 * cs, 0, v.pool_bias[2], 2 * c4, c4, h, w, st)) return -2;
+    if (launch_pool(net->Q2, 2 * cs, cs, net->Q3, cs, 0, v.pool_bias[3], c4, c4, h, w, st)) return -2;
+    const float *bin[4] = {net->Z, net->Q1, net->Q2, net->Q3};
+    const int bstride[4] = {4 * cs, 3 * cs, 2 * cs, cs};
     for (int br = 0; br < 4; ++br) {
-        const float *bin = net->Z;  // branch input rows
-        int bstride = 4 * cs, boff = 0;
-        if (br > 0) {  // br successive 3x3 average pools of the pre-activation, then bias + ReLU
-            const float *src = net->Z;
-            int sstride = 4 * cs, soff = br * cs;
-            float *pp[2] = {net->Pa, net->Pb};
-            for (int k = 0; k < br; ++k) {
-                float *dst = pp[k & 1];
-                if (launch_pool(src, sstride, soff, dst, cs, 0, k == br - 1 ? v.pool_bias[br] : nullptr, c4, h, w, st)) return -2;
-                src = dst; sstride = cs; soff = 0;
-            }
-            bin = src; bstride = cs; boff = 0;
-        }
-        if (launch_conv(v.b3a[br], bin, bstride, boff, net->U, cs, 0, nullptr, OJF_ACT_RELU, cs, 1.0f, h, w, st)) return -2;
+        if (launch_conv(v.b3a[br], bin[br], bstride[br], 0, net->U, cs, 0, nullptr, OJF_ACT_RELU, cs, 1.0f, h, w, st)) return -2;
         if (launch_conv(v.b3b[br], net->U, cs, 0, net->V, cs, 0, nullptr, OJF_ACT_RELU, cs, 1.0f, h, w, st)) return -2;
         if (launch_conv(v.b1[br], net->V, cs, 0, net->CAT, 4 * os, br * os, nullptr, OJF_ACT_RELU, os, 1.0f, h, w, st)) return -2;
     }
@@ -554,7 +562,7 @@ OJF_API void ojf_net_destroy(ojf_net *net)
         for (auto &pc : net->dense[hd]) release(pc);
     for (auto &pc : net->pred) release(pc);
     for (auto &v : net->vortex) free_vortex(v);
-    float *bufs[] = {net->X[0], net->X[1], net->T, net->Z, net->Pa, net->Pb, net->U, net->V,
+    float *bufs[] = {net->X[0], net->X[1], net->T, net->Z, net->Q1, net->Q2, net->Q3, net->U, net->V,
                      net->CAT, net->YY, net->Y3, net->PA, net->PB, net->partial};
     for (float *p : bufs)
         if (p) (void)hipFree(p);
@@ -653,8 +661,9 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
     if (!rc && net->heads == 2) rc = alloc_rows(&net->X[1], np, (gf + 1) * cs);
     if (!rc) rc = alloc_rows(&net->T, np, cs);
     if (!rc) rc = alloc_rows(&net->Z, np, 4 * cs);
-    if (!rc) rc = alloc_rows(&net->Pa, np, cs);
-    if (!rc) rc = alloc_rows(&net->Pb, np, cs);
+    if (!rc) rc = alloc_rows(&net->Q1, np, 3 * cs);
+    if (!rc) rc = alloc_rows(&net->Q2, np, 2 * cs);
+    if (!rc) rc = alloc_rows(&net->Q3, np, cs);
     if (!rc) rc = alloc_rows(&net->U, np, cs);
     if (!rc) rc = alloc_rows(&net->V, np, cs);
     if (!rc) rc = alloc_rows(&net->CAT, np, 4 * os);
