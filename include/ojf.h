@@ -106,15 +106,14 @@ int ojf_net_create(ojf_net **out, int version, int n_points, int growth, int use
 void ojf_net_destroy(ojf_net *net);
 /* number of folded conv layers ojf_net_create expects for this topology, <0 if unsupported */
 int ojf_net_layer_count(int version, int n_points, int growth, int use_semantics);
-/* Device pointer + pixel stride (floats) of the net's input rows: channel c of pixel n lives at
- * base[n*stride + c]; channels [0,P) fusion_values, [P,2P) fusion_weights, [2P] depth frame.  With
- * semantics (v3) a second row set holds [values | weights | (1+id)/n_classes] (model.py:274).
- * ojf_extract can write straight into these (out_stride = stride). */
-int ojf_net_input(ojf_net *net, int head, float **base_dev, int *stride);
-/* Fills channel 2P of head 0 with the depth frame and, when the net uses semantics, head 1 with
- * values | weights (copied from head 0) | (1+sem_id)/n_classes  (pipeline.py:90-96). */
-int ojf_net_prepare_input(ojf_net *net, const float *depth_dev, const uint8_t *sem_ids_dev,
-                          int n_classes, ojf_stream_t stream);
+/* Packs the net's input from the extractor's row-major outputs (modules/pipeline.py:74-102):
+ * channels [0,P) fusion_values, [P,2P) fusion_weights (both [h*w, rows_stride] f32), [2P] the depth
+ * frame; with semantics (v3) a second head gets values | weights | (1+sem_id)/n_classes
+ * (model.py:274), v2 appends the semantic channel to the single head (model.py:207).  The net's
+ * internal activation layout (planes of 4 channels) is private to the library. */
+int ojf_net_prepare_input(ojf_net *net, const float *values_dev, const float *weights_dev, int rows_stride,
+                          const float *depth_dev, const uint8_t *sem_ids_dev, int n_classes,
+                          ojf_stream_t stream);
 /* Runs the net; est_dev receives output_scale*tanh(.) for (pixel n, sample k) at [n*est_stride+k]. */
 int ojf_net_forward(ojf_net *net, float *est_dev, int est_stride, ojf_stream_t stream);
 /* useful multiply-accumulates per pixel of this topology (padding excluded) */

@@ -43,8 +43,7 @@ SIGNATURES = {
     'ojf_net_create': (_i, [_c.POINTER(_vp), _i, _i, _i, _i, _f, _c.POINTER(ConvLayer), _i, _i, _i]),
     'ojf_net_destroy': (None, [_vp]),
     'ojf_net_layer_count': (_i, [_i, _i, _i, _i]),
-    'ojf_net_input': (_i, [_vp, _i, _c.POINTER(_vp), _c.POINTER(_i)]),
-    'ojf_net_prepare_input': (_i, [_vp, _vp, _vp, _i, _vp]),
+    'ojf_net_prepare_input': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     'ojf_net_forward': (_i, [_vp, _vp, _i, _vp]),
     'ojf_net_macs_per_pixel': (_c.c_int64, [_vp]),
     'ojf_conv2d': (_i, [_vp, _i, _i, _vp, _i, _i, _c.POINTER(ConvLayer), _i, _i, _i, _vp]),

@@ -5,17 +5,25 @@
 // chain, so tsdf_est agrees with the reference's fp32 CPU net to ~1e-6 (tolerance stated in the
 // tests: 1e-5).  The +-0.1 truncation band of the TSDF rules out bf16.
 //
-// Data layout: activations are NHWC rows in HBM, one row per pixel, channel groups padded to a
-// multiple of 4 floats (19 -> 20, 114 -> 116) so every operand fetch is a 16-byte access; pad
-// channels carry zeros (zero weights + zero bias in the producing layer).  A convolution is an
-// implicit GEMM  out[pixel, oc] = sum_{tap, c} in[pixel + tap, c] * W[oc, tap, c]  with
-//   MFMA rows    = 16 consecutive pixels,   MFMA cols = 16 output channels,
-//   K            = (tap, channel) walked 16 channels at a time: lane (i, g) fetches channels
-//                  16c+4g..+3 of pixel i as one float4 and feeds element j to MFMA j of the chunk;
-//                  the packed weights use the same (g, j) permutation, so both operand fetches are
-//                  full 16-byte-per-lane loads (1 KiB per wave instruction).
-// Out-of-image taps contribute zero; whole taps are skipped when no lane of the wave is inside
-// the image (dilation 9 / 27 near the borders).  Bias + activation are fused into the epilogue.
+// Data layout ("C4 planes"): an activation tensor with C channels (padded to a multiple of 4:
+// 19 -> 20, 114 -> 116; pad channels carry zeros) is stored as C/4 planes of float4, element
+// (channel group cg, pixel p) at plane[cg * npix + p].  A wave's 16 consecutive pixels of one
+// channel group are 256 contiguous bytes, so every MFMA operand fetch and every result store is a
+// fully coalesced 16-byte-per-lane access WITHOUT an LDS transpose (the first version used NHWC rows:
+// its fragment-shaped loads touched 64 different cache lines per wave instruction and the kernel
+// sat at the texture-addresser limit, ~4x off the MFMA bound).
+//
+// A convolution is an implicit GEMM  D[oc, pixel] = sum_K W[oc, K] * X[K, pixel]:
+//   MFMA rows = 16 output channels (A operand = packed weights), MFMA cols = 16 consecutive pixels
+//   (B operand = activations), K = flattened list of (tap, 4-channel group) pairs, G = tap*c4 + cg.
+//   In superstep S lane group g (= lane >> 4) owns group G = 4S + g: it fetches that group's float4 of
+//   ITS tap's source pixel and feeds element j to MFMA j of the superstep; the packed weights use
+//   the same (g, j) permutation.  Any channel count that is a multiple of 4 works without tails,
+//   out-of-image taps contribute zeros, supersteps whose every source pixel is outside the image
+//   are skipped (dilation 9 / 27 near the borders), and the loop is software pipelined (operands of
+//   superstep S+1 in flight while the 4*MT*NT MFMAs of S issue).
+//   The accumulator of lane (pixel i, g) holds output channels 4g..4g+3 of its pixel: the epilogue
+//   adds bias, applies the activation and writes ONE float4 into the output plane.
 //
 // Algebraic restructuring of VortexPooling (model.py:100-161), exact up to fp32 rounding:
 //   * the four branch-entry 1x1 convolutions commute with the (linear) 3x3 average pools, so they
@@ -37,16 +45,18 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // kernels
 // ------------------------------------------------------------------------------------------------
 struct ConvArgs {
-    const float *in;
-    float *out;
-    const float *wp;    // packed weights [oc tile][tap][k step][lane]
-    const float *bias;  // [n_ot*16]
-    int in_stride, in_off, out_stride, out_off;
+    const f32x4 *in;   // input planes; channel group cg of this conv's window = plane in_g0 + cg
+    f32x4 *out;        // output planes (NULL when out_rows is used)
+    float *out_rows;   // last layer only: row-major [npix, rows_stride] scalars, channels < rows_n
+    const f32x4 *wp;   // packed weights [oc tile][superstep][lane] float4
+    const float *bias; // [n_ot*16]
+    int in_g0, out_g0, rows_stride, rows_n;
     int h, w, npix;
     int taps, dil;
-    int n16, n4, ksteps;  // per tap: full 16-channel chunks, 4-channel tail steps, n16*4+n4
-    int c_store;          // channels written (multiple of 4)
-    int act, act_n;       // activation applied to output channels < act_n
+    int c4;          // input channel groups per tap
+    int nsteps;      // supersteps = ceil(taps * c4 / 4)
+    int og_store;    // output channel groups written (planar mode)
+    int act, act_n;  // activation applied to output channels < act_n
     float scale;
 };
 
@@ -85,83 +95,91 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const size_t tap_block = (size_t)a.ksteps * 64;
-    for (int t = 0; t < a.taps; ++t) {
+    const f32x4 *wb[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) wb[n] = a.wp + (size_t)(ot0 + n) * a.nsteps * 64 + lane;
+
+    // this lane group's position in the flattened K list
+    int t = g / a.c4, cg = g - t * a.c4;
+
+    auto fetch = [&](f32x4(&xv)[MT], f32x4(&wv)[NT], int S, bool &live) {
         int dy = 0, dx = 0;
         if (a.taps == 9) {
-            dy = (t / 3 - 1) * a.dil;
-            dx = (t % 3 - 1) * a.dil;
+            const int ky = (t * 11) >> 5;  // t / 3 for t < 12
+            dy = (ky - 1) * a.dil;
+            dx = (t - 3 * ky - 1) * a.dil;
         }
-        const float *src[MT];
-        bool ok[MT];
+        const bool tap_ok = t < a.taps;
+        const f32x4 *plane = a.in + (size_t)(a.in_g0 + cg) * a.npix;
         bool any_ok = false;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int sy = py[m] + dy, sx = px[m] + dx;
-            ok[m] = pv[m] && (unsigned)sy < (unsigned)a.h && (unsigned)sx < (unsigned)a.w;
-            src[m] = a.in + (size_t)(ok[m] ? sy * a.w + sx : 0) * a.in_stride + a.in_off;
-            any_ok |= ok[m];
+            const bool ok = tap_ok && pv[m] && (unsigned)sy < (unsigned)a.h && (unsigned)sx < (unsigned)a.w;
+            xv[m] = ok ? plane[sy * a.w + sx] : f32x4{0.f, 0.f, 0.f, 0.f};
+            any_ok |= ok;
         }
-        if (!__any(any_ok)) continue;  // the whole wave looks outside the image for this tap
-        const float *wt[NT];
+        live = __any(any_ok);  // dead superstep: every source pixel of the wave is outside the image
 #pragma unroll
-        for (int n = 0; n < NT; ++n) wt[n] = a.wp + ((size_t)(ot0 + n) * a.taps + t) * tap_block;
-
-#pragma unroll 2
-        for (int c = 0; c < a.n16; ++c) {
-            f32x4 av[MT], bv[NT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-                av[m] = ok[m] ? *reinterpret_cast<const f32x4 *>(src[m] + 16 * c + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int n = 0; n < NT; ++n) bv[n] = *reinterpret_cast<const f32x4 *>(wt[n] + (size_t)c * 256 + lane * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int n = 0; n < NT; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][j], bv[n][j], acc[m][n], 0, 0, 0);
+        for (int n = 0; n < NT; ++n) wv[n] = wb[n][(size_t)S * 64];
+        cg += 4;  // advance to superstep S+1
+        while (cg >= a.c4) {
+            cg -= a.c4;
+            ++t;
         }
-        for (int s = 0; s < a.n4; ++s) {
-            float av[MT], bv[NT];
+    };
+    auto mac = [&](const f32x4(&xv)[MT], const f32x4(&wv)[NT]) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) av[m] = ok[m] ? src[m][16 * a.n16 + 4 * s + g] : 0.0f;
-#pragma unroll
-            for (int n = 0; n < NT; ++n) bv[n] = wt[n][(size_t)a.n16 * 256 + s * 64 + lane];
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[n], acc[m][n], 0, 0, 0);
-        }
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[n][j], xv[m][j], acc[m][n], 0, 0, 0);
+    };
+
+    f32x4 x0[MT], w0[NT], x1[MT], w1[NT];
+    bool live0, live1 = false;
+    fetch(x0, w0, 0, live0);
+    for (int S = 0; S < a.nsteps; S += 2) {
+        if (S + 1 < a.nsteps) fetch(x1, w1, S + 1, live1);
+        if (live0) mac(x0, w0);
+        if (S + 1 >= a.nsteps) break;
+        if (S + 2 < a.nsteps) fetch(x0, w0, S + 2, live0);
+        if (live1) mac(x1, w1);
     }
 
-    // C/D layout of 16x16x4: lane (i16, g) holds rows g*4+r (pixels), column i16 (output channel)
+    // C/D layout of 16x16x4: lane (i16, g) holds column i16 (pixel) and rows 4g..4g+3 (output channels)
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-        const int oc = (ot0 + n) * 16 + i16;
-        if (oc >= a.c_store) continue;
-        const float b = a.bias[oc];
-        const bool do_act = oc < a.act_n;
+        const int og = (ot0 + n) * 4 + g;  // output channel group
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(a.bias + (size_t)(ot0 + n) * 16 + 4 * g);
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m) {
+            const int p = strip + m * 16 + i16;
+            if (p >= a.npix) continue;
+            f32x4 v = acc[m][n] + b;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int p = strip + m * 16 + g * 4 + r;
-                if (p >= a.npix) continue;
-                float v = acc[m][n][r] + b;
-                if (do_act) v = activate(v, a.act);
-                a.out[(size_t)p * a.out_stride + a.out_off + oc] = v * a.scale;
+            for (int j = 0; j < 4; ++j) {
+                if (og * 4 + j < a.act_n) v[j] = activate(v[j], a.act);
+                v[j] *= a.scale;
             }
+            if (a.out_rows) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (og * 4 + j < a.rows_n) a.out_rows[(size_t)p * a.rows_stride + og * 4 + j] = v[j];
+            } else if (og < a.og_store) {
+                a.out[(size_t)(a.out_g0 + og) * a.npix + p] = v;
+            }
+        }
     }
 }
 
 struct PoolArgs {
-    const float *in;
-    float *out;
+    const f32x4 *in;
+    f32x4 *out;
     const float *bias;  // bias + ReLU (the branch's BN+ReLU after its 1x1) for the first act_c4 groups
-    int in_stride, in_off, out_stride, out_off, h, w, c4, act_c4;
+    int in_g0, out_g0, h, w, c4, act_c4;
 };
 
 // 3x3 average pool, stride 1, zero padding 1, count_include_pad (always / 9): nn.AvgPool2d(3,1,1)
@@ -170,48 +188,47 @@ __global__ __launch_bounds__(256) void avgpool3_kernel(const PoolArgs a)
     const int item = blockIdx.x * blockDim.x + threadIdx.x;
     const int npix = a.h * a.w;
     if (item >= npix * a.c4) return;
-    const int p = item / a.c4, cg = item - p * a.c4;
+    const int cg = item / npix, p = item - cg * npix;
     const int y = p / a.w, x = p - y * a.w;
+    const f32x4 *plane = a.in + (size_t)(a.in_g0 + cg) * npix;
     f32x4 s{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
         for (int dx = -1; dx <= 1; ++dx) {
             const int sy = y + dy, sx = x + dx;
-            if ((unsigned)sy < (unsigned)a.h && (unsigned)sx < (unsigned)a.w)
-                s += *reinterpret_cast<const f32x4 *>(a.in + (size_t)(sy * a.w + sx) * a.in_stride + a.in_off + 4 * cg);
+            if ((unsigned)sy < (unsigned)a.h && (unsigned)sx < (unsigned)a.w) s += plane[sy * a.w + sx];
         }
     s = s / 9.0f;
     if (cg < a.act_c4) {
-        const f32x4 b = *reinterpret_cast<const f32x4 *>(a.bias + 4 * cg);
-        s += b;
+        s += *reinterpret_cast<const f32x4 *>(a.bias + 4 * cg);
 #pragma unroll
         for (int j = 0; j < 4; ++j) s[j] = s[j] > 0.0f ? s[j] : 0.0f;
     }
-    *reinterpret_cast<f32x4 *>(a.out + (size_t)p * a.out_stride + a.out_off + 4 * cg) = s;
+    a.out[(size_t)(a.out_g0 + cg) * npix + p] = s;
 }
 
-constexpr int kSumBlocks = 128;
+constexpr int kSumBlocks = 32;
 
-// per-channel partial sums over a strip of pixels (deterministic two-stage global average):
-// thread (row r, float4 group cg) strides over the strip's pixels; rows are reduced in fixed order
-__global__ __launch_bounds__(256) void colsum_kernel(const float *in, int stride, int cphys, int npix, float *partial)
+// per-channel partial sums (deterministic two-stage global average): block (b, cg) sums the float4s
+// of plane cg over pixel strip b; fixed-order shuffle + LDS reduction
+__global__ __launch_bounds__(256) void colsum_kernel(const f32x4 *in, int g0, int npix, float *partial)
 {
-    __shared__ f32x4 red[256];
-    const int ngrp = cphys >> 2;
-    const int rows = 256 / ngrp;
-    const int r = threadIdx.x / ngrp, cg = threadIdx.x - r * ngrp;
+    __shared__ f32x4 red[4];
+    const int cg = blockIdx.y;
     const int per = (npix + gridDim.x - 1) / gridDim.x;
-    const int p0 = blockIdx.x * per;
-    const int p1 = min(npix, p0 + per);
+    const int p0 = blockIdx.x * per, p1 = min(npix, p0 + per);
+    const f32x4 *plane = in + (size_t)(g0 + cg) * npix;
     f32x4 s{0.f, 0.f, 0.f, 0.f};
-    if (r < rows)
-        for (int p = p0 + r; p < p1; p += rows) s += *reinterpret_cast<const f32x4 *>(in + (size_t)p * stride + 4 * cg);
-    red[threadIdx.x] = s;
+    for (int p = p0 + threadIdx.x; p < p1; p += 256) s += plane[p];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        for (int off = 32; off > 0; off >>= 1) s[j] += __shfl_down(s[j], off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (r == 0) {
-        for (int j = 1; j < rows; ++j) s += red[j * ngrp + cg];
-        *reinterpret_cast<f32x4 *>(partial + blockIdx.x * 256 + 4 * cg) = s;
+    if (threadIdx.x == 0) {
+        s = (red[0] + red[1]) + (red[2] + red[3]);
+        *reinterpret_cast<f32x4 *>(partial + (size_t)blockIdx.x * 256 + 4 * cg) = s;
     }
 }
 
@@ -250,30 +267,65 @@ __global__ __launch_bounds__(256) void gave_bias_kernel(const float *partial, in
 }
 
 struct PrepArgs {
+    const float *values;   // [npix, rows_stride] fusion_values
+    const float *weights;  // [npix, rows_stride] fusion_weights
     const float *depth;
     const uint8_t *sem;
-    float *x0;
-    float *x1;
-    int stride, npix, P, n_classes, v2_sem;
+    f32x4 *x0;
+    f32x4 *x1;
+    int rows_stride, npix, P, cs4, n_classes, v2_sem;
 };
 
-// modules/pipeline.py:90-96: tsdf_frame channel = raw depth; semantic_frame = (1 + id) / n_classes
+// modules/pipeline.py:74-102 _prepare_fusion_input: channels [values(P) | weights(P) | depth | (sem)]
+// packed into the first dense-growth slot of each head; semantic_frame = (1 + id) / n_classes
 __global__ __launch_bounds__(256) void prepare_input_kernel(const PrepArgs a)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.npix) return;
-    float *r0 = a.x0 + (size_t)p * a.stride;
-    r0[2 * a.P] = a.depth[p];
-    if (a.sem) {
-        const float sf = (1.0f + (float)a.sem[p]) / (float)a.n_classes;
-        if (a.v2_sem) {
-            r0[2 * a.P + 1] = sf;
-        } else {
-            float *r1 = a.x1 + (size_t)p * a.stride;
-            for (int c = 0; c < 2 * a.P; ++c) r1[c] = r0[c];
-            r1[2 * a.P] = sf;
+    const float *v = a.values + (size_t)p * a.rows_stride;
+    const float *wt = a.weights + (size_t)p * a.rows_stride;
+    const float d = a.depth[p];
+    const float sf = a.sem ? (1.0f + (float)a.sem[p]) / (float)a.n_classes : 0.0f;
+    for (int cg = 0; cg < a.cs4; ++cg) {
+        f32x4 r0, r1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * cg + j;
+            float base = 0.0f;
+            if (c < a.P) base = v[c];
+            else if (c < 2 * a.P) base = wt[c - a.P];
+            r0[j] = base;
+            r1[j] = base;
+            if (c == 2 * a.P) { r0[j] = d; r1[j] = sf; }
+            if (c == 2 * a.P + 1 && a.v2_sem) r0[j] = sf;
         }
+        a.x0[(size_t)cg * a.npix + p] = r0;
+        if (a.x1) a.x1[(size_t)cg * a.npix + p] = r1;
     }
+}
+
+// rows <-> planes (ojf_conv2d test entry point only)
+__global__ __launch_bounds__(256) void rows_to_planes_kernel(const float *rows, int stride, int off, int c, f32x4 *planes,
+                                                              int c4, int npix)
+{
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= npix * c4) return;
+    const int cg = item / npix, p = item - cg * npix;
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (4 * cg + j < c) ? rows[(size_t)p * stride + off + 4 * cg + j] : 0.0f;
+    planes[(size_t)cg * npix + p] = v;
+}
+
+__global__ __launch_bounds__(256) void planes_to_rows_kernel(const f32x4 *planes, int c4, int npix, float *rows, int stride,
+                                                              int off)
+{
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= npix * c4) return;
+    const int cg = item / npix, p = item - cg * npix;
+    const f32x4 v = planes[(size_t)cg * npix + p];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rows[(size_t)p * stride + off + 4 * cg + j] = v[j];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -324,20 +376,18 @@ static int finish(const ConvBuilder &b, PackedConv &pc)
     pc.taps = b.taps;
     pc.dil = b.dil;
     pc.n_ot = round_up(round_up(b.c_out_phys, 16) / 16, kNT);
-    const int n16 = b.c_in_phys / 16, n4 = (b.c_in_phys % 16) / 4, ksteps = n16 * 4 + n4;
-    std::vector<float> wp((size_t)pc.n_ot * b.taps * ksteps * 64, 0.0f), bias((size_t)pc.n_ot * 16, 0.0f);
+    const int c4 = b.c_in_phys / 4, groups = b.taps * c4, nsteps = (groups + 3) / 4;
+    std::vector<float> wp((size_t)pc.n_ot * nsteps * 256, 0.0f), bias((size_t)pc.n_ot * 16, 0.0f);
     for (int ot = 0; ot < pc.n_ot; ++ot)
-        for (int t = 0; t < b.taps; ++t) {
-            float *blk = wp.data() + ((size_t)ot * b.taps + t) * ksteps * 64;
+        for (int S = 0; S < nsteps; ++S)
             for (int lane = 0; lane < 64; ++lane) {
-                const int oc = ot * 16 + (lane & 15), g = lane >> 4;
-                if (oc >= b.c_out_phys) continue;
-                const float *row = b.W.data() + ((size_t)oc * b.taps + t) * b.c_in_phys;
-                for (int c = 0; c < n16; ++c)
-                    for (int j = 0; j < 4; ++j) blk[(size_t)c * 256 + lane * 4 + j] = row[16 * c + 4 * g + j];
-                for (int s = 0; s < n4; ++s) blk[(size_t)n16 * 256 + s * 64 + lane] = row[16 * n16 + 4 * s + g];
+                const int oc = ot * 16 + (lane & 15), G = 4 * S + (lane >> 4);
+                if (oc >= b.c_out_phys || G >= groups) continue;
+                const int t = G / c4, cg = G % c4;
+                const float *row = b.W.data() + ((size_t)oc * b.taps + t) * b.c_in_phys + 4 * cg;
+                float *dst = wp.data() + (((size_t)ot * nsteps + S) * 64 + lane) * 4;
+                for (int j = 0; j < 4; ++j) dst[j] = row[j];
             }
-        }
     for (int o = 0; o < b.c_out_phys; ++o) bias[o] = b.B[o];
     if (upload(wp, &pc.wp)) return -2;
     if (upload(bias, &pc.bias)) return -2;
@@ -351,17 +401,23 @@ static void release(PackedConv &pc)
     pc.wp = pc.bias = nullptr;
 }
 
-static int launch_conv(const PackedConv &pc, const float *in, int in_stride, int in_off, float *out, int out_stride,
-                       int out_off, const float *bias, int act, int act_n, float scale, int h, int w, hipStream_t st,
-                       int c_store = -1)
+static inline f32x4 *planes(float *p) { return reinterpret_cast<f32x4 *>(p); }
+static inline const f32x4 *planes(const float *p) { return reinterpret_cast<const f32x4 *>(p); }
+
+// in / out: plane buffers; in_g0 / out_g0: first channel group of the window.
+// rows != NULL: the result goes to row-major scalars instead (last layer -> caller's est rows).
+static int launch_conv(const PackedConv &pc, const float *in, int in_g0, float *out, int out_g0, const float *bias,
+                       int act, int act_n, float scale, int h, int w, hipStream_t st, float *rows = nullptr,
+                       int rows_stride = 0, int rows_n = 0)
 {
     ConvArgs a;
-    a.in = in; a.out = out; a.wp = pc.wp; a.bias = bias ? bias : pc.bias;
-    a.in_stride = in_stride; a.in_off = in_off; a.out_stride = out_stride; a.out_off = out_off;
+    a.in = planes(in); a.out = planes(out); a.out_rows = rows;
+    a.wp = planes(pc.wp); a.bias = bias ? bias : pc.bias;
+    a.in_g0 = in_g0; a.out_g0 = out_g0; a.rows_stride = rows_stride; a.rows_n = rows_n;
     a.h = h; a.w = w; a.npix = h * w;
     a.taps = pc.taps; a.dil = pc.dil;
-    a.n16 = pc.c_in_phys / 16; a.n4 = (pc.c_in_phys % 16) / 4; a.ksteps = a.n16 * 4 + a.n4;
-    a.c_store = c_store >= 0 ? c_store : round_up(pc.c_out_phys, 4);
+    a.c4 = pc.c_in_phys / 4; a.nsteps = (pc.taps * a.c4 + 3) / 4;
+    a.og_store = round_up(pc.c_out_phys, 4) / 4;
     a.act = act; a.act_n = act_n; a.scale = scale;
     constexpr int MT = 2;
     const int strips = (a.npix + MT * 16 - 1) / (MT * 16);
@@ -394,8 +450,8 @@ struct ojf_net {
     std::vector<ojf::PackedConv> dense[2];  // block0 / block2 (or v2's block): 2*gf convs each
     ojf::Vortex vortex[3];                  // v3: vortex0, vortex2, vortex3 ; v2: vortex, -, vortex_final
     std::vector<ojf::PackedConv> pred;
-    // activation rows
-    float *X[2] = {nullptr, nullptr};  // dense-growth buffers, (gf+1)*cs channels
+    // activation planes (C4 layout), sizes in channels
+    float *X[2] = {nullptr, nullptr};  // dense-growth buffers, (gf+1)*cs
     float *T = nullptr;                // cs
     float *Z = nullptr;                // 4*cs
     float *Q1 = nullptr, *Q2 = nullptr, *Q3 = nullptr;  // pooled branch pre-activations: 3cs, 2cs, cs
@@ -409,7 +465,7 @@ struct ojf_net {
 
 namespace ojf {
 
-static int alloc_rows(float **p, size_t npix, int ch)
+static int alloc_planes(float **p, size_t npix, int ch)
 {
     OJF_HIP(hipMalloc(reinterpret_cast<void **>(p), npix * ch * sizeof(float)));
     OJF_HIP(hipMemset(*p, 0, npix * ch * sizeof(float)));
@@ -488,52 +544,51 @@ static void free_vortex(Vortex &v)
         if (p) (void)hipFree(p);
 }
 
-static int launch_pool(const float *in, int in_stride, int in_off, float *out, int out_stride, int out_off,
-                       const float *bias, int c4, int act_c4, int h, int w, hipStream_t st)
+static int launch_pool(const float *in, int in_g0, float *out, int out_g0, const float *bias, int c4, int act_c4, int h,
+                       int w, hipStream_t st)
 {
-    PoolArgs a{in, out, bias, in_stride, in_off, out_stride, out_off, h, w, c4, act_c4};
+    PoolArgs a{planes(in), planes(out), bias, in_g0, out_g0, h, w, c4, act_c4};
     const int items = h * w * c4;
     hipLaunchKernelGGL(avgpool3_kernel, dim3((items + 255) / 256), dim3(256), 0, st, a);
     return check_hip(hipGetLastError(), "avgpool3_kernel launch");
 }
 
-static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_stride, int in_off, float *out, int out_stride,
-                      int out_off, hipStream_t st)
+// in: planes, window starting at group in_g0 (c_in_phys/4 groups); out: planes at group out_g0
+static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float *out, int out_g0, hipStream_t st)
 {
-    const int h = net->h, w = net->w, cs = net->cs, os = net->os, c4 = cs / 4;
+    const int h = net->h, w = net->w, c4 = net->cs / 4, o4 = net->os / 4;
     // global-average branch -> bias of the final conv
-    hipLaunchKernelGGL(colsum_kernel, dim3(kSumBlocks), dim3(256), 0, st, in + in_off, in_stride, v.c_in_phys, net->npix,
+    hipLaunchKernelGGL(colsum_kernel, dim3(kSumBlocks, v.c_in_phys / 4), dim3(256), 0, st, planes(in), in_g0, net->npix,
                        net->partial);
     OJF_HIP(hipGetLastError());
     hipLaunchKernelGGL(gave_bias_kernel, dim3(1), dim3(256), 0, st, net->partial, v.c_in_phys, net->npix, v.Wg, v.bg,
                        v.Wfg, v.bf, net->pool_in, v.bias_final, v.fin.n_ot * 16);
     OJF_HIP(hipGetLastError());
     // branch entries: one GEMM, branch 0 gets bias + ReLU in the epilogue
-    if (launch_conv(v.stacked, in, in_stride, in_off, net->Z, 4 * cs, 0, nullptr, OJF_ACT_RELU, cs, 1.0f, h, w, st)) return -2;
-    // pool pyramid on the pre-activations of branches 1..3 (one launch per level; the first cs
-    // channels of each level are that level's branch input and get its bias + ReLU):
-    //   Q1 = pool(Z[cs:4cs]) ; Q2 = pool(Q1[cs:3cs]) ; Q3 = pool(Q2[cs:2cs])
-    if (launch_pool(net->Z, 4 * cs, cs, net->Q1, 3 * cs, 0, v.pool_bias[1], 3 * c4, c4, h, w, st)) return -2;
-    if (launch_pool(net->Q1, 3 * cs, cs, net->Q2, 2 * cs, 0, v.pool_bias[2], 2 * c4, c4, h, w, st)) return -2;
-    if (launch_pool(net->Q2, 2 * cs, cs, net->Q3, cs, 0, v.pool_bias[3], c4, c4, h, w, st)) return -2;
+    if (launch_conv(v.stacked, in, in_g0, net->Z, 0, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w, st)) return -2;
+    // pool pyramid on the pre-activations of branches 1..3 (one launch per level; the first c4
+    // groups of each level are that level's branch input and get its bias + ReLU):
+    //   Q1 = pool(Z[slots 1..3]) ; Q2 = pool(Q1[slots 1..2]) ; Q3 = pool(Q2[slot 1])
+    if (launch_pool(net->Z, c4, net->Q1, 0, v.pool_bias[1], 3 * c4, c4, h, w, st)) return -2;
+    if (launch_pool(net->Q1, c4, net->Q2, 0, v.pool_bias[2], 2 * c4, c4, h, w, st)) return -2;
+    if (launch_pool(net->Q2, c4, net->Q3, 0, v.pool_bias[3], c4, c4, h, w, st)) return -2;
     const float *bin[4] = {net->Z, net->Q1, net->Q2, net->Q3};
-    const int bstride[4] = {4 * cs, 3 * cs, 2 * cs, cs};
     for (int br = 0; br < 4; ++br) {
-        if (launch_conv(v.b3a[br], bin[br], bstride[br], 0, net->U, cs, 0, nullptr, OJF_ACT_RELU, cs, 1.0f, h, w, st)) return -2;
-        if (launch_conv(v.b3b[br], net->U, cs, 0, net->V, cs, 0, nullptr, OJF_ACT_RELU, cs, 1.0f, h, w, st)) return -2;
-        if (launch_conv(v.b1[br], net->V, cs, 0, net->CAT, 4 * os, br * os, nullptr, OJF_ACT_RELU, os, 1.0f, h, w, st)) return -2;
+        if (launch_conv(v.b3a[br], bin[br], 0, net->U, 0, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w, st)) return -2;
+        if (launch_conv(v.b3b[br], net->U, 0, net->V, 0, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w, st)) return -2;
+        if (launch_conv(v.b1[br], net->V, 0, net->CAT, br * o4, nullptr, OJF_ACT_RELU, net->os, 1.0f, h, w, st)) return -2;
     }
-    return launch_conv(v.fin, net->CAT, 4 * os, 0, out, out_stride, out_off, v.bias_final, OJF_ACT_NONE, 0, 1.0f, h, w, st);
+    return launch_conv(v.fin, net->CAT, 0, out, out_g0, v.bias_final, OJF_ACT_NONE, 0, 1.0f, h, w, st);
 }
 
 static int run_dense(ojf_net *net, int head, hipStream_t st)
 {
-    const int cs = net->cs, xs = (net->gf + 1) * cs;
+    const int c4 = net->cs / 4;
     for (int i = 0; i < net->gf; ++i) {
-        if (launch_conv(net->dense[head][2 * i], net->X[head], xs, 0, net->T, cs, 0, nullptr, OJF_ACT_LEAKY, cs, 1.0f,
+        if (launch_conv(net->dense[head][2 * i], net->X[head], 0, net->T, 0, nullptr, OJF_ACT_LEAKY, net->cs, 1.0f,
                         net->h, net->w, st)) return -2;
-        if (launch_conv(net->dense[head][2 * i + 1], net->T, cs, 0, net->X[head], xs, (i + 1) * cs, nullptr,
-                        OJF_ACT_LEAKY, cs, 1.0f, net->h, net->w, st)) return -2;
+        if (launch_conv(net->dense[head][2 * i + 1], net->T, 0, net->X[head], (i + 1) * c4, nullptr, OJF_ACT_LEAKY,
+                        net->cs, 1.0f, net->h, net->w, st)) return -2;
     }
     return 0;
 }
@@ -647,8 +702,7 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
             prev_phys = round_up(l.c_out, 4);
         }
     }
-    // subtract the gave convs (1x1 map) from the per-pixel MAC count
-    if (!rc) {
+    if (!rc) {  // the gave convs act on a 1x1 map: not a per-pixel cost
         int idx = 0;
         auto skip_dense = [&]() { idx += 2 * gf; };
         auto sub_gave = [&]() { net->macs_per_pixel -= (int64_t)L[idx].c_in * L[idx].c_out; idx += 18; };
@@ -657,21 +711,21 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
         sub_gave();
     }
     const size_t np = (size_t)net->npix;
-    if (!rc) rc = alloc_rows(&net->X[0], np, (gf + 1) * cs);
-    if (!rc && net->heads == 2) rc = alloc_rows(&net->X[1], np, (gf + 1) * cs);
-    if (!rc) rc = alloc_rows(&net->T, np, cs);
-    if (!rc) rc = alloc_rows(&net->Z, np, 4 * cs);
-    if (!rc) rc = alloc_rows(&net->Q1, np, 3 * cs);
-    if (!rc) rc = alloc_rows(&net->Q2, np, 2 * cs);
-    if (!rc) rc = alloc_rows(&net->Q3, np, cs);
-    if (!rc) rc = alloc_rows(&net->U, np, cs);
-    if (!rc) rc = alloc_rows(&net->V, np, cs);
-    if (!rc) rc = alloc_rows(&net->CAT, np, 4 * os);
-    if (!rc) rc = alloc_rows(&net->YY, np, net->heads * os);
-    if (!rc) rc = alloc_rows(&net->Y3, np, os);
-    if (!rc) rc = alloc_rows(&net->PA, np, os);
-    if (!rc) rc = alloc_rows(&net->PB, np, os);
-    if (!rc) rc = alloc_rows(&net->partial, kSumBlocks, 256);
+    if (!rc) rc = alloc_planes(&net->X[0], np, (gf + 1) * cs);
+    if (!rc && net->heads == 2) rc = alloc_planes(&net->X[1], np, (gf + 1) * cs);
+    if (!rc) rc = alloc_planes(&net->T, np, cs);
+    if (!rc) rc = alloc_planes(&net->Z, np, 4 * cs);
+    if (!rc) rc = alloc_planes(&net->Q1, np, 3 * cs);
+    if (!rc) rc = alloc_planes(&net->Q2, np, 2 * cs);
+    if (!rc) rc = alloc_planes(&net->Q3, np, cs);
+    if (!rc) rc = alloc_planes(&net->U, np, cs);
+    if (!rc) rc = alloc_planes(&net->V, np, cs);
+    if (!rc) rc = alloc_planes(&net->CAT, np, 4 * os);
+    if (!rc) rc = alloc_planes(&net->YY, np, net->heads * os);
+    if (!rc) rc = alloc_planes(&net->Y3, np, os);
+    if (!rc) rc = alloc_planes(&net->PA, np, os);
+    if (!rc) rc = alloc_planes(&net->PB, np, os);
+    if (!rc) rc = alloc_planes(&net->partial, kSumBlocks, 256);
     if (rc) {
         const std::string keep = ojf_last_error();
         ojf_net_destroy(net);
@@ -682,31 +736,20 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
     return 0;
 }
 
-OJF_API int ojf_net_input(ojf_net *net, int head, float **base, int *stride)
+OJF_API int ojf_net_prepare_input(ojf_net *net, const float *values, const float *weights, int rows_stride,
+                                  const float *depth, const uint8_t *sem_ids, int n_classes, ojf_stream_t stream)
 {
     using namespace ojf;
-    if (!net || !base || !stride) return fail("ojf_net_input: null pointer argument");
-    if (head < 0 || head >= net->heads) return fail("ojf_net_input: no such input head");
-    *base = net->X[head];
-    *stride = (net->gf + 1) * net->cs;
-    return 0;
-}
-
-OJF_API int ojf_net_prepare_input(ojf_net *net, const float *depth, const uint8_t *sem_ids, int n_classes,
-                                  ojf_stream_t stream)
-{
-    using namespace ojf;
-    if (!net || !depth) return fail("ojf_net_prepare_input: null pointer argument");
+    if (!net || !values || !weights || !depth) return fail("ojf_net_prepare_input: null pointer argument");
+    if (rows_stride < net->P) return fail("ojf_net_prepare_input: rows_stride < n_points");
     if (net->sem && (!sem_ids || n_classes <= 0))
         return fail("ojf_net_prepare_input: this net uses semantics: sem_ids and n_classes are required");
     PrepArgs a;
-    a.depth = depth;
+    a.values = values; a.weights = weights; a.depth = depth;
     a.sem = net->sem ? sem_ids : nullptr;
-    a.x0 = net->X[0];
-    a.x1 = net->X[1];
-    a.stride = (net->gf + 1) * net->cs;
-    a.npix = net->npix;
-    a.P = net->P;
+    a.x0 = planes(net->X[0]);
+    a.x1 = net->heads == 2 ? planes(net->X[1]) : nullptr;
+    a.rows_stride = rows_stride; a.npix = net->npix; a.P = net->P; a.cs4 = net->cs / 4;
     a.n_classes = n_classes;
     a.v2_sem = (net->version == 2 && net->sem) ? 1 : 0;
     hipLaunchKernelGGL(prepare_input_kernel, dim3((a.npix + 255) / 256), dim3(256), 0, as_stream(stream), a);
@@ -719,36 +762,34 @@ OJF_API int ojf_net_forward(ojf_net *net, float *est, int est_stride, ojf_stream
     if (!net || !est) return fail("ojf_net_forward: null pointer argument");
     if (est_stride < net->P) return fail("ojf_net_forward: est_stride < n_points");
     hipStream_t st = as_stream(stream);
-    const int os = net->os, xs = (net->gf + 1) * net->cs;
+    const int o4 = net->os / 4;
     if (run_dense(net, 0, st)) return -2;
-    const float *pin;
     if (net->version == 3) {
-        if (run_vortex(net, net->vortex[0], net->X[0], xs, 0, net->YY, net->heads * os, 0, st)) return -2;
+        if (run_vortex(net, net->vortex[0], net->X[0], 0, net->YY, 0, st)) return -2;
         if (net->heads == 2) {
             if (run_dense(net, 1, st)) return -2;
-            if (run_vortex(net, net->vortex[1], net->X[1], xs, 0, net->YY, net->heads * os, os, st)) return -2;
+            if (run_vortex(net, net->vortex[1], net->X[1], 0, net->YY, o4, st)) return -2;
         }
-        if (run_vortex(net, net->vortex[2], net->YY, net->heads * os, 0, net->Y3, os, 0, st)) return -2;
-        pin = net->Y3;
+        if (run_vortex(net, net->vortex[2], net->YY, 0, net->Y3, 0, st)) return -2;
     } else {
-        if (run_vortex(net, net->vortex[0], net->X[0], xs, 0, net->YY, os, 0, st)) return -2;
-        if (run_vortex(net, net->vortex[2], net->YY, os, 0, net->Y3, os, 0, st)) return -2;
-        pin = net->Y3;
+        if (run_vortex(net, net->vortex[0], net->X[0], 0, net->YY, 0, st)) return -2;
+        if (run_vortex(net, net->vortex[2], net->YY, 0, net->Y3, 0, st)) return -2;
     }
     // prediction head: 1x1 chain; BN-folded LeakyReLU stages, the last layer is Tanh * output_scale
+    const float *pin = net->Y3;
     const int np = (int)net->pred.size();
-    int in_stride = os;
     float *pp[2] = {net->PA, net->PB};
     for (int i = 0; i < np; ++i) {
         const PackedConv &pc = net->pred[i];
         const bool last = (i == np - 1);
-        float *dst = last ? est : pp[i & 1];
-        // the last layer stores exactly n_points channels into the caller's rows (stride >= n_points)
-        if (launch_conv(pc, pin, in_stride, 0, dst, last ? est_stride : os, 0, nullptr,
-                        last ? OJF_ACT_TANH : OJF_ACT_LEAKY, pc.n_ot * 16, last ? net->scale : 1.0f, net->h, net->w, st,
-                        last ? net->P : -1)) return -2;
-        pin = dst;
-        in_stride = os;
+        if (last) {  // exactly n_points channels into the caller's row-major est
+            if (launch_conv(pc, pin, 0, nullptr, 0, nullptr, OJF_ACT_TANH, pc.n_ot * 16, net->scale, net->h, net->w, st,
+                            est, est_stride, net->P)) return -2;
+        } else {
+            if (launch_conv(pc, pin, 0, pp[i & 1], 0, nullptr, OJF_ACT_LEAKY, pc.n_ot * 16, 1.0f, net->h, net->w, st))
+                return -2;
+            pin = pp[i & 1];
+        }
     }
     return 0;
 }
@@ -761,18 +802,30 @@ OJF_API int ojf_conv2d(const float *in, int in_stride, int in_off, float *out, i
     using namespace ojf;
     if (!in || !out || !layer || !layer->weight_host || !layer->bias_host) return fail("ojf_conv2d: null pointer argument");
     if ((layer->ksize != 1 && layer->ksize != 3) || layer->dilation < 1) return fail("ojf_conv2d: 1x1 or 3x3 kernels only");
-    if (in_stride % 4 || in_off % 4 || out_stride % 4 || out_off % 4)
-        return fail("ojf_conv2d: strides and offsets must be multiples of 4 floats");
     const int cin_phys = round_up(layer->c_in, 4), cout_phys = round_up(layer->c_out, 4);
-    if (in_off + cin_phys > in_stride || out_off + cout_phys > out_stride)
-        return fail("ojf_conv2d: channel window (padded to 4) exceeds the row stride");
+    if (in_off + layer->c_in > in_stride || out_off + cout_phys > out_stride)
+        return fail("ojf_conv2d: channel window exceeds the row stride");
+    hipStream_t st = as_stream(stream);
+    const int npix = h * w;
     ConvBuilder b(cin_phys, cout_phys, layer->ksize, layer->dilation);
     b.add(*layer, 0, layer->c_in, slot_map(layer->c_in, layer->c_in, cin_phys), 0, true);
     PackedConv pc;
     if (finish(b, pc)) return -2;
-    int rc = launch_conv(pc, in, in_stride, in_off, out, out_stride, out_off, nullptr, act, cout_phys, 1.0f, h, w,
-                         as_stream(stream));
-    if (!rc) rc = check_hip(hipStreamSynchronize(as_stream(stream)), "ojf_conv2d sync");  // test-only API: packs per call
+    float *pin = nullptr, *pout = nullptr;
+    int rc = alloc_planes(&pin, npix, cin_phys);
+    if (!rc) rc = alloc_planes(&pout, npix, cout_phys);
+    if (!rc) {
+        hipLaunchKernelGGL(rows_to_planes_kernel, dim3((npix * (cin_phys / 4) + 255) / 256), dim3(256), 0, st, in, in_stride,
+                           in_off, layer->c_in, planes(pin), cin_phys / 4, npix);
+        rc = launch_conv(pc, pin, 0, pout, 0, nullptr, act, cout_phys, 1.0f, h, w, st);
+    }
+    if (!rc) {
+        hipLaunchKernelGGL(planes_to_rows_kernel, dim3((npix * (cout_phys / 4) + 255) / 256), dim3(256), 0, st,
+                           planes(pout), cout_phys / 4, npix, out, out_stride, out_off);
+        rc = check_hip(hipStreamSynchronize(st), "ojf_conv2d sync");  // test-only API: packs per call
+    }
+    if (pin) (void)hipFree(pin);
+    if (pout) (void)hipFree(pout);
     release(pc);
     return rc;
 }

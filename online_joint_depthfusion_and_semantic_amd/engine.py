@@ -1,9 +1,10 @@
 """HIP executor of the fusion net (ojf_net_* in include/ojf.h) fed from a torch parameter container.
 
 ``FusionNetEngine`` folds the BatchNorms of a ``FusionNet_v2``/``FusionNet_v3`` module (running
-statistics, eval semantics), hands the folded layers to libojf, and exposes the device-side input
-rows so that ``ojf_extract`` writes its result directly where the first convolution reads it
-(no ``_prepare_fusion_input`` permute/copy: modules/pipeline.py:74-102).
+statistics, eval semantics) and hands the folded layers to libojf.  Per frame, ``prepare_input``
+packs the extractor's row-major outputs + depth (+ semantic frame) into the library's private
+activation layout (one small kernel instead of the reference's view/permute/contiguous chain,
+modules/pipeline.py:74-102) and ``forward`` runs the convolution chain.
 """
 import ctypes
 
@@ -25,14 +26,6 @@ def _layer_array(layers):
         arr[i].weight_host = w.ctypes.data
         arr[i].bias_host = b.ctypes.data
     return arr, keep
-
-
-class _DeviceRows:
-    """Exposes library-owned device memory to torch through the CUDA array interface."""
-
-    def __init__(self, ptr, shape):
-        self.__cuda_array_interface__ = {'shape': tuple(shape), 'typestr': '<f4', 'data': (int(ptr), False),
-                                         'version': 3, 'strides': None}
 
 
 class FusionNetEngine:
@@ -57,26 +50,22 @@ class FusionNetEngine:
                                          int(self.use_semantics), float(net.scale), arr, len(layers), h, w)
         _lib.check(rc, 'ojf_net_create')
         self.handle = handle
-        base, stride = ctypes.c_void_p(), ctypes.c_int()
-        _lib.check(self.lib.ojf_net_input(self.handle, 0, ctypes.byref(base), ctypes.byref(stride)), 'ojf_net_input')
-        self.in_ptr, self.in_stride = base.value, stride.value
         self.macs_per_pixel = int(self.lib.ojf_net_macs_per_pixel(self.handle))
         heads = 2 if (version == 3 and self.use_semantics) else 1
         n_vortex = heads + 1 if version == 3 else 2
         # conv_mfma_kernel launches per forward: dense blocks, 14 per VortexPooling, prediction head
         self.conv_launches = 2 * net.gf * heads + 14 * n_vortex + 2 * (net.gf - 1) + 3
 
-    def input_view(self, head=0):
-        """torch view [h*w, in_stride] of the net's input rows of ``head`` (memory owned by libojf)."""
-        base, stride = ctypes.c_void_p(), ctypes.c_int()
-        _lib.check(self.lib.ojf_net_input(self.handle, head, ctypes.byref(base), ctypes.byref(stride)), 'ojf_net_input')
-        return torch.as_tensor(_DeviceRows(base.value, (self.h * self.w, stride.value)), device=self.device)
-
-    def prepare_input(self, depth, sem_ids=None, n_classes=0):
+    def prepare_input(self, values, weights, depth, sem_ids=None, n_classes=0):
+        """values / weights: cuda f32 [h*w, stride] rows from the extractor; depth: cuda f32 [h,w]."""
+        assert values.is_cuda and values.dtype == torch.float32 and values.is_contiguous()
+        assert weights.is_cuda and weights.dtype == torch.float32 and weights.is_contiguous()
+        assert values.shape == weights.shape and values.shape[0] == self.h * self.w
         assert depth.is_cuda and depth.dtype == torch.float32 and depth.is_contiguous()
         if sem_ids is not None:
             assert sem_ids.is_cuda and sem_ids.dtype == torch.uint8 and sem_ids.is_contiguous()
-        rc = self.lib.ojf_net_prepare_input(self.handle, _lib.ptr(depth), _lib.ptr(sem_ids), int(n_classes),
+        rc = self.lib.ojf_net_prepare_input(self.handle, _lib.ptr(values), _lib.ptr(weights), values.shape[-1],
+                                            _lib.ptr(depth), _lib.ptr(sem_ids), int(n_classes),
                                             _lib.stream_ptr(self.device))
         _lib.check(rc, 'ojf_net_prepare_input')
 

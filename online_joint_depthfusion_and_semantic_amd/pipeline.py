@@ -4,7 +4,7 @@
 ``Database``; the work is done by three HIP stages on the current stream with no host round trip
 in between:
 
-    ojf_extract  -> writes fusion_values / fusion_weights straight into the net's input rows
+    ojf_extract  -> fusion_values / fusion_weights rows [N,9] (kept: they are part of the API)
     ojf_net_*    -> fp32-MFMA FusionNet (eval mode, BN folded)            [inference]
                     torch autograd on the same device                     [training, needs grads]
     ojf_integrate-> recomputes indices/weights, resolves colliding voxel writes, updates the
@@ -96,6 +96,8 @@ class Pipeline(torch.nn.Module):
             self._engine = FusionNetEngine(self._fusion_network, h, w, device)
             self._engine_key = key
             self._est = torch.empty((h * w, self.n_points), dtype=torch.float32, device=device)
+            self._fv = torch.empty((h * w, self.n_points), dtype=torch.float32, device=device)
+            self._fw = torch.empty((h * w, self.n_points), dtype=torch.float32, device=device)
         return self._engine
 
     def _get_workspace(self, shape, h, w, device):
@@ -161,10 +163,10 @@ class Pipeline(torch.nn.Module):
         P = self.n_points
         self._mark()
         ops.extract(frame, Ki, E, volume['origin'], volume['resolution'], tsdf, weights, n_points=P,
-                    out_values=eng.in_ptr, out_weights=eng.in_ptr + 4 * P, out_stride=eng.in_stride)
+                    out_values=self._fv, out_weights=self._fw, out_stride=P)
         self._mark()
         use_sem = self.config.FUSION_MODEL.use_semantics
-        eng.prepare_input(frame, sem_ids if use_sem else None, self.n_classes if use_sem else 0)
+        eng.prepare_input(self._fv, self._fw, frame, sem_ids if use_sem else None, self.n_classes if use_sem else 0)
         eng.forward(self._est)
         self._mark()
 

@@ -48,8 +48,7 @@ def test_conv2d_layer(cuda, cin, cout, k, dil, act, h, w):
            _lib.ACT_TANH: torch.tanh}[act](ref)
     cin_p, cout_p = (cin + 3) // 4 * 4, (cout + 3) // 4 * 4
     in_off, out_off = 4, 8  # embedded in wider rows, like the dense-growth buffers
-    xr = torch.full((h * w, cin_p + 8), 7.0)  # junk around the window must not leak in
-    xr[:, in_off:in_off + cin_p] = 0
+    xr = torch.full((h * w, cin + 9), 7.0)  # junk around the window must not leak in
     xr[:, in_off:in_off + cin] = x[0].permute(1, 2, 0).reshape(h * w, cin)
     xr = xr.to(cuda)
     out = torch.full((h * w, cout_p + 12), -3.0, device=cuda)
@@ -78,11 +77,9 @@ def test_fusion_net_forward(cuda, version, sem, h, w):
     with torch.no_grad():
         ref = net(x)[0].permute(1, 2, 0).reshape(h * w, 9)
     eng = FusionNetEngine(net, h, w, cuda)
-    rows = eng.input_view(0)
-    assert rows.shape == (h * w, eng.in_stride) and rows.data_ptr() == eng.in_ptr
-    rows[:, 0:9] = x['tsdf_values'][0].permute(1, 2, 0).reshape(h * w, 9).to(cuda)
-    rows[:, 9:18] = x['tsdf_weights'][0].permute(1, 2, 0).reshape(h * w, 9).to(cuda)
-    eng.prepare_input(x['tsdf_frame'].reshape(h, w).contiguous().to(cuda),
+    fv = x['tsdf_values'][0].permute(1, 2, 0).reshape(h * w, 9).contiguous().to(cuda)
+    fw = x['tsdf_weights'][0].permute(1, 2, 0).reshape(h * w, 9).contiguous().to(cuda)
+    eng.prepare_input(fv, fw, x['tsdf_frame'].reshape(h, w).contiguous().to(cuda),
                       x['sem_ids'].contiguous().to(cuda) if sem else None, 30)
     for stride in (9, 12):
         est = torch.full((h * w, stride), 5.0, device=cuda)
