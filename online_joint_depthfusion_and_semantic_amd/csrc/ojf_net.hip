@@ -31,6 +31,7 @@
 //     instead of in_chs (114/228);
 //   * the global-average branch is constant over the image: it is reduced to a per-frame bias of
 //     the final 1x1 convolution (two tiny kernels), removing its 114 input columns from that GEMM.
+#include <cstdlib>
 #include <vector>
 
 #include "ojf_common.h"
@@ -45,7 +46,7 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // kernels
 // ------------------------------------------------------------------------------------------------
 struct ConvArgs {
-    const f32x4 *in;   // input planes; channel group cg of this conv's window = plane in_g0 + cg
+    const f32x4 *in;   // input planes (in[-1] is a zero float4); group cg of the window = plane in_g0 + cg
     f32x4 *out;        // output planes (NULL when out_rows is used)
     float *out_rows;   // last layer only: row-major [npix, rows_stride] scalars, channels < rows_n
     const f32x4 *wp;   // packed weights [oc tile][superstep][lane] float4
@@ -60,34 +61,56 @@ struct ConvArgs {
     float scale;
 };
 
-__device__ __forceinline__ float activate(float v, int act)
+// ReLU / LeakyReLU / identity are one select with a slope (0, 0.01, 1); Tanh is a separate,
+// wave-uniform path (last layer only)
+__device__ __forceinline__ float act_slope(int act)
 {
-    switch (act) {
-        case OJF_ACT_RELU: return v > 0.0f ? v : 0.0f;
-        case OJF_ACT_LEAKY: return v > 0.0f ? v : 0.01f * v;
-        case OJF_ACT_TANH: return tanhf(v);
-        default: return v;
-    }
+    return act == OJF_ACT_RELU ? 0.0f : (act == OJF_ACT_LEAKY ? 0.01f : 1.0f);
 }
 
-template <int MT, int NT>
+constexpr int kMaxSteps = 128;  // supersteps per conv (K <= 2048)
+constexpr int kPadSteps = 4;    // dead supersteps appended for the three-stage prefetch (fetches reach S+4)
+
+// ABL is a profiling-only ablation mask (tests/microbench): 1 = no activation loads, 2 = no weight
+// loads, 4 = no MFMA, 8 = no per-superstep index math.  Product launches always use ABL = 0.
+template <int MT, int NT, int ABL = 0>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
 {
+    // Per-(superstep, lane group) source table, built once per block: float4 index of the tap's
+    // plane origin relative to a.in (-1 = the zero float4 every activation buffer keeps in front of
+    // its planes) and the tap's (dy, dx).  kPadSteps dead supersteps pad the end so that the
+    // three-stage prefetch needs no tail handling.
+    __shared__ int2 tab[(kMaxSteps + kPadSteps) * 4];
+    for (int G = threadIdx.x; G < (a.nsteps + kPadSteps) * 4; G += 256) {
+        const int t = G / a.c4, cg = G - t * a.c4;
+        int off = -1, dy = -30000, dx = 0;
+        if (t < a.taps) {
+            dy = dx = 0;
+            if (a.taps == 9) {
+                const int ky = t / 3;
+                dy = (ky - 1) * a.dil;
+                dx = (t - 3 * ky - 1) * a.dil;
+            }
+            off = (a.in_g0 + cg) * a.npix + dy * a.w + dx;
+        }
+        tab[G] = int2{off, (int)(((unsigned)dy << 16) | ((unsigned)dx & 0xffffu))};
+    }
+    __syncthreads();
+
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
     const int strip = (blockIdx.x * 4 + wave) * (MT * 16);
     if (strip >= a.npix) return;
-    const int ot0 = blockIdx.y * NT;
+    constexpr int ot0 = 0;  // a wave covers every output-channel tile
 
-    int py[MT], px[MT];
-    bool pv[MT];
+    int py[MT], px[MT], plin[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int p = strip + m * 16 + i16;
-        pv[m] = p < a.npix;
-        py[m] = p / a.w;
-        px[m] = p - py[m] * a.w;
+        plin[m] = p;
+        py[m] = p < a.npix ? p / a.w : -0x40000000;  // rows far outside the image for padding lanes
+        px[m] = p - (p / a.w) * a.w;
     }
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -95,40 +118,53 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const f32x4 *wb[NT];
+    const f32x4 *wb[NT];  // packed weights carry kPadSteps zero supersteps at the end as well
 #pragma unroll
-    for (int n = 0; n < NT; ++n) wb[n] = a.wp + (size_t)(ot0 + n) * a.nsteps * 64 + lane;
+    for (int n = 0; n < NT; ++n) wb[n] = a.wp + (size_t)(ot0 + n) * (a.nsteps + kPadSteps) * 64 + lane;
 
-    // this lane group's position in the flattened K list
-    int t = g / a.c4, cg = g - t * a.c4;
-
+    // Operand fetch of superstep S.  Nothing consumes the loaded values before the MFMAs (invalid
+    // taps select the INDEX of the zero float4 instead of masking data), so three stages stay in
+    // flight behind counted waits.
     auto fetch = [&](f32x4(&xv)[MT], f32x4(&wv)[NT], int S, bool &live) {
-        int dy = 0, dx = 0;
-        if (a.taps == 9) {
-            const int ky = (t * 11) >> 5;  // t / 3 for t < 12
-            dy = (ky - 1) * a.dil;
-            dx = (t - 3 * ky - 1) * a.dil;
-        }
-        const bool tap_ok = t < a.taps;
-        const f32x4 *plane = a.in + (size_t)(a.in_g0 + cg) * a.npix;
-        bool any_ok = false;
+        if constexpr (ABL & 8) {
+            live = true;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int sy = py[m] + dy, sx = px[m] + dx;
-            const bool ok = tap_ok && pv[m] && (unsigned)sy < (unsigned)a.h && (unsigned)sx < (unsigned)a.w;
-            xv[m] = ok ? plane[sy * a.w + sx] : f32x4{0.f, 0.f, 0.f, 0.f};
-            any_ok |= ok;
-        }
-        live = __any(any_ok);  // dead superstep: every source pixel of the wave is outside the image
+            for (int m = 0; m < MT; ++m) {
+                if constexpr (ABL & 1) xv[m] = f32x4{1.f, 2.f, 3.f, 4.f};
+                else xv[m] = a.in[plin[m]];
+            }
+        } else {
+            const int2 e = tab[S * 4 + g];
+            const int dy = e.y >> 16, dx = (int)(short)(e.y & 0xffff);
+            bool any_ok = false;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) wv[n] = wb[n][(size_t)S * 64];
-        cg += 4;  // advance to superstep S+1
-        while (cg >= a.c4) {
-            cg -= a.c4;
-            ++t;
+            for (int m = 0; m < MT; ++m) {
+                const bool ok = (unsigned)(py[m] + dy) < (unsigned)a.h && (unsigned)(px[m] + dx) < (unsigned)a.w;
+                const int idx = ok ? e.x + plin[m] : -1;
+                if constexpr (ABL & 1) {
+                    xv[m] = f32x4{1.f, 2.f, 3.f, 4.f};
+                    asm volatile("" ::"v"(idx));
+                } else {
+                    xv[m] = a.in[idx];
+                }
+                any_ok |= ok;
+            }
+            live = __any(any_ok);  // dead superstep: every source pixel of the wave is outside the image
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            if constexpr (ABL & 2) wv[n] = f32x4{1.f, 1.f, 1.f, 1.f};
+            else wv[n] = wb[n][(size_t)S * 64];
         }
     };
     auto mac = [&](const f32x4(&xv)[MT], const f32x4(&wv)[NT]) {
+        if constexpr (ABL & 4) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(xv[m][0]), "v"(xv[m][1]), "v"(xv[m][2]), "v"(xv[m][3]));
+#pragma unroll
+            for (int n = 0; n < NT; ++n) asm volatile("" ::"v"(wv[n][0]), "v"(wv[n][1]), "v"(wv[n][2]), "v"(wv[n][3]));
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -138,18 +174,23 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[n][j], xv[m][j], acc[m][n], 0, 0, 0);
     };
 
-    f32x4 x0[MT], w0[NT], x1[MT], w1[NT];
-    bool live0, live1 = false;
-    fetch(x0, w0, 0, live0);
-    for (int S = 0; S < a.nsteps; S += 2) {
-        if (S + 1 < a.nsteps) fetch(x1, w1, S + 1, live1);
-        if (live0) mac(x0, w0);
-        if (S + 1 >= a.nsteps) break;
-        if (S + 2 < a.nsteps) fetch(x0, w0, S + 2, live0);
-        if (live1) mac(x1, w1);
+    // three operand stages in flight: superstep S+2 is fetched while S computes
+    f32x4 x0[MT], w0[NT], x1[MT], w1[NT], x2[MT], w2[NT];
+    bool l0, l1, l2;
+    fetch(x0, w0, 0, l0);
+    fetch(x1, w1, 1, l1);
+    for (int S = 0; S < a.nsteps; S += 3) {
+        fetch(x2, w2, S + 2, l2);
+        if (l0) mac(x0, w0);
+        fetch(x0, w0, S + 3, l0);
+        if (l1) mac(x1, w1);
+        fetch(x1, w1, S + 4, l1);
+        if (l2) mac(x2, w2);
     }
 
     // C/D layout of 16x16x4: lane (i16, g) holds column i16 (pixel) and rows 4g..4g+3 (output channels)
+    const float slope = act_slope(a.act);
+    const bool use_tanh = a.act == OJF_ACT_TANH;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int og = (ot0 + n) * 4 + g;  // output channel group
@@ -157,13 +198,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int p = strip + m * 16 + i16;
-            if (p >= a.npix) continue;
             f32x4 v = acc[m][n] + b;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (og * 4 + j < a.act_n) v[j] = activate(v[j], a.act);
-                v[j] *= a.scale;
+                const float lin = v[j];
+                float r = lin > 0.0f ? lin : lin * slope;
+                if (use_tanh) r = tanhf(lin);
+                v[j] = (og * 4 + j < a.act_n ? r : lin) * a.scale;
             }
+            if (p >= a.npix) continue;
             if (a.out_rows) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -337,7 +380,7 @@ struct PackedConv {
     int c_in_phys = 0, c_out_phys = 0, taps = 1, dil = 1, n_ot = 0;
 };
 
-constexpr int kNT = 2;  // output-channel tiles per wave; packed weights are padded to a multiple
+constexpr int kNT = 2;  // packed weights are padded to a multiple of this many output-channel tiles
 
 struct ConvBuilder {
     int c_in_phys, c_out_phys, taps, dil;
@@ -377,7 +420,9 @@ static int finish(const ConvBuilder &b, PackedConv &pc)
     pc.dil = b.dil;
     pc.n_ot = round_up(round_up(b.c_out_phys, 16) / 16, kNT);
     const int c4 = b.c_in_phys / 4, groups = b.taps * c4, nsteps = (groups + 3) / 4;
-    std::vector<float> wp((size_t)pc.n_ot * nsteps * 256, 0.0f), bias((size_t)pc.n_ot * 16, 0.0f);
+    if (nsteps > kMaxSteps) return fail("conv packing: K too large for the tap table");
+    const int nsp = nsteps + kPadSteps;  // dead (all-zero) supersteps for the prefetch tail
+    std::vector<float> wp((size_t)pc.n_ot * nsp * 256, 0.0f), bias((size_t)pc.n_ot * 16, 0.0f);
     for (int ot = 0; ot < pc.n_ot; ++ot)
         for (int S = 0; S < nsteps; ++S)
             for (int lane = 0; lane < 64; ++lane) {
@@ -385,7 +430,7 @@ static int finish(const ConvBuilder &b, PackedConv &pc)
                 if (oc >= b.c_out_phys || G >= groups) continue;
                 const int t = G / c4, cg = G % c4;
                 const float *row = b.W.data() + ((size_t)oc * b.taps + t) * b.c_in_phys + 4 * cg;
-                float *dst = wp.data() + (((size_t)ot * nsteps + S) * 64 + lane) * 4;
+                float *dst = wp.data() + (((size_t)ot * nsp + S) * 64 + lane) * 4;
                 for (int j = 0; j < 4; ++j) dst[j] = row[j];
             }
     for (int o = 0; o < b.c_out_phys; ++o) bias[o] = b.B[o];
@@ -419,10 +464,33 @@ static int launch_conv(const PackedConv &pc, const float *in, int in_g0, float *
     a.c4 = pc.c_in_phys / 4; a.nsteps = (pc.taps * a.c4 + 3) / 4;
     a.og_store = round_up(pc.c_out_phys, 4) / 4;
     a.act = act; a.act_n = act_n; a.scale = scale;
-    constexpr int MT = 2;
-    const int strips = (a.npix + MT * 16 - 1) / (MT * 16);
-    dim3 grid((strips + 3) / 4, pc.n_ot / kNT);
-    hipLaunchKernelGGL((conv_mfma_kernel<MT, kNT>), grid, dim3(256), 0, st, a);
+    // one wave computes ALL output-channel tiles of its pixel strip (activations are fetched once);
+    // MT (16-pixel tiles per wave) trades operand reuse against the number of waves in flight
+    static const int mt_env = getenv("OJF_CONV_MT") ? atoi(getenv("OJF_CONV_MT")) : 0;
+    const int nt = pc.n_ot;
+    int mt = (nt <= 2) ? 2 : 1;
+    if (mt_env == 1 || mt_env == 2) mt = mt_env;
+    const int strips = (a.npix + mt * 16 - 1) / (mt * 16);
+    const dim3 grid((strips + 3) / 4, 1), block(256);
+#define OJF_LAUNCH(MT_, NT_) hipLaunchKernelGGL((conv_mfma_kernel<MT_, NT_>), grid, block, 0, st, a)
+    if (mt == 2) {
+        switch (nt) {
+            case 2: OJF_LAUNCH(2, 2); break;
+            case 4: OJF_LAUNCH(2, 4); break;
+            case 6: OJF_LAUNCH(2, 6); break;
+            case 8: OJF_LAUNCH(2, 8); break;
+            default: return fail("conv: unsupported number of output tiles");
+        }
+    } else {
+        switch (nt) {
+            case 2: OJF_LAUNCH(1, 2); break;
+            case 4: OJF_LAUNCH(1, 4); break;
+            case 6: OJF_LAUNCH(1, 6); break;
+            case 8: OJF_LAUNCH(1, 8); break;
+            default: return fail("conv: unsupported number of output tiles");
+        }
+    }
+#undef OJF_LAUNCH
     return check_hip(hipGetLastError(), "conv_mfma_kernel launch");
 }
 
@@ -465,11 +533,22 @@ struct ojf_net {
 
 namespace ojf {
 
+// every activation buffer keeps kPrefix floats of zeros in front of its planes: index -1 (in float4
+// units) is what out-of-image taps read
+constexpr size_t kPrefix = 64;  // keeps the planes 256-byte aligned
+
 static int alloc_planes(float **p, size_t npix, int ch)
 {
-    OJF_HIP(hipMalloc(reinterpret_cast<void **>(p), npix * ch * sizeof(float)));
-    OJF_HIP(hipMemset(*p, 0, npix * ch * sizeof(float)));
+    float *raw = nullptr;
+    OJF_HIP(hipMalloc(reinterpret_cast<void **>(&raw), (npix * ch + kPrefix) * sizeof(float)));
+    OJF_HIP(hipMemset(raw, 0, (npix * ch + kPrefix) * sizeof(float)));
+    *p = raw + kPrefix;
     return 0;
+}
+
+static void free_planes(float *p)
+{
+    if (p) (void)hipFree(p - kPrefix);
 }
 
 static int build_vortex(ojf_net *net, Vortex &v, const ojf_conv_layer *L, int c_in, const std::vector<int> &in_map,
@@ -619,8 +698,7 @@ OJF_API void ojf_net_destroy(ojf_net *net)
     for (auto &v : net->vortex) free_vortex(v);
     float *bufs[] = {net->X[0], net->X[1], net->T, net->Z, net->Q1, net->Q2, net->Q3, net->U, net->V,
                      net->CAT, net->YY, net->Y3, net->PA, net->PB, net->partial};
-    for (float *p : bufs)
-        if (p) (void)hipFree(p);
+    for (float *p : bufs) free_planes(p);
     delete net;
 }
 
@@ -824,8 +902,8 @@ OJF_API int ojf_conv2d(const float *in, int in_stride, int in_off, float *out, i
                            planes(pout), cout_phys / 4, npix, out, out_stride, out_off);
         rc = check_hip(hipStreamSynchronize(st), "ojf_conv2d sync");  // test-only API: packs per call
     }
-    if (pin) (void)hipFree(pin);
-    if (pout) (void)hipFree(pout);
+    free_planes(pin);
+    free_planes(pout);
     release(pc);
     return rc;
 }

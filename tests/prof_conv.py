@@ -1,0 +1,22 @@
+"""Profiling helper (not a test): times single conv layer shapes through ojf_net-like launches (via ojf_conv2d is
+host-sync heavy, so we time whole-net forwards and selected env ablations instead)."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from online_joint_depthfusion_and_semantic_amd.config import default_config
+from online_joint_depthfusion_and_semantic_amd.pipeline import Pipeline
+dev = torch.device('cuda:0')
+h, w = 240, 320
+pipe = Pipeline(default_config(h, w))
+torch.manual_seed(0)
+for m in pipe._fusion_network.modules():
+    if isinstance(m, torch.nn.Conv2d): torch.nn.init.xavier_normal_(m.weight)
+pipe = pipe.to(dev).eval()
+eng = pipe._get_engine(h, w, dev)
+fv = torch.rand(h * w, 9, device=dev) * 0.1; fw = torch.rand(h * w, 9, device=dev); d = torch.rand(h, w, device=dev) * 3
+est = torch.empty(h * w, 9, device=dev)
+eng.prepare_input(fv, fw, d)
+for i in range(5): eng.forward(est)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(30): eng.forward(est)
+torch.cuda.synchronize()
+print('ABLATE=%s MT=%s net forward %.1f us' % (os.environ.get('OJF_CONV_ABLATE'), os.environ.get('OJF_CONV_MT'), (time.perf_counter() - t0) / 30 * 1e6))
