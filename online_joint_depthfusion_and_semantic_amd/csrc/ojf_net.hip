@@ -218,6 +218,149 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused 1x1 chain (the prediction head, model.py:24-52,252-256): 11 pointwise layers in ONE launch.
+// With weights as the MFMA A operand, the accumulator of lane (pixel i, g) for output tile n holds
+// channels 16n+4g..+3 of its pixel - exactly the B-operand fragment (channel group 4S+g, S = n) the
+// next layer needs.  Activations therefore never leave registers between layers: each layer is
+//   nxt[n2] = sum_S sum_j mfma(W_l[n2][S][j], act(cur[S])[j]),
+// only the weights stream, and they are staged per layer (in <= 24 KB parts) through LDS so that the
+// four waves of a block share one fetch.  Tile counts are compile-time (two supported topologies:
+// 19- and 20-channel growth), so every register array is statically indexed.
+// ------------------------------------------------------------------------------------------------
+constexpr int kChainLdsFloat4 = 24 * 1024 / 16;
+
+struct ChainArgs {
+    const f32x4 *in;  // input planes, c4_in groups starting at in_g0
+    const f32x4 *w;   // per layer: [n2 < NTOUT][S < NTIN][lane] float4, layers back to back
+    const float *bias;  // per layer NTOUT*16 floats, back to back
+    float *out_rows;  // [npix, rows_stride], channels < rows_n
+    int in_g0, c4_in, npix, rows_stride, rows_n;
+    float scale;
+};
+
+constexpr int chain_parts(int ntin, int ntout) { return (ntin * ntout + 23) / 24; }  // <= 24 KB of weights per LDS part
+constexpr int chain_per(int ntin, int ntout) { return (ntout + chain_parts(ntin, ntout) - 1) / chain_parts(ntin, ntout); }
+constexpr int chain_first_size(int ntin, int ntout)
+{   // float4 count of a layer's first part
+    return (chain_per(ntin, ntout) < ntout ? chain_per(ntin, ntout) : ntout) * ntin * 64;
+}
+constexpr int kChainPre = 6;  // float4 registers per thread holding the prefetched next part (24 KB / 256 threads)
+
+// `pre` carries the weights of this layer's first part on entry (already fetched from HBM/L2 while
+// the previous part computed) and the next layer's first part on exit: global latency never sits
+// between two compute phases, only two barriers around the LDS refill do.
+template <int MT, int NTIN, int NTOUT, bool LAST, int NEXT_FIRST>
+__device__ __forceinline__ void chain_layer(f32x4 (&cur)[MT][8], f32x4 *wlds, const f32x4 *wg, const float *bias,
+                                            const ChainArgs &a, const int (&p)[MT], int lane, f32x4 (&pre)[kChainPre])
+{
+    constexpr int parts = chain_parts(NTIN, NTOUT);
+    constexpr int per = chain_per(NTIN, NTOUT);
+    f32x4 nxt[MT][NTOUT];
+#pragma unroll
+    for (int part = 0; part < parts; ++part) {
+        const int nb = part * per;
+        const int ne = nb + per < NTOUT ? nb + per : NTOUT;
+        const int size = (ne - nb) * NTIN * 64;
+        __syncthreads();  // readers of the previous part are done
+#pragma unroll
+        for (int k = 0; k < kChainPre; ++k)
+            if ((int)threadIdx.x + 256 * k < size) wlds[threadIdx.x + 256 * k] = pre[k];
+        __syncthreads();
+        // issue the fetch of the following part (next part of this layer, or the next layer's first)
+        const int nnb = ne;
+        const int nne = nnb + per < NTOUT ? nnb + per : NTOUT;
+        const int nsize = part + 1 < parts ? (nne - nnb) * NTIN * 64 : NEXT_FIRST;
+        const f32x4 *nsrc = part + 1 < parts ? wg + (size_t)nnb * NTIN * 64 : wg + (size_t)NTIN * NTOUT * 64;
+#pragma unroll
+        for (int k = 0; k < kChainPre; ++k)
+            if ((int)threadIdx.x + 256 * k < nsize) pre[k] = nsrc[threadIdx.x + 256 * k];
+#pragma unroll
+        for (int n2 = 0; n2 < NTOUT; ++n2) {
+            if (n2 < nb || n2 >= ne) continue;
+            f32x4 acc[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int S = 0; S < NTIN; ++S) {
+                const f32x4 wv = wlds[((n2 - nb) * NTIN + S) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], cur[m][S][j], acc[m], 0, 0, 0);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) nxt[m][n2] = acc[m];
+        }
+    }
+    const int g = lane >> 4;
+#pragma unroll
+    for (int n2 = 0; n2 < NTOUT; ++n2) {
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + n2 * 16 + 4 * g);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            f32x4 v = nxt[m][n2] + b;
+            if constexpr (LAST) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int oc = n2 * 16 + 4 * g + j;
+                    if (oc < a.rows_n && p[m] < a.npix) a.out_rows[(size_t)p[m] * a.rows_stride + oc] = tanhf(v[j]) * a.scale;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.0f ? v[j] : 0.01f * v[j];  // LeakyReLU
+                cur[m][n2] = v;
+            }
+        }
+    }
+}
+
+template <int MT, int NTIN, int NTOUT>
+__device__ __forceinline__ void chain_run(f32x4 (&cur)[MT][8], f32x4 *wlds, const f32x4 *wg, const float *bias,
+                                          const ChainArgs &a, const int (&p)[MT], int lane, f32x4 (&pre)[kChainPre])
+{
+    chain_layer<MT, NTIN, NTOUT, true, 0>(cur, wlds, wg, bias, a, p, lane, pre);
+}
+
+template <int MT, int NTIN, int NTOUT, int NTNEXT, int... REST>
+__device__ __forceinline__ void chain_run(f32x4 (&cur)[MT][8], f32x4 *wlds, const f32x4 *wg, const float *bias,
+                                          const ChainArgs &a, const int (&p)[MT], int lane, f32x4 (&pre)[kChainPre])
+{
+    chain_layer<MT, NTIN, NTOUT, false, chain_first_size(NTOUT, NTNEXT)>(cur, wlds, wg, bias, a, p, lane, pre);
+    chain_run<MT, NTOUT, NTNEXT, REST...>(cur, wlds, wg + (size_t)NTIN * NTOUT * 64, bias + NTOUT * 16, a, p, lane, pre);
+}
+
+template <int MT, int NT0, int... NTS>
+__global__ __launch_bounds__(256) void chain1x1_kernel(const ChainArgs a)
+{
+    __shared__ f32x4 wlds[kChainLdsFloat4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int strip = (blockIdx.x * 4 + wave) * (MT * 16);
+    int p[MT];
+    f32x4 cur[MT][8];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        p[m] = strip + m * 16 + i16;  // waves past the image still take part in the barriers
+#pragma unroll
+        for (int S = 0; S < NT0; ++S) {
+            const int G = 4 * S + g;
+            const bool ok = p[m] < a.npix && G < a.c4_in;
+            cur[m][S] = a.in[ok ? (a.in_g0 + G) * a.npix + p[m] : -1];
+        }
+    }
+    f32x4 pre[kChainPre];
+    {   // first part of the first layer
+        constexpr int first[] = {NTS...};
+        constexpr int size0 = chain_first_size(NT0, first[0]);
+#pragma unroll
+        for (int k = 0; k < kChainPre; ++k)
+            if ((int)threadIdx.x + 256 * k < size0) pre[k] = a.w[threadIdx.x + 256 * k];
+    }
+    chain_run<MT, NT0, NTS...>(cur, wlds, a.w, a.bias, a, p, lane, pre);
+}
+
 struct PoolArgs {
     const f32x4 *in;
     f32x4 *out;
@@ -518,6 +661,8 @@ struct ojf_net {
     std::vector<ojf::PackedConv> dense[2];  // block0 / block2 (or v2's block): 2*gf convs each
     ojf::Vortex vortex[3];                  // v3: vortex0, vortex2, vortex3 ; v2: vortex, -, vortex_final
     std::vector<ojf::PackedConv> pred;
+    float *chain_w = nullptr, *chain_b = nullptr;  // fused prediction head (when the topology is supported)
+    int chain_kind = 0;                             // 0 = unfused, 19 / 20 = growth channels of the fused kernel
     // activation planes (C4 layout), sizes in channels
     float *X[2] = {nullptr, nullptr};  // dense-growth buffers, (gf+1)*cs
     float *T = nullptr;                // cs
@@ -699,6 +844,8 @@ OJF_API void ojf_net_destroy(ojf_net *net)
     float *bufs[] = {net->X[0], net->X[1], net->T, net->Z, net->Q1, net->Q2, net->Q3, net->U, net->V,
                      net->CAT, net->YY, net->Y3, net->PA, net->PB, net->partial};
     for (float *p : bufs) free_planes(p);
+    if (net->chain_w) (void)hipFree(net->chain_w);
+    if (net->chain_b) (void)hipFree(net->chain_b);
     delete net;
 }
 
@@ -780,6 +927,32 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
             prev_phys = round_up(l.c_out, 4);
         }
     }
+    if (!rc && n_points == 9 && growth == 5 && (c == 19 || c == 20)) {
+        // fused prediction head: repack the 11 pointwise layers as [n2][S][lane] float4 per layer
+        const int first = n_layers - (2 * (gf - 1) + 3);
+        std::vector<float> cw, cb;
+        int prev_phys = os;
+        for (int l = first; l < n_layers; ++l) {
+            const ojf_conv_layer &ly = L[l];
+            const int nt_in = (prev_phys + 15) / 16, out_phys = round_up(ly.c_out, 4), nt_out = (out_phys + 15) / 16;
+            const size_t base = cw.size();
+            cw.resize(base + (size_t)nt_out * nt_in * 256, 0.0f);
+            for (int n2 = 0; n2 < nt_out; ++n2)
+                for (int S = 0; S < nt_in; ++S)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 4; ++j) {
+                            const int oc = n2 * 16 + (lane & 15), k = 16 * S + 4 * (lane >> 4) + j;
+                            if (oc < ly.c_out && k < ly.c_in)
+                                cw[base + (((size_t)n2 * nt_in + S) * 64 + lane) * 4 + j] = ly.weight_host[(size_t)oc * ly.c_in + k];
+                        }
+            const size_t bb = cb.size();
+            cb.resize(bb + (size_t)nt_out * 16, 0.0f);
+            for (int o = 0; o < ly.c_out; ++o) cb[bb + o] = ly.bias_host[o];
+            prev_phys = out_phys;
+        }
+        if (upload(cw, &net->chain_w) || upload(cb, &net->chain_b)) rc = -2;
+        else net->chain_kind = c;
+    }
     if (!rc) {  // the gave convs act on a 1x1 map: not a per-pixel cost
         int idx = 0;
         auto skip_dense = [&]() { idx += 2 * gf; };
@@ -854,6 +1027,21 @@ OJF_API int ojf_net_forward(ojf_net *net, float *est, int est_stride, ojf_stream
         if (run_vortex(net, net->vortex[2], net->YY, 0, net->Y3, 0, st)) return -2;
     }
     // prediction head: 1x1 chain; BN-folded LeakyReLU stages, the last layer is Tanh * output_scale
+    static const bool unfused = getenv("OJF_NO_CHAIN") != nullptr;  // ablation switch only
+    if (net->chain_kind && !unfused) {
+        ChainArgs ca;
+        ca.in = planes(net->Y3); ca.w = planes(net->chain_w); ca.bias = net->chain_b;
+        ca.out_rows = est; ca.in_g0 = 0; ca.c4_in = o4; ca.npix = net->npix;
+        ca.rows_stride = est_stride; ca.rows_n = net->P; ca.scale = net->scale;
+        constexpr int MT = 2;
+        const int strips = (net->npix + MT * 16 - 1) / (MT * 16);
+        const dim3 grid((strips + 3) / 4), block(256);
+        if (net->chain_kind == 19)
+            hipLaunchKernelGGL((chain1x1_kernel<MT, 8, 6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1>), grid, block, 0, st, ca);
+        else
+            hipLaunchKernelGGL((chain1x1_kernel<MT, 8, 7, 7, 5, 5, 4, 4, 3, 3, 2, 2, 1>), grid, block, 0, st, ca);
+        return check_hip(hipGetLastError(), "chain1x1_kernel launch");
+    }
     const float *pin = net->Y3;
     const int np = (int)net->pred.size();
     float *pp[2] = {net->PA, net->PB};
