@@ -250,9 +250,12 @@ constexpr int kChainPre = 6;  // float4 registers per thread holding the prefetc
 // `pre` carries the weights of this layer's first part on entry (already fetched from HBM/L2 while
 // the previous part computed) and the next layer's first part on exit: global latency never sits
 // between two compute phases, only two barriers around the LDS refill do.
-template <int MT, int NTIN, int NTOUT, bool LAST, int NEXT_FIRST>
+enum { kChainLeaky = 0, kChainRelu = 1, kChainAccumulate = 2, kChainLastRows = 3 };
+
+template <int MT, int NTIN, int NTOUT, int MODE, int NEXT_FIRST>
 __device__ __forceinline__ void chain_layer(f32x4 (&cur)[MT][8], f32x4 *wlds, const f32x4 *wg, const float *bias,
-                                            const ChainArgs &a, const int (&p)[MT], int lane, f32x4 (&pre)[kChainPre])
+                                            const ChainArgs &a, const int (&p)[MT], int lane, f32x4 (&pre)[kChainPre],
+                                            f32x4 (*out)[8] = nullptr, const f32x4 *next_src = nullptr)
 {
     constexpr int parts = chain_parts(NTIN, NTOUT);
     constexpr int per = chain_per(NTIN, NTOUT);
@@ -271,46 +274,54 @@ __device__ __forceinline__ void chain_layer(f32x4 (&cur)[MT][8], f32x4 *wlds, co
         const int nnb = ne;
         const int nne = nnb + per < NTOUT ? nnb + per : NTOUT;
         const int nsize = part + 1 < parts ? (nne - nnb) * NTIN * 64 : NEXT_FIRST;
-        const f32x4 *nsrc = part + 1 < parts ? wg + (size_t)nnb * NTIN * 64 : wg + (size_t)NTIN * NTOUT * 64;
+        const f32x4 *nsrc = part + 1 < parts ? wg + (size_t)nnb * NTIN * 64
+                                             : (next_src ? next_src : wg + (size_t)NTIN * NTOUT * 64);
 #pragma unroll
         for (int k = 0; k < kChainPre; ++k)
             if ((int)threadIdx.x + 256 * k < nsize) pre[k] = nsrc[threadIdx.x + 256 * k];
 #pragma unroll
-        for (int n2 = 0; n2 < NTOUT; ++n2) {
-            if (n2 < nb || n2 >= ne) continue;
-            f32x4 acc[MT];
+        for (int n2 = 0; n2 < NTOUT; ++n2)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int m = 0; m < MT; ++m)
+                if (n2 >= nb && n2 < ne) nxt[m][n2] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // S outer, output tiles inner: (ne - nb) * MT independent accumulators per MFMA round
 #pragma unroll
-            for (int S = 0; S < NTIN; ++S) {
+        for (int S = 0; S < NTIN; ++S)
+#pragma unroll
+            for (int n2 = 0; n2 < NTOUT; ++n2) {
+                if (n2 < nb || n2 >= ne) continue;
                 const f32x4 wv = wlds[((n2 - nb) * NTIN + S) * 64 + lane];
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
-                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], cur[m][S][j], acc[m], 0, 0, 0);
+                        nxt[m][n2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], cur[m][S][j], nxt[m][n2], 0, 0, 0);
             }
-#pragma unroll
-            for (int m = 0; m < MT; ++m) nxt[m][n2] = acc[m];
-        }
     }
     const int g = lane >> 4;
 #pragma unroll
     for (int n2 = 0; n2 < NTOUT; ++n2) {
-        const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + n2 * 16 + 4 * g);
+        if constexpr (MODE == kChainAccumulate) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            f32x4 v = nxt[m][n2] + b;
-            if constexpr (LAST) {
+            for (int m = 0; m < MT; ++m) out[m][n2] += nxt[m][n2];
+        } else {
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + n2 * 16 + 4 * g);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int oc = n2 * 16 + 4 * g + j;
-                    if (oc < a.rows_n && p[m] < a.npix) a.out_rows[(size_t)p[m] * a.rows_stride + oc] = tanhf(v[j]) * a.scale;
+            for (int m = 0; m < MT; ++m) {
+                f32x4 v = nxt[m][n2] + b;
+                if constexpr (MODE == kChainLastRows) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int oc = n2 * 16 + 4 * g + j;
+                        if (oc < a.rows_n && p[m] < a.npix)
+                            a.out_rows[(size_t)p[m] * a.rows_stride + oc] = tanhf(v[j]) * a.scale;
+                    }
+                } else {
+                    constexpr float slope = MODE == kChainRelu ? 0.0f : 0.01f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.0f ? v[j] : slope * v[j];
+                    cur[m][n2] = v;
                 }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.0f ? v[j] : 0.01f * v[j];  // LeakyReLU
-                cur[m][n2] = v;
             }
         }
     }
@@ -320,14 +331,14 @@ template <int MT, int NTIN, int NTOUT>
 __device__ __forceinline__ void chain_run(f32x4 (&cur)[MT][8], f32x4 *wlds, const f32x4 *wg, const float *bias,
                                           const ChainArgs &a, const int (&p)[MT], int lane, f32x4 (&pre)[kChainPre])
 {
-    chain_layer<MT, NTIN, NTOUT, true, 0>(cur, wlds, wg, bias, a, p, lane, pre);
+    chain_layer<MT, NTIN, NTOUT, kChainLastRows, 0>(cur, wlds, wg, bias, a, p, lane, pre);
 }
 
 template <int MT, int NTIN, int NTOUT, int NTNEXT, int... REST>
 __device__ __forceinline__ void chain_run(f32x4 (&cur)[MT][8], f32x4 *wlds, const f32x4 *wg, const float *bias,
                                           const ChainArgs &a, const int (&p)[MT], int lane, f32x4 (&pre)[kChainPre])
 {
-    chain_layer<MT, NTIN, NTOUT, false, chain_first_size(NTOUT, NTNEXT)>(cur, wlds, wg, bias, a, p, lane, pre);
+    chain_layer<MT, NTIN, NTOUT, kChainLeaky, chain_first_size(NTOUT, NTNEXT)>(cur, wlds, wg, bias, a, p, lane, pre);
     chain_run<MT, NTOUT, NTNEXT, REST...>(cur, wlds, wg + (size_t)NTIN * NTOUT * 64, bias + NTOUT * 16, a, p, lane, pre);
 }
 
@@ -359,6 +370,76 @@ __global__ __launch_bounds__(256) void chain1x1_kernel(const ChainArgs a)
             if ((int)threadIdx.x + 256 * k < size0) pre[k] = a.w[threadIdx.x + 256 * k];
     }
     chain_run<MT, NT0, NTS...>(cur, wlds, a.w, a.bias, a, p, lane, pre);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused VortexPooling tail (model.py:131-141,157-159): for each of the four branches
+//   t_b = ReLU(W1_b v_b + b1_b)   (mid -> out channels, the branch's closing 1x1 + BN + ReLU)
+//   y  += Wf_b t_b                (that branch's column block of the final 1x1 over the concat)
+// followed by y + bias' (final conv bias + BN + the folded global-average branch).  The 4 x 116-channel
+// concat tensor of the reference never exists: t_b lives in registers between the two GEMMs (same
+// accumulator -> operand identity as the prediction-head chain) and y accumulates across branches.
+// ------------------------------------------------------------------------------------------------
+struct TailArgs {
+    const f32x4 *v[4];  // branch inputs (planes, c4 groups each)
+    const f32x4 *w;     // stream: W1_0 [NO][NV][64], Wf_0 [NO][NO][64], W1_1, Wf_1, ...
+    const float *b1;    // 4 x NO*16
+    const float *bias_final;  // NO*16 (per-frame: includes the global-average branch)
+    f32x4 *out;
+    int c4, out_g0, og_store, npix;
+};
+
+template <int MT, int NV, int NO>
+__global__ __launch_bounds__(256) void vortex_tail_kernel(const TailArgs a)
+{
+    __shared__ f32x4 wlds[kChainLdsFloat4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int strip = (blockIdx.x * 4 + wave) * (MT * 16);
+    int p[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) p[m] = strip + m * 16 + i16;
+    ChainArgs ca;  // only npix is read by the layer code in these modes
+    ca.npix = a.npix; ca.out_rows = nullptr; ca.rows_n = 0; ca.rows_stride = 0; ca.scale = 1.0f;
+    f32x4 y[MT][8];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NO; ++n) y[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 pre[kChainPre];
+    {
+        constexpr int size0 = chain_first_size(NV, NO);
+#pragma unroll
+        for (int k = 0; k < kChainPre; ++k)
+            if ((int)threadIdx.x + 256 * k < size0) pre[k] = a.w[threadIdx.x + 256 * k];
+    }
+    constexpr size_t per_branch = (size_t)(NV * NO + NO * NO) * 64;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        f32x4 cur[MT][8];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int S = 0; S < NV; ++S) {
+                const int G = 4 * S + g;
+                const bool ok = p[m] < a.npix && G < a.c4;
+                cur[m][S] = a.v[b][ok ? G * a.npix + p[m] : -1];
+            }
+        const f32x4 *w1 = a.w + b * per_branch, *wf = w1 + (size_t)NV * NO * 64;
+        chain_layer<MT, NV, NO, kChainRelu, chain_first_size(NO, NO)>(cur, wlds, w1, a.b1 + b * NO * 16, ca, p, lane, pre);
+        if (b < 3)
+            chain_layer<MT, NO, NO, kChainAccumulate, chain_first_size(NV, NO)>(cur, wlds, wf, nullptr, ca, p, lane, pre, y);
+        else
+            chain_layer<MT, NO, NO, kChainAccumulate, 0>(cur, wlds, wf, nullptr, ca, p, lane, pre, y);
+    }
+#pragma unroll
+    for (int n = 0; n < NO; ++n) {
+        const int og = n * 4 + g;
+        const f32x4 bf = *reinterpret_cast<const f32x4 *>(a.bias_final + n * 16 + 4 * g);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            if (p[m] < a.npix && og < a.og_store) a.out[(size_t)(a.out_g0 + og) * a.npix + p[m]] = y[m][n] + bf;
+    }
 }
 
 struct PoolArgs {
@@ -649,6 +730,7 @@ struct Vortex {
     PackedConv stacked, b3a[4], b3b[4], b1[4], fin;
     float *pool_bias[4] = {nullptr, nullptr, nullptr, nullptr};
     float *Wg = nullptr, *bg = nullptr, *Wfg = nullptr, *bf = nullptr, *bias_final = nullptr;
+    float *tail_w = nullptr, *tail_b1 = nullptr;  // fused tail (closing 1x1s + final conv), when supported
 };
 
 }  // namespace ojf
@@ -668,7 +750,8 @@ struct ojf_net {
     float *T = nullptr;                // cs
     float *Z = nullptr;                // 4*cs
     float *Q1 = nullptr, *Q2 = nullptr, *Q3 = nullptr;  // pooled branch pre-activations: 3cs, 2cs, cs
-    float *U = nullptr, *V = nullptr;                    // cs
+    float *U = nullptr;                                  // cs
+    float *V = nullptr;                                  // 4*cs: closing-3x3 outputs of the four branches
     float *CAT = nullptr;              // 4*os
     float *YY = nullptr;               // heads*os (vortex0 | vortex2 outputs)
     float *Y3 = nullptr;               // os
@@ -750,6 +833,33 @@ static int build_vortex(ojf_net *net, Vortex &v, const ojf_conv_layer *L, int c_
         std::vector<float> zero((size_t)v.fin.n_ot * 16, 0.0f);
         if (upload(zero, &v.bias_final)) return -2;
     }
+    if ((cs + 15) / 16 == 2 && (os + 15) / 16 == 8) {  // fused tail: [W1_b | Wf_b] per branch, [n2][S][lane] float4
+        const int NV = 2, NO = 8;
+        std::vector<float> tw((size_t)4 * (NV * NO + NO * NO) * 256, 0.0f), tb((size_t)4 * NO * 16, 0.0f);
+        const ojf_conv_layer &lf = L[17];
+        for (int br = 0; br < 4; ++br) {
+            const ojf_conv_layer &l1 = L[4 + 4 * br];
+            float *w1 = tw.data() + (size_t)br * (NV * NO + NO * NO) * 256, *wf = w1 + (size_t)NV * NO * 256;
+            for (int n2 = 0; n2 < NO; ++n2)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int oc = n2 * 16 + (lane & 15);
+                    if (oc >= out) continue;
+                    for (int j = 0; j < 4; ++j) {
+                        for (int S = 0; S < NV; ++S) {
+                            const int k = 16 * S + 4 * (lane >> 4) + j;
+                            if (k < c) w1[(((size_t)n2 * NV + S) * 64 + lane) * 4 + j] = l1.weight_host[(size_t)oc * c + k];
+                        }
+                        for (int S = 0; S < NO; ++S) {
+                            const int k = 16 * S + 4 * (lane >> 4) + j;
+                            if (k < out)
+                                wf[(((size_t)n2 * NO + S) * 64 + lane) * 4 + j] = lf.weight_host[(size_t)oc * 5 * out + out * (br + 1) + k];
+                        }
+                    }
+                }
+            for (int o = 0; o < out; ++o) tb[(size_t)br * NO * 16 + o] = l1.bias_host[o];
+        }
+        if (upload(tw, &v.tail_w) || upload(tb, &v.tail_b1)) return -2;
+    }
     return 0;
 }
 
@@ -763,7 +873,7 @@ static void free_vortex(Vortex &v)
         release(v.b1[b]);
         if (v.pool_bias[b]) (void)hipFree(v.pool_bias[b]);
     }
-    float *ptrs[] = {v.Wg, v.bg, v.Wfg, v.bf, v.bias_final};
+    float *ptrs[] = {v.Wg, v.bg, v.Wfg, v.bf, v.bias_final, v.tail_w, v.tail_b1};
     for (float *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -797,12 +907,23 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
     if (launch_pool(net->Q1, c4, net->Q2, 0, v.pool_bias[2], 2 * c4, c4, h, w, st)) return -2;
     if (launch_pool(net->Q2, c4, net->Q3, 0, v.pool_bias[3], c4, c4, h, w, st)) return -2;
     const float *bin[4] = {net->Z, net->Q1, net->Q2, net->Q3};
+    static const bool unfused = getenv("OJF_NO_TAIL") != nullptr;  // ablation switch only
+    const bool fused = v.tail_w && !unfused;
     for (int br = 0; br < 4; ++br) {
         if (launch_conv(v.b3a[br], bin[br], 0, net->U, 0, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w, st)) return -2;
-        if (launch_conv(v.b3b[br], net->U, 0, net->V, 0, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w, st)) return -2;
-        if (launch_conv(v.b1[br], net->V, 0, net->CAT, br * o4, nullptr, OJF_ACT_RELU, net->os, 1.0f, h, w, st)) return -2;
+        if (launch_conv(v.b3b[br], net->U, 0, net->V, br * c4, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w, st)) return -2;
+        if (!fused && launch_conv(v.b1[br], net->V, br * c4, net->CAT, br * o4, nullptr, OJF_ACT_RELU, net->os, 1.0f, h, w, st))
+            return -2;
     }
-    return launch_conv(v.fin, net->CAT, 0, out, out_g0, v.bias_final, OJF_ACT_NONE, 0, 1.0f, h, w, st);
+    if (!fused) return launch_conv(v.fin, net->CAT, 0, out, out_g0, v.bias_final, OJF_ACT_NONE, 0, 1.0f, h, w, st);
+    TailArgs ta;
+    for (int br = 0; br < 4; ++br) ta.v[br] = planes(net->V) + (size_t)br * c4 * net->npix;
+    ta.w = planes(v.tail_w); ta.b1 = v.tail_b1; ta.bias_final = v.bias_final;
+    ta.out = planes(out); ta.c4 = c4; ta.out_g0 = out_g0; ta.og_store = o4; ta.npix = net->npix;
+    constexpr int MT = 1;
+    const int strips = (net->npix + MT * 16 - 1) / (MT * 16);
+    hipLaunchKernelGGL((vortex_tail_kernel<MT, 2, 8>), dim3((strips + 3) / 4), dim3(256), 0, st, ta);
+    return check_hip(hipGetLastError(), "vortex_tail_kernel launch");
 }
 
 static int run_dense(ojf_net *net, int head, hipStream_t st)
@@ -970,7 +1091,7 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
     if (!rc) rc = alloc_planes(&net->Q2, np, 2 * cs);
     if (!rc) rc = alloc_planes(&net->Q3, np, cs);
     if (!rc) rc = alloc_planes(&net->U, np, cs);
-    if (!rc) rc = alloc_planes(&net->V, np, cs);
+    if (!rc) rc = alloc_planes(&net->V, np, 4 * cs);
     if (!rc) rc = alloc_planes(&net->CAT, np, 4 * os);
     if (!rc) rc = alloc_planes(&net->YY, np, net->heads * os);
     if (!rc) rc = alloc_planes(&net->Y3, np, os);
