@@ -1,0 +1,52 @@
+"""Training loss and LR schedule of the fusion net (utils/loss.py:65-103, utils/schedulers.py:12-28)."""
+import torch
+from torch.optim.lr_scheduler import _LRScheduler
+
+
+class FusionLoss(torch.nn.Module):
+    """w_l1 * mean|e - t| + w_l2 * mean (e - t)^2 + w_cos * CosineEmbedding(sign e, sign t).
+
+    est / target: [1, Nv, P] (rows = valid pixels).  Quirk kept from the reference: the sign tensors
+    are ``reshape``d (not transposed) to [1, P, Nv] before the cosine term (utils/loss.py:87-89), and an
+    empty batch yields the constant 1 without a graph (utils/loss.py:81-82)."""
+
+    def __init__(self, reduction='none', w_l1=1., w_l2=10., w_cos=0.1):
+        super().__init__()
+        self.l1 = torch.nn.L1Loss(reduction=reduction)
+        self.l2 = torch.nn.MSELoss(reduction=reduction)
+        self.lambda1 = w_l1 if w_l1 is not None else 0.
+        self.lambda2 = w_l2 if w_l2 is not None else 0.
+        self.lambda3 = w_cos if w_cos is not None else 0.
+
+    def forward(self, est, target):
+        if est.shape[1] == 0:
+            return torch.ones_like(est).sum().clamp(min=1)
+        s_e = torch.sign(est).reshape([est.shape[0], est.shape[2], est.shape[1]])
+        s_t = torch.sign(target).reshape([target.shape[0], target.shape[2], target.shape[1]])
+        n = torch.ones_like(est).sum()
+        l1 = self.l1(est, target).sum() / n
+        l2 = self.l2(est, target).sum() / n
+        # CosineEmbeddingLoss(margin=0, 'mean') with an all-ones label, written out: torch >= 2 rejects the
+        # reference's [1, P, Nv] label tensor, torch 1.4 broadcast it (1 - cos along dim 1, eps 1e-12)
+        dot = (s_e * s_t).sum(dim=1)
+        n1 = (s_e * s_e).sum(dim=1) + 1e-12
+        n2 = (s_t * s_t).sum(dim=1) + 1e-12
+        l3 = (1.0 - dot / torch.sqrt(n1 * n2)).mean()
+        return self.lambda1 * l1 + self.lambda2 * l2 + self.lambda3 * l3
+
+
+class PolynomialLR(_LRScheduler):
+    """lr = base_lr * (1 - iter / max_iter) ** gamma (utils/schedulers.py:12-21)."""
+
+    def __init__(self, optimizer, max_iter, decay_iter=1, gamma=0.9, last_epoch=-1):
+        self.decay_iter, self.max_iter, self.gamma = decay_iter, max_iter, gamma
+        super().__init__(optimizer, last_epoch)
+
+    def get_lr(self):
+        factor = (1 - self.last_epoch / float(self.max_iter)) ** self.gamma
+        return [base_lr * factor for base_lr in self.base_lrs]
+
+
+class ConstantLR(_LRScheduler):
+    def get_lr(self):
+        return list(self.base_lrs)

@@ -181,3 +181,29 @@ class SyntheticStream:
             s.from_array(labels, self.bbox)
             return (g, s)
         return (g,)
+
+
+class SyntheticDataset:
+    """torch-Dataset-shaped collection of scenes (one SyntheticStream each), frames interleaved
+    scene-major like the reference's file lists.  ``__getitem__`` returns the un-batched sample
+    dict of tensors a DataLoader(batch_size=1) collates into the batch ``Pipeline.fuse`` expects."""
+
+    def __init__(self, h, w, grid, frames_per_scene, scenes=('room_0',), seed=1911, n_classes=30,
+                 depth_key='tof_depth'):
+        self.streams = {s: SyntheticStream(h, w, grid, frames_per_scene, scene=s, seed=seed + 17 * i,
+                                           n_classes=n_classes, depth_key=depth_key)
+                        for i, s in enumerate(scenes)}
+        self.scenes = list(scenes)
+        self.frames_per_scene = frames_per_scene
+
+    def __len__(self):
+        return len(self.scenes) * self.frames_per_scene
+
+    def __getitem__(self, item):
+        import torch
+        s = self.scenes[item // self.frames_per_scene]
+        f = self.streams[s].frame(item % self.frames_per_scene)
+        return {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in f.items()}
+
+    def get_grid(self, scene, truncation, semantic_grid=True):
+        return self.streams[scene].get_grid(scene, truncation, semantic_grid)

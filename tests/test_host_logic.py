@@ -119,3 +119,38 @@ def test_camera_arrays_follow_reference_host_math():
     E44 = np.vstack([f['extrinsics'], [0, 0, 0, 1]])
     _, E2 = ops.camera_arrays(f['intrinsics'], E44)  # ScanNet-style 4x4 poses
     assert np.array_equal(E, E2) and np.array_equal(E, f['extrinsics'].astype(np.float32).reshape(12))
+
+
+def test_fusion_loss_and_schedule():
+    from online_joint_depthfusion_and_semantic_amd.loss import FusionLoss, PolynomialLR
+    torch.manual_seed(0)
+    e, t = torch.randn(1, 57, 9) * 0.1, torch.randn(1, 57, 9) * 0.1
+    x1 = torch.sign(e).reshape(1, 9, 57)[0].T
+    x2 = torch.sign(t).reshape(1, 9, 57)[0].T
+    l3 = torch.nn.CosineEmbeddingLoss(margin=0.0, reduction='mean')(x1, x2, torch.ones(57))
+    want = (e - t).abs().mean() + 10 * ((e - t) ** 2).mean() + 0.1 * l3  # utils/loss.py:65-103
+    assert abs(float(FusionLoss()(e, t)) - float(want)) < 1e-7
+    empty = FusionLoss()(e[:, :0], t[:, :0])
+    assert float(empty) == 1.0 and empty.grad_fn is None
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=1.0)
+    sch = PolynomialLR(opt, max_iter=100)
+    for _ in range(10):
+        opt.step()
+        sch.step()
+    assert abs(opt.param_groups[0]['lr'] - (1 - 10 / 100) ** 0.9) < 1e-12  # utils/schedulers.py:19-21
+
+
+def test_synthetic_dataset_and_checkpoint_keys():
+    from online_joint_depthfusion_and_semantic_amd.synthetic import SyntheticDataset
+    from online_joint_depthfusion_and_semantic_amd.drivers import remove_parent
+    ds = SyntheticDataset(12, 16, 16, 3, scenes=['a', 'b'])
+    assert len(ds) == 6 and ds.scenes == ['a', 'b']
+    s = ds[4]
+    assert s['frame_id'].startswith('b/') and s['tof_depth'].shape == (12, 16) and s['extrinsics'].shape == (3, 4)
+    b = next(iter(torch.utils.data.DataLoader(ds, batch_size=1)))
+    assert b['tof_depth'].shape == (1, 12, 16) and b['frame_id'][0].startswith('a/') and b['mask'].dtype == torch.bool
+    g = ds.get_grid('b', 0.1, True)
+    assert g[0].volume.shape == (16, 16, 16) and g[1].volume.dtype == np.uint8
+    st = remove_parent({'_fusion_network.pred.0.w': 1, 'x': 2}, '_fusion_network')
+    assert st == {'pred.0.w': 1, 'x': 2}
