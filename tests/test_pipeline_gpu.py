@@ -137,3 +137,28 @@ def test_stream_config_A_against_oracle(cuda, sem):
     db.reset(s)
     assert float(db.fusion_weights[s].float().abs().sum()) == 0 and db.state[s] is False
     assert torch.all(db.scenes_est[s].volume == torch.tensor(0.1, dtype=torch.float16))
+
+
+def test_fuse_with_predicted_semantics(cuda):
+    """semantic_strategy 'predict': AdapNet++ (torch ops on the GPU) -> softmax -> (score, id) per pixel
+    (pipeline.py:42-60,181-185) feeding the HIP semantic volume update."""
+    h, w, grid = 64, 96, 32
+    cfg = default_config(h, w, semantics=True, use_semantics=True, n_classes=12)
+    cfg.SETTINGS.device = str(cuda)
+    cfg.DATA.semantic_strategy = 'predict'
+    st = make_stream(h, w, grid, n_classes=12)
+    db = Database(st, database_config(cfg))
+    torch.manual_seed(0)
+    pipe = Pipeline(cfg).to(cuda).eval()
+    assert pipe._semantic_2d_network is not None
+    with torch.no_grad():
+        for i in range(2):
+            pipe.fuse(_batch(st, i, cuda), db, cuda)
+    s = st.scene
+    w_vol = db.fusion_weights[s].float()
+    sc = db.scores[s].volume.float()
+    touched = w_vol > 0
+    assert int(touched.sum()) > 500
+    assert float(sc[touched].min()) > 0 and float(sc[touched].max()) <= 1.0  # softmax confidences
+    assert float(sc[~touched].abs().max()) == 0
+    assert int(db.ids_est[s].volume.max()) < 12
