@@ -73,6 +73,18 @@ def cpu_baseline(args, h, w, grid, semantics):
                       'the reference (oracle/torch_port.py), %.2f s/frame' % (args.cpu_frames, w, h, grid, t)}
 
 
+def pmc_traffic(h, w, grid, semantics):
+    """HBM bytes per frame per kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
+    collected in separate runs of this bench, tests/pmc_traffic.py; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md §HBM prescribes for wide coalesced reads on gfx950).  Only valid for the
+    default workload it was measured on; otherwise None."""
+    path = os.path.join(ROOT, 'profiles', 'r01_traffic_pmc.json')
+    if (h, w, grid, semantics) != (240, 320, 256, False) or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)
+
+
 def algorithmic_bytes(st, frames, n_points, n_tail, semantics):
     """Compulsory HBM bytes of extract + integrate per frame, averaged over a sample."""
     from oracle import oracle  # only to COUNT distinct voxels on the host; not part of the timed path
@@ -177,6 +189,13 @@ def main():
         sample = list(range(args.warmup, n_frames, max(1, args.steps // 4)))[:4]
         bytes_frame, ug, us = algorithmic_bytes(st, sample, P, T, args.semantics)
         ei_s = (stages['extract'] + stages['integrate']) / 1e3
+        tr = pmc_traffic(h, w, grid, args.semantics)
+        net_traffic = hbm_traffic = None
+        if tr:
+            net_k = [k for k in tr if k.startswith(('conv_mfma', 'chain1x1', 'vortex_tail'))]
+            net_traffic = sum(tr[k]['fetch_bytes_per_frame_x2'] + tr[k]['write_bytes_per_frame'] for k in net_k) / n_conv
+            hbm_traffic = sum(tr[k]['fetch_bytes_per_frame_x2'] + tr[k]['write_bytes_per_frame']
+                              for k in tr if 'extract' in k or 'integrate' in k)
         out = {
             'metric': 'frames/sec fused (320x240, 256^3 grid)', 'value': fps, 'unit': 'frames/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
@@ -188,12 +207,12 @@ def main():
             'stages_ms': stages,
             'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel', 'launches_per_frame': n_conv,
                          'achieved': flops / net_s / 1e12, 'peak': F32_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
-                         'frac': flops / net_s / 1e12 / F32_MFMA_PEAK_TF, 'traffic': None,
+                         'frac': flops / net_s / 1e12 / F32_MFMA_PEAK_TF, 'traffic': net_traffic,
                          'flops_per_frame': flops, 'avg_launch_us': 1e6 * net_s / n_conv,
-                         'note': 'useful flops of all conv launches of one frame / HIP-event time of the net stage'},
+                         'note': 'useful flops of all MFMA conv launches of one frame / HIP-event time of the net stage; traffic = PMC HBM bytes per launch (profiles/r01_traffic_pmc.json)'},
             'roofline_hbm': {'bound': 'hbm', 'kernel': 'extract_kernel + integrate_*_kernel',
                              'achieved': bytes_frame / ei_s / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                             'frac': bytes_frame / ei_s / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                             'frac': bytes_frame / ei_s / 1e9 / HBM_PEAK_GBS, 'traffic': hbm_traffic,
                              'bytes_per_frame': bytes_frame, 'unique_gather_voxels': ug, 'unique_scatter_voxels': us},
         }
         if world == 1 and args.cpu_frames > 0:

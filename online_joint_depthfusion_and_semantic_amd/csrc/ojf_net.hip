@@ -73,9 +73,14 @@ constexpr int kPadSteps = 4;    // dead supersteps appended for the three-stage 
 
 // ABL is a profiling-only ablation mask (tests/microbench): 1 = no activation loads, 2 = no weight
 // loads, 4 = no MFMA, 8 = no per-superstep index math.  Product launches always use ABL = 0.
+struct ConvGroup {
+    ConvArgs g[4];  // independent convolutions of identical tile shape run as one launch (blockIdx.y)
+};
+
 template <int MT, int NT, int ABL = 0>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a)
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGroup grp)
 {
+    const ConvArgs &a = grp.g[blockIdx.y];
     // Per-(superstep, lane group) source table, built once per block: float4 index of the tap's
     // plane origin relative to a.in (-1 = the zero float4 every activation buffer keeps in front of
     // its planes) and the tap's (dy, dx).  kPadSteps dead supersteps pad the end so that the
@@ -673,30 +678,22 @@ static void release(PackedConv &pc)
 static inline f32x4 *planes(float *p) { return reinterpret_cast<f32x4 *>(p); }
 static inline const f32x4 *planes(const float *p) { return reinterpret_cast<const f32x4 *>(p); }
 
-// in / out: plane buffers; in_g0 / out_g0: first channel group of the window.
-// rows != NULL: the result goes to row-major scalars instead (last layer -> caller's est rows).
-static int launch_conv(const PackedConv &pc, const float *in, int in_g0, float *out, int out_g0, const float *bias,
-                       int act, int act_n, float scale, int h, int w, hipStream_t st, float *rows = nullptr,
-                       int rows_stride = 0, int rows_n = 0)
+// Launches n (<= 4) independent convolutions with the same number of output tiles as ONE grid
+// (blockIdx.y = problem): the four branches of a VortexPooling run together instead of as four
+// under-filled launches with their own ramp-up and tail.
+static int launch_conv_args(const ConvArgs *args, int n, int nt, hipStream_t st)
 {
-    ConvArgs a;
-    a.in = planes(in); a.out = planes(out); a.out_rows = rows;
-    a.wp = planes(pc.wp); a.bias = bias ? bias : pc.bias;
-    a.in_g0 = in_g0; a.out_g0 = out_g0; a.rows_stride = rows_stride; a.rows_n = rows_n;
-    a.h = h; a.w = w; a.npix = h * w;
-    a.taps = pc.taps; a.dil = pc.dil;
-    a.c4 = pc.c_in_phys / 4; a.nsteps = (pc.taps * a.c4 + 3) / 4;
-    a.og_store = round_up(pc.c_out_phys, 4) / 4;
-    a.act = act; a.act_n = act_n; a.scale = scale;
+    ConvGroup grp;
+    for (int i = 0; i < n; ++i) grp.g[i] = args[i];
+    for (int i = n; i < 4; ++i) grp.g[i] = args[0];
     // one wave computes ALL output-channel tiles of its pixel strip (activations are fetched once);
     // MT (16-pixel tiles per wave) trades operand reuse against the number of waves in flight
     static const int mt_env = getenv("OJF_CONV_MT") ? atoi(getenv("OJF_CONV_MT")) : 0;
-    const int nt = pc.n_ot;
     int mt = (nt <= 2) ? 2 : 1;
     if (mt_env == 1 || mt_env == 2) mt = mt_env;
-    const int strips = (a.npix + mt * 16 - 1) / (mt * 16);
-    const dim3 grid((strips + 3) / 4, 1), block(256);
-#define OJF_LAUNCH(MT_, NT_) hipLaunchKernelGGL((conv_mfma_kernel<MT_, NT_>), grid, block, 0, st, a)
+    const int strips = (args[0].npix + mt * 16 - 1) / (mt * 16);
+    const dim3 grid((strips + 3) / 4, n), block(256);
+#define OJF_LAUNCH(MT_, NT_) hipLaunchKernelGGL((conv_mfma_kernel<MT_, NT_>), grid, block, 0, st, grp)
     if (mt == 2) {
         switch (nt) {
             case 2: OJF_LAUNCH(2, 2); break;
@@ -716,6 +713,31 @@ static int launch_conv(const PackedConv &pc, const float *in, int in_g0, float *
     }
 #undef OJF_LAUNCH
     return check_hip(hipGetLastError(), "conv_mfma_kernel launch");
+}
+
+static void fill_conv_args(ConvArgs &a, const PackedConv &pc, const float *in, int in_g0, float *out, int out_g0,
+                           const float *bias, int act, int act_n, float scale, int h, int w)
+{
+    a.in = planes(in); a.out = planes(out); a.out_rows = nullptr;
+    a.wp = planes(pc.wp); a.bias = bias ? bias : pc.bias;
+    a.in_g0 = in_g0; a.out_g0 = out_g0; a.rows_stride = 0; a.rows_n = 0;
+    a.h = h; a.w = w; a.npix = h * w;
+    a.taps = pc.taps; a.dil = pc.dil;
+    a.c4 = pc.c_in_phys / 4; a.nsteps = (pc.taps * a.c4 + 3) / 4;
+    a.og_store = round_up(pc.c_out_phys, 4) / 4;
+    a.act = act; a.act_n = act_n; a.scale = scale;
+}
+
+// in / out: plane buffers; in_g0 / out_g0: first channel group of the window.
+// rows != NULL: the result goes to row-major scalars instead (last layer -> caller's est rows).
+static int launch_conv(const PackedConv &pc, const float *in, int in_g0, float *out, int out_g0, const float *bias,
+                       int act, int act_n, float scale, int h, int w, hipStream_t st, float *rows = nullptr,
+                       int rows_stride = 0, int rows_n = 0)
+{
+    ConvArgs a;
+    fill_conv_args(a, pc, in, in_g0, out, out_g0, bias, act, act_n, scale, h, w);
+    a.out_rows = rows; a.rows_stride = rows_stride; a.rows_n = rows_n;
+    return launch_conv_args(&a, 1, pc.n_ot, st);
 }
 
 static std::vector<int> slot_map(int n_logical, int group, int slot)
@@ -750,7 +772,7 @@ struct ojf_net {
     float *T = nullptr;                // cs
     float *Z = nullptr;                // 4*cs
     float *Q1 = nullptr, *Q2 = nullptr, *Q3 = nullptr;  // pooled branch pre-activations: 3cs, 2cs, cs
-    float *U = nullptr;                                  // cs
+    float *U = nullptr;                                  // 4*cs: first-3x3 outputs of the four branches
     float *V = nullptr;                                  // 4*cs: closing-3x3 outputs of the four branches
     float *CAT = nullptr;              // 4*os
     float *YY = nullptr;               // heads*os (vortex0 | vortex2 outputs)
@@ -909,12 +931,19 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
     const float *bin[4] = {net->Z, net->Q1, net->Q2, net->Q3};
     static const bool unfused = getenv("OJF_NO_TAIL") != nullptr;  // ablation switch only
     const bool fused = v.tail_w && !unfused;
-    for (int br = 0; br < 4; ++br) {
-        if (launch_conv(v.b3a[br], bin[br], 0, net->U, 0, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w, st)) return -2;
-        if (launch_conv(v.b3b[br], net->U, 0, net->V, br * c4, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w, st)) return -2;
-        if (!fused && launch_conv(v.b1[br], net->V, br * c4, net->CAT, br * o4, nullptr, OJF_ACT_RELU, net->os, 1.0f, h, w, st))
-            return -2;
+    {   // the four branches' dilated 3x3 pairs: two grouped launches (all first convs, then all second convs)
+        ConvArgs ga[4], gb[4];
+        for (int br = 0; br < 4; ++br) {
+            fill_conv_args(ga[br], v.b3a[br], bin[br], 0, net->U, br * c4, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w);
+            fill_conv_args(gb[br], v.b3b[br], net->U, br * c4, net->V, br * c4, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w);
+        }
+        if (launch_conv_args(ga, 4, v.b3a[0].n_ot, st)) return -2;
+        if (launch_conv_args(gb, 4, v.b3b[0].n_ot, st)) return -2;
     }
+    if (!fused)
+        for (int br = 0; br < 4; ++br)
+            if (launch_conv(v.b1[br], net->V, br * c4, net->CAT, br * o4, nullptr, OJF_ACT_RELU, net->os, 1.0f, h, w, st))
+                return -2;
     if (!fused) return launch_conv(v.fin, net->CAT, 0, out, out_g0, v.bias_final, OJF_ACT_NONE, 0, 1.0f, h, w, st);
     TailArgs ta;
     for (int br = 0; br < 4; ++br) ta.v[br] = planes(net->V) + (size_t)br * c4 * net->npix;
@@ -1090,7 +1119,7 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
     if (!rc) rc = alloc_planes(&net->Q1, np, 3 * cs);
     if (!rc) rc = alloc_planes(&net->Q2, np, 2 * cs);
     if (!rc) rc = alloc_planes(&net->Q3, np, cs);
-    if (!rc) rc = alloc_planes(&net->U, np, cs);
+    if (!rc) rc = alloc_planes(&net->U, np, 4 * cs);
     if (!rc) rc = alloc_planes(&net->V, np, 4 * cs);
     if (!rc) rc = alloc_planes(&net->CAT, np, 4 * os);
     if (!rc) rc = alloc_planes(&net->YY, np, net->heads * os);

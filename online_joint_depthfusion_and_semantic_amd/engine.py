@@ -53,8 +53,9 @@ class FusionNetEngine:
         self.macs_per_pixel = int(self.lib.ojf_net_macs_per_pixel(self.handle))
         heads = 2 if (version == 3 and self.use_semantics) else 1
         n_vortex = heads + 1 if version == 3 else 2
-        # conv_mfma_kernel launches per forward: dense blocks, 14 per VortexPooling, prediction head
-        self.conv_launches = 2 * net.gf * heads + 14 * n_vortex + 2 * (net.gf - 1) + 3
+        # MFMA launches per forward: 2 per dense block; per VortexPooling 1 stacked entry conv + 2 grouped
+        # launches (the four branches' dilated 3x3 pairs) + 1 fused tail; 1 fused prediction-head chain
+        self.conv_launches = 2 * net.gf * heads + 4 * n_vortex + 1
 
     def prepare_input(self, values, weights, depth, sem_ids=None, n_classes=0):
         """values / weights: cuda f32 [h*w, stride] rows from the extractor; depth: cuda f32 [h,w]."""

@@ -17,13 +17,15 @@ static float time_variant(const PackedConv &pc, float *in, float *out, int h, in
     a.h = h; a.w = w; a.npix = h * w; a.taps = pc.taps; a.dil = pc.dil;
     a.c4 = pc.c_in_phys / 4; a.nsteps = (pc.taps * a.c4 + 3) / 4;
     a.og_store = pc.c_out_phys / 4; a.act = OJF_ACT_RELU; a.act_n = pc.c_out_phys; a.scale = 1.0f;
+    ConvGroup grp;
+    for (int i = 0; i < 4; ++i) grp.g[i] = a;
     const int strips = (a.npix + MT * 16 - 1) / (MT * 16);
     dim3 grid((strips + 3) / 4, 1), block(256);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, ABL>), grid, block, 0, 0, a);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, ABL>), grid, block, 0, 0, grp);
     hipEventRecord(e0, 0);
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, ABL>), grid, block, 0, 0, a);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, ABL>), grid, block, 0, 0, grp);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms = 0;
