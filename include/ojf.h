@@ -85,6 +85,17 @@ int ojf_integrate(const float *depth_filtered_dev, const float *Kinv_host, const
                   int mode, void *workspace_dev, size_t workspace_bytes, uint32_t *stats_dev,
                   ojf_stream_t stream);
 
+/* Entry-list variant with the reference Integrator's own inputs (modules/integrator.py:15-126 fed by
+ * Pipeline._prepare_volume_update, modules/pipeline.py:137-171): n_rows = valid pixels x n_tail rows, each
+ * with a clamped value f32, 8 corner indices i64[8,3] and 8 corner weights f64[8] (all dev); row_ids u8 /
+ * row_scores f32 per row with id_vol / score_vol for the semantic update (all four or none).  FAST
+ * accumulation; the workspace is the OJF_MODE_FAST one of a (h*w*n_tail >= n_rows) configuration. */
+int ojf_integrate_entries(const float *values_dev, const int64_t *indices_dev, const double *weights_dev,
+                          const uint8_t *row_ids_dev, const float *row_scores_dev, int64_t n_rows,
+                          uint16_t *tsdf_dev, uint16_t *weights_vol_dev, uint8_t *id_vol_dev,
+                          uint16_t *score_vol_dev, int X, int Y, int Z, void *workspace_dev,
+                          size_t workspace_bytes, uint32_t *stats_dev, ojf_stream_t stream);
+
 /* ---- FUSION NET ------------------------------------------------------------------------------
  * Replaces FusionNet_v3.forward / FusionNet_v2.forward in eval mode (modules/model.py:164-283)
  * together with Pipeline._prepare_fusion_input / _fusion (modules/pipeline.py:62-102).

@@ -187,10 +187,63 @@ __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(Integra
     for (unsigned int i = threadIdx.x; i < n_new; i += 256) a.touched[base_new + i] = newlist[i];
 }
 
+// Entry-list variant for the reference's own Integrator.forward signature (modules/integrator.py:15-126):
+// the caller hands over materialised updates - per row r (valid pixel x sample) a clamped value, 8 int64
+// corner indices and 8 fp64 corner weights - exactly the tensors Pipeline._prepare_volume_update builds
+// (pipeline.py:137-171).  Same order-free accumulators and the same finalize pass as the fused path;
+// entry id = r*8 + q reproduces the reference's entry order for the semantic "last writer wins" rule.
+struct EntryArgs {
+    const float *values;     // [R]
+    const int64_t *indices;  // [R, 8, 3]
+    const double *weights;   // [R, 8]
+    const uint8_t *row_ids;  // [R] or NULL
+    int R;
+};
+
+__global__ __launch_bounds__(256) void integrate_entries_kernel(IntegrateArgs a, EntryArgs e)
+{
+    __shared__ unsigned int newlist[256 * 8];
+    __shared__ unsigned int n_new, base_new, n_entries;
+    if (threadIdx.x == 0) { n_new = 0; n_entries = 0; }
+    __syncthreads();
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned int n_in = 0;
+    if (r < e.R) {
+        const float v = e.values[r];
+        const bool sem = a.id_vol != nullptr;
+        const uint8_t id_e = sem ? e.row_ids[r] : 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int64_t *ix = e.indices + ((size_t)r * 8 + q) * 3;
+            const int64_t idx[3] = {ix[0], ix[1], ix[2]};
+            if (!in_volume(idx, a.X, a.Y, a.Z)) continue;  // integrator.py:48-53
+            const unsigned int lin = (unsigned int)(((size_t)idx[0] * a.Y + (size_t)idx[1]) * a.Z + (size_t)idx[2]);
+            const float we = (float)e.weights[(size_t)r * 8 + q];  // integrator.py:45
+            const float ue = we * v;                               // integrator.py:55
+            const unsigned int eid = (unsigned int)r * 8u + q + 1u;
+            VoxelAcc *rec = a.acc + lin;
+            const unsigned int prev = atomicMax(&rec->e_last, eid);
+            if (prev == 0) newlist[atomicAdd(&n_new, 1u)] = lin;
+            atomicAdd(&rec->w, (unsigned long long)__double2ll_rn((double)we * kFixScale));
+            atomicAdd(&rec->u, (unsigned long long)__double2ll_rn((double)ue * kFixScale));
+            if (sem && a.id_vol[lin] != id_e) atomicMax(&rec->e_diff, eid);
+            ++n_in;
+        }
+    }
+    if (n_in) atomicAdd(&n_entries, n_in);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (n_new) base_new = atomicAdd(&a.counters[0], n_new);
+        if (n_entries) atomicAdd(&a.counters[1], n_entries);
+    }
+    __syncthreads();
+    for (unsigned int i = threadIdx.x; i < n_new; i += 256) a.touched[base_new + i] = newlist[i];
+}
+
 __global__ __launch_bounds__(256) void integrate_finalize_kernel(IntegrateArgs a)
 {
     const unsigned int count = a.counters[0];
-    const unsigned int per_pixel = (unsigned int)a.n_tail * 8u;
+    const unsigned int per_pixel = (unsigned int)a.n_tail * 8u;  // entries per sem_ids / sem_scores element
     const bool sem = a.id_vol != nullptr;
     for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
         const size_t lin = a.touched[t];
@@ -299,4 +352,42 @@ OJF_API int ojf_integrate(const float *depth_filtered, const float *Ki, const fl
     OJF_HIP(hipGetLastError());
     hipLaunchKernelGGL(integrate_finalize_kernel, dim3(1024), dim3(256), 0, st, a);
     return check_hip(hipGetLastError(), "ojf_integrate launch");
+}
+
+OJF_API int ojf_integrate_entries(const float *values, const int64_t *indices, const double *weights,
+                                  const uint8_t *row_ids, const float *row_scores, int64_t n_rows, uint16_t *tsdf,
+                                  uint16_t *wgt, uint8_t *id_vol, uint16_t *score_vol, int X, int Y, int Z, void *ws,
+                                  size_t ws_bytes, uint32_t *stats, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (!values || !indices || !weights || !tsdf || !wgt || !ws) return fail("ojf_integrate_entries: null pointer argument");
+    if (X <= 0 || Y <= 0 || Z <= 0 || n_rows < 0) return fail("ojf_integrate_entries: bad sizes");
+    if ((uint64_t)X * Y * Z >= 0xffffffffull) return fail("ojf_integrate_entries: volume has >= 2^32 voxels");
+    if ((uint64_t)n_rows * 8 >= 0xffffffffull) return fail("ojf_integrate_entries: too many rows");
+    const int n_sem = (row_ids != nullptr) + (row_scores != nullptr) + (id_vol != nullptr) + (score_vol != nullptr);
+    if (n_sem != 0 && n_sem != 4)
+        return fail("ojf_integrate_entries: row_ids, row_scores, id_vol, score_vol must be all set or all NULL");
+    const size_t nvox = (size_t)X * Y * Z;
+    const size_t entries = (size_t)n_rows * 8;
+    const size_t need = kHeaderBytes + nvox * sizeof(VoxelAcc) + (entries < nvox ? entries : nvox) * sizeof(unsigned int);
+    if (ws_bytes < need) return fail("ojf_integrate_entries: workspace too small");
+    hipStream_t st = as_stream(stream);
+    char *base = static_cast<char *>(ws);
+    IntegrateArgs a;
+    a.depth = nullptr; a.est = nullptr; a.tsdf = tsdf; a.wgt = wgt;
+    a.sem_ids = row_ids; a.sem_scores = row_scores; a.id_vol = id_vol; a.score_vol = score_vol;
+    a.counters = reinterpret_cast<unsigned int *>(base);
+    a.acc = reinterpret_cast<VoxelAcc *>(base + kHeaderBytes);
+    a.touched = reinterpret_cast<unsigned int *>(base + kHeaderBytes + nvox * sizeof(VoxelAcc));
+    a.stats = stats;
+    a.X = X; a.Y = Y; a.Z = Z; a.h = 1; a.w = 1; a.n_points = 1; a.est_stride = 0; a.trunc = 0.0f; a.ablate = 0;
+    a.n_tail = 1;  // finalize maps entry id -> row as (id - 1) / (n_tail * 8)
+    OJF_HIP(hipMemsetAsync(a.counters, 0, kHeaderBytes, st));
+    if (n_rows > 0) {
+        EntryArgs e{values, indices, weights, row_ids, (int)n_rows};
+        hipLaunchKernelGGL(integrate_entries_kernel, dim3((unsigned int)((n_rows + 255) / 256)), dim3(256), 0, st, a, e);
+        OJF_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(integrate_finalize_kernel, dim3(1024), dim3(256), 0, st, a);
+    return check_hip(hipGetLastError(), "ojf_integrate_entries launch");
 }

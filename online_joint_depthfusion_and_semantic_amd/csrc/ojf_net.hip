@@ -779,6 +779,10 @@ struct ojf_net {
     float *Y3 = nullptr;               // os
     float *PA = nullptr, *PB = nullptr;  // pred ping-pong, os each
     float *partial = nullptr;          // kSumBlocks*256
+    // the global-average branch (two tiny latency-bound kernels) runs on a side stream, concurrently
+    // with the branch convolutions, and joins before the fused tail
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 namespace ojf {
@@ -913,13 +917,16 @@ static int launch_pool(const float *in, int in_g0, float *out, int out_g0, const
 static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float *out, int out_g0, hipStream_t st)
 {
     const int h = net->h, w = net->w, c4 = net->cs / 4, o4 = net->os / 4;
-    // global-average branch -> bias of the final conv
-    hipLaunchKernelGGL(colsum_kernel, dim3(kSumBlocks, v.c_in_phys / 4), dim3(256), 0, st, planes(in), in_g0, net->npix,
-                       net->partial);
+    // global-average branch -> bias of the final conv, on the side stream (fork here, join before the tail)
+    OJF_HIP(hipEventRecord(net->ev_fork, st));
+    OJF_HIP(hipStreamWaitEvent(net->side, net->ev_fork, 0));
+    hipLaunchKernelGGL(colsum_kernel, dim3(kSumBlocks, v.c_in_phys / 4), dim3(256), 0, net->side, planes(in), in_g0,
+                       net->npix, net->partial);
     OJF_HIP(hipGetLastError());
-    hipLaunchKernelGGL(gave_bias_kernel, dim3(1), dim3(256), 0, st, net->partial, v.c_in_phys, net->npix, v.Wg, v.bg,
-                       v.Wfg, v.bf, net->pool_in, v.bias_final, v.fin.n_ot * 16);
+    hipLaunchKernelGGL(gave_bias_kernel, dim3(1), dim3(256), 0, net->side, net->partial, v.c_in_phys, net->npix, v.Wg,
+                       v.bg, v.Wfg, v.bf, net->pool_in, v.bias_final, v.fin.n_ot * 16);
     OJF_HIP(hipGetLastError());
+    OJF_HIP(hipEventRecord(net->ev_join, net->side));
     // branch entries: one GEMM, branch 0 gets bias + ReLU in the epilogue
     if (launch_conv(v.stacked, in, in_g0, net->Z, 0, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w, st)) return -2;
     // pool pyramid on the pre-activations of branches 1..3 (one launch per level; the first c4
@@ -940,6 +947,7 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
         if (launch_conv_args(ga, 4, v.b3a[0].n_ot, st)) return -2;
         if (launch_conv_args(gb, 4, v.b3b[0].n_ot, st)) return -2;
     }
+    OJF_HIP(hipStreamWaitEvent(st, net->ev_join, 0));  // bias of the final conv is ready
     if (!fused)
         for (int br = 0; br < 4; ++br)
             if (launch_conv(v.b1[br], net->V, br * c4, net->CAT, br * o4, nullptr, OJF_ACT_RELU, net->os, 1.0f, h, w, st))
@@ -994,6 +1002,9 @@ OJF_API void ojf_net_destroy(ojf_net *net)
     float *bufs[] = {net->X[0], net->X[1], net->T, net->Z, net->Q1, net->Q2, net->Q3, net->U, net->V,
                      net->CAT, net->YY, net->Y3, net->PA, net->PB, net->partial};
     for (float *p : bufs) free_planes(p);
+    if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
+    if (net->ev_join) (void)hipEventDestroy(net->ev_join);
+    if (net->side) (void)hipStreamDestroy(net->side);
     if (net->chain_w) (void)hipFree(net->chain_w);
     if (net->chain_b) (void)hipFree(net->chain_b);
     delete net;
@@ -1127,6 +1138,9 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
     if (!rc) rc = alloc_planes(&net->PA, np, os);
     if (!rc) rc = alloc_planes(&net->PB, np, os);
     if (!rc) rc = alloc_planes(&net->partial, kSumBlocks, 256);
+    if (!rc) rc = check_hip(hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking), "hipStreamCreate");
+    if (!rc) rc = check_hip(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming), "hipEventCreate");
+    if (!rc) rc = check_hip(hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming), "hipEventCreate");
     if (rc) {
         const std::string keep = ojf_last_error();
         ojf_net_destroy(net);

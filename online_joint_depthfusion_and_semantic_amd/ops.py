@@ -126,6 +126,41 @@ def integrate(depth_filtered, Ki, E, origin, resolution, est, tsdf, weights, wor
     _lib.check(rc, 'ojf_integrate')
 
 
+class EntryWorkspace:
+    """FAST-mode scratch for ``integrate_entries``: header + 24 B/voxel accumulators + touched list."""
+
+    def __init__(self, shape, max_rows, device):
+        _lib.require_gpu()
+        X, Y, Z = shape
+        nvox = X * Y * Z
+        self.shape, self.max_rows = tuple(shape), int(max_rows)
+        self.bytes = 256 + nvox * 24 + min(self.max_rows * 8, nvox) * 4
+        self.buf = torch.zeros(self.bytes, dtype=torch.uint8, device=device)  # accumulators start clean
+        self.stats = torch.zeros(4, dtype=torch.int32, device=device)
+
+
+def integrate_entries(values, indices, weights, tsdf, weights_volume, workspace, row_ids=None, row_scores=None,
+                      id_vol=None, score_vol=None):
+    """Scatter materialised updates (the reference Integrator's inputs) into the volumes, in place.
+    values [R] f32, indices [R,8,3] i64, weights [R,8] f64 (cuda, contiguous)."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    R = values.numel()
+    assert values.is_cuda and values.dtype == torch.float32 and values.is_contiguous()
+    assert indices.dtype == torch.int64 and indices.is_contiguous() and indices.numel() == R * 24
+    assert weights.dtype == torch.float64 and weights.is_contiguous() and weights.numel() == R * 8
+    X, Y, Z = _vol16(tsdf).shape
+    assert _vol16(weights_volume).shape == tsdf.shape and workspace.shape == (X, Y, Z) and R <= workspace.max_rows
+    if row_ids is not None:
+        assert row_ids.dtype == torch.uint8 and row_ids.is_contiguous() and row_ids.numel() == R
+        assert row_scores.dtype == torch.float32 and row_scores.is_contiguous() and row_scores.numel() == R
+    rc = lib.ojf_integrate_entries(_lib.ptr(values), _lib.ptr(indices), _lib.ptr(weights), _lib.ptr(row_ids),
+                                   _lib.ptr(row_scores), R, _lib.ptr(tsdf), _lib.ptr(weights_volume), _lib.ptr(id_vol),
+                                   _lib.ptr(score_vol), X, Y, Z, _lib.ptr(workspace.buf), workspace.bytes,
+                                   _lib.ptr(workspace.stats), _lib.stream_ptr(values.device))
+    _lib.check(rc, 'ojf_integrate_entries')
+
+
 def volume_fill(vol, value):
     _lib.require_gpu()
     lib = _lib.load()

@@ -167,3 +167,51 @@ def test_error_paths(cuda):
     with pytest.raises(AssertionError):  # workspace built for another frame size
         ops.integrate(_t(fi['fd'][:6], cuda), fi['Ki'], fi['E'], st.origin, st.resolution, _t(fi['est'][:96], cuda),
                       vols['tsdf'], vols['wgt'], ws)
+
+
+@pytest.mark.parametrize('semantics', [False, True])
+def test_reference_style_extractor_integrator_modules(cuda, semantics):
+    """The drop-in Extractor / Integrator modules with the reference's own call signatures
+    (extractor.py:24, integrator.py:15): Extractor.forward's full dict feeds the reference-style
+    _prepare_volume_update slicing (pipeline.py:137-171) and Integrator.forward(updates, ...)."""
+    from online_joint_depthfusion_and_semantic_amd.config import default_config
+    from online_joint_depthfusion_and_semantic_amd.extractor import Extractor
+    from online_joint_depthfusion_and_semantic_amd.integrator import Integrator
+    h, w, grid = 60, 80, 64
+    cfg = default_config(h, w, semantics=semantics)
+    cfg.SETTINGS.device = str(cuda)
+    ex, ig = Extractor(cfg), Integrator(cfg)
+    st = make_stream(h, w, grid)
+    vols = fresh_volumes(grid, semantics)
+    g = to_cuda(vols, cuda)
+    for i in range(3):
+        b = st.batch(i)
+        fi = frame_inputs(st, i)
+        out = ex.forward(b['tof_depth'].to(cuda), b['extrinsics'], b['intrinsics'], g['tsdf'], g['wgt'],
+                         torch.from_numpy(st.origin), st.resolution)
+        ref = oracle.extract(fi['depth'], fi['Ki'], fi['E'], st.origin, st.resolution, vols['tsdf'], vols['wgt'], debug=True)
+        assert n_mismatch(out['fusion_values'][0].cpu().numpy(), ref['fusion_values']) == 0
+        assert n_mismatch(out['indices'][0].cpu().numpy(), ref['indices']) == 0
+        assert n_mismatch(out['weights'][0].cpu().numpy(), ref['weights']) == 0
+        est = _t(fi['est'], cuda).view(1, h * w, 9)
+        valid = (_t(fi['fd'], cuda).view(1, h * w, 1) != 0).nonzero()[:, 1]
+        updates = dict(values=torch.clamp(est[:, valid, :7], -0.1, 0.1), indices=out['indices'][:, valid, :7],
+                       weights=out['weights'][:, valid, :7])
+        if semantics:
+            rep = lambda t: t.view(1, h * w, 1).unsqueeze(-2).repeat(1, 1, 9, 1)[:, valid, :7]
+            updates['semantics'] = rep(_t(fi['sem_ids'], cuda))
+            updates['scores'] = rep(_t(fi['sem_scores'], cuda))
+        pre = {k: v.copy() for k, v in vols.items()}
+        touched = _oracle_integrate(st, fi, vols, semantics)
+        gg = to_cuda(pre, cuda)  # common pre-frame state
+        r = ig.forward(updates, gg['tsdf'], gg['wgt'], gg.get('scores'), gg.get('ids'))
+        assert r[0] is gg['tsdf'] and r[1] is gg['wgt']
+        assert int(ig._entry_ws.stats[0].item()) == touched
+        for key in ('tsdf', 'wgt'):
+            got = gg[key].cpu().numpy()
+            ulp = np.where(np.isnan(got), 0, f16_ulp_distance(got, vols[key]))
+            assert ulp.max() <= 1 and (np.isnan(got) == np.isnan(vols[key])).all(), (key, i)
+        if semantics:
+            assert n_mismatch(gg['ids'].cpu().numpy(), vols['ids']) == 0
+            assert n_mismatch(gg['scores'].cpu().numpy(), vols['scores']) == 0
+        g = to_cuda(vols, cuda)
