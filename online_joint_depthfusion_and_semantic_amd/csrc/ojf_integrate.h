@@ -32,7 +32,6 @@ struct IntegrateArgs {
     uint32_t *stats;
     int X, Y, Z, h, w, n_points, n_tail, est_stride;
     float trunc;
-    int ablate;  // profiling only (env OJF_ABLATE): bit0 skip the HBM flush, bit1 skip the LDS hash
 };
 
 size_t fast_workspace_bytes(int X, int Y, int Z, int h, int w, int n_tail);

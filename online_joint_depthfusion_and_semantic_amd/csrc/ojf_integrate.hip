@@ -27,58 +27,13 @@ size_t fast_workspace_bytes(int X, int Y, int Z, int h, int w, int n_tail)
     return kHeaderBytes + nvox * sizeof(VoxelAcc) + cap * sizeof(unsigned int);
 }
 
-__global__ __launch_bounds__(256) void integrate_accumulate_kernel(IntegrateArgs a, Camera cam)
-{
-    const int N = a.h * a.w;
-    const int item = blockIdx.x * blockDim.x + threadIdx.x;
-    if (item >= N * a.n_tail) return;
-    const int k = item / N;
-    const int n = item - k * N;
-    const float z = a.depth[n];
-    if (!(z != 0.0f)) return;  // modules/pipeline.py:145-146
-    const int r = n / a.w, c = n - r * a.w;
-
-    float pw[3];
-    double cv[3], dir[3];
-    unproject(r, c, z, cam, pw);
-    ray_frame(pw, cam, cv, dir);
-    RaySample s;
-    ray_sample(cv, dir, k, (a.n_points - 1) / 2, s);
-
-    float v = a.est[(size_t)n * a.est_stride + k];  // pipeline.py:153-156
-    v = v < -a.trunc ? -a.trunc : (v > a.trunc ? a.trunc : v);
-    const bool sem = a.id_vol != nullptr;
-    const uint8_t id_e = sem ? a.sem_ids[n] : 0;
-    const unsigned int e0 = ((unsigned int)n * a.n_tail + k) * 8u + 1u;
-    unsigned int n_in = 0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        int64_t idx[3];
-        double wq;
-        corner(s, q, idx, wq);
-        if (!in_volume(idx, a.X, a.Y, a.Z)) continue;  // integrator.py:48-53
-        const size_t lin = ((size_t)idx[0] * a.Y + (size_t)idx[1]) * a.Z + (size_t)idx[2];
-        const float we = (float)wq;  // integrator.py:45
-        const float ue = we * v;     // integrator.py:55
-        const long long xw = __double2ll_rn((double)we * kFixScale);
-        const long long xu = __double2ll_rn((double)ue * kFixScale);
-        VoxelAcc *rec = a.acc + lin;
-        const unsigned int prev = atomicMax(&rec->e_last, e0 + q);
-        if (prev == 0) a.touched[atomicAdd(&a.counters[0], 1u)] = (unsigned int)lin;
-        atomicAdd(&rec->w, (unsigned long long)xw);
-        atomicAdd(&rec->u, (unsigned long long)xu);
-        if (sem && a.id_vol[lin] != id_e) atomicMax(&rec->e_diff, e0 + q);  // integrator.py:105
-        ++n_in;
-    }
-    if (n_in) atomicAdd(&a.counters[1], n_in);
-}
-
 // LDS-aggregated accumulate: one block owns an 8x8 pixel tile and all n_tail samples of its rays.
 // A wave is the 64 pixels of the tile at one ray offset, so its lanes hit a few dozen distinct voxels;
 // colliding writes are first combined in a 2048-slot LDS hash (integer adds / maxima: order-free,
 // hence still bit-deterministic), and only one record per (tile, voxel) goes to HBM.  This removes
 // the serialised same-address global atomics that dominated the direct kernel (~16 entries/voxel ->
-// ~2.6 tiles/voxel).  A full hash falls back to direct global atomics for that entry.
+// ~2.6 tiles/voxel; measured 686 us for per-entry global atomics -> 96 us).  A full hash falls back to
+// direct global atomics for that entry.
 constexpr int kSlots = 2048;
 constexpr unsigned int kEmpty = 0xffffffffu;
 
@@ -144,7 +99,6 @@ __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(Integra
             const unsigned int e = e0 + q;
             const unsigned int ed = (sem && a.id_vol[lin] != id_e) ? e : 0u;  // integrator.py:105
             ++n_in;
-            if (a.ablate & 2) { asm volatile("" ::"v"(xw), "v"(xu), "v"(ed)); continue; }
             const unsigned int h0 = (lin * 2654435761u) >> 21;
             int slot = -1;
             for (int probe = 0; probe < 16; ++probe) {
@@ -164,7 +118,6 @@ __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(Integra
     }
     if (n_in) atomicAdd(&n_entries, n_in);
     __syncthreads();
-    if (a.ablate & 1) return;
     // one HBM record per (tile, voxel).  First touches are collected in LDS and appended to the
     // global touched list with ONE counter atomic per tile: a per-record append on the single
     // counter word serialises at the memory side (measured: 350 us of a 440 us kernel).
@@ -332,8 +285,6 @@ OJF_API int ojf_integrate(const float *depth_filtered, const float *Ki, const fl
     a.acc = nullptr; a.touched = nullptr; a.stats = stats;
     a.X = X; a.Y = Y; a.Z = Z; a.h = h; a.w = w; a.n_points = n_points; a.n_tail = n_tail;
     a.est_stride = est_stride; a.trunc = trunc;
-    static const int ablate = getenv("OJF_ABLATE") ? atoi(getenv("OJF_ABLATE")) : 0;
-    a.ablate = ablate;
     const Camera cam = make_camera(Ki, E, origin, res);
 
     OJF_HIP(hipMemsetAsync(a.counters, 0, kHeaderBytes, st));
@@ -341,14 +292,8 @@ OJF_API int ojf_integrate(const float *depth_filtered, const float *Ki, const fl
 
     a.acc = reinterpret_cast<VoxelAcc *>(base + kHeaderBytes);
     a.touched = reinterpret_cast<unsigned int *>(base + kHeaderBytes + (size_t)X * Y * Z * sizeof(VoxelAcc));
-    static const bool direct = getenv("OJF_INTEGRATE_DIRECT") != nullptr;  // ablation switch only
-    if (direct) {
-        const int items = h * w * n_tail;
-        hipLaunchKernelGGL(integrate_accumulate_kernel, dim3((items + 255) / 256), dim3(256), 0, st, a, cam);
-    } else {
-        const int tiles = ((h + 7) / 8) * ((w + 7) / 8);
-        hipLaunchKernelGGL(integrate_accumulate_tiled_kernel, dim3(tiles), dim3(256), 0, st, a, cam);
-    }
+    const int tiles = ((h + 7) / 8) * ((w + 7) / 8);
+    hipLaunchKernelGGL(integrate_accumulate_tiled_kernel, dim3(tiles), dim3(256), 0, st, a, cam);
     OJF_HIP(hipGetLastError());
     hipLaunchKernelGGL(integrate_finalize_kernel, dim3(1024), dim3(256), 0, st, a);
     return check_hip(hipGetLastError(), "ojf_integrate launch");
@@ -380,7 +325,7 @@ OJF_API int ojf_integrate_entries(const float *values, const int64_t *indices, c
     a.acc = reinterpret_cast<VoxelAcc *>(base + kHeaderBytes);
     a.touched = reinterpret_cast<unsigned int *>(base + kHeaderBytes + nvox * sizeof(VoxelAcc));
     a.stats = stats;
-    a.X = X; a.Y = Y; a.Z = Z; a.h = 1; a.w = 1; a.n_points = 1; a.est_stride = 0; a.trunc = 0.0f; a.ablate = 0;
+    a.X = X; a.Y = Y; a.Z = Z; a.h = 1; a.w = 1; a.n_points = 1; a.est_stride = 0; a.trunc = 0.0f;
     a.n_tail = 1;  // finalize maps entry id -> row as (id - 1) / (n_tail * 8)
     OJF_HIP(hipMemsetAsync(a.counters, 0, kHeaderBytes, st));
     if (n_rows > 0) {

@@ -688,9 +688,7 @@ static int launch_conv_args(const ConvArgs *args, int n, int nt, hipStream_t st)
     for (int i = n; i < 4; ++i) grp.g[i] = args[0];
     // one wave computes ALL output-channel tiles of its pixel strip (activations are fetched once);
     // MT (16-pixel tiles per wave) trades operand reuse against the number of waves in flight
-    static const int mt_env = getenv("OJF_CONV_MT") ? atoi(getenv("OJF_CONV_MT")) : 0;
-    int mt = (nt <= 2) ? 2 : 1;
-    if (mt_env == 1 || mt_env == 2) mt = mt_env;
+    const int mt = (nt <= 2) ? 2 : 1;
     const int strips = (args[0].npix + mt * 16 - 1) / (mt * 16);
     const dim3 grid((strips + 3) / 4, n), block(256);
 #define OJF_LAUNCH(MT_, NT_) hipLaunchKernelGGL((conv_mfma_kernel<MT_, NT_>), grid, block, 0, st, grp)
