@@ -257,14 +257,20 @@ constexpr int kChainPre = 6;  // float4 registers per thread holding the prefetc
 // between two compute phases, only two barriers around the LDS refill do.
 enum { kChainLeaky = 0, kChainRelu = 1, kChainAccumulate = 2, kChainLastRows = 3 };
 
-template <int MT, int NTIN, int NTOUT, int MODE, int NEXT_FIRST>
-__device__ __forceinline__ void chain_layer(f32x4 (&cur)[MT][8], f32x4 *wlds, const f32x4 *wg, const float *bias,
-                                            const ChainArgs &a, const int (&p)[MT], int lane, f32x4 (&pre)[kChainPre],
-                                            f32x4 (*out)[8] = nullptr, const f32x4 *next_src = nullptr)
+// One pointwise layer on register-resident activations: out[n2] (+)= sum_S sum_j mfma(W[n2][S][j], in[S][j]),
+// then (unless accumulating) bias + activation in place.  `in` and `out` are distinct, statically indexed
+// register arrays (callers ping-pong two of them), so no staging copy exists.
+// `pre` carries the weights of this layer's first part on entry (already fetched from HBM/L2 while the
+// previous part computed) and the next layer's first part on exit: global latency never sits between two
+// compute phases, only the two barriers around the LDS refill do.
+template <int MT, int NTIN, int NTOUT, int MODE, int NEXT_FIRST, int NA, int NB>
+__device__ __forceinline__ void chain_layer(const f32x4 (&in)[MT][NA], f32x4 (&out)[MT][NB], f32x4 *wlds, const f32x4 *wg,
+                                            const float *bias, const ChainArgs &a, const int (&p)[MT], int lane,
+                                            f32x4 (&pre)[kChainPre], const f32x4 *next_src = nullptr)
 {
+    static_assert(NTIN <= NA && NTOUT <= NB, "register arrays too small for this layer");
     constexpr int parts = chain_parts(NTIN, NTOUT);
     constexpr int per = chain_per(NTIN, NTOUT);
-    f32x4 nxt[MT][NTOUT];
 #pragma unroll
     for (int part = 0; part < parts; ++part) {
         const int nb = part * per;
@@ -284,11 +290,13 @@ __device__ __forceinline__ void chain_layer(f32x4 (&cur)[MT][8], f32x4 *wlds, co
 #pragma unroll
         for (int k = 0; k < kChainPre; ++k)
             if ((int)threadIdx.x + 256 * k < nsize) pre[k] = nsrc[threadIdx.x + 256 * k];
+        if constexpr (MODE != kChainAccumulate) {
 #pragma unroll
-        for (int n2 = 0; n2 < NTOUT; ++n2)
+            for (int n2 = 0; n2 < NTOUT; ++n2)
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-                if (n2 >= nb && n2 < ne) nxt[m][n2] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int m = 0; m < MT; ++m)
+                    if (n2 >= nb && n2 < ne) out[m][n2] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         // S outer, output tiles inner: (ne - nb) * MT independent accumulators per MFMA round
 #pragma unroll
         for (int S = 0; S < NTIN; ++S)
@@ -300,20 +308,17 @@ __device__ __forceinline__ void chain_layer(f32x4 (&cur)[MT][8], f32x4 *wlds, co
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
-                        nxt[m][n2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], cur[m][S][j], nxt[m][n2], 0, 0, 0);
+                        out[m][n2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], in[m][S][j], out[m][n2], 0, 0, 0);
             }
     }
-    const int g = lane >> 4;
+    if constexpr (MODE != kChainAccumulate) {
+        const int g = lane >> 4;
 #pragma unroll
-    for (int n2 = 0; n2 < NTOUT; ++n2) {
-        if constexpr (MODE == kChainAccumulate) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) out[m][n2] += nxt[m][n2];
-        } else {
+        for (int n2 = 0; n2 < NTOUT; ++n2) {
             const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + n2 * 16 + 4 * g);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                f32x4 v = nxt[m][n2] + b;
+                f32x4 v = out[m][n2] + b;
                 if constexpr (MODE == kChainLastRows) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -325,26 +330,29 @@ __device__ __forceinline__ void chain_layer(f32x4 (&cur)[MT][8], f32x4 *wlds, co
                     constexpr float slope = MODE == kChainRelu ? 0.0f : 0.01f;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.0f ? v[j] : slope * v[j];
-                    cur[m][n2] = v;
+                    out[m][n2] = v;
                 }
             }
         }
     }
 }
 
+// layer l reads `x` and writes `y`; the recursion swaps the two arrays for layer l+1
 template <int MT, int NTIN, int NTOUT>
-__device__ __forceinline__ void chain_run(f32x4 (&cur)[MT][8], f32x4 *wlds, const f32x4 *wg, const float *bias,
-                                          const ChainArgs &a, const int (&p)[MT], int lane, f32x4 (&pre)[kChainPre])
+__device__ __forceinline__ void chain_run(f32x4 (&x)[MT][8], f32x4 (&y)[MT][8], f32x4 *wlds, const f32x4 *wg,
+                                          const float *bias, const ChainArgs &a, const int (&p)[MT], int lane,
+                                          f32x4 (&pre)[kChainPre])
 {
-    chain_layer<MT, NTIN, NTOUT, kChainLastRows, 0>(cur, wlds, wg, bias, a, p, lane, pre);
+    chain_layer<MT, NTIN, NTOUT, kChainLastRows, 0>(x, y, wlds, wg, bias, a, p, lane, pre);
 }
 
 template <int MT, int NTIN, int NTOUT, int NTNEXT, int... REST>
-__device__ __forceinline__ void chain_run(f32x4 (&cur)[MT][8], f32x4 *wlds, const f32x4 *wg, const float *bias,
-                                          const ChainArgs &a, const int (&p)[MT], int lane, f32x4 (&pre)[kChainPre])
+__device__ __forceinline__ void chain_run(f32x4 (&x)[MT][8], f32x4 (&y)[MT][8], f32x4 *wlds, const f32x4 *wg,
+                                          const float *bias, const ChainArgs &a, const int (&p)[MT], int lane,
+                                          f32x4 (&pre)[kChainPre])
 {
-    chain_layer<MT, NTIN, NTOUT, kChainLeaky, chain_first_size(NTOUT, NTNEXT)>(cur, wlds, wg, bias, a, p, lane, pre);
-    chain_run<MT, NTOUT, NTNEXT, REST...>(cur, wlds, wg + (size_t)NTIN * NTOUT * 64, bias + NTOUT * 16, a, p, lane, pre);
+    chain_layer<MT, NTIN, NTOUT, kChainLeaky, chain_first_size(NTOUT, NTNEXT)>(x, y, wlds, wg, bias, a, p, lane, pre);
+    chain_run<MT, NTOUT, NTNEXT, REST...>(y, x, wlds, wg + (size_t)NTIN * NTOUT * 64, bias + NTOUT * 16, a, p, lane, pre);
 }
 
 template <int MT, int NT0, int... NTS>
@@ -355,7 +363,7 @@ __global__ __launch_bounds__(256) void chain1x1_kernel(const ChainArgs a)
     const int i16 = lane & 15, g = lane >> 4;
     const int strip = (blockIdx.x * 4 + wave) * (MT * 16);
     int p[MT];
-    f32x4 cur[MT][8];
+    f32x4 x[MT][8], y[MT][8];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         p[m] = strip + m * 16 + i16;  // waves past the image still take part in the barriers
@@ -363,7 +371,7 @@ __global__ __launch_bounds__(256) void chain1x1_kernel(const ChainArgs a)
         for (int S = 0; S < NT0; ++S) {
             const int G = 4 * S + g;
             const bool ok = p[m] < a.npix && G < a.c4_in;
-            cur[m][S] = a.in[ok ? (a.in_g0 + G) * a.npix + p[m] : -1];
+            x[m][S] = a.in[ok ? (a.in_g0 + G) * a.npix + p[m] : -1];
         }
     }
     f32x4 pre[kChainPre];
@@ -374,7 +382,7 @@ __global__ __launch_bounds__(256) void chain1x1_kernel(const ChainArgs a)
         for (int k = 0; k < kChainPre; ++k)
             if ((int)threadIdx.x + 256 * k < size0) pre[k] = a.w[threadIdx.x + 256 * k];
     }
-    chain_run<MT, NT0, NTS...>(cur, wlds, a.w, a.bias, a, p, lane, pre);
+    chain_run<MT, NT0, NTS...>(x, y, wlds, a.w, a.bias, a, p, lane, pre);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -406,7 +414,7 @@ __global__ __launch_bounds__(256) void vortex_tail_kernel(const TailArgs a)
     for (int m = 0; m < MT; ++m) p[m] = strip + m * 16 + i16;
     ChainArgs ca;  // only npix is read by the layer code in these modes
     ca.npix = a.npix; ca.out_rows = nullptr; ca.rows_n = 0; ca.rows_stride = 0; ca.scale = 1.0f;
-    f32x4 y[MT][8];
+    f32x4 y[MT][NO];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -421,21 +429,21 @@ __global__ __launch_bounds__(256) void vortex_tail_kernel(const TailArgs a)
     constexpr size_t per_branch = (size_t)(NV * NO + NO * NO) * 64;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        f32x4 cur[MT][8];
+        f32x4 vin[MT][NV], t[MT][NO];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int S = 0; S < NV; ++S) {
                 const int G = 4 * S + g;
                 const bool ok = p[m] < a.npix && G < a.c4;
-                cur[m][S] = a.v[b][ok ? G * a.npix + p[m] : -1];
+                vin[m][S] = a.v[b][ok ? G * a.npix + p[m] : -1];
             }
         const f32x4 *w1 = a.w + b * per_branch, *wf = w1 + (size_t)NV * NO * 64;
-        chain_layer<MT, NV, NO, kChainRelu, chain_first_size(NO, NO)>(cur, wlds, w1, a.b1 + b * NO * 16, ca, p, lane, pre);
+        chain_layer<MT, NV, NO, kChainRelu, chain_first_size(NO, NO)>(vin, t, wlds, w1, a.b1 + b * NO * 16, ca, p, lane, pre);
         if (b < 3)
-            chain_layer<MT, NO, NO, kChainAccumulate, chain_first_size(NV, NO)>(cur, wlds, wf, nullptr, ca, p, lane, pre, y);
+            chain_layer<MT, NO, NO, kChainAccumulate, chain_first_size(NV, NO)>(t, y, wlds, wf, nullptr, ca, p, lane, pre);
         else
-            chain_layer<MT, NO, NO, kChainAccumulate, 0>(cur, wlds, wf, nullptr, ca, p, lane, pre, y);
+            chain_layer<MT, NO, NO, kChainAccumulate, 0>(t, y, wlds, wf, nullptr, ca, p, lane, pre);
     }
 #pragma unroll
     for (int n = 0; n < NO; ++n) {
