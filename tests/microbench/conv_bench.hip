@@ -7,7 +7,7 @@
 
 using namespace ojf;
 
-template <int MT, int NT, int ABL>
+template <int MT, int NT, int ABL, bool SKIP = true>
 static float time_variant(const PackedConv &pc, float *in, float *out, int h, int w, int reps)
 {
     ConvArgs a;
@@ -23,9 +23,9 @@ static float time_variant(const PackedConv &pc, float *in, float *out, int h, in
     dim3 grid((strips + 3) / 4, 1), block(256);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, ABL>), grid, block, 0, 0, grp);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, ABL, SKIP>), grid, block, 0, 0, grp);
     hipEventRecord(e0, 0);
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, ABL>), grid, block, 0, 0, grp);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, ABL, SKIP>), grid, block, 0, 0, grp);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms = 0;
@@ -57,9 +57,11 @@ static void run_shape(const char *name, int cin, int cout, int k, int dil, int h
     float t7 = time_variant<MT, NT, 7>(pc, in, out, h, w, reps);
     float t11 = time_variant<MT, NT, 11>(pc, in, out, h, w, reps);
     float t15 = time_variant<MT, NT, 15>(pc, in, out, h, w, reps);
+    float tn = time_variant<MT, NT, 0, false>(pc, in, out, h, w, reps);
+    float tn3 = time_variant<MT, NT, 3, false>(pc, in, out, h, w, reps);
     printf("%-26s MT=%d NT=%d padded %.2f GMAC (MFMA-bound %.1f us) | full %.1f  noX %.1f  noW %.1f  noXW %.1f  noMFMA %.1f  "
-           "noXW+noMFMA %.1f  noXW+noIdx %.1f  nothing %.1f us\n",
-           name, MT, NT, gmac, gmac / 78.6e-3, t0, t1, t2, t3, t4, t7, t11, t15);
+           "noXW+noMFMA %.1f  noXW+noIdx %.1f  nothing %.1f | NOSKIP full %.1f noXW %.1f us\n",
+           name, MT, NT, gmac, gmac / 78.6e-3, t0, t1, t2, t3, t4, t7, t11, t15, tn, tn3);
     free_planes(in); free_planes(out); release(pc);
 }
 
