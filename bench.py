@@ -117,6 +117,7 @@ def main():
     ap.add_argument('--semantics', action='store_true', help='BASELINE configs[2]-style: gt labels + semantic head')
     ap.add_argument('--mode', default='fast', choices=['fast', 'parity'])
     ap.add_argument('--cpu-frames', type=int, default=4, help='timed frames of the CPU baseline (0 = skip)')
+    ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL, default) | gloo (validation of the N>1 path on a 1-GPU box)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -126,11 +127,15 @@ def main():
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)')
-    dev = torch.device('cuda', local)
+    dev = torch.device('cuda', local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)  # RCCL; used only for the barrier + max-reduce of the time
+        # RCCL; used only for the barrier + max-reduce of the time (no data-path collective)
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     h, w, grid = args.height, args.width, args.grid
     cfg = default_config(h, w, semantics=args.semantics, integrate_mode=args.mode)
@@ -174,7 +179,7 @@ def main():
         elapsed = time.perf_counter() - t0
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == 'nccl' else 'cpu')
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     stages = pipe.stage_times_ms()  # live HIP events recorded on the launch stream inside the timed region
