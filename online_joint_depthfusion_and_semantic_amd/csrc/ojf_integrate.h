@@ -5,17 +5,21 @@
 
 namespace ojf {
 
-struct alignas(8) VoxelAcc {
-    unsigned long long w;  // sum of corner weights, 2^-36 fixed point (two's complement)
-    unsigned long long u;  // sum of weight * clamped update
-    unsigned int e_last;   // 1 + highest entry id that hit this voxel (0 = untouched)
-    unsigned int e_diff;   // 1 + highest entry id whose class differs from the voxel's old class
+// One partial sum of one voxel, produced by one pixel tile (or one entry on the slow paths).  Records of
+// a voxel form a singly linked list hanging off the dense `head` table (index + 1, 0 = end).
+struct alignas(16) VoxelRec {
+    unsigned int lin;       // linear voxel index
+    unsigned int next;      // next record of the same voxel (index + 1), 0 = end of list
+    unsigned long long w;   // sum of corner weights, 2^-36 fixed point (two's complement)
+    unsigned long long u;   // sum of weight * clamped update
+    unsigned int e_last;    // 1 + highest entry id in this partial
+    unsigned int e_diff;    // 1 + highest entry id whose class differs from the voxel's old class (0 = none)
 };
-static_assert(sizeof(VoxelAcc) == 24, "VoxelAcc layout");
+static_assert(sizeof(VoxelRec) == 32, "VoxelRec layout");
 
 constexpr double kFixScale = 68719476736.0;          // 2^36
 constexpr double kFixInv = 1.0 / 68719476736.0;
-constexpr size_t kHeaderBytes = 256;                  // counters: [0] touched voxels, [1] entries
+constexpr size_t kHeaderBytes = 256;                  // counters: [0] touched voxels, [1] entries, [2] records
 
 struct IntegrateArgs {
     const float *depth;  // filtered frame
@@ -27,7 +31,8 @@ struct IntegrateArgs {
     uint8_t *id_vol;
     uint16_t *score_vol;
     unsigned int *counters;
-    VoxelAcc *acc;
+    unsigned int *head;   // dense [X*Y*Z]: first record of the voxel (index + 1), 0 = untouched; left zeroed
+    VoxelRec *recs;
     unsigned int *touched;
     uint32_t *stats;
     int X, Y, Z, h, w, n_points, n_tail, est_stride;

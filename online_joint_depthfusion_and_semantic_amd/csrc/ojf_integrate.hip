@@ -5,49 +5,51 @@
 // FAST mode (this file).  Colliding voxel writes (~16 entries per touched voxel) are resolved with
 // order-free integer arithmetic so that the result does not depend on scheduling:
 //   * sum(w) and sum(w*v) are accumulated as 2^-36 fixed point in 64-bit integers (integer adds
-//     are associative, so any combining order - in-wave, in-LDS, global atomics - gives the same
+//     are associative, so any combining order - in-LDS per tile, then per voxel - gives the same
 //     bits); the total is rounded once to fp32 where the reference rounds after every add, which
 //     moves at most a handful of voxels per frame by one fp16 ulp;
 //   * the semantic "last writer wins" rule is an integer max over entry ids, i.e. exact.
-// Per-voxel accumulators live in a dense workspace that every call leaves zeroed: the finalize
-// pass walks the list of touched voxels, applies the running-mean update and clears its records.
+// Each pixel tile emits ONE record per voxel it touches and links it into that voxel's list with a
+// single atomic exchange on a dense 4-byte head table (measured: every additional global atomic per
+// record costs ~18 us per frame, a per-record append to one shared counter ~350 us).  The finalize
+// pass walks the touched voxels, sums their 2-3 records, applies the running-mean update and zeroes
+// the head entries, so every call leaves the workspace clean.
 //
 // PARITY mode (ojf_integrate_parity.hip) reproduces the reference's sequential fp32 sums bit for bit.
-#include <cstdlib>
-
 #include "ojf_integrate.h"
 
 namespace ojf {
+
+static size_t record_capacity(size_t entries) { return entries; }  // worst case: every entry its own record
 
 size_t fast_workspace_bytes(int X, int Y, int Z, int h, int w, int n_tail)
 {
     const size_t nvox = (size_t)X * Y * Z;
     const size_t entries = (size_t)h * w * n_tail * 8;
     const size_t cap = entries < nvox ? entries : nvox;
-    return kHeaderBytes + nvox * sizeof(VoxelAcc) + cap * sizeof(unsigned int);
+    return kHeaderBytes + nvox * sizeof(unsigned int) + record_capacity(entries) * sizeof(VoxelRec) + cap * sizeof(unsigned int);
+}
+
+constexpr int kSlots = 2048;
+constexpr unsigned int kEmpty = 0xffffffffu;
+
+// publish one record; returns true when this is the voxel's first record of the frame
+__device__ __forceinline__ bool link_record(const IntegrateArgs &a, unsigned int idx, unsigned int lin,
+                                            unsigned long long xw, unsigned long long xu, unsigned int e_last,
+                                            unsigned int e_diff)
+{
+    const unsigned int prev = atomicExch(&a.head[lin], idx + 1u);
+    VoxelRec r;
+    r.lin = lin; r.next = prev; r.w = xw; r.u = xu; r.e_last = e_last; r.e_diff = e_diff;
+    a.recs[idx] = r;
+    return prev == 0;
 }
 
 // LDS-aggregated accumulate: one block owns an 8x8 pixel tile and all n_tail samples of its rays.
 // A wave is the 64 pixels of the tile at one ray offset, so its lanes hit a few dozen distinct voxels;
-// colliding writes are first combined in a 2048-slot LDS hash (integer adds / maxima: order-free,
-// hence still bit-deterministic), and only one record per (tile, voxel) goes to HBM.  This removes
-// the serialised same-address global atomics that dominated the direct kernel (~16 entries/voxel ->
-// ~2.6 tiles/voxel; measured 686 us for per-entry global atomics -> 96 us).  A full hash falls back to
-// direct global atomics for that entry.
-constexpr int kSlots = 2048;
-constexpr unsigned int kEmpty = 0xffffffffu;
-
-__device__ __forceinline__ void global_accumulate(const IntegrateArgs &a, unsigned int lin, unsigned long long xw,
-                                                  unsigned long long xu, unsigned int e_last, unsigned int e_diff)
-{
-    VoxelAcc *rec = a.acc + lin;
-    const unsigned int prev = atomicMax(&rec->e_last, e_last);
-    if (prev == 0) a.touched[atomicAdd(&a.counters[0], 1u)] = lin;
-    atomicAdd(&rec->w, xw);
-    atomicAdd(&rec->u, xu);
-    if (e_diff) atomicMax(&rec->e_diff, e_diff);
-}
-
+// colliding writes are first combined in a 2048-slot LDS hash (integer adds / maxima), and only one
+// record per (tile, voxel) goes to HBM (~16 entries/voxel -> ~2.6 tiles/voxel).  Entries that find the
+// hash full become single-entry records.
 __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(IntegrateArgs a, Camera cam)
 {
     __shared__ unsigned int keys[kSlots];
@@ -56,11 +58,11 @@ __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(Integra
     __shared__ unsigned int elast[kSlots];
     __shared__ unsigned int ediff[kSlots];
     __shared__ unsigned int newlist[kSlots];  // voxels this tile touched first
-    __shared__ unsigned int n_entries, n_new, base_new;
+    __shared__ unsigned int n_entries, n_new, base_new, n_rec, base_rec;
     for (int s = threadIdx.x; s < kSlots; s += 256) {
         keys[s] = kEmpty; accw[s] = 0; accu[s] = 0; elast[s] = 0; ediff[s] = 0;
     }
-    if (threadIdx.x == 0) { n_entries = 0; n_new = 0; }
+    if (threadIdx.x == 0) { n_entries = 0; n_new = 0; n_rec = 0; }
     __syncthreads();
 
     const int tiles_x = (a.w + 7) >> 3;
@@ -111,31 +113,36 @@ __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(Integra
                 atomicAdd(&accu[slot], xu);
                 atomicMax(&elast[slot], e);
                 if (ed) atomicMax(&ediff[slot], ed);
-            } else {
-                global_accumulate(a, lin, xw, xu, e, ed);
+            } else {  // hash full: a record of its own (rare)
+                const unsigned int ridx = atomicAdd(&a.counters[2], 1u);
+                if (link_record(a, ridx, lin, xw, xu, e, ed)) a.touched[atomicAdd(&a.counters[0], 1u)] = lin;
             }
         }
     }
     if (n_in) atomicAdd(&n_entries, n_in);
     __syncthreads();
-    // one HBM record per (tile, voxel).  First touches are collected in LDS and appended to the
-    // global touched list with ONE counter atomic per tile: a per-record append on the single
-    // counter word serialises at the memory side (measured: 350 us of a 440 us kernel).
-    for (int s = threadIdx.x; s < kSlots; s += 256) {
-        const unsigned int lin = keys[s];
-        if (lin == kEmpty) continue;
-        VoxelAcc *rec = a.acc + lin;
-        const unsigned int prev = atomicMax(&rec->e_last, elast[s]);
-        if (prev == 0) newlist[atomicAdd(&n_new, 1u)] = lin;
-        atomicAdd(&rec->w, accw[s]);
-        atomicAdd(&rec->u, accu[s]);
-        if (ediff[s]) atomicMax(&rec->e_diff, ediff[s]);
+    // count this tile's records, reserve their range with ONE counter atomic, then publish them
+    unsigned int mine[kSlots / 256];
+#pragma unroll
+    for (int j = 0; j < kSlots / 256; ++j) {
+        const int s = threadIdx.x + 256 * j;
+        mine[j] = keys[s] != kEmpty ? atomicAdd(&n_rec, 1u) : kEmpty;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (n_new) base_new = atomicAdd(&a.counters[0], n_new);
+        if (n_rec) base_rec = atomicAdd(&a.counters[2], n_rec);
         if (n_entries) atomicAdd(&a.counters[1], n_entries);
     }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kSlots / 256; ++j) {
+        if (mine[j] == kEmpty) continue;
+        const int s = threadIdx.x + 256 * j;
+        const unsigned int lin = keys[s];
+        if (link_record(a, base_rec + mine[j], lin, accw[s], accu[s], elast[s], ediff[s])) newlist[atomicAdd(&n_new, 1u)] = lin;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && n_new) base_new = atomicAdd(&a.counters[0], n_new);
     __syncthreads();
     for (unsigned int i = threadIdx.x; i < n_new; i += 256) a.touched[base_new + i] = newlist[i];
 }
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(Integra
 // Entry-list variant for the reference's own Integrator.forward signature (modules/integrator.py:15-126):
 // the caller hands over materialised updates - per row r (valid pixel x sample) a clamped value, 8 int64
 // corner indices and 8 fp64 corner weights - exactly the tensors Pipeline._prepare_volume_update builds
-// (pipeline.py:137-171).  Same order-free accumulators and the same finalize pass as the fused path;
+// (pipeline.py:137-171).  Every in-volume entry becomes its own record (index r*8 + q: no counter);
 // entry id = r*8 + q reproduces the reference's entry order for the semantic "last writer wins" rule.
 struct EntryArgs {
     const float *values;     // [R]
@@ -174,12 +181,10 @@ __global__ __launch_bounds__(256) void integrate_entries_kernel(IntegrateArgs a,
             const float we = (float)e.weights[(size_t)r * 8 + q];  // integrator.py:45
             const float ue = we * v;                               // integrator.py:55
             const unsigned int eid = (unsigned int)r * 8u + q + 1u;
-            VoxelAcc *rec = a.acc + lin;
-            const unsigned int prev = atomicMax(&rec->e_last, eid);
-            if (prev == 0) newlist[atomicAdd(&n_new, 1u)] = lin;
-            atomicAdd(&rec->w, (unsigned long long)__double2ll_rn((double)we * kFixScale));
-            atomicAdd(&rec->u, (unsigned long long)__double2ll_rn((double)ue * kFixScale));
-            if (sem && a.id_vol[lin] != id_e) atomicMax(&rec->e_diff, eid);
+            const unsigned int ed = (sem && a.id_vol[lin] != id_e) ? eid : 0u;
+            if (link_record(a, (unsigned int)r * 8u + q, lin, (unsigned long long)__double2ll_rn((double)we * kFixScale),
+                            (unsigned long long)__double2ll_rn((double)ue * kFixScale), eid, ed))
+                newlist[atomicAdd(&n_new, 1u)] = lin;
             ++n_in;
         }
     }
@@ -200,11 +205,20 @@ __global__ __launch_bounds__(256) void integrate_finalize_kernel(IntegrateArgs a
     const bool sem = a.id_vol != nullptr;
     for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
         const size_t lin = a.touched[t];
-        VoxelAcc *rec = a.acc + lin;
-        const VoxelAcc r = *rec;
-        rec->w = 0; rec->u = 0; rec->e_last = 0; rec->e_diff = 0;  // leave the workspace clean
-        const float W = (float)((double)(long long)r.w * kFixInv);
-        const float U = (float)((double)(long long)r.u * kFixInv);
+        unsigned int ri = a.head[lin];
+        a.head[lin] = 0;  // leave the workspace clean
+        long long sw = 0, su = 0;
+        unsigned int e_last = 0, e_diff = 0;
+        while (ri) {  // 2-3 records per voxel; integer sums: any order gives the same bits
+            const VoxelRec r = a.recs[ri - 1];
+            sw += (long long)r.w;
+            su += (long long)r.u;
+            e_last = r.e_last > e_last ? r.e_last : e_last;
+            e_diff = r.e_diff > e_diff ? r.e_diff : e_diff;
+            ri = r.next;
+        }
+        const float W = (float)((double)sw * kFixInv);
+        const float U = (float)((double)su * kFixInv);
         const float w_old = h2f(a.wgt[lin]), v_old = h2f(a.tsdf[lin]);  // integrator.py:72-75
         const float w_new = w_old + W;                                   // :77
         const float num = w_old * v_old + U;                             // :82
@@ -212,10 +226,10 @@ __global__ __launch_bounds__(256) void integrate_finalize_kernel(IntegrateArgs a
         a.tsdf[lin] = f2h(num / w_new);                                  // :83,88
         if (sem) {  // integrator.py:93-124 with "highest entry wins" for duplicates
             const float s_old = h2f(a.score_vol[lin]);
-            const float s_last = a.sem_scores[(r.e_last - 1u) / per_pixel];
+            const float s_last = a.sem_scores[(e_last - 1u) / per_pixel];
             a.score_vol[lin] = f2h(s_last > s_old ? s_last : s_old);     // :113-114,124
-            if (r.e_diff) {                                               // :105,116-117,123
-                const unsigned int n_d = (r.e_diff - 1u) / per_pixel;
+            if (e_diff) {                                                 // :105,116-117,123
+                const unsigned int n_d = (e_diff - 1u) / per_pixel;
                 if (a.sem_scores[n_d] > s_old) a.id_vol[lin] = a.sem_ids[n_d];
             }
         }
@@ -223,7 +237,7 @@ __global__ __launch_bounds__(256) void integrate_finalize_kernel(IntegrateArgs a
     if (a.stats && blockIdx.x == 0 && threadIdx.x == 0) {
         a.stats[0] = count;
         a.stats[1] = a.counters[1];
-        a.stats[2] = 0;
+        a.stats[2] = a.counters[2];
         a.stats[3] = 0;
     }
 }
@@ -247,8 +261,8 @@ OJF_API int ojf_integrate_workspace_init(void *ws, size_t ws_bytes, int X, int Y
     const size_t need = ojf_integrate_workspace_bytes(X, Y, Z, h, w, n_tail, mode);
     if (need == 0) return fail("ojf_integrate_workspace_init: bad sizes or mode");
     if (ws_bytes < need) return fail("ojf_integrate_workspace_init: workspace too small");
-    // FAST: header + dense accumulators must start zeroed (every call restores that invariant)
-    const size_t zero_bytes = mode == OJF_MODE_FAST ? kHeaderBytes + (size_t)X * Y * Z * sizeof(VoxelAcc)
+    // FAST: header + dense head table must start zeroed (every call restores that invariant)
+    const size_t zero_bytes = mode == OJF_MODE_FAST ? kHeaderBytes + (size_t)X * Y * Z * sizeof(unsigned int)
                                                     : kHeaderBytes;
     return check_hip(hipMemsetAsync(ws, 0, zero_bytes, as_stream(stream)), "workspace memset");
 }
@@ -282,7 +296,7 @@ OJF_API int ojf_integrate(const float *depth_filtered, const float *Ki, const fl
     a.depth = depth_filtered; a.est = est; a.tsdf = tsdf; a.wgt = wgt;
     a.sem_ids = sem_ids; a.sem_scores = sem_scores; a.id_vol = id_vol; a.score_vol = score_vol;
     a.counters = reinterpret_cast<unsigned int *>(base);
-    a.acc = nullptr; a.touched = nullptr; a.stats = stats;
+    a.head = nullptr; a.recs = nullptr; a.touched = nullptr; a.stats = stats;
     a.X = X; a.Y = Y; a.Z = Z; a.h = h; a.w = w; a.n_points = n_points; a.n_tail = n_tail;
     a.est_stride = est_stride; a.trunc = trunc;
     const Camera cam = make_camera(Ki, E, origin, res);
@@ -290,8 +304,12 @@ OJF_API int ojf_integrate(const float *depth_filtered, const float *Ki, const fl
     OJF_HIP(hipMemsetAsync(a.counters, 0, kHeaderBytes, st));
     if (mode == OJF_MODE_PARITY) return integrate_parity(a, cam, base + kHeaderBytes, ws_bytes - kHeaderBytes, st);
 
-    a.acc = reinterpret_cast<VoxelAcc *>(base + kHeaderBytes);
-    a.touched = reinterpret_cast<unsigned int *>(base + kHeaderBytes + (size_t)X * Y * Z * sizeof(VoxelAcc));
+    {
+        const size_t nvox = (size_t)X * Y * Z, entries = (size_t)h * w * n_tail * 8;
+        a.head = reinterpret_cast<unsigned int *>(base + kHeaderBytes);
+        a.recs = reinterpret_cast<VoxelRec *>(base + kHeaderBytes + nvox * sizeof(unsigned int));
+        a.touched = reinterpret_cast<unsigned int *>(base + kHeaderBytes + nvox * sizeof(unsigned int) + entries * sizeof(VoxelRec));
+    }
     const int tiles = ((h + 7) / 8) * ((w + 7) / 8);
     hipLaunchKernelGGL(integrate_accumulate_tiled_kernel, dim3(tiles), dim3(256), 0, st, a, cam);
     OJF_HIP(hipGetLastError());
@@ -314,7 +332,8 @@ OJF_API int ojf_integrate_entries(const float *values, const int64_t *indices, c
         return fail("ojf_integrate_entries: row_ids, row_scores, id_vol, score_vol must be all set or all NULL");
     const size_t nvox = (size_t)X * Y * Z;
     const size_t entries = (size_t)n_rows * 8;
-    const size_t need = kHeaderBytes + nvox * sizeof(VoxelAcc) + (entries < nvox ? entries : nvox) * sizeof(unsigned int);
+    const size_t need = kHeaderBytes + nvox * sizeof(unsigned int) + entries * sizeof(VoxelRec) +
+                        (entries < nvox ? entries : nvox) * sizeof(unsigned int);
     if (ws_bytes < need) return fail("ojf_integrate_entries: workspace too small");
     hipStream_t st = as_stream(stream);
     char *base = static_cast<char *>(ws);
@@ -322,8 +341,9 @@ OJF_API int ojf_integrate_entries(const float *values, const int64_t *indices, c
     a.depth = nullptr; a.est = nullptr; a.tsdf = tsdf; a.wgt = wgt;
     a.sem_ids = row_ids; a.sem_scores = row_scores; a.id_vol = id_vol; a.score_vol = score_vol;
     a.counters = reinterpret_cast<unsigned int *>(base);
-    a.acc = reinterpret_cast<VoxelAcc *>(base + kHeaderBytes);
-    a.touched = reinterpret_cast<unsigned int *>(base + kHeaderBytes + nvox * sizeof(VoxelAcc));
+    a.head = reinterpret_cast<unsigned int *>(base + kHeaderBytes);
+    a.recs = reinterpret_cast<VoxelRec *>(base + kHeaderBytes + nvox * sizeof(unsigned int));
+    a.touched = reinterpret_cast<unsigned int *>(base + kHeaderBytes + nvox * sizeof(unsigned int) + entries * sizeof(VoxelRec));
     a.stats = stats;
     a.X = X; a.Y = Y; a.Z = Z; a.h = 1; a.w = 1; a.n_points = 1; a.est_stride = 0; a.trunc = 0.0f;
     a.n_tail = 1;  // finalize maps entry id -> row as (id - 1) / (n_tail * 8)

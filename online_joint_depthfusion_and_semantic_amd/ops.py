@@ -127,15 +127,16 @@ def integrate(depth_filtered, Ki, E, origin, resolution, est, tsdf, weights, wor
 
 
 class EntryWorkspace:
-    """FAST-mode scratch for ``integrate_entries``: header + 24 B/voxel accumulators + touched list."""
+    """FAST-mode scratch for ``integrate_entries``: header + 4 B/voxel head table + one 32-B record per entry
+    + touched list (layout of csrc/ojf_integrate.hip)."""
 
     def __init__(self, shape, max_rows, device):
         _lib.require_gpu()
         X, Y, Z = shape
         nvox = X * Y * Z
         self.shape, self.max_rows = tuple(shape), int(max_rows)
-        self.bytes = 256 + nvox * 24 + min(self.max_rows * 8, nvox) * 4
-        self.buf = torch.zeros(self.bytes, dtype=torch.uint8, device=device)  # accumulators start clean
+        self.bytes = 256 + nvox * 4 + self.max_rows * 8 * 32 + min(self.max_rows * 8, nvox) * 4
+        self.buf = torch.zeros(self.bytes, dtype=torch.uint8, device=device)  # the head table starts clean
         self.stats = torch.zeros(4, dtype=torch.int32, device=device)
 
 

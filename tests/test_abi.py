@@ -55,4 +55,5 @@ def test_argument_validation_without_device():
                            None, None, None, None, None) != 0
     assert b'null' in lib.ojf_last_error()
     assert lib.ojf_integrate_workspace_bytes(0, 8, 8, 4, 4, 7, 0) == 0
-    assert lib.ojf_integrate_workspace_bytes(8, 8, 8, 4, 4, 7, 0) == 256 + 512 * 24 + 512 * 4
+    # header + 4 B/voxel head table + one 32-B record per entry + touched list
+    assert lib.ojf_integrate_workspace_bytes(8, 8, 8, 4, 4, 7, 0) == 256 + 512 * 4 + 896 * 32 + 512 * 4
