@@ -49,8 +49,10 @@ int ojf_device_count(void);
  * Replaces Extractor.forward (modules/extractor.py:24-79): compute_coordinates (:82-120),
  * extract_values (:309-345), interpolation_weights (:533-593), trilinear_interpolation (:640-681).
  * depth: dev f32[h*w], the UNFILTERED frame (modules/pipeline.py:202).
- * out_values / out_weights: dev f32, element (pixel n, sample k) at [n*out_stride + k]; the
- *   reference's fusion_values / fusion_weights are the out_stride == n_points case.
+ * out_values / out_weights: dev f32.  out_layout 0 (rows): element (pixel n, sample k) at
+ *   [n*out_stride + k] - the reference's fusion_values / fusion_weights are the out_stride == n_points
+ *   case.  out_layout 1 (sample planes): element at [k*out_stride + n], out_stride >= h*w - every store of
+ *   a wave is contiguous (the row layout scatters 4-byte stores at a 36-byte pitch: 6x write traffic).
  * pad_value: what out-of-volume corners read for TSDF (-0.1 in the reference, extractor.py:663).
  * Optional debug outputs (NULL to skip) reproduce the other entries of the reference's dict:
  *   dbg_indices i64[h*w,n_points,8,3], dbg_weights f64[h*w,n_points,8], dbg_points f64[h*w,n_points,3],
@@ -59,7 +61,7 @@ int ojf_extract(const float *depth_dev, const float *Kinv_host, const float *E_h
                 const double *origin_host, double resolution, const uint16_t *tsdf_dev,
                 const uint16_t *weights_dev, int X, int Y, int Z, int h, int w, int n_points,
                 float pad_value, float *out_values_dev, float *out_weights_dev, int out_stride,
-                int64_t *dbg_indices_dev, double *dbg_weights_dev, double *dbg_points_dev,
+                int out_layout, int64_t *dbg_indices_dev, double *dbg_weights_dev, double *dbg_points_dev,
                 float *dbg_pcl_dev, ojf_stream_t stream);
 
 /* ---- INTEGRATE -----------------------------------------------------------------------------
@@ -118,12 +120,13 @@ void ojf_net_destroy(ojf_net *net);
 /* number of folded conv layers ojf_net_create expects for this topology, <0 if unsupported */
 int ojf_net_layer_count(int version, int n_points, int growth, int use_semantics);
 /* Packs the net's input from the extractor's row-major outputs (modules/pipeline.py:74-102):
- * channels [0,P) fusion_values, [P,2P) fusion_weights (both [h*w, rows_stride] f32), [2P] the depth
+ * channels [0,P) fusion_values, [P,2P) fusion_weights (both f32, laid out as ojf_extract's out_layout
+ * `in_layout` with stride `rows_stride`), [2P] the depth
  * frame; with semantics (v3) a second head gets values | weights | (1+sem_id)/n_classes
  * (model.py:274), v2 appends the semantic channel to the single head (model.py:207).  The net's
  * internal activation layout (planes of 4 channels) is private to the library. */
 int ojf_net_prepare_input(ojf_net *net, const float *values_dev, const float *weights_dev, int rows_stride,
-                          const float *depth_dev, const uint8_t *sem_ids_dev, int n_classes,
+                          int in_layout, const float *depth_dev, const uint8_t *sem_ids_dev, int n_classes,
                           ojf_stream_t stream);
 /* Runs the net; est_dev receives output_scale*tanh(.) for (pixel n, sample k) at [n*est_stride+k]. */
 int ojf_net_forward(ojf_net *net, float *est_dev, int est_stride, ojf_stream_t stream);

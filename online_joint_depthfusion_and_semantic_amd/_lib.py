@@ -34,7 +34,7 @@ SIGNATURES = {
     'ojf_version': (_c.c_char_p, []),
     'ojf_last_error': (_c.c_char_p, []),
     'ojf_device_count': (_i, []),
-    'ojf_extract': (_i, [_vp, _vp, _vp, _vp, _d, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i,
+    'ojf_extract': (_i, [_vp, _vp, _vp, _vp, _d, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _i,
                          _vp, _vp, _vp, _vp, _vp]),
     'ojf_integrate_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     'ojf_integrate_workspace_init': (_i, [_vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -44,7 +44,7 @@ SIGNATURES = {
     'ojf_net_create': (_i, [_c.POINTER(_vp), _i, _i, _i, _i, _f, _c.POINTER(ConvLayer), _i, _i, _i]),
     'ojf_net_destroy': (None, [_vp]),
     'ojf_net_layer_count': (_i, [_i, _i, _i, _i]),
-    'ojf_net_prepare_input': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
+    'ojf_net_prepare_input': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp]),
     'ojf_net_forward': (_i, [_vp, _vp, _i, _vp]),
     'ojf_net_macs_per_pixel': (_c.c_int64, [_vp]),
     'ojf_conv2d': (_i, [_vp, _i, _i, _vp, _i, _i, _c.POINTER(ConvLayer), _i, _i, _i, _vp]),

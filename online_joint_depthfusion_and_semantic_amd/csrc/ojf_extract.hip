@@ -20,7 +20,7 @@ struct ExtractArgs {
     double *dbg_w;
     double *dbg_pts;
     float *dbg_pcl;
-    int X, Y, Z, h, w, n_points, out_stride;
+    int X, Y, Z, h, w, n_points, out_stride, out_layout;
     float pad_value;
 };
 
@@ -67,8 +67,9 @@ __global__ __launch_bounds__(256) void extract_kernel(ExtractArgs a, Camera cam)
         sv += (double)val[q] * wq[q];
         sw += (double)wt[q] * wq[q];
     }
-    a.out_values[(size_t)n * a.out_stride + k] = (float)sv;
-    a.out_weights[(size_t)n * a.out_stride + k] = (float)sw;
+    const size_t o = a.out_layout ? (size_t)k * a.out_stride + n : (size_t)n * a.out_stride + k;
+    a.out_values[o] = (float)sv;
+    a.out_weights[o] = (float)sw;
 
     if (a.dbg_w) {
         double *o = a.dbg_w + ((size_t)n * a.n_points + k) * 8;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void extract_kernel(ExtractArgs a, Camera cam)
 OJF_API int ojf_extract(const float *depth, const float *Ki, const float *E, const double *origin,
                         double res, const uint16_t *tsdf, const uint16_t *wgt, int X, int Y, int Z,
                         int h, int w, int n_points, float pad_value, float *out_values,
-                        float *out_weights, int out_stride, int64_t *dbg_idx, double *dbg_w,
+                        float *out_weights, int out_stride, int out_layout, int64_t *dbg_idx, double *dbg_w,
                         double *dbg_pts, float *dbg_pcl, ojf_stream_t stream)
 {
     using namespace ojf;
@@ -99,11 +100,13 @@ OJF_API int ojf_extract(const float *depth, const float *Ki, const float *E, con
     if (X <= 0 || Y <= 0 || Z <= 0 || h <= 0 || w <= 0)
         return fail("ojf_extract: non-positive volume or frame size");
     if (n_points < 1 || (n_points & 1) == 0) return fail("ojf_extract: n_points must be odd and >= 1");
-    if (out_stride < n_points) return fail("ojf_extract: out_stride < n_points");
+    if (out_layout != 0 && out_layout != 1) return fail("ojf_extract: out_layout must be 0 (rows) or 1 (sample planes)");
+    if (out_layout == 0 && out_stride < n_points) return fail("ojf_extract: out_stride < n_points");
+    if (out_layout == 1 && out_stride < h * w) return fail("ojf_extract: plane stride < h*w");
     if ((int64_t)h * w * n_points > 0x7fffffffLL) return fail("ojf_extract: frame too large");
     if (!(res > 0.0)) return fail("ojf_extract: resolution must be > 0");
     ExtractArgs a{depth, tsdf, wgt, out_values, out_weights, dbg_idx, dbg_w, dbg_pts, dbg_pcl,
-                  X, Y, Z, h, w, n_points, out_stride, pad_value};
+                  X, Y, Z, h, w, n_points, out_stride, out_layout, pad_value};
     const Camera cam = make_camera(Ki, E, origin, res);
     const int items = h * w * n_points;
     hipLaunchKernelGGL(extract_kernel, dim3((items + 255) / 256), dim3(256), 0, as_stream(stream), a, cam);

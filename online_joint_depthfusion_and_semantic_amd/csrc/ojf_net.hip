@@ -556,7 +556,7 @@ struct PrepArgs {
     const uint8_t *sem;
     f32x4 *x0;
     f32x4 *x1;
-    int rows_stride, npix, P, cs4, n_classes, v2_sem;
+    int rows_stride, in_layout, npix, P, cs4, n_classes, v2_sem;
 };
 
 // modules/pipeline.py:74-102 _prepare_fusion_input: channels [values(P) | weights(P) | depth | (sem)]
@@ -565,8 +565,11 @@ __global__ __launch_bounds__(256) void prepare_input_kernel(const PrepArgs a)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.npix) return;
-    const float *v = a.values + (size_t)p * a.rows_stride;
-    const float *wt = a.weights + (size_t)p * a.rows_stride;
+    // rows: element (p, c) at [p*stride + c]; sample planes: [c*stride + p]
+    const size_t pix = a.in_layout ? (size_t)p : (size_t)p * a.rows_stride;
+    const size_t chn = a.in_layout ? (size_t)a.rows_stride : 1;
+    const float *v = a.values + pix;
+    const float *wt = a.weights + pix;
     const float d = a.depth[p];
     const float sf = a.sem ? (1.0f + (float)a.sem[p]) / (float)a.n_classes : 0.0f;
     for (int cg = 0; cg < a.cs4; ++cg) {
@@ -575,8 +578,8 @@ __global__ __launch_bounds__(256) void prepare_input_kernel(const PrepArgs a)
         for (int j = 0; j < 4; ++j) {
             const int c = 4 * cg + j;
             float base = 0.0f;
-            if (c < a.P) base = v[c];
-            else if (c < 2 * a.P) base = wt[c - a.P];
+            if (c < a.P) base = v[c * chn];
+            else if (c < 2 * a.P) base = wt[(c - a.P) * chn];
             r0[j] = base;
             r1[j] = base;
             if (c == 2 * a.P) { r0[j] = d; r1[j] = sf; }
@@ -1163,11 +1166,13 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
 }
 
 OJF_API int ojf_net_prepare_input(ojf_net *net, const float *values, const float *weights, int rows_stride,
-                                  const float *depth, const uint8_t *sem_ids, int n_classes, ojf_stream_t stream)
+                                  int in_layout, const float *depth, const uint8_t *sem_ids, int n_classes, ojf_stream_t stream)
 {
     using namespace ojf;
     if (!net || !values || !weights || !depth) return fail("ojf_net_prepare_input: null pointer argument");
-    if (rows_stride < net->P) return fail("ojf_net_prepare_input: rows_stride < n_points");
+    if (in_layout != 0 && in_layout != 1) return fail("ojf_net_prepare_input: in_layout must be 0 or 1");
+    if (in_layout == 0 && rows_stride < net->P) return fail("ojf_net_prepare_input: rows_stride < n_points");
+    if (in_layout == 1 && rows_stride < net->npix) return fail("ojf_net_prepare_input: plane stride < h*w");
     if (net->sem && (!sem_ids || n_classes <= 0))
         return fail("ojf_net_prepare_input: this net uses semantics: sem_ids and n_classes are required");
     PrepArgs a;
@@ -1175,7 +1180,7 @@ OJF_API int ojf_net_prepare_input(ojf_net *net, const float *values, const float
     a.sem = net->sem ? sem_ids : nullptr;
     a.x0 = planes(net->X[0]);
     a.x1 = net->heads == 2 ? planes(net->X[1]) : nullptr;
-    a.rows_stride = rows_stride; a.npix = net->npix; a.P = net->P; a.cs4 = net->cs / 4;
+    a.rows_stride = rows_stride; a.in_layout = in_layout; a.npix = net->npix; a.P = net->P; a.cs4 = net->cs / 4;
     a.n_classes = n_classes;
     a.v2_sem = (net->version == 2 && net->sem) ? 1 : 0;
     hipLaunchKernelGGL(prepare_input_kernel, dim3((a.npix + 255) / 256), dim3(256), 0, as_stream(stream), a);

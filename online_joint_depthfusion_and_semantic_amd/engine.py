@@ -57,16 +57,17 @@ class FusionNetEngine:
         # launches (the four branches' dilated 3x3 pairs) + 1 fused tail; 1 fused prediction-head chain
         self.conv_launches = 2 * net.gf * heads + 4 * n_vortex + 1
 
-    def prepare_input(self, values, weights, depth, sem_ids=None, n_classes=0):
-        """values / weights: cuda f32 [h*w, stride] rows from the extractor; depth: cuda f32 [h,w]."""
+    def prepare_input(self, values, weights, depth, sem_ids=None, n_classes=0, planes=False):
+        """values / weights: cuda f32 from the extractor, rows [h*w, stride] or (planes=True) sample planes
+        [n_points, h*w]; depth: cuda f32 [h,w]."""
         assert values.is_cuda and values.dtype == torch.float32 and values.is_contiguous()
         assert weights.is_cuda and weights.dtype == torch.float32 and weights.is_contiguous()
-        assert values.shape == weights.shape and values.shape[0] == self.h * self.w
+        assert values.shape == weights.shape and values.shape[1 if planes else 0] == self.h * self.w
         assert depth.is_cuda and depth.dtype == torch.float32 and depth.is_contiguous()
         if sem_ids is not None:
             assert sem_ids.is_cuda and sem_ids.dtype == torch.uint8 and sem_ids.is_contiguous()
         rc = self.lib.ojf_net_prepare_input(self.handle, _lib.ptr(values), _lib.ptr(weights), values.shape[-1],
-                                            _lib.ptr(depth), _lib.ptr(sem_ids), int(n_classes),
+                                            1 if planes else 0, _lib.ptr(depth), _lib.ptr(sem_ids), int(n_classes),
                                             _lib.stream_ptr(self.device))
         _lib.check(rc, 'ojf_net_prepare_input')
 

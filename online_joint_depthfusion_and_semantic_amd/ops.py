@@ -38,11 +38,12 @@ def _vol16(t):
 
 
 def extract(depth, Ki, E, origin, resolution, tsdf, weights, n_points=9, pad_value=-0.1,
-            out_values=None, out_weights=None, out_stride=None, debug=False):
+            out_values=None, out_weights=None, out_stride=None, debug=False, planes=False):
     """Gather along the depth rays.  depth: cuda f32 [h,w] (or [1,h,w]).  Returns a dict with
     fusion_values / fusion_weights [h*w, n_points] (plus indices / weights / points / pcl when
     ``debug``).  ``out_values``/``out_weights``/``out_stride`` let the caller place the result
-    inside a wider row buffer (the net's input rows)."""
+    inside a wider row buffer; ``planes=True`` selects the coalesced sample-plane layout
+    [n_points, h*w] (element (n,k) at [k*stride + n]) that Pipeline.fuse feeds to the net."""
     _lib.require_gpu()
     lib = _lib.load()
     depth = depth.reshape(depth.shape[-2], depth.shape[-1])
@@ -53,9 +54,10 @@ def extract(depth, Ki, E, origin, resolution, tsdf, weights, n_points=9, pad_val
     assert _vol16(weights).shape == tsdf.shape
     dev = depth.device
     if out_values is None:
-        out_stride = n_points
-        out_values = torch.empty((N, n_points), dtype=torch.float32, device=dev)
-        out_weights = torch.empty((N, n_points), dtype=torch.float32, device=dev)
+        out_stride = N if planes else n_points
+        shape = (n_points, N) if planes else (N, n_points)
+        out_values = torch.empty(shape, dtype=torch.float32, device=dev)
+        out_weights = torch.empty(shape, dtype=torch.float32, device=dev)
     origin = _origin_array(origin)
     dbg = {}
     if debug:
@@ -68,7 +70,7 @@ def extract(depth, Ki, E, origin, resolution, tsdf, weights, n_points=9, pad_val
     rc = lib.ojf_extract(_lib.ptr(depth), _lib.ptr(Ki), _lib.ptr(E), _lib.ptr(origin),
                          float(resolution), _lib.ptr(tsdf), _lib.ptr(weights), X, Y, Z, h, w,
                          n_points, float(pad_value), ov, ow,
-                         int(out_stride), _lib.ptr(dbg.get('indices')), _lib.ptr(dbg.get('weights')),
+                         int(out_stride), 1 if planes else 0, _lib.ptr(dbg.get('indices')), _lib.ptr(dbg.get('weights')),
                          _lib.ptr(dbg.get('points')), _lib.ptr(dbg.get('pcl')), _lib.stream_ptr(dev))
     _lib.check(rc, 'ojf_extract')
     out = dict(fusion_values=out_values, fusion_weights=out_weights)

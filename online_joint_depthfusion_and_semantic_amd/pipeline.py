@@ -96,8 +96,8 @@ class Pipeline(torch.nn.Module):
             self._engine = FusionNetEngine(self._fusion_network, h, w, device)
             self._engine_key = key
             self._est = torch.empty((h * w, self.n_points), dtype=torch.float32, device=device)
-            self._fv = torch.empty((h * w, self.n_points), dtype=torch.float32, device=device)
-            self._fw = torch.empty((h * w, self.n_points), dtype=torch.float32, device=device)
+            self._fv = torch.empty((self.n_points, h * w), dtype=torch.float32, device=device)  # sample planes
+            self._fw = torch.empty((self.n_points, h * w), dtype=torch.float32, device=device)
         return self._engine
 
     def _get_workspace(self, shape, h, w, device):
@@ -163,10 +163,11 @@ class Pipeline(torch.nn.Module):
         P = self.n_points
         self._mark()
         ops.extract(frame, Ki, E, volume['origin'], volume['resolution'], tsdf, weights, n_points=P,
-                    out_values=self._fv, out_weights=self._fw, out_stride=P)
+                    out_values=self._fv, out_weights=self._fw, out_stride=h * w, planes=True)
         self._mark()
         use_sem = self.config.FUSION_MODEL.use_semantics
-        eng.prepare_input(self._fv, self._fw, frame, sem_ids if use_sem else None, self.n_classes if use_sem else 0)
+        eng.prepare_input(self._fv, self._fw, frame, sem_ids if use_sem else None, self.n_classes if use_sem else 0,
+                          planes=True)
         eng.forward(self._est)
         self._mark()
 

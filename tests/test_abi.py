@@ -51,7 +51,7 @@ def test_no_silent_cpu_fallback():
 def test_argument_validation_without_device():
     lib = _lib.load()
     # null pointers are rejected before any HIP call
-    assert lib.ojf_extract(None, None, None, None, 0.02, None, None, 8, 8, 8, 4, 4, 9, -0.1, None, None, 9,
+    assert lib.ojf_extract(None, None, None, None, 0.02, None, None, 8, 8, 8, 4, 4, 9, -0.1, None, None, 9, 0,
                            None, None, None, None, None) != 0
     assert b'null' in lib.ojf_last_error()
     assert lib.ojf_integrate_workspace_bytes(0, 8, 8, 4, 4, 7, 0) == 0

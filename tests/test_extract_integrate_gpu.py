@@ -215,3 +215,18 @@ def test_reference_style_extractor_integrator_modules(cuda, semantics):
             assert n_mismatch(gg['ids'].cpu().numpy(), vols['ids']) == 0
             assert n_mismatch(gg['scores'].cpu().numpy(), vols['scores']) == 0
         g = to_cuda(vols, cuda)
+
+
+def test_extract_sample_plane_layout(cuda):
+    """out_layout 1 (sample planes, the layout Pipeline.fuse uses) holds the same bits as the row layout."""
+    st = make_stream(24, 32, 32)
+    rng = np.random.default_rng(9)
+    tsdf = _t(rng.uniform(-0.1, 0.1, (32,) * 3).astype(np.float16), cuda)
+    wgt = _t(rng.uniform(0, 4, (32,) * 3).astype(np.float16), cuda)
+    fi = frame_inputs(st, 1)
+    d = _t(fi['depth'], cuda)
+    rows = ops.extract(d, fi['Ki'], fi['E'], st.origin, st.resolution, tsdf, wgt)
+    pl = ops.extract(d, fi['Ki'], fi['E'], st.origin, st.resolution, tsdf, wgt, planes=True)
+    assert pl['fusion_values'].shape == (9, 24 * 32)
+    assert torch.equal(pl['fusion_values'].t().contiguous(), rows['fusion_values'])
+    assert torch.equal(pl['fusion_weights'].t().contiguous(), rows['fusion_weights'])
