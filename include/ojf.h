@@ -145,7 +145,10 @@ int ojf_conv2d(const float *in_dev, int in_stride, int in_off, float *out_dev, i
  * ojf_volume_filter: Database.filter (:108-112): where weights < value: tsdf = init_value, weights = 0.
  * ojf_volume_evaluate: utils/metrics.py:111-127 evaluation() on device: with mask = weights > 0 and
  *   est/gt clipped to +-0.04, sums_dev f64[8] receives {n_mask, sum_sq_err, sum_abs_err,
- *   n_intersection(est<0 & gt<0), n_union(est<0 | gt<0), n_sign_equal, 0, 0}. */
+ *   n_intersection(est<0 & gt<0), n_union(est<0 | gt<0), n_sign_equal, 0, 0}.
+ * ojf_volume_median5_u8: Database.filter_semantics (:114-116) = scipy.ndimage.median_filter(ids, size=5):
+ *   5x5x5 window, 'reflect' boundary, rank-62 element; out must differ from in. */
+int ojf_volume_median5_u8(const uint8_t *in_dev, uint8_t *out_dev, int X, int Y, int Z, ojf_stream_t stream);
 int ojf_volume_fill_f16(uint16_t *vol_dev, size_t n, float value, ojf_stream_t stream);
 int ojf_volume_fill_u8(uint8_t *vol_dev, size_t n, uint8_t value, ojf_stream_t stream);
 int ojf_volume_filter(uint16_t *tsdf_dev, uint16_t *weights_dev, size_t n, float threshold,

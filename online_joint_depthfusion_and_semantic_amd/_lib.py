@@ -51,6 +51,7 @@ SIGNATURES = {
     'ojf_volume_fill_f16': (_i, [_vp, _sz, _f, _vp]),
     'ojf_volume_fill_u8': (_i, [_vp, _sz, _c.c_uint8, _vp]),
     'ojf_volume_filter': (_i, [_vp, _vp, _sz, _f, _f, _vp]),
+    'ojf_volume_median5_u8': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'ojf_volume_evaluate': (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
 }
 

@@ -81,6 +81,53 @@ __global__ __launch_bounds__(256) void evaluate_kernel(const uint16_t *est, cons
     }
 }
 
+
+// Database.filter_semantics (modules/database.py:114-116): scipy.ndimage.median_filter(ids, size=5) on the
+// u8 label volume - 5x5x5 window, 'reflect' boundary (d c b a | a b c d | d c b a), median = element of
+// rank 62 of the 125 sorted values.  One block filters an 8x8x8 brick: the 12^3 neighbourhood is staged in
+// LDS once, each lane then radix-selects the rank-62 byte of its window (8 bit-steps of counting).
+__device__ __forceinline__ int reflect_index(int i, int n)
+{
+    if (n == 1) return 0;
+    const int period = 2 * n;
+    i %= period;
+    if (i < 0) i += period;
+    return i < n ? i : period - 1 - i;
+}
+
+__global__ __launch_bounds__(512) void median5_u8_kernel(const uint8_t *in, uint8_t *out, int X, int Y, int Z)
+{
+    __shared__ uint8_t tile[12][12][12];
+    const int bx = blockIdx.x * 8, by = blockIdx.y * 8, bz = blockIdx.z * 8;
+    for (int i = threadIdx.x; i < 12 * 12 * 12; i += 512) {
+        const int lx = i / 144, ly = (i / 12) % 12, lz = i % 12;
+        const int gx = reflect_index(bx + lx - 2, X), gy = reflect_index(by + ly - 2, Y), gz = reflect_index(bz + lz - 2, Z);
+        tile[lx][ly][lz] = in[((size_t)gx * Y + gy) * Z + gz];
+    }
+    __syncthreads();
+    const int lx = threadIdx.x >> 6, ly = (threadIdx.x >> 3) & 7, lz = threadIdx.x & 7;
+    const int x = bx + lx, y = by + ly, z = bz + lz;
+    if (x >= X || y >= Y || z >= Z) return;
+    // radix select: fix the bits of the rank-62 element from the most significant down
+    unsigned int prefix = 0, rank = 62;
+    for (int bit = 7; bit >= 0; --bit) {
+        const unsigned int mask = (0xffu << (bit + 1)) & 0xffu;  // bits already decided
+        unsigned int zeros = 0;  // candidates (matching the prefix) whose current bit is 0
+        for (int dx = 0; dx < 5; ++dx)
+            for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+                for (int dz = 0; dz < 5; ++dz) {
+                    const unsigned int v = tile[lx + dx][ly + dy][lz + dz];
+                    zeros += ((v & mask) == prefix && !((v >> bit) & 1u)) ? 1u : 0u;
+                }
+        if (rank >= zeros) {
+            rank -= zeros;
+            prefix |= 1u << bit;
+        }
+    }
+    out[((size_t)x * Y + y) * Z + z] = (uint8_t)prefix;
+}
+
 }  // namespace ojf
 
 OJF_API int ojf_volume_fill_f16(uint16_t *vol, size_t n, float value, ojf_stream_t stream)
@@ -127,4 +174,15 @@ OJF_API int ojf_volume_evaluate(const uint16_t *est, const uint16_t *gt, const u
     hipLaunchKernelGGL(evaluate_kernel, dim3(stream_grid(n)), dim3(256), 0, as_stream(stream), est, gt, wgt, n,
                        sums);
     return check_hip(hipGetLastError(), "ojf_volume_evaluate launch");
+}
+
+OJF_API int ojf_volume_median5_u8(const uint8_t *in, uint8_t *out, int X, int Y, int Z, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (!in || !out) return fail("ojf_volume_median5_u8: null volume");
+    if (in == out) return fail("ojf_volume_median5_u8: in-place filtering is not supported");
+    if (X <= 0 || Y <= 0 || Z <= 0) return fail("ojf_volume_median5_u8: non-positive size");
+    const dim3 grid((X + 7) / 8, (Y + 7) / 8, (Z + 7) / 8);
+    hipLaunchKernelGGL(median5_u8_kernel, grid, dim3(512), 0, as_stream(stream), in, out, X, Y, Z);
+    return check_hip(hipGetLastError(), "ojf_volume_median5_u8 launch");
 }

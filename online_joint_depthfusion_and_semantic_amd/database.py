@@ -179,13 +179,16 @@ class Database(torch.utils.data.Dataset):
                 self.fusion_weights[s][low] = 0
 
     def filter_semantics(self, value=5):
-        from scipy.ndimage import median_filter
+        """database.py:114-116: median filter of the label volume (on device for the reference's size 5)."""
         for s in self.scenes:
             v = self.ids_est[s].volume
-            if torch.is_tensor(v):
-                self.ids_est[s].volume = torch.from_numpy(median_filter(v.cpu().numpy(), size=value)).to(v.device)
+            if _is_dev(v) and value == 5:
+                self.ids_est[s].volume = ops.volume_median5(v)
             else:
-                self.ids_est[s].volume = median_filter(v, size=value)
+                from scipy.ndimage import median_filter
+                host = v.cpu().numpy() if torch.is_tensor(v) else v
+                res = median_filter(host, size=value)
+                self.ids_est[s].volume = torch.from_numpy(res).to(v.device) if torch.is_tensor(v) else res
 
     def evaluate(self, mode='train', workspace=None):
         """database.py:265-309 (note: averages over ALL scenes, untouched ones included, :304)."""

@@ -196,3 +196,15 @@ def volume_evaluate(est, gt, weights):
     n, sq, ab, inter, union, same = sums[:6].tolist()
     eps = 1.e-10
     return {'mse': sq / (n + eps), 'mad': ab / (n + eps), 'iou': inter / (union + eps), 'acc': same / (n + eps)}
+
+
+def volume_median5(ids):
+    """scipy.ndimage.median_filter(ids, size=5) on a cuda u8 volume (Database.filter_semantics)."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    assert ids.is_cuda and ids.dtype == torch.uint8 and ids.is_contiguous() and ids.dim() == 3
+    out = torch.empty_like(ids)
+    X, Y, Z = ids.shape
+    rc = lib.ojf_volume_median5_u8(_lib.ptr(ids), _lib.ptr(out), X, Y, Z, _lib.stream_ptr(ids.device))
+    _lib.check(rc, 'ojf_volume_median5_u8')
+    return out
