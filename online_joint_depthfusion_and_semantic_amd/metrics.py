@@ -43,3 +43,49 @@ def semantic_evaluation(est, target, mask, n_class):
     present = np.where(est_ids | gt_ids)[0]
     metrics = {'Mean Acc': np.sum(acc[1:]) / valid_ids, 'Mean IoU': np.sum(iou[1:]) / valid_ids}
     return metrics, dict(zip(present, iou[present]))
+
+
+# ---- reconstruction F-score ------------------------------------------------------------------------
+# The reference quotes F-scores (README.md:6) but contains no F-score code; this is
+# the engine's own definition, applied identically to oracle volumes and HIP volumes for parity:
+# surface samples = zero crossings of the TSDF along the three grid axes (linear interpolation between
+# two adjacent observed voxels of opposite sign), F = harmonic mean of precision / recall at distance tau.
+
+def surface_points(tsdf, mask, origin, resolution):
+    """Zero-crossing points [M,3] (world units) of a TSDF volume; ``mask`` marks observed voxels."""
+    t = np.nan_to_num(np.asarray(tsdf, dtype=np.float32))
+    m = np.asarray(mask, dtype=bool)
+    pts = []
+    for axis in range(3):
+        a = [slice(None)] * 3
+        b = [slice(None)] * 3
+        a[axis], b[axis] = slice(0, -1), slice(1, None)
+        ta, tb = t[tuple(a)], t[tuple(b)]
+        cross = m[tuple(a)] & m[tuple(b)] & ((ta < 0) != (tb < 0))
+        idx = np.argwhere(cross).astype(np.float64)
+        if idx.size == 0:
+            continue
+        va, vb = ta[cross].astype(np.float64), tb[cross].astype(np.float64)
+        frac = va / (va - vb)  # position of the zero between the two voxel centres
+        idx[:, axis] += frac
+        pts.append((idx + 0.5) * float(resolution) + np.asarray(origin, dtype=np.float64))
+    return np.concatenate(pts, axis=0) if pts else np.zeros((0, 3))
+
+
+def f_score(points_est, points_gt, tau):
+    """Precision, recall and F-score of two point sets at distance threshold ``tau``."""
+    from scipy.spatial import cKDTree
+    if len(points_est) == 0 or len(points_gt) == 0:
+        return {'precision': 0.0, 'recall': 0.0, 'fscore': 0.0}
+    d_e = cKDTree(points_gt).query(points_est)[0]
+    d_g = cKDTree(points_est).query(points_gt)[0]
+    p, r = float((d_e <= tau).mean()), float((d_g <= tau).mean())
+    return {'precision': p, 'recall': r, 'fscore': 0.0 if p + r == 0 else 2 * p * r / (p + r)}
+
+
+def reconstruction_f_score(est, gt, weights, origin, resolution, tau=None):
+    """F-score of the fused TSDF against the ground-truth TSDF restricted to the observed region
+    (weights > 0), threshold tau (default: 1.5 voxels)."""
+    mask = np.asarray(weights) > 0
+    tau = 1.5 * float(resolution) if tau is None else tau
+    return f_score(surface_points(est, mask, origin, resolution), surface_points(gt, mask, origin, resolution), tau)

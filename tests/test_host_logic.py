@@ -154,3 +154,20 @@ def test_synthetic_dataset_and_checkpoint_keys():
     assert g[0].volume.shape == (16, 16, 16) and g[1].volume.dtype == np.uint8
     st = remove_parent({'_fusion_network.pred.0.w': 1, 'x': 2}, '_fusion_network')
     assert st == {'pred.0.w': 1, 'x': 2}
+
+
+def test_f_score_known_answers():
+    # a plane x = 1.03 sampled on an 8 cm grid: the zero crossings of its exact SDF recover the plane
+    g, res, origin = 24, 0.08, np.array([0.0, 0.0, 0.0])
+    xs = (np.arange(g) + 0.5) * res
+    sdf = np.broadcast_to((1.03 - xs)[:, None, None], (g, g, g)).astype(np.float32)
+    pts = metrics.surface_points(sdf, np.ones((g, g, g), bool), origin, res)
+    assert len(pts) == g * g and np.abs(pts[:, 0] - 1.03).max() < 1e-6
+    same = metrics.reconstruction_f_score(sdf, sdf, np.ones_like(sdf), origin, res)
+    assert same == {'precision': 1.0, 'recall': 1.0, 'fscore': 1.0}
+    shifted = np.broadcast_to((1.03 + 0.5 - xs)[:, None, None], (g, g, g)).astype(np.float32)
+    far = metrics.reconstruction_f_score(shifted, sdf, np.ones_like(sdf), origin, res)
+    assert far['fscore'] == 0.0
+    near = metrics.reconstruction_f_score(sdf + 0.05, sdf, np.ones_like(sdf), origin, res)  # 5 cm < 1.5 voxels
+    assert near['fscore'] == 1.0
+    assert metrics.f_score(np.zeros((0, 3)), pts, 0.1)['fscore'] == 0.0

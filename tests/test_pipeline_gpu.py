@@ -128,6 +128,10 @@ def test_stream_config_A_against_oracle(cuda, sem):
     want = metrics.evaluation(vols['tsdf'], gt, vols['wgt'] > 0)
     for k in want:
         assert abs(want[k] - have[k]) <= 1e-3 * max(1.0, abs(want[k])), (k, want[k], have[k])
+    # reconstruction F-score (the engine's own definition, metrics.py) is equal on oracle and HIP volumes
+    f_have = metrics.reconstruction_f_score(got_t, gt, got_w, st.origin, st.resolution)
+    f_want = metrics.reconstruction_f_score(vols['tsdf'], gt, vols['wgt'], st.origin, st.resolution)
+    assert abs(f_have['fscore'] - f_want['fscore']) <= 1e-3 and f_want['fscore'] > 0.05, (f_have, f_want)
     # filter (outlier removal) on device == numpy semantics
     db.filter(value=2.0)
     low = vols['wgt'] < np.float16(2.0)
