@@ -36,6 +36,12 @@ from online_joint_depthfusion_and_semantic_amd.synthetic import SyntheticStream 
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
 F32_MFMA_PEAK_TF = 157.3  # dense fp32-input MFMA peak (v_mfma_f32_16x16x4_f32)
+F16_MFMA_PEAK_TF = 2516.6  # dense fp16 MFMA peak (v_mfma_f32_16x16x32_f16)
+# split-fp16 arithmetic issues three fp16 MFMAs per product block: the rate at which it can retire
+# fp32-equivalent (useful) flops is a third of the fp16 peak
+ARITH = {'f32': ('f32', 'f32-input MFMA (v_mfma_f32_16x16x4_f32)', F32_MFMA_PEAK_TF),
+         'f16x3': ('f16x3', 'split-fp16: 3 x v_mfma_f32_16x16x32_f16 per product block, fp32 accumulate, fp32 activations',
+                   F16_MFMA_PEAK_TF / 3.0)}
 
 
 def seeded_weights(pipe, seed=1911):
@@ -116,6 +122,7 @@ def main():
     ap.add_argument('--grid', type=int, default=256)
     ap.add_argument('--semantics', action='store_true', help='BASELINE configs[2]-style: gt labels + semantic head')
     ap.add_argument('--mode', default='fast', choices=['fast', 'parity'])
+    ap.add_argument('--arith', default='f16x3', choices=['f16x3', 'f32'], help='net MFMA arithmetic (include/ojf.h OJF_ARITH_*)')
     ap.add_argument('--cpu-frames', type=int, default=4, help='timed frames of the CPU baseline (0 = skip)')
     ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL, default) | gloo (validation of the N>1 path on a 1-GPU box)')
     args = ap.parse_args()
@@ -140,6 +147,7 @@ def main():
     h, w, grid = args.height, args.width, args.grid
     cfg = default_config(h, w, semantics=args.semantics, integrate_mode=args.mode)
     cfg.SETTINGS.device = str(dev)
+    cfg.FUSION_MODEL.arithmetic = args.arith
     n_frames = args.steps + args.warmup
     st = SyntheticStream(h, w, grid, n_frames, scene='room_%d' % rank, seed=1911 + rank)
     db = Database(st, database_config(cfg))
@@ -197,24 +205,29 @@ def main():
         tr = pmc_traffic(h, w, grid, args.semantics)
         net_traffic = hbm_traffic = None
         if tr:
-            net_k = [k for k in tr if k.startswith(('conv_mfma', 'chain1x1', 'vortex_tail'))]
+            net_k = [k for k in tr if k.startswith(('conv_mfma', 'conv_f16x3', 'chain1x1', 'vortex_tail'))]
             net_traffic = sum(tr[k]['fetch_bytes_per_frame_x2'] + tr[k]['write_bytes_per_frame'] for k in net_k) / n_conv
             hbm_traffic = sum(tr[k]['fetch_bytes_per_frame_x2'] + tr[k]['write_bytes_per_frame']
                               for k in tr if 'extract' in k or 'integrate' in k)
         out = {
             'metric': 'frames/sec fused (320x240, 256^3 grid)', 'value': fps, 'unit': 'frames/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': ARITH[args.arith][0], 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: geometry-only fusion, %dx%d depth into a %d^3 fp16 TSDF grid, '
                                    'FusionNet_v3%s, one scene per GPU' % (w, h, grid, ' + gt semantics' if args.semantics else ''),
                        'frame': [h, w], 'grid': grid, 'n_points': P, 'n_tail_points': T, 'integrate_mode': args.mode,
-                       'volume_dtype': 'f16', 'net_arithmetic': 'f32 MFMA', 'parallelism': 'scene-sharded x%d' % world},
+                       'volume_dtype': 'f16', 'net_arithmetic': ARITH[args.arith][1], 'parallelism': 'scene-sharded x%d' % world},
             'stages_ms': stages,
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel', 'launches_per_frame': n_conv,
-                         'achieved': flops / net_s / 1e12, 'peak': F32_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
-                         'frac': flops / net_s / 1e12 / F32_MFMA_PEAK_TF, 'traffic': net_traffic,
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_f16x3_kernel' if args.arith == 'f16x3' else 'conv_mfma_kernel',
+                         'launches_per_frame': n_conv,
+                         'achieved': flops / net_s / 1e12, 'peak': ARITH[args.arith][2], 'unit': 'TFLOP/s',
+                         'frac': flops / net_s / 1e12 / ARITH[args.arith][2], 'traffic': net_traffic,
                          'flops_per_frame': flops, 'avg_launch_us': 1e6 * net_s / n_conv,
-                         'note': 'useful flops of all MFMA conv launches of one frame / HIP-event time of the net stage; traffic = PMC HBM bytes per launch (profiles/r01_traffic_pmc.json)'},
+                         'frac_of_f32_mfma_peak': flops / net_s / 1e12 / F32_MFMA_PEAK_TF,
+                         'note': 'useful (fp32-equivalent, padding excluded) flops of all MFMA launches of one frame / HIP-event '
+                                 'time of the net stage; peak = dense MFMA peak of the arithmetic (f16x3: 2516.6/3 TFLOP/s because '
+                                 'every product block costs three fp16 MFMAs; f32: 157.3); traffic = PMC HBM bytes per launch '
+                                 '(profiles/r01_traffic_pmc.json)'},
             'roofline_hbm': {'bound': 'hbm', 'kernel': 'extract_kernel + integrate_*_kernel',
                              'achieved': bytes_frame / ei_s / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                              'frac': bytes_frame / ei_s / 1e9 / HBM_PEAK_GBS, 'traffic': hbm_traffic,

@@ -40,6 +40,11 @@ typedef void *ojf_stream_t; /* hipStream_t */
 #define OJF_ACT_LEAKY 2 /* negative slope 0.01 (nn.LeakyReLU default, modules/model.py:12) */
 #define OJF_ACT_TANH 3
 
+/* arithmetic of the MFMA kernels of the net (fp32 activations in memory, fp32 accumulation in both) */
+#define OJF_ARITH_F32 0   /* v_mfma_f32_16x16x4_f32: a k-ordered fmaf chain */
+#define OJF_ARITH_F16X3 1 /* default: operands split into two fp16 halves, three v_mfma_f32_16x16x32_f16 per
+                             product block; fp32-class accuracy (drops only lo*lo ~ 2^-22), operands < 65504 */
+
 const char *ojf_version(void);
 const char *ojf_last_error(void);
 /* number of visible HIP devices, or <0 with ojf_last_error() set (no GPU / no driver) */
@@ -132,6 +137,11 @@ int ojf_net_prepare_input(ojf_net *net, const float *values_dev, const float *we
 int ojf_net_forward(ojf_net *net, float *est_dev, int est_stride, ojf_stream_t stream);
 /* useful multiply-accumulates per pixel of this topology (padding excluded) */
 int64_t ojf_net_macs_per_pixel(const ojf_net *net);
+/* Arithmetic used by nets created (and ojf_conv2d calls made) AFTER this call: OJF_ARITH_F32 | OJF_ARITH_F16X3.
+ * A net keeps the arithmetic it was created with.  Not thread-safe against concurrent ojf_net_create. */
+int ojf_net_set_arithmetic(int arithmetic);
+/* arithmetic of `net`, or the current default when net == NULL */
+int ojf_net_get_arithmetic(const ojf_net *net);
 
 /* Stand-alone fused convolution on NHWC fp32 rows (the kernel the net is built from; exported so
  * the parity tests can pin it layer by layer against torch.nn.functional.conv2d).

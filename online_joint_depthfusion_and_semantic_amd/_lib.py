@@ -14,6 +14,8 @@ LIB_PATH = os.path.join(_HERE, 'libojf.so')
 MODE_FAST = 0
 MODE_PARITY = 1
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3
+ARITH_F32, ARITH_F16X3 = 0, 1
+ARITHMETIC = {'f32': ARITH_F32, 'f16x3': ARITH_F16X3}
 
 
 class OjfError(RuntimeError):
@@ -47,6 +49,8 @@ SIGNATURES = {
     'ojf_net_prepare_input': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp]),
     'ojf_net_forward': (_i, [_vp, _vp, _i, _vp]),
     'ojf_net_macs_per_pixel': (_c.c_int64, [_vp]),
+    'ojf_net_set_arithmetic': (_i, [_i]),
+    'ojf_net_get_arithmetic': (_i, [_vp]),
     'ojf_conv2d': (_i, [_vp, _i, _i, _vp, _i, _i, _c.POINTER(ConvLayer), _i, _i, _i, _vp]),
     'ojf_volume_fill_f16': (_i, [_vp, _sz, _f, _vp]),
     'ojf_volume_fill_u8': (_i, [_vp, _sz, _c.c_uint8, _vp]),

@@ -45,7 +45,8 @@ def default_config(h=240, w=320, semantics=False, use_semantics=None, n_classes=
         'SETTINGS': {'gpu': True, 'implementation': 'efficient', 'device': 'cuda:0', 'seed': 1911,
                      'integrate_mode': integrate_mode},
         'FUSION_MODEL': {'name': model, 'output_scale': 1.0, 'n_points': 9, 'n_tail_points': 7,
-                         'growth_factor': 6, 'use_semantics': bool(use_semantics)},
+                         'growth_factor': 6, 'use_semantics': bool(use_semantics),
+                         'arithmetic': 'f16x3'},  # 'f16x3' | 'f32' (include/ojf.h OJF_ARITH_*)
         'SEMANTIC_2D_MODEL': {'stage': 2, 'n_classes': n_classes},
         'TRAINING': {'optimization': {'accumulation_steps': 8, 'clipping': True}},
         'TESTING': {'outlier_filter_val': 2},

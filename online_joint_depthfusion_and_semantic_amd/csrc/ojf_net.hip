@@ -1,9 +1,18 @@
 // FUSION NET: eval-mode FusionNet_v3 / FusionNet_v2 (modules/model.py:164-283) as a chain of fused
 // convolution kernels on the gfx950 matrix cores.
 //
-// Arithmetic: fp32 in / fp32 accumulate MFMA (v_mfma_f32_16x16x4_f32) - bitwise a k-ordered fmaf
-// chain, so tsdf_est agrees with the reference's fp32 CPU net to ~1e-6 (tolerance stated in the
-// tests: 1e-5).  The +-0.1 truncation band of the TSDF rules out bf16.
+// Arithmetic (ojf_net_set_arithmetic, captured per net at creation), both with fp32 accumulation and
+// fp32 activations in memory; tsdf_est agrees with the reference's fp32 CPU net to a few 1e-6
+// (tolerance stated in the tests: 1e-5).  The +-0.1 truncation band of the TSDF rules out plain
+// bf16/fp16 operands.
+//   OJF_ARITH_F32   v_mfma_f32_16x16x4_f32: bitwise a k-ordered fmaf chain; 1024 MAC per 32 cycles.
+//   OJF_ARITH_F16X3 (default) split-fp16: x = xh + xl, w = wh + wl with fp16 halves (round to nearest);
+//                   x*w ~= wl*xh + wh*xl + wh*xh on v_mfma_f32_16x16x32_f16 (8192 MAC per 16 cycles,
+//                   three of them per product block: 5.3x the fp32-input MFMA rate).  The dropped wl*xl
+//                   term is <= 2^-22 |x w|; measured layer error is below the fp32 chain's
+//                   (tests/microbench/conv_f16x3_bench.hip).  Operands must stay below 65504 in
+//                   magnitude (fp16 range) - true for TSDF values, fp16 volume weights, metric depth and
+//                   the BN-folded activations of a trained net; OJF_ARITH_F32 has no such limit.
 //
 // Data layout ("C4 planes"): an activation tensor with C channels (padded to a multiple of 4:
 // 19 -> 20, 114 -> 116; pad channels carry zeros) is stored as C/4 planes of float4, element
@@ -39,6 +48,25 @@
 namespace ojf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// x (8 fp32 values) -> fp16 halves xh + xl, both rounded to nearest; x - xh is exact in fp32
+__device__ __forceinline__ void split_f16(const f32x4 &a, const f32x4 &b, f16x8 &hi, f16x8 &lo)
+{
+    const f32x8 x = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    hi = __builtin_convertvector(x, f16x8);
+    lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x8), f16x8);
+}
+
+// acc += W * X for one 16x16 tile over a 32-wide K block, W and X given as split halves
+__device__ __forceinline__ f32x4 mfma_f16x3(const f32x4 &wh, const f32x4 &wl, const f16x8 &xh, const f16x8 &xl, f32x4 acc)
+{
+    const f16x8 h = __builtin_bit_cast(f16x8, wh), l = __builtin_bit_cast(f16x8, wl);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(l, xh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(h, xl, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(h, xh, acc, 0, 0, 0);
+}
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -71,25 +99,44 @@ __device__ __forceinline__ float act_slope(int act)
 constexpr int kMaxSteps = 128;  // supersteps per conv (K <= 2048)
 constexpr int kPadSteps = 4;    // dead supersteps appended for the three-stage prefetch (fetches reach S+4)
 
-// ABL is a profiling-only ablation mask (tests/microbench): 1 = no activation loads, 2 = no weight
-// loads, 4 = no MFMA, 8 = no per-superstep index math.  Product launches always use ABL = 0.
-struct ConvGroup {
-    ConvArgs g[4];  // independent convolutions of identical tile shape run as one launch (blockIdx.y)
-};
-
-// SKIP: skip supersteps whose every source pixel lies outside the image (worth it for dilation 9 / 27);
-// without it the loop body is one basic block and the scheduler interleaves the next fetch's address
-// math with the MFMAs.
-template <int MT, int NT, int ABL = 0, bool SKIP = true>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGroup grp)
+// C/D layout of the 16x16 MFMAs: lane (i16, g) holds column i16 (pixel) and rows 4g..4g+3 (output channels)
+template <int MT, int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x4 (&acc)[MT][NT], int strip, int i16, int g)
 {
-    const ConvArgs &a = grp.g[blockIdx.y];
-    // Per-(superstep, lane group) source table, built once per block: float4 index of the tap's
-    // plane origin relative to a.in (-1 = the zero float4 every activation buffer keeps in front of
-    // its planes) and the tap's (dy, dx).  kPadSteps dead supersteps pad the end so that the
-    // three-stage prefetch needs no tail handling.
-    __shared__ int2 tab[(kMaxSteps + kPadSteps) * 4];
-    for (int G = threadIdx.x; G < (a.nsteps + kPadSteps) * 4; G += 256) {
+    const float slope = act_slope(a.act);
+    const bool use_tanh = a.act == OJF_ACT_TANH;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int og = n * 4 + g;  // output channel group
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(a.bias + (size_t)n * 16 + 4 * g);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int p = strip + m * 16 + i16;
+            f32x4 v = acc[m][n] + b;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float lin = v[j];
+                float r = lin > 0.0f ? lin : lin * slope;
+                if (use_tanh) r = tanhf(lin);
+                v[j] = (og * 4 + j < a.act_n ? r : lin) * a.scale;
+            }
+            if (p >= a.npix) continue;
+            if (a.out_rows) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (og * 4 + j < a.rows_n) a.out_rows[(size_t)p * a.rows_stride + og * 4 + j] = v[j];
+            } else if (og < a.og_store) {
+                a.out[(size_t)(a.out_g0 + og) * a.npix + p] = v;
+            }
+        }
+    }
+}
+
+// Per-(superstep, slot) source table: float4 index of the tap's plane origin relative to a.in (-1 = the zero
+// float4 every activation buffer keeps in front of its planes) and the tap's (dy, dx) packed in one int.
+__device__ __forceinline__ void build_tap_table(int2 *tab, const ConvArgs &a, int entries)
+{
+    for (int G = threadIdx.x; G < entries; G += 256) {
         const int t = G / a.c4, cg = G - t * a.c4;
         int off = -1, dy = -30000, dx = 0;
         if (t < a.taps) {
@@ -103,6 +150,25 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGroup grp)
         }
         tab[G] = int2{off, (int)(((unsigned)dy << 16) | ((unsigned)dx & 0xffffu))};
     }
+}
+
+// ABL is a profiling-only ablation mask (tests/microbench): 1 = no activation loads, 2 = no weight
+// loads, 4 = no MFMA, 8 = no per-superstep index math.  Product launches always use ABL = 0.
+struct ConvGroup {
+    ConvArgs g[4];  // independent convolutions of identical tile shape run as one launch (blockIdx.y)
+};
+
+// SKIP: skip supersteps whose every source pixel lies outside the image (worth it for dilation 9 / 27);
+// without it the loop body is one basic block and the scheduler interleaves the next fetch's address
+// math with the MFMAs.
+template <int MT, int NT, int ABL = 0, bool SKIP = true>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGroup grp)
+{
+    const ConvArgs &a = grp.g[blockIdx.y];
+    // tap table built once per block; kPadSteps dead supersteps pad the end so that the three-stage
+    // prefetch needs no tail handling
+    __shared__ int2 tab[(kMaxSteps + kPadSteps) * 4];
+    build_tap_table(tab, a, (a.nsteps + kPadSteps) * 4);
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -196,34 +262,103 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGroup grp)
         if (!SKIP || l2) mac(x2, w2);
     }
 
-    // C/D layout of 16x16x4: lane (i16, g) holds column i16 (pixel) and rows 4g..4g+3 (output channels)
-    const float slope = act_slope(a.act);
-    const bool use_tanh = a.act == OJF_ACT_TANH;
+    conv_epilogue<MT, NT>(a, acc, strip, i16, g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Split-fp16 variant of the generic convolution (OJF_ARITH_F16X3).  Same C4-planar fp32 activations in
+// and out; a superstep is one 32-wide K block = 8 (tap, 4-channel group) entries, lane group g owns
+// entries 8S+2g and 8S+2g+1 (K slot j < 4: channel j of the first, j >= 4: channel j-4 of the second),
+// converts its 8 fp32 values to fp16 halves in registers and issues 3 MFMAs per output tile.
+// The packed weights ([S][n][hi|lo][lane] x 8 halfs) are staged through LDS in chunks of CS supersteps
+// shared by the four waves of the block: with the 5x faster MFMA the per-wave L1 weight stream of the
+// fp32 kernel would be the bound (measured: 35 -> 26 us on the grouped 19->19 3x3 launches).
+// ------------------------------------------------------------------------------------------------
+constexpr int kPad16 = 6;  // dead supersteps behind the weights and the tap table (chunk copies + prefetch)
+constexpr int conv16_chunk(int nt) { return nt <= 2 ? 6 : 3; }  // supersteps per LDS chunk (<= 24 KB)
+
+template <int MT, int NT, bool SKIP = true>
+__global__ __launch_bounds__(256) void conv_f16x3_kernel(const ConvGroup grp)
+{
+    constexpr int CS = conv16_chunk(NT);
+    const ConvArgs &a = grp.g[blockIdx.y];
+    __shared__ int2 tab[(kMaxSteps + kPad16) * 8];
+    __shared__ f32x4 wl[CS * NT * 128];
+    build_tap_table(tab, a, (a.nsteps + kPad16) * 8);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int strip = (blockIdx.x * 4 + wave) * (MT * 16);  // waves past the image still take part in the barriers
+
+    int py[MT], px[MT], plin[MT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int og = (ot0 + n) * 4 + g;  // output channel group
-        const f32x4 b = *reinterpret_cast<const f32x4 *>(a.bias + (size_t)(ot0 + n) * 16 + 4 * g);
+    for (int m = 0; m < MT; ++m) {
+        const int p = strip + m * 16 + i16;
+        plin[m] = p;
+        py[m] = p < a.npix ? p / a.w : -0x40000000;
+        px[m] = p - (p / a.w) * a.w;
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto fetch = [&](f32x4(&xa)[MT], f32x4(&xb)[MT], int S, bool &live) {
+        const int2 e0 = tab[S * 8 + 2 * g], e1 = tab[S * 8 + 2 * g + 1];
+        const int dy0 = e0.y >> 16, dx0 = (int)(short)(e0.y & 0xffff);
+        const int dy1 = e1.y >> 16, dx1 = (int)(short)(e1.y & 0xffff);
+        bool any_ok = false;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const int p = strip + m * 16 + i16;
-            f32x4 v = acc[m][n] + b;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float lin = v[j];
-                float r = lin > 0.0f ? lin : lin * slope;
-                if (use_tanh) r = tanhf(lin);
-                v[j] = (og * 4 + j < a.act_n ? r : lin) * a.scale;
-            }
-            if (p >= a.npix) continue;
-            if (a.out_rows) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (og * 4 + j < a.rows_n) a.out_rows[(size_t)p * a.rows_stride + og * 4 + j] = v[j];
-            } else if (og < a.og_store) {
-                a.out[(size_t)(a.out_g0 + og) * a.npix + p] = v;
-            }
+            const bool ok0 = (unsigned)(py[m] + dy0) < (unsigned)a.h && (unsigned)(px[m] + dx0) < (unsigned)a.w;
+            const bool ok1 = (unsigned)(py[m] + dy1) < (unsigned)a.h && (unsigned)(px[m] + dx1) < (unsigned)a.w;
+            xa[m] = a.in[ok0 ? e0.x + plin[m] : -1];
+            xb[m] = a.in[ok1 ? e1.x + plin[m] : -1];
+            any_ok |= ok0 | ok1;
         }
+        live = SKIP ? __any(any_ok) : true;
+    };
+    auto mac = [&](const f32x4(&xa)[MT], const f32x4(&xb)[MT], int sl) {
+        f32x4 wh[NT], wlo[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            wh[n] = wl[(sl * NT + n) * 128 + lane];
+            wlo[n] = wl[(sl * NT + n) * 128 + 64 + lane];
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            f16x8 xh, xl;
+            split_f16(xa[m], xb[m], xh, xl);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = mfma_f16x3(wh[n], wlo[n], xh, xl, acc[m][n]);
+        }
+    };
+
+    __syncthreads();  // tap table
+    f32x4 xa0[MT], xb0[MT], xa1[MT], xb1[MT], xa2[MT], xb2[MT];
+    bool v0, v1, v2;
+    fetch(xa0, xb0, 0, v0);
+    fetch(xa1, xb1, 1, v1);
+    int sl = CS;
+    for (int S = 0; S < a.nsteps; S += 3) {
+        if (sl == CS) {  // next weight chunk (CS is a multiple of the 3 supersteps of one iteration)
+            if (S) __syncthreads();
+            const f32x4 *src = a.wp + (size_t)S * NT * 128;
+#pragma unroll
+            for (int i = 0; i < CS * NT * 128 / 256; ++i) wl[i * 256 + threadIdx.x] = src[i * 256 + threadIdx.x];
+            __syncthreads();
+            sl = 0;
+        }
+        fetch(xa2, xb2, S + 2, v2);
+        if (!SKIP || v0) mac(xa0, xb0, sl);
+        fetch(xa0, xb0, S + 3, v0);
+        if (!SKIP || v1) mac(xa1, xb1, sl + 1);
+        fetch(xa1, xb1, S + 4, v1);
+        if (!SKIP || v2) mac(xa2, xb2, sl + 2);
+        sl += 3;
     }
+    conv_epilogue<MT, NT>(a, acc, strip, i16, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -240,45 +375,70 @@ constexpr int kChainLdsFloat4 = 24 * 1024 / 16;
 
 struct ChainArgs {
     const f32x4 *in;  // input planes, c4_in groups starting at in_g0
-    const f32x4 *w;   // per layer: [n2 < NTOUT][S < NTIN][lane] float4, layers back to back
+    const f32x4 *w;   // per layer: [n2 < NTOUT][K block][lane] fragments (see chain_unit), layers back to back
     const float *bias;  // per layer NTOUT*16 floats, back to back
     float *out_rows;  // [npix, rows_stride], channels < rows_n
     int in_g0, c4_in, npix, rows_stride, rows_n;
     float scale;
 };
 
-constexpr int chain_parts(int ntin, int ntout) { return (ntin * ntout + 23) / 24; }  // <= 24 KB of weights per LDS part
-constexpr int chain_per(int ntin, int ntout) { return (ntout + chain_parts(ntin, ntout) - 1) / chain_parts(ntin, ntout); }
-constexpr int chain_first_size(int ntin, int ntout)
+// Weight fragments of one (output tile, K block) pair.  fp32: K block = one 16-channel input tile, 64 float4
+// (lane (oc i16, g) holds W[oc][16S+4g .. +3]).  split-fp16: K block = two input tiles (32 channels), 128 float4 =
+// hi | lo fragments of 8 halfs; K slot j < 4 is channel 4g+j of tile 2S', j >= 4 channel 4g+j-4 of tile 2S'+1 - i.e.
+// exactly the two accumulator quads lane (pixel, g) holds, so activations still never leave registers.
+constexpr int chain_kblocks(int arith, int ntin) { return arith == OJF_ARITH_F16X3 ? (ntin + 1) / 2 : ntin; }
+constexpr int chain_unit(int arith) { return arith == OJF_ARITH_F16X3 ? 128 : 64; }
+constexpr int chain_layer_size(int arith, int ntin, int ntout) { return ntout * chain_kblocks(arith, ntin) * chain_unit(arith); }
+constexpr int chain_parts(int arith, int ntin, int ntout)
+{   // <= 24 KB of weights per LDS part
+    return (chain_layer_size(arith, ntin, ntout) + kChainLdsFloat4 - 1) / kChainLdsFloat4;
+}
+constexpr int chain_per(int arith, int ntin, int ntout)
+{
+    return (ntout + chain_parts(arith, ntin, ntout) - 1) / chain_parts(arith, ntin, ntout);
+}
+constexpr int chain_first_size(int arith, int ntin, int ntout)
 {   // float4 count of a layer's first part
-    return (chain_per(ntin, ntout) < ntout ? chain_per(ntin, ntout) : ntout) * ntin * 64;
+    return (chain_per(arith, ntin, ntout) < ntout ? chain_per(arith, ntin, ntout) : ntout) * chain_kblocks(arith, ntin) *
+           chain_unit(arith);
 }
 constexpr int kChainPre = 6;  // float4 registers per thread holding the prefetched next part (24 KB / 256 threads)
 
-// `pre` carries the weights of this layer's first part on entry (already fetched from HBM/L2 while
-// the previous part computed) and the next layer's first part on exit: global latency never sits
-// between two compute phases, only two barriers around the LDS refill do.
 enum { kChainLeaky = 0, kChainRelu = 1, kChainAccumulate = 2, kChainLastRows = 3 };
 
-// One pointwise layer on register-resident activations: out[n2] (+)= sum_S sum_j mfma(W[n2][S][j], in[S][j]),
-// then (unless accumulating) bias + activation in place.  `in` and `out` are distinct, statically indexed
-// register arrays (callers ping-pong two of them), so no staging copy exists.
+// One pointwise layer on register-resident activations: out[n2] (+)= sum_K W[n2][K] * in[K], then (unless
+// accumulating) bias + activation in place.  `in` and `out` are distinct, statically indexed register arrays
+// (callers ping-pong two of them), so no staging copy exists.
 // `pre` carries the weights of this layer's first part on entry (already fetched from HBM/L2 while the
 // previous part computed) and the next layer's first part on exit: global latency never sits between two
 // compute phases, only the two barriers around the LDS refill do.
-template <int MT, int NTIN, int NTOUT, int MODE, int NEXT_FIRST, int NA, int NB>
+template <int ARITH, int MT, int NTIN, int NTOUT, int MODE, int NEXT_FIRST, int NA, int NB>
 __device__ __forceinline__ void chain_layer(const f32x4 (&in)[MT][NA], f32x4 (&out)[MT][NB], f32x4 *wlds, const f32x4 *wg,
                                             const float *bias, const ChainArgs &a, const int (&p)[MT], int lane,
                                             f32x4 (&pre)[kChainPre], const f32x4 *next_src = nullptr)
 {
     static_assert(NTIN <= NA && NTOUT <= NB, "register arrays too small for this layer");
-    constexpr int parts = chain_parts(NTIN, NTOUT);
-    constexpr int per = chain_per(NTIN, NTOUT);
+    constexpr int parts = chain_parts(ARITH, NTIN, NTOUT);
+    constexpr int per = chain_per(ARITH, NTIN, NTOUT);
+    constexpr int KB = chain_kblocks(ARITH, NTIN);
+    constexpr int unit = chain_unit(ARITH);
+    static_assert(per * KB * unit <= kChainLdsFloat4, "LDS part too large");
+    // split-fp16: the fp16 halves of the layer input, once per layer
+    f16x8 xh[MT][ARITH == OJF_ARITH_F16X3 ? KB : 1], xl[MT][ARITH == OJF_ARITH_F16X3 ? KB : 1];
+    if constexpr (ARITH == OJF_ARITH_F16X3) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int S = 0; S < KB; ++S) {
+                const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+                split_f16(in[m][2 * S], 2 * S + 1 < NTIN ? in[m][2 * S + 1 < NTIN ? 2 * S + 1 : 0] : zero, xh[m][S], xl[m][S]);
+            }
+    }
 #pragma unroll
     for (int part = 0; part < parts; ++part) {
         const int nb = part * per;
         const int ne = nb + per < NTOUT ? nb + per : NTOUT;
-        const int size = (ne - nb) * NTIN * 64;
+        const int size = (ne - nb) * KB * unit;
         __syncthreads();  // readers of the previous part are done
 #pragma unroll
         for (int k = 0; k < kChainPre; ++k)
@@ -287,9 +447,9 @@ __device__ __forceinline__ void chain_layer(const f32x4 (&in)[MT][NA], f32x4 (&o
         // issue the fetch of the following part (next part of this layer, or the next layer's first)
         const int nnb = ne;
         const int nne = nnb + per < NTOUT ? nnb + per : NTOUT;
-        const int nsize = part + 1 < parts ? (nne - nnb) * NTIN * 64 : NEXT_FIRST;
-        const f32x4 *nsrc = part + 1 < parts ? wg + (size_t)nnb * NTIN * 64
-                                             : (next_src ? next_src : wg + (size_t)NTIN * NTOUT * 64);
+        const int nsize = part + 1 < parts ? (nne - nnb) * KB * unit : NEXT_FIRST;
+        const f32x4 *nsrc = part + 1 < parts ? wg + (size_t)nnb * KB * unit
+                                             : (next_src ? next_src : wg + (size_t)chain_layer_size(ARITH, NTIN, NTOUT));
 #pragma unroll
         for (int k = 0; k < kChainPre; ++k)
             if ((int)threadIdx.x + 256 * k < nsize) pre[k] = nsrc[threadIdx.x + 256 * k];
@@ -300,18 +460,25 @@ __device__ __forceinline__ void chain_layer(const f32x4 (&in)[MT][NA], f32x4 (&o
                 for (int m = 0; m < MT; ++m)
                     if (n2 >= nb && n2 < ne) out[m][n2] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        // S outer, output tiles inner: (ne - nb) * MT independent accumulators per MFMA round
+        // K block outer, output tiles inner: (ne - nb) * MT independent accumulators per MFMA round
 #pragma unroll
-        for (int S = 0; S < NTIN; ++S)
+        for (int S = 0; S < KB; ++S)
 #pragma unroll
             for (int n2 = 0; n2 < NTOUT; ++n2) {
                 if (n2 < nb || n2 >= ne) continue;
-                const f32x4 wv = wlds[((n2 - nb) * NTIN + S) * 64 + lane];
+                if constexpr (ARITH == OJF_ARITH_F16X3) {
+                    const f32x4 wh = wlds[((n2 - nb) * KB + S) * 128 + lane];
+                    const f32x4 wl = wlds[((n2 - nb) * KB + S) * 128 + 64 + lane];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                    for (int m = 0; m < MT; ++m) out[m][n2] = mfma_f16x3(wh, wl, xh[m][S], xl[m][S], out[m][n2]);
+                } else {
+                    const f32x4 wv = wlds[((n2 - nb) * KB + S) * 64 + lane];
 #pragma unroll
-                    for (int m = 0; m < MT; ++m)
-                        out[m][n2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], in[m][S][j], out[m][n2], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            out[m][n2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], in[m][S][j], out[m][n2], 0, 0, 0);
+                }
             }
     }
     if constexpr (MODE != kChainAccumulate) {
@@ -341,24 +508,26 @@ __device__ __forceinline__ void chain_layer(const f32x4 (&in)[MT][NA], f32x4 (&o
 }
 
 // layer l reads `x` and writes `y`; the recursion swaps the two arrays for layer l+1
-template <int MT, int NTIN, int NTOUT>
+template <int ARITH, int MT, int NTIN, int NTOUT>
 __device__ __forceinline__ void chain_run(f32x4 (&x)[MT][8], f32x4 (&y)[MT][8], f32x4 *wlds, const f32x4 *wg,
                                           const float *bias, const ChainArgs &a, const int (&p)[MT], int lane,
                                           f32x4 (&pre)[kChainPre])
 {
-    chain_layer<MT, NTIN, NTOUT, kChainLastRows, 0>(x, y, wlds, wg, bias, a, p, lane, pre);
+    chain_layer<ARITH, MT, NTIN, NTOUT, kChainLastRows, 0>(x, y, wlds, wg, bias, a, p, lane, pre);
 }
 
-template <int MT, int NTIN, int NTOUT, int NTNEXT, int... REST>
+template <int ARITH, int MT, int NTIN, int NTOUT, int NTNEXT, int... REST>
 __device__ __forceinline__ void chain_run(f32x4 (&x)[MT][8], f32x4 (&y)[MT][8], f32x4 *wlds, const f32x4 *wg,
                                           const float *bias, const ChainArgs &a, const int (&p)[MT], int lane,
                                           f32x4 (&pre)[kChainPre])
 {
-    chain_layer<MT, NTIN, NTOUT, kChainLeaky, chain_first_size(NTOUT, NTNEXT)>(x, y, wlds, wg, bias, a, p, lane, pre);
-    chain_run<MT, NTOUT, NTNEXT, REST...>(y, x, wlds, wg + (size_t)NTIN * NTOUT * 64, bias + NTOUT * 16, a, p, lane, pre);
+    chain_layer<ARITH, MT, NTIN, NTOUT, kChainLeaky, chain_first_size(ARITH, NTOUT, NTNEXT)>(x, y, wlds, wg, bias, a, p,
+                                                                                             lane, pre);
+    chain_run<ARITH, MT, NTOUT, NTNEXT, REST...>(y, x, wlds, wg + (size_t)chain_layer_size(ARITH, NTIN, NTOUT),
+                                                 bias + NTOUT * 16, a, p, lane, pre);
 }
 
-template <int MT, int NT0, int... NTS>
+template <int ARITH, int MT, int NT0, int... NTS>
 __global__ __launch_bounds__(256) void chain1x1_kernel(const ChainArgs a)
 {
     __shared__ f32x4 wlds[kChainLdsFloat4];
@@ -380,12 +549,12 @@ __global__ __launch_bounds__(256) void chain1x1_kernel(const ChainArgs a)
     f32x4 pre[kChainPre];
     {   // first part of the first layer
         constexpr int first[] = {NTS...};
-        constexpr int size0 = chain_first_size(NT0, first[0]);
+        constexpr int size0 = chain_first_size(ARITH, NT0, first[0]);
 #pragma unroll
         for (int k = 0; k < kChainPre; ++k)
             if ((int)threadIdx.x + 256 * k < size0) pre[k] = a.w[threadIdx.x + 256 * k];
     }
-    chain_run<MT, NT0, NTS...>(x, y, wlds, a.w, a.bias, a, p, lane, pre);
+    chain_run<ARITH, MT, NT0, NTS...>(x, y, wlds, a.w, a.bias, a, p, lane, pre);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -398,14 +567,14 @@ __global__ __launch_bounds__(256) void chain1x1_kernel(const ChainArgs a)
 // ------------------------------------------------------------------------------------------------
 struct TailArgs {
     const f32x4 *v[4];  // branch inputs (planes, c4 groups each)
-    const f32x4 *w;     // stream: W1_0 [NO][NV][64], Wf_0 [NO][NO][64], W1_1, Wf_1, ...
+    const f32x4 *w;     // stream: W1_0 [NO][NV], Wf_0 [NO][NO], W1_1, Wf_1, ... (chain_layer fragments)
     const float *b1;    // 4 x NO*16
     const float *bias_final;  // NO*16 (per-frame: includes the global-average branch)
     f32x4 *out;
     int c4, out_g0, og_store, npix;
 };
 
-template <int MT, int NV, int NO>
+template <int ARITH, int MT, int NV, int NO>
 __global__ __launch_bounds__(256) void vortex_tail_kernel(const TailArgs a)
 {
     __shared__ f32x4 wlds[kChainLdsFloat4];
@@ -424,12 +593,12 @@ __global__ __launch_bounds__(256) void vortex_tail_kernel(const TailArgs a)
         for (int n = 0; n < NO; ++n) y[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 pre[kChainPre];
     {
-        constexpr int size0 = chain_first_size(NV, NO);
+        constexpr int size0 = chain_first_size(ARITH, NV, NO);
 #pragma unroll
         for (int k = 0; k < kChainPre; ++k)
             if ((int)threadIdx.x + 256 * k < size0) pre[k] = a.w[threadIdx.x + 256 * k];
     }
-    constexpr size_t per_branch = (size_t)(NV * NO + NO * NO) * 64;
+    constexpr size_t per_branch = (size_t)chain_layer_size(ARITH, NV, NO) + chain_layer_size(ARITH, NO, NO);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         f32x4 vin[MT][NV], t[MT][NO];
@@ -441,12 +610,14 @@ __global__ __launch_bounds__(256) void vortex_tail_kernel(const TailArgs a)
                 const bool ok = p[m] < a.npix && G < a.c4;
                 vin[m][S] = a.v[b][ok ? G * a.npix + p[m] : -1];
             }
-        const f32x4 *w1 = a.w + b * per_branch, *wf = w1 + (size_t)NV * NO * 64;
-        chain_layer<MT, NV, NO, kChainRelu, chain_first_size(NO, NO)>(vin, t, wlds, w1, a.b1 + b * NO * 16, ca, p, lane, pre);
+        const f32x4 *w1 = a.w + b * per_branch, *wf = w1 + (size_t)chain_layer_size(ARITH, NV, NO);
+        chain_layer<ARITH, MT, NV, NO, kChainRelu, chain_first_size(ARITH, NO, NO)>(vin, t, wlds, w1, a.b1 + b * NO * 16, ca, p,
+                                                                                   lane, pre);
         if (b < 3)
-            chain_layer<MT, NO, NO, kChainAccumulate, chain_first_size(NV, NO)>(t, y, wlds, wf, nullptr, ca, p, lane, pre);
+            chain_layer<ARITH, MT, NO, NO, kChainAccumulate, chain_first_size(ARITH, NV, NO)>(t, y, wlds, wf, nullptr, ca, p,
+                                                                                            lane, pre);
         else
-            chain_layer<MT, NO, NO, kChainAccumulate, 0>(t, y, wlds, wf, nullptr, ca, p, lane, pre);
+            chain_layer<ARITH, MT, NO, NO, kChainAccumulate, 0>(t, y, wlds, wf, nullptr, ca, p, lane, pre);
     }
 #pragma unroll
     for (int n = 0; n < NO; ++n) {
@@ -618,10 +789,20 @@ __global__ __launch_bounds__(256) void planes_to_rows_kernel(const f32x4 *planes
 // host side: packing and the layer schedule
 // ------------------------------------------------------------------------------------------------
 struct PackedConv {
-    float *wp = nullptr;    // device
+    float *wp = nullptr;    // device; layout depends on arith
     float *bias = nullptr;  // device, n_ot*16 floats
     int c_in_phys = 0, c_out_phys = 0, taps = 1, dil = 1, n_ot = 0;
+    int arith = OJF_ARITH_F32, nsteps = 0;  // supersteps: 4 (fp32) or 8 (split-fp16) K entries each
 };
+
+static int g_default_arith = OJF_ARITH_F16X3;
+
+// fp16 halves of a weight, both rounded to nearest (host side of split_f16)
+static inline void split_weight(float v, _Float16 &hi, _Float16 &lo)
+{
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
 
 constexpr int kNT = 2;  // packed weights are padded to a multiple of this many output-channel tiles
 
@@ -654,28 +835,51 @@ static int upload(const std::vector<float> &h, float **d)
     return 0;
 }
 
-static int finish(const ConvBuilder &b, PackedConv &pc)
+static int finish(const ConvBuilder &b, PackedConv &pc, int arith = OJF_ARITH_F32)
 {
     if (b.c_in_phys % 4) return fail("conv packing: c_in_phys must be a multiple of 4");
     pc.c_in_phys = b.c_in_phys;
     pc.c_out_phys = b.c_out_phys;
     pc.taps = b.taps;
     pc.dil = b.dil;
+    pc.arith = arith;
     pc.n_ot = round_up(round_up(b.c_out_phys, 16) / 16, kNT);
-    const int c4 = b.c_in_phys / 4, groups = b.taps * c4, nsteps = (groups + 3) / 4;
+    const int c4 = b.c_in_phys / 4, groups = b.taps * c4;
+    const int per = arith == OJF_ARITH_F16X3 ? 8 : 4;  // K entries per superstep
+    const int nsteps = (groups + per - 1) / per;
     if (nsteps > kMaxSteps) return fail("conv packing: K too large for the tap table");
-    const int nsp = nsteps + kPadSteps;  // dead (all-zero) supersteps for the prefetch tail
-    std::vector<float> wp((size_t)pc.n_ot * nsp * 256, 0.0f), bias((size_t)pc.n_ot * 16, 0.0f);
-    for (int ot = 0; ot < pc.n_ot; ++ot)
+    pc.nsteps = nsteps;
+    std::vector<float> wp, bias((size_t)pc.n_ot * 16, 0.0f);
+    if (arith == OJF_ARITH_F16X3) {
+        // [S][ot][hi|lo][lane] x 8 halfs; dead (all-zero) supersteps behind for the chunk copies
+        const int nsp = nsteps + kPad16;
+        wp.assign((size_t)nsp * pc.n_ot * 128 * 4, 0.0f);
+        _Float16 *hp = reinterpret_cast<_Float16 *>(wp.data());
         for (int S = 0; S < nsteps; ++S)
-            for (int lane = 0; lane < 64; ++lane) {
-                const int oc = ot * 16 + (lane & 15), G = 4 * S + (lane >> 4);
-                if (oc >= b.c_out_phys || G >= groups) continue;
-                const int t = G / c4, cg = G % c4;
-                const float *row = b.W.data() + ((size_t)oc * b.taps + t) * b.c_in_phys + 4 * cg;
-                float *dst = wp.data() + (((size_t)ot * nsp + S) * 64 + lane) * 4;
-                for (int j = 0; j < 4; ++j) dst[j] = row[j];
-            }
+            for (int ot = 0; ot < pc.n_ot; ++ot)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int oc = ot * 16 + (lane & 15), G = 8 * S + 2 * (lane >> 4) + (j >> 2);
+                        if (oc >= b.c_out_phys || G >= groups) continue;
+                        const int t = G / c4, cg = G % c4;
+                        const float v = b.W[((size_t)oc * b.taps + t) * b.c_in_phys + 4 * cg + (j & 3)];
+                        const size_t base = ((size_t)S * pc.n_ot + ot) * 2 * 64 * 8;
+                        split_weight(v, hp[base + (size_t)lane * 8 + j], hp[base + 64 * 8 + (size_t)lane * 8 + j]);
+                    }
+    } else {
+        const int nsp = nsteps + kPadSteps;  // dead (all-zero) supersteps for the prefetch tail
+        wp.assign((size_t)pc.n_ot * nsp * 256, 0.0f);
+        for (int ot = 0; ot < pc.n_ot; ++ot)
+            for (int S = 0; S < nsteps; ++S)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int oc = ot * 16 + (lane & 15), G = 4 * S + (lane >> 4);
+                    if (oc >= b.c_out_phys || G >= groups) continue;
+                    const int t = G / c4, cg = G % c4;
+                    const float *row = b.W.data() + ((size_t)oc * b.taps + t) * b.c_in_phys + 4 * cg;
+                    float *dst = wp.data() + (((size_t)ot * nsp + S) * 64 + lane) * 4;
+                    for (int j = 0; j < 4; ++j) dst[j] = row[j];
+                }
+    }
     for (int o = 0; o < b.c_out_phys; ++o) bias[o] = b.B[o];
     if (upload(wp, &pc.wp)) return -2;
     if (upload(bias, &pc.bias)) return -2;
@@ -695,38 +899,51 @@ static inline const f32x4 *planes(const float *p) { return reinterpret_cast<cons
 // Launches n (<= 4) independent convolutions with the same number of output tiles as ONE grid
 // (blockIdx.y = problem): the four branches of a VortexPooling run together instead of as four
 // under-filled launches with their own ramp-up and tail.
-static int launch_conv_args(const ConvArgs *args, int n, int nt, hipStream_t st)
+static int launch_conv_args(const ConvArgs *args, int n, int nt, hipStream_t st, int arith)
 {
     ConvGroup grp;
     for (int i = 0; i < n; ++i) grp.g[i] = args[i];
     for (int i = n; i < 4; ++i) grp.g[i] = args[0];
     // one wave computes ALL output-channel tiles of its pixel strip (activations are fetched once);
-    // MT (16-pixel tiles per wave) trades operand reuse against the number of waves in flight
-    // MT = 1 everywhere: 4800 waves over 1024 SIMDs quantise to 5 rounds where MT = 2 (2400 waves) needs 3
-    // rounds of twice the length (78 % vs 94 % balance); measured 14.9 vs 17.3 us on the 19->19 3x3 layers
-    const int mt = 1;
+    // MT (16-pixel tiles per wave) trades operand reuse against the number of waves in flight.
+    // fp32: MT = 1 everywhere: 4800 waves over 1024 SIMDs quantise to 5 rounds where MT = 2 (2400 waves) needs 3
+    // rounds of twice the length (78 % vs 94 % balance); measured 14.9 vs 17.3 us on the 19->19 3x3 layers.
+    // split-fp16: the grouped launches (4 x 4800 waves) and the wide layers gain from sharing the LDS weight
+    // reads between two pixel tiles (26.4 -> 23.2 us, 25.4 -> 23.3 us); single narrow layers do not.
+    static const int mt_env = getenv("OJF_CONV_MT") ? atoi(getenv("OJF_CONV_MT")) : 0;  // tuning switch only
+    const int mt = arith == OJF_ARITH_F16X3 ? (mt_env ? mt_env : ((n > 1 || nt >= 6) ? 2 : 1)) : 1;
     const int strips = (args[0].npix + mt * 16 - 1) / (mt * 16);
     const dim3 grid((strips + 3) / 4, n), block(256);
-#define OJF_LAUNCH(MT_, NT_) hipLaunchKernelGGL((conv_mfma_kernel<MT_, NT_>), grid, block, 0, st, grp)
-    if (mt == 2) {
+#define OJF_LAUNCH32(NT_) hipLaunchKernelGGL((conv_mfma_kernel<1, NT_>), grid, block, 0, st, grp)
+#define OJF_LAUNCH16(MT_, NT_) hipLaunchKernelGGL((conv_f16x3_kernel<MT_, NT_>), grid, block, 0, st, grp)
+    if (arith == OJF_ARITH_F16X3 && mt == 2) {
         switch (nt) {
-            case 2: OJF_LAUNCH(2, 2); break;
-            case 4: OJF_LAUNCH(2, 4); break;
-            case 6: OJF_LAUNCH(2, 6); break;
-            case 8: OJF_LAUNCH(2, 8); break;
+            case 2: OJF_LAUNCH16(2, 2); break;
+            case 4: OJF_LAUNCH16(2, 4); break;
+            case 6: OJF_LAUNCH16(2, 6); break;
+            case 8: OJF_LAUNCH16(2, 8); break;
+            default: return fail("conv: unsupported number of output tiles");
+        }
+    } else if (arith == OJF_ARITH_F16X3) {
+        switch (nt) {
+            case 2: OJF_LAUNCH16(1, 2); break;
+            case 4: OJF_LAUNCH16(1, 4); break;
+            case 6: OJF_LAUNCH16(1, 6); break;
+            case 8: OJF_LAUNCH16(1, 8); break;
             default: return fail("conv: unsupported number of output tiles");
         }
     } else {
         switch (nt) {
-            case 2: OJF_LAUNCH(1, 2); break;
-            case 4: OJF_LAUNCH(1, 4); break;
-            case 6: OJF_LAUNCH(1, 6); break;
-            case 8: OJF_LAUNCH(1, 8); break;
+            case 2: OJF_LAUNCH32(2); break;
+            case 4: OJF_LAUNCH32(4); break;
+            case 6: OJF_LAUNCH32(6); break;
+            case 8: OJF_LAUNCH32(8); break;
             default: return fail("conv: unsupported number of output tiles");
         }
     }
-#undef OJF_LAUNCH
-    return check_hip(hipGetLastError(), "conv_mfma_kernel launch");
+#undef OJF_LAUNCH32
+#undef OJF_LAUNCH16
+    return check_hip(hipGetLastError(), "conv kernel launch");
 }
 
 static void fill_conv_args(ConvArgs &a, const PackedConv &pc, const float *in, int in_g0, float *out, int out_g0,
@@ -737,7 +954,7 @@ static void fill_conv_args(ConvArgs &a, const PackedConv &pc, const float *in, i
     a.in_g0 = in_g0; a.out_g0 = out_g0; a.rows_stride = 0; a.rows_n = 0;
     a.h = h; a.w = w; a.npix = h * w;
     a.taps = pc.taps; a.dil = pc.dil;
-    a.c4 = pc.c_in_phys / 4; a.nsteps = (pc.taps * a.c4 + 3) / 4;
+    a.c4 = pc.c_in_phys / 4; a.nsteps = pc.nsteps;
     a.og_store = round_up(pc.c_out_phys, 4) / 4;
     a.act = act; a.act_n = act_n; a.scale = scale;
 }
@@ -751,7 +968,7 @@ static int launch_conv(const PackedConv &pc, const float *in, int in_g0, float *
     ConvArgs a;
     fill_conv_args(a, pc, in, in_g0, out, out_g0, bias, act, act_n, scale, h, w);
     a.out_rows = rows; a.rows_stride = rows_stride; a.rows_n = rows_n;
-    return launch_conv_args(&a, 1, pc.n_ot, st);
+    return launch_conv_args(&a, 1, pc.n_ot, st, pc.arith);
 }
 
 static std::vector<int> slot_map(int n_logical, int group, int slot)
@@ -759,6 +976,34 @@ static std::vector<int> slot_map(int n_logical, int group, int slot)
     std::vector<int> m(n_logical);
     for (int j = 0; j < n_logical; ++j) m[j] = (j / group) * slot + (j % group);
     return m;
+}
+
+// Fragments of one pointwise layer for chain_layer, appended to dst; weight(oc, k) returns 0 outside the layer.
+template <class F>
+static void pack_chain_layer(std::vector<float> &dst, int arith, int nt_out, int nt_in, F weight)
+{
+    const size_t base = dst.size();
+    dst.resize(base + (size_t)chain_layer_size(arith, nt_in, nt_out) * 4, 0.0f);
+    if (arith == OJF_ARITH_F16X3) {
+        const int KB = chain_kblocks(arith, nt_in);
+        _Float16 *hp = reinterpret_cast<_Float16 *>(dst.data() + base);
+        for (int n2 = 0; n2 < nt_out; ++n2)
+            for (int S = 0; S < KB; ++S)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int oc = n2 * 16 + (lane & 15), g = lane >> 4;
+                        const int k = 32 * S + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
+                        const size_t ub = ((size_t)n2 * KB + S) * 2 * 64 * 8;
+                        split_weight(weight(oc, k), hp[ub + (size_t)lane * 8 + j], hp[ub + 64 * 8 + (size_t)lane * 8 + j]);
+                    }
+    } else {
+        for (int n2 = 0; n2 < nt_out; ++n2)
+            for (int S = 0; S < nt_in; ++S)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j)
+                        dst[base + (((size_t)n2 * nt_in + S) * 64 + lane) * 4 + j] =
+                            weight(n2 * 16 + (lane & 15), 16 * S + 4 * (lane >> 4) + j);
+    }
 }
 
 struct Vortex {
@@ -773,6 +1018,7 @@ struct Vortex {
 
 struct ojf_net {
     int version, P, c, cs, gf, sem, heads, h, w, npix;
+    int arith;  // OJF_ARITH_* captured at creation
     int pool_in, os;  // (gf+1)*c and its padded slot
     float scale;
     int64_t macs_per_pixel;
@@ -844,7 +1090,7 @@ static int build_vortex(ojf_net *net, Vortex &v, const ojf_conv_layer *L, int c_
                 if (upload(pb, &v.pool_bias[br])) return -2;
             }
         }
-        if (finish(b, v.stacked)) return -2;
+        if (finish(b, v.stacked, net->arith)) return -2;
     }
     const std::vector<int> id_c = slot_map(c, c, cs);
     for (int br = 0; br < 4; ++br) {
@@ -855,13 +1101,13 @@ static int build_vortex(ojf_net *net, Vortex &v, const ojf_conv_layer *L, int c_
         ba.add(la, 0, c, id_c, 0, true);
         bb.add(lb, 0, c, id_c, 0, true);
         b1.add(l1, 0, c, id_c, 0, true);
-        if (finish(ba, v.b3a[br]) || finish(bb, v.b3b[br]) || finish(b1, v.b1[br])) return -2;
+        if (finish(ba, v.b3a[br], net->arith) || finish(bb, v.b3b[br], net->arith) || finish(b1, v.b1[br], net->arith)) return -2;
     }
     {   // final 1x1 over [gave | b0 | b1 | b2 | b3]; the gave columns become a per-frame bias
         const ojf_conv_layer &lf = L[17];
         ConvBuilder b(4 * os, os, 1, 1);
         b.add(lf, out, 5 * out, slot_map(4 * out, out, os), 0, false);
-        if (finish(b, v.fin)) return -2;
+        if (finish(b, v.fin, net->arith)) return -2;
         std::vector<float> Wg((size_t)out * c_in_phys, 0.0f), bg(out), Wfg((size_t)out * out), bf(out);
         for (int o = 0; o < out; ++o) {  // stored transposed: [input][output]
             for (int ci = 0; ci < c_in; ++ci) Wg[(size_t)in_map[ci] * out + o] = L[0].weight_host[(size_t)o * c_in + ci];
@@ -873,29 +1119,18 @@ static int build_vortex(ojf_net *net, Vortex &v, const ojf_conv_layer *L, int c_
         std::vector<float> zero((size_t)v.fin.n_ot * 16, 0.0f);
         if (upload(zero, &v.bias_final)) return -2;
     }
-    if ((cs + 15) / 16 == 2 && (os + 15) / 16 == 8) {  // fused tail: [W1_b | Wf_b] per branch, [n2][S][lane] float4
+    if ((cs + 15) / 16 == 2 && (os + 15) / 16 == 8) {  // fused tail: [W1_b | Wf_b] fragments per branch
         const int NV = 2, NO = 8;
-        std::vector<float> tw((size_t)4 * (NV * NO + NO * NO) * 256, 0.0f), tb((size_t)4 * NO * 16, 0.0f);
+        std::vector<float> tw, tb((size_t)4 * NO * 16, 0.0f);
         const ojf_conv_layer &lf = L[17];
         for (int br = 0; br < 4; ++br) {
             const ojf_conv_layer &l1 = L[4 + 4 * br];
-            float *w1 = tw.data() + (size_t)br * (NV * NO + NO * NO) * 256, *wf = w1 + (size_t)NV * NO * 256;
-            for (int n2 = 0; n2 < NO; ++n2)
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int oc = n2 * 16 + (lane & 15);
-                    if (oc >= out) continue;
-                    for (int j = 0; j < 4; ++j) {
-                        for (int S = 0; S < NV; ++S) {
-                            const int k = 16 * S + 4 * (lane >> 4) + j;
-                            if (k < c) w1[(((size_t)n2 * NV + S) * 64 + lane) * 4 + j] = l1.weight_host[(size_t)oc * c + k];
-                        }
-                        for (int S = 0; S < NO; ++S) {
-                            const int k = 16 * S + 4 * (lane >> 4) + j;
-                            if (k < out)
-                                wf[(((size_t)n2 * NO + S) * 64 + lane) * 4 + j] = lf.weight_host[(size_t)oc * 5 * out + out * (br + 1) + k];
-                        }
-                    }
-                }
+            pack_chain_layer(tw, net->arith, NO, NV, [&](int oc, int k) {
+                return oc < out && k < c ? l1.weight_host[(size_t)oc * c + k] : 0.0f;
+            });
+            pack_chain_layer(tw, net->arith, NO, NO, [&](int oc, int k) {
+                return oc < out && k < out ? lf.weight_host[(size_t)oc * 5 * out + out * (br + 1) + k] : 0.0f;
+            });
             for (int o = 0; o < out; ++o) tb[(size_t)br * NO * 16 + o] = l1.bias_host[o];
         }
         if (upload(tw, &v.tail_w) || upload(tb, &v.tail_b1)) return -2;
@@ -958,8 +1193,8 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
             fill_conv_args(ga[br], v.b3a[br], bin[br], 0, net->U, br * c4, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w);
             fill_conv_args(gb[br], v.b3b[br], net->U, br * c4, net->V, br * c4, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w);
         }
-        if (launch_conv_args(ga, 4, v.b3a[0].n_ot, st)) return -2;
-        if (launch_conv_args(gb, 4, v.b3b[0].n_ot, st)) return -2;
+        if (launch_conv_args(ga, 4, v.b3a[0].n_ot, st, net->arith)) return -2;
+        if (launch_conv_args(gb, 4, v.b3b[0].n_ot, st, net->arith)) return -2;
     }
     OJF_HIP(hipStreamWaitEvent(st, net->ev_join, 0));  // bias of the final conv is ready
     if (!fused)
@@ -973,7 +1208,10 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
     ta.out = planes(out); ta.c4 = c4; ta.out_g0 = out_g0; ta.og_store = o4; ta.npix = net->npix;
     constexpr int MT = 1;
     const int strips = (net->npix + MT * 16 - 1) / (MT * 16);
-    hipLaunchKernelGGL((vortex_tail_kernel<MT, 2, 8>), dim3((strips + 3) / 4), dim3(256), 0, st, ta);
+    if (net->arith == OJF_ARITH_F16X3)
+        hipLaunchKernelGGL((vortex_tail_kernel<OJF_ARITH_F16X3, MT, 2, 8>), dim3((strips + 3) / 4), dim3(256), 0, st, ta);
+    else
+        hipLaunchKernelGGL((vortex_tail_kernel<OJF_ARITH_F32, MT, 2, 8>), dim3((strips + 3) / 4), dim3(256), 0, st, ta);
     return check_hip(hipGetLastError(), "vortex_tail_kernel launch");
 }
 
@@ -1040,6 +1278,7 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
 
     ojf_net *net = new ojf_net();
     net->version = version; net->P = n_points; net->gf = growth; net->sem = sem;
+    net->arith = g_default_arith;
     net->c = 2 * n_points + 1 + (version == 2 ? sem : 0);
     net->cs = round_up(net->c, 4);
     net->heads = (version == 3 && sem) ? 2 : 1;
@@ -1063,7 +1302,7 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
             ba.add(la, 0, (i + 1) * c, slot_map((i + 1) * c, c, cs), 0, true);
             bb.add(lb, 0, c, slot_map(c, c, cs), 0, true);
             PackedConv pa, pb;
-            if (finish(ba, pa) || finish(bb, pb)) return -2;
+            if (finish(ba, pa, net->arith) || finish(bb, pb, net->arith)) return -2;
             net->dense[head].push_back(pa);
             net->dense[head].push_back(pb);
         }
@@ -1097,29 +1336,22 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
             ConvBuilder b(prev_phys, round_up(l.c_out, 4), 1, 1);
             b.add(l, 0, l.c_in, slot_map(l.c_in, l.c_in, prev_phys), 0, true);
             PackedConv pc;
-            if (finish(b, pc)) { rc = -2; break; }
+            if (finish(b, pc, net->arith)) { rc = -2; break; }
             net->pred.push_back(pc);
             prev_phys = round_up(l.c_out, 4);
         }
     }
     if (!rc && n_points == 9 && growth == 5 && (c == 19 || c == 20)) {
-        // fused prediction head: repack the 11 pointwise layers as [n2][S][lane] float4 per layer
+        // fused prediction head: repack the 11 pointwise layers as chain_layer fragments
         const int first = n_layers - (2 * (gf - 1) + 3);
         std::vector<float> cw, cb;
         int prev_phys = os;
         for (int l = first; l < n_layers; ++l) {
             const ojf_conv_layer &ly = L[l];
             const int nt_in = (prev_phys + 15) / 16, out_phys = round_up(ly.c_out, 4), nt_out = (out_phys + 15) / 16;
-            const size_t base = cw.size();
-            cw.resize(base + (size_t)nt_out * nt_in * 256, 0.0f);
-            for (int n2 = 0; n2 < nt_out; ++n2)
-                for (int S = 0; S < nt_in; ++S)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int j = 0; j < 4; ++j) {
-                            const int oc = n2 * 16 + (lane & 15), k = 16 * S + 4 * (lane >> 4) + j;
-                            if (oc < ly.c_out && k < ly.c_in)
-                                cw[base + (((size_t)n2 * nt_in + S) * 64 + lane) * 4 + j] = ly.weight_host[(size_t)oc * ly.c_in + k];
-                        }
+            pack_chain_layer(cw, net->arith, nt_out, nt_in, [&](int oc, int k) {
+                return oc < ly.c_out && k < ly.c_in ? ly.weight_host[(size_t)oc * ly.c_in + k] : 0.0f;
+            });
             const size_t bb = cb.size();
             cb.resize(bb + (size_t)nt_out * 16, 0.0f);
             for (int o = 0; o < ly.c_out; ++o) cb[bb + o] = ly.bias_host[o];
@@ -1216,10 +1448,15 @@ OJF_API int ojf_net_forward(ojf_net *net, float *est, int est_stride, ojf_stream
         constexpr int MT = 1;  // 4800 waves balance over 1024 SIMDs better than 2400 (see launch_conv_args)
         const int strips = (net->npix + MT * 16 - 1) / (MT * 16);
         const dim3 grid((strips + 3) / 4), block(256);
-        if (net->chain_kind == 19)
-            hipLaunchKernelGGL((chain1x1_kernel<MT, 8, 6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1>), grid, block, 0, st, ca);
+        const bool h16 = net->arith == OJF_ARITH_F16X3;
+        if (net->chain_kind == 19 && h16)
+            hipLaunchKernelGGL((chain1x1_kernel<OJF_ARITH_F16X3, MT, 8, 6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1>), grid, block, 0, st, ca);
+        else if (net->chain_kind == 19)
+            hipLaunchKernelGGL((chain1x1_kernel<OJF_ARITH_F32, MT, 8, 6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1>), grid, block, 0, st, ca);
+        else if (h16)
+            hipLaunchKernelGGL((chain1x1_kernel<OJF_ARITH_F16X3, MT, 8, 7, 7, 5, 5, 4, 4, 3, 3, 2, 2, 1>), grid, block, 0, st, ca);
         else
-            hipLaunchKernelGGL((chain1x1_kernel<MT, 8, 7, 7, 5, 5, 4, 4, 3, 3, 2, 2, 1>), grid, block, 0, st, ca);
+            hipLaunchKernelGGL((chain1x1_kernel<OJF_ARITH_F32, MT, 8, 7, 7, 5, 5, 4, 4, 3, 3, 2, 2, 1>), grid, block, 0, st, ca);
         return check_hip(hipGetLastError(), "chain1x1_kernel launch");
     }
     const float *pin = net->Y3;
@@ -1242,6 +1479,16 @@ OJF_API int ojf_net_forward(ojf_net *net, float *est, int est_stride, ojf_stream
 
 OJF_API int64_t ojf_net_macs_per_pixel(const ojf_net *net) { return net ? net->macs_per_pixel : -1; }
 
+OJF_API int ojf_net_set_arithmetic(int arithmetic)
+{
+    if (arithmetic != OJF_ARITH_F32 && arithmetic != OJF_ARITH_F16X3)
+        return ojf::fail("ojf_net_set_arithmetic: unknown arithmetic (OJF_ARITH_F32 or OJF_ARITH_F16X3)");
+    ojf::g_default_arith = arithmetic;
+    return 0;
+}
+
+OJF_API int ojf_net_get_arithmetic(const ojf_net *net) { return net ? net->arith : ojf::g_default_arith; }
+
 OJF_API int ojf_conv2d(const float *in, int in_stride, int in_off, float *out, int out_stride, int out_off,
                        const ojf_conv_layer *layer, int act, int h, int w, ojf_stream_t stream)
 {
@@ -1256,7 +1503,7 @@ OJF_API int ojf_conv2d(const float *in, int in_stride, int in_off, float *out, i
     ConvBuilder b(cin_phys, cout_phys, layer->ksize, layer->dilation);
     b.add(*layer, 0, layer->c_in, slot_map(layer->c_in, layer->c_in, cin_phys), 0, true);
     PackedConv pc;
-    if (finish(b, pc)) return -2;
+    if (finish(b, pc, g_default_arith)) return -2;
     float *pin = nullptr, *pout = nullptr;
     int rc = alloc_planes(&pin, npix, cin_phys);
     if (!rc) rc = alloc_planes(&pout, npix, cout_phys);

@@ -29,9 +29,13 @@ def _layer_array(layers):
 
 
 class FusionNetEngine:
-    def __init__(self, net, h, w, device):
+    def __init__(self, net, h, w, device, arithmetic='f16x3'):
+        """arithmetic: 'f16x3' (split-fp16 MFMA, default) | 'f32' (fp32-input MFMA); include/ojf.h OJF_ARITH_*."""
         _lib.require_gpu()
         self.lib = _lib.load()
+        if arithmetic not in _lib.ARITHMETIC:
+            raise ValueError('arithmetic must be one of {}'.format(sorted(_lib.ARITHMETIC)))
+        self.arithmetic = arithmetic
         if isinstance(net, FusionNet_v3):
             version = 3
         elif isinstance(net, FusionNet_v2):
@@ -46,6 +50,7 @@ class FusionNetEngine:
         arr, keep = _layer_array(layers)
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
+            _lib.check(self.lib.ojf_net_set_arithmetic(_lib.ARITHMETIC[arithmetic]), 'ojf_net_set_arithmetic')
             rc = self.lib.ojf_net_create(ctypes.byref(handle), version, net.n_points, net.gf,
                                          int(self.use_semantics), float(net.scale), arr, len(layers), h, w)
         _lib.check(rc, 'ojf_net_create')

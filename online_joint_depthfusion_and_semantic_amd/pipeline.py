@@ -89,11 +89,13 @@ class Pipeline(torch.nn.Module):
         return sum(t._version for t in list(net.parameters()) + list(net.buffers()))
 
     def _get_engine(self, h, w, device):
-        key = (h, w, str(device), self._weights_fingerprint())
+        arith = self.config.FUSION_MODEL.get('arithmetic', 'f16x3')
+        key = (h, w, str(device), arith, self._weights_fingerprint())
         if self._engine is None or self._engine_key != key:
             if self._engine is not None:
                 self._engine.close()
-            self._engine = FusionNetEngine(self._fusion_network, h, w, device)
+            self._engine = FusionNetEngine(self._fusion_network, h, w, device,
+                                           arithmetic=arith)
             self._engine_key = key
             self._est = torch.empty((h * w, self.n_points), dtype=torch.float32, device=device)
             self._fv = torch.empty((self.n_points, h * w), dtype=torch.float32, device=device)  # sample planes

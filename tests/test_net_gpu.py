@@ -1,5 +1,6 @@
-"""-m gpu: the HIP fusion net (fp32 MFMA convolutions) against the fp32 torch-CPU reference of the
-same layers.  Stated tolerance: |tsdf_est difference| <= 1e-5 absolute."""
+"""-m gpu: the HIP fusion net against the fp32 torch-CPU reference of the same layers, in both arithmetic
+modes of the MFMA kernels (include/ojf.h: split-fp16 'f16x3' = default, fp32-input 'f32').
+Stated tolerance: |tsdf_est difference| <= 1e-5 absolute, for both."""
 import numpy as np
 import pytest
 import torch
@@ -38,7 +39,9 @@ def seeded_net(version, sem, h, w, seed=0):
     (19, 19, 3, 9, _lib.ACT_RELU), (19, 19, 3, 27, _lib.ACT_RELU), (114, 95, 1, 1, _lib.ACT_LEAKY),
     (19, 114, 1, 1, _lib.ACT_RELU), (228, 19, 1, 1, _lib.ACT_NONE), (19, 9, 1, 1, _lib.ACT_TANH), (64, 48, 3, 2, _lib.ACT_NONE)])
 @pytest.mark.parametrize('h,w', [(24, 32), (37, 53)])
-def test_conv2d_layer(cuda, cin, cout, k, dil, act, h, w):
+@pytest.mark.parametrize('arith', ['f16x3', 'f32'])
+def test_conv2d_layer(cuda, arith, cin, cout, k, dil, act, h, w):
+    _lib.check(_lib.load().ojf_net_set_arithmetic(_lib.ARITHMETIC[arith]), 'ojf_net_set_arithmetic')
     g = torch.Generator().manual_seed(cin * 1000 + cout + k + dil)
     x = torch.randn(1, cin, h, w, generator=g)
     wt = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)
@@ -57,7 +60,9 @@ def test_conv2d_layer(cuda, cin, cout, k, dil, act, h, w):
     assert torch.all(got[:, :out_off] == -3.0) and torch.all(got[:, out_off + cout_p:] == -3.0)
     assert torch.all(got[:, out_off + cout:out_off + cout_p] == 0)  # pad channels carry zeros
     y = got[:, out_off:out_off + cout].reshape(h, w, cout).permute(2, 0, 1)
-    assert float((y - ref[0]).abs().max()) <= TOL
+    err = float((y - ref[0]).abs().max())
+    print('conv2d', arith, cin, cout, k, dil, 'max err %.2e' % err)
+    assert err <= TOL
 
 
 def _inputs(h, w, seed=1):
@@ -70,13 +75,15 @@ def _inputs(h, w, seed=1):
 
 @pytest.mark.parametrize('version,sem', [('v3', False), ('v3', True), ('v2', False), ('v2', True)])
 @pytest.mark.parametrize('h,w', [(24, 32), (60, 80), (120, 160)])
-def test_fusion_net_forward(cuda, version, sem, h, w):
+@pytest.mark.parametrize('arith', ['f16x3', 'f32'])
+def test_fusion_net_forward(cuda, arith, version, sem, h, w):
     net = seeded_net(version, sem, h, w)
     x = _inputs(h, w)
     x['semantic_frame'] = ((1 + x['sem_ids'].float()) / 30).view(1, 1, h, w)
     with torch.no_grad():
         ref = net(x)[0].permute(1, 2, 0).reshape(h * w, 9)
-    eng = FusionNetEngine(net, h, w, cuda)
+    eng = FusionNetEngine(net, h, w, cuda, arithmetic=arith)
+    assert eng.lib.ojf_net_get_arithmetic(eng.handle) == _lib.ARITHMETIC[arith]
     fv = x['tsdf_values'][0].permute(1, 2, 0).reshape(h * w, 9).contiguous().to(cuda)
     fw = x['tsdf_weights'][0].permute(1, 2, 0).reshape(h * w, 9).contiguous().to(cuda)
     eng.prepare_input(fv, fw, x['tsdf_frame'].reshape(h, w).contiguous().to(cuda),
@@ -86,6 +93,7 @@ def test_fusion_net_forward(cuda, version, sem, h, w):
         eng.forward(est)
         got = est.cpu()
         err = float((got[:, :9] - ref).abs().max())
+        print('net', arith, version, sem, h, w, 'max err %.2e' % err)
         assert err <= TOL, (version, sem, h, w, err)
         if stride > 9:
             assert torch.all(got[:, 9:] == 5.0)
