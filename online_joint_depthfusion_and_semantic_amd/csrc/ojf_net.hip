@@ -56,7 +56,10 @@ __device__ __forceinline__ void split_f16(const f32x4 &a, const f32x4 &b, f16x8 
 {
     const f32x8 x = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
     hi = __builtin_convertvector(x, f16x8);
-    lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x8), f16x8);
+    f32x8 r;  // x - hi, exact; written as an fma so that the fp16 -> fp32 conversion folds into v_fma_mix_f32
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = __builtin_fmaf((float)hi[i], -1.0f, x[i]);
+    lo = __builtin_convertvector(r, f16x8);
 }
 
 // acc += W * X for one 16x16 tile over a 32-wide K block, W and X given as split halves
@@ -149,6 +152,26 @@ __device__ __forceinline__ void build_tap_table(int2 *tab, const ConvArgs &a, in
             off = (a.in_g0 + cg) * a.npix + dy * a.w + dx;
         }
         tab[G] = int2{off, (int)(((unsigned)dy << 16) | ((unsigned)dx & 0xffffu))};
+    }
+}
+
+// split-fp16 kernel: byte offset of the tap's plane origin relative to a.in, and the tap's bit (0 = dead entry)
+__device__ __forceinline__ void build_tap_table16(int2 *tab, const ConvArgs &a, int entries)
+{
+    for (int G = threadIdx.x; G < entries; G += 256) {
+        const int t = G / a.c4, cg = G - t * a.c4;
+        int off = 0, bit = 0;
+        if (t < a.taps) {
+            int dy = 0, dx = 0;
+            if (a.taps == 9) {
+                const int ky = t / 3;
+                dy = (ky - 1) * a.dil;
+                dx = (t - 3 * ky - 1) * a.dil;
+            }
+            off = ((a.in_g0 + cg) * a.npix + dy * a.w + dx) * 16;
+            bit = 1 << t;
+        }
+        tab[G] = int2{off, bit};
     }
 }
 
@@ -284,40 +307,52 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const ConvGroup grp)
     const ConvArgs &a = grp.g[blockIdx.y];
     __shared__ int2 tab[(kMaxSteps + kPad16) * 8];
     __shared__ f32x4 wl[CS * NT * 128];
-    build_tap_table(tab, a, (a.nsteps + kPad16) * 8);
+    build_tap_table16(tab, a, (a.nsteps + kPad16) * 8);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
     const int strip = (blockIdx.x * 4 + wave) * (MT * 16);  // waves past the image still take part in the barriers
 
-    int py[MT], px[MT], plin[MT];
+    // vm: bit t set <=> tap t of this lane's pixel lies inside the image (bit 0 only for 1x1); p16: byte offset
+    int p16[MT];
+    unsigned vm[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int p = strip + m * 16 + i16;
-        plin[m] = p;
-        py[m] = p < a.npix ? p / a.w : -0x40000000;
-        px[m] = p - (p / a.w) * a.w;
+        p16[m] = p * 16;
+        const int py = p / a.w, px = p - py * a.w;
+        unsigned rm = 0, cm = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            rm |= ((unsigned)(py + (k - 1) * a.dil) < (unsigned)a.h ? 1u : 0u) << k;
+            cm |= ((unsigned)(px + (k - 1) * a.dil) < (unsigned)a.w ? 1u : 0u) << k;
+        }
+        const unsigned all9 = ((rm & 1u) ? cm : 0u) | ((rm & 2u) ? cm << 3 : 0u) | ((rm & 4u) ? cm << 6 : 0u);
+        vm[m] = p < a.npix ? (a.taps == 9 ? all9 : 1u) : 0u;
     }
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<f32x4 *>(a.in), 0, (a.in_g0 + a.c4) * a.npix * 16, 0x00020000);
 
+    // Operand fetch of superstep S: two (tap, channel group) entries per lane group.  The 9 taps' in-image tests
+    // are one bit each in vm[] (computed once per wave), so an entry costs and + compare + add + select; buffer
+    // loads return zeros for the out-of-range offset of an invalid tap.
     auto fetch = [&](f32x4(&xa)[MT], f32x4(&xb)[MT], int S, bool &live) {
         const int2 e0 = tab[S * 8 + 2 * g], e1 = tab[S * 8 + 2 * g + 1];
-        const int dy0 = e0.y >> 16, dx0 = (int)(short)(e0.y & 0xffff);
-        const int dy1 = e1.y >> 16, dx1 = (int)(short)(e1.y & 0xffff);
-        bool any_ok = false;
+        unsigned any = 0;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const bool ok0 = (unsigned)(py[m] + dy0) < (unsigned)a.h && (unsigned)(px[m] + dx0) < (unsigned)a.w;
-            const bool ok1 = (unsigned)(py[m] + dy1) < (unsigned)a.h && (unsigned)(px[m] + dx1) < (unsigned)a.w;
-            xa[m] = a.in[ok0 ? e0.x + plin[m] : -1];
-            xb[m] = a.in[ok1 ? e1.x + plin[m] : -1];
-            any_ok |= ok0 | ok1;
+            const unsigned o0 = (unsigned)(e0.x + p16[m]) | ((vm[m] & (unsigned)e0.y) ? 0u : 0xffffffffu);
+            const unsigned o1 = (unsigned)(e1.x + p16[m]) | ((vm[m] & (unsigned)e1.y) ? 0u : 0xffffffffu);
+            xa[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o0, 0, 0));
+            xb[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o1, 0, 0));
+            any |= vm[m] & (unsigned)(e0.y | e1.y);
         }
-        live = SKIP ? __any(any_ok) : true;
+        live = SKIP ? __any(any != 0) : true;  // dead superstep: every source pixel of the wave is outside the image
     };
     auto mac = [&](const f32x4(&xa)[MT], const f32x4(&xb)[MT], int sl) {
         f32x4 wh[NT], wlo[NT];
@@ -371,7 +406,7 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const ConvGroup grp)
 // four waves of a block share one fetch.  Tile counts are compile-time (two supported topologies:
 // 19- and 20-channel growth), so every register array is statically indexed.
 // ------------------------------------------------------------------------------------------------
-constexpr int kChainLdsFloat4 = 24 * 1024 / 16;
+constexpr int kChainLdsFloat4 = 48 * 1024 / 16;
 
 struct ChainArgs {
     const f32x4 *in;  // input planes, c4_in groups starting at in_g0
@@ -402,7 +437,7 @@ constexpr int chain_first_size(int arith, int ntin, int ntout)
     return (chain_per(arith, ntin, ntout) < ntout ? chain_per(arith, ntin, ntout) : ntout) * chain_kblocks(arith, ntin) *
            chain_unit(arith);
 }
-constexpr int kChainPre = 6;  // float4 registers per thread holding the prefetched next part (24 KB / 256 threads)
+constexpr int kChainPre = kChainLdsFloat4 / 256;  // float4 registers per thread holding the prefetched next part
 
 enum { kChainLeaky = 0, kChainRelu = 1, kChainAccumulate = 2, kChainLastRows = 3 };
 
@@ -1206,12 +1241,16 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
     for (int br = 0; br < 4; ++br) ta.v[br] = planes(net->V) + (size_t)br * c4 * net->npix;
     ta.w = planes(v.tail_w); ta.b1 = v.tail_b1; ta.bias_final = v.bias_final;
     ta.out = planes(out); ta.c4 = c4; ta.out_g0 = out_g0; ta.og_store = o4; ta.npix = net->npix;
-    constexpr int MT = 1;
-    const int strips = (net->npix + MT * 16 - 1) / (MT * 16);
-    if (net->arith == OJF_ARITH_F16X3)
-        hipLaunchKernelGGL((vortex_tail_kernel<OJF_ARITH_F16X3, MT, 2, 8>), dim3((strips + 3) / 4), dim3(256), 0, st, ta);
+    static const int mt_env = getenv("OJF_TAIL_MT") ? atoi(getenv("OJF_TAIL_MT")) : 1;  // tuning switch only
+    const int mt = net->arith == OJF_ARITH_F16X3 ? mt_env : 1;
+    const int strips = (net->npix + mt * 16 - 1) / (mt * 16);
+    const dim3 grid((strips + 3) / 4), block(256);
+    if (net->arith == OJF_ARITH_F16X3 && mt == 2)
+        hipLaunchKernelGGL((vortex_tail_kernel<OJF_ARITH_F16X3, 2, 2, 8>), grid, block, 0, st, ta);
+    else if (net->arith == OJF_ARITH_F16X3)
+        hipLaunchKernelGGL((vortex_tail_kernel<OJF_ARITH_F16X3, 1, 2, 8>), grid, block, 0, st, ta);
     else
-        hipLaunchKernelGGL((vortex_tail_kernel<OJF_ARITH_F32, MT, 2, 8>), dim3((strips + 3) / 4), dim3(256), 0, st, ta);
+        hipLaunchKernelGGL((vortex_tail_kernel<OJF_ARITH_F32, 1, 2, 8>), grid, block, 0, st, ta);
     return check_hip(hipGetLastError(), "vortex_tail_kernel launch");
 }
 
@@ -1445,18 +1484,23 @@ OJF_API int ojf_net_forward(ojf_net *net, float *est, int est_stride, ojf_stream
         ca.in = planes(net->Y3); ca.w = planes(net->chain_w); ca.bias = net->chain_b;
         ca.out_rows = est; ca.in_g0 = 0; ca.c4_in = o4; ca.npix = net->npix;
         ca.rows_stride = est_stride; ca.rows_n = net->P; ca.scale = net->scale;
-        constexpr int MT = 1;  // 4800 waves balance over 1024 SIMDs better than 2400 (see launch_conv_args)
-        const int strips = (net->npix + MT * 16 - 1) / (MT * 16);
-        const dim3 grid((strips + 3) / 4), block(256);
+        static const int mt_env = getenv("OJF_CHAIN_MT") ? atoi(getenv("OJF_CHAIN_MT")) : 1;  // tuning switch only
         const bool h16 = net->arith == OJF_ARITH_F16X3;
-        if (net->chain_kind == 19 && h16)
-            hipLaunchKernelGGL((chain1x1_kernel<OJF_ARITH_F16X3, MT, 8, 6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1>), grid, block, 0, st, ca);
+        const int mt = h16 ? mt_env : 1;  // fp32: 4800 waves balance over 1024 SIMDs better than 2400 (see launch_conv_args)
+        const int strips = (net->npix + mt * 16 - 1) / (mt * 16);
+        const dim3 grid((strips + 3) / 4), block(256);
+        if (net->chain_kind == 19 && h16 && mt == 2)
+            hipLaunchKernelGGL((chain1x1_kernel<OJF_ARITH_F16X3, 2, 8, 6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1>), grid, block, 0, st, ca);
+        else if (net->chain_kind == 19 && h16)
+            hipLaunchKernelGGL((chain1x1_kernel<OJF_ARITH_F16X3, 1, 8, 6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1>), grid, block, 0, st, ca);
         else if (net->chain_kind == 19)
-            hipLaunchKernelGGL((chain1x1_kernel<OJF_ARITH_F32, MT, 8, 6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1>), grid, block, 0, st, ca);
+            hipLaunchKernelGGL((chain1x1_kernel<OJF_ARITH_F32, 1, 8, 6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1>), grid, block, 0, st, ca);
+        else if (h16 && mt == 2)
+            hipLaunchKernelGGL((chain1x1_kernel<OJF_ARITH_F16X3, 2, 8, 7, 7, 5, 5, 4, 4, 3, 3, 2, 2, 1>), grid, block, 0, st, ca);
         else if (h16)
-            hipLaunchKernelGGL((chain1x1_kernel<OJF_ARITH_F16X3, MT, 8, 7, 7, 5, 5, 4, 4, 3, 3, 2, 2, 1>), grid, block, 0, st, ca);
+            hipLaunchKernelGGL((chain1x1_kernel<OJF_ARITH_F16X3, 1, 8, 7, 7, 5, 5, 4, 4, 3, 3, 2, 2, 1>), grid, block, 0, st, ca);
         else
-            hipLaunchKernelGGL((chain1x1_kernel<OJF_ARITH_F32, MT, 8, 7, 7, 5, 5, 4, 4, 3, 3, 2, 2, 1>), grid, block, 0, st, ca);
+            hipLaunchKernelGGL((chain1x1_kernel<OJF_ARITH_F32, 1, 8, 7, 7, 5, 5, 4, 4, 3, 3, 2, 2, 1>), grid, block, 0, st, ca);
         return check_hip(hipGetLastError(), "chain1x1_kernel launch");
     }
     const float *pin = net->Y3;
