@@ -85,8 +85,15 @@ class Pipeline(torch.nn.Module):
 
     # ---- cached device objects ----------------------------------------------------------------
     def _weights_fingerprint(self):
+        """In-place weight updates (optimizer steps, load_state_dict) bump the tensors' version counters.  Walking
+        the module tree costs ~0.3 ms, so the tensor list is cached and re-collected every 64 frames."""
         net = self._fusion_network
-        return sum(t._version for t in list(net.parameters()) + list(net.buffers()))
+        cache = self.__dict__.get('_fp_cache')
+        if cache is None or cache[0] != id(net) or cache[2] >= 64:
+            cache = [id(net), list(net.parameters()) + list(net.buffers()), 0]
+            self.__dict__['_fp_cache'] = cache
+        cache[2] += 1
+        return (len(cache[1]), sum(t._version for t in cache[1]))
 
     def _get_engine(self, h, w, device):
         arith = self.config.FUSION_MODEL.get('arithmetic', 'f16x3')
