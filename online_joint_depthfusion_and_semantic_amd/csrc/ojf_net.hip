@@ -300,7 +300,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGroup grp)
 constexpr int kPad16 = 6;  // dead supersteps behind the weights and the tap table (chunk copies + prefetch)
 constexpr int conv16_chunk(int nt) { return nt <= 2 ? 6 : 3; }  // supersteps per LDS chunk (<= 24 KB)
 
-template <int MT, int NT, bool SKIP = true>
+// ABL: profiling-only ablation mask (tests/microbench): 1 = no activation loads, 2 = no LDS weight reads,
+// 4 = no MFMA, 8 = no fp16 split.  Product launches always use ABL = 0.
+template <int MT, int NT, bool SKIP = true, int ABL = 0>
 __global__ __launch_bounds__(256) void conv_f16x3_kernel(const ConvGroup grp)
 {
     constexpr int CS = conv16_chunk(NT);
@@ -341,16 +343,22 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const ConvGroup grp)
     // Operand fetch of superstep S: two (tap, channel group) entries per lane group.  The 9 taps' in-image tests
     // are one bit each in vm[] (computed once per wave), so an entry costs and + compare + add + select; buffer
     // loads return zeros for the out-of-range offset of an invalid tap.
-    auto fetch = [&](f32x4(&xa)[MT], f32x4(&xb)[MT], int S, bool &live) {
-        const int2 e0 = tab[S * 8 + 2 * g], e1 = tab[S * 8 + 2 * g + 1];
+    const int4 *tab4 = reinterpret_cast<const int4 *>(tab) + g;  // lane group g's two entries of a superstep
+    auto fetch = [&](f32x4(&xa)[MT], f32x4(&xb)[MT], const int4 e, bool &live) {
         unsigned any = 0;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const unsigned o0 = (unsigned)(e0.x + p16[m]) | ((vm[m] & (unsigned)e0.y) ? 0u : 0xffffffffu);
-            const unsigned o1 = (unsigned)(e1.x + p16[m]) | ((vm[m] & (unsigned)e1.y) ? 0u : 0xffffffffu);
-            xa[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o0, 0, 0));
-            xb[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o1, 0, 0));
-            any |= vm[m] & (unsigned)(e0.y | e1.y);
+            const unsigned o0 = (unsigned)(e.x + p16[m]) | ((vm[m] & (unsigned)e.y) ? 0u : 0xffffffffu);
+            const unsigned o1 = (unsigned)(e.z + p16[m]) | ((vm[m] & (unsigned)e.w) ? 0u : 0xffffffffu);
+            if constexpr (ABL & 1) {
+                xa[m] = f32x4{1.f, 2.f, 3.f, 4.f};
+                xb[m] = f32x4{1.f, 2.f, 3.f, 4.f};
+                asm volatile("" ::"v"(o0), "v"(o1));
+            } else {
+                xa[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o0, 0, 0));
+                xb[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o1, 0, 0));
+            }
+            any |= vm[m] & (unsigned)(e.y | e.w);
         }
         live = SKIP ? __any(any != 0) : true;  // dead superstep: every source pixel of the wave is outside the image
     };
@@ -358,38 +366,64 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const ConvGroup grp)
         f32x4 wh[NT], wlo[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            wh[n] = wl[(sl * NT + n) * 128 + lane];
-            wlo[n] = wl[(sl * NT + n) * 128 + 64 + lane];
+            if constexpr (ABL & 2) {
+                wh[n] = wlo[n] = f32x4{1.f, 1.f, 1.f, 1.f};
+                asm volatile("" ::"s"(sl));
+            } else {
+                wh[n] = wl[(sl * NT + n) * 128 + lane];
+                wlo[n] = wl[(sl * NT + n) * 128 + 64 + lane];
+            }
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             f16x8 xh, xl;
-            split_f16(xa[m], xb[m], xh, xl);
+            if constexpr (ABL & 8) {
+                xh = __builtin_bit_cast(f16x8, xa[m]);
+                xl = __builtin_bit_cast(f16x8, xb[m]);
+            } else {
+                split_f16(xa[m], xb[m], xh, xl);
+            }
+            if constexpr (ABL & 4) {
+                asm volatile("" ::"v"(xh), "v"(xl));
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[m][n] = mfma_f16x3(wh[n], wlo[n], xh, xl, acc[m][n]);
+                for (int n = 0; n < NT; ++n) asm volatile("" ::"v"(wh[n]), "v"(wlo[n]));
+            } else {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = mfma_f16x3(wh[n], wlo[n], xh, xl, acc[m][n]);
+            }
         }
     };
 
     __syncthreads();  // tap table
     f32x4 xa0[MT], xb0[MT], xa1[MT], xb1[MT], xa2[MT], xb2[MT];
     bool v0, v1, v2;
-    fetch(xa0, xb0, 0, v0);
-    fetch(xa1, xb1, 1, v1);
+    constexpr int kPre = CS * NT * 128 / 256;  // float4 per thread of one weight chunk
+    f32x4 wpre[kPre];                          // the next chunk, in flight while the current one computes
+#pragma unroll
+    for (int i = 0; i < kPre; ++i) wpre[i] = a.wp[i * 256 + threadIdx.x];
+    fetch(xa0, xb0, tab4[0], v0);
+    fetch(xa1, xb1, tab4[4], v1);
     int sl = CS;
     for (int S = 0; S < a.nsteps; S += 3) {
+        // the three table reads of this iteration are issued together (one LDS latency instead of three)
+        const int4 t2 = tab4[(S + 2) * 4], t3 = tab4[(S + 3) * 4], t4 = tab4[(S + 4) * 4];
         if (sl == CS) {  // next weight chunk (CS is a multiple of the 3 supersteps of one iteration)
             if (S) __syncthreads();
-            const f32x4 *src = a.wp + (size_t)S * NT * 128;
 #pragma unroll
-            for (int i = 0; i < CS * NT * 128 / 256; ++i) wl[i * 256 + threadIdx.x] = src[i * 256 + threadIdx.x];
+            for (int i = 0; i < kPre; ++i) wl[i * 256 + threadIdx.x] = wpre[i];
             __syncthreads();
+            if (S + CS < a.nsteps) {
+                const f32x4 *src = a.wp + (size_t)(S + CS) * NT * 128;
+#pragma unroll
+                for (int i = 0; i < kPre; ++i) wpre[i] = src[i * 256 + threadIdx.x];
+            }
             sl = 0;
         }
-        fetch(xa2, xb2, S + 2, v2);
+        fetch(xa2, xb2, t2, v2);
         if (!SKIP || v0) mac(xa0, xb0, sl);
-        fetch(xa0, xb0, S + 3, v0);
+        fetch(xa0, xb0, t3, v0);
         if (!SKIP || v1) mac(xa1, xb1, sl + 1);
-        fetch(xa1, xb1, S + 4, v1);
+        fetch(xa1, xb1, t4, v1);
         if (!SKIP || v2) mac(xa2, xb2, sl + 2);
         sl += 3;
     }
@@ -664,37 +698,66 @@ __global__ __launch_bounds__(256) void vortex_tail_kernel(const TailArgs a)
     }
 }
 
-struct PoolArgs {
-    const f32x4 *in;
-    f32x4 *out;
-    const float *bias;  // bias + ReLU (the branch's BN+ReLU after its 1x1) for the first act_c4 groups
-    int in_g0, out_g0, h, w, c4, act_c4;
+// Pool pyramid of a VortexPooling (model.py:143-155): branch b = 1..3 sees its entry-conv pre-activation pooled b
+// times by nn.AvgPool2d(3, 1, 1) (zero padding, count_include_pad: always / 9), then bias + ReLU.  One launch:
+// a block takes a 32x8-pixel tile of ONE channel group, stages it with a halo of b pixels in LDS and applies the b
+// pooling levels there (every level is zero outside the image, like the padded intermediate tensors of the
+// reference); the intermediate levels never reach HBM.  Summation order per level = row-major taps, as before.
+struct PyramidArgs {
+    const f32x4 *z;        // entry-conv output planes; branch b's pre-activation = groups [b*c4, (b+1)*c4)
+    f32x4 *q[3];           // branch inputs out: planes of c4 groups each
+    const float *bias[3];  // per branch: c4*4 floats
+    int h, w, c4;
 };
 
-// 3x3 average pool, stride 1, zero padding 1, count_include_pad (always / 9): nn.AvgPool2d(3,1,1)
-__global__ __launch_bounds__(256) void avgpool3_kernel(const PoolArgs a)
+constexpr int kPoolTW = 32, kPoolTH = 8, kPoolStride = kPoolTW + 6;
+
+__global__ __launch_bounds__(256) void pool_pyramid_kernel(const PyramidArgs a)
 {
-    const int item = blockIdx.x * blockDim.x + threadIdx.x;
-    const int npix = a.h * a.w;
-    if (item >= npix * a.c4) return;
-    const int cg = item / npix, p = item - cg * npix;
-    const int y = p / a.w, x = p - y * a.w;
-    const f32x4 *plane = a.in + (size_t)(a.in_g0 + cg) * npix;
-    f32x4 s{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-            const int sy = y + dy, sx = x + dx;
-            if ((unsigned)sy < (unsigned)a.h && (unsigned)sx < (unsigned)a.w) s += plane[sy * a.w + sx];
+    __shared__ f32x4 buf[2][kPoolStride * (kPoolTH + 6)];
+    const int lv = blockIdx.y / a.c4 + 1, cg = blockIdx.y - (lv - 1) * a.c4;  // levels of this block's group
+    const int tiles_x = (a.w + kPoolTW - 1) / kPoolTW;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int x0 = tx * kPoolTW, y0 = ty * kPoolTH, npix = a.h * a.w;
+    const f32x4 *plane = a.z + (size_t)(lv * a.c4 + cg) * npix;
+    const f32x4 zero{0.f, 0.f, 0.f, 0.f};
+    {
+        const int W0 = kPoolTW + 2 * lv, H0 = kPoolTH + 2 * lv;
+        for (int i = threadIdx.x; i < W0 * H0; i += 256) {
+            const int ly = i / W0, lx = i - ly * W0;
+            const int gy = y0 - lv + ly, gx = x0 - lv + lx;
+            const bool in = (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
+            buf[0][ly * kPoolStride + lx] = in ? plane[gy * a.w + gx] : zero;
         }
-    s = s / 9.0f;
-    if (cg < a.act_c4) {
-        s += *reinterpret_cast<const f32x4 *>(a.bias + 4 * cg);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s[j] = s[j] > 0.0f ? s[j] : 0.0f;
     }
-    a.out[(size_t)(a.out_g0 + cg) * npix + p] = s;
+    __syncthreads();
+    int cur = 0;
+    for (int l = 1; l <= lv; ++l) {
+        const int halo = lv - l;  // halo of this level's region; the source region has halo + 1
+        const int Wl = kPoolTW + 2 * halo, Hl = kPoolTH + 2 * halo;
+        const f32x4 *src = buf[cur];
+        for (int i = threadIdx.x; i < Wl * Hl; i += 256) {
+            const int ly = i / Wl, lx = i - ly * Wl;
+            const int gy = y0 - halo + ly, gx = x0 - halo + lx;
+            const bool in = (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
+            f32x4 s = zero;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) s += src[(ly + dy) * kPoolStride + lx + dx];
+            s = s / 9.0f;
+            if (l < lv) {
+                buf[cur ^ 1][ly * kPoolStride + lx] = in ? s : zero;
+            } else if (in) {
+                s += *reinterpret_cast<const f32x4 *>(a.bias[lv - 1] + 4 * cg);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[j] = s[j] > 0.0f ? s[j] : 0.0f;
+                a.q[lv - 1][(size_t)cg * npix + gy * a.w + gx] = s;
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
 }
 
 constexpr int kSumBlocks = 32;
@@ -1066,7 +1129,7 @@ struct ojf_net {
     float *X[2] = {nullptr, nullptr};  // dense-growth buffers, (gf+1)*cs
     float *T = nullptr;                // cs
     float *Z = nullptr;                // 4*cs
-    float *Q1 = nullptr, *Q2 = nullptr, *Q3 = nullptr;  // pooled branch pre-activations: 3cs, 2cs, cs
+    float *Q1 = nullptr, *Q2 = nullptr, *Q3 = nullptr;  // inputs of branches 1..3 (pool pyramid outputs), cs each
     float *U = nullptr;                                  // 4*cs: first-3x3 outputs of the four branches
     float *V = nullptr;                                  // 4*cs: closing-3x3 outputs of the four branches
     float *CAT = nullptr;              // 4*os
@@ -1198,15 +1261,6 @@ static void free_vortex(Vortex &v)
         if (p) (void)hipFree(p);
 }
 
-static int launch_pool(const float *in, int in_g0, float *out, int out_g0, const float *bias, int c4, int act_c4, int h,
-                       int w, hipStream_t st)
-{
-    PoolArgs a{planes(in), planes(out), bias, in_g0, out_g0, h, w, c4, act_c4};
-    const int items = h * w * c4;
-    hipLaunchKernelGGL(avgpool3_kernel, dim3((items + 255) / 256), dim3(256), 0, st, a);
-    return check_hip(hipGetLastError(), "avgpool3_kernel launch");
-}
-
 // in: planes, window starting at group in_g0 (c_in_phys/4 groups); out: planes at group out_g0
 static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float *out, int out_g0, hipStream_t st)
 {
@@ -1223,12 +1277,16 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
     OJF_HIP(hipEventRecord(net->ev_join, net->side));
     // branch entries: one GEMM, branch 0 gets bias + ReLU in the epilogue
     if (launch_conv(v.stacked, in, in_g0, net->Z, 0, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w, st)) return -2;
-    // pool pyramid on the pre-activations of branches 1..3 (one launch per level; the first c4
-    // groups of each level are that level's branch input and get its bias + ReLU):
-    //   Q1 = pool(Z[slots 1..3]) ; Q2 = pool(Q1[slots 1..2]) ; Q3 = pool(Q2[slot 1])
-    if (launch_pool(net->Z, c4, net->Q1, 0, v.pool_bias[1], 3 * c4, c4, h, w, st)) return -2;
-    if (launch_pool(net->Q1, c4, net->Q2, 0, v.pool_bias[2], 2 * c4, c4, h, w, st)) return -2;
-    if (launch_pool(net->Q2, c4, net->Q3, 0, v.pool_bias[3], c4, c4, h, w, st)) return -2;
+    {   // pool pyramid on the pre-activations of branches 1..3: Q_b = ReLU(pool^b(Z[slot b]) + bias_b), one launch
+        PyramidArgs pa;
+        pa.z = planes(net->Z);
+        pa.q[0] = planes(net->Q1); pa.q[1] = planes(net->Q2); pa.q[2] = planes(net->Q3);
+        for (int b = 0; b < 3; ++b) pa.bias[b] = v.pool_bias[b + 1];
+        pa.h = h; pa.w = w; pa.c4 = c4;
+        const int tiles = ((w + kPoolTW - 1) / kPoolTW) * ((h + kPoolTH - 1) / kPoolTH);
+        hipLaunchKernelGGL(pool_pyramid_kernel, dim3(tiles, 3 * c4), dim3(256), 0, st, pa);
+        OJF_HIP(hipGetLastError());
+    }
     const float *bin[4] = {net->Z, net->Q1, net->Q2, net->Q3};
     static const bool unfused = getenv("OJF_NO_TAIL") != nullptr;  // ablation switch only
     const bool fused = v.tail_w && !unfused;
@@ -1426,8 +1484,8 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
     if (!rc && net->heads == 2) rc = alloc_planes(&net->X[1], np, (gf + 1) * cs);
     if (!rc) rc = alloc_planes(&net->T, np, cs);
     if (!rc) rc = alloc_planes(&net->Z, np, 4 * cs);
-    if (!rc) rc = alloc_planes(&net->Q1, np, 3 * cs);
-    if (!rc) rc = alloc_planes(&net->Q2, np, 2 * cs);
+    if (!rc) rc = alloc_planes(&net->Q1, np, cs);
+    if (!rc) rc = alloc_planes(&net->Q2, np, cs);
     if (!rc) rc = alloc_planes(&net->Q3, np, cs);
     if (!rc) rc = alloc_planes(&net->U, np, 4 * cs);
     if (!rc) rc = alloc_planes(&net->V, np, 4 * cs);
