@@ -51,6 +51,7 @@ SIGNATURES = {
     'ojf_net_macs_per_pixel': (_c.c_int64, [_vp]),
     'ojf_net_set_arithmetic': (_i, [_i]),
     'ojf_net_get_arithmetic': (_i, [_vp]),
+    'ojf_net_check': (_i, [_vp]),
     'ojf_conv2d': (_i, [_vp, _i, _i, _vp, _i, _i, _c.POINTER(ConvLayer), _i, _i, _i, _vp]),
     'ojf_volume_fill_f16': (_i, [_vp, _sz, _f, _vp]),
     'ojf_volume_fill_u8': (_i, [_vp, _sz, _c.c_uint8, _vp]),

@@ -40,6 +40,7 @@
 //     instead of in_chs (114/228);
 //   * the global-average branch is constant over the image: it is reduced to a per-frame bias of
 //     the final 1x1 convolution (two tiny kernels), removing its 114 input columns from that GEMM.
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 
@@ -82,6 +83,7 @@ struct ConvArgs {
     float *out_rows;   // last layer only: row-major [npix, rows_stride] scalars, channels < rows_n
     const f32x4 *wp;   // packed weights [oc tile][superstep][lane] float4
     const float *bias; // [n_ot*16]
+    const float *rinv; // split-fp16: [n_ot*16] inverse of the per-output-channel power-of-two weight scale
     int in_g0, out_g0, rows_stride, rows_n;
     int h, w, npix;
     int taps, dil;
@@ -90,7 +92,28 @@ struct ConvArgs {
     int og_store;    // output channel groups written (planar mode)
     int act, act_n;  // activation applied to output channels < act_n
     float scale;
+    int *ovf;        // split-fp16 only: set to 1 when an activation leaves the fp16 range (host-mapped flag)
 };
+
+// Split-fp16 range guard.  Kernels keep a running maximum of the magnitudes of every value a later layer will
+// split (2 VALU per float4: v_max3_f32 with |.| modifiers) and raise the flag if it exceeds the fp16 range.
+// v_max ignores NaN operands; that is sufficient here: with finite weights (checked at creation) and guarded
+// inputs (prepare_input_kernel tests NaN explicitly) the FIRST out-of-range event is always a finite value beyond
+// 65504 or an infinity at a guarded point - NaN can only appear downstream of one.
+__device__ __forceinline__ float guard_max(float mx, const f32x4 &v)
+{
+    return fmaxf(fmaxf(fmaxf(mx, fabsf(v[0])), fmaxf(fabsf(v[1]), fabsf(v[2]))), fabsf(v[3]));
+}
+__device__ __forceinline__ bool beyond_f16(const f32x4 &v)  // NaN-aware form for raw inputs
+{
+    const float t = (v[0] + v[1]) + (v[2] + v[3]);
+    return !(guard_max(0.0f, v) <= 65504.0f) || t != t;
+}
+__device__ __forceinline__ f32x4 fma4(const f32x4 &a, const f32x4 &b, const f32x4 &c)
+{
+    return f32x4{__builtin_fmaf(a[0], b[0], c[0]), __builtin_fmaf(a[1], b[1], c[1]), __builtin_fmaf(a[2], b[2], c[2]),
+                 __builtin_fmaf(a[3], b[3], c[3])};
+}
 
 // ReLU / LeakyReLU / identity are one select with a slope (0, 0.01, 1); Tanh is a separate,
 // wave-uniform path (last layer only)
@@ -103,19 +126,23 @@ constexpr int kMaxSteps = 128;  // supersteps per conv (K <= 2048)
 constexpr int kPadSteps = 4;    // dead supersteps appended for the three-stage prefetch (fetches reach S+4)
 
 // C/D layout of the 16x16 MFMAs: lane (i16, g) holds column i16 (pixel) and rows 4g..4g+3 (output channels)
-template <int MT, int NT>
+template <int MT, int NT, bool GUARD = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x4 (&acc)[MT][NT], int strip, int i16, int g)
 {
     const float slope = act_slope(a.act);
     const bool use_tanh = a.act == OJF_ACT_TANH;
+    float gmax = 0.0f;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int og = n * 4 + g;  // output channel group
         const f32x4 b = *reinterpret_cast<const f32x4 *>(a.bias + (size_t)n * 16 + 4 * g);
+        f32x4 ri{1.f, 1.f, 1.f, 1.f};
+        if constexpr (GUARD) ri = *reinterpret_cast<const f32x4 *>(a.rinv + (size_t)n * 16 + 4 * g);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int p = strip + m * 16 + i16;
-            f32x4 v = acc[m][n] + b;
+            const f32x4 lin4 = GUARD ? fma4(acc[m][n], ri, b) : acc[m][n] + b;
+            f32x4 v = lin4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float lin = v[j];
@@ -130,9 +157,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x4 (&a
                     if (og * 4 + j < a.rows_n) a.out_rows[(size_t)p * a.rows_stride + og * 4 + j] = v[j];
             } else if (og < a.og_store) {
                 a.out[(size_t)(a.out_g0 + og) * a.npix + p] = v;
+                if constexpr (GUARD) gmax = guard_max(gmax, lin4);  // pre-activation magnitude
             }
         }
     }
+    if constexpr (GUARD)
+        if (gmax > 65504.0f && a.ovf) *a.ovf = 1;
 }
 
 // Per-(superstep, slot) source table: float4 index of the tap's plane origin relative to a.in (-1 = the zero
@@ -427,7 +457,7 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const ConvGroup grp)
         if (!SKIP || v2) mac(xa2, xb2, sl + 2);
         sl += 3;
     }
-    conv_epilogue<MT, NT>(a, acc, strip, i16, g);
+    conv_epilogue<MT, NT, true>(a, acc, strip, i16, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -449,6 +479,7 @@ struct ChainArgs {
     float *out_rows;  // [npix, rows_stride], channels < rows_n
     int in_g0, c4_in, npix, rows_stride, rows_n;
     float scale;
+    int *ovf;  // split-fp16 range guard flag (see ConvArgs)
 };
 
 // Weight fragments of one (output tile, K block) pair.  fp32: K block = one 16-channel input tile, 64 float4
@@ -471,6 +502,8 @@ constexpr int chain_first_size(int arith, int ntin, int ntout)
     return (chain_per(arith, ntin, ntout) < ntout ? chain_per(arith, ntin, ntout) : ntout) * chain_kblocks(arith, ntin) *
            chain_unit(arith);
 }
+// per-layer floats in the bias stream: bias[NTOUT*16], and for split-fp16 the inverse row scales behind it
+constexpr int chain_bias_stride(int arith, int ntout) { return (arith == OJF_ARITH_F16X3 ? 2 : 1) * ntout * 16; }
 constexpr int kChainPre = kChainLdsFloat4 / 256;  // float4 registers per thread holding the prefetched next part
 
 enum { kChainLeaky = 0, kChainRelu = 1, kChainAccumulate = 2, kChainLastRows = 3 };
@@ -552,12 +585,16 @@ __device__ __forceinline__ void chain_layer(const f32x4 (&in)[MT][NA], f32x4 (&o
     }
     if constexpr (MODE != kChainAccumulate) {
         const int g = lane >> 4;
+        float gmax = 0.0f;
 #pragma unroll
         for (int n2 = 0; n2 < NTOUT; ++n2) {
             const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + n2 * 16 + 4 * g);
+            f32x4 ri{1.f, 1.f, 1.f, 1.f};
+            if constexpr (ARITH == OJF_ARITH_F16X3) ri = *reinterpret_cast<const f32x4 *>(bias + (NTOUT + n2) * 16 + 4 * g);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                f32x4 v = out[m][n2] + b;
+                const f32x4 lin4 = ARITH == OJF_ARITH_F16X3 ? fma4(out[m][n2], ri, b) : out[m][n2] + b;
+                f32x4 v = lin4;
                 if constexpr (MODE == kChainLastRows) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -569,10 +606,13 @@ __device__ __forceinline__ void chain_layer(const f32x4 (&in)[MT][NA], f32x4 (&o
                     constexpr float slope = MODE == kChainRelu ? 0.0f : 0.01f;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.0f ? v[j] : slope * v[j];
+                    if constexpr (ARITH == OJF_ARITH_F16X3) gmax = guard_max(gmax, lin4);  // pre-activation magnitude
                     out[m][n2] = v;
                 }
             }
         }
+        if constexpr (ARITH == OJF_ARITH_F16X3)
+            if (gmax > 65504.0f && a.ovf) *a.ovf = 1;
     }
 }
 
@@ -593,7 +633,7 @@ __device__ __forceinline__ void chain_run(f32x4 (&x)[MT][8], f32x4 (&y)[MT][8], 
     chain_layer<ARITH, MT, NTIN, NTOUT, kChainLeaky, chain_first_size(ARITH, NTOUT, NTNEXT)>(x, y, wlds, wg, bias, a, p,
                                                                                              lane, pre);
     chain_run<ARITH, MT, NTOUT, NTNEXT, REST...>(y, x, wlds, wg + (size_t)chain_layer_size(ARITH, NTIN, NTOUT),
-                                                 bias + NTOUT * 16, a, p, lane, pre);
+                                                 bias + chain_bias_stride(ARITH, NTOUT), a, p, lane, pre);
 }
 
 template <int ARITH, int MT, int NT0, int... NTS>
@@ -637,10 +677,12 @@ __global__ __launch_bounds__(256) void chain1x1_kernel(const ChainArgs a)
 struct TailArgs {
     const f32x4 *v[4];  // branch inputs (planes, c4 groups each)
     const f32x4 *w;     // stream: W1_0 [NO][NV], Wf_0 [NO][NO], W1_1, Wf_1, ... (chain_layer fragments)
-    const float *b1;    // 4 x NO*16
+    const float *b1;    // 4 x chain_bias_stride: closing-1x1 biases (+ inverse row scales)
     const float *bias_final;  // NO*16 (per-frame: includes the global-average branch)
+    const float *rinv_final;  // split-fp16: NO*16 inverse row scales of the final conv (common to the four blocks)
     f32x4 *out;
     int c4, out_g0, og_store, npix;
+    int *ovf;  // split-fp16 range guard flag (see ConvArgs)
 };
 
 template <int ARITH, int MT, int NV, int NO>
@@ -654,7 +696,7 @@ __global__ __launch_bounds__(256) void vortex_tail_kernel(const TailArgs a)
 #pragma unroll
     for (int m = 0; m < MT; ++m) p[m] = strip + m * 16 + i16;
     ChainArgs ca;  // only npix is read by the layer code in these modes
-    ca.npix = a.npix; ca.out_rows = nullptr; ca.rows_n = 0; ca.rows_stride = 0; ca.scale = 1.0f;
+    ca.npix = a.npix; ca.out_rows = nullptr; ca.rows_n = 0; ca.rows_stride = 0; ca.scale = 1.0f; ca.ovf = a.ovf;
     f32x4 y[MT][NO];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -680,7 +722,7 @@ __global__ __launch_bounds__(256) void vortex_tail_kernel(const TailArgs a)
                 vin[m][S] = a.v[b][ok ? G * a.npix + p[m] : -1];
             }
         const f32x4 *w1 = a.w + b * per_branch, *wf = w1 + (size_t)chain_layer_size(ARITH, NV, NO);
-        chain_layer<ARITH, MT, NV, NO, kChainRelu, chain_first_size(ARITH, NO, NO)>(vin, t, wlds, w1, a.b1 + b * NO * 16, ca, p,
+        chain_layer<ARITH, MT, NV, NO, kChainRelu, chain_first_size(ARITH, NO, NO)>(vin, t, wlds, w1, a.b1 + b * chain_bias_stride(ARITH, NO), ca, p,
                                                                                    lane, pre);
         if (b < 3)
             chain_layer<ARITH, MT, NO, NO, kChainAccumulate, chain_first_size(ARITH, NV, NO)>(t, y, wlds, wf, nullptr, ca, p,
@@ -688,14 +730,23 @@ __global__ __launch_bounds__(256) void vortex_tail_kernel(const TailArgs a)
         else
             chain_layer<ARITH, MT, NO, NO, kChainAccumulate, 0>(t, y, wlds, wf, nullptr, ca, p, lane, pre);
     }
+    float gmax = 0.0f;
 #pragma unroll
     for (int n = 0; n < NO; ++n) {
         const int og = n * 4 + g;
         const f32x4 bf = *reinterpret_cast<const f32x4 *>(a.bias_final + n * 16 + 4 * g);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
-            if (p[m] < a.npix && og < a.og_store) a.out[(size_t)(a.out_g0 + og) * a.npix + p[m]] = y[m][n] + bf;
+            if (p[m] < a.npix && og < a.og_store) {
+                f32x4 v = y[m][n] + bf;
+                if constexpr (ARITH == OJF_ARITH_F16X3)
+                    v = fma4(y[m][n], *reinterpret_cast<const f32x4 *>(a.rinv_final + n * 16 + 4 * g), bf);
+                a.out[(size_t)(a.out_g0 + og) * a.npix + p[m]] = v;
+                if constexpr (ARITH == OJF_ARITH_F16X3) gmax = guard_max(gmax, v);
+            }
     }
+    if constexpr (ARITH == OJF_ARITH_F16X3)
+        if (gmax > 65504.0f && a.ovf) *a.ovf = 1;
 }
 
 // Pool pyramid of a VortexPooling (model.py:143-155): branch b = 1..3 sees its entry-conv pre-activation pooled b
@@ -826,6 +877,7 @@ struct PrepArgs {
     f32x4 *x0;
     f32x4 *x1;
     int rows_stride, in_layout, npix, P, cs4, n_classes, v2_sem;
+    int *ovf;  // split-fp16 range guard flag (NULL for fp32 arithmetic)
 };
 
 // modules/pipeline.py:74-102 _prepare_fusion_input: channels [values(P) | weights(P) | depth | (sem)]
@@ -841,6 +893,7 @@ __global__ __launch_bounds__(256) void prepare_input_kernel(const PrepArgs a)
     const float *wt = a.weights + pix;
     const float d = a.depth[p];
     const float sf = a.sem ? (1.0f + (float)a.sem[p]) / (float)a.n_classes : 0.0f;
+    bool bad = false;
     for (int cg = 0; cg < a.cs4; ++cg) {
         f32x4 r0, r1;
 #pragma unroll
@@ -856,7 +909,9 @@ __global__ __launch_bounds__(256) void prepare_input_kernel(const PrepArgs a)
         }
         a.x0[(size_t)cg * a.npix + p] = r0;
         if (a.x1) a.x1[(size_t)cg * a.npix + p] = r1;
+        bad = bad || beyond_f16(r0) || beyond_f16(r1);
     }
+    if (bad && a.ovf) *a.ovf = 1;
 }
 
 // rows <-> planes (ojf_conv2d test entry point only)
@@ -889,11 +944,49 @@ __global__ __launch_bounds__(256) void planes_to_rows_kernel(const f32x4 *planes
 struct PackedConv {
     float *wp = nullptr;    // device; layout depends on arith
     float *bias = nullptr;  // device, n_ot*16 floats
+    float *rinv = nullptr;  // device, n_ot*16 floats (split-fp16 only)
     int c_in_phys = 0, c_out_phys = 0, taps = 1, dil = 1, n_ot = 0;
     int arith = OJF_ARITH_F32, nsteps = 0;  // supersteps: 4 (fp32) or 8 (split-fp16) K entries each
 };
 
 static int g_default_arith = OJF_ARITH_F16X3;
+
+// Range guard of the split-fp16 arithmetic: one host-mapped flag per process.  Kernels store 1 when a value that
+// a later layer would split leaves the fp16 range (or is NaN); the host polls it without synchronising
+// (ojf_net_forward) or after a stream synchronise (ojf_net_check).  No traffic unless it fires.
+static volatile int *g_ovf_host = nullptr;
+static int *g_ovf_dev = nullptr;
+
+static int *overflow_flag()
+{
+    if (!g_ovf_dev) {
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, sizeof(int), hipHostMallocMapped) != hipSuccess) return nullptr;
+        *static_cast<int *>(h) = 0;
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) return nullptr;
+        g_ovf_host = static_cast<volatile int *>(h);
+        g_ovf_dev = static_cast<int *>(d);
+    }
+    return g_ovf_dev;
+}
+
+static const char *kOverflowMsg =
+    "split-fp16 arithmetic: an activation or input left the fp16 range (|x| > 65504 or NaN); results since the last "
+    "ojf_net_check are invalid - use ojf_net_set_arithmetic(OJF_ARITH_F32) for this network";
+
+// Split-fp16 weights are equilibrated per output channel: row oc is multiplied by the power of two that brings its
+// largest magnitude to [2^13, 2^14) before it is split, and the accumulator is multiplied by the inverse in the
+// epilogue (both exact).  BN folding scales whole rows by 1/sqrt(var) - without this, rows of ~1e-5 (large input
+// channels such as the fp16 weight counts) would sit in the fp16 subnormals and lose their mantissa.
+static inline float row_scale(float row_max)
+{
+    if (!(row_max > 0.0f) || !std::isfinite(row_max)) return 1.0f;
+    int e = 0;
+    (void)std::frexp(row_max, &e);  // row_max = m * 2^e, m in [0.5, 1)
+    int k = 14 - e;
+    k = k > 100 ? 100 : (k < -100 ? -100 : k);
+    return std::ldexp(1.0f, k);
+}
 
 // fp16 halves of a weight, both rounded to nearest (host side of split_f16)
 static inline void split_weight(float v, _Float16 &hi, _Float16 &lo)
@@ -949,6 +1042,15 @@ static int finish(const ConvBuilder &b, PackedConv &pc, int arith = OJF_ARITH_F3
     pc.nsteps = nsteps;
     std::vector<float> wp, bias((size_t)pc.n_ot * 16, 0.0f);
     if (arith == OJF_ARITH_F16X3) {
+        std::vector<float> rs((size_t)pc.n_ot * 16, 1.0f), rinv((size_t)pc.n_ot * 16, 1.0f);
+        for (int oc = 0; oc < b.c_out_phys; ++oc) {
+            float mx = 0.0f;
+            const float *row = b.W.data() + (size_t)oc * b.taps * b.c_in_phys;
+            for (int i = 0; i < b.taps * b.c_in_phys; ++i) mx = std::fmax(mx, std::fabs(row[i]));
+            rs[oc] = row_scale(mx);
+            rinv[oc] = 1.0f / rs[oc];
+        }
+        if (upload(rinv, &pc.rinv)) return -2;
         // [S][ot][hi|lo][lane] x 8 halfs; dead (all-zero) supersteps behind for the chunk copies
         const int nsp = nsteps + kPad16;
         wp.assign((size_t)nsp * pc.n_ot * 128 * 4, 0.0f);
@@ -960,7 +1062,7 @@ static int finish(const ConvBuilder &b, PackedConv &pc, int arith = OJF_ARITH_F3
                         const int oc = ot * 16 + (lane & 15), G = 8 * S + 2 * (lane >> 4) + (j >> 2);
                         if (oc >= b.c_out_phys || G >= groups) continue;
                         const int t = G / c4, cg = G % c4;
-                        const float v = b.W[((size_t)oc * b.taps + t) * b.c_in_phys + 4 * cg + (j & 3)];
+                        const float v = rs[oc] * b.W[((size_t)oc * b.taps + t) * b.c_in_phys + 4 * cg + (j & 3)];
                         const size_t base = ((size_t)S * pc.n_ot + ot) * 2 * 64 * 8;
                         split_weight(v, hp[base + (size_t)lane * 8 + j], hp[base + 64 * 8 + (size_t)lane * 8 + j]);
                     }
@@ -988,7 +1090,8 @@ static void release(PackedConv &pc)
 {
     if (pc.wp) (void)hipFree(pc.wp);
     if (pc.bias) (void)hipFree(pc.bias);
-    pc.wp = pc.bias = nullptr;
+    if (pc.rinv) (void)hipFree(pc.rinv);
+    pc.wp = pc.bias = pc.rinv = nullptr;
 }
 
 static inline f32x4 *planes(float *p) { return reinterpret_cast<f32x4 *>(p); }
@@ -1047,8 +1150,9 @@ static int launch_conv_args(const ConvArgs *args, int n, int nt, hipStream_t st,
 static void fill_conv_args(ConvArgs &a, const PackedConv &pc, const float *in, int in_g0, float *out, int out_g0,
                            const float *bias, int act, int act_n, float scale, int h, int w)
 {
+    a.ovf = pc.arith == OJF_ARITH_F16X3 ? overflow_flag() : nullptr;
     a.in = planes(in); a.out = planes(out); a.out_rows = nullptr;
-    a.wp = planes(pc.wp); a.bias = bias ? bias : pc.bias;
+    a.wp = planes(pc.wp); a.bias = bias ? bias : pc.bias; a.rinv = pc.rinv;
     a.in_g0 = in_g0; a.out_g0 = out_g0; a.rows_stride = 0; a.rows_n = 0;
     a.h = h; a.w = w; a.npix = h * w;
     a.taps = pc.taps; a.dil = pc.dil;
@@ -1076,9 +1180,24 @@ static std::vector<int> slot_map(int n_logical, int group, int slot)
     return m;
 }
 
-// Fragments of one pointwise layer for chain_layer, appended to dst; weight(oc, k) returns 0 outside the layer.
+// per-output-row power-of-two scales of a pointwise layer (ones for fp32 arithmetic); n_k input channels
 template <class F>
-static void pack_chain_layer(std::vector<float> &dst, int arith, int nt_out, int nt_in, F weight)
+static std::vector<float> chain_row_scales(int arith, int nt_out, int n_k, F weight)
+{
+    std::vector<float> r((size_t)nt_out * 16, 1.0f);
+    if (arith != OJF_ARITH_F16X3) return r;
+    for (int oc = 0; oc < nt_out * 16; ++oc) {
+        float mx = 0.0f;
+        for (int k = 0; k < n_k; ++k) mx = std::fmax(mx, std::fabs(weight(oc, k)));
+        r[oc] = row_scale(mx);
+    }
+    return r;
+}
+
+// Fragments of one pointwise layer for chain_layer, appended to dst; weight(oc, k) returns 0 outside the layer,
+// rs = row scales (chain_row_scales).
+template <class F>
+static void pack_chain_layer(std::vector<float> &dst, int arith, int nt_out, int nt_in, const std::vector<float> &rs, F weight)
 {
     const size_t base = dst.size();
     dst.resize(base + (size_t)chain_layer_size(arith, nt_in, nt_out) * 4, 0.0f);
@@ -1092,7 +1211,7 @@ static void pack_chain_layer(std::vector<float> &dst, int arith, int nt_out, int
                         const int oc = n2 * 16 + (lane & 15), g = lane >> 4;
                         const int k = 32 * S + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
                         const size_t ub = ((size_t)n2 * KB + S) * 2 * 64 * 8;
-                        split_weight(weight(oc, k), hp[ub + (size_t)lane * 8 + j], hp[ub + 64 * 8 + (size_t)lane * 8 + j]);
+                        split_weight(rs[oc] * weight(oc, k), hp[ub + (size_t)lane * 8 + j], hp[ub + 64 * 8 + (size_t)lane * 8 + j]);
                     }
     } else {
         for (int n2 = 0; n2 < nt_out; ++n2)
@@ -1104,12 +1223,23 @@ static void pack_chain_layer(std::vector<float> &dst, int arith, int nt_out, int
     }
 }
 
+// bias stream entry of a chain layer: bias[nt_out*16] and, for split-fp16, the inverse row scales behind it
+static void append_chain_bias(std::vector<float> &dst, int arith, int nt_out, int c_out, const float *bias_host,
+                              const std::vector<float> &rs)
+{
+    const size_t bb = dst.size();
+    dst.resize(bb + (size_t)chain_bias_stride(arith, nt_out), 0.0f);
+    for (int o = 0; o < c_out; ++o) dst[bb + o] = bias_host[o];
+    if (arith == OJF_ARITH_F16X3)
+        for (int o = 0; o < nt_out * 16; ++o) dst[bb + (size_t)nt_out * 16 + o] = 1.0f / rs[o];
+}
+
 struct Vortex {
     int c_in = 0, c_in_phys = 0;
     PackedConv stacked, b3a[4], b3b[4], b1[4], fin;
     float *pool_bias[4] = {nullptr, nullptr, nullptr, nullptr};
     float *Wg = nullptr, *bg = nullptr, *Wfg = nullptr, *bf = nullptr, *bias_final = nullptr;
-    float *tail_w = nullptr, *tail_b1 = nullptr;  // fused tail (closing 1x1s + final conv), when supported
+    float *tail_w = nullptr, *tail_b1 = nullptr, *tail_rinv = nullptr;  // fused tail (closing 1x1s + final conv), when supported
 };
 
 }  // namespace ojf
@@ -1229,18 +1359,25 @@ static int build_vortex(ojf_net *net, Vortex &v, const ojf_conv_layer *L, int c_
     }
     if ((cs + 15) / 16 == 2 && (os + 15) / 16 == 8) {  // fused tail: [W1_b | Wf_b] fragments per branch
         const int NV = 2, NO = 8;
-        std::vector<float> tw, tb((size_t)4 * NO * 16, 0.0f);
+        std::vector<float> tw, tb;
         const ojf_conv_layer &lf = L[17];
+        // the four column blocks of the final conv accumulate into one set of rows: one common row scale
+        const std::vector<float> rf = chain_row_scales(net->arith, NO, 4 * out, [&](int oc, int k) {
+            return oc < out ? lf.weight_host[(size_t)oc * 5 * out + out + k] : 0.0f;
+        });
         for (int br = 0; br < 4; ++br) {
             const ojf_conv_layer &l1 = L[4 + 4 * br];
-            pack_chain_layer(tw, net->arith, NO, NV, [&](int oc, int k) {
-                return oc < out && k < c ? l1.weight_host[(size_t)oc * c + k] : 0.0f;
-            });
-            pack_chain_layer(tw, net->arith, NO, NO, [&](int oc, int k) {
+            auto w1 = [&](int oc, int k) { return oc < out && k < c ? l1.weight_host[(size_t)oc * c + k] : 0.0f; };
+            const std::vector<float> r1 = chain_row_scales(net->arith, NO, c, w1);
+            pack_chain_layer(tw, net->arith, NO, NV, r1, w1);
+            pack_chain_layer(tw, net->arith, NO, NO, rf, [&](int oc, int k) {
                 return oc < out && k < out ? lf.weight_host[(size_t)oc * 5 * out + out * (br + 1) + k] : 0.0f;
             });
-            for (int o = 0; o < out; ++o) tb[(size_t)br * NO * 16 + o] = l1.bias_host[o];
+            append_chain_bias(tb, net->arith, NO, out, l1.bias_host, r1);
         }
+        std::vector<float> rfi(rf.size());
+        for (size_t i = 0; i < rf.size(); ++i) rfi[i] = 1.0f / rf[i];
+        if (upload(rfi, &v.tail_rinv)) return -2;
         if (upload(tw, &v.tail_w) || upload(tb, &v.tail_b1)) return -2;
     }
     return 0;
@@ -1256,7 +1393,7 @@ static void free_vortex(Vortex &v)
         release(v.b1[b]);
         if (v.pool_bias[b]) (void)hipFree(v.pool_bias[b]);
     }
-    float *ptrs[] = {v.Wg, v.bg, v.Wfg, v.bf, v.bias_final, v.tail_w, v.tail_b1};
+    float *ptrs[] = {v.Wg, v.bg, v.Wfg, v.bf, v.bias_final, v.tail_w, v.tail_b1, v.tail_rinv};
     for (float *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -1307,8 +1444,9 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
     if (!fused) return launch_conv(v.fin, net->CAT, 0, out, out_g0, v.bias_final, OJF_ACT_NONE, 0, 1.0f, h, w, st);
     TailArgs ta;
     for (int br = 0; br < 4; ++br) ta.v[br] = planes(net->V) + (size_t)br * c4 * net->npix;
-    ta.w = planes(v.tail_w); ta.b1 = v.tail_b1; ta.bias_final = v.bias_final;
+    ta.w = planes(v.tail_w); ta.b1 = v.tail_b1; ta.bias_final = v.bias_final; ta.rinv_final = v.tail_rinv;
     ta.out = planes(out); ta.c4 = c4; ta.out_g0 = out_g0; ta.og_store = o4; ta.npix = net->npix;
+    ta.ovf = net->arith == OJF_ARITH_F16X3 ? overflow_flag() : nullptr;
     static const int mt_env = getenv("OJF_TAIL_MT") ? atoi(getenv("OJF_TAIL_MT")) : 1;  // tuning switch only
     const int mt = net->arith == OJF_ARITH_F16X3 ? mt_env : 1;
     const int strips = (net->npix + mt * 16 - 1) / (mt * 16);
@@ -1386,6 +1524,13 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
     for (int i = 0; i < n_layers; ++i)
         if (!L[i].weight_host || !L[i].bias_host || (L[i].ksize != 1 && L[i].ksize != 3) || L[i].dilation < 1)
             return fail("ojf_net_create: malformed layer descriptor");
+    for (int i = 0; i < n_layers; ++i) {  // the split-fp16 range guard relies on finite parameters
+        const size_t nw = (size_t)L[i].c_out * L[i].c_in * L[i].ksize * L[i].ksize;
+        for (size_t k = 0; k < nw; ++k)
+            if (!std::isfinite(L[i].weight_host[k])) return fail("ojf_net_create: non-finite weight");
+        for (int k = 0; k < L[i].c_out; ++k)
+            if (!std::isfinite(L[i].bias_host[k])) return fail("ojf_net_create: non-finite bias");
+    }
 
     ojf_net *net = new ojf_net();
     net->version = version; net->P = n_points; net->gf = growth; net->sem = sem;
@@ -1460,12 +1605,10 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
         for (int l = first; l < n_layers; ++l) {
             const ojf_conv_layer &ly = L[l];
             const int nt_in = (prev_phys + 15) / 16, out_phys = round_up(ly.c_out, 4), nt_out = (out_phys + 15) / 16;
-            pack_chain_layer(cw, net->arith, nt_out, nt_in, [&](int oc, int k) {
-                return oc < ly.c_out && k < ly.c_in ? ly.weight_host[(size_t)oc * ly.c_in + k] : 0.0f;
-            });
-            const size_t bb = cb.size();
-            cb.resize(bb + (size_t)nt_out * 16, 0.0f);
-            for (int o = 0; o < ly.c_out; ++o) cb[bb + o] = ly.bias_host[o];
+            auto wl = [&](int oc, int k) { return oc < ly.c_out && k < ly.c_in ? ly.weight_host[(size_t)oc * ly.c_in + k] : 0.0f; };
+            const std::vector<float> rs = chain_row_scales(net->arith, nt_out, ly.c_in, wl);
+            pack_chain_layer(cw, net->arith, nt_out, nt_in, rs, wl);
+            append_chain_bias(cb, net->arith, nt_out, ly.c_out, ly.bias_host, rs);
             prev_phys = out_phys;
         }
         if (upload(cw, &net->chain_w) || upload(cb, &net->chain_b)) rc = -2;
@@ -1531,6 +1674,7 @@ OJF_API int ojf_net_prepare_input(ojf_net *net, const float *values, const float
     a.rows_stride = rows_stride; a.in_layout = in_layout; a.npix = net->npix; a.P = net->P; a.cs4 = net->cs / 4;
     a.n_classes = n_classes;
     a.v2_sem = (net->version == 2 && net->sem) ? 1 : 0;
+    a.ovf = net->arith == OJF_ARITH_F16X3 ? overflow_flag() : nullptr;
     hipLaunchKernelGGL(prepare_input_kernel, dim3((a.npix + 255) / 256), dim3(256), 0, as_stream(stream), a);
     return check_hip(hipGetLastError(), "prepare_input_kernel launch");
 }
@@ -1560,6 +1704,7 @@ static int forward_launches(ojf_net *net, float *est, int est_stride, hipStream_
         ca.in = planes(net->Y3); ca.w = planes(net->chain_w); ca.bias = net->chain_b;
         ca.out_rows = est; ca.in_g0 = 0; ca.c4_in = o4; ca.npix = net->npix;
         ca.rows_stride = est_stride; ca.rows_n = net->P; ca.scale = net->scale;
+        ca.ovf = net->arith == OJF_ARITH_F16X3 ? overflow_flag() : nullptr;
         static const int mt_env = getenv("OJF_CHAIN_MT") ? atoi(getenv("OJF_CHAIN_MT")) : 1;  // tuning switch only
         const bool h16 = net->arith == OJF_ARITH_F16X3;
         const int mt = h16 ? mt_env : 1;  // fp32: 4800 waves balance over 1024 SIMDs better than 2400 (see launch_conv_args)
@@ -1635,6 +1780,7 @@ OJF_API int ojf_net_forward(ojf_net *net, float *est, int est_stride, ojf_stream
     if (!net || !est) return fail("ojf_net_forward: null pointer argument");
     if (est_stride < net->P) return fail("ojf_net_forward: est_stride < n_points");
     hipStream_t st = as_stream(stream);
+    if (net->arith == OJF_ARITH_F16X3 && g_ovf_host && *g_ovf_host) return fail(kOverflowMsg);
     if (net->use_graph) {
         if (!net->gexec || net->g_est != est || net->g_stride != est_stride) capture_graph(net, est, est_stride);
         if (net->gexec) return check_hip(hipGraphLaunch(net->gexec, st), "hipGraphLaunch (net forward)");
@@ -1653,6 +1799,17 @@ OJF_API int ojf_net_set_arithmetic(int arithmetic)
 }
 
 OJF_API int ojf_net_get_arithmetic(const ojf_net *net) { return net ? net->arith : ojf::g_default_arith; }
+
+OJF_API int ojf_net_check(ojf_stream_t stream)
+{
+    using namespace ojf;
+    OJF_HIP(hipStreamSynchronize(as_stream(stream)));
+    if (g_ovf_host && *g_ovf_host) {
+        *g_ovf_host = 0;
+        return fail(kOverflowMsg);
+    }
+    return 0;
+}
 
 OJF_API int ojf_conv2d(const float *in, int in_stride, int in_off, float *out, int out_stride, int out_off,
                        const ojf_conv_layer *layer, int act, int h, int w, ojf_stream_t stream)
@@ -1681,6 +1838,10 @@ OJF_API int ojf_conv2d(const float *in, int in_stride, int in_off, float *out, i
         hipLaunchKernelGGL(planes_to_rows_kernel, dim3((npix * (cout_phys / 4) + 255) / 256), dim3(256), 0, st,
                            planes(pout), cout_phys / 4, npix, out, out_stride, out_off);
         rc = check_hip(hipStreamSynchronize(st), "ojf_conv2d sync");  // test-only API: packs per call
+        if (!rc && g_ovf_host && *g_ovf_host) {
+            *g_ovf_host = 0;
+            rc = fail(kOverflowMsg);
+        }
     }
     free_planes(pin);
     free_planes(pout);

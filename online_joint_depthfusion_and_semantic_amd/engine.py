@@ -83,6 +83,10 @@ class FusionNetEngine:
         _lib.check(rc, 'ojf_net_forward')
         return est
 
+    def check(self):
+        """Synchronise the stream and raise OjfError if the split-fp16 range guard fired (include/ojf.h)."""
+        _lib.check(self.lib.ojf_net_check(_lib.stream_ptr(self.device)), 'ojf_net_check')
+
     def close(self):
         if getattr(self, 'handle', None):
             torch.cuda.synchronize(self.device)

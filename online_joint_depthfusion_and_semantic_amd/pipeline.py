@@ -152,7 +152,7 @@ class Pipeline(torch.nn.Module):
             raise ValueError('Pipeline: batch size 1 only (one scene per frame, pipeline.py:199)')
         frame = frame.to(self.device).float().contiguous()
         mask = batch['mask'].to(self.device).reshape(frame.shape)
-        filtered = torch.where(mask, frame, torch.zeros_like(frame))  # pipeline.py:196
+        filtered = torch.where(mask, frame, 0.0)  # pipeline.py:196 (one launch)
         return frame[0], filtered[0]
 
     # ---- inference frame step (pipeline.py:173-248) ---------------------------------------------

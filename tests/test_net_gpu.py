@@ -99,3 +99,65 @@ def test_fusion_net_forward(cuda, arith, version, sem, h, w):
             assert torch.all(got[:, 9:] == 5.0)
     assert eng.macs_per_pixel == (326876 if not sem else (508820 if version == 'v3' else None)) or version == 'v2'
     eng.close()
+
+
+def _large_weight_inputs(h, w):
+    x = _inputs(h, w, seed=5)
+    g = torch.Generator().manual_seed(9)
+    x['tsdf_weights'] = torch.rand(1, 9, h, w, generator=g) * 60000.0
+    x['tsdf_weights'][0, :, :4] = 65504.0  # fp16 max: what a saturated fp16 weight volume hands over
+    return x
+
+
+def _run(eng, x, h, w, cuda):
+    fv = x['tsdf_values'][0].permute(1, 2, 0).reshape(h * w, 9).contiguous().to(cuda)
+    fw = x['tsdf_weights'][0].permute(1, 2, 0).reshape(h * w, 9).contiguous().to(cuda)
+    eng.prepare_input(fv, fw, x['tsdf_frame'].reshape(h, w).contiguous().to(cuda), None, 0)
+    est = torch.empty((h * w, 9), device=cuda)
+    eng.forward(est)
+    return est
+
+
+@pytest.mark.parametrize('arith', ['f16x3', 'f32'])
+def test_fusion_net_large_volume_weights(cuda, arith):
+    """The weight channels come from fp16 volumes and reach tens of thousands after long streams.  With weights
+    that normalise them (what BN statistics of a trained net do: here the columns of the weight channels are
+    scaled by 1e-4) both arithmetics agree with the fp32 reference to the stated tolerance."""
+    h, w = 48, 64
+    net = seeded_net('v3', False, h, w, seed=3)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.Conv2d) and m.in_channels % 19 == 0:
+                m.weight[:, 9:18] *= 1e-4
+    x = _large_weight_inputs(h, w)
+    with torch.no_grad():
+        ref = net(x)[0].permute(1, 2, 0).reshape(h * w, 9)
+    eng = FusionNetEngine(net, h, w, cuda, arithmetic=arith)
+    got = _run(eng, x, h, w, cuda).cpu()
+    eng.check()
+    err = float((got - ref).abs().max())
+    print('net large weights', arith, 'max err %.2e' % err)
+    assert err <= TOL, err
+    eng.close()
+
+
+def test_f16x3_range_guard(cuda):
+    """Un-normalised weights drive activations beyond the fp16 range: the split-fp16 path must say so (never return
+    silently wrong numbers), the fp32-input path must still be right."""
+    h, w = 48, 64
+    net = seeded_net('v3', False, h, w, seed=3)
+    x = _large_weight_inputs(h, w)
+    with torch.no_grad():
+        ref = net(x)[0].permute(1, 2, 0).reshape(h * w, 9)
+    eng = FusionNetEngine(net, h, w, cuda, arithmetic='f16x3')
+    _run(eng, x, h, w, cuda)
+    with pytest.raises(_lib.OjfError, match='fp16 range'):
+        eng.check()
+    eng.check()  # the check cleared the flag
+    eng.close()
+    eng = FusionNetEngine(net, h, w, cuda, arithmetic='f32')
+    got = _run(eng, x, h, w, cuda).cpu()
+    eng.check()
+    assert torch.isfinite(got).all()
+    assert float((got - ref).abs().max()) <= 2e-3  # pre-activations ~1e4 here: 1e-7 relative
+    eng.close()
