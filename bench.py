@@ -185,6 +185,7 @@ def main():
             pipe.fuse(batches[i], db, dev)
         sync()
         elapsed = time.perf_counter() - t0
+    pipe.check()  # outside the timed region: raises if the split-fp16 range guard fired on any frame
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == 'nccl' else 'cpu')

@@ -93,7 +93,10 @@ struct ConvArgs {
     int act, act_n;  // activation applied to output channels < act_n
     float scale;
     int *ovf;        // split-fp16 only: set to 1 when an activation leaves the fp16 range (host-mapped flag)
+    unsigned w_magic, c4_magic;  // ceil(2^32 / w), ceil(2^32 / c4): x / d == umulhi(x, magic) while x * d < 2^32 (0: divide)
 };
+
+__device__ __forceinline__ int fast_div(int x, int d, unsigned magic) { return magic ? (int)__umulhi((unsigned)x, magic) : x / d; }
 
 // Split-fp16 range guard.  Kernels keep a running maximum of the magnitudes of every value a later layer will
 // split (2 VALU per float4: v_max3_f32 with |.| modifiers) and raise the flag if it exceeds the fp16 range.
@@ -189,7 +192,7 @@ __device__ __forceinline__ void build_tap_table(int2 *tab, const ConvArgs &a, in
 __device__ __forceinline__ void build_tap_table16(int2 *tab, const ConvArgs &a, int entries)
 {
     for (int G = threadIdx.x; G < entries; G += 256) {
-        const int t = G / a.c4, cg = G - t * a.c4;
+        const int t = fast_div(G, a.c4, a.c4_magic), cg = G - t * a.c4;
         int off = 0, bit = 0;
         if (t < a.taps) {
             int dy = 0, dx = 0;
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const ConvGroup grp)
     for (int m = 0; m < MT; ++m) {
         const int p = strip + m * 16 + i16;
         p16[m] = p * 16;
-        const int py = p / a.w, px = p - py * a.w;
+        const int py = fast_div(p, a.w, a.w_magic), px = p - py * a.w;
         unsigned rm = 0, cm = 0;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -1147,6 +1150,13 @@ static int launch_conv_args(const ConvArgs *args, int n, int nt, hipStream_t st,
     return check_hip(hipGetLastError(), "conv kernel launch");
 }
 
+// magic of fast_div for divisor d and dividends below `limit` (0 = use a real division)
+static unsigned div_magic(int d, uint64_t limit)
+{
+    if (d <= 1 || limit * (uint64_t)d >= (1ull << 32)) return 0;
+    return (unsigned)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d);
+}
+
 static void fill_conv_args(ConvArgs &a, const PackedConv &pc, const float *in, int in_g0, float *out, int out_g0,
                            const float *bias, int act, int act_n, float scale, int h, int w)
 {
@@ -1157,6 +1167,8 @@ static void fill_conv_args(ConvArgs &a, const PackedConv &pc, const float *in, i
     a.h = h; a.w = w; a.npix = h * w;
     a.taps = pc.taps; a.dil = pc.dil;
     a.c4 = pc.c_in_phys / 4; a.nsteps = pc.nsteps;
+    a.w_magic = div_magic(w, (uint64_t)h * w);
+    a.c4_magic = div_magic(a.c4, (uint64_t)(pc.nsteps + kPad16) * 8);
     a.og_store = round_up(pc.c_out_phys, 4) / 4;
     a.act = act; a.act_n = act_n; a.scale = scale;
 }

@@ -58,6 +58,7 @@ def test_fusion(config, dataset, device, rank=0, world=1, state_dict=None, log=p
             if not torch.all(torch.isfinite(batch['extrinsics'])):
                 continue
             pipeline.fuse(_host_pose_batch(batch, device), database, device)
+    pipeline.check()  # loud if the split-fp16 range guard fired
     database.filter(value=config.TESTING.outlier_filter_val)  # on device; to_numpy() only for export
     results, per_scene = database.evaluate(mode='test')
     for k, v in results.items():

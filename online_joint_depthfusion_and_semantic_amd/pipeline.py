@@ -83,6 +83,12 @@ class Pipeline(torch.nn.Module):
                 acc[j] += ev[4 * f + j].elapsed_time(ev[4 * f + j + 1])
         return {'extract': acc[0] / n, 'net': acc[1] / n, 'integrate': acc[2] / n}
 
+    def check(self):
+        """Synchronise and raise OjfError if the split-fp16 range guard fired since the last check (the frames
+        fused in between are invalid then; set FUSION_MODEL.arithmetic = 'f32').  Cheap: call per scene / epoch."""
+        if self._engine is not None:
+            self._engine.check()
+
     # ---- cached device objects ----------------------------------------------------------------
     def _weights_fingerprint(self):
         """In-place weight updates (optimizer steps, load_state_dict) bump the tensors' version counters.  Walking
