@@ -492,9 +492,17 @@ struct ChainArgs {
 constexpr int chain_kblocks(int arith, int ntin) { return arith == OJF_ARITH_F16X3 ? (ntin + 1) / 2 : ntin; }
 constexpr int chain_unit(int arith) { return arith == OJF_ARITH_F16X3 ? 128 : 64; }
 constexpr int chain_layer_size(int arith, int ntin, int ntout) { return ntout * chain_kblocks(arith, ntin) * chain_unit(arith); }
+// How the weight parts reach LDS:
+//   fp32:       global -> registers (`pre`, issued one part ahead) -> ds_write, one 48 KB buffer, two barriers per part
+//   split-fp16: LDS-DMA (global_load_lds_dwordx4, 1 KB per wave instruction) straight into the other half of a
+//               2 x 24 KB double buffer while the current part computes: no staging registers (48 VGPRs less, which
+//               is what lets more waves hide the LDS latency of the 5x faster MFMA phase), no ds_write pass, one
+//               barrier per part.
+constexpr bool chain_dma(int arith) { return arith == OJF_ARITH_F16X3; }
+constexpr int chain_cap(int arith) { return chain_dma(arith) ? kChainLdsFloat4 / 2 : kChainLdsFloat4; }  // float4 per part
 constexpr int chain_parts(int arith, int ntin, int ntout)
-{   // <= 24 KB of weights per LDS part
-    return (chain_layer_size(arith, ntin, ntout) + kChainLdsFloat4 - 1) / kChainLdsFloat4;
+{
+    return (chain_layer_size(arith, ntin, ntout) + chain_cap(arith) - 1) / chain_cap(arith);
 }
 constexpr int chain_per(int arith, int ntin, int ntout)
 {
@@ -509,6 +517,19 @@ constexpr int chain_first_size(int arith, int ntin, int ntout)
 constexpr int chain_bias_stride(int arith, int ntout) { return (arith == OJF_ARITH_F16X3 ? 2 : 1) * ntout * 16; }
 constexpr int kChainPre = kChainLdsFloat4 / 256;  // float4 registers per thread holding the prefetched next part
 
+// LDS-DMA of `size` float4 (a multiple of 64) from src to the LDS address dst: wave w moves the 1 KB chunks
+// w, w+4, ...; completion = this wave's vmcnt reaching 0, visibility to the block = the barrier after that
+__device__ __forceinline__ void dma_part(const f32x4 *src, f32x4 *dst, int size, int wave, int lane)
+{
+#pragma unroll
+    for (int c0 = 0; c0 < kChainLdsFloat4 / 2 / 64; c0 += 4) {
+        const int c = c0 + wave;
+        if (c * 64 < size)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + c * 64 + lane),
+                                             (void __attribute__((address_space(3))) *)(dst + c * 64), 16, 0, 0);
+    }
+}
+
 enum { kChainLeaky = 0, kChainRelu = 1, kChainAccumulate = 2, kChainLastRows = 3 };
 
 // One pointwise layer on register-resident activations: out[n2] (+)= sum_K W[n2][K] * in[K], then (unless
@@ -520,14 +541,14 @@ enum { kChainLeaky = 0, kChainRelu = 1, kChainAccumulate = 2, kChainLastRows = 3
 template <int ARITH, int MT, int NTIN, int NTOUT, int MODE, int NEXT_FIRST, int NA, int NB>
 __device__ __forceinline__ void chain_layer(const f32x4 (&in)[MT][NA], f32x4 (&out)[MT][NB], f32x4 *wlds, const f32x4 *wg,
                                             const float *bias, const ChainArgs &a, const int (&p)[MT], int lane,
-                                            f32x4 (&pre)[kChainPre], const f32x4 *next_src = nullptr)
+                                            f32x4 (&pre)[kChainPre], int &buf, const f32x4 *next_src = nullptr)
 {
     static_assert(NTIN <= NA && NTOUT <= NB, "register arrays too small for this layer");
     constexpr int parts = chain_parts(ARITH, NTIN, NTOUT);
     constexpr int per = chain_per(ARITH, NTIN, NTOUT);
     constexpr int KB = chain_kblocks(ARITH, NTIN);
     constexpr int unit = chain_unit(ARITH);
-    static_assert(per * KB * unit <= kChainLdsFloat4, "LDS part too large");
+    static_assert(per * KB * unit <= chain_cap(ARITH), "LDS part too large");
     // split-fp16: the fp16 halves of the layer input, once per layer
     f16x8 xh[MT][ARITH == OJF_ARITH_F16X3 ? KB : 1], xl[MT][ARITH == OJF_ARITH_F16X3 ? KB : 1];
     if constexpr (ARITH == OJF_ARITH_F16X3) {
@@ -544,20 +565,29 @@ __device__ __forceinline__ void chain_layer(const f32x4 (&in)[MT][NA], f32x4 (&o
         const int nb = part * per;
         const int ne = nb + per < NTOUT ? nb + per : NTOUT;
         const int size = (ne - nb) * KB * unit;
-        __syncthreads();  // readers of the previous part are done
-#pragma unroll
-        for (int k = 0; k < kChainPre; ++k)
-            if ((int)threadIdx.x + 256 * k < size) wlds[threadIdx.x + 256 * k] = pre[k];
-        __syncthreads();
-        // issue the fetch of the following part (next part of this layer, or the next layer's first)
+        // the following part (next part of this layer, or the next layer's first)
         const int nnb = ne;
         const int nne = nnb + per < NTOUT ? nnb + per : NTOUT;
         const int nsize = part + 1 < parts ? (nne - nnb) * KB * unit : NEXT_FIRST;
         const f32x4 *nsrc = part + 1 < parts ? wg + (size_t)nnb * KB * unit
                                              : (next_src ? next_src : wg + (size_t)chain_layer_size(ARITH, NTIN, NTOUT));
+        const f32x4 *wpart = wlds;
+        if constexpr (chain_dma(ARITH)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's chunks of the current part have landed
+            __syncthreads();  // ... everybody's have, and the readers of the other buffer are done with it
+            wpart = wlds + buf * chain_cap(ARITH);
+            buf ^= 1;
+            dma_part(nsrc, wlds + buf * chain_cap(ARITH), nsize, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane);
+        } else {
+            __syncthreads();  // readers of the previous part are done
 #pragma unroll
-        for (int k = 0; k < kChainPre; ++k)
-            if ((int)threadIdx.x + 256 * k < nsize) pre[k] = nsrc[threadIdx.x + 256 * k];
+            for (int k = 0; k < kChainPre; ++k)
+                if ((int)threadIdx.x + 256 * k < size) wlds[threadIdx.x + 256 * k] = pre[k];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kChainPre; ++k)
+                if ((int)threadIdx.x + 256 * k < nsize) pre[k] = nsrc[threadIdx.x + 256 * k];
+        }
         if constexpr (MODE != kChainAccumulate) {
 #pragma unroll
             for (int n2 = 0; n2 < NTOUT; ++n2)
@@ -572,12 +602,12 @@ __device__ __forceinline__ void chain_layer(const f32x4 (&in)[MT][NA], f32x4 (&o
             for (int n2 = 0; n2 < NTOUT; ++n2) {
                 if (n2 < nb || n2 >= ne) continue;
                 if constexpr (ARITH == OJF_ARITH_F16X3) {
-                    const f32x4 wh = wlds[((n2 - nb) * KB + S) * 128 + lane];
-                    const f32x4 wl = wlds[((n2 - nb) * KB + S) * 128 + 64 + lane];
+                    const f32x4 wh = wpart[((n2 - nb) * KB + S) * 128 + lane];
+                    const f32x4 wl = wpart[((n2 - nb) * KB + S) * 128 + 64 + lane];
 #pragma unroll
                     for (int m = 0; m < MT; ++m) out[m][n2] = mfma_f16x3(wh, wl, xh[m][S], xl[m][S], out[m][n2]);
                 } else {
-                    const f32x4 wv = wlds[((n2 - nb) * KB + S) * 64 + lane];
+                    const f32x4 wv = wpart[((n2 - nb) * KB + S) * 64 + lane];
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -623,20 +653,20 @@ __device__ __forceinline__ void chain_layer(const f32x4 (&in)[MT][NA], f32x4 (&o
 template <int ARITH, int MT, int NTIN, int NTOUT>
 __device__ __forceinline__ void chain_run(f32x4 (&x)[MT][8], f32x4 (&y)[MT][8], f32x4 *wlds, const f32x4 *wg,
                                           const float *bias, const ChainArgs &a, const int (&p)[MT], int lane,
-                                          f32x4 (&pre)[kChainPre])
+                                          f32x4 (&pre)[kChainPre], int &buf)
 {
-    chain_layer<ARITH, MT, NTIN, NTOUT, kChainLastRows, 0>(x, y, wlds, wg, bias, a, p, lane, pre);
+    chain_layer<ARITH, MT, NTIN, NTOUT, kChainLastRows, 0>(x, y, wlds, wg, bias, a, p, lane, pre, buf);
 }
 
 template <int ARITH, int MT, int NTIN, int NTOUT, int NTNEXT, int... REST>
 __device__ __forceinline__ void chain_run(f32x4 (&x)[MT][8], f32x4 (&y)[MT][8], f32x4 *wlds, const f32x4 *wg,
                                           const float *bias, const ChainArgs &a, const int (&p)[MT], int lane,
-                                          f32x4 (&pre)[kChainPre])
+                                          f32x4 (&pre)[kChainPre], int &buf)
 {
     chain_layer<ARITH, MT, NTIN, NTOUT, kChainLeaky, chain_first_size(ARITH, NTOUT, NTNEXT)>(x, y, wlds, wg, bias, a, p,
-                                                                                             lane, pre);
+                                                                                             lane, pre, buf);
     chain_run<ARITH, MT, NTOUT, NTNEXT, REST...>(y, x, wlds, wg + (size_t)chain_layer_size(ARITH, NTIN, NTOUT),
-                                                 bias + chain_bias_stride(ARITH, NTOUT), a, p, lane, pre);
+                                                 bias + chain_bias_stride(ARITH, NTOUT), a, p, lane, pre, buf);
 }
 
 template <int ARITH, int MT, int NT0, int... NTS>
@@ -659,14 +689,19 @@ __global__ __launch_bounds__(256) void chain1x1_kernel(const ChainArgs a)
         }
     }
     f32x4 pre[kChainPre];
+    int buf = 0;
     {   // first part of the first layer
         constexpr int first[] = {NTS...};
         constexpr int size0 = chain_first_size(ARITH, NT0, first[0]);
+        if constexpr (chain_dma(ARITH)) {
+            dma_part(a.w, wlds, size0, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane);
+        } else {
 #pragma unroll
-        for (int k = 0; k < kChainPre; ++k)
-            if ((int)threadIdx.x + 256 * k < size0) pre[k] = a.w[threadIdx.x + 256 * k];
+            for (int k = 0; k < kChainPre; ++k)
+                if ((int)threadIdx.x + 256 * k < size0) pre[k] = a.w[threadIdx.x + 256 * k];
+        }
     }
-    chain_run<ARITH, MT, NT0, NTS...>(x, y, wlds, a.w, a.bias, a, p, lane, pre);
+    chain_run<ARITH, MT, NT0, NTS...>(x, y, wlds, a.w, a.bias, a, p, lane, pre, buf);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -697,10 +732,10 @@ struct TailArgs {
 // the prediction-head topologies chain_run is instantiated for (growth channels 19 / 20)
 template <int ARITH, int MT, int KIND>
 __device__ __forceinline__ void head_run(f32x4 (&x)[MT][8], f32x4 (&y)[MT][8], f32x4 *wlds, const f32x4 *wg, const float *bias,
-                                         const ChainArgs &a, const int (&p)[MT], int lane, f32x4 (&pre)[kChainPre])
+                                         const ChainArgs &a, const int (&p)[MT], int lane, f32x4 (&pre)[kChainPre], int &buf)
 {
-    if constexpr (KIND == 19) chain_run<ARITH, MT, 8, 6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1>(x, y, wlds, wg, bias, a, p, lane, pre);
-    else chain_run<ARITH, MT, 8, 7, 7, 5, 5, 4, 4, 3, 3, 2, 2, 1>(x, y, wlds, wg, bias, a, p, lane, pre);
+    if constexpr (KIND == 19) chain_run<ARITH, MT, 8, 6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1>(x, y, wlds, wg, bias, a, p, lane, pre, buf);
+    else chain_run<ARITH, MT, 8, 7, 7, 5, 5, 4, 4, 3, 3, 2, 2, 1>(x, y, wlds, wg, bias, a, p, lane, pre, buf);
 }
 constexpr int head_first_size(int arith, int kind) { return chain_first_size(arith, 8, kind == 19 ? 6 : 7); }
 
@@ -725,11 +760,16 @@ __global__ __launch_bounds__(256) void vortex_tail_kernel(const TailArgs a)
 #pragma unroll
         for (int n = 0; n < NO; ++n) y[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 pre[kChainPre];
+    int buf = 0;
     {
         constexpr int size0 = chain_first_size(ARITH, NV, NO);
+        if constexpr (chain_dma(ARITH)) {
+            dma_part(a.w, wlds, size0, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane);
+        } else {
 #pragma unroll
-        for (int k = 0; k < kChainPre; ++k)
-            if ((int)threadIdx.x + 256 * k < size0) pre[k] = a.w[threadIdx.x + 256 * k];
+            for (int k = 0; k < kChainPre; ++k)
+                if ((int)threadIdx.x + 256 * k < size0) pre[k] = a.w[threadIdx.x + 256 * k];
+        }
     }
     constexpr size_t per_branch = (size_t)chain_layer_size(ARITH, NV, NO) + chain_layer_size(ARITH, NO, NO);
     f32x4 t[MT][NO];
@@ -746,13 +786,13 @@ __global__ __launch_bounds__(256) void vortex_tail_kernel(const TailArgs a)
             }
         const f32x4 *w1 = a.w + b * per_branch, *wf = w1 + (size_t)chain_layer_size(ARITH, NV, NO);
         chain_layer<ARITH, MT, NV, NO, kChainRelu, chain_first_size(ARITH, NO, NO)>(vin, t, wlds, w1, a.b1 + b * chain_bias_stride(ARITH, NO), ca, p,
-                                                                                   lane, pre);
+                                                                                   lane, pre, buf);
         if (b < 3)
             chain_layer<ARITH, MT, NO, NO, kChainAccumulate, chain_first_size(ARITH, NV, NO)>(t, y, wlds, wf, nullptr, ca, p,
-                                                                                            lane, pre);
+                                                                                            lane, pre, buf);
         else
             chain_layer<ARITH, MT, NO, NO, kChainAccumulate, CHAIN ? head_first_size(ARITH, CHAIN) : 0>(
-                t, y, wlds, wf, nullptr, ca, p, lane, pre, a.chain_w);
+                t, y, wlds, wf, nullptr, ca, p, lane, pre, buf, a.chain_w);
     }
     float gmax = 0.0f;
 #pragma unroll
@@ -773,7 +813,7 @@ __global__ __launch_bounds__(256) void vortex_tail_kernel(const TailArgs a)
         if (gmax > 65504.0f && a.ovf) *a.ovf = 1;
     if constexpr (CHAIN) {
         ca.out_rows = a.out_rows; ca.rows_stride = a.rows_stride; ca.rows_n = a.rows_n; ca.scale = a.scale;
-        head_run<ARITH, MT, CHAIN>(y, t, wlds, a.chain_w, a.chain_b, ca, p, lane, pre);
+        head_run<ARITH, MT, CHAIN>(y, t, wlds, a.chain_w, a.chain_b, ca, p, lane, pre, buf);
     }
 }
 
