@@ -670,7 +670,7 @@ __device__ __forceinline__ void chain_run(f32x4 (&x)[MT][8], f32x4 (&y)[MT][8], 
 }
 
 template <int ARITH, int MT, int NT0, int... NTS>
-__global__ __launch_bounds__(256) void chain1x1_kernel(const ChainArgs a)
+__global__ __launch_bounds__(256, 3) void chain1x1_kernel(const ChainArgs a)
 {
     __shared__ f32x4 wlds[kChainLdsFloat4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -742,7 +742,7 @@ constexpr int head_first_size(int arith, int kind) { return chain_first_size(ari
 // CHAIN = 0: write the VortexPooling result planes.  CHAIN = 19 / 20: feed it straight into the prediction head
 // (same accumulator -> operand identity) and write est rows; the 114-channel tensor between them never exists.
 template <int ARITH, int MT, int NV, int NO, int CHAIN = 0>
-__global__ __launch_bounds__(256) void vortex_tail_kernel(const TailArgs a)
+__global__ __launch_bounds__(256, 3) void vortex_tail_kernel(const TailArgs a)
 {
     static_assert(CHAIN == 0 || NO == 8, "the fused prediction head expects 8 input tiles");
     __shared__ f32x4 wlds[kChainLdsFloat4];
