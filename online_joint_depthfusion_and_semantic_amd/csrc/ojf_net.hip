@@ -430,10 +430,6 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const ConvGroup grp)
     __syncthreads();  // tap table
     f32x4 xa0[MT], xb0[MT], xa1[MT], xb1[MT], xa2[MT], xb2[MT];
     bool v0, v1, v2;
-    constexpr int kPre = CS * NT * 128 / 256;  // float4 per thread of one weight chunk
-    f32x4 wpre[kPre];                          // the next chunk, in flight while the current one computes
-#pragma unroll
-    for (int i = 0; i < kPre; ++i) wpre[i] = a.wp[i * 256 + threadIdx.x];
     fetch(xa0, xb0, tab4[0], v0);
     fetch(xa1, xb1, tab4[4], v1);
     int sl = CS;
@@ -441,15 +437,13 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const ConvGroup grp)
         // the three table reads of this iteration are issued together (one LDS latency instead of three)
         const int4 t2 = tab4[(S + 2) * 4], t3 = tab4[(S + 3) * 4], t4 = tab4[(S + 4) * 4];
         if (sl == CS) {  // next weight chunk (CS is a multiple of the 3 supersteps of one iteration)
+            // plain copy: prefetching the chunk through registers one chunk ahead measured slower on the wide and
+            // the grouped launches (17.9 -> 20.7 us, 23.1 -> 25.1 us: VGPRs) and equal elsewhere
             if (S) __syncthreads();
+            const f32x4 *src = a.wp + (size_t)S * NT * 128;
 #pragma unroll
-            for (int i = 0; i < kPre; ++i) wl[i * 256 + threadIdx.x] = wpre[i];
+            for (int i = 0; i < CS * NT * 128 / 256; ++i) wl[i * 256 + threadIdx.x] = src[i * 256 + threadIdx.x];
             __syncthreads();
-            if (S + CS < a.nsteps) {
-                const f32x4 *src = a.wp + (size_t)(S + CS) * NT * 128;
-#pragma unroll
-                for (int i = 0; i < kPre; ++i) wpre[i] = src[i * 256 + threadIdx.x];
-            }
             sl = 0;
         }
         fetch(xa2, xb2, t2, v2);

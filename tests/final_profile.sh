@@ -9,3 +9,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/kt -o k
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/final/pf -o pf -- python bench.py --steps 20 --warmup 2 > /dev/null 2> gpurun_out/final/pf.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/final/pw -o pw -- python bench.py --steps 20 --warmup 2 > /dev/null 2> gpurun_out/final/pw.err
 find gpurun_out/final -name '*.csv' | head -20
+python bench.py --arith f32 --cpu-frames 0 > gpurun_out/final/bench_f32.json 2>/dev/null
+python bench.py --height 120 --width 160 --grid 64 --cpu-frames 0 > gpurun_out/final/bench_A.json 2>/dev/null
+python bench.py --mode parity --steps 100 --cpu-frames 0 > gpurun_out/final/bench_parity.json 2>/dev/null
+python bench.py --height 480 --width 640 --grid 512 --semantics --steps 60 --warmup 5 --cpu-frames 0 > gpurun_out/final/bench_C.json 2>/dev/null
+python bench.py --height 480 --width 640 --grid 512 --steps 60 --warmup 5 --cpu-frames 0 > gpurun_out/final/bench_Cgeo.json 2>/dev/null
