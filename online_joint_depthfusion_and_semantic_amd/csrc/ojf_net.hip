@@ -1171,10 +1171,10 @@ static int launch_conv_args(const ConvArgs *args, int n, int nt, hipStream_t st,
     // MT (16-pixel tiles per wave) trades operand reuse against the number of waves in flight.
     // fp32: MT = 1 everywhere: 4800 waves over 1024 SIMDs quantise to 5 rounds where MT = 2 (2400 waves) needs 3
     // rounds of twice the length (78 % vs 94 % balance); measured 14.9 vs 17.3 us on the 19->19 3x3 layers.
-    // split-fp16: the grouped launches (4 x 4800 waves) and the wide layers gain from sharing the LDS weight
-    // reads between two pixel tiles (26.4 -> 23.2 us, 25.4 -> 23.3 us); single narrow layers do not.
+    // split-fp16: two pixel tiles per wave share the LDS weight reads and the per-wave prologue; measured in one run
+    // (net stage): MT = 2 everywhere 0.501 ms, MT = 2 only for grouped / wide launches 0.508 ms, MT = 1 0.514 ms.
     static const int mt_env = getenv("OJF_CONV_MT") ? atoi(getenv("OJF_CONV_MT")) : 0;  // tuning switch only
-    const int mt = arith == OJF_ARITH_F16X3 ? (mt_env ? mt_env : ((n > 1 || nt >= 6) ? 2 : 1)) : 1;
+    const int mt = arith == OJF_ARITH_F16X3 ? (mt_env ? mt_env : 2) : 1;
     const int strips = (args[0].npix + mt * 16 - 1) / (mt * 16);
     const dim3 grid((strips + 3) / 4, n), block(256);
 #define OJF_LAUNCH32(NT_) hipLaunchKernelGGL((conv_mfma_kernel<1, NT_>), grid, block, 0, st, grp)
