@@ -1,11 +1,13 @@
 // EXTRACT: ray-cast gather of fp16 TSDF / weight voxels along unprojected depth rays with the
 // reference's 8-corner interpolation (modules/extractor.py:24-79, :640-681).
 //
-// Mapping: one lane per (sample k, pixel n), k-major, so the 64 lanes of a wave are 64 consecutive
-// pixels of one image row at the same ray offset: their stencils walk neighbouring voxels (the z
-// axis is contiguous in HBM) and the 16 fp16 loads per lane are all independent and in flight
-// together.  No LDS: the per-frame gather footprint (<= a few MB of 128-B lines) lives in L2/MALL.
-// HBM-bound integer/byte work by nature: ~0.1 flop per byte, the roofline is bandwidth.
+// Mapping: a block is 64 consecutive pixels x n_points samples, wave k = ray offset k, so the 64 lanes of a wave
+// are 64 consecutive pixels of one image row at the same ray offset: their stencils walk neighbouring voxels (the
+// z axis is contiguous in HBM) and the 16 fp16 loads per lane are all independent and in flight together.
+// Wave 0 computes the 64 ray frames (fp32 unprojection, fp64 normalisation: three fp64 divisions and a square
+// root - a third of the per-item instruction count) ONCE and hands them to the other waves through 3 KB of LDS; the
+// kernel is bound by instruction issue of the fp64 index math and the gather latency, not by bytes: the per-frame
+// gather footprint (<= a few MB of 128-B lines) lives in L2/MALL.
 #include "ojf_common.h"
 
 namespace ojf {
@@ -24,20 +26,13 @@ struct ExtractArgs {
     float pad_value;
 };
 
-__global__ __launch_bounds__(256) void extract_kernel(ExtractArgs a, Camera cam)
-{
-    const int N = a.h * a.w;
-    const int item = blockIdx.x * blockDim.x + threadIdx.x;
-    if (item >= N * a.n_points) return;
-    const int k = item / N;
-    const int n = item - k * N;
-    const int r = n / a.w, c = n - r * a.w;
-    const int half = (a.n_points - 1) / 2;
+constexpr int kMaxTilePoints = 16;  // 64 * n_points threads per block
 
-    float pw[3];
-    double cv[3], dir[3];
-    unproject(r, c, a.depth[n], cam, pw);
-    ray_frame(pw, cam, cv, dir);
+// body shared by the two mappings: sample k of pixel n on the ray frame (cv, dir)
+__device__ __forceinline__ void extract_item(const ExtractArgs &a, int n, int k, const double cv[3], const double dir[3],
+                                             const float pw[3])
+{
+    const int half = (a.n_points - 1) / 2;
     RaySample s;
     ray_sample(cv, dir, k, half, s);
 
@@ -86,6 +81,51 @@ __global__ __launch_bounds__(256) void extract_kernel(ExtractArgs a, Camera cam)
     }
 }
 
+// n_points <= kMaxTilePoints: blockDim.x = 64 * n_points, wave k = sample k of the block's 64 pixels
+__global__ __launch_bounds__(64 * kMaxTilePoints) void extract_tile_kernel(ExtractArgs a, Camera cam)
+{
+    __shared__ double frame[6][64];
+    __shared__ float pcl[3][64];
+    const int N = a.h * a.w;
+    const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    if (k == 0 && n < N) {
+        const int r = n / a.w, c = n - r * a.w;
+        float pw[3];
+        double cv[3], dir[3];
+        unproject(r, c, a.depth[n], cam, pw);
+        ray_frame(pw, cam, cv, dir);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            frame[i][lane] = cv[i];
+            frame[3 + i][lane] = dir[i];
+            pcl[i][lane] = pw[i];
+        }
+    }
+    __syncthreads();
+    if (n >= N) return;
+    const double cv[3] = {frame[0][lane], frame[1][lane], frame[2][lane]};
+    const double dir[3] = {frame[3][lane], frame[4][lane], frame[5][lane]};
+    const float pw[3] = {pcl[0][lane], pcl[1][lane], pcl[2][lane]};
+    extract_item(a, n, k, cv, dir, pw);
+}
+
+// any n_points: one lane per (sample k, pixel n), k-major; every item computes its own ray frame
+__global__ __launch_bounds__(256) void extract_kernel(ExtractArgs a, Camera cam)
+{
+    const int N = a.h * a.w;
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= N * a.n_points) return;
+    const int k = item / N;
+    const int n = item - k * N;
+    const int r = n / a.w, c = n - r * a.w;
+    float pw[3];
+    double cv[3], dir[3];
+    unproject(r, c, a.depth[n], cam, pw);
+    ray_frame(pw, cam, cv, dir);
+    extract_item(a, n, k, cv, dir, pw);
+}
+
 }  // namespace ojf
 
 OJF_API int ojf_extract(const float *depth, const float *Ki, const float *E, const double *origin,
@@ -108,7 +148,11 @@ OJF_API int ojf_extract(const float *depth, const float *Ki, const float *E, con
     ExtractArgs a{depth, tsdf, wgt, out_values, out_weights, dbg_idx, dbg_w, dbg_pts, dbg_pcl,
                   X, Y, Z, h, w, n_points, out_stride, out_layout, pad_value};
     const Camera cam = make_camera(Ki, E, origin, res);
-    const int items = h * w * n_points;
-    hipLaunchKernelGGL(extract_kernel, dim3((items + 255) / 256), dim3(256), 0, as_stream(stream), a, cam);
+    if (n_points <= kMaxTilePoints) {
+        hipLaunchKernelGGL(extract_tile_kernel, dim3((h * w + 63) / 64), dim3(64 * n_points), 0, as_stream(stream), a, cam);
+    } else {
+        const int items = h * w * n_points;
+        hipLaunchKernelGGL(extract_kernel, dim3((items + 255) / 256), dim3(256), 0, as_stream(stream), a, cam);
+    }
     return check_hip(hipGetLastError(), "ojf_extract launch");
 }

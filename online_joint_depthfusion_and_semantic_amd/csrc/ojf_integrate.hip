@@ -59,14 +59,30 @@ __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(Integra
     __shared__ unsigned int ediff[kSlots];
     __shared__ unsigned int newlist[kSlots];  // voxels this tile touched first
     __shared__ unsigned int n_entries, n_new, base_new, n_rec, base_rec;
+    __shared__ double frame[6][64];  // ray frame (voxel-space point, unit direction) of the tile's 64 pixels
     for (int s = threadIdx.x; s < kSlots; s += 256) {
         keys[s] = kEmpty; accw[s] = 0; accu[s] = 0; elast[s] = 0; ediff[s] = 0;
     }
     if (threadIdx.x == 0) { n_entries = 0; n_new = 0; n_rec = 0; }
-    __syncthreads();
-
     const int tiles_x = (a.w + 7) >> 3;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    if (threadIdx.x < 64) {  // once per pixel instead of once per (pixel, sample): three fp64 divisions and a sqrt each
+        const int p = threadIdx.x;
+        const int r = ty * 8 + (p >> 3), c = tx * 8 + (p & 7);
+        if (r < a.h && c < a.w) {
+            float pw[3];
+            double cv[3], dir[3];
+            unproject(r, c, a.depth[r * a.w + c], cam, pw);
+            ray_frame(pw, cam, cv, dir);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                frame[i][p] = cv[i];
+                frame[3 + i][p] = dir[i];
+            }
+        }
+    }
+    __syncthreads();
+
     const bool sem = a.id_vol != nullptr;
     const int half = (a.n_points - 1) / 2;
     unsigned int n_in = 0;
@@ -77,10 +93,8 @@ __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(Integra
         const int n = r * a.w + c;
         const float z = a.depth[n];
         if (!(z != 0.0f)) continue;  // modules/pipeline.py:145-146
-        float pw[3];
-        double cv[3], dir[3];
-        unproject(r, c, z, cam, pw);
-        ray_frame(pw, cam, cv, dir);
+        const double cv[3] = {frame[0][p], frame[1][p], frame[2][p]};
+        const double dir[3] = {frame[3][p], frame[4][p], frame[5][p]};
         RaySample s;
         ray_sample(cv, dir, k, half, s);
         float v = a.est[(size_t)n * a.est_stride + k];  // pipeline.py:153-156
