@@ -59,8 +59,8 @@ class FusionNetEngine:
         heads = 2 if (version == 3 and self.use_semantics) else 1
         n_vortex = heads + 1 if version == 3 else 2
         # MFMA launches per forward: 2 per dense block; per VortexPooling 1 stacked entry conv + 2 grouped
-        # launches (the four branches' dilated 3x3 pairs) + 1 fused tail; 1 fused prediction-head chain
-        self.conv_launches = 2 * net.gf * heads + 4 * n_vortex + 1
+        # launches (the four branches' dilated 3x3 pairs) + 1 fused tail (the last one also runs the prediction head)
+        self.conv_launches = 2 * net.gf * heads + 4 * n_vortex
 
     def prepare_input(self, values, weights, depth, sem_ids=None, n_classes=0, planes=False):
         """values / weights: cuda f32 from the extractor, rows [h*w, stride] or (planes=True) sample planes

@@ -158,7 +158,10 @@ class Pipeline(torch.nn.Module):
             raise ValueError('Pipeline: batch size 1 only (one scene per frame, pipeline.py:199)')
         frame = frame.to(self.device).float().contiguous()
         mask = batch['mask'].to(self.device).reshape(frame.shape)
-        filtered = torch.where(mask, frame, 0.0)  # pipeline.py:196 (one launch)
+        zero = self.__dict__.get('_zero')
+        if zero is None or zero.device != frame.device:
+            zero = self.__dict__['_zero'] = torch.zeros((), dtype=torch.float32, device=frame.device)
+        filtered = torch.where(mask, frame, zero)  # pipeline.py:196; one launch (a python scalar costs a fill kernel)
         return frame[0], filtered[0]
 
     # ---- inference frame step (pipeline.py:173-248) ---------------------------------------------
