@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const ConvGroup grp)
 {
     constexpr int CS = conv16_chunk(NT);
     const ConvArgs &a = grp.g[blockIdx.y];
-    __shared__ int2 tab[(kMaxSteps + kPad16) * 8];
+    extern __shared__ int2 tab[];  // (nsteps + kPad16) * 8 entries, sized by the launch: LDS per block bounds the waves in flight
     __shared__ f32x4 wl[CS * NT * 128];
     build_tap_table16(tab, a, (a.nsteps + kPad16) * 8);
 
@@ -1178,7 +1178,10 @@ static int launch_conv_args(const ConvArgs *args, int n, int nt, hipStream_t st,
     const int strips = (args[0].npix + mt * 16 - 1) / (mt * 16);
     const dim3 grid((strips + 3) / 4, n), block(256);
 #define OJF_LAUNCH32(NT_) hipLaunchKernelGGL((conv_mfma_kernel<1, NT_>), grid, block, 0, st, grp)
-#define OJF_LAUNCH16(MT_, NT_) hipLaunchKernelGGL((conv_f16x3_kernel<MT_, NT_>), grid, block, 0, st, grp)
+    int max_steps = 0;
+    for (int i = 0; i < n; ++i) max_steps = args[i].nsteps > max_steps ? args[i].nsteps : max_steps;
+    const size_t tab_bytes = (size_t)(max_steps + kPad16) * 8 * sizeof(int2);  // (no measurable effect vs the full 8.6 KB)
+#define OJF_LAUNCH16(MT_, NT_) hipLaunchKernelGGL((conv_f16x3_kernel<MT_, NT_>), grid, block, tab_bytes, st, grp)
     if (arith == OJF_ARITH_F16X3 && mt == 2) {
         switch (nt) {
             case 2: OJF_LAUNCH16(2, 2); break;

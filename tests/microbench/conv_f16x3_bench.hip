@@ -55,7 +55,8 @@ static void run_shape(const char *name, int cin, int cout, int k, int dil, int h
     const int strips1 = (npix + 15) / 16, strips = (npix + MT * 16 - 1) / (MT * 16);
     const dim3 grid1((strips1 + 3) / 4, ngroup), grid((strips + 3) / 4, ngroup), block(256);
     const float t32 = time_it([&] { hipLaunchKernelGGL((conv_mfma_kernel<1, NT>), grid1, block, 0, 0, g32); }, 50);
-#define T16(ABL_) time_it([&] { hipLaunchKernelGGL((conv_f16x3_kernel<MT, NT, true, ABL_>), grid, block, 0, 0, g16); }, 50)
+    const size_t tab_bytes = (size_t)(a16.nsteps + kPad16) * 8 * sizeof(int2);
+#define T16(ABL_) time_it([&] { hipLaunchKernelGGL((conv_f16x3_kernel<MT, NT, true, ABL_>), grid, block, tab_bytes, 0, g16); }, 50)
     const float t0 = T16(0), t1 = T16(1), t2 = T16(2), t4 = T16(4), t8 = T16(8), t12 = T16(12), t3 = T16(3), t15 = T16(15), t14 = T16(14), t13 = T16(13);
     printf("%-16s x%d MT=%d NT=%d | f32 %.1f | f16x3 %.1f | noX %.1f noW %.1f noMFMA %.1f noSplit %.1f noMFMA+noSplit %.1f noXW %.1f "
            "onlyX %.1f onlyW %.1f nothing %.1f us\n",
