@@ -19,7 +19,7 @@ static_assert(sizeof(VoxelRec) == 32, "VoxelRec layout");
 
 constexpr double kFixScale = 68719476736.0;          // 2^36
 constexpr double kFixInv = 1.0 / 68719476736.0;
-constexpr size_t kHeaderBytes = 256;                  // counters: [0] touched voxels, [1] entries, [2] records
+constexpr size_t kHeaderBytes = 256;                  // counters: [0] counter-allocated touched voxels, [2] counter-allocated records
 
 struct IntegrateArgs {
     const float *depth;  // filtered frame
@@ -34,6 +34,9 @@ struct IntegrateArgs {
     unsigned int *head;   // dense [X*Y*Z]: first record of the voxel (index + 1), 0 = untouched; left zeroed
     VoxelRec *recs;
     unsigned int *touched;
+    unsigned int *tile_new;   // tiled FAST path: voxels first touched by each tile (its slice of `touched`)
+    unsigned int list_base;   // first element of the counter-allocated parts of `touched` / `recs`
+    int n_tiles;              // 0 on the entry-list path
     uint32_t *stats;
     int X, Y, Z, h, w, n_points, n_tail, est_stride;
     float trunc;

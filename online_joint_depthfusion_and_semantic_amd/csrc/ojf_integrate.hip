@@ -11,27 +11,35 @@
 //   * the semantic "last writer wins" rule is an integer max over entry ids, i.e. exact.
 // Each pixel tile emits ONE record per voxel it touches and links it into that voxel's list with a
 // single atomic exchange on a dense 4-byte head table (measured: every additional global atomic per
-// record costs ~18 us per frame, a per-record append to one shared counter ~350 us).  The finalize
-// pass walks the touched voxels, sums their 2-3 records, applies the running-mean update and zeroes
-// the head entries, so every call leaves the workspace clean.
+// record costs ~18 us per frame, a per-record append to one shared counter ~350 us).  Records and
+// first-touch lists live in per-tile slices of the workspace (tile t owns [t*2048, (t+1)*2048) of both), so
+// the hot path has NO same-address global atomics: three per-tile counter atomics on one cache line cost
+// 14 us per frame.  Only the rare hash-full entries and the entry-list path allocate from counters, behind
+// the slices.  The finalize pass walks the touched voxels, sums their 2-3 records, applies the running-mean
+// update and zeroes the head entries, so every call leaves the workspace clean.
 //
 // PARITY mode (ojf_integrate_parity.hip) reproduces the reference's sequential fp32 sums bit for bit.
 #include "ojf_integrate.h"
 
 namespace ojf {
 
-static size_t record_capacity(size_t entries) { return entries; }  // worst case: every entry its own record
+constexpr int kSlots = 2048;
+constexpr unsigned int kEmpty = 0xffffffffu;
+
+static size_t tile_count(int h, int w) { return (size_t)((h + 7) / 8) * ((w + 7) / 8); }
+// records / first touches: a 2048-element slice per tile, then room for every entry that found its tile's hash full
+static size_t list_capacity(int h, int w, int n_tail)
+{
+    const size_t per_tile = (size_t)64 * n_tail * 8;
+    return tile_count(h, w) * (kSlots + per_tile);
+}
 
 size_t fast_workspace_bytes(int X, int Y, int Z, int h, int w, int n_tail)
 {
-    const size_t nvox = (size_t)X * Y * Z;
-    const size_t entries = (size_t)h * w * n_tail * 8;
-    const size_t cap = entries < nvox ? entries : nvox;
-    return kHeaderBytes + nvox * sizeof(unsigned int) + record_capacity(entries) * sizeof(VoxelRec) + cap * sizeof(unsigned int);
+    const size_t nvox = (size_t)X * Y * Z, cap = list_capacity(h, w, n_tail);
+    return kHeaderBytes + nvox * sizeof(unsigned int) + cap * sizeof(VoxelRec) + cap * sizeof(unsigned int) +
+           tile_count(h, w) * sizeof(unsigned int);
 }
-
-constexpr int kSlots = 2048;
-constexpr unsigned int kEmpty = 0xffffffffu;
 
 // publish one record; returns true when this is the voxel's first record of the frame
 __device__ __forceinline__ bool link_record(const IntegrateArgs &a, unsigned int idx, unsigned int lin,
@@ -58,7 +66,7 @@ __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(Integra
     __shared__ unsigned int elast[kSlots];
     __shared__ unsigned int ediff[kSlots];
     __shared__ unsigned int newlist[kSlots];  // voxels this tile touched first
-    __shared__ unsigned int n_entries, n_new, base_new, n_rec, base_rec;
+    __shared__ unsigned int n_entries, n_new, n_rec, base_rec;
     __shared__ double frame[6][64];  // ray frame (voxel-space point, unit direction) of the tile's 64 pixels
     for (int s = threadIdx.x; s < kSlots; s += 256) {
         keys[s] = kEmpty; accw[s] = 0; accu[s] = 0; elast[s] = 0; ediff[s] = 0;
@@ -127,15 +135,16 @@ __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(Integra
                 atomicAdd(&accu[slot], xu);
                 atomicMax(&elast[slot], e);
                 if (ed) atomicMax(&ediff[slot], ed);
-            } else {  // hash full: a record of its own (rare)
-                const unsigned int ridx = atomicAdd(&a.counters[2], 1u);
-                if (link_record(a, ridx, lin, xw, xu, e, ed)) a.touched[atomicAdd(&a.counters[0], 1u)] = lin;
+            } else {  // hash full: a record of its own behind the tile slices (rare)
+                const unsigned int ridx = a.list_base + atomicAdd(&a.counters[2], 1u);
+                if (link_record(a, ridx, lin, xw, xu, e, ed)) a.touched[a.list_base + atomicAdd(&a.counters[0], 1u)] = lin;
+                if (a.stats) atomicAdd(&a.stats[2], 1u);
             }
         }
     }
     if (n_in) atomicAdd(&n_entries, n_in);
     __syncthreads();
-    // count this tile's records, reserve their range with ONE counter atomic, then publish them
+    // number this tile's records inside its own slice of the record array, then publish them
     unsigned int mine[kSlots / 256];
 #pragma unroll
     for (int j = 0; j < kSlots / 256; ++j) {
@@ -144,8 +153,11 @@ __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(Integra
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (n_rec) base_rec = atomicAdd(&a.counters[2], n_rec);
-        if (n_entries) atomicAdd(&a.counters[1], n_entries);
+        base_rec = blockIdx.x * kSlots;
+        if (a.stats) {  // test / profiling only: same-line atomics cost 14 us per frame
+            atomicAdd(&a.stats[1], n_entries);
+            atomicAdd(&a.stats[2], n_rec);
+        }
     }
     __syncthreads();
     // All of a thread's list-head exchanges are issued before any of their results is used: the returning
@@ -164,9 +176,8 @@ __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(Integra
         if (prev[j] == 0) newlist[atomicAdd(&n_new, 1u)] = r.lin;
     }
     __syncthreads();
-    if (threadIdx.x == 0 && n_new) base_new = atomicAdd(&a.counters[0], n_new);
-    __syncthreads();
-    for (unsigned int i = threadIdx.x; i < n_new; i += 256) a.touched[base_new + i] = newlist[i];
+    if (threadIdx.x == 0) a.tile_new[blockIdx.x] = n_new;
+    for (unsigned int i = threadIdx.x; i < n_new; i += 256) a.touched[blockIdx.x * kSlots + i] = newlist[i];
 }
 
 // Entry-list variant for the reference's own Integrator.forward signature (modules/integrator.py:15-126):
@@ -214,54 +225,58 @@ __global__ __launch_bounds__(256) void integrate_entries_kernel(IntegrateArgs a,
     __syncthreads();
     if (threadIdx.x == 0) {
         if (n_new) base_new = atomicAdd(&a.counters[0], n_new);
-        if (n_entries) atomicAdd(&a.counters[1], n_entries);
+        if (a.stats && n_entries) atomicAdd(&a.stats[1], n_entries);
     }
     __syncthreads();
-    for (unsigned int i = threadIdx.x; i < n_new; i += 256) a.touched[base_new + i] = newlist[i];
+    for (unsigned int i = threadIdx.x; i < n_new; i += 256) a.touched[a.list_base + base_new + i] = newlist[i];
 }
 
+__device__ __forceinline__ void finalize_voxel(const IntegrateArgs &a, size_t lin, unsigned int per_pixel, bool sem)
+{
+    unsigned int ri = a.head[lin];
+    a.head[lin] = 0;  // leave the workspace clean
+    long long sw = 0, su = 0;
+    unsigned int e_last = 0, e_diff = 0;
+    while (ri) {  // 2-3 records per voxel; integer sums: any order gives the same bits
+        const VoxelRec r = a.recs[ri - 1];
+        sw += (long long)r.w;
+        su += (long long)r.u;
+        e_last = r.e_last > e_last ? r.e_last : e_last;
+        e_diff = r.e_diff > e_diff ? r.e_diff : e_diff;
+        ri = r.next;
+    }
+    const float W = (float)((double)sw * kFixInv);
+    const float U = (float)((double)su * kFixInv);
+    const float w_old = h2f(a.wgt[lin]), v_old = h2f(a.tsdf[lin]);  // integrator.py:72-75
+    const float w_new = w_old + W;                                   // :77
+    const float num = w_old * v_old + U;                             // :82
+    a.wgt[lin] = f2h(w_new);                                         // :78,87
+    a.tsdf[lin] = f2h(num / w_new);                                  // :83,88
+    if (sem) {  // integrator.py:93-124 with "highest entry wins" for duplicates
+        const float s_old = h2f(a.score_vol[lin]);
+        const float s_last = a.sem_scores[(e_last - 1u) / per_pixel];
+        a.score_vol[lin] = f2h(s_last > s_old ? s_last : s_old);     // :113-114,124
+        if (e_diff) {                                                 // :105,116-117,123
+            const unsigned int n_d = (e_diff - 1u) / per_pixel;
+            if (a.sem_scores[n_d] > s_old) a.id_vol[lin] = a.sem_ids[n_d];
+        }
+    }
+}
+
+// one lane per touched voxel: first the per-tile slices, then the counter-allocated list
 __global__ __launch_bounds__(256) void integrate_finalize_kernel(IntegrateArgs a)
 {
-    const unsigned int count = a.counters[0];
     const unsigned int per_pixel = (unsigned int)a.n_tail * 8u;  // entries per sem_ids / sem_scores element
     const bool sem = a.id_vol != nullptr;
-    for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
-        const size_t lin = a.touched[t];
-        unsigned int ri = a.head[lin];
-        a.head[lin] = 0;  // leave the workspace clean
-        long long sw = 0, su = 0;
-        unsigned int e_last = 0, e_diff = 0;
-        while (ri) {  // 2-3 records per voxel; integer sums: any order gives the same bits
-            const VoxelRec r = a.recs[ri - 1];
-            sw += (long long)r.w;
-            su += (long long)r.u;
-            e_last = r.e_last > e_last ? r.e_last : e_last;
-            e_diff = r.e_diff > e_diff ? r.e_diff : e_diff;
-            ri = r.next;
-        }
-        const float W = (float)((double)sw * kFixInv);
-        const float U = (float)((double)su * kFixInv);
-        const float w_old = h2f(a.wgt[lin]), v_old = h2f(a.tsdf[lin]);  // integrator.py:72-75
-        const float w_new = w_old + W;                                   // :77
-        const float num = w_old * v_old + U;                             // :82
-        a.wgt[lin] = f2h(w_new);                                         // :78,87
-        a.tsdf[lin] = f2h(num / w_new);                                  // :83,88
-        if (sem) {  // integrator.py:93-124 with "highest entry wins" for duplicates
-            const float s_old = h2f(a.score_vol[lin]);
-            const float s_last = a.sem_scores[(e_last - 1u) / per_pixel];
-            a.score_vol[lin] = f2h(s_last > s_old ? s_last : s_old);     // :113-114,124
-            if (e_diff) {                                                 // :105,116-117,123
-                const unsigned int n_d = (e_diff - 1u) / per_pixel;
-                if (a.sem_scores[n_d] > s_old) a.id_vol[lin] = a.sem_ids[n_d];
-            }
-        }
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const unsigned int n = a.tile_new[tile];
+        for (unsigned int i = threadIdx.x; i < n; i += blockDim.x) finalize_voxel(a, a.touched[(size_t)tile * kSlots + i], per_pixel, sem);
+        if (a.stats && threadIdx.x == 0 && n) atomicAdd(&a.stats[0], n);
     }
-    if (a.stats && blockIdx.x == 0 && threadIdx.x == 0) {
-        a.stats[0] = count;
-        a.stats[1] = a.counters[1];
-        a.stats[2] = a.counters[2];
-        a.stats[3] = 0;
-    }
+    const unsigned int count = a.counters[0];
+    for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x)
+        finalize_voxel(a, a.touched[a.list_base + t], per_pixel, sem);
+    if (a.stats && blockIdx.x == 0 && threadIdx.x == 0 && count) atomicAdd(&a.stats[0], count);
 }
 
 }  // namespace ojf
@@ -318,7 +333,7 @@ OJF_API int ojf_integrate(const float *depth_filtered, const float *Ki, const fl
     a.depth = depth_filtered; a.est = est; a.tsdf = tsdf; a.wgt = wgt;
     a.sem_ids = sem_ids; a.sem_scores = sem_scores; a.id_vol = id_vol; a.score_vol = score_vol;
     a.counters = reinterpret_cast<unsigned int *>(base);
-    a.head = nullptr; a.recs = nullptr; a.touched = nullptr; a.stats = stats;
+    a.head = nullptr; a.recs = nullptr; a.touched = nullptr; a.tile_new = nullptr; a.list_base = 0; a.n_tiles = 0; a.stats = stats;
     a.X = X; a.Y = Y; a.Z = Z; a.h = h; a.w = w; a.n_points = n_points; a.n_tail = n_tail;
     a.est_stride = est_stride; a.trunc = trunc;
     const Camera cam = make_camera(Ki, E, origin, res);
@@ -326,16 +341,21 @@ OJF_API int ojf_integrate(const float *depth_filtered, const float *Ki, const fl
     OJF_HIP(hipMemsetAsync(a.counters, 0, kHeaderBytes, st));
     if (mode == OJF_MODE_PARITY) return integrate_parity(a, cam, base + kHeaderBytes, ws_bytes - kHeaderBytes, st);
 
+    const int tiles = (int)tile_count(h, w);
     {
-        const size_t nvox = (size_t)X * Y * Z, entries = (size_t)h * w * n_tail * 8;
-        a.head = reinterpret_cast<unsigned int *>(base + kHeaderBytes);
-        a.recs = reinterpret_cast<VoxelRec *>(base + kHeaderBytes + nvox * sizeof(unsigned int));
-        a.touched = reinterpret_cast<unsigned int *>(base + kHeaderBytes + nvox * sizeof(unsigned int) + entries * sizeof(VoxelRec));
+        const size_t nvox = (size_t)X * Y * Z, cap = list_capacity(h, w, n_tail);
+        char *q = base + kHeaderBytes;
+        a.head = reinterpret_cast<unsigned int *>(q); q += nvox * sizeof(unsigned int);
+        a.recs = reinterpret_cast<VoxelRec *>(q); q += cap * sizeof(VoxelRec);
+        a.touched = reinterpret_cast<unsigned int *>(q); q += cap * sizeof(unsigned int);
+        a.tile_new = reinterpret_cast<unsigned int *>(q);
+        a.n_tiles = tiles;
+        a.list_base = (unsigned int)tiles * kSlots;
     }
-    const int tiles = ((h + 7) / 8) * ((w + 7) / 8);
+    if (stats) OJF_HIP(hipMemsetAsync(stats, 0, 4 * sizeof(uint32_t), st));
     hipLaunchKernelGGL(integrate_accumulate_tiled_kernel, dim3(tiles), dim3(256), 0, st, a, cam);
     OJF_HIP(hipGetLastError());
-    hipLaunchKernelGGL(integrate_finalize_kernel, dim3(1024), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(integrate_finalize_kernel, dim3(tiles < 1024 ? 1024 : tiles), dim3(256), 0, st, a);
     return check_hip(hipGetLastError(), "ojf_integrate launch");
 }
 
@@ -366,10 +386,11 @@ OJF_API int ojf_integrate_entries(const float *values, const int64_t *indices, c
     a.head = reinterpret_cast<unsigned int *>(base + kHeaderBytes);
     a.recs = reinterpret_cast<VoxelRec *>(base + kHeaderBytes + nvox * sizeof(unsigned int));
     a.touched = reinterpret_cast<unsigned int *>(base + kHeaderBytes + nvox * sizeof(unsigned int) + entries * sizeof(VoxelRec));
-    a.stats = stats;
+    a.stats = stats; a.tile_new = nullptr; a.list_base = 0; a.n_tiles = 0;
     a.X = X; a.Y = Y; a.Z = Z; a.h = 1; a.w = 1; a.n_points = 1; a.est_stride = 0; a.trunc = 0.0f;
     a.n_tail = 1;  // finalize maps entry id -> row as (id - 1) / (n_tail * 8)
     OJF_HIP(hipMemsetAsync(a.counters, 0, kHeaderBytes, st));
+    if (stats) OJF_HIP(hipMemsetAsync(stats, 0, 4 * sizeof(uint32_t), st));
     if (n_rows > 0) {
         EntryArgs e{values, indices, weights, row_ids, (int)n_rows};
         hipLaunchKernelGGL(integrate_entries_kernel, dim3((unsigned int)((n_rows + 255) / 256)), dim3(256), 0, st, a, e);

@@ -99,9 +99,10 @@ class IntegrateWorkspace:
 
 def integrate(depth_filtered, Ki, E, origin, resolution, est, tsdf, weights, workspace,
               n_points=9, n_tail=7, trunc=0.1, est_stride=None, sem_ids=None, sem_scores=None,
-              id_vol=None, score_vol=None, mode=MODE_FAST):
+              id_vol=None, score_vol=None, mode=MODE_FAST, stats=False):
     """Scatter the clamped net output into the volumes, in place.  est: cuda f32 rows with
-    ``est_stride`` floats per pixel (default: est.shape[-1])."""
+    ``est_stride`` floats per pixel (default: est.shape[-1]).  stats=True fills ``workspace.stats``
+    ({touched voxels, scatter entries, records, 0}; costs ~14 us per frame of same-line atomics)."""
     _lib.require_gpu()
     lib = _lib.load()
     depth_filtered = depth_filtered.reshape(depth_filtered.shape[-2], depth_filtered.shape[-1])
@@ -123,8 +124,8 @@ def integrate(depth_filtered, Ki, E, origin, resolution, est, tsdf, weights, wor
                            float(resolution), _lib.ptr(est), int(est_stride), n_points, n_tail,
                            float(trunc), _lib.ptr(tsdf), _lib.ptr(weights), _lib.ptr(sem_ids),
                            _lib.ptr(sem_scores), _lib.ptr(id_vol), _lib.ptr(score_vol), X, Y, Z, h, w,
-                           mode, _lib.ptr(workspace.buf), workspace.bytes, _lib.ptr(workspace.stats),
-                           _lib.stream_ptr(depth_filtered.device))
+                           mode, _lib.ptr(workspace.buf), workspace.bytes,
+                           _lib.ptr(workspace.stats) if stats else None, _lib.stream_ptr(depth_filtered.device))
     _lib.check(rc, 'ojf_integrate')
 
 

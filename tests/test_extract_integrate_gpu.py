@@ -58,7 +58,7 @@ def _run_integrate(st, fi, vols_gpu, ws, mode, semantics, cuda):
         kw = dict(sem_ids=_t(fi['sem_ids'].reshape(-1), cuda), sem_scores=_t(fi['sem_scores'].reshape(-1), cuda),
                   id_vol=vols_gpu['ids'], score_vol=vols_gpu['scores'])
     ops.integrate(_t(fi['fd'], cuda), fi['Ki'], fi['E'], st.origin, st.resolution, _t(fi['est'], cuda),
-                  vols_gpu['tsdf'], vols_gpu['wgt'], ws, mode=mode, **kw)
+                  vols_gpu['tsdf'], vols_gpu['wgt'], ws, mode=mode, stats=True, **kw)
 
 
 def _oracle_integrate(st, fi, vols, semantics):
