@@ -58,18 +58,22 @@ __device__ __forceinline__ bool link_record(const IntegrateArgs &a, unsigned int
 // colliding writes are first combined in a 2048-slot LDS hash (integer adds / maxima), and only one
 // record per (tile, voxel) goes to HBM (~16 entries/voxel -> ~2.6 tiles/voxel).  Entries that find the
 // hash full become single-entry records.
+// SEM = false (geometry only) drops the two entry-id tables: 51 KB instead of 67 KB of LDS per block, i.e. three
+// blocks per CU instead of two for a kernel that is bound by the latency of its atomics.
+template <bool SEM>
 __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(IntegrateArgs a, Camera cam)
 {
     __shared__ unsigned int keys[kSlots];
     __shared__ unsigned long long accw[kSlots];
     __shared__ unsigned long long accu[kSlots];
-    __shared__ unsigned int elast[kSlots];
-    __shared__ unsigned int ediff[kSlots];
+    __shared__ unsigned int elast[SEM ? kSlots : 1];
+    __shared__ unsigned int ediff[SEM ? kSlots : 1];
     __shared__ unsigned int newlist[kSlots];  // voxels this tile touched first
     __shared__ unsigned int n_entries, n_new, n_rec, base_rec;
     __shared__ double frame[6][64];  // ray frame (voxel-space point, unit direction) of the tile's 64 pixels
     for (int s = threadIdx.x; s < kSlots; s += 256) {
-        keys[s] = kEmpty; accw[s] = 0; accu[s] = 0; elast[s] = 0; ediff[s] = 0;
+        keys[s] = kEmpty; accw[s] = 0; accu[s] = 0;
+        if constexpr (SEM) { elast[s] = 0; ediff[s] = 0; }
     }
     if (threadIdx.x == 0) { n_entries = 0; n_new = 0; n_rec = 0; }
     const int tiles_x = (a.w + 7) >> 3;
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(Integra
     }
     __syncthreads();
 
-    const bool sem = a.id_vol != nullptr;
+    constexpr bool sem = SEM;
     const int half = (a.n_points - 1) / 2;
     unsigned int n_in = 0;
     for (int item = threadIdx.x; item < 64 * a.n_tail; item += 256) {
@@ -133,8 +137,10 @@ __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(Integra
             if (slot >= 0) {
                 atomicAdd(&accw[slot], xw);
                 atomicAdd(&accu[slot], xu);
-                atomicMax(&elast[slot], e);
-                if (ed) atomicMax(&ediff[slot], ed);
+                if constexpr (SEM) {
+                    atomicMax(&elast[slot], e);
+                    if (ed) atomicMax(&ediff[slot], ed);
+                }
             } else {  // hash full: a record of its own behind the tile slices (rare)
                 const unsigned int ridx = a.list_base + atomicAdd(&a.counters[2], 1u);
                 if (link_record(a, ridx, lin, xw, xu, e, ed)) a.touched[a.list_base + atomicAdd(&a.counters[0], 1u)] = lin;
@@ -171,7 +177,8 @@ __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(Integra
         if (mine[j] == kEmpty) continue;
         const int s = threadIdx.x + 256 * j;
         VoxelRec r;
-        r.lin = keys[s]; r.next = prev[j]; r.w = accw[s]; r.u = accu[s]; r.e_last = elast[s]; r.e_diff = ediff[s];
+        r.lin = keys[s]; r.next = prev[j]; r.w = accw[s]; r.u = accu[s];
+        r.e_last = SEM ? elast[s] : 0u; r.e_diff = SEM ? ediff[s] : 0u;
         a.recs[base_rec + mine[j]] = r;
         if (prev[j] == 0) newlist[atomicAdd(&n_new, 1u)] = r.lin;
     }
@@ -353,7 +360,8 @@ OJF_API int ojf_integrate(const float *depth_filtered, const float *Ki, const fl
         a.list_base = (unsigned int)tiles * kSlots;
     }
     if (stats) OJF_HIP(hipMemsetAsync(stats, 0, 4 * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(integrate_accumulate_tiled_kernel, dim3(tiles), dim3(256), 0, st, a, cam);
+    if (id_vol) hipLaunchKernelGGL(integrate_accumulate_tiled_kernel<true>, dim3(tiles), dim3(256), 0, st, a, cam);
+    else hipLaunchKernelGGL(integrate_accumulate_tiled_kernel<false>, dim3(tiles), dim3(256), 0, st, a, cam);
     OJF_HIP(hipGetLastError());
     hipLaunchKernelGGL(integrate_finalize_kernel, dim3(tiles < 1024 ? 1024 : tiles), dim3(256), 0, st, a);
     return check_hip(hipGetLastError(), "ojf_integrate launch");
