@@ -1377,6 +1377,12 @@ static void free_planes(float *p)
     if (p) (void)hipFree(p - kPrefix);
 }
 
+// buffers only the unfused fall-back paths need are allocated at their first use (synchronous, outside any capture)
+static int ensure_planes(float **p, size_t npix, int ch)
+{
+    return *p ? 0 : alloc_planes(p, npix, ch);
+}
+
 static int build_vortex(ojf_net *net, Vortex &v, const ojf_conv_layer *L, int c_in, const std::vector<int> &in_map,
                         int c_in_phys)
 {
@@ -1512,10 +1518,12 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
         if (launch_conv_args(gb, 4, v.b3b[0].n_ot, st, net->arith)) return -2;
     }
     OJF_HIP(hipStreamWaitEvent(st, net->ev_join, 0));  // bias of the final conv is ready
-    if (!fused)
+    if (!fused) {
+        if (ensure_planes(&net->CAT, (size_t)net->npix, 4 * net->os)) return -2;
         for (int br = 0; br < 4; ++br)
             if (launch_conv(v.b1[br], net->V, br * c4, net->CAT, br * o4, nullptr, OJF_ACT_RELU, net->os, 1.0f, h, w, st))
                 return -2;
+    }
     if (!fused) return launch_conv(v.fin, net->CAT, 0, out, out_g0, v.bias_final, OJF_ACT_NONE, 0, 1.0f, h, w, st);
     TailArgs ta;
     for (int br = 0; br < 4; ++br) ta.v[br] = planes(net->V) + (size_t)br * c4 * net->npix;
@@ -1716,11 +1724,8 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
     if (!rc) rc = alloc_planes(&net->Q3, np, cs);
     if (!rc) rc = alloc_planes(&net->U, np, 4 * cs);
     if (!rc) rc = alloc_planes(&net->V, np, 4 * cs);
-    if (!rc) rc = alloc_planes(&net->CAT, np, 4 * os);
     if (!rc) rc = alloc_planes(&net->YY, np, net->heads * os);
     if (!rc) rc = alloc_planes(&net->Y3, np, os);
-    if (!rc) rc = alloc_planes(&net->PA, np, os);
-    if (!rc) rc = alloc_planes(&net->PB, np, os);
     if (!rc) rc = alloc_planes(&net->partial, kSumBlocks, 256);
     if (!rc) rc = check_hip(hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking), "hipStreamCreate");
     if (!rc) rc = check_hip(hipStreamCreateWithFlags(&net->cap, hipStreamNonBlocking), "hipStreamCreate");
@@ -1792,19 +1797,14 @@ static int forward_launches(ojf_net *net, float *est, int est_stride, hipStream_
     }
     if (head_done) return 0;
     if (net->chain_kind && !unfused) {
-        static const int mt_env = getenv("OJF_CHAIN_MT") ? atoi(getenv("OJF_CHAIN_MT")) : 1;  // tuning switch only
+        // stand-alone head (the tail fusion is off or unavailable); one pixel tile per wave: two measured slower
         const bool h16 = net->arith == OJF_ARITH_F16X3;
-        const int mt = h16 ? mt_env : 1;  // fp32: 4800 waves balance over 1024 SIMDs better than 2400 (see launch_conv_args)
-        const int strips = (net->npix + mt * 16 - 1) / (mt * 16);
+        const int strips = (net->npix + 15) / 16;
         const dim3 grid((strips + 3) / 4), block(256);
-        if (net->chain_kind == 19 && h16 && mt == 2)
-            hipLaunchKernelGGL((chain1x1_kernel<OJF_ARITH_F16X3, 2, 8, 6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1>), grid, block, 0, st, ca);
-        else if (net->chain_kind == 19 && h16)
+        if (net->chain_kind == 19 && h16)
             hipLaunchKernelGGL((chain1x1_kernel<OJF_ARITH_F16X3, 1, 8, 6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1>), grid, block, 0, st, ca);
         else if (net->chain_kind == 19)
             hipLaunchKernelGGL((chain1x1_kernel<OJF_ARITH_F32, 1, 8, 6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1>), grid, block, 0, st, ca);
-        else if (h16 && mt == 2)
-            hipLaunchKernelGGL((chain1x1_kernel<OJF_ARITH_F16X3, 2, 8, 7, 7, 5, 5, 4, 4, 3, 3, 2, 2, 1>), grid, block, 0, st, ca);
         else if (h16)
             hipLaunchKernelGGL((chain1x1_kernel<OJF_ARITH_F16X3, 1, 8, 7, 7, 5, 5, 4, 4, 3, 3, 2, 2, 1>), grid, block, 0, st, ca);
         else
@@ -1813,6 +1813,7 @@ static int forward_launches(ojf_net *net, float *est, int est_stride, hipStream_
     }
     const float *pin = net->Y3;
     const int np = (int)net->pred.size();
+    if (ensure_planes(&net->PA, (size_t)net->npix, net->os) || ensure_planes(&net->PB, (size_t)net->npix, net->os)) return -2;
     float *pp[2] = {net->PA, net->PB};
     for (int i = 0; i < np; ++i) {
         const PackedConv &pc = net->pred[i];
@@ -1845,6 +1846,9 @@ static void capture_graph(ojf_net *net, float *est, int est_stride)
     drop_graph(net);
     net->g_est = est;
     net->g_stride = est_stride;
+    // no allocation may happen while capturing: have the fall-back paths' buffers in place
+    if (ensure_planes(&net->CAT, (size_t)net->npix, 4 * net->os) || ensure_planes(&net->PA, (size_t)net->npix, net->os) ||
+        ensure_planes(&net->PB, (size_t)net->npix, net->os)) { net->use_graph = false; return; }
     if (hipStreamBeginCapture(net->cap, hipStreamCaptureModeThreadLocal) != hipSuccess) { net->use_graph = false; return; }
     const int rc = forward_launches(net, est, est_stride, net->cap);
     hipGraph_t g = nullptr;

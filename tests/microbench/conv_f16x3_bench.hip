@@ -67,11 +67,18 @@ static void run_shape(const char *name, int cin, int cout, int k, int dil, int h
 int main()
 {
     const int h = 240, w = 320;
-    run_shape<1, 2>("3x3 19->19 d1", 19, 19, 3, 1, h, w, 1);
-    run_shape<2, 2>("3x3 19->19 d1", 19, 19, 3, 1, h, w, 4);
-    run_shape<1, 2>("3x3 57->19 d1", 57, 19, 3, 1, h, w, 1);
-    run_shape<1, 2>("3x3 95->19 d1", 95, 19, 3, 1, h, w, 1);
-    run_shape<2, 2>("3x3 95->19 d1", 95, 19, 3, 1, h, w, 1);
+    // dense block today: K grows
+    run_shape<2, 2>("3x3 19->19", 19, 19, 3, 1, h, w, 1);
+    run_shape<2, 2>("3x3 38->19", 38, 19, 3, 1, h, w, 1);
+    run_shape<2, 2>("3x3 57->19", 57, 19, 3, 1, h, w, 1);
+    run_shape<2, 2>("3x3 76->19", 76, 19, 3, 1, h, w, 1);
+    run_shape<2, 2>("3x3 95->19", 95, 19, 3, 1, h, w, 1);
+    // alternative: every new 19-channel slot feeds all later layers at once (N grows instead of K)
+    run_shape<2, 8>("3x3 19->100", 19, 100, 3, 1, h, w, 1);
+    run_shape<1, 8>("3x3 19->100", 19, 100, 3, 1, h, w, 1);
+    run_shape<2, 6>("3x3 19->80", 19, 80, 3, 1, h, w, 1);
+    run_shape<2, 4>("3x3 19->60", 19, 60, 3, 1, h, w, 1);
+    run_shape<2, 4>("3x3 19->40", 19, 40, 3, 1, h, w, 1);
     run_shape<2, 6>("1x1 114->76", 114, 76, 1, 1, h, w, 1);
     return 0;
 }

@@ -161,3 +161,73 @@ def test_f16x3_range_guard(cuda):
     assert torch.isfinite(got).all()
     assert float((got - ref).abs().max()) <= 2e-3  # pre-activations ~1e4 here: 1e-7 relative
     eng.close()
+
+
+@pytest.mark.parametrize('arith', ['f16x3', 'f32'])
+@pytest.mark.parametrize('version,sem,n_points,growth', [('v3', False, 5, 4), ('v3', True, 3, 3), ('v2', True, 7, 5)])
+def test_fusion_net_other_topologies(cuda, arith, version, sem, n_points, growth):
+    """Channel counts other than 19/20 x 6 take the generic paths (stand-alone closing 1x1 convolutions and final
+    conv instead of the fused tail, layer-by-layer prediction head): same tolerance."""
+    h, w = 40, 56
+    cfg = NS(n_points=n_points, growth_factor=growth, use_semantics=sem, output_scale=1.0, resx=w, resy=h)
+    torch.manual_seed(11)
+    net = getattr(model, 'FusionNet_' + version)(cfg)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            torch.nn.init.xavier_normal_(m.weight)
+            m.bias.data.normal_(0, 0.05)
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.1)
+    net = net.eval()
+    g = torch.Generator().manual_seed(2)
+    x = dict(tsdf_values=(torch.rand(1, n_points, h, w, generator=g) - 0.5) * 0.2,
+             tsdf_weights=torch.rand(1, n_points, h, w, generator=g) * 4,
+             tsdf_frame=torch.rand(1, 1, h, w, generator=g) * 4)
+    sem_ids = torch.randint(0, 30, (h, w), generator=g, dtype=torch.uint8)
+    x['semantic_frame'] = ((1 + sem_ids.float()) / 30).view(1, 1, h, w)
+    with torch.no_grad():
+        ref = net(x)[0].permute(1, 2, 0).reshape(h * w, n_points)
+    eng = FusionNetEngine(net, h, w, cuda, arithmetic=arith)
+    fv = x['tsdf_values'][0].permute(1, 2, 0).reshape(h * w, n_points).contiguous().to(cuda)
+    fw = x['tsdf_weights'][0].permute(1, 2, 0).reshape(h * w, n_points).contiguous().to(cuda)
+    eng.prepare_input(fv, fw, x['tsdf_frame'].reshape(h, w).contiguous().to(cuda), sem_ids.to(cuda) if sem else None, 30)
+    est = torch.empty((h * w, n_points), device=cuda)
+    eng.forward(est)
+    eng.check()
+    err = float((est.cpu() - ref).abs().max())
+    print('net topology', arith, version, sem, n_points, growth, 'max err %.2e' % err)
+    assert err <= TOL, err
+    eng.close()
+
+
+def test_fusion_net_graph_replay(cuda, monkeypatch):
+    """OJF_NET_GRAPH=1 (opt-in): the launch sequence of a forward is captured once per output buffer and replayed;
+    results must be identical to the plain launches, also after the output buffer changes."""
+    h, w = 60, 80
+    net = seeded_net('v3', False, h, w)
+    x = _inputs(h, w)
+
+    def run(env):
+        if env:
+            monkeypatch.setenv('OJF_NET_GRAPH', '1')
+        else:
+            monkeypatch.delenv('OJF_NET_GRAPH', raising=False)
+        eng = FusionNetEngine(net, h, w, cuda)
+        outs = []
+        est_a, est_b = torch.empty((h * w, 9), device=cuda), torch.empty((h * w, 12), device=cuda)
+        for est in (est_a, est_a, est_b, est_a):
+            fv = x['tsdf_values'][0].permute(1, 2, 0).reshape(h * w, 9).contiguous().to(cuda)
+            fw = x['tsdf_weights'][0].permute(1, 2, 0).reshape(h * w, 9).contiguous().to(cuda)
+            eng.prepare_input(fv, fw, x['tsdf_frame'].reshape(h, w).contiguous().to(cuda), None, 0)
+            eng.forward(est)
+            outs.append(est[:, :9].clone().cpu())
+        eng.check()
+        eng.close()
+        return outs
+
+    plain, graph = run(False), run(True)
+    for a, b in zip(plain, graph):
+        assert torch.equal(a, b)
