@@ -41,7 +41,10 @@ def _host_pose_batch(batch, device):
 
 
 def _loader(dataset, scenes, shuffle=False):
-    idx = [i for i in range(len(dataset)) if dataset.scenes[i // dataset.frames_per_scene] in scenes]
+    if hasattr(dataset, 'scene_of_item'):  # Replica / ScanNet adapters
+        idx = [i for i in range(len(dataset)) if dataset.scene_of_item(i) in scenes]
+    else:
+        idx = [i for i in range(len(dataset)) if dataset.scenes[i // dataset.frames_per_scene] in scenes]
     return torch.utils.data.DataLoader(torch.utils.data.Subset(dataset, idx), batch_size=1, shuffle=shuffle)
 
 
@@ -134,6 +137,37 @@ def _training_defaults(config):
     return config
 
 
+def get_data_config(config, mode):
+    """utils/setup.py:28-70: the flat per-split config the dataset classes read."""
+    import copy
+    from .config import AttrDict
+    from .datasets import ToTensor
+    d = AttrDict(copy.deepcopy(dict(config.DATA)))
+    d.device = config.SETTINGS.device
+    d.implementation = config.SETTINGS.get('implementation', None)
+    d.mode = mode
+    if mode == 'train':
+        d.scene_list, d.frame_ratio = d.train_scene_list, config.TRAINING.train_ratio
+    elif mode == 'val':
+        d.scene_list, d.frame_ratio = d.val_scene_list, config.TRAINING.val_ratio
+    else:
+        d.scene_list, d.frame_ratio = d.test_scene_list, config.TESTING.test_ratio
+    for key, default in (('fusion_strategy', None), ('data_load_strategy', None), ('intensity_grad', False)):
+        d.setdefault(key, default)
+    d.n_classes = config.get('SEMANTIC_2D_MODEL', {}).get('n_classes', None)
+    d.augmentations = None  # photometric / geometric augmentations of the 2-D segmentation training are out of scope
+    d.transform = ToTensor()
+    return d
+
+
+def get_data(name, data_config):
+    """utils/setup.py:73-77: ``DATA.dataset`` -> dataset object (``Replica`` | ``ScanNet``)."""
+    from . import datasets
+    if name not in ('Replica', 'ScanNet'):
+        raise ValueError('unknown dataset {!r} (Replica | ScanNet)'.format(name))
+    return getattr(datasets, name)(data_config)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('mode', choices=['train', 'test'])
@@ -152,8 +186,11 @@ def main():
     config.SETTINGS.device = str(device)
     config = _training_defaults(config)
     n_scenes = args.scenes or world
-    dataset = SyntheticDataset(config.DATA.resy, config.DATA.resx, args.grid, args.frames,
-                               scenes=['room_%d' % i for i in range(n_scenes)])
+    if config.DATA.get('dataset', 'synthetic') in ('Replica', 'ScanNet'):  # real data in the reference's layout
+        dataset = get_data(config.DATA.dataset, get_data_config(config, args.mode))
+    else:
+        dataset = SyntheticDataset(config.DATA.resy, config.DATA.resx, args.grid, args.frames,
+                                   scenes=['room_%d' % i for i in range(n_scenes)])
     if args.mode == 'test':
         state = torch.load(args.checkpoint, map_location='cpu')['model_state'] if args.checkpoint else None
         test_fusion(config, dataset, device, rank, world, state)

@@ -1,0 +1,244 @@
+"""CPU: the Replica / ScanNet adapters (datasets.py) on synthetic scenes written to disk in the reference's
+layouts.  OpenCV / h5py are not in the image, so the reference classes cannot produce golden samples (parity
+unpinned, see datasets.py); what is checked is every documented convention: list-file columns, frame order, BGR
+channel order and normalisation constants, OpenCV's nearest-neighbour index rule, millimetre depth, masks, the
+Replica pose round trip and square-frame intrinsics, ScanNet's intrinsics scaling and label mapping, grid
+truncation / padding / bounding box."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from online_joint_depthfusion_and_semantic_amd import datasets
+from online_joint_depthfusion_and_semantic_amd.config import AttrDict
+from online_joint_depthfusion_and_semantic_amd.synthetic import SyntheticStream, gt_volumes, grid_spec
+
+PIL = pytest.importorskip('PIL.Image')
+
+
+def _write_png16(path, metres):
+    PIL.fromarray(np.round(metres * 1000.0).astype(np.uint16)).save(path)
+
+
+def _write_rgb(path, bgr):
+    PIL.fromarray(bgr[:, :, ::-1].astype(np.uint8)).save(path)
+
+
+def _replica_tree(root, st, n):
+    scene, traj = st.scene, '1'
+    dirs = {m: os.path.join(root, scene, traj, m) for m in
+            ('left_rgb', 'left_depth_gt', 'left_depth_noise_5.0', 'left_camera_matrix', 'left_class30')}
+    for d in dirs.values():
+        os.makedirs(d)
+    frames = []
+    rng = np.random.default_rng(0)
+    for i in range(n):
+        f = st.frame(i)
+        bgr = rng.integers(0, 256, size=(st.h, st.w, 3), dtype=np.uint8)
+        f['bgr'] = bgr
+        _write_rgb(os.path.join(dirs['left_rgb'], '%d.png' % i), bgr)
+        _write_png16(os.path.join(dirs['left_depth_gt'], '%d.png' % i), f['depth_gt'])
+        _write_png16(os.path.join(dirs['left_depth_noise_5.0'], '%d.png' % i), f['tof_depth'])
+        np.savetxt(os.path.join(dirs['left_camera_matrix'], '%d.txt' % i), datasets.Replica.file_from_pose(f['extrinsics']))
+        sem = np.repeat(f['semantic_gt'][:, :, None], 3, axis=2)
+        PIL.fromarray(sem).save(os.path.join(dirs['left_class30'], '%d.png' % i))
+        frames.append(f)
+    with open(os.path.join(root, 'list.txt'), 'w') as fp:
+        fp.write(' '.join('{}/{}/{}'.format(scene, traj, m) for m in
+                          ('left_depth_gt', 'left_depth_noise_5.0', 'left_rgb', 'left_camera_matrix', 'left_class30')) + '\n')
+    return frames
+
+
+def _cfg(root, h, w, **kw):
+    base = dict(root_dir=root, resy=h, resx=w, pad=0, augmentations=None, normalize=False, transform=None, frame_ratio=1,
+                scene_list=os.path.join(root, 'list.txt'), input='tof_depth', target='depth_gt', semantics='class30',
+                mode='test', intensity_grad=False, truncation_strategy='standard', fusion_strategy='routingNet',
+                data_load_strategy='max_depth_diversity')
+    base.update(kw)
+    return AttrDict(base)
+
+
+def test_opencv_nearest_rule():
+    img = np.arange(7 * 5).reshape(7, 5)
+    out = datasets.resize_nearest(img, 3, 4)  # cv2: src = min(floor(dst * src / dst_size), src - 1)
+    assert out.tolist() == [[img[int(np.floor(y * 7 / 4)), int(np.floor(x * 5 / 3))] for x in range(3)] for y in range(4)]
+    assert datasets.resize_nearest(img, 5, 7).tolist() == img.tolist()
+    up = datasets.resize_nearest(img, 10, 14)
+    assert up[13, 9] == img[6, 4] and up[1, 1] == img[0, 0]
+
+
+def test_replica_samples(tmp_path):
+    h = w = 64
+    st = SyntheticStream(h, w, 32, 12)
+    frames = _replica_tree(str(tmp_path), st, 4)
+    ds = datasets.Replica(_cfg(str(tmp_path), h, w))
+    assert len(ds) == 4 and ds.scenes == [st.scene]
+    for i, f in enumerate(frames):
+        s = ds[i]
+        assert s['frame_id'] == '{}/1/{}'.format(st.scene, i) and s['item_id'] == i
+        assert s['image'].dtype == np.float32 and np.array_equal(s['image'], f['bgr'].astype(np.float32))  # BGR, as cv2
+        mm = np.round(f['tof_depth'] * 1000.0) / 1000.0
+        assert s['tof_depth'].dtype == np.float32 and np.array_equal(s['tof_depth'], mm.astype(np.float32))
+        assert np.array_equal(s['depth_gt'], (np.round(f['depth_gt'] * 1000.0) / 1000.0).astype(np.float32))
+        assert s['mask'].dtype == bool and np.array_equal(s['mask'], (mm > 0.05) & (mm < 5.0))
+        assert s['semantic_gt'].dtype == np.uint8 and np.array_equal(s['semantic_gt'], f['semantic_gt'])
+        assert s['extrinsics'].shape == (3, 4)
+        np.testing.assert_allclose(s['extrinsics'], f['extrinsics'], atol=2e-6)  # float32 steps inside the conversion
+        np.testing.assert_allclose(s['intrinsics'], f['intrinsics'], atol=1e-12)   # square frame, 90 degree fov
+    # normalisation constants are per BGR channel
+    s = datasets.Replica(_cfg(str(tmp_path), h, w, normalize=True))[0]
+    want = (frames[0]['bgr'] - np.array(datasets.REPLICA_BGR_MEAN)) / np.array(datasets.REPLICA_BGR_STD)
+    np.testing.assert_allclose(s['image'], want.astype(np.float32))
+    # frame_ratio and a down-scaled read
+    ds2 = datasets.Replica(_cfg(str(tmp_path), 32, 32, frame_ratio=2, semantics=None, target=None))
+    assert [ds2[i]['frame_id'].split('/')[-1] for i in range(len(ds2))] == ['0', '2']
+    assert np.array_equal(ds2[0]['tof_depth'], datasets.resize_nearest(np.round(frames[0]['tof_depth'] * 1000.0), 32, 32)
+                          .astype(np.float64).__truediv__(1000.0).astype(np.float32))
+    assert abs(ds2[0]['intrinsics'][0, 0] - 16.0) < 1e-12 and 'semantic_gt' not in ds2[0]  # rows/2 / tan(45 deg)
+
+
+def test_replica_pose_convention():
+    # a Replica camera file stores a world-to-camera matrix in an x-right / y-up / z-backward, z-up-world
+    # convention; the loader must hand out camera-to-world with z forward, y down (replica.py:266-279)
+    rng = np.random.default_rng(3)
+    for _ in range(5):
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        q *= np.sign(np.linalg.det(q))
+        pose = np.concatenate([q, rng.normal(size=(3, 1))], axis=1)
+        back = datasets.Replica.pose_from_file(datasets.Replica.file_from_pose(pose))
+        np.testing.assert_allclose(back, pose, atol=5e-6)
+    ident = datasets.Replica.pose_from_file(np.eye(4))  # camera at the origin looking down its own -z
+    np.testing.assert_allclose(ident[:, 2], [0, 1, 0], atol=1e-7)   # viewing direction: world +y after the 90 degree turn
+    np.testing.assert_allclose(ident[:, 3], [0, 0, 0], atol=1e-7)
+
+
+def test_replica_batches_and_grid(tmp_path):
+    h = w = 64
+    grid = 32
+    st = SyntheticStream(h, w, grid, 12)
+    _replica_tree(str(tmp_path), st, 3)
+    tsdf, labels = gt_volumes(grid, 0.1)
+    origin, res, bbox = grid_spec(grid)
+    datasets.export_grid_npz(os.path.join(str(tmp_path), st.scene, 'gt_semantic_sdf', 'semantic_sdf.hdf'),
+                             tsdf.astype(np.float32) * 3.0, bbox, res, labels)  # x3: the loader must truncate
+    ds = datasets.Replica(_cfg(str(tmp_path), h, w, transform=datasets.ToTensor(), pad=2))
+    batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=1)))
+    assert batch['image'].shape == (1, 3, h, w) and batch['tof_depth'].shape == (1, h, w)
+    assert batch['mask'].dtype == torch.bool and batch['extrinsics'].shape == (1, 3, 4)
+    assert batch['intrinsics'].dtype == torch.float64 and batch['frame_id'] == ['{}/1/0'.format(st.scene)]
+    g, s = ds.get_grid(st.scene, 0.1, True)
+    assert g.volume.shape == (grid + 4,) * 3 and g.volume.dtype == np.float16
+    assert float(np.abs(g.volume.astype(np.float32)).max()) <= 0.1 + 1e-3
+    assert np.all(g.volume[:2] == np.float16(-0.1))                       # padding value is -truncation
+    np.testing.assert_allclose(g.bbox[:, 0], bbox[:, 0] - 2 * res)
+    np.testing.assert_allclose(g.bbox[:, 1], g.bbox[:, 0] + res * (grid + 4))
+    assert s.volume.dtype == np.uint8 and np.all(s.volume[:2] == 0)
+    inner = s.volume[2:-2, 2:-2, 2:-2]
+    assert np.array_equal(inner, labels)  # truncated values never exceed the band, so no label is reset here
+
+
+def test_scannet_samples(tmp_path):
+    root = str(tmp_path)
+    h, w = 48, 64
+    st = SyntheticStream(h, w, 32, 12)
+    scene = 'scene0000_00'
+    base = os.path.join(root, 'scans', scene)
+    for m in ('color', 'depth', 'pose', 'label-filt'):
+        os.makedirs(os.path.join(base, m))
+    k_file = np.array([[577.6, 0, 318.9, 0], [0, 578.7, 242.7, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    np.savetxt(os.path.join(base, 'intrinsic_depth.txt'), k_file)
+    frames = []
+    rng = np.random.default_rng(1)
+    for i in range(3):
+        f = st.frame(i)
+        bgr = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        f['bgr'] = bgr
+        _write_rgb(os.path.join(base, 'color', '%d.png' % (10 * i)), bgr)
+        _write_png16(os.path.join(base, 'depth', '%d.png' % (10 * i)), f['tof_depth'])
+        pose = np.concatenate([f['extrinsics'], [[0, 0, 0, 1]]], axis=0)
+        np.savetxt(os.path.join(base, 'pose', '%d.txt' % (10 * i)), pose)
+        raw = (f['semantic_gt'].astype(np.uint16) % 4) + 1   # raw ScanNet ids 1..4
+        f['raw'] = raw
+        PIL.fromarray(raw.astype(np.uint16)).save(os.path.join(base, 'label-filt', '%d.png' % (10 * i)))
+        frames.append(f)
+    with open(os.path.join(root, 'list.txt'), 'w') as fp:
+        fp.write(' '.join('scans/{}/{}'.format(scene, m) for m in ('depth', 'color', 'label-filt', 'pose')) +
+                 ' scans/{}\n'.format(scene))
+    with open(os.path.join(root, 'scannetv2-labels.combined.tsv'), 'w') as fp:
+        fp.write('id\traw_category\tcategory\tcount\tnyu40id\n')
+        for raw_id, nyu in ((1, 1), (2, 13), (3, 39), (4, 40)):
+            fp.write('%d\tx\tx\t1\t%d\n' % (raw_id, nyu))
+    cfg = _cfg(root, h, w, input='depth_gt', target='depth_gt', semantics='nyu40')
+    ds = datasets.ScanNet(cfg)
+    assert len(ds) == 3 and ds.scenes == [scene]
+    kx, ky = w / 640, h / 480
+    want_k = np.array([[kx, 0, kx], [0, ky, ky], [0, 0, 1]], dtype=np.float32) @ k_file[:3, :3]
+    for i, f in enumerate(frames):
+        s = ds[i]
+        assert s['frame_id'] == '{}/{}'.format(scene, 10 * i)
+        assert np.array_equal(s['image'], f['bgr'].astype(np.float32))
+        mm = np.round(f['tof_depth'] * 1000.0) / 1000.0
+        assert np.array_equal(s['depth_gt'], mm.astype(np.float32)) and np.array_equal(s['mask'], mm > 0.01)
+        assert s['extrinsics'].shape == (4, 4) and s['extrinsics'].dtype == np.float32
+        np.testing.assert_allclose(s['extrinsics'][:3], f['extrinsics'], atol=1e-6)
+        np.testing.assert_allclose(s['intrinsics'], want_k)
+        nyu40 = np.array([0, 1, 13, 39, 40])[f['raw']]
+        assert np.array_equal(s['semantic_gt'], nyu40.astype(np.uint8))
+    ds20 = datasets.ScanNet(_cfg(root, h, w, input='depth_gt', target=None, semantics='nyu20'))
+    idx20 = {1: 1, 13: 0, 39: 20, 40: 0}  # 13 and 40 are outside the 21-class benchmark subset
+    want = np.vectorize(lambda r: idx20[{1: 1, 2: 13, 3: 39, 4: 40}[int(r)]])(frames[0]['raw'])
+    assert np.array_equal(ds20[0]['semantic_gt'], want.astype(np.uint8))
+
+
+def test_hybrid_order_is_a_permutation(tmp_path):
+    h = w = 32
+    root = str(tmp_path)
+    names = []
+    lines = []
+    for sc in ('room_0', 'room_1', 'office_0'):
+        for traj in ('1', '2', '3'):
+            for m in ('left_rgb', 'left_depth_gt', 'left_depth_noise_5.0', 'left_camera_matrix'):
+                os.makedirs(os.path.join(root, sc, traj, m))
+            for i in range(2):
+                _write_rgb(os.path.join(root, sc, traj, 'left_rgb', '%d.png' % i), np.zeros((h, w, 3), np.uint8))
+                _write_png16(os.path.join(root, sc, traj, 'left_depth_noise_5.0', '%d.png' % i), np.ones((h, w)))
+                _write_png16(os.path.join(root, sc, traj, 'left_depth_gt', '%d.png' % i), np.ones((h, w)))
+                np.savetxt(os.path.join(root, sc, traj, 'left_camera_matrix', '%d.txt' % i), np.eye(4))
+                names.append('{}/{}/{}'.format(sc, traj, i))
+            lines.append(' '.join('{}/{}/{}'.format(sc, traj, m) for m in
+                                  ('left_depth_gt', 'left_depth_noise_5.0', 'left_rgb', 'left_camera_matrix')))
+    with open(os.path.join(root, 'list.txt'), 'w') as fp:
+        fp.write('\n'.join(lines) + '\n')
+    ds = datasets.Replica(_cfg(root, h, w, semantics=None, target=None, mode='train', scene_list='list.txt',
+                               data_load_strategy='hybrid', load_scenes_at_once=2))
+    got = [ds[i]['frame_id'] for i in range(len(ds))]
+    assert sorted(got) == sorted(names) and sorted(ds.scenes) == ['office_0', 'room_0', 'room_1']
+    # depth / colour / camera lists stay aligned frame by frame
+    assert [p.replace('left_rgb', 'X').rsplit('.', 1)[0] for p in ds.color_images] == \
+           [p.replace('left_depth_noise_5.0', 'X').rsplit('.', 1)[0] for p in ds.depth_images]
+
+
+def test_driver_data_config(tmp_path):
+    """drivers.get_data_config / get_data (utils/setup.py:28-77) pick the split's list and frame ratio."""
+    from online_joint_depthfusion_and_semantic_amd import drivers
+    from online_joint_depthfusion_and_semantic_amd.config import default_config
+    h = w = 64
+    st = SyntheticStream(h, w, 32, 12)
+    _replica_tree(str(tmp_path), st, 4)
+    cfg = default_config(h, w, semantics=True)
+    cfg.DATA.update(dataset='Replica', root_dir=str(tmp_path), train_scene_list=os.path.join(str(tmp_path), 'list.txt'),
+                    val_scene_list=os.path.join(str(tmp_path), 'list.txt'), test_scene_list=os.path.join(str(tmp_path), 'list.txt'),
+                    normalize=False, truncation_strategy='standard')
+    cfg.TRAINING.update(train_ratio=1, val_ratio=2)
+    cfg.TESTING.update(test_ratio=3)
+    ds = drivers.get_data('Replica', drivers.get_data_config(cfg, 'test'))
+    assert len(ds) == 2 and [ds.scene_of_item(i) for i in range(2)] == [st.scene] * 2
+    s = ds[1]
+    assert s['frame_id'].endswith('/3') and torch.is_tensor(s['tof_depth']) and s['image'].shape == (3, h, w)
+    assert len(drivers.get_data('Replica', drivers.get_data_config(cfg, 'val'))) == 2
+    assert len(drivers.get_data('Replica', drivers.get_data_config(cfg, 'train'))) == 4
+    loader = drivers._loader(ds, [st.scene])
+    assert len(loader) == 2 and len(drivers._loader(ds, ['other'])) == 0
+    with pytest.raises(ValueError):
+        drivers.get_data('KITTI', drivers.get_data_config(cfg, 'test'))
