@@ -198,7 +198,7 @@ def test_hybrid_order_is_a_permutation(tmp_path):
     lines = []
     for sc in ('room_0', 'room_1', 'office_0'):
         for traj in ('1', '2', '3'):
-            for m in ('left_rgb', 'left_depth_gt', 'left_depth_noise_5.0', 'left_camera_matrix'):
+            for m in ('left_rgb', 'left_depth_gt', 'left_depth_noise_5.0', 'left_camera_matrix', 'left_class30'):
                 os.makedirs(os.path.join(root, sc, traj, m))
             for i in range(2):
                 _write_rgb(os.path.join(root, sc, traj, 'left_rgb', '%d.png' % i), np.zeros((h, w, 3), np.uint8))
@@ -207,7 +207,7 @@ def test_hybrid_order_is_a_permutation(tmp_path):
                 np.savetxt(os.path.join(root, sc, traj, 'left_camera_matrix', '%d.txt' % i), np.eye(4))
                 names.append('{}/{}/{}'.format(sc, traj, i))
             lines.append(' '.join('{}/{}/{}'.format(sc, traj, m) for m in
-                                  ('left_depth_gt', 'left_depth_noise_5.0', 'left_rgb', 'left_camera_matrix')))
+                                  ('left_depth_gt', 'left_depth_noise_5.0', 'left_rgb', 'left_camera_matrix', 'left_class30')))
     with open(os.path.join(root, 'list.txt'), 'w') as fp:
         fp.write('\n'.join(lines) + '\n')
     ds = datasets.Replica(_cfg(root, h, w, semantics=None, target=None, mode='train', scene_list='list.txt',

@@ -28,3 +28,63 @@ def test_train_then_test_round_trip(cuda, tmp_path):
     results, per_scene, db2 = run_test_fusion(cfg, ds, cuda, state_dict=ck['model_state'], log=lambda *a: None)
     assert set(results) == {'mse', 'mad', 'iou', 'acc'} and all(np.isfinite(v) for v in results.values())
     assert set(per_scene) == {'room_0', 'room_1'}
+
+
+def test_test_fusion_on_a_replica_layout(cuda, tmp_path):
+    """The Replica adapter (datasets.py) feeding the test driver end to end: frames written to disk in the
+    reference's layout (16-bit millimetre depth, camera-matrix files, npz GT grid) are fused and evaluated; the
+    result must equal fusing the same decoded samples through ``Pipeline.fuse`` directly."""
+    PIL = pytest.importorskip('PIL.Image')
+    from online_joint_depthfusion_and_semantic_amd import datasets, drivers
+    from online_joint_depthfusion_and_semantic_amd.config import database_config
+    from online_joint_depthfusion_and_semantic_amd.database import Database
+    from online_joint_depthfusion_and_semantic_amd.pipeline import Pipeline
+    from online_joint_depthfusion_and_semantic_amd.synthetic import SyntheticStream, gt_volumes, grid_spec
+    h = w = 64
+    grid, n = 64, 6
+    root = str(tmp_path)
+    st = SyntheticStream(h, w, grid, 12)
+    # the list format always carries five columns: [0] GT depth, [1] ToF depth, [-3] colour, [-2] cameras, [-1] semantics
+    mods = ('left_depth_gt', 'left_depth_noise_5.0', 'left_rgb', 'left_camera_matrix', 'left_class30')
+    for m in mods:
+        os.makedirs(os.path.join(root, st.scene, '1', m))
+    for i in range(n):
+        f = st.frame(i)
+        PIL.fromarray(np.zeros((h, w, 3), np.uint8)).save(os.path.join(root, st.scene, '1', 'left_rgb', '%d.png' % i))
+        for m, key in (('left_depth_gt', 'depth_gt'), ('left_depth_noise_5.0', 'tof_depth')):
+            PIL.fromarray(np.round(f[key] * 1000.0).astype(np.uint16)).save(os.path.join(root, st.scene, '1', m, '%d.png' % i))
+        np.savetxt(os.path.join(root, st.scene, '1', 'left_camera_matrix', '%d.txt' % i),
+                   datasets.Replica.file_from_pose(f['extrinsics']))
+    with open(os.path.join(root, 'list.txt'), 'w') as fp:
+        fp.write(' '.join('{}/1/{}'.format(st.scene, m) for m in mods) + '\n')
+    tsdf, _ = gt_volumes(grid, 0.1)
+    _, res, bbox = grid_spec(grid)
+    datasets.export_grid_npz(os.path.join(root, st.scene, 'gt_semantic_sdf', 'sdf.hdf'), tsdf.astype(np.float32), bbox, res)
+
+    config = _training_defaults(default_config(h, w))
+    config.SETTINGS.device = str(cuda)
+    lst = os.path.join(root, 'list.txt')
+    config.DATA.update(dataset='Replica', root_dir=root, train_scene_list=lst, val_scene_list=lst, test_scene_list=lst,
+                       normalize=False, truncation_strategy='standard')
+    config.TESTING.test_ratio = 1
+    ds = drivers.get_data('Replica', drivers.get_data_config(config, 'test'))
+    torch.manual_seed(5)
+    state = Pipeline(config)._fusion_network.state_dict()
+    results, per_scene, db = run_test_fusion(config, ds, cuda, state_dict=state, log=lambda *a: None)
+    assert set(results) >= {'iou', 'acc', 'mse', 'mad'} and all(np.isfinite(v) for v in results.values())
+
+    pipe = Pipeline(config)
+    pipe._fusion_network.load_state_dict(state)
+    pipe = pipe.to(cuda).eval()
+    db2 = Database(ds, database_config(config))
+    with torch.no_grad():
+        for i in range(len(ds)):
+            s = ds[i]
+            batch = {k: (v.unsqueeze(0) if torch.is_tensor(v) else [v]) for k, v in s.items()}
+            batch = {k: (v.to(cuda) if torch.is_tensor(v) and k not in ('extrinsics', 'intrinsics') else v) for k, v in batch.items()}
+            pipe.fuse(batch, db2, cuda)
+    pipe.check()
+    db2.filter(value=config.TESTING.outlier_filter_val)
+    a, b = db.scenes_est[st.scene].volume, db2.scenes_est[st.scene].volume
+    assert torch.equal(torch.as_tensor(a).cpu().view(torch.int16), torch.as_tensor(b).cpu().view(torch.int16))
+    assert int((torch.as_tensor(db.fusion_weights[st.scene]).float() > 0).sum()) > 1000
