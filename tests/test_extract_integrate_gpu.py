@@ -230,3 +230,40 @@ def test_extract_sample_plane_layout(cuda):
     assert pl['fusion_values'].shape == (9, 24 * 32)
     assert torch.equal(pl['fusion_values'].t().contiguous(), rows['fusion_values'])
     assert torch.equal(pl['fusion_weights'].t().contiguous(), rows['fusion_weights'])
+
+
+@pytest.mark.parametrize('h,w,n_points', [(13, 15, 9), (13, 15, 1), (13, 15, 17), (7, 9, 5)])
+def test_extract_ragged_sizes_and_sample_counts(cuda, h, w, n_points):
+    """Frames whose pixel count is not a multiple of the 64-pixel block, and ray sample counts on both sides of
+    the tile kernel's limit (16; above it the one-lane-per-item kernel runs): bit-exact like the rest."""
+    st = make_stream(h, w, 32)
+    rng = np.random.default_rng(9)
+    tsdf = rng.uniform(-0.1, 0.1, (32,) * 3).astype(np.float16)
+    wgt = rng.uniform(0, 6, (32,) * 3).astype(np.float16)
+    fi = frame_inputs(st, 1)
+    fi['depth'][2, 3] = 0.0
+    ref = oracle.extract(fi['depth'], fi['Ki'], fi['E'], st.origin, st.resolution, tsdf, wgt, n_points=n_points, debug=True)
+    out = ops.extract(_t(fi['depth'], cuda), fi['Ki'], fi['E'], st.origin, st.resolution, _t(tsdf, cuda), _t(wgt, cuda),
+                      n_points=n_points, debug=True)
+    for key in ref:
+        assert n_mismatch(out[key].cpu().numpy(), ref[key]) == 0, key
+    assert out['fusion_values'].shape[-1] == n_points
+
+
+def test_integrate_ragged_frame(cuda):
+    """A frame that ends inside a 64-pixel block and inside 8x8 tiles on both axes (13x15)."""
+    h, w, grid = 13, 15, 32
+    st = make_stream(h, w, grid)
+    vols = fresh_volumes(grid, False)
+    ws = {m: ops.IntegrateWorkspace((grid,) * 3, h, w, 7, m, cuda) for m in (ops.MODE_FAST, ops.MODE_PARITY)}
+    for mode in (ops.MODE_PARITY, ops.MODE_FAST):
+        ref = {k: v.copy() for k, v in vols.items()}
+        g = to_cuda(vols, cuda)
+        for i in range(3):
+            fi = frame_inputs(st, i)
+            touched = _oracle_integrate(st, fi, ref, False)
+            _run_integrate(st, fi, g, ws[mode], mode, False, cuda)
+            assert int(ws[mode].stats[0].item()) == touched
+        for key in ref:
+            ulp = f16_ulp_distance(g[key].cpu().numpy(), ref[key])
+            assert ulp.max() <= (0 if mode == ops.MODE_PARITY else 1), (mode, key)
