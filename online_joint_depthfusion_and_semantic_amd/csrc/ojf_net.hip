@@ -130,7 +130,8 @@ constexpr int kPadSteps = 4;    // dead supersteps appended for the three-stage 
 
 // C/D layout of the 16x16 MFMAs: lane (i16, g) holds column i16 (pixel) and rows 4g..4g+3 (output channels)
 template <int MT, int NT, bool GUARD = false>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x4 (&acc)[MT][NT], int strip, int i16, int g)
+__device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x4 (&acc)[MT][NT], int strip, int i16, int g,
+                                              const f32x4 (&bvec)[NT], const f32x4 (&rvec)[NT])
 {
     const float slope = act_slope(a.act);
     const bool use_tanh = a.act == OJF_ACT_TANH;
@@ -138,9 +139,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x4 (&a
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int og = n * 4 + g;  // output channel group
-        const f32x4 b = *reinterpret_cast<const f32x4 *>(a.bias + (size_t)n * 16 + 4 * g);
-        f32x4 ri{1.f, 1.f, 1.f, 1.f};
-        if constexpr (GUARD) ri = *reinterpret_cast<const f32x4 *>(a.rinv + (size_t)n * 16 + 4 * g);
+        const f32x4 b = bvec[n];
+        const f32x4 ri = rvec[n];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int p = strip + m * 16 + i16;
@@ -318,7 +318,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGroup grp)
         if (!SKIP || l2) mac(x2, w2);
     }
 
-    conv_epilogue<MT, NT>(a, acc, strip, i16, g);
+    f32x4 bvec[NT], rvec[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        bvec[n] = *reinterpret_cast<const f32x4 *>(a.bias + (size_t)n * 16 + 4 * g);
+        rvec[n] = f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+    conv_epilogue<MT, NT>(a, acc, strip, i16, g, bvec, rvec);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -372,6 +378,17 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const ConvGroup grp)
         for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<f32x4 *>(a.in), 0, (a.in_g0 + a.c4) * a.npix * 16, 0x00020000);
+    // bias and inverse row scale of the epilogue: for the narrow layers they are fetched here, so that their latency
+    // hides behind the main loop (the wide ones cannot afford the registers: 268 VGPRs at NT = 8)
+    constexpr bool kHoist = NT <= 4;
+    f32x4 bvec[NT], rvec[NT];
+    if constexpr (kHoist) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            bvec[n] = *reinterpret_cast<const f32x4 *>(a.bias + (size_t)n * 16 + 4 * g);
+            rvec[n] = *reinterpret_cast<const f32x4 *>(a.rinv + (size_t)n * 16 + 4 * g);
+        }
+    }
 
     // Operand fetch of superstep S: two (tap, channel group) entries per lane group.  The 9 taps' in-image tests
     // are one bit each in vm[] (computed once per wave), so an entry costs and + compare + add + select; buffer
@@ -454,7 +471,14 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const ConvGroup grp)
         if (!SKIP || v2) mac(xa2, xb2, sl + 2);
         sl += 3;
     }
-    conv_epilogue<MT, NT, true>(a, acc, strip, i16, g);
+    if constexpr (!kHoist) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            bvec[n] = *reinterpret_cast<const f32x4 *>(a.bias + (size_t)n * 16 + 4 * g);
+            rvec[n] = *reinterpret_cast<const f32x4 *>(a.rinv + (size_t)n * 16 + 4 * g);
+        }
+    }
+    conv_epilogue<MT, NT, true>(a, acc, strip, i16, g, bvec, rvec);
 }
 
 // ------------------------------------------------------------------------------------------------
