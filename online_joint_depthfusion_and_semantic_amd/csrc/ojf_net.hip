@@ -849,31 +849,38 @@ struct PyramidArgs {
 
 constexpr int kPoolTW = 32, kPoolTH = 8, kPoolStride = kPoolTW + 6;
 
-__global__ __launch_bounds__(256) void pool_pyramid_kernel(const PyramidArgs a)
+// LV = pooling levels of this block's channel group: region sizes are compile-time (the per-element index
+// divisions become multiplies)
+template <int LV>
+__device__ __forceinline__ void pool_pyramid_body(const PyramidArgs &a, f32x4 (&buf)[2][kPoolStride * (kPoolTH + 6)], int cg)
 {
-    __shared__ f32x4 buf[2][kPoolStride * (kPoolTH + 6)];
-    const int lv = blockIdx.y / a.c4 + 1, cg = blockIdx.y - (lv - 1) * a.c4;  // levels of this block's group
     const int tiles_x = (a.w + kPoolTW - 1) / kPoolTW;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int x0 = tx * kPoolTW, y0 = ty * kPoolTH, npix = a.h * a.w;
-    const f32x4 *plane = a.z + (size_t)(lv * a.c4 + cg) * npix;
+    const f32x4 *plane = a.z + (size_t)(LV * a.c4 + cg) * npix;
     const f32x4 zero{0.f, 0.f, 0.f, 0.f};
     {
-        const int W0 = kPoolTW + 2 * lv, H0 = kPoolTH + 2 * lv;
-        for (int i = threadIdx.x; i < W0 * H0; i += 256) {
+        constexpr int W0 = kPoolTW + 2 * LV, H0 = kPoolTH + 2 * LV;
+#pragma unroll
+        for (int i0 = 0; i0 < W0 * H0; i0 += 256) {
+            const int i = i0 + threadIdx.x;
+            if (i >= W0 * H0) break;
             const int ly = i / W0, lx = i - ly * W0;
-            const int gy = y0 - lv + ly, gx = x0 - lv + lx;
+            const int gy = y0 - LV + ly, gx = x0 - LV + lx;
             const bool in = (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
             buf[0][ly * kPoolStride + lx] = in ? plane[gy * a.w + gx] : zero;
         }
     }
     __syncthreads();
-    int cur = 0;
-    for (int l = 1; l <= lv; ++l) {
-        const int halo = lv - l;  // halo of this level's region; the source region has halo + 1
+#pragma unroll
+    for (int l = 1; l <= LV; ++l) {
+        const int halo = LV - l;  // halo of this level's region; the source region has halo + 1
         const int Wl = kPoolTW + 2 * halo, Hl = kPoolTH + 2 * halo;
-        const f32x4 *src = buf[cur];
-        for (int i = threadIdx.x; i < Wl * Hl; i += 256) {
+        const f32x4 *src = buf[(l - 1) & 1];
+#pragma unroll
+        for (int i0 = 0; i0 < Wl * Hl; i0 += 256) {
+            const int i = i0 + threadIdx.x;
+            if (i >= Wl * Hl) break;
             const int ly = i / Wl, lx = i - ly * Wl;
             const int gy = y0 - halo + ly, gx = x0 - halo + lx;
             const bool in = (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
@@ -883,18 +890,26 @@ __global__ __launch_bounds__(256) void pool_pyramid_kernel(const PyramidArgs a)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) s += src[(ly + dy) * kPoolStride + lx + dx];
             s = s / 9.0f;
-            if (l < lv) {
-                buf[cur ^ 1][ly * kPoolStride + lx] = in ? s : zero;
+            if (l < LV) {
+                buf[l & 1][ly * kPoolStride + lx] = in ? s : zero;
             } else if (in) {
-                s += *reinterpret_cast<const f32x4 *>(a.bias[lv - 1] + 4 * cg);
+                s += *reinterpret_cast<const f32x4 *>(a.bias[LV - 1] + 4 * cg);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) s[j] = s[j] > 0.0f ? s[j] : 0.0f;
-                a.q[lv - 1][(size_t)cg * npix + gy * a.w + gx] = s;
+                a.q[LV - 1][(size_t)cg * npix + gy * a.w + gx] = s;
             }
         }
-        __syncthreads();
-        cur ^= 1;
+        if (l < LV) __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(256) void pool_pyramid_kernel(const PyramidArgs a)
+{
+    __shared__ f32x4 buf[2][kPoolStride * (kPoolTH + 6)];
+    const int lv = blockIdx.y / a.c4 + 1, cg = blockIdx.y - (lv - 1) * a.c4;  // levels of this block's group
+    if (lv == 1) pool_pyramid_body<1>(a, buf, cg);
+    else if (lv == 2) pool_pyramid_body<2>(a, buf, cg);
+    else pool_pyramid_body<3>(a, buf, cg);
 }
 
 constexpr int kSumBlocks = 32;
