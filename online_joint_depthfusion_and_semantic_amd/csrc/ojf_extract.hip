@@ -36,23 +36,48 @@ __device__ __forceinline__ void extract_item(const ExtractArgs &a, int n, int k,
     RaySample s;
     ray_sample(cv, dir, k, half, s);
 
-    // issue all 16 gathers before the first use
+    // Gathers.  Corners 2m and 2m+1 share (x, y) and differ by nb.z in {-1, 0, +1} along the contiguous z axis: when
+    // both lie inside the volume ONE (2-byte aligned) 4-byte load per volume fetches the pair, which halves the
+    // number of scattered load instructions (the gathers are 60 % of this kernel).  All loads are issued before
+    // the first use.
     float val[8], wt[8];
     double wq[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        int64_t idx[3];
-        corner(s, q, idx, wq[q]);
-        val[q] = a.pad_value;  // modules/extractor.py:663-664
-        wt[q] = 0.0f;
-        if (in_volume(idx, a.X, a.Y, a.Z)) {
-            const size_t lin = ((size_t)idx[0] * a.Y + (size_t)idx[1]) * a.Z + (size_t)idx[2];
-            val[q] = h2f(a.tsdf[lin]);
-            wt[q] = h2f(a.wgt[lin]);
+    for (int m = 0; m < 4; ++m) {
+        int64_t i0[3], i1[3];
+        corner(s, 2 * m, i0, wq[2 * m]);
+        corner(s, 2 * m + 1, i1, wq[2 * m + 1]);
+        const bool in0 = in_volume(i0, a.X, a.Y, a.Z), in1 = in_volume(i1, a.X, a.Y, a.Z);
+        val[2 * m] = val[2 * m + 1] = a.pad_value;  // modules/extractor.py:663-664
+        wt[2 * m] = wt[2 * m + 1] = 0.0f;
+        const size_t lin0 = ((size_t)i0[0] * a.Y + (size_t)i0[1]) * a.Z + (size_t)i0[2];
+        if (in0 && in1 && i1[2] != i0[2]) {
+            const bool up = i1[2] > i0[2];                   // corner 2m+1 is the upper z neighbour
+            const size_t lo = up ? lin0 : lin0 - 1;
+            unsigned int tv, wv;                              // two fp16 each: [z_lo | z_lo + 1]
+            __builtin_memcpy(&tv, a.tsdf + lo, 4);
+            __builtin_memcpy(&wv, a.wgt + lo, 4);
+            const uint16_t t_lo = (uint16_t)(tv & 0xffffu), t_hi = (uint16_t)(tv >> 16);
+            const uint16_t w_lo = (uint16_t)(wv & 0xffffu), w_hi = (uint16_t)(wv >> 16);
+            val[2 * m] = h2f(up ? t_lo : t_hi);
+            val[2 * m + 1] = h2f(up ? t_hi : t_lo);
+            wt[2 * m] = h2f(up ? w_lo : w_hi);
+            wt[2 * m + 1] = h2f(up ? w_hi : w_lo);
+        } else {
+            if (in0) {
+                val[2 * m] = h2f(a.tsdf[lin0]);
+                wt[2 * m] = h2f(a.wgt[lin0]);
+            }
+            if (in1) {
+                const size_t lin1 = ((size_t)i1[0] * a.Y + (size_t)i1[1]) * a.Z + (size_t)i1[2];
+                val[2 * m + 1] = h2f(a.tsdf[lin1]);
+                wt[2 * m + 1] = h2f(a.wgt[lin1]);
+            }
         }
         if (a.dbg_idx) {
-            int64_t *o = a.dbg_idx + ((size_t)n * a.n_points + k) * 24 + 3 * q;
-            o[0] = idx[0]; o[1] = idx[1]; o[2] = idx[2];
+            int64_t *o = a.dbg_idx + ((size_t)n * a.n_points + k) * 24 + 6 * m;
+            o[0] = i0[0]; o[1] = i0[1]; o[2] = i0[2];
+            o[3] = i1[0]; o[4] = i1[1]; o[5] = i1[2];
         }
     }
     // fp64 products, summed in corner order, rounded once to fp32 (extractor.py:673-681)
