@@ -10,9 +10,11 @@
 //                   x*w ~= wl*xh + wh*xl + wh*xh on v_mfma_f32_16x16x32_f16 (8192 MAC per 16 cycles,
 //                   three of them per product block: 5.3x the fp32-input MFMA rate).  The dropped wl*xl
 //                   term is <= 2^-22 |x w|; measured layer error is below the fp32 chain's
-//                   (tests/microbench/conv_f16x3_bench.hip).  Operands must stay below 65504 in
-//                   magnitude (fp16 range) - true for TSDF values, fp16 volume weights, metric depth and
-//                   the BN-folded activations of a trained net; OJF_ARITH_F32 has no such limit.
+//                   (tests/microbench/conv_f16x3_bench.hip).  Weight rows are equilibrated by powers of two
+//                   (row_scale) so that BN-folded rows of any magnitude keep their mantissa.  Operands must
+//                   stay below 65504 in magnitude (fp16 range) - true for TSDF values, fp16 volume weights,
+//                   metric depth and the BN-folded activations of a trained net; every kernel guards it
+//                   (guard_max, ojf_net_check) and OJF_ARITH_F32 has no such limit.
 //
 // Data layout ("C4 planes"): an activation tensor with C channels (padded to a multiple of 4:
 // 19 -> 20, 114 -> 116; pad channels carry zeros) is stored as C/4 planes of float4, element
@@ -25,12 +27,13 @@
 // A convolution is an implicit GEMM  D[oc, pixel] = sum_K W[oc, K] * X[K, pixel]:
 //   MFMA rows = 16 output channels (A operand = packed weights), MFMA cols = 16 consecutive pixels
 //   (B operand = activations), K = flattened list of (tap, 4-channel group) pairs, G = tap*c4 + cg.
-//   In superstep S lane group g (= lane >> 4) owns group G = 4S + g: it fetches that group's float4 of
-//   ITS tap's source pixel and feeds element j to MFMA j of the superstep; the packed weights use
-//   the same (g, j) permutation.  Any channel count that is a multiple of 4 works without tails,
-//   out-of-image taps contribute zeros, supersteps whose every source pixel is outside the image
-//   are skipped (dilation 9 / 27 near the borders), and the loop is software pipelined (operands of
-//   superstep S+1 in flight while the 4*MT*NT MFMAs of S issue).
+//   fp32: in superstep S lane group g (= lane >> 4) owns group G = 4S + g: it fetches that group's float4 of
+//   ITS tap's source pixel and feeds element j to MFMA j of the superstep; split-fp16: a superstep is one
+//   32-wide K block, lane group g owns groups 8S + 2g and 8S + 2g + 1, splits its 8 values into fp16 halves
+//   and issues 3 MFMAs per output tile.  The packed weights use the same (g, j) permutation.  Any channel count
+//   that is a multiple of 4 works without tails, out-of-image taps contribute zeros, supersteps whose every
+//   source pixel is outside the image are skipped (dilation 9 / 27 near the borders), and the loop is software
+//   pipelined (three operand stages in flight).
 //   The accumulator of lane (pixel i, g) holds output channels 4g..4g+3 of its pixel: the epilogue
 //   adds bias, applies the activation and writes ONE float4 into the output plane.
 //
@@ -39,7 +42,11 @@
 //     run as ONE 1x1 GEMM on x with 4*mid output channels, and the pools run on mid (19) channels
 //     instead of in_chs (114/228);
 //   * the global-average branch is constant over the image: it is reduced to a per-frame bias of
-//     the final 1x1 convolution (two tiny kernels), removing its 114 input columns from that GEMM.
+//     the final 1x1 convolution (two tiny kernels on a side stream), removing its 114 input columns from that GEMM.
+// Launches of one forward pass (geometry-only v3): 10 dense-block convolutions, per VortexPooling {branch-entry
+// GEMM, pool pyramid, two grouped launches of the four branches' dilated 3x3, fused tail}; the last tail also runs
+// the 11-layer prediction head: 22 launches on the main stream.  Environment switches (tuning / ablation only):
+// OJF_CONV_MT, OJF_NO_TAIL, OJF_NO_CHAIN, OJF_NO_HEAD_FUSION, OJF_NET_GRAPH=1 (opt-in hipGraph replay).
 #include <cmath>
 #include <cstdlib>
 #include <vector>
