@@ -37,7 +37,8 @@ def seeded_net(version, sem, h, w, seed=0):
 @pytest.mark.parametrize('cin,cout,k,dil,act', [
     (19, 19, 3, 1, _lib.ACT_LEAKY), (38, 19, 3, 1, _lib.ACT_LEAKY), (19, 19, 3, 3, _lib.ACT_RELU),
     (19, 19, 3, 9, _lib.ACT_RELU), (19, 19, 3, 27, _lib.ACT_RELU), (114, 95, 1, 1, _lib.ACT_LEAKY),
-    (19, 114, 1, 1, _lib.ACT_RELU), (228, 19, 1, 1, _lib.ACT_NONE), (19, 9, 1, 1, _lib.ACT_TANH), (64, 48, 3, 2, _lib.ACT_NONE)])
+    (19, 114, 1, 1, _lib.ACT_RELU), (228, 19, 1, 1, _lib.ACT_NONE), (19, 9, 1, 1, _lib.ACT_TANH), (64, 48, 3, 2, _lib.ACT_NONE),
+    (57, 19, 3, 1, _lib.ACT_LEAKY), (95, 19, 3, 1, _lib.ACT_LEAKY), (32, 32, 3, 1, _lib.ACT_RELU)])  # LDS-tiled 3x3 (wide inputs)
 @pytest.mark.parametrize('h,w', [(24, 32), (37, 53)])
 @pytest.mark.parametrize('arith', ['f16x3', 'f32'])
 def test_conv2d_layer(cuda, arith, cin, cout, k, dil, act, h, w):
