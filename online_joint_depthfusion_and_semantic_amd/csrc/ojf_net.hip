@@ -1377,20 +1377,23 @@ struct ojf_net {
     int chain_kind = 0;                             // 0 = unfused, 19 / 20 = growth channels of the fused kernel
     // activation planes (C4 layout), sizes in channels
     float *X[2] = {nullptr, nullptr};  // dense-growth buffers, (gf+1)*cs
-    float *T = nullptr;                // cs
-    float *Z = nullptr;                // 4*cs
-    float *Q1 = nullptr, *Q2 = nullptr, *Q3 = nullptr;  // inputs of branches 1..3 (pool pyramid outputs), cs each
-    float *U = nullptr;                                  // 4*cs: first-3x3 outputs of the four branches
-    float *V = nullptr;                                  // 4*cs: closing-3x3 outputs of the four branches
+    // Scratch of one head's dense block + VortexPooling.  Two sets: with two heads (v3 + semantics) the second head runs
+    // concurrently on its own stream (the kernels are latency-bound and leave most of the GPU idle), so it needs its
+    // own intermediates, side stream and events; everything else (and the last VortexPooling) uses set 0.
+    struct Scratch {
+        float *T = nullptr, *Z = nullptr, *Q1 = nullptr, *Q2 = nullptr, *Q3 = nullptr, *U = nullptr, *V = nullptr;
+        float *partial = nullptr;
+        hipStream_t side = nullptr;
+        hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    } sc[2];
+    hipStream_t head1 = nullptr;  // stream of the second head
+    hipEvent_t ev_head_fork = nullptr, ev_head_join = nullptr;
+    // (per set: T cs | Z 4*cs entry-conv output | Q1..Q3 cs pool-pyramid outputs | U, V 4*cs outputs of the branches'
+    //  first / closing 3x3 | partial kSumBlocks*256 | side stream + events of the global-average branch)
     float *CAT = nullptr;              // 4*os
     float *YY = nullptr;               // heads*os (vortex0 | vortex2 outputs)
     float *Y3 = nullptr;               // os
     float *PA = nullptr, *PB = nullptr;  // pred ping-pong, os each
-    float *partial = nullptr;          // kSumBlocks*256
-    // the global-average branch (two tiny latency-bound kernels) runs on a side stream, concurrently
-    // with the branch convolutions, and joins before the fused tail
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // Optional (OJF_NET_GRAPH=1): the launch sequence of a forward pass captured once per output buffer and
     // replayed with hipGraphLaunch.  Measured on ROCm 7.2 / MI355X: host enqueue time of a forward 160 -> 87 us,
     // but the GPU runs the graph 3-8 % SLOWER than the plain launches (0.555 vs 0.538 ms at 320x240,
@@ -1526,53 +1529,53 @@ static void free_vortex(Vortex &v)
 
 // in: planes, window starting at group in_g0 (c_in_phys/4 groups); out: planes at group out_g0
 static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float *out, int out_g0, hipStream_t st,
-                      const ChainArgs *head = nullptr, bool *head_done = nullptr)
+                      ojf_net::Scratch &sc, const ChainArgs *head = nullptr, bool *head_done = nullptr)
 {
     const int h = net->h, w = net->w, c4 = net->cs / 4, o4 = net->os / 4;
     // global-average branch -> bias of the final conv, on the side stream (fork here, join before the tail)
-    OJF_HIP(hipEventRecord(net->ev_fork, st));
-    OJF_HIP(hipStreamWaitEvent(net->side, net->ev_fork, 0));
-    hipLaunchKernelGGL(colsum_kernel, dim3(kSumBlocks, v.c_in_phys / 4), dim3(256), 0, net->side, planes(in), in_g0,
-                       net->npix, net->partial);
+    OJF_HIP(hipEventRecord(sc.ev_fork, st));
+    OJF_HIP(hipStreamWaitEvent(sc.side, sc.ev_fork, 0));
+    hipLaunchKernelGGL(colsum_kernel, dim3(kSumBlocks, v.c_in_phys / 4), dim3(256), 0, sc.side, planes(in), in_g0,
+                       net->npix, sc.partial);
     OJF_HIP(hipGetLastError());
-    hipLaunchKernelGGL(gave_bias_kernel, dim3(1), dim3(256), 0, net->side, net->partial, v.c_in_phys, net->npix, v.Wg,
+    hipLaunchKernelGGL(gave_bias_kernel, dim3(1), dim3(256), 0, sc.side, sc.partial, v.c_in_phys, net->npix, v.Wg,
                        v.bg, v.Wfg, v.bf, net->pool_in, v.bias_final, v.fin.n_ot * 16);
     OJF_HIP(hipGetLastError());
-    OJF_HIP(hipEventRecord(net->ev_join, net->side));
+    OJF_HIP(hipEventRecord(sc.ev_join, sc.side));
     // branch entries: one GEMM, branch 0 gets bias + ReLU in the epilogue
-    if (launch_conv(v.stacked, in, in_g0, net->Z, 0, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w, st)) return -2;
+    if (launch_conv(v.stacked, in, in_g0, sc.Z, 0, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w, st)) return -2;
     {   // pool pyramid on the pre-activations of branches 1..3: Q_b = ReLU(pool^b(Z[slot b]) + bias_b), one launch
         PyramidArgs pa;
-        pa.z = planes(net->Z);
-        pa.q[0] = planes(net->Q1); pa.q[1] = planes(net->Q2); pa.q[2] = planes(net->Q3);
+        pa.z = planes(sc.Z);
+        pa.q[0] = planes(sc.Q1); pa.q[1] = planes(sc.Q2); pa.q[2] = planes(sc.Q3);
         for (int b = 0; b < 3; ++b) pa.bias[b] = v.pool_bias[b + 1];
         pa.h = h; pa.w = w; pa.c4 = c4;
         const int tiles = ((w + kPoolTW - 1) / kPoolTW) * ((h + kPoolTH - 1) / kPoolTH);
         hipLaunchKernelGGL(pool_pyramid_kernel, dim3(tiles, 3 * c4), dim3(256), 0, st, pa);
         OJF_HIP(hipGetLastError());
     }
-    const float *bin[4] = {net->Z, net->Q1, net->Q2, net->Q3};
+    const float *bin[4] = {sc.Z, sc.Q1, sc.Q2, sc.Q3};
     static const bool unfused = getenv("OJF_NO_TAIL") != nullptr;  // ablation switch only
     const bool fused = v.tail_w && !unfused;
     {   // the four branches' dilated 3x3 pairs: two grouped launches (all first convs, then all second convs)
         ConvArgs ga[4], gb[4];
         for (int br = 0; br < 4; ++br) {
-            fill_conv_args(ga[br], v.b3a[br], bin[br], 0, net->U, br * c4, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w);
-            fill_conv_args(gb[br], v.b3b[br], net->U, br * c4, net->V, br * c4, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w);
+            fill_conv_args(ga[br], v.b3a[br], bin[br], 0, sc.U, br * c4, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w);
+            fill_conv_args(gb[br], v.b3b[br], sc.U, br * c4, sc.V, br * c4, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w);
         }
         if (launch_conv_args(ga, 4, v.b3a[0].n_ot, st, net->arith)) return -2;
         if (launch_conv_args(gb, 4, v.b3b[0].n_ot, st, net->arith)) return -2;
     }
-    OJF_HIP(hipStreamWaitEvent(st, net->ev_join, 0));  // bias of the final conv is ready
+    OJF_HIP(hipStreamWaitEvent(st, sc.ev_join, 0));  // bias of the final conv is ready
     if (!fused) {
         if (ensure_planes(&net->CAT, (size_t)net->npix, 4 * net->os)) return -2;
         for (int br = 0; br < 4; ++br)
-            if (launch_conv(v.b1[br], net->V, br * c4, net->CAT, br * o4, nullptr, OJF_ACT_RELU, net->os, 1.0f, h, w, st))
+            if (launch_conv(v.b1[br], sc.V, br * c4, net->CAT, br * o4, nullptr, OJF_ACT_RELU, net->os, 1.0f, h, w, st))
                 return -2;
     }
     if (!fused) return launch_conv(v.fin, net->CAT, 0, out, out_g0, v.bias_final, OJF_ACT_NONE, 0, 1.0f, h, w, st);
     TailArgs ta;
-    for (int br = 0; br < 4; ++br) ta.v[br] = planes(net->V) + (size_t)br * c4 * net->npix;
+    for (int br = 0; br < 4; ++br) ta.v[br] = planes(sc.V) + (size_t)br * c4 * net->npix;
     ta.w = planes(v.tail_w); ta.b1 = v.tail_b1; ta.bias_final = v.bias_final; ta.rinv_final = v.tail_rinv;
     ta.out = planes(out); ta.c4 = c4; ta.out_g0 = out_g0; ta.og_store = o4; ta.npix = net->npix;
     ta.ovf = net->arith == OJF_ARITH_F16X3 ? overflow_flag() : nullptr;
@@ -1601,10 +1604,11 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
 static int run_dense(ojf_net *net, int head, hipStream_t st)
 {
     const int c4 = net->cs / 4;
+    float *T = net->sc[head].T;
     for (int i = 0; i < net->gf; ++i) {
-        if (launch_conv(net->dense[head][2 * i], net->X[head], 0, net->T, 0, nullptr, OJF_ACT_LEAKY, net->cs, 1.0f,
+        if (launch_conv(net->dense[head][2 * i], net->X[head], 0, T, 0, nullptr, OJF_ACT_LEAKY, net->cs, 1.0f,
                         net->h, net->w, st)) return -2;
-        if (launch_conv(net->dense[head][2 * i + 1], net->T, 0, net->X[head], (i + 1) * c4, nullptr, OJF_ACT_LEAKY,
+        if (launch_conv(net->dense[head][2 * i + 1], T, 0, net->X[head], (i + 1) * c4, nullptr, OJF_ACT_LEAKY,
                         net->cs, 1.0f, net->h, net->w, st)) return -2;
     }
     return 0;
@@ -1636,14 +1640,20 @@ OJF_API void ojf_net_destroy(ojf_net *net)
         for (auto &pc : net->dense[hd]) release(pc);
     for (auto &pc : net->pred) release(pc);
     for (auto &v : net->vortex) free_vortex(v);
-    float *bufs[] = {net->X[0], net->X[1], net->T, net->Z, net->Q1, net->Q2, net->Q3, net->U, net->V,
-                     net->CAT, net->YY, net->Y3, net->PA, net->PB, net->partial};
+    float *bufs[] = {net->X[0], net->X[1], net->CAT, net->YY, net->Y3, net->PA, net->PB};
     for (float *p : bufs) free_planes(p);
+    for (auto &sc : net->sc) {
+        float *sb[] = {sc.T, sc.Z, sc.Q1, sc.Q2, sc.Q3, sc.U, sc.V, sc.partial};
+        for (float *p : sb) free_planes(p);
+        if (sc.ev_fork) (void)hipEventDestroy(sc.ev_fork);
+        if (sc.ev_join) (void)hipEventDestroy(sc.ev_join);
+        if (sc.side) (void)hipStreamDestroy(sc.side);
+    }
+    if (net->ev_head_fork) (void)hipEventDestroy(net->ev_head_fork);
+    if (net->ev_head_join) (void)hipEventDestroy(net->ev_head_join);
+    if (net->head1) (void)hipStreamDestroy(net->head1);
     drop_graph(net);
     if (net->cap) (void)hipStreamDestroy(net->cap);
-    if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
-    if (net->ev_join) (void)hipEventDestroy(net->ev_join);
-    if (net->side) (void)hipStreamDestroy(net->side);
     if (net->chain_w) (void)hipFree(net->chain_w);
     if (net->chain_b) (void)hipFree(net->chain_b);
     delete net;
@@ -1763,24 +1773,32 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
     const size_t np = (size_t)net->npix;
     if (!rc) rc = alloc_planes(&net->X[0], np, (gf + 1) * cs);
     if (!rc && net->heads == 2) rc = alloc_planes(&net->X[1], np, (gf + 1) * cs);
-    if (!rc) rc = alloc_planes(&net->T, np, cs);
-    if (!rc) rc = alloc_planes(&net->Z, np, 4 * cs);
-    if (!rc) rc = alloc_planes(&net->Q1, np, cs);
-    if (!rc) rc = alloc_planes(&net->Q2, np, cs);
-    if (!rc) rc = alloc_planes(&net->Q3, np, cs);
-    if (!rc) rc = alloc_planes(&net->U, np, 4 * cs);
-    if (!rc) rc = alloc_planes(&net->V, np, 4 * cs);
+    for (int hd = 0; hd < net->heads && !rc; ++hd) {
+        ojf_net::Scratch &sc = net->sc[hd];
+        rc = alloc_planes(&sc.T, np, cs);
+        if (!rc) rc = alloc_planes(&sc.Z, np, 4 * cs);
+        if (!rc) rc = alloc_planes(&sc.Q1, np, cs);
+        if (!rc) rc = alloc_planes(&sc.Q2, np, cs);
+        if (!rc) rc = alloc_planes(&sc.Q3, np, cs);
+        if (!rc) rc = alloc_planes(&sc.U, np, 4 * cs);
+        if (!rc) rc = alloc_planes(&sc.V, np, 4 * cs);
+        if (!rc) rc = alloc_planes(&sc.partial, kSumBlocks, 256);
+        if (!rc) rc = check_hip(hipStreamCreateWithFlags(&sc.side, hipStreamNonBlocking), "hipStreamCreate");
+        if (!rc) rc = check_hip(hipEventCreateWithFlags(&sc.ev_fork, hipEventDisableTiming), "hipEventCreate");
+        if (!rc) rc = check_hip(hipEventCreateWithFlags(&sc.ev_join, hipEventDisableTiming), "hipEventCreate");
+    }
+    if (!rc && net->heads == 2) {
+        rc = check_hip(hipStreamCreateWithFlags(&net->head1, hipStreamNonBlocking), "hipStreamCreate");
+        if (!rc) rc = check_hip(hipEventCreateWithFlags(&net->ev_head_fork, hipEventDisableTiming), "hipEventCreate");
+        if (!rc) rc = check_hip(hipEventCreateWithFlags(&net->ev_head_join, hipEventDisableTiming), "hipEventCreate");
+    }
     if (!rc) rc = alloc_planes(&net->YY, np, net->heads * os);
     if (!rc) rc = alloc_planes(&net->Y3, np, os);
-    if (!rc) rc = alloc_planes(&net->partial, kSumBlocks, 256);
-    if (!rc) rc = check_hip(hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking), "hipStreamCreate");
     if (!rc) rc = check_hip(hipStreamCreateWithFlags(&net->cap, hipStreamNonBlocking), "hipStreamCreate");
     {
         const char *g = getenv("OJF_NET_GRAPH");  // opt-in: see the note at ojf_net::cap
         net->use_graph = g && g[0] == '1';
     }
-    if (!rc) rc = check_hip(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming), "hipEventCreate");
-    if (!rc) rc = check_hip(hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming), "hipEventCreate");
     if (rc) {
         const std::string keep = ojf_last_error();
         ojf_net_destroy(net);
@@ -1829,17 +1847,29 @@ static int forward_launches(ojf_net *net, float *est, int est_stride, hipStream_
     ca.ovf = net->arith == OJF_ARITH_F16X3 ? overflow_flag() : nullptr;
     const ChainArgs *head = (net->chain_kind && !unfused) ? &ca : nullptr;
     bool head_done = false;  // set when the last VortexPooling's tail kernel ran the head as well
-    if (run_dense(net, 0, st)) return -2;
+    static const bool serial_heads = getenv("OJF_SERIAL_HEADS") != nullptr;  // ablation switch only
     if (net->version == 3) {
-        if (run_vortex(net, net->vortex[0], net->X[0], 0, net->YY, 0, st)) return -2;
-        if (net->heads == 2) {
-            if (run_dense(net, 1, st)) return -2;
-            if (run_vortex(net, net->vortex[1], net->X[1], 0, net->YY, o4, st)) return -2;
+        const bool two = net->heads == 2;
+        hipStream_t s1 = (two && !serial_heads) ? net->head1 : st;
+        if (two && s1 != st) {  // the semantic head runs beside the geometric one
+            OJF_HIP(hipEventRecord(net->ev_head_fork, st));
+            OJF_HIP(hipStreamWaitEvent(s1, net->ev_head_fork, 0));
         }
-        if (run_vortex(net, net->vortex[2], net->YY, 0, net->Y3, 0, st, head, &head_done)) return -2;
+        if (two) {
+            if (run_dense(net, 1, s1)) return -2;
+            if (run_vortex(net, net->vortex[1], net->X[1], 0, net->YY, o4, s1, net->sc[1])) return -2;
+        }
+        if (run_dense(net, 0, st)) return -2;
+        if (run_vortex(net, net->vortex[0], net->X[0], 0, net->YY, 0, st, net->sc[0])) return -2;
+        if (two && s1 != st) {
+            OJF_HIP(hipEventRecord(net->ev_head_join, s1));
+            OJF_HIP(hipStreamWaitEvent(st, net->ev_head_join, 0));
+        }
+        if (run_vortex(net, net->vortex[2], net->YY, 0, net->Y3, 0, st, net->sc[0], head, &head_done)) return -2;
     } else {
-        if (run_vortex(net, net->vortex[0], net->X[0], 0, net->YY, 0, st)) return -2;
-        if (run_vortex(net, net->vortex[2], net->YY, 0, net->Y3, 0, st, head, &head_done)) return -2;
+        if (run_dense(net, 0, st)) return -2;
+        if (run_vortex(net, net->vortex[0], net->X[0], 0, net->YY, 0, st, net->sc[0])) return -2;
+        if (run_vortex(net, net->vortex[2], net->YY, 0, net->Y3, 0, st, net->sc[0], head, &head_done)) return -2;
     }
     if (head_done) return 0;
     if (net->chain_kind && !unfused) {
