@@ -1384,7 +1384,7 @@ struct ojf_net {
         float *T = nullptr, *Z = nullptr, *Q1 = nullptr, *Q2 = nullptr, *Q3 = nullptr, *U = nullptr, *V = nullptr;
         float *partial = nullptr;
         hipStream_t side = nullptr;
-        hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+        hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_entry = nullptr;
     } sc[2];
     hipStream_t head1 = nullptr;  // stream of the second head
     hipEvent_t ev_head_fork = nullptr, ev_head_join = nullptr;
@@ -1541,9 +1541,9 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
     hipLaunchKernelGGL(gave_bias_kernel, dim3(1), dim3(256), 0, sc.side, sc.partial, v.c_in_phys, net->npix, v.Wg,
                        v.bg, v.Wfg, v.bf, net->pool_in, v.bias_final, v.fin.n_ot * 16);
     OJF_HIP(hipGetLastError());
-    OJF_HIP(hipEventRecord(sc.ev_join, sc.side));
     // branch entries: one GEMM, branch 0 gets bias + ReLU in the epilogue
     if (launch_conv(v.stacked, in, in_g0, sc.Z, 0, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w, st)) return -2;
+    OJF_HIP(hipEventRecord(sc.ev_entry, st));
     {   // pool pyramid on the pre-activations of branches 1..3: Q_b = ReLU(pool^b(Z[slot b]) + bias_b), one launch
         PyramidArgs pa;
         pa.z = planes(sc.Z);
@@ -1563,9 +1563,21 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
             fill_conv_args(ga[br], v.b3a[br], bin[br], 0, sc.U, br * c4, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w);
             fill_conv_args(gb[br], v.b3b[br], sc.U, br * c4, sc.V, br * c4, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w);
         }
-        if (launch_conv_args(ga, 4, v.b3a[0].n_ot, st, net->arith)) return -2;
-        if (launch_conv_args(gb, 4, v.b3b[0].n_ot, st, net->arith)) return -2;
+        // Branch 0 needs no pooling: its 3x3 pair follows the global-average kernels on the side stream (37 us of tiny
+        // kernels + 2 x 9 us there against pyramid + two grouped launches of the other three branches here).
+        static const bool b0_main = getenv("OJF_BRANCH0_MAIN") != nullptr;  // ablation switch only
+        if (b0_main) {
+            if (launch_conv_args(ga, 4, v.b3a[0].n_ot, st, net->arith)) return -2;
+            if (launch_conv_args(gb, 4, v.b3b[0].n_ot, st, net->arith)) return -2;
+        } else {
+            OJF_HIP(hipStreamWaitEvent(sc.side, sc.ev_entry, 0));
+            if (launch_conv_args(ga, 1, v.b3a[0].n_ot, sc.side, net->arith)) return -2;
+            if (launch_conv_args(gb, 1, v.b3b[0].n_ot, sc.side, net->arith)) return -2;
+            if (launch_conv_args(ga + 1, 3, v.b3a[1].n_ot, st, net->arith)) return -2;
+            if (launch_conv_args(gb + 1, 3, v.b3b[1].n_ot, st, net->arith)) return -2;
+        }
     }
+    OJF_HIP(hipEventRecord(sc.ev_join, sc.side));
     OJF_HIP(hipStreamWaitEvent(st, sc.ev_join, 0));  // bias of the final conv is ready
     if (!fused) {
         if (ensure_planes(&net->CAT, (size_t)net->npix, 4 * net->os)) return -2;
@@ -1647,6 +1659,7 @@ OJF_API void ojf_net_destroy(ojf_net *net)
         for (float *p : sb) free_planes(p);
         if (sc.ev_fork) (void)hipEventDestroy(sc.ev_fork);
         if (sc.ev_join) (void)hipEventDestroy(sc.ev_join);
+        if (sc.ev_entry) (void)hipEventDestroy(sc.ev_entry);
         if (sc.side) (void)hipStreamDestroy(sc.side);
     }
     if (net->ev_head_fork) (void)hipEventDestroy(net->ev_head_fork);
@@ -1786,6 +1799,7 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
         if (!rc) rc = check_hip(hipStreamCreateWithFlags(&sc.side, hipStreamNonBlocking), "hipStreamCreate");
         if (!rc) rc = check_hip(hipEventCreateWithFlags(&sc.ev_fork, hipEventDisableTiming), "hipEventCreate");
         if (!rc) rc = check_hip(hipEventCreateWithFlags(&sc.ev_join, hipEventDisableTiming), "hipEventCreate");
+        if (!rc) rc = check_hip(hipEventCreateWithFlags(&sc.ev_entry, hipEventDisableTiming), "hipEventCreate");
     }
     if (!rc && net->heads == 2) {
         rc = check_hip(hipStreamCreateWithFlags(&net->head1, hipStreamNonBlocking), "hipStreamCreate");
