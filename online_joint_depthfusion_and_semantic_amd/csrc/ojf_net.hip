@@ -1566,7 +1566,7 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
         // Branch 0 needs no pooling: its 3x3 pair follows the global-average kernels on the side stream (37 us of tiny
         // kernels + 2 x 9 us there against pyramid + two grouped launches of the other three branches here).
         static const bool b0_main = getenv("OJF_BRANCH0_MAIN") != nullptr;  // ablation switch only
-        if (b0_main) {
+        if (b0_main || net->npix < 32768) {  // small frames: the extra stream hand-over costs more than it hides (160x120: +12 %)
             if (launch_conv_args(ga, 4, v.b3a[0].n_ot, st, net->arith)) return -2;
             if (launch_conv_args(gb, 4, v.b3b[0].n_ot, st, net->arith)) return -2;
         } else {
