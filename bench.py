@@ -211,7 +211,7 @@ def main():
             hbm_traffic = sum(tr[k]['fetch_bytes_per_frame_x2'] + tr[k]['write_bytes_per_frame']
                               for k in tr if 'extract' in k or 'integrate' in k)
         out = {
-            'metric': 'frames/sec fused (320x240, 256^3 grid)', 'value': fps, 'unit': 'frames/sec',
+            'metric': 'frames/sec fused (%dx%d, %d^3 grid)' % (w, h, grid), 'value': fps, 'unit': 'frames/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': ARITH[args.arith][0], 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: geometry-only fusion, %dx%d depth into a %d^3 fp16 TSDF grid, '
