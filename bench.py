@@ -121,6 +121,8 @@ def main():
     ap.add_argument('--width', type=int, default=320)
     ap.add_argument('--grid', type=int, default=256)
     ap.add_argument('--semantics', action='store_true', help='BASELINE configs[2]-style: gt labels + semantic head')
+    ap.add_argument('--semantic-strategy', default='gt', choices=['gt', 'predict'],
+                    help="with --semantics: 'predict' runs AdapNet++ (random init, torch ops on the GPU) on every frame")
     ap.add_argument('--mode', default='fast', choices=['fast', 'parity'])
     ap.add_argument('--arith', default='f16x3', choices=['f16x3', 'f32'], help='net MFMA arithmetic (include/ojf.h OJF_ARITH_*)')
     ap.add_argument('--cpu-frames', type=int, default=4, help='timed frames of the CPU baseline (0 = skip)')
@@ -148,6 +150,8 @@ def main():
     cfg = default_config(h, w, semantics=args.semantics, integrate_mode=args.mode)
     cfg.SETTINGS.device = str(dev)
     cfg.FUSION_MODEL.arithmetic = args.arith
+    if args.semantics:
+        cfg.DATA.semantic_strategy = args.semantic_strategy
     n_frames = args.steps + args.warmup
     st = SyntheticStream(h, w, grid, n_frames, scene='room_%d' % rank, seed=1911 + rank)
     db = Database(st, database_config(cfg))
@@ -159,9 +163,10 @@ def main():
     # frames resident in HBM before the clock starts; poses and ids stay host-side metadata
     batches = []
     image = torch.zeros((1, 3, h, w), device=dev)  # only its shape is read on this path
+    predict = args.semantics and args.semantic_strategy == 'predict'
     for i in range(n_frames):
         f = st.frame(i)
-        b = {'image': image, 'frame_id': [f['frame_id']],
+        b = {'image': torch.from_numpy(f['image']).unsqueeze(0).to(dev) if predict else image, 'frame_id': [f['frame_id']],
              st.depth_key: torch.from_numpy(f[st.depth_key]).unsqueeze(0).to(dev),
              'mask': torch.from_numpy(f['mask']).unsqueeze(0).to(dev),
              'extrinsics': torch.from_numpy(f['extrinsics']).unsqueeze(0),
@@ -215,7 +220,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': ARITH[args.arith][0], 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: geometry-only fusion, %dx%d depth into a %d^3 fp16 TSDF grid, '
-                                   'FusionNet_v3%s, one scene per GPU' % (w, h, grid, ' + gt semantics' if args.semantics else ''),
+                                   'FusionNet_v3%s, one scene per GPU' % (w, h, grid, (' + %s semantics' % ('AdapNet++ (predict)' if predict else 'gt')) if args.semantics else ''),
                        'frame': [h, w], 'grid': grid, 'n_points': P, 'n_tail_points': T, 'integrate_mode': args.mode,
                        'volume_dtype': 'f16', 'net_arithmetic': ARITH[args.arith][1], 'parallelism': 'scene-sharded x%d' % world},
             'stages_ms': stages,
