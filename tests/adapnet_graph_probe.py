@@ -33,3 +33,24 @@ x_cl, y_cl = img.contiguous(memory_format=torch.channels_last), dep.contiguous(m
 print('eager channels_last %.2f ms' % timeit(lambda: run(net_cl, x_cl, y_cl)))
 with torch.autocast('cuda', dtype=torch.float16):
     print('eager fp16 autocast %.2f ms' % timeit(lambda: run(net_cl, x_cl, y_cl)))
+
+def capture(fn):
+    s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3): fn()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fn()
+    return g, out
+
+def half_run():
+    with torch.autocast('cuda', dtype=torch.float16):
+        return run(net_cl, x_cl, y_cl)
+g2, out2 = capture(lambda: run(net_cl, x_cl, y_cl))
+print('graph channels_last fp32 %.2f ms' % timeit(lambda: g2.replay()))
+g3, out3 = capture(half_run)
+print('graph channels_last fp16 %.2f ms' % timeit(lambda: g3.replay()))
+ref = run(net_cl, x_cl, y_cl)
+g3.replay(); torch.cuda.synchronize()
+print('fp16 vs fp32: max score diff %.2e, id agreement %.4f' % (float((out3[0].float() - ref[0]).abs().max()), float((out3[1] == ref[1]).float().mean())))
