@@ -1383,6 +1383,7 @@ struct ojf_net {
     struct Scratch {
         float *T = nullptr, *Z = nullptr, *Q1 = nullptr, *Q2 = nullptr, *Q3 = nullptr, *U = nullptr, *V = nullptr;
         float *partial = nullptr;
+        float *CAT = nullptr;  // 4*os, unfused tail only (allocated at first use)
         hipStream_t side = nullptr;
         hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_entry = nullptr;
     } sc[2];
@@ -1390,7 +1391,6 @@ struct ojf_net {
     hipEvent_t ev_head_fork = nullptr, ev_head_join = nullptr;
     // (per set: T cs | Z 4*cs entry-conv output | Q1..Q3 cs pool-pyramid outputs | U, V 4*cs outputs of the branches'
     //  first / closing 3x3 | partial kSumBlocks*256 | side stream + events of the global-average branch)
-    float *CAT = nullptr;              // 4*os
     float *YY = nullptr;               // heads*os (vortex0 | vortex2 outputs)
     float *Y3 = nullptr;               // os
     float *PA = nullptr, *PB = nullptr;  // pred ping-pong, os each
@@ -1580,12 +1580,12 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
     OJF_HIP(hipEventRecord(sc.ev_join, sc.side));
     OJF_HIP(hipStreamWaitEvent(st, sc.ev_join, 0));  // bias of the final conv is ready
     if (!fused) {
-        if (ensure_planes(&net->CAT, (size_t)net->npix, 4 * net->os)) return -2;
+        if (ensure_planes(&sc.CAT, (size_t)net->npix, 4 * net->os)) return -2;
         for (int br = 0; br < 4; ++br)
-            if (launch_conv(v.b1[br], sc.V, br * c4, net->CAT, br * o4, nullptr, OJF_ACT_RELU, net->os, 1.0f, h, w, st))
+            if (launch_conv(v.b1[br], sc.V, br * c4, sc.CAT, br * o4, nullptr, OJF_ACT_RELU, net->os, 1.0f, h, w, st))
                 return -2;
     }
-    if (!fused) return launch_conv(v.fin, net->CAT, 0, out, out_g0, v.bias_final, OJF_ACT_NONE, 0, 1.0f, h, w, st);
+    if (!fused) return launch_conv(v.fin, sc.CAT, 0, out, out_g0, v.bias_final, OJF_ACT_NONE, 0, 1.0f, h, w, st);
     TailArgs ta;
     for (int br = 0; br < 4; ++br) ta.v[br] = planes(sc.V) + (size_t)br * c4 * net->npix;
     ta.w = planes(v.tail_w); ta.b1 = v.tail_b1; ta.bias_final = v.bias_final; ta.rinv_final = v.tail_rinv;
@@ -1652,10 +1652,10 @@ OJF_API void ojf_net_destroy(ojf_net *net)
         for (auto &pc : net->dense[hd]) release(pc);
     for (auto &pc : net->pred) release(pc);
     for (auto &v : net->vortex) free_vortex(v);
-    float *bufs[] = {net->X[0], net->X[1], net->CAT, net->YY, net->Y3, net->PA, net->PB};
+    float *bufs[] = {net->X[0], net->X[1], net->YY, net->Y3, net->PA, net->PB};
     for (float *p : bufs) free_planes(p);
     for (auto &sc : net->sc) {
-        float *sb[] = {sc.T, sc.Z, sc.Q1, sc.Q2, sc.Q3, sc.U, sc.V, sc.partial};
+        float *sb[] = {sc.T, sc.Z, sc.Q1, sc.Q2, sc.Q3, sc.U, sc.V, sc.partial, sc.CAT};
         for (float *p : sb) free_planes(p);
         if (sc.ev_fork) (void)hipEventDestroy(sc.ev_fork);
         if (sc.ev_join) (void)hipEventDestroy(sc.ev_join);
@@ -1937,7 +1937,9 @@ static void capture_graph(ojf_net *net, float *est, int est_stride)
     net->g_est = est;
     net->g_stride = est_stride;
     // no allocation may happen while capturing: have the fall-back paths' buffers in place
-    if (ensure_planes(&net->CAT, (size_t)net->npix, 4 * net->os) || ensure_planes(&net->PA, (size_t)net->npix, net->os) ||
+    if (ensure_planes(&net->sc[0].CAT, (size_t)net->npix, 4 * net->os) ||
+        (net->heads == 2 && ensure_planes(&net->sc[1].CAT, (size_t)net->npix, 4 * net->os)) ||
+        ensure_planes(&net->PA, (size_t)net->npix, net->os) ||
         ensure_planes(&net->PB, (size_t)net->npix, net->os)) { net->use_graph = false; return; }
     if (hipStreamBeginCapture(net->cap, hipStreamCaptureModeThreadLocal) != hipSuccess) { net->use_graph = false; return; }
     const int rc = forward_launches(net, est, est_stride, net->cap);

@@ -54,3 +54,15 @@ print('graph channels_last fp16 %.2f ms' % timeit(lambda: g3.replay()))
 ref = run(net_cl, x_cl, y_cl)
 g3.replay(); torch.cuda.synchronize()
 print('fp16 vs fp32: max score diff %.2e, id agreement %.4f' % (float((out3[0].float() - ref[0]).abs().max()), float((out3[1] == ref[1]).float().mean())))
+
+import copy
+try:
+    from torch.fx.experimental.optimization import fuse
+    fused = fuse(copy.deepcopy(net).eval())
+    ref = run(net, img, dep)
+    outf = run(fused, img, dep)
+    print('fx conv-bn fused: max score diff %.2e' % float((outf[0] - ref[0]).abs().max()))
+    g4, out4 = capture(lambda: run(fused, img, dep))
+    print('graph fused fp32    %.2f ms' % timeit(lambda: g4.replay()))
+except Exception as e:
+    print('fx fuse failed:', repr(e)[:300])
