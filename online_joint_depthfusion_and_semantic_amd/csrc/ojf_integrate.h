@@ -10,15 +10,18 @@ namespace ojf {
 struct alignas(16) VoxelRec {
     unsigned int lin;       // linear voxel index
     unsigned int next;      // next record of the same voxel (index + 1), 0 = end of list
-    unsigned long long w;   // sum of corner weights, 2^-36 fixed point (two's complement)
+    unsigned long long w;   // sum of corner weights, 2^-44 fixed point (two's complement)
     unsigned long long u;   // sum of weight * clamped update
     unsigned int e_last;    // 1 + highest entry id in this partial
     unsigned int e_diff;    // 1 + highest entry id whose class differs from the voxel's old class (0 = none)
 };
 static_assert(sizeof(VoxelRec) == 32, "VoxelRec layout");
 
-constexpr double kFixScale = 68719476736.0;          // 2^36
-constexpr double kFixInv = 1.0 / 68719476736.0;
+// 2^-44: a voxel whose weight barely survives fp16 (W ~ 2^-25, a few dozen entries) still gets sum(w v) / sum(w) to
+// half an fp16 ulp (2^-36 left up to 6 ulp there: tests/test_extract_integrate_gpu.py::test_full_size_properties_config_C);
+// 19 integer bits remain: per-frame weight sums below 5e5 per voxel.
+constexpr double kFixScale = 17592186044416.0;        // 2^44
+constexpr double kFixInv = 1.0 / 17592186044416.0;
 constexpr size_t kHeaderBytes = 256;                  // counters: [0] counter-allocated touched voxels, [2] counter-allocated records
 
 struct IntegrateArgs {

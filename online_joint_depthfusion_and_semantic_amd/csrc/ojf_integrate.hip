@@ -4,7 +4,7 @@
 //
 // FAST mode (this file).  Colliding voxel writes (~16 entries per touched voxel) are resolved with
 // order-free integer arithmetic so that the result does not depend on scheduling:
-//   * sum(w) and sum(w*v) are accumulated as 2^-36 fixed point in 64-bit integers (integer adds
+//   * sum(w) and sum(w*v) are accumulated as 2^-44 fixed point in 64-bit integers (integer adds
 //     are associative, so any combining order - in-LDS per tile, then per voxel - gives the same
 //     bits); the total is rounded once to fp32 where the reference rounds after every add, which
 //     moves at most a handful of voxels per frame by one fp16 ulp;

@@ -267,3 +267,47 @@ def test_integrate_ragged_frame(cuda):
         for key in ref:
             ulp = f16_ulp_distance(g[key].cpu().numpy(), ref[key])
             assert ulp.max() <= (0 if mode == ops.MODE_PARITY else 1), (mode, key)
+
+
+def test_full_size_properties_config_C(cuda):
+    """BASELINE configs[4] size (640x480 depth into a 512^3 grid), where the scalar oracle would take minutes: the
+    size-independent properties instead.  (1) extract of an empty volume returns exactly (init value, 0) for
+    every in-volume sample; (2) a constant update on the empty volume gives TSDF = fp16(v) at every touched voxel
+    and leaves the rest alone; (3) FAST and PARITY agree to one fp16 ulp; (4) the call is deterministic;
+    (5) extracting the fused volume back along the same rays returns v (within the interpolation of touched and
+    untouched corners: never outside [min(v, init), max(v, init)])."""
+    h, w, grid = 480, 640, 512
+    st = make_stream(h, w, grid)
+    fi = frame_inputs(st, 2)
+    v = np.float32(-0.03)
+    est = np.full((h * w, 9), v, np.float32)
+    depth, fd = _t(fi['depth'], cuda), _t(fi['fd'], cuda)
+    outs = {}
+    for mode in (ops.MODE_FAST, ops.MODE_PARITY, ops.MODE_FAST):
+        tsdf = torch.full((grid,) * 3, 0.1, dtype=torch.float16, device=cuda)
+        wgt = torch.zeros((grid,) * 3, dtype=torch.float16, device=cuda)
+        if not outs:
+            ex = ops.extract(depth, fi['Ki'], fi['E'], st.origin, st.resolution, tsdf, wgt)
+            fv, fw = ex['fusion_values'].cpu().numpy(), ex['fusion_weights'].cpu().numpy()
+            assert np.all(fw == 0) and np.all((fv == np.float32(np.float16(0.1))) | (fv < np.float32(0.1)))
+        ws = ops.IntegrateWorkspace((grid,) * 3, h, w, 7, mode, cuda)
+        ops.integrate(fd, fi['Ki'], fi['E'], st.origin, st.resolution, _t(est, cuda), tsdf, wgt, ws, mode=mode, stats=True)
+        touched = wgt > 0
+        n_touched = int(touched.sum())
+        assert n_touched == int(ws.stats[0].item()) and n_touched > 200000
+        t = tsdf[touched].float().cpu().numpy()
+        assert f16_ulp_distance(t.astype(np.float16), np.full(t.shape, np.float16(v), np.float16)).max() <= 1
+        rest = tsdf[~touched]
+        assert bool(((rest == 0.1) | torch.isnan(rest)).all())
+        outs.setdefault(mode, []).append((tsdf.cpu().numpy(), wgt.cpu().numpy()))
+        del ws
+    (t0, w0), (t1, w1) = outs[ops.MODE_FAST]
+    assert n_mismatch(t0, t1) == 0 and n_mismatch(w0, w1) == 0  # deterministic
+    tp, wp = outs[ops.MODE_PARITY][0]
+    assert f16_ulp_distance(t0, tp).max() <= 1 and f16_ulp_distance(w0, wp).max() <= 1
+    ex = ops.extract(depth, fi['Ki'], fi['E'], st.origin, st.resolution, _t(tp, cuda), _t(wp, cuda))
+    fv = ex['fusion_values'].cpu().numpy()
+    valid = fi['fd'].reshape(-1) != 0
+    mid = fv[valid][:, 1:8]  # the seven integrated samples of valid rays
+    assert mid.min() >= float(np.float16(v)) - 1e-3 and mid.max() <= 0.1 + 1e-3
+    assert np.median(mid) < 0.0  # most of what the rays see is the fused band
