@@ -311,3 +311,40 @@ def test_full_size_properties_config_C(cuda):
     mid = fv[valid][:, 1:8]  # the seven integrated samples of valid rays
     assert mid.min() >= float(np.float16(v)) - 1e-3 and mid.max() <= 0.1 + 1e-3
     assert np.median(mid) < 0.0  # most of what the rays see is the fused band
+
+
+@pytest.mark.parametrize('semantics', [False, True])
+def test_integrate_hash_overflow_path(cuda, semantics):
+    """Coarse frame into a fine grid with 15 integrated samples per ray (48x64 rays into 256^3: ~4000 distinct voxels
+    per 8x8 tile against 2048 hash slots): the entries that find their tile's hash full take the counter-allocated
+    record path behind the tile slices.  Same bars as everywhere else."""
+    h, w, grid, P, T = 48, 64, 256, 17, 15
+    st = make_stream(h, w, grid)
+    vols = fresh_volumes(grid, semantics)
+    tiles = (h // 8) * (w // 8)
+    for mode in (ops.MODE_PARITY, ops.MODE_FAST):
+        ref = {k: v.copy() for k, v in vols.items()}
+        g = to_cuda(vols, cuda)
+        ws = ops.IntegrateWorkspace((grid,) * 3, h, w, T, mode, cuda)
+        for i in range(2):
+            fi = frame_inputs(st, i, n_points=P)
+            if mode == ops.MODE_FAST:
+                g = to_cuda(ref, cuda)  # FAST is specified per frame from a common pre-frame state
+            kw_o, kw_g = {}, {}
+            if semantics:
+                kw_o = dict(sem_ids=fi['sem_ids'], sem_scores=fi['sem_scores'], id_vol=ref['ids'], score_vol=ref['scores'])
+                kw_g = dict(sem_ids=_t(fi['sem_ids'].reshape(-1), cuda), sem_scores=_t(fi['sem_scores'].reshape(-1), cuda),
+                            id_vol=g['ids'], score_vol=g['scores'])
+            touched = oracle.integrate(fi['fd'], fi['Ki'], fi['E'], st.origin, st.resolution, fi['est'], ref['tsdf'], ref['wgt'],
+                                       n_points=P, n_tail=T, **kw_o)
+            ops.integrate(_t(fi['fd'], cuda), fi['Ki'], fi['E'], st.origin, st.resolution, _t(fi['est'], cuda), g['tsdf'], g['wgt'],
+                          ws, n_points=P, n_tail=T, mode=mode, stats=True, **kw_g)
+            assert int(ws.stats[0].item()) == touched
+            if mode == ops.MODE_FAST:
+                assert int(ws.stats[2].item()) > tiles * 2048  # more records than the tile slices alone can hold
+            for key in ('tsdf', 'wgt'):
+                ulp = f16_ulp_distance(g[key].cpu().numpy(), ref[key])
+                assert ulp.max() <= (0 if mode == ops.MODE_PARITY else 1), (mode, key, i)
+            if semantics:
+                assert n_mismatch(g['ids'].cpu().numpy(), ref['ids']) == 0
+                assert n_mismatch(g['scores'].cpu().numpy(), ref['scores']) == 0
