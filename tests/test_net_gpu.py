@@ -75,7 +75,7 @@ def _inputs(h, w, seed=1):
 
 
 @pytest.mark.parametrize('version,sem', [('v3', False), ('v3', True), ('v2', False), ('v2', True)])
-@pytest.mark.parametrize('h,w', [(24, 32), (60, 80), (120, 160)])
+@pytest.mark.parametrize('h,w', [(24, 32), (60, 80), (120, 160), (45, 77)])  # the last: ragged strips, tiles and pool tiles
 @pytest.mark.parametrize('arith', ['f16x3', 'f32'])
 def test_fusion_net_forward(cuda, arith, version, sem, h, w):
     net = seeded_net(version, sem, h, w)
@@ -232,3 +232,19 @@ def test_fusion_net_graph_replay(cuda, monkeypatch):
     plain, graph = run(False), run(True)
     for a, b in zip(plain, graph):
         assert torch.equal(a, b)
+
+
+def test_fusion_net_forward_640x480(cuda):
+    """BASELINE configs[4] frame size through the whole net (default arithmetic), against the fp32 CPU net."""
+    h, w = 480, 640
+    net = seeded_net('v3', False, h, w)
+    x = _inputs(h, w)
+    with torch.no_grad():
+        ref = net(x)[0].permute(1, 2, 0).reshape(h * w, 9)
+    eng = FusionNetEngine(net, h, w, cuda)
+    got = _run(eng, x, h, w, cuda).cpu()
+    eng.check()
+    err = float((got - ref).abs().max())
+    print('net 640x480 max err %.2e' % err)
+    assert err <= TOL, err
+    eng.close()
