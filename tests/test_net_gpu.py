@@ -75,7 +75,7 @@ def _inputs(h, w, seed=1):
 
 
 @pytest.mark.parametrize('version,sem', [('v3', False), ('v3', True), ('v2', False), ('v2', True)])
-@pytest.mark.parametrize('h,w', [(24, 32), (60, 80), (120, 160), (45, 77)])  # the last: ragged strips, tiles and pool tiles
+@pytest.mark.parametrize('h,w', [(24, 32), (60, 80), (120, 160), (45, 77), (5, 7)])  # ragged strips / tiles; a frame smaller than a tile
 @pytest.mark.parametrize('arith', ['f16x3', 'f32'])
 def test_fusion_net_forward(cuda, arith, version, sem, h, w):
     net = seeded_net(version, sem, h, w)
