@@ -107,17 +107,17 @@ __device__ __forceinline__ int fast_div(int x, int d, unsigned magic) { return m
 
 // Split-fp16 range guard.  Kernels keep a running maximum of the magnitudes of every value a later layer will
 // split (2 VALU per float4: v_max3_f32 with |.| modifiers) and raise the flag if it exceeds the fp16 range.
-// v_max ignores NaN operands; that is sufficient here: with finite weights (checked at creation) and guarded
-// inputs (prepare_input_kernel tests NaN explicitly) the FIRST out-of-range event is always a finite value beyond
-// 65504 or an infinity at a guarded point - NaN can only appear downstream of one.
+// v_max ignores NaN operands, deliberately: a NaN input (the reference writes NaN TSDF into voxels it touches with
+// zero total weight, and later frames gather them) propagates to NaN outputs in both arithmetics exactly as in the
+// fp32 reference, so it is not an error here either.  With finite weights (checked at creation) an out-of-range
+// event is always a finite value beyond 65504 or an infinity at a guarded point first.
 __device__ __forceinline__ float guard_max(float mx, const f32x4 &v)
 {
     return fmaxf(fmaxf(fmaxf(mx, fabsf(v[0])), fmaxf(fabsf(v[1]), fabsf(v[2]))), fabsf(v[3]));
 }
-__device__ __forceinline__ bool beyond_f16(const f32x4 &v)  // NaN-aware form for raw inputs
+__device__ __forceinline__ bool beyond_f16(const f32x4 &v)  // raw inputs; NaN is not a range violation (see above)
 {
-    const float t = (v[0] + v[1]) + (v[2] + v[3]);
-    return !(guard_max(0.0f, v) <= 65504.0f) || t != t;
+    return guard_max(0.0f, v) > 65504.0f;
 }
 __device__ __forceinline__ f32x4 fma4(const f32x4 &a, const f32x4 &b, const f32x4 &c)
 {
@@ -902,7 +902,7 @@ __device__ __forceinline__ void pool_pyramid_body(const PyramidArgs &a, f32x4 (&
             } else if (in) {
                 s += *reinterpret_cast<const f32x4 *>(a.bias[LV - 1] + 4 * cg);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) s[j] = s[j] > 0.0f ? s[j] : 0.0f;
+                for (int j = 0; j < 4; ++j) s[j] = s[j] < 0.0f ? 0.0f : s[j];  // keeps NaN, like torch.relu
                 a.q[LV - 1][(size_t)cg * npix + gy * a.w + gx] = s;
             }
         }

@@ -248,3 +248,22 @@ def test_fusion_net_forward_640x480(cuda):
     print('net 640x480 max err %.2e' % err)
     assert err <= TOL, err
     eng.close()
+
+
+@pytest.mark.parametrize('arith', ['f16x3', 'f32'])
+def test_nan_inputs_propagate_like_the_reference(cuda, arith):
+    """The reference stores NaN TSDF in voxels it touches with zero total weight; a later frame gathers them and
+    feeds NaN to the net, whose global-average branch spreads it to every output.  Same here, in both arithmetics -
+    and it is not a range-guard violation."""
+    h, w = 24, 32
+    net = seeded_net('v3', False, h, w)
+    x = _inputs(h, w)
+    x['tsdf_values'][0, 4, 10, 11] = float('nan')
+    with torch.no_grad():
+        ref = net(x)[0]
+    assert torch.isnan(ref).all()
+    eng = FusionNetEngine(net, h, w, cuda, arithmetic=arith)
+    got = _run(eng, x, h, w, cuda).cpu()
+    eng.check()  # NaN in -> NaN out is not an error
+    assert torch.isnan(got).all()
+    eng.close()
