@@ -145,8 +145,8 @@ int ojf_net_set_arithmetic(int arithmetic);
 int ojf_net_get_arithmetic(const ojf_net *net);
 /* Range guard of OJF_ARITH_F16X3.  Every kernel that produces a value a later layer splits into fp16 halves
  * raises a process-wide flag if that value is beyond +-65504 (it cannot be split; a trained, BN-folded FusionNet
- * stays orders of magnitude below).  NaN inputs are not violations: they propagate to NaN outputs as in fp32.  ojf_net_forward polls the flag without synchronising and fails
- * once it is set; ojf_net_check synchronises `stream`, returns non-zero (and clears the flag) if it was raised
+ * stays orders of magnitude below).  NaN inputs are not violations: they propagate to NaN outputs as in fp32.
+ * ojf_net_forward polls the flag without synchronising and fails once it is set; ojf_net_check synchronises `stream`, returns non-zero (and clears the flag) if it was raised
  * since the last check.  Results produced in between are invalid: switch that network to OJF_ARITH_F32. */
 int ojf_net_check(ojf_stream_t stream);
 
