@@ -173,6 +173,37 @@ int ojf_volume_filter(uint16_t *tsdf_dev, uint16_t *weights_dev, size_t n, float
 int ojf_volume_evaluate(const uint16_t *est_dev, const uint16_t *gt_dev, const uint16_t *weights_dev,
                         size_t n, double *sums_dev, ojf_stream_t stream);
 
+/* ---- MESH (Database.get_mesh / save 'ply' and 'test' modes) ------------------------------------
+ * ojf_mesh_extract: iso-surface of a fused volume as a triangle list, replacing the host-side
+ *   skimage.measure.marching_cubes call in modules/database.py:118-139,203-261 and utils/saving.py:42-47.
+ *   Marching tetrahedra on the 6-tetrahedra split of every cell (watertight, no ambiguous cases) - same surface up
+ *   to the triangulation, NOT the same triangle list as skimage's Lewiner tables.  Cells with a NaN corner or
+ *   (weights_dev != NULL) an unobserved corner are skipped.
+ *   workspace_dev: ojf_mesh_workspace_bytes(X,Y,Z) bytes of device memory (per-block counts / offsets).
+ *   Call once with capacity = 0 (vertices may be NULL) to get *count_dev = number of triangles, then again with
+ *   buffers of capacity triangles: vertices_dev f32[capacity][3][3] = origin + voxel_index * resolution (origin 0
+ *   gives the reference's mesh frame); labels_dev u8[capacity][3] (or NULL) = ids_dev at the voxel nearest to each
+ *   vertex, ties to even as np.round does (database.py:124-127; 0 when ids_dev is NULL); keys_dev u64[capacity][3]
+ *   (or NULL) = 8 * linear index of the lower voxel of the grid edge the vertex lies on + direction code (bit i set:
+ *   the edge advances on axis i) - equal keys <=> same vertex, bit-identical position, so an indexed watertight
+ *   mesh is one integer sort away.  *count_dev always receives the full number of triangles; those beyond capacity
+ *   are dropped.  No atomics: the triangle order is a pure function of the volume. */
+size_t ojf_mesh_workspace_bytes(int X, int Y, int Z);
+int ojf_mesh_extract(const uint16_t *tsdf_dev, const uint16_t *weights_dev, const uint8_t *ids_dev, int X, int Y,
+                     int Z, float iso, const double *origin_host, double resolution, void *workspace_dev,
+                     size_t workspace_bytes, float *vertices_dev, uint8_t *labels_dev, uint64_t *keys_dev,
+                     uint32_t capacity, uint32_t *count_dev, ojf_stream_t stream);
+
+/* ojf_points_within: the inner loop of the reconstruction F-score (the reference quotes F-scores, README.md:6, but
+ *   holds no code for them - SURVEY.md 0.10; definition in metrics.py / mesh.py).  hit_dev[i] (or NULL) = 1 when a
+ *   point of the set lies within tau of query i, *n_hit_dev = number of such queries.  The set arrives binned:
+ *   points_sorted_dev f32[M][3] ordered by cell, cell = floor((p - grid_origin) / cell_size) per axis on a
+ *   GX x GY x GZ grid (z fastest), cell_start_dev u32[GX*GY*GZ + 1] the offsets; cell_size >= tau.  Queries outside
+ *   the grid are legal.  Distances are evaluated in f64: the counts are exact. */
+int ojf_points_within(const float *query_dev, size_t n_query, const float *points_sorted_dev,
+                      const uint32_t *cell_start_dev, const double *grid_origin_host, double cell_size, int GX, int GY,
+                      int GZ, double tau, uint8_t *hit_dev, uint32_t *n_hit_dev, ojf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

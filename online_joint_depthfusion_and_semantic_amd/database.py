@@ -227,16 +227,46 @@ class Database(torch.utils.data.Dataset):
             results[k] /= len(self.scenes_est.keys())
         return results, per_scene
 
-    # ---- IO (volumes only; mesh export is out of scope of the hot path) ---
-    def save(self, path, save_mode='tsdf', scene_id=None):
+    # ---- IO: volumes as hdf (or npy), meshes as ply from the HIP marching-tetrahedra kernel (mesh.py) ---
+    def _device_volume(self, vol, dtype):
+        if not torch.is_tensor(vol):
+            vol = torch.from_numpy(np.ascontiguousarray(vol))
+        return vol.to(device='cuda', dtype=dtype).contiguous()
+
+    def get_mesh(self, scene_id, semantics=False, palette=None):
+        """database.py:118-139: (vertices, faces, normals, rgb) of the zero level set of the estimated volume in
+        the reference's mesh frame (voxel index * voxel size, no origin).  Marching tetrahedra instead of skimage's
+        marching cubes: same surface, different triangulation (mesh.py)."""
+        from . import mesh
+        ids = self._device_volume(self.ids_est[scene_id].volume, torch.uint8) if semantics else None
+        m = mesh.extract_mesh(self._device_volume(self.scenes_est[scene_id].volume, torch.float16), ids=ids,
+                              resolution=float(self.resolution[scene_id]), palette=palette)
+        return m['vertices'], m['faces'], m['normals'], m['rgb']
+
+    def save(self, path, save_mode='tsdf', scene_id=None, palette=None):
+        """database.py:172-261: 'tsdf' (volumes), 'ply' (mesh), 'test' (volumes + mesh + label-coloured mesh whose
+        alpha channel carries the label id)."""
         if scene_id is None:
             raise NotImplementedError
-        if save_mode not in ('tsdf', 'test'):
-            raise NotImplementedError('mesh export (marching cubes / ply) is not part of this engine')
+        if save_mode not in ('tsdf', 'ply', 'test'):
+            raise ValueError('unknown save_mode {!r}'.format(save_mode))
+        base = scene_id.replace('/', '.')
+        if save_mode in ('ply', 'test'):
+            from . import mesh
+            sem = self.semantics and save_mode == 'test'
+            ids = self._device_volume(self.ids_est[scene_id].volume, torch.uint8) if sem else None
+            m = mesh.extract_mesh(self._device_volume(self.scenes_est[scene_id].volume, torch.float16), ids=ids,
+                                  resolution=float(self.resolution[scene_id]), palette=palette)
+            mesh.save_ply(os.path.join(path, base + '.ply'), m['vertices'], m['faces'], m['normals'])
+            if sem:
+                table = np.array(mesh.default_palette() if palette is None else palette, dtype=np.uint8)
+                rgba = np.concatenate([table[m['labels']], m['labels'][:, None]], axis=1)
+                mesh.save_ply(os.path.join(path, base + '_semantic.ply'), m['vertices'], m['faces'], m['normals'], rgba)
+            if save_mode == 'ply':
+                return
 
         def host(a):
             return a.detach().cpu().numpy() if torch.is_tensor(a) else a
-        base = scene_id.replace('/', '.')
         arrays = {'tsdf': ('TSDF', host(self.scenes_est[scene_id].volume)),
                   'weights': ('weights', host(self.fusion_weights[scene_id]))}
         if self.semantics:

@@ -85,7 +85,14 @@ def f_score(points_est, points_gt, tau):
 
 def reconstruction_f_score(est, gt, weights, origin, resolution, tau=None):
     """F-score of the fused TSDF against the ground-truth TSDF restricted to the observed region
-    (weights > 0), threshold tau (default: 1.5 voxels)."""
+    (weights > 0), threshold tau (default: 1.5 voxels).  Volumes that live on the device are scored there
+    (mesh.reconstruction_f_score: same definition, ojf_points_within instead of a k-d tree)."""
+    import torch
+    if torch.is_tensor(est) and est.is_cuda:
+        from . import mesh
+        dev = est.device
+        return mesh.reconstruction_f_score(est, torch.as_tensor(gt).to(dev), torch.as_tensor(weights).to(dev), origin,
+                                           resolution, tau)
     mask = np.asarray(weights) > 0
     tau = 1.5 * float(resolution) if tau is None else tau
     return f_score(surface_points(est, mask, origin, resolution), surface_points(gt, mask, origin, resolution), tau)
