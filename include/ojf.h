@@ -197,10 +197,11 @@ int ojf_mesh_extract(const uint16_t *tsdf_dev, const uint16_t *weights_dev, cons
 /* ojf_points_within: the inner loop of the reconstruction F-score (the reference quotes F-scores, README.md:6, but
  *   holds no code for them - SURVEY.md 0.10; definition in metrics.py / mesh.py).  hit_dev[i] (or NULL) = 1 when a
  *   point of the set lies within tau of query i, *n_hit_dev = number of such queries.  The set arrives binned:
- *   points_sorted_dev f32[M][3] ordered by cell, cell = floor((p - grid_origin) / cell_size) per axis on a
+ *   points_sorted_dev f64[M][3] ordered by cell, cell = floor((p - grid_origin) / cell_size) per axis on a
  *   GX x GY x GZ grid (z fastest), cell_start_dev u32[GX*GY*GZ + 1] the offsets; cell_size >= tau.  Queries outside
- *   the grid are legal.  Distances are evaluated in f64: the counts are exact. */
-int ojf_points_within(const float *query_dev, size_t n_query, const float *points_sorted_dev,
+ *   the grid are legal.  Points and distances are f64 and the test is sqrt(dx^2+dy^2+dz^2) <= tau, the comparison
+ *   scipy's cKDTree-based host metric makes, so the counts agree with it. */
+int ojf_points_within(const double *query_dev, size_t n_query, const double *points_sorted_dev,
                       const uint32_t *cell_start_dev, const double *grid_origin_host, double cell_size, int GX, int GY,
                       int GZ, double tau, uint8_t *hit_dev, uint32_t *n_hit_dev, ojf_stream_t stream);
 

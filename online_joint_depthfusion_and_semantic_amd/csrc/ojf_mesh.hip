@@ -235,14 +235,15 @@ __global__ __launch_bounds__(1024) void mesh_scan_kernel(unsigned int *blocks, u
 
 // F-score support: hit[i] = 1 when some point of a cell-sorted set lies within tau of query i.  The set is binned on
 // a grid of cell size >= tau (cell c holds points [cell_start[c], cell_start[c+1])), so the 27 cells around the
-// query's own cell hold every candidate.  One thread per query; distances in f64, so the hit counts are exact.
+// query's own cell hold every candidate.  One thread per query; f64 points and distances, compared the way
+// scipy's cKDTree.query(...)[0] <= tau compares them, so the hit counts equal the host metric's.
 struct NearArgs {
-    const float *query, *points;
+    const double *query, *points;
     const unsigned int *cell_start;
     unsigned char *hit;
     unsigned int *n_hit;
     size_t n_query;
-    double origin[3], cell, tau2;
+    double origin[3], cell, tau;
     int G[3];
 };
 
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256) void points_within_kernel(NearArgs a)
         int c[3];
         bool finite = true;
         for (int d = 0; d < 3; ++d) {
-            q[d] = (double)a.query[3 * i + d];
+            q[d] = a.query[3 * i + d];
             const double f = floor((q[d] - a.origin[d]) / a.cell);
             finite = finite && f == f && f > -2.0e9 && f < 2.0e9;
             c[d] = finite ? (int)f : 0;
@@ -270,9 +271,9 @@ __global__ __launch_bounds__(256) void points_within_kernel(NearArgs a)
                     const size_t row = ((size_t)x * a.G[1] + y) * a.G[2];  // the three z cells are adjacent in the list
                     const unsigned int lo = a.cell_start[row + z0], hi = a.cell_start[row + z1 + 1];
                     for (unsigned int j = lo; j < hi; ++j) {
-                        const double ex = (double)a.points[3 * (size_t)j] - q[0], ey = (double)a.points[3 * (size_t)j + 1] - q[1],
-                                     ez = (double)a.points[3 * (size_t)j + 2] - q[2];
-                        if (ex * ex + ey * ey + ez * ez <= a.tau2) {
+                        const double ex = a.points[3 * (size_t)j] - q[0], ey = a.points[3 * (size_t)j + 1] - q[1],
+                                     ez = a.points[3 * (size_t)j + 2] - q[2];
+                        if (sqrt(ex * ex + ey * ey + ez * ez) <= a.tau) {  // the k-d tree's test, rounding for rounding
                             found = true;
                             break;
                         }
@@ -328,7 +329,7 @@ OJF_API int ojf_mesh_extract(const uint16_t *tsdf, const uint16_t *wgt, const ui
     return check_hip(hipGetLastError(), "mesh_kernel launch");
 }
 
-OJF_API int ojf_points_within(const float *query, size_t n_query, const float *points_sorted, const uint32_t *cell_start,
+OJF_API int ojf_points_within(const double *query, size_t n_query, const double *points_sorted, const uint32_t *cell_start,
                               const double *grid_origin, double cell, int GX, int GY, int GZ, double tau, uint8_t *hit,
                               uint32_t *n_hit, ojf_stream_t stream)
 {
@@ -344,7 +345,7 @@ OJF_API int ojf_points_within(const float *query, size_t n_query, const float *p
     NearArgs a;
     a.query = query; a.points = points_sorted; a.cell_start = cell_start; a.hit = hit; a.n_hit = n_hit; a.n_query = n_query;
     a.origin[0] = grid_origin[0]; a.origin[1] = grid_origin[1]; a.origin[2] = grid_origin[2];
-    a.cell = cell; a.tau2 = tau * tau; a.G[0] = GX; a.G[1] = GY; a.G[2] = GZ;
+    a.cell = cell; a.tau = tau; a.G[0] = GX; a.G[1] = GY; a.G[2] = GZ;
     hipLaunchKernelGGL(points_within_kernel, dim3((unsigned int)((n_query + 255) / 256)), dim3(256), 0, st, a);
     return check_hip(hipGetLastError(), "points_within_kernel launch");
 }

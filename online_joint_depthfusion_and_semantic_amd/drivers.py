@@ -48,8 +48,9 @@ def _loader(dataset, scenes, shuffle=False):
     return torch.utils.data.DataLoader(torch.utils.data.Subset(dataset, idx), batch_size=1, shuffle=shuffle)
 
 
-def test_fusion(config, dataset, device, rank=0, world=1, state_dict=None, log=print):
-    """Fuses this rank's scenes frame by frame, then filter -> evaluate (test_fusion.py:73-118)."""
+def test_fusion(config, dataset, device, rank=0, world=1, state_dict=None, log=print, test_dir=None):
+    """Fuses this rank's scenes frame by frame, then filter -> evaluate (test_fusion.py:73-118) and, when ``test_dir``
+    is given, exports every scene with ``SETTINGS.save_mode`` ('test' | 'ply' | 'tsdf', test_fusion.py:120-122)."""
     shard = ShardedScenes(dataset, rank, world)
     database = Database(shard, database_config(config))
     pipeline = Pipeline(config)
@@ -66,6 +67,10 @@ def test_fusion(config, dataset, device, rank=0, world=1, state_dict=None, log=p
     results, per_scene = database.evaluate(mode='test')
     for k, v in results.items():
         log('rank {} {}: {}'.format(rank, k, v))
+    if test_dir is not None:
+        os.makedirs(test_dir, exist_ok=True)
+        for scene_id in database.scenes_est.keys():
+            database.save(path=test_dir, save_mode=config.SETTINGS.get('save_mode', 'test'), scene_id=scene_id)
     return results, per_scene, database
 
 

@@ -131,21 +131,21 @@ def surface_points(tsdf, mask, origin, resolution):
 
 
 def points_within(query, points, tau):
-    """Number of rows of ``query`` [N,3] with a row of ``points`` [M,3] within ``tau`` (cuda tensors; compared as f32
-    coordinates with f64 distances, ojf_points_within).  Returns (count, hit u8[N])."""
+    """Number of rows of ``query`` [N,3] with a row of ``points`` [M,3] within ``tau`` (cuda tensors, evaluated in
+    f64 by ojf_points_within exactly like ``cKDTree(points).query(query)[0] <= tau``).  Returns (count, hit u8[N])."""
     _lib.require_gpu()
     lib = _lib.load()
-    q = query.to(torch.float32).contiguous()
-    p = points.to(torch.float32).contiguous()
+    q = query.to(torch.float64).contiguous()
+    p = points.to(torch.float64).contiguous()
     hit = torch.zeros(q.shape[0], dtype=torch.uint8, device=q.device)
     if q.shape[0] == 0 or p.shape[0] == 0:
         return 0, hit
     cell = max(float(tau), 1e-30)
-    lo = p.to(torch.float64).min(dim=0).values
-    span = p.to(torch.float64).max(dim=0).values - lo
+    lo = p.min(dim=0).values
+    span = p.max(dim=0).values - lo
     # coarsen the bins when tau is tiny against the extent: the cell list must stay addressable
     cell = max(cell, float(span.max().item()) / 1024.0)
-    c = torch.floor((p.to(torch.float64) - lo) / cell).to(torch.int64)
+    c = torch.floor((p - lo) / cell).to(torch.int64)
     G = [int(v) + 1 for v in c.max(dim=0).values.tolist()]
     key = (c[:, 0] * G[1] + c[:, 1]) * G[2] + c[:, 2]
     key, order = torch.sort(key)

@@ -70,8 +70,15 @@ def test_test_fusion_on_a_replica_layout(cuda, tmp_path):
     ds = drivers.get_data('Replica', drivers.get_data_config(config, 'test'))
     torch.manual_seed(5)
     state = Pipeline(config)._fusion_network.state_dict()
-    results, per_scene, db = run_test_fusion(config, ds, cuda, state_dict=state, log=lambda *a: None)
+    out_dir = os.path.join(root, 'test_out')
+    results, per_scene, db = run_test_fusion(config, ds, cuda, state_dict=state, log=lambda *a: None, test_dir=out_dir)
     assert set(results) >= {'iou', 'acc', 'mse', 'mad'} and all(np.isfinite(v) for v in results.values())
+    # test_fusion.py:120-122: every scene exported with SETTINGS.save_mode (default 'test': volumes + ply)
+    from online_joint_depthfusion_and_semantic_amd import mesh
+    exported = mesh.load_ply(os.path.join(out_dir, st.scene.replace('/', '.') + '.ply'))
+    assert exported['vertices'].shape[0] > 100 and exported['faces'].max() < exported['vertices'].shape[0]
+    assert np.isfinite(exported['vertices']).all() and exported['normals'].shape == exported['vertices'].shape
+    assert any(n.startswith(st.scene.replace('/', '.') + '.tsdf.') for n in os.listdir(out_dir))
 
     pipe = Pipeline(config)
     pipe._fusion_network.load_state_dict(state)
