@@ -157,6 +157,26 @@ int ojf_conv2d(const float *in_dev, int in_stride, int in_off, float *out_dev, i
                int out_off, const ojf_conv_layer *layer_host, int act, int h, int w,
                ojf_stream_t stream);
 
+/* ---- SEGCONV: convolutions of the 2-D semantic front-end (AdapNet++) ---------------------------
+ * One prepacked layer = nn.Conv2d (groups 1, square kernel <= 7, any stride / dilation / zero padding) with what
+ * follows it in modules/adapnet.py folded in: eval-mode BatchNorm as scale_host[c_out] (multiplied into the weights)
+ * and bias_host[c_out] (either may be NULL), then per call an optional residual add (Bottleneck :33-38 /
+ * BottleneckSSMA :60-84), activation act = 0 none | 1 ReLU | 2 sigmoid (SSMA gate :331-337) and an optional
+ * elementwise product with mul_dev after the activation (x * link(x), :353).
+ * Tensors are NHWC fp32, batch 1 (torch channels_last): pointer to the first channel of pixel 0 + floats per pixel
+ * row, so channel slices of a concatenation buffer are addressed in place.  The input rows must hold
+ * round_up(c_in, 8) readable, finite channels (the extra ones meet zero weights) and be 16-byte aligned.
+ * Output size: floor((h + 2*padding - dilation*(ksize-1) - 1) / stride) + 1 per axis, like torch.
+ * Arithmetic: split-fp16 MFMA with fp32 accumulation (see ojf_net_set_arithmetic); the range guard of
+ * ojf_net_check covers these launches too.  weight_host is [c_out][c_in][ksize][ksize] (torch layout). */
+typedef struct ojf_segconv ojf_segconv;
+int ojf_segconv_create(ojf_segconv **out, const float *weight_host, const float *scale_host, const float *bias_host,
+                       int c_in, int c_out, int ksize, int stride, int dilation, int padding);
+void ojf_segconv_destroy(ojf_segconv *conv);
+int ojf_segconv_forward(const ojf_segconv *conv, const float *in_dev, int in_stride, float *out_dev, int out_stride,
+                        const float *res_dev, int res_stride, const float *mul_dev, int mul_stride, int act, int h,
+                        int w, ojf_stream_t stream);
+
 /* ---- VOLUME HELPERS (Database) -------------------------------------------------------------
  * ojf_volume_fill_*: Database.reset (modules/database.py:351-370).
  * ojf_volume_filter: Database.filter (:108-112): where weights < value: tsdf = init_value, weights = 0.

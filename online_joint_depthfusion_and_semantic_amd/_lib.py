@@ -58,6 +58,9 @@ SIGNATURES = {
     'ojf_volume_filter': (_i, [_vp, _vp, _sz, _f, _f, _vp]),
     'ojf_volume_median5_u8': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'ojf_volume_evaluate': (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
+    'ojf_segconv_create': (_i, [_c.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
+    'ojf_segconv_destroy': (None, [_vp]),
+    'ojf_segconv_forward': (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'ojf_points_within': (_i, [_vp, _sz, _vp, _vp, _vp, _d, _i, _i, _i, _d, _vp, _vp, _vp]),
     'ojf_mesh_workspace_bytes': (_sz, [_i, _i, _i]),
     'ojf_mesh_extract': (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _d, _vp, _sz, _vp, _vp, _vp, _c.c_uint32, _vp, _vp]),

@@ -1078,6 +1078,8 @@ static int *overflow_flag()
     return g_ovf_dev;
 }
 
+int *range_flag_device() { return overflow_flag(); }  // shared with ojf_seg.hip
+
 static const char *kOverflowMsg =
     "split-fp16 arithmetic: an activation or input left the fp16 range (|x| > 65504 or NaN); results since the last "
     "ojf_net_check are invalid - use ojf_net_set_arithmetic(OJF_ARITH_F32) for this network";

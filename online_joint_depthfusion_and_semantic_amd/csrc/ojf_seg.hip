@@ -1,0 +1,322 @@
+// SEGCONV: the convolutions of the 2-D semantic front-end (AdapNet++, modules/adapnet.py: ResNet-50 bottlenecks :101-130,
+// multi-scale units :12-84, eASPP :152-216, SSMA :320-354, decoder 3x3 stacks :219-317) as ONE implicit-GEMM kernel
+// family on the matrix cores, with what follows each of them in the reference folded into the launch: BatchNorm
+// (eval mode, folded into the weights and a bias), the residual add, ReLU / sigmoid.
+//
+// Layout: activations are NHWC fp32 (torch channels_last, batch 1): a pixel's channels are contiguous, so a lane's
+// B fragment of v_mfma_f32_16x16x32_f16 - 8 consecutive K values = 8 consecutive input channels of one tap - is two
+// 16-byte loads.  GEMM view: D[c_out][pixel] = sum_k W[c_out][k] X[k][pixel], k = (tap, channel); weights are the A
+// operand, packed on the host in fragment order as split fp16 halves (same arithmetic as the fusion net, see
+// ojf_net.hip: x*w = wl*xh + wh*xl + wh*xh, fp32 accumulate, rows equilibrated by a power of two).  A lane's
+// accumulator holds 4 consecutive output channels of one pixel: one 16-byte NHWC store.
+//
+// A wave computes 4 output-channel tiles (64 channels) x NW pixel tiles (16 pixels each); a block is 4 waves laid out
+// WM along the channels x 4/WM along the pixels.  Operands come straight from global memory through L1 (buffer loads,
+// out-of-image taps are out-of-range offsets that return zeros); the next K block is in flight while the current
+// one is multiplied.  Channel slices of a wider tensor (concatenations) are addressed by pointer + row stride.
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+#include "ojf_common.h"
+
+namespace ojf {
+
+int *range_flag_device();  // ojf_net.hip: the split-fp16 range guard flag (host-mapped), shared by all kernels
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split8(const f32x4 &a, const f32x4 &b, f16x8 &hi, f16x8 &lo)
+{
+    const f32x8 x = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    hi = __builtin_convertvector(x, f16x8);
+    f32x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = __builtin_fmaf((float)hi[i], -1.0f, x[i]);  // exact remainder
+    lo = __builtin_convertvector(r, f16x8);
+}
+
+__device__ __forceinline__ f32x4 mfma3(const f32x4 &wh, const f32x4 &wl, const f16x8 &xh, const f16x8 &xl, f32x4 acc)
+{
+    const f16x8 h = __builtin_bit_cast(f16x8, wh), l = __builtin_bit_cast(f16x8, wl);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(l, xh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(h, xl, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(h, xh, acc, 0, 0, 0);
+}
+
+constexpr int kMW = 4;  // output-channel tiles per wave
+
+struct SegArgs {
+    const float *in;
+    float *out;
+    const float *res;      // residual rows added before the activation, or NULL
+    const float *mul;      // rows multiplied in after the activation (SSMA gate), or NULL
+    const f32x4 *wp;       // [c_out tile][K block][hi, lo][lane]
+    const float *rinv;     // [tiles*16] inverse row scales
+    const float *bias;     // [tiles*16]
+    int in_stride, out_stride, res_stride, mul_stride;  // floats per pixel row
+    int H, W, Ho, Wo;
+    int stride, pad, dil, ksize;
+    int c8;                // groups of 8 input channels per tap
+    int n_kb;              // K blocks of 4 (tap, group) entries
+    int n_ct;              // packed output-channel tiles (multiple of kMW)
+    int c_out;
+    int act;               // 0 none, 1 ReLU, 2 sigmoid
+    int vec_store;         // rows are 16-byte aligned: float4 stores
+    unsigned in_bytes;
+    int *ovf;
+};
+
+template <int NW, int WM>
+__global__ __launch_bounds__(256) void segconv_kernel(SegArgs a)
+{
+    constexpr int WN = 4 / WM;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ct0 = ((int)blockIdx.y * WM + wave % WM) * kMW;
+    const int pt0 = ((int)blockIdx.x * WN + wave / WM) * NW;
+    const int n_pix = a.Ho * a.Wo;
+    if (ct0 >= a.n_ct || pt0 * 16 >= n_pix) return;  // wave-uniform
+    const int col = lane & 15, kg = lane >> 4;
+
+    int iy0[NW], ix0[NW];
+    bool live[NW];
+#pragma unroll
+    for (int n = 0; n < NW; ++n) {
+        const int p = (pt0 + n) * 16 + col;
+        live[n] = p < n_pix;
+        const int oy = p / a.Wo, ox = p - oy * a.Wo;
+        iy0[n] = oy * a.stride - a.pad;
+        ix0[n] = ox * a.stride - a.pad;
+    }
+    // this lane group's walk over the (tap, channel group) entries: entry kb*4 + kg of K block kb
+    int tap = kg / a.c8, cg = kg - tap * a.c8;
+    int ty = tap / a.ksize, tx = tap - ty * a.ksize;
+
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in), 0, a.in_bytes, 0x00020000);
+    const f32x4 *wlane = a.wp + (size_t)ct0 * a.n_kb * 128 + lane;
+
+    f32x4 acc[kMW][NW];
+#pragma unroll
+    for (int m = 0; m < kMW; ++m)
+#pragma unroll
+        for (int n = 0; n < NW; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 xa[NW], xb[NW], wh[kMW], wl[kMW];
+    auto fetch = [&](int kb, f32x4 (&fa)[NW], f32x4 (&fb)[NW], f32x4 (&fh)[kMW], f32x4 (&fl)[kMW]) {
+        const int dy = ty * a.dil, dx = tx * a.dil;
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            const int iy = iy0[n] + dy, ix = ix0[n] + dx;
+            const bool ok = live[n] && ty < a.ksize && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const unsigned off = ok ? (unsigned)(((iy * a.W + ix) * a.in_stride + cg * 8) * 4) : 0xfffffff0u;
+            fa[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+            fb[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off + 16u : 0xfffffff0u, 0, 0));
+        }
+#pragma unroll
+        for (int m = 0; m < kMW; ++m) {
+            const f32x4 *w = wlane + ((size_t)m * a.n_kb + kb) * 128;
+            fh[m] = w[0];
+            fl[m] = w[64];
+        }
+        cg += 4;  // next K block: four entries further
+        while (cg >= a.c8) {
+            cg -= a.c8;
+            if (++tx == a.ksize) {
+                tx = 0;
+                ++ty;
+            }
+        }
+    };
+
+    fetch(0, xa, xb, wh, wl);
+    for (int kb = 0; kb < a.n_kb; ++kb) {
+        f32x4 na[NW], nb[NW], nh[kMW], nl[kMW];
+        if (kb + 1 < a.n_kb) fetch(kb + 1, na, nb, nh, nl);
+        f16x8 xh[NW], xl[NW];
+#pragma unroll
+        for (int n = 0; n < NW; ++n) split8(xa[n], xb[n], xh[n], xl[n]);
+#pragma unroll
+        for (int m = 0; m < kMW; ++m)
+#pragma unroll
+            for (int n = 0; n < NW; ++n) acc[m][n] = mfma3(wh[m], wl[m], xh[n], xl[n], acc[m][n]);
+        if (kb + 1 < a.n_kb) {
+#pragma unroll
+            for (int n = 0; n < NW; ++n) {
+                xa[n] = na[n];
+                xb[n] = nb[n];
+            }
+#pragma unroll
+            for (int m = 0; m < kMW; ++m) {
+                wh[m] = nh[m];
+                wl[m] = nl[m];
+            }
+        }
+    }
+
+    // epilogue: lane holds output channels c .. c+3 of pixel (pt0+n)*16 + col
+    float gmax = 0.0f;
+#pragma unroll
+    for (int m = 0; m < kMW; ++m) {
+        const int c = (ct0 + m) * 16 + kg * 4;
+        if (c >= a.c_out) continue;
+        const f32x4 rv = *reinterpret_cast<const f32x4 *>(a.rinv + c), bv = *reinterpret_cast<const f32x4 *>(a.bias + c);
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            const int p = (pt0 + n) * 16 + col;
+            if (p >= n_pix) continue;
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(acc[m][n][i], rv[i], bv[i]);
+            const bool full = c + 3 < a.c_out;
+            if (a.res) {
+                const float *r = a.res + (size_t)p * a.res_stride + c;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (full || c + i < a.c_out) v[i] += r[i];
+            }
+            gmax = fmaxf(fmaxf(fmaxf(gmax, fabsf(v[0])), fmaxf(fabsf(v[1]), fabsf(v[2]))), fabsf(v[3]));
+            if (a.act == 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = v[i] < 0.0f ? 0.0f : v[i];  // keeps NaN, like torch.relu
+            } else if (a.act == 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = 1.0f / (1.0f + expf(-v[i]));
+            }
+            if (a.mul) {
+                const float *g = a.mul + (size_t)p * a.mul_stride + c;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (full || c + i < a.c_out) v[i] *= g[i];
+            }
+            float *o = a.out + (size_t)p * a.out_stride + c;
+            if (full && a.vec_store) {
+                *reinterpret_cast<f32x4 *>(o) = v;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (c + i < a.c_out) o[i] = v[i];
+            }
+        }
+    }
+    if (a.ovf && gmax > 65504.0f) *a.ovf = 1;  // a later layer would split this value: outside the fp16 range
+}
+
+inline float pow2_row_scale(float row_max)
+{
+    if (!(row_max > 0.0f) || !std::isfinite(row_max)) return 1.0f;
+    int e = 0;
+    (void)std::frexp(row_max, &e);
+    int k = 14 - e;
+    k = k > 100 ? 100 : (k < -100 ? -100 : k);
+    return std::ldexp(1.0f, k);
+}
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+}  // namespace
+}  // namespace ojf
+
+struct ojf_segconv {
+    int c_in, c_out, ksize, stride, dil, pad;
+    int c8, n_kb, n_ct;
+    ojf::f32x4 *wp;
+    float *rinv, *bias;
+};
+
+OJF_API int ojf_segconv_create(ojf_segconv **out, const float *weight, const float *scale, const float *bias, int c_in, int c_out,
+                               int ksize, int stride, int dilation, int padding)
+{
+    using namespace ojf;
+    if (!out || !weight) return fail("ojf_segconv_create: null pointer argument");
+    if (c_in < 1 || c_out < 1 || ksize < 1 || ksize > 7 || stride < 1 || dilation < 1 || padding < 0)
+        return fail("ojf_segconv_create: bad layer geometry");
+    const int taps = ksize * ksize, c8 = round_up(c_in, 8) / 8;
+    const int n_entries = taps * c8, n_kb = (n_entries + 3) / 4, n_ct = round_up((c_out + 15) / 16, kMW);
+    const size_t n_w = (size_t)c_out * c_in * taps;
+    for (size_t i = 0; i < n_w; ++i)
+        if (!std::isfinite(weight[i])) return fail("ojf_segconv_create: non-finite weight");
+    std::vector<_Float16> packed((size_t)n_ct * n_kb * 2 * 64 * 8, (_Float16)0.0f);
+    std::vector<float> rinv((size_t)n_ct * 16, 1.0f), b((size_t)n_ct * 16, 0.0f);
+    for (int oc = 0; oc < c_out; ++oc) {
+        const float s = scale ? scale[oc] : 1.0f;
+        if (!std::isfinite(s) || (bias && !std::isfinite(bias[oc]))) return fail("ojf_segconv_create: non-finite scale or bias");
+        float mx = 0.0f;
+        for (size_t i = 0; i < (size_t)c_in * taps; ++i) mx = std::fmax(mx, std::fabs(weight[(size_t)oc * c_in * taps + i] * s));
+        const float rs = pow2_row_scale(mx);
+        rinv[oc] = 1.0f / rs;
+        b[oc] = bias ? bias[oc] : 0.0f;
+        const int ct = oc / 16, row = oc % 16;
+        for (int t = 0; t < taps; ++t)
+            for (int ci = 0; ci < c_in; ++ci) {
+                const float w = weight[((size_t)oc * c_in + ci) * taps + t] * s * rs;  // BN scale folded, row equilibrated
+                const int e = t * c8 + ci / 8, j = ci % 8;                               // entry, element
+                const int kb = e / 4, kg = e % 4, lane = kg * 16 + row;
+                const _Float16 hi = (_Float16)w, lo = (_Float16)(w - (float)hi);
+                const size_t base = (((size_t)ct * n_kb + kb) * 2) * 64;
+                packed[(base + lane) * 8 + j] = hi;
+                packed[(base + 64 + lane) * 8 + j] = lo;
+            }
+    }
+    ojf_segconv *c = new ojf_segconv{c_in, c_out, ksize, stride, dilation, padding, c8, n_kb, n_ct, nullptr, nullptr, nullptr};
+    int rc = check_hip(hipMalloc(&c->wp, packed.size() * sizeof(_Float16)), "hipMalloc(segconv weights)");
+    if (!rc) rc = check_hip(hipMalloc(&c->rinv, rinv.size() * sizeof(float)), "hipMalloc(segconv rinv)");
+    if (!rc) rc = check_hip(hipMalloc(&c->bias, b.size() * sizeof(float)), "hipMalloc(segconv bias)");
+    if (!rc) rc = check_hip(hipMemcpy(c->wp, packed.data(), packed.size() * sizeof(_Float16), hipMemcpyHostToDevice), "segconv H2D");
+    if (!rc) rc = check_hip(hipMemcpy(c->rinv, rinv.data(), rinv.size() * sizeof(float), hipMemcpyHostToDevice), "segconv H2D");
+    if (!rc) rc = check_hip(hipMemcpy(c->bias, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice), "segconv H2D");
+    if (rc) {
+        (void)hipFree(c->wp); (void)hipFree(c->rinv); (void)hipFree(c->bias);
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return 0;
+}
+
+OJF_API void ojf_segconv_destroy(ojf_segconv *c)
+{
+    if (!c) return;
+    (void)hipFree(c->wp); (void)hipFree(c->rinv); (void)hipFree(c->bias);
+    delete c;
+}
+
+OJF_API int ojf_segconv_forward(const ojf_segconv *c, const float *in, int in_stride, float *out, int out_stride, const float *res,
+                                int res_stride, const float *mul, int mul_stride, int act, int h, int w, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (!c || !in || !out) return fail("ojf_segconv_forward: null pointer argument");
+    if (h < 1 || w < 1 || act < 0 || act > 2) return fail("ojf_segconv_forward: bad size or activation");
+    if (in_stride < c->c8 * 8 || in_stride % 4 || (reinterpret_cast<uintptr_t>(in) & 15))
+        return fail("ojf_segconv_forward: input rows must hold round_up(c_in, 8) channels, 16-byte aligned");
+    if (out_stride < c->c_out || (res && res_stride < c->c_out) || (mul && mul_stride < c->c_out))
+        return fail("ojf_segconv_forward: row stride smaller than c_out");
+    const int span = c->dil * (c->ksize - 1) + 1;
+    const int Ho = (h + 2 * c->pad - span) / c->stride + 1, Wo = (w + 2 * c->pad - span) / c->stride + 1;
+    if (Ho < 1 || Wo < 1) return fail("ojf_segconv_forward: empty output");
+    const size_t in_bytes = ((size_t)h * w - 1) * in_stride * 4 + (size_t)c->c8 * 32;
+    if (in_bytes >= 0xfffffff0ull) return fail("ojf_segconv_forward: input larger than 4 GB");
+    SegArgs a;
+    a.in = in; a.out = out; a.res = res; a.mul = mul; a.wp = c->wp; a.rinv = c->rinv; a.bias = c->bias;
+    a.in_stride = in_stride; a.out_stride = out_stride; a.res_stride = res_stride; a.mul_stride = mul_stride;
+    a.H = h; a.W = w; a.Ho = Ho; a.Wo = Wo; a.stride = c->stride; a.pad = c->pad; a.dil = c->dil; a.ksize = c->ksize;
+    a.c8 = c->c8; a.n_kb = c->n_kb; a.n_ct = c->n_ct; a.c_out = c->c_out; a.act = act;
+    a.vec_store = (out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) ? 1 : 0;
+    a.in_bytes = (unsigned)in_bytes;
+    a.ovf = range_flag_device();
+    hipStream_t st = as_stream(stream);
+    const int n_pt = (Ho * Wo + 15) / 16, groups = c->n_ct / kMW;  // pixel tiles, 64-channel groups
+    // block shapes: 64 ch x 128 px | 128 ch x 64 px | 256 ch x 16 px; the last two trade operand reuse for more blocks
+    const long b0 = (long)((n_pt + 7) / 8) * groups, b2 = (long)n_pt * ((groups + 3) / 4);
+    if (groups == 1 || b0 >= 512) {
+        hipLaunchKernelGGL((segconv_kernel<2, 1>), dim3((n_pt + 7) / 8, groups), dim3(256), 0, st, a);
+    } else if (groups >= 4 && b2 > b0) {
+        hipLaunchKernelGGL((segconv_kernel<1, 4>), dim3(n_pt, (groups + 3) / 4), dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((segconv_kernel<2, 2>), dim3((n_pt + 3) / 4, (groups + 1) / 2), dim3(256), 0, st, a);
+    }
+    return check_hip(hipGetLastError(), "segconv_kernel launch");
+}

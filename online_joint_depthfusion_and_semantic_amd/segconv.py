@@ -1,0 +1,81 @@
+"""Host side of the SEGCONV kernels (csrc/ojf_seg.hip, include/ojf.h ``ojf_segconv_*``): one prepacked
+``nn.Conv2d`` (+ eval-mode ``BatchNorm2d`` + residual + activation) of the AdapNet++ front-end
+(modules/adapnet.py) per object, run on NHWC (torch ``channels_last``) fp32 tensors of batch 1.
+
+No fallback: without libojf / a GPU the calls raise."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+ACT = {None: 0, 'none': 0, 'relu': 1, 'sigmoid': 2}
+
+
+def nhwc(channels, h, w, device, zero=True):
+    """[1, channels, h, w] fp32 tensor in channels_last memory (channels padded by the caller where a consumer
+    reads groups of 8)."""
+    make = torch.zeros if zero else torch.empty
+    return make((1, h, w, channels), dtype=torch.float32, device=device).permute(0, 3, 1, 2)
+
+
+def _rows(t):
+    """(pointer to channel 0 of pixel 0, floats per pixel row) of an NHWC view [1, C, H, W] (channel slices allowed)."""
+    assert t.dim() == 4 and t.shape[0] == 1 and t.dtype == torch.float32 and t.is_cuda
+    C, H, W = t.shape[1:]
+    row = t.stride(3) if W > 1 else (t.stride(2) if H > 1 else max(C, 1))
+    assert (C == 1 or t.stride(1) == 1) and (H == 1 or W == 1 or t.stride(2) == W * row), 'segconv wants NHWC (channels_last) tensors'
+    return t.data_ptr(), row
+
+
+class SegConv:
+    """``conv`` [+ ``bn`` in eval mode] prepacked for the device; call with NHWC tensors."""
+
+    def __init__(self, conv, bn=None):
+        _lib.require_gpu()
+        lib = _lib.load()
+        assert isinstance(conv, torch.nn.Conv2d) and conv.groups == 1 and conv.padding_mode == 'zeros'
+        k, s, d, p = conv.kernel_size, conv.stride, conv.dilation, conv.padding
+        assert k[0] == k[1] and s[0] == s[1] and d[0] == d[1] and p[0] == p[1], 'square geometry only'
+        w = conv.weight.detach().to('cpu', torch.float32).contiguous()
+        bias = conv.bias.detach().to('cpu', torch.float32) if conv.bias is not None else torch.zeros(w.shape[0])
+        scale = None
+        if bn is not None:  # y = (conv + b - mean) * gamma / sqrt(var + eps) + beta
+            inv = (bn.running_var.detach().cpu().float() + bn.eps).rsqrt()
+            gamma = bn.weight.detach().cpu().float() if bn.weight is not None else torch.ones_like(inv)
+            beta = bn.bias.detach().cpu().float() if bn.bias is not None else torch.zeros_like(inv)
+            scale = (gamma * inv).contiguous()
+            bias = (bias - bn.running_mean.detach().cpu().float()) * scale + beta
+        bias = bias.contiguous()
+        self.c_out, self.c_in = int(w.shape[0]), int(w.shape[1])
+        self.k, self.stride, self.dil, self.pad = int(k[0]), int(s[0]), int(d[0]), int(p[0])
+        handle = ctypes.c_void_p()
+        rc = lib.ojf_segconv_create(ctypes.byref(handle), w.data_ptr(), None if scale is None else scale.data_ptr(),
+                                    bias.data_ptr(), self.c_in, self.c_out, self.k, self.stride, self.dil, self.pad)
+        _lib.check(rc, 'ojf_segconv_create')
+        self._h, self._lib = handle, lib
+
+    def __del__(self):
+        if getattr(self, '_h', None):
+            self._lib.ojf_segconv_destroy(self._h)
+            self._h = None
+
+    def out_size(self, h, w):
+        span = self.dil * (self.k - 1) + 1
+        return (h + 2 * self.pad - span) // self.stride + 1, (w + 2 * self.pad - span) // self.stride + 1
+
+    def __call__(self, x, out=None, act=None, residual=None, mul=None):
+        """x: NHWC view [1, >=c_in, H, W] whose rows hold round_up(c_in, 8) finite channels.  out: NHWC view to
+        write (default: a fresh tensor with c_out channels, padded to a multiple of 8 with zeros)."""
+        H, W = x.shape[2:]
+        Ho, Wo = self.out_size(H, W)
+        if out is None:
+            out = nhwc((self.c_out + 7) // 8 * 8, Ho, Wo, x.device)[:, :self.c_out]
+        assert out.shape[1] == self.c_out and tuple(out.shape[2:]) == (Ho, Wo)
+        xp, xs = _rows(x)
+        op, os_ = _rows(out)
+        rp, rs = _rows(residual) if residual is not None else (None, 0)
+        mp, ms = _rows(mul) if mul is not None else (None, 0)
+        rc = self._lib.ojf_segconv_forward(self._h, xp, xs, op, os_, rp, rs, mp, ms, ACT[act], H, W, _lib.stream_ptr(x.device))
+        _lib.check(rc, 'ojf_segconv_forward')
+        return out

@@ -1,0 +1,102 @@
+"""SEGCONV (ojf_segconv_*): every convolution shape of AdapNet++ at 320x240 against torch's fp32 conv2d (+ eval
+BatchNorm, residual, activation) on the same device.  Tolerance: the split-fp16 MFMA products carry ~2^-22 relative
+error per term, fp32 accumulation order differs from MIOpen's: |err| <= 2e-5 * (sum_k |w||x| scale) - checked as
+max|err| <= 3e-5 * max|ref| + 1e-6 per layer."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def to_nhwc(x, pad_to=8):
+    from online_joint_depthfusion_and_semantic_amd.segconv import nhwc
+    c = x.shape[1]
+    buf = nhwc((c + pad_to - 1) // pad_to * pad_to, x.shape[2], x.shape[3], x.device)
+    buf[:, :c] = x
+    return buf[:, :c]
+
+
+# (c_in, c_out, k, stride, dilation, padding, h, w)  - the layer shapes of adapnet.py at a 240x320 frame
+SHAPES = [
+    (3, 64, 7, 2, 1, 3, 240, 320),      # stem
+    (64, 64, 1, 1, 1, 0, 60, 80), (64, 64, 3, 1, 1, 1, 60, 80), (64, 256, 1, 1, 1, 0, 60, 80), (256, 64, 1, 1, 1, 0, 60, 80),
+    (256, 24, 1, 1, 1, 0, 60, 80),      # skip2
+    (256, 128, 1, 1, 1, 0, 60, 80), (128, 128, 3, 2, 1, 1, 60, 80), (256, 512, 1, 2, 1, 0, 60, 80), (128, 512, 1, 1, 1, 0, 30, 40),
+    (128, 32, 3, 1, 2, 2, 30, 40),      # multi-scale halves of layer2
+    (64, 512, 1, 1, 1, 0, 30, 40), (512, 24, 1, 1, 1, 0, 30, 40),
+    (512, 256, 1, 1, 1, 0, 30, 40), (256, 256, 3, 2, 1, 1, 30, 40), (512, 1024, 1, 2, 1, 0, 30, 40), (256, 1024, 1, 1, 1, 0, 15, 20),
+    (256, 128, 3, 1, 16, 16, 15, 20), (1024, 256, 1, 1, 1, 0, 15, 20),
+    (1024, 512, 1, 1, 1, 0, 15, 20), (512, 256, 3, 1, 8, 8, 15, 20), (512, 2048, 1, 1, 1, 0, 15, 20), (1024, 2048, 1, 1, 1, 0, 15, 20),
+    (2048, 64, 1, 1, 1, 0, 15, 20), (64, 64, 3, 1, 12, 12, 15, 20), (64, 256, 1, 1, 1, 0, 15, 20), (1280, 256, 1, 1, 1, 0, 15, 20),
+    (2048, 256, 1, 1, 1, 0, 1, 1),      # eASPP image-pooling branch
+    (512, 16, 3, 1, 1, 1, 15, 20), (16, 512, 3, 1, 1, 1, 15, 20), (512, 256, 3, 1, 1, 1, 15, 20),  # SSMA res
+    (48, 4, 3, 1, 1, 1, 30, 40), (4, 48, 3, 1, 1, 1, 30, 40), (48, 24, 3, 1, 1, 1, 60, 80),         # SSMA skips
+    (280, 256, 3, 1, 1, 1, 30, 40), (256, 256, 3, 1, 1, 1, 60, 80), (256, 30, 1, 1, 1, 0, 60, 80), (256, 24, 1, 1, 1, 0, 1, 1),
+    (24, 40, 3, 1, 1, 1, 7, 5), (8, 8, 5, 3, 2, 4, 33, 17),  # odd geometry: ragged tiles, 5x5, stride 3
+]
+
+
+@pytest.mark.parametrize('shape', SHAPES, ids=lambda s: 'x'.join(map(str, s)))
+def test_conv_bn_act_matches_torch(shape):
+    from online_joint_depthfusion_and_semantic_amd.segconv import SegConv
+    cin, cout, k, s, d, p, h, w = shape
+    g = torch.Generator().manual_seed(cin * 131 + cout)
+    conv = nn.Conv2d(cin, cout, k, stride=s, dilation=d, padding=p, bias=(cout % 3 == 0)).cuda()
+    bn = nn.BatchNorm2d(cout).cuda().eval()
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / np.sqrt(cin * k * k))
+        bn.weight.copy_(torch.rand(cout, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(cout, generator=g) * 0.3)
+        bn.running_mean.copy_(torch.randn(cout, generator=g) * 0.2)
+        bn.running_var.copy_(torch.rand(cout, generator=g) * 2 + 0.1)
+    x = (torch.randn((1, cin, h, w), generator=g) * 2).cuda()
+    with torch.no_grad():
+        lin = bn(conv(x))
+        res = torch.randn(lin.shape, generator=g).cuda()
+        gate = torch.rand(lin.shape, generator=g).cuda()
+        cases = {'plain': (SegConv(conv), conv(x), {}),
+                 'bn_relu': (SegConv(conv, bn), F.relu(lin), {'act': 'relu'}),
+                 'bn_res_relu': (SegConv(conv, bn), F.relu(lin + res), {'act': 'relu', 'residual': to_nhwc(res)}),
+                 'sigmoid_mul': (SegConv(conv, bn), torch.sigmoid(lin) * gate, {'act': 'sigmoid', 'mul': to_nhwc(gate)})}
+    xin = to_nhwc(x)
+    for name, (op, want, kw) in cases.items():
+        got = op(xin, **kw)
+        assert got.shape == want.shape, name
+        err = (got - want).abs().max().item()
+        assert err <= 3e-5 * want.abs().max().item() + 1e-6, (name, err, want.abs().max().item())
+    from online_joint_depthfusion_and_semantic_amd import _lib
+    assert _lib.load().ojf_net_check(_lib.stream_ptr(x.device)) == 0  # range guard silent
+
+
+def test_channel_slices_and_guard():
+    """Concatenation by pointer + stride: two convs write halves of one buffer, a third reads a slice of it."""
+    from online_joint_depthfusion_and_semantic_amd import _lib
+    from online_joint_depthfusion_and_semantic_amd.segconv import SegConv, nhwc
+    torch.manual_seed(0)
+    a, b, c = nn.Conv2d(16, 24, 3, padding=1).cuda(), nn.Conv2d(16, 40, 1).cuda(), nn.Conv2d(40, 8, 3, padding=2, dilation=2).cuda()
+    x = torch.randn(1, 16, 21, 13).cuda()
+    xin = to_nhwc(x)
+    cat = nhwc(64, 21, 13, x.device)
+    SegConv(a)(xin, out=cat[:, :24], act='relu')
+    SegConv(b)(xin, out=cat[:, 24:], act=None)
+    with torch.no_grad():
+        want = torch.cat((F.relu(a(x)), b(x)), 1)
+        assert (cat - want).abs().max().item() <= 3e-5 * want.abs().max().item()
+        y = SegConv(c)(cat[:, 24:])
+        assert (y - c(want[:, 24:])).abs().max().item() <= 1e-4
+    lib = _lib.load()
+    # values beyond the fp16 range raise the guard instead of returning Inf silently
+    big = to_nhwc(torch.full((1, 16, 21, 13), 3.0e4).cuda())
+    with torch.no_grad():
+        a.weight.fill_(1.0)
+    SegConv(a)(big)
+    assert lib.ojf_net_check(_lib.stream_ptr(x.device)) != 0 and b'fp16 range' in lib.ojf_last_error()
+    assert lib.ojf_net_check(_lib.stream_ptr(x.device)) == 0  # cleared
+    # argument validation
+    with pytest.raises(AssertionError):
+        SegConv(a)(x)  # NCHW-contiguous input is refused
+    with pytest.raises(RuntimeError):
+        SegConv(a)(nhwc(12, 5, 5, x.device)[:, :16] if False else nhwc(20, 5, 5, x.device)[:, 1:17])  # misaligned rows
