@@ -1,0 +1,182 @@
+"""Inference engine of the AdapNet++ front-end on the SEGCONV kernels (csrc/ojf_seg.hip).
+
+``SegEngine(net)`` walks an ``adapnet.AdapNet`` module tree (the reference's ``modules/adapnet.py`` tree, same
+state_dict), prepacks every ``Conv2d`` together with the eval-mode ``BatchNorm2d`` that follows it, and runs the
+forward pass of ``AdapNet.forward`` (adapnet.py:390-415) for inference: activations stay NHWC (torch channels_last)
+fp32, every convolution + BN + residual + ReLU / sigmoid(+gate) is ONE HIP launch, concatenations are written in
+place through channel slices.  What remains on torch ops: max-pool, the two global average pools, the three
+transposed convolutions of the decoder (BN folded into their weights here), the always-on dropout quirk of
+layer3[2] (adapnet.py:80-82) and the final softmax.  The auxiliary heads (adapnet.py:299-305) do not feed the result
+and are skipped.  ~772 launches of the torch forward become ~165.
+
+The engine snapshots the weights: build it after ``load_state_dict`` (``Pipeline`` rebuilds it when the
+parameters change).  No fallback path: it needs libojf and a GPU.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import adapnet
+from .segconv import SegConv, nhwc
+
+
+def _folded_deconv(deconv, bn):
+    """(weight, bias) of ``bn(deconv(x))`` in eval mode; ConvTranspose2d weights are [c_in, c_out, k, k]."""
+    inv = (bn.running_var.detach() + bn.eps).rsqrt() * bn.weight.detach()
+    w = (deconv.weight.detach() * inv.view(1, -1, 1, 1)).contiguous(memory_format=torch.channels_last)
+    b = (deconv.bias.detach() - bn.running_mean.detach()) * inv + bn.bias.detach()
+    return w, b.contiguous()
+
+
+class _Unit:
+    """Bottleneck / BottleneckSSMA of the encoder."""
+
+    def __init__(self, m):
+        self.multi = isinstance(m, adapnet.BottleneckSSMA)
+        self.c1 = SegConv(m.conv1, m.bn1)
+        if self.multi:
+            self.c2a, self.c2b = SegConv(m.conv2a, m.bn2a), SegConv(m.conv2b, m.bn2b)
+            self.module = m  # the dropout flag is read at call time (AdapNet.no_resn50_dropout)
+        else:
+            self.c2 = SegConv(m.conv2, m.bn2)
+        self.c3 = SegConv(m.conv3, m.bn3)
+        self.down = SegConv(m.downsample[0], m.downsample[1]) if m.downsample is not None else None
+
+    def __call__(self, x):
+        idn = x if self.down is None else self.down(x)
+        y = self.c1(x, act='relu')
+        if self.multi:
+            half = self.c2a.c_out
+            cat = nhwc(2 * half, y.shape[2], y.shape[3], x.device, zero=False)
+            self.c2a(y, out=cat[:, :half], act='relu')
+            self.c2b(y, out=cat[:, half:], act='relu')
+            y = self.c3(cat, residual=idn, act='relu')
+            return F.dropout(y, p=0.5, training=True) if self.module.dropout else y
+        y = self.c2(y, act='relu')
+        return self.c3(y, residual=idn, act='relu')
+
+
+class _Encoder:
+    def __init__(self, m):
+        r = m.res_n50_enc
+        self.stem = SegConv(r.conv1, r.bn1)
+        self.layers = [[_Unit(u) for u in layer] for layer in (r.layer1, r.layer2, r.layer3, r.layer4)]
+        self.skip2 = SegConv(m.enc_skip2_conv, m.enc_skip2_conv_bn)
+        self.skip1 = SegConv(m.enc_skip1_conv, m.enc_skip1_conv_bn)
+
+    def __call__(self, image, skip2_out, skip1_out):
+        """image [1,3,H,W] (any layout).  The two skip tensors are written into the given NHWC slices."""
+        x = nhwc(8, image.shape[2], image.shape[3], image.device)  # stem reads groups of 8 channels: 3 + 5 zeros
+        x[:, :3] = image
+        x = self.stem(x[:, :3], act='relu')
+        x = F.max_pool2d(x, 3, stride=2, padding=1).contiguous(memory_format=torch.channels_last)
+        for u in self.layers[0]:
+            x = u(x)
+        self.skip2(x, out=skip2_out)
+        for u in self.layers[1]:
+            x = u(x)
+        self.skip1(x, out=skip1_out)
+        for layer in self.layers[2:]:
+            for u in layer:
+                x = u(x)
+        return x
+
+
+class _EASPP:
+    def __init__(self, m):
+        self.b1 = SegConv(m.branch1_conv, m.branch1_bn)
+        self.cascades = [[SegConv(seq[i], seq[i + 1]) for i in (0, 3, 6, 9)] for seq in m.branch234]
+        self.b5 = SegConv(m.branch5_conv)  # its BatchNorm is unused by the reference (adapnet.py:209-210)
+        self.fin = SegConv(m.eASPP_fin_conv, m.eASPP_fin_bn)
+
+    def __call__(self, x, out):
+        h, w = x.shape[2:]
+        n = self.b1.c_out
+        cat = nhwc(5 * n, h, w, x.device, zero=False)
+        self.b1(x, out=cat[:, :n], act='relu')
+        for i, convs in enumerate(self.cascades):
+            y = x
+            for c in convs[:-1]:
+                y = c(y, act='relu')
+            convs[-1](y, out=cat[:, (i + 1) * n:(i + 2) * n], act='relu')
+        pooled = x.mean(dim=(2, 3), keepdim=True).contiguous(memory_format=torch.channels_last)
+        cat[:, 4 * n:] = self.b5(pooled, act='relu')  # bilinear upsampling of a 1x1 map = broadcast
+        return self.fin(cat, out=out, act='relu')
+
+
+class _SSMA:
+    def __init__(self, m):
+        self.squeeze, self.excite = SegConv(m.link[0]), SegConv(m.link[2])
+        self.final = SegConv(m.final_conv[0], m.final_conv[1])
+
+    def __call__(self, cat, out=None):
+        """cat: NHWC tensor already holding (x1, x2) along the channels."""
+        gate = self.excite(self.squeeze(cat, act='relu'), act='sigmoid', mul=cat)  # x * link(x)
+        return self.final(gate, out=out)
+
+
+class SegEngine:
+    def __init__(self, net):
+        assert isinstance(net, adapnet.AdapNet) and not net.training, 'SegEngine: an AdapNet in eval() mode'
+        self.fusion, self.n_classes = net.fusion, net.n_classes
+        self.enc1 = _Encoder(net.encoder_mod1)
+        if self.fusion:
+            self.enc2 = _Encoder(net.encoder_mod2)
+            self.aspp1, self.aspp2 = _EASPP(net.eASPP_mod1), _EASPP(net.eASPP_mod2)
+            self.ssma_res, self.ssma_s1, self.ssma_s2 = _SSMA(net.ssma_res), _SSMA(net.ssma_s1), _SSMA(net.ssma_s2)
+        else:
+            self.aspp1 = _EASPP(net.eASPP)
+        d = net.decoder
+        self.deconv1 = (_folded_deconv(d.deconv1, d.deconv1_bn), d.deconv1)
+        self.stage2 = [SegConv(d.stage2[0], d.stage2[1]), SegConv(d.stage2[3], d.stage2[4])]
+        self.deconv2 = (_folded_deconv(d.stage2[6], d.stage2[7]), d.stage2[6])
+        self.stage3 = [SegConv(d.stage3[0], d.stage3[1]), SegConv(d.stage3[3], d.stage3[4]), SegConv(d.stage3[6], d.stage3[7])]
+        self.deconv3 = (_folded_deconv(d.stage3[8], d.stage3[9]), d.stage3[8])
+        self.fuse1, self.fuse2 = SegConv(d.fuse_conv1), SegConv(d.fuse_conv2)
+
+    @staticmethod
+    def _deconv(x, packed, relu):
+        (w, b), m = packed
+        y = F.conv_transpose2d(x, w, b, stride=m.stride, padding=m.padding)
+        y = y.contiguous(memory_format=torch.channels_last)
+        return y.relu_() if relu else y
+
+    def _skip(self, x, skip, conv, out):
+        """Decoder._skip (adapnet.py:292-296): with two modalities the skip is gated by the pooled decoder state."""
+        if not self.fusion:
+            out.copy_(skip)
+            return
+        pooled = x.mean(dim=(2, 3), keepdim=True).contiguous(memory_format=torch.channels_last)
+        torch.mul(conv(pooled, act='relu'), skip, out=out)
+
+    def forward(self, mod1, mod2=None):
+        """Logits [1, n_classes, H, W] (channels_last memory) = AdapNet.forward(...)[0]."""
+        dev = mod1.device
+        H, W = mod1.shape[2:]
+        assert mod1.shape[0] == 1 and H % 16 == 0 and W % 16 == 0, 'SegEngine: batch 1, frame sides multiples of 16'
+        h4, w4, h8, w8, h16, w16 = H // 4, W // 4, H // 8, W // 8, H // 16, W // 16
+        k = 2 if self.fusion else 1
+        s2 = nhwc(24 * k, h4, w4, dev, zero=False)   # skip2 of both modalities side by side = SSMA's concatenation
+        s1 = nhwc(24 * k, h8, w8, dev, zero=False)
+        top = nhwc(256 * k, h16, w16, dev, zero=False)
+        x = self.enc1(mod1, s2[:, :24], s1[:, :24])
+        self.aspp1(x, top[:, :256])
+        cat2 = nhwc(280, h8, w8, dev, zero=False)    # decoder stage 2 input: (deconv1 output, skip1)
+        cat3 = nhwc(280, h4, w4, dev, zero=False)    # decoder stage 3 input: (stage 2 output, skip2)
+        if self.fusion:
+            x2 = self.enc2(mod2, s2[:, 24:], s1[:, 24:])
+            self.aspp2(x2, top[:, 256:])
+            skip2 = self.ssma_s2(s2)
+            skip1 = self.ssma_s1(s1)
+            x = self.ssma_res(top)
+        else:
+            skip2, skip1, x = s2, s1, top
+        cat2[:, :256] = self._deconv(x, self.deconv1, relu=True)
+        self._skip(cat2[:, :256], skip1, self.fuse1, cat2[:, 256:])
+        y = self.stage2[1](self.stage2[0](cat2, act='relu'), act='relu')
+        cat3[:, :256] = self._deconv(y, self.deconv2, relu=False)
+        self._skip(cat3[:, :256], skip2, self.fuse2, cat3[:, 256:])
+        y = self.stage3[1](self.stage3[0](cat3, act='relu'), act='relu')
+        y = self.stage3[2](y)
+        return self._deconv(y, self.deconv3, relu=False)
+
+    __call__ = forward

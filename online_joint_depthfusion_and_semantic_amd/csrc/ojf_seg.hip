@@ -10,10 +10,10 @@
 // ojf_net.hip: x*w = wl*xh + wh*xl + wh*xh, fp32 accumulate, rows equilibrated by a power of two).  A lane's
 // accumulator holds 4 consecutive output channels of one pixel: one 16-byte NHWC store.
 //
-// A wave computes 4 output-channel tiles (64 channels) x NW pixel tiles (16 pixels each); a block is 4 waves laid out
-// WM along the channels x 4/WM along the pixels.  Operands come straight from global memory through L1 (buffer loads,
-// out-of-image taps are out-of-range offsets that return zeros); the next K block is in flight while the current
-// one is multiplied.  Channel slices of a wider tensor (concatenations) are addressed by pointer + row stride.
+// A wave computes 4 output-channel tiles (64 channels) x NW pixel tiles (16 pixels each); a block is 4 waves, either
+// laid out WM along the channels x 4/WM along the pixels, or - for the layers with few pixels - sharing one tile pair
+// and splitting K four ways (LDS reduction, fixed order).  Operands come straight from global memory through L1
+// (buffer loads, out-of-image taps are out-of-range offsets that return zeros), three K blocks in flight per wave.  Channel slices of a wider tensor (concatenations) are addressed by pointer + row stride.
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -71,16 +71,27 @@ struct SegArgs {
     int *ovf;
 };
 
-template <int NW, int WM>
+constexpr int kDepth = 3;  // K blocks in flight per wave: a cold weight fetch costs ~1 us, the MFMAs of a block ~0.1 us
+
+// SPLITK = false: the 4 waves of a block take different (channel group, pixel tiles) pairs: WM along the channels.
+// SPLITK = true (layers with few pixels: too few waves to hide the weight stream otherwise): the 4 waves share ONE
+// pair and each walks a quarter of K; partial sums meet in LDS and wave 0 runs the epilogue.  Fixed order: deterministic.
+template <int NW, int WM, bool SPLITK>
 __global__ __launch_bounds__(256) void segconv_kernel(SegArgs a)
 {
-    constexpr int WN = 4 / WM;
+    constexpr int WN = SPLITK ? 1 : 4 / WM;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ct0 = ((int)blockIdx.y * WM + wave % WM) * kMW;
-    const int pt0 = ((int)blockIdx.x * WN + wave / WM) * NW;
+    const int ct0 = SPLITK ? (int)blockIdx.y * kMW : ((int)blockIdx.y * WM + wave % WM) * kMW;
+    const int pt0 = SPLITK ? (int)blockIdx.x * NW : ((int)blockIdx.x * WN + wave / WM) * NW;
     const int n_pix = a.Ho * a.Wo;
-    if (ct0 >= a.n_ct || pt0 * 16 >= n_pix) return;  // wave-uniform
+    if (!SPLITK && (ct0 >= a.n_ct || pt0 * 16 >= n_pix)) return;  // wave-uniform
     const int col = lane & 15, kg = lane >> 4;
+    int kb0 = 0, kb1 = a.n_kb;
+    if constexpr (SPLITK) {
+        const int per = (a.n_kb + 3) / 4;
+        kb0 = wave * per;
+        kb1 = kb0 + per < a.n_kb ? kb0 + per : a.n_kb;
+    }
 
     int iy0[NW], ix0[NW];
     bool live[NW];
@@ -93,7 +104,8 @@ __global__ __launch_bounds__(256) void segconv_kernel(SegArgs a)
         ix0[n] = ox * a.stride - a.pad;
     }
     // this lane group's walk over the (tap, channel group) entries: entry kb*4 + kg of K block kb
-    int tap = kg / a.c8, cg = kg - tap * a.c8;
+    const int e0 = kb0 * 4 + kg;
+    int tap = e0 / a.c8, cg = e0 - tap * a.c8;
     int ty = tap / a.ksize, tx = tap - ty * a.ksize;
 
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in), 0, a.in_bytes, 0x00020000);
@@ -105,9 +117,15 @@ __global__ __launch_bounds__(256) void segconv_kernel(SegArgs a)
 #pragma unroll
         for (int n = 0; n < NW; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    f32x4 xa[NW], xb[NW], wh[kMW], wl[kMW];
+    f32x4 xa[kDepth][NW], xb[kDepth][NW], wh[kDepth][kMW], wl[kDepth][kMW];
     auto fetch = [&](int kb, f32x4 (&fa)[NW], f32x4 (&fb)[NW], f32x4 (&fh)[kMW], f32x4 (&fl)[kMW]) {
         const int dy = ty * a.dil, dx = tx * a.dil;
+#pragma unroll
+        for (int m = 0; m < kMW; ++m) {
+            const f32x4 *w = wlane + ((size_t)m * a.n_kb + kb) * 128;
+            fh[m] = w[0];
+            fl[m] = w[64];
+        }
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
             const int iy = iy0[n] + dy, ix = ix0[n] + dx;
@@ -115,12 +133,6 @@ __global__ __launch_bounds__(256) void segconv_kernel(SegArgs a)
             const unsigned off = ok ? (unsigned)(((iy * a.W + ix) * a.in_stride + cg * 8) * 4) : 0xfffffff0u;
             fa[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
             fb[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off + 16u : 0xfffffff0u, 0, 0));
-        }
-#pragma unroll
-        for (int m = 0; m < kMW; ++m) {
-            const f32x4 *w = wlane + ((size_t)m * a.n_kb + kb) * 128;
-            fh[m] = w[0];
-            fl[m] = w[64];
         }
         cg += 4;  // next K block: four entries further
         while (cg >= a.c8) {
@@ -132,29 +144,45 @@ __global__ __launch_bounds__(256) void segconv_kernel(SegArgs a)
         }
     };
 
-    fetch(0, xa, xb, wh, wl);
-    for (int kb = 0; kb < a.n_kb; ++kb) {
-        f32x4 na[NW], nb[NW], nh[kMW], nl[kMW];
-        if (kb + 1 < a.n_kb) fetch(kb + 1, na, nb, nh, nl);
-        f16x8 xh[NW], xl[NW];
 #pragma unroll
-        for (int n = 0; n < NW; ++n) split8(xa[n], xb[n], xh[n], xl[n]);
+    for (int s = 0; s < kDepth; ++s)
+        if (kb0 + s < kb1) fetch(kb0 + s, xa[s], xb[s], wh[s], wl[s]);
+    for (int kb = kb0; kb < kb1; kb += kDepth) {
 #pragma unroll
-        for (int m = 0; m < kMW; ++m)
+        for (int s = 0; s < kDepth; ++s) {
+            if (kb + s < kb1) {  // wave-uniform
+                f16x8 xh[NW], xl[NW];
 #pragma unroll
-            for (int n = 0; n < NW; ++n) acc[m][n] = mfma3(wh[m], wl[m], xh[n], xl[n], acc[m][n]);
-        if (kb + 1 < a.n_kb) {
+                for (int n = 0; n < NW; ++n) split8(xa[s][n], xb[s][n], xh[n], xl[n]);
 #pragma unroll
-            for (int n = 0; n < NW; ++n) {
-                xa[n] = na[n];
-                xb[n] = nb[n];
-            }
+                for (int m = 0; m < kMW; ++m)
 #pragma unroll
-            for (int m = 0; m < kMW; ++m) {
-                wh[m] = nh[m];
-                wl[m] = nl[m];
+                    for (int n = 0; n < NW; ++n) acc[m][n] = mfma3(wh[s][m], wl[s][m], xh[n], xl[n], acc[m][n]);
+                if (kb + s + kDepth < kb1) fetch(kb + s + kDepth, xa[s], xb[s], wh[s], wl[s]);
             }
         }
+    }
+
+    if constexpr (SPLITK) {
+        __shared__ f32x4 part[3][kMW * NW][64];
+        if (wave) {
+#pragma unroll
+            for (int m = 0; m < kMW; ++m)
+#pragma unroll
+                for (int n = 0; n < NW; ++n) part[wave - 1][m * NW + n][lane] = acc[m][n];
+        }
+        __syncthreads();
+        if (wave) return;
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int m = 0; m < kMW; ++m)
+#pragma unroll
+                for (int n = 0; n < NW; ++n) {
+                    const f32x4 q = part[w][m * NW + n][lane];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[m][n][i] += q[i];
+                }
     }
 
     // epilogue: lane holds output channels c .. c+3 of pixel (pt0+n)*16 + col
@@ -309,14 +337,16 @@ OJF_API int ojf_segconv_forward(const ojf_segconv *c, const float *in, int in_st
     a.ovf = range_flag_device();
     hipStream_t st = as_stream(stream);
     const int n_pt = (Ho * Wo + 15) / 16, groups = c->n_ct / kMW;  // pixel tiles, 64-channel groups
-    // block shapes: 64 ch x 128 px | 128 ch x 64 px | 256 ch x 16 px; the last two trade operand reuse for more blocks
-    const long b0 = (long)((n_pt + 7) / 8) * groups, b2 = (long)n_pt * ((groups + 3) / 4);
-    if (groups == 1 || b0 >= 512) {
-        hipLaunchKernelGGL((segconv_kernel<2, 1>), dim3((n_pt + 7) / 8, groups), dim3(256), 0, st, a);
-    } else if (groups >= 4 && b2 > b0) {
-        hipLaunchKernelGGL((segconv_kernel<1, 4>), dim3(n_pt, (groups + 3) / 4), dim3(256), 0, st, a);
+    // Enough independent waves (>= 4 per CU) to hide the operand latency: waves own their (channels, pixels) pair.
+    // Otherwise the four waves of a block split K (when K is long enough to be worth the LDS reduction).
+    const long waves2 = (long)groups * ((n_pt + 1) / 2);
+    if (waves2 >= 1024 || c->n_kb < 8) {
+        if (groups == 1) hipLaunchKernelGGL((segconv_kernel<2, 1, false>), dim3((n_pt + 7) / 8, 1), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((segconv_kernel<2, 2, false>), dim3((n_pt + 3) / 4, (groups + 1) / 2), dim3(256), 0, st, a);
+    } else if (waves2 >= 256) {
+        hipLaunchKernelGGL((segconv_kernel<2, 1, true>), dim3((n_pt + 1) / 2, groups), dim3(256), 0, st, a);
     } else {
-        hipLaunchKernelGGL((segconv_kernel<2, 2>), dim3((n_pt + 3) / 4, (groups + 1) / 2), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((segconv_kernel<1, 1, true>), dim3(n_pt, groups), dim3(256), 0, st, a);
     }
     return check_hip(hipGetLastError(), "segconv_kernel launch");
 }

@@ -70,7 +70,7 @@ class SegConv:
         H, W = x.shape[2:]
         Ho, Wo = self.out_size(H, W)
         if out is None:
-            out = nhwc((self.c_out + 7) // 8 * 8, Ho, Wo, x.device)[:, :self.c_out]
+            out = nhwc((self.c_out + 7) // 8 * 8, Ho, Wo, x.device, zero=self.c_out % 8 != 0)[:, :self.c_out]
         assert out.shape[1] == self.c_out and tuple(out.shape[2:]) == (Ho, Wo)
         xp, xs = _rows(x)
         op, os_ = _rows(out)

@@ -1,0 +1,39 @@
+"""Profiling / bring-up helper (not a test): SegEngine vs the torch AdapNet module at 320x240."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from online_joint_depthfusion_and_semantic_amd import _lib
+from online_joint_depthfusion_and_semantic_amd.adapnet import AdapNet
+from online_joint_depthfusion_and_semantic_amd.adapnet_engine import SegEngine
+from online_joint_depthfusion_and_semantic_amd.config import default_config
+dev = torch.device('cuda:0')
+cfg = default_config(240, 320, semantics=True)
+torch.manual_seed(0)
+net = AdapNet(cfg.SEMANTIC_2D_MODEL).to(dev).eval()
+net.no_resn50_dropout()
+img = torch.randn(1, 3, 240, 320, device=dev); dep = torch.rand(1, 3, 240, 320, device=dev) * 3
+with torch.no_grad():
+    ref = net(img, dep)[0]
+    eng = SegEngine(net)
+    out = eng(img, dep)
+    torch.cuda.synchronize()
+    print('guard rc', _lib.load().ojf_net_check(_lib.stream_ptr(dev)))
+    print('ref absmax %.3e  out absmax %.3e  max err %.3e  rel %.3e' % (ref.abs().max(), out.abs().max(), (ref - out).abs().max(), (ref - out).abs().max() / ref.abs().max()))
+    a, b = torch.softmax(ref, 1).max(1), torch.softmax(out, 1).max(1)
+    print('score err %.3e  id agreement %.5f' % ((a[0] - b[0]).abs().max(), (a[1] == b[1]).float().mean()))
+
+    def timeit(fn, reps=30):
+        for _ in range(5): fn()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(reps): fn()
+        torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps * 1e3
+    print('torch eager %.2f ms   engine eager %.2f ms' % (timeit(lambda: net(img, dep)), timeit(lambda: eng(img, dep))))
+    s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3): eng(img, dep)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        res = torch.softmax(eng(img, dep), 1).max(1)
+    print('engine graph replay %.2f ms' % timeit(lambda: g.replay()))
+    g.replay(); torch.cuda.synchronize()
+    print('graph score err %.3e' % (res[0] - a[0]).abs().max())
