@@ -71,14 +71,16 @@ struct SegArgs {
     int *ovf;
 };
 
-constexpr int kDepth = 3;  // K blocks in flight per wave: a cold weight fetch costs ~1 us, the MFMAs of a block ~0.1 us
 
-// SPLITK = false: the 4 waves of a block take different (channel group, pixel tiles) pairs: WM along the channels.
-// SPLITK = true (layers with few pixels: too few waves to hide the weight stream otherwise): the 4 waves share ONE
-// pair and each walks a quarter of K; partial sums meet in LDS and wave 0 runs the epilogue.  Fixed order: deterministic.
-template <int NW, int WM, bool SPLITK>
-__global__ __launch_bounds__(256) void segconv_kernel(SegArgs a)
+// KS = 1: the 4 waves of a block take different (channel group, pixel tiles) pairs: WM along the channels.
+// KS = 4 | 8 (layers with few pixels: too few waves to hide the weight stream otherwise): the KS waves of a block share
+// ONE pair and each walks 1/KS of K; partial sums meet in LDS and wave 0 runs the epilogue.  Fixed order: deterministic.
+// Measured on the 15x20 maps of layer3/4: parallelism beats operand reuse (NW = 1: 2.33 ms per frame, 2: 2.69, 4: 3.69).
+// kDepth = K blocks in flight per wave (a cold weight fetch costs ~1 us, the MFMAs of a block ~0.1 us).
+template <int NW, int WM, int KS, int kDepth>
+__global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void segconv_kernel(SegArgs a)
 {
+    constexpr bool SPLITK = KS > 1;  // KS waves of a block split K
     constexpr int WN = SPLITK ? 1 : 4 / WM;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ct0 = SPLITK ? (int)blockIdx.y * kMW : ((int)blockIdx.y * WM + wave % WM) * kMW;
@@ -88,8 +90,9 @@ __global__ __launch_bounds__(256) void segconv_kernel(SegArgs a)
     const int col = lane & 15, kg = lane >> 4;
     int kb0 = 0, kb1 = a.n_kb;
     if constexpr (SPLITK) {
-        const int per = (a.n_kb + 3) / 4;
+        const int per = (a.n_kb + KS - 1) / KS;
         kb0 = wave * per;
+        kb0 = kb0 < a.n_kb ? kb0 : a.n_kb;
         kb1 = kb0 + per < a.n_kb ? kb0 + per : a.n_kb;
     }
 
@@ -118,18 +121,23 @@ __global__ __launch_bounds__(256) void segconv_kernel(SegArgs a)
         for (int n = 0; n < NW; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     f32x4 xa[kDepth][NW], xb[kDepth][NW], wh[kDepth][kMW], wl[kDepth][kMW];
+    // Branch-free on purpose: a conditional around the loads makes the compiler drain every outstanding load at the
+    // join (s_waitcnt vmcnt(0)), which serialises the pipeline.  K blocks past the end fetch zeros (activations) and
+    // the last valid weights (finite), so they add exact zeros.
     auto fetch = [&](int kb, f32x4 (&fa)[NW], f32x4 (&fb)[NW], f32x4 (&fh)[kMW], f32x4 (&fl)[kMW]) {
         const int dy = ty * a.dil, dx = tx * a.dil;
+        const bool in_range = kb < kb1;
+        const int kbc = kb < a.n_kb ? kb : a.n_kb - 1;
 #pragma unroll
         for (int m = 0; m < kMW; ++m) {
-            const f32x4 *w = wlane + ((size_t)m * a.n_kb + kb) * 128;
+            const f32x4 *w = wlane + ((size_t)m * a.n_kb + kbc) * 128;
             fh[m] = w[0];
             fl[m] = w[64];
         }
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
             const int iy = iy0[n] + dy, ix = ix0[n] + dx;
-            const bool ok = live[n] && ty < a.ksize && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const bool ok = in_range && live[n] && ty < a.ksize && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
             const unsigned off = ok ? (unsigned)(((iy * a.W + ix) * a.in_stride + cg * 8) * 4) : 0xfffffff0u;
             fa[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
             fb[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off + 16u : 0xfffffff0u, 0, 0));
@@ -143,28 +151,31 @@ __global__ __launch_bounds__(256) void segconv_kernel(SegArgs a)
             }
         }
     };
-
+    auto multiply = [&](const f32x4 (&fa)[NW], const f32x4 (&fb)[NW], const f32x4 (&fh)[kMW], const f32x4 (&fl)[kMW]) {
+        f16x8 xh[NW], xl[NW];
 #pragma unroll
-    for (int s = 0; s < kDepth; ++s)
-        if (kb0 + s < kb1) fetch(kb0 + s, xa[s], xb[s], wh[s], wl[s]);
-    for (int kb = kb0; kb < kb1; kb += kDepth) {
+        for (int n = 0; n < NW; ++n) split8(fa[n], fb[n], xh[n], xl[n]);
+#pragma unroll
+        for (int m = 0; m < kMW; ++m)
+#pragma unroll
+            for (int n = 0; n < NW; ++n) acc[m][n] = mfma3(fh[m], fl[m], xh[n], xl[n], acc[m][n]);
+    };
+
+    const int rounds = (kb1 - kb0 + kDepth - 1) / kDepth;  // groups of kDepth K blocks (may be 0 for an idle split-K wave)
+#pragma unroll
+    for (int s = 0; s < kDepth; ++s) fetch(kb0 + s, xa[s], xb[s], wh[s], wl[s]);
+    for (int r = 1; r < rounds; ++r) {
 #pragma unroll
         for (int s = 0; s < kDepth; ++s) {
-            if (kb + s < kb1) {  // wave-uniform
-                f16x8 xh[NW], xl[NW];
-#pragma unroll
-                for (int n = 0; n < NW; ++n) split8(xa[s][n], xb[s][n], xh[n], xl[n]);
-#pragma unroll
-                for (int m = 0; m < kMW; ++m)
-#pragma unroll
-                    for (int n = 0; n < NW; ++n) acc[m][n] = mfma3(wh[s][m], wl[s][m], xh[n], xl[n], acc[m][n]);
-                if (kb + s + kDepth < kb1) fetch(kb + s + kDepth, xa[s], xb[s], wh[s], wl[s]);
-            }
+            multiply(xa[s], xb[s], wh[s], wl[s]);
+            fetch(kb0 + r * kDepth + s, xa[s], xb[s], wh[s], wl[s]);
         }
     }
+#pragma unroll
+    for (int s = 0; s < kDepth; ++s) multiply(xa[s], xb[s], wh[s], wl[s]);
 
     if constexpr (SPLITK) {
-        __shared__ f32x4 part[3][kMW * NW][64];
+        __shared__ f32x4 part[KS - 1][kMW * NW][64];
         if (wave) {
 #pragma unroll
             for (int m = 0; m < kMW; ++m)
@@ -174,7 +185,7 @@ __global__ __launch_bounds__(256) void segconv_kernel(SegArgs a)
         __syncthreads();
         if (wave) return;
 #pragma unroll
-        for (int w = 0; w < 3; ++w)
+        for (int w = 0; w < KS - 1; ++w)
 #pragma unroll
             for (int m = 0; m < kMW; ++m)
 #pragma unroll
@@ -340,13 +351,14 @@ OJF_API int ojf_segconv_forward(const ojf_segconv *c, const float *in, int in_st
     // Enough independent waves (>= 4 per CU) to hide the operand latency: waves own their (channels, pixels) pair.
     // Otherwise the four waves of a block split K (when K is long enough to be worth the LDS reduction).
     const long waves2 = (long)groups * ((n_pt + 1) / 2);
+    static const int force_ks = getenv("OJF_SEG_KS") ? atoi(getenv("OJF_SEG_KS")) : 0;  // tuning only
     if (waves2 >= 1024 || c->n_kb < 8) {
-        if (groups == 1) hipLaunchKernelGGL((segconv_kernel<2, 1, false>), dim3((n_pt + 7) / 8, 1), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((segconv_kernel<2, 2, false>), dim3((n_pt + 3) / 4, (groups + 1) / 2), dim3(256), 0, st, a);
-    } else if (waves2 >= 256) {
-        hipLaunchKernelGGL((segconv_kernel<2, 1, true>), dim3((n_pt + 1) / 2, groups), dim3(256), 0, st, a);
+        if (groups == 1) hipLaunchKernelGGL((segconv_kernel<2, 1, 1, 3>), dim3((n_pt + 7) / 8, 1), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((segconv_kernel<2, 2, 1, 3>), dim3((n_pt + 3) / 4, (groups + 1) / 2), dim3(256), 0, st, a);
     } else {
-        hipLaunchKernelGGL((segconv_kernel<1, 1, true>), dim3(n_pt, groups), dim3(256), 0, st, a);
+        const int ks = force_ks ? force_ks : (c->n_kb >= 32 && (long)groups * n_pt < 512 ? 8 : 4);
+        if (ks == 8) hipLaunchKernelGGL((segconv_kernel<1, 1, 8, 3>), dim3(n_pt, groups), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((segconv_kernel<1, 1, 4, 3>), dim3(n_pt, groups), dim3(256), 0, st, a);
     }
     return check_hip(hipGetLastError(), "segconv_kernel launch");
 }
