@@ -77,16 +77,16 @@ struct SegArgs {
 // ONE pair and each walks 1/KS of K; partial sums meet in LDS and wave 0 runs the epilogue.  Fixed order: deterministic.
 // Measured on the 15x20 maps of layer3/4: parallelism beats operand reuse (NW = 1: 2.33 ms per frame, 2: 2.69, 4: 3.69).
 // kDepth = K blocks in flight per wave (a cold weight fetch costs ~1 us, the MFMAs of a block ~0.1 us).
-template <int NW, int WM, int KS, int kDepth>
+template <int MW, int NW, int WM, int KS, int kDepth>
 __global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void segconv_kernel(SegArgs a)
 {
     constexpr bool SPLITK = KS > 1;  // KS waves of a block split K
     constexpr int WN = SPLITK ? 1 : 4 / WM;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ct0 = SPLITK ? (int)blockIdx.y * kMW : ((int)blockIdx.y * WM + wave % WM) * kMW;
+    const int ct0 = SPLITK ? (int)blockIdx.y * MW : ((int)blockIdx.y * WM + wave % WM) * MW;
     const int pt0 = SPLITK ? (int)blockIdx.x * NW : ((int)blockIdx.x * WN + wave / WM) * NW;
     const int n_pix = a.Ho * a.Wo;
-    if (!SPLITK && (ct0 >= a.n_ct || pt0 * 16 >= n_pix)) return;  // wave-uniform
+    if (!SPLITK && (ct0 >= a.n_ct || pt0 * 16 >= n_pix)) return;  // wave-uniform (n_ct is a multiple of 4 >= MW)
     const int col = lane & 15, kg = lane >> 4;
     int kb0 = 0, kb1 = a.n_kb;
     if constexpr (SPLITK) {
@@ -114,22 +114,22 @@ __global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void segconv_kernel(SegArgs
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in), 0, a.in_bytes, 0x00020000);
     const f32x4 *wlane = a.wp + (size_t)ct0 * a.n_kb * 128 + lane;
 
-    f32x4 acc[kMW][NW];
+    f32x4 acc[MW][NW];
 #pragma unroll
-    for (int m = 0; m < kMW; ++m)
+    for (int m = 0; m < MW; ++m)
 #pragma unroll
         for (int n = 0; n < NW; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    f32x4 xa[kDepth][NW], xb[kDepth][NW], wh[kDepth][kMW], wl[kDepth][kMW];
+    f32x4 xa[kDepth][NW], xb[kDepth][NW], wh[kDepth][MW], wl[kDepth][MW];
     // Branch-free on purpose: a conditional around the loads makes the compiler drain every outstanding load at the
     // join (s_waitcnt vmcnt(0)), which serialises the pipeline.  K blocks past the end fetch zeros (activations) and
     // the last valid weights (finite), so they add exact zeros.
-    auto fetch = [&](int kb, f32x4 (&fa)[NW], f32x4 (&fb)[NW], f32x4 (&fh)[kMW], f32x4 (&fl)[kMW]) {
+    auto fetch = [&](int kb, f32x4 (&fa)[NW], f32x4 (&fb)[NW], f32x4 (&fh)[MW], f32x4 (&fl)[MW]) {
         const int dy = ty * a.dil, dx = tx * a.dil;
         const bool in_range = kb < kb1;
         const int kbc = kb < a.n_kb ? kb : a.n_kb - 1;
 #pragma unroll
-        for (int m = 0; m < kMW; ++m) {
+        for (int m = 0; m < MW; ++m) {
             const f32x4 *w = wlane + ((size_t)m * a.n_kb + kbc) * 128;
             fh[m] = w[0];
             fl[m] = w[64];
@@ -151,12 +151,12 @@ __global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void segconv_kernel(SegArgs
             }
         }
     };
-    auto multiply = [&](const f32x4 (&fa)[NW], const f32x4 (&fb)[NW], const f32x4 (&fh)[kMW], const f32x4 (&fl)[kMW]) {
+    auto multiply = [&](const f32x4 (&fa)[NW], const f32x4 (&fb)[NW], const f32x4 (&fh)[MW], const f32x4 (&fl)[MW]) {
         f16x8 xh[NW], xl[NW];
 #pragma unroll
         for (int n = 0; n < NW; ++n) split8(fa[n], fb[n], xh[n], xl[n]);
 #pragma unroll
-        for (int m = 0; m < kMW; ++m)
+        for (int m = 0; m < MW; ++m)
 #pragma unroll
             for (int n = 0; n < NW; ++n) acc[m][n] = mfma3(fh[m], fl[m], xh[n], xl[n], acc[m][n]);
     };
@@ -175,10 +175,10 @@ __global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void segconv_kernel(SegArgs
     for (int s = 0; s < kDepth; ++s) multiply(xa[s], xb[s], wh[s], wl[s]);
 
     if constexpr (SPLITK) {
-        __shared__ f32x4 part[KS - 1][kMW * NW][64];
+        __shared__ f32x4 part[KS - 1][MW * NW][64];
         if (wave) {
 #pragma unroll
-            for (int m = 0; m < kMW; ++m)
+            for (int m = 0; m < MW; ++m)
 #pragma unroll
                 for (int n = 0; n < NW; ++n) part[wave - 1][m * NW + n][lane] = acc[m][n];
         }
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void segconv_kernel(SegArgs
 #pragma unroll
         for (int w = 0; w < KS - 1; ++w)
 #pragma unroll
-            for (int m = 0; m < kMW; ++m)
+            for (int m = 0; m < MW; ++m)
 #pragma unroll
                 for (int n = 0; n < NW; ++n) {
                     const f32x4 q = part[w][m * NW + n][lane];
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void segconv_kernel(SegArgs
     // epilogue: lane holds output channels c .. c+3 of pixel (pt0+n)*16 + col
     float gmax = 0.0f;
 #pragma unroll
-    for (int m = 0; m < kMW; ++m) {
+    for (int m = 0; m < MW; ++m) {
         const int c = (ct0 + m) * 16 + kg * 4;
         if (c >= a.c_out) continue;
         const f32x4 rv = *reinterpret_cast<const f32x4 *>(a.rinv + c), bv = *reinterpret_cast<const f32x4 *>(a.bias + c);
@@ -351,14 +351,21 @@ OJF_API int ojf_segconv_forward(const ojf_segconv *c, const float *in, int in_st
     // Enough independent waves (>= 4 per CU) to hide the operand latency: waves own their (channels, pixels) pair.
     // Otherwise the four waves of a block split K (when K is long enough to be worth the LDS reduction).
     const long waves2 = (long)groups * ((n_pt + 1) / 2);
-    static const int force_ks = getenv("OJF_SEG_KS") ? atoi(getenv("OJF_SEG_KS")) : 0;  // tuning only
+    static const int force_mw = getenv("OJF_SEG_MW") ? atoi(getenv("OJF_SEG_MW")) : 0;  // tuning only
     if (waves2 >= 1024 || c->n_kb < 8) {
-        if (groups == 1) hipLaunchKernelGGL((segconv_kernel<2, 1, 1, 3>), dim3((n_pt + 7) / 8, 1), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((segconv_kernel<2, 2, 1, 3>), dim3((n_pt + 3) / 4, (groups + 1) / 2), dim3(256), 0, st, a);
+        if (groups == 1) hipLaunchKernelGGL((segconv_kernel<4, 2, 1, 1, 3>), dim3((n_pt + 7) / 8, 1), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((segconv_kernel<4, 2, 2, 1, 3>), dim3((n_pt + 3) / 4, (groups + 1) / 2), dim3(256), 0, st, a);
     } else {
-        const int ks = force_ks ? force_ks : (c->n_kb >= 32 && (long)groups * n_pt < 512 ? 8 : 4);
-        if (ks == 8) hipLaunchKernelGGL((segconv_kernel<1, 1, 8, 3>), dim3(n_pt, groups), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((segconv_kernel<1, 1, 4, 3>), dim3(n_pt, groups), dim3(256), 0, st, a);
+        // few pixels: the 4 waves of a block split K.  Channel tiles per block: as many as leave >= 150 blocks (measured
+        // per layer shape on the 15x20 / 30x40 maps: one CU cannot pull a block's operands faster than ~150 GB/s, so
+        // small layers want many small blocks; cross-block K splitting is not an option - the device-scope fence it
+        // needs writes back the whole L2 and doubled the frame time)
+        int mw = 4;
+        while (mw > 1 && (long)n_pt * (c->n_ct / mw) < 150) mw /= 2;
+        if (force_mw) mw = force_mw;
+        if (mw == 1) hipLaunchKernelGGL((segconv_kernel<1, 1, 1, 4, 3>), dim3(n_pt, c->n_ct), dim3(256), 0, st, a);
+        else if (mw == 2) hipLaunchKernelGGL((segconv_kernel<2, 1, 1, 4, 3>), dim3(n_pt, c->n_ct / 2), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((segconv_kernel<4, 1, 1, 4, 3>), dim3(n_pt, groups), dim3(256), 0, st, a);
     }
     return check_hip(hipGetLastError(), "segconv_kernel launch");
 }
