@@ -172,6 +172,13 @@ int ojf_conv2d(const float *in_dev, int in_stride, int in_off, float *out_dev, i
 typedef struct ojf_segconv ojf_segconv;
 int ojf_segconv_create(ojf_segconv **out, const float *weight_host, const float *scale_host, const float *bias_host,
                        int c_in, int c_out, int ksize, int stride, int dilation, int padding);
+/* nn.ConvTranspose2d(c_in, c_out, kernel 2*stride, stride, padding stride/2) - the three upsampling layers of the
+ * decoder (adapnet.py:226,236,247) - as a 3x3 convolution to stride^2 phase copies of the channels whose store does
+ * the pixel shuffle.  weight_host is [c_in][c_out][2*stride][2*stride] (torch layout); scale / bias as above.  Run it
+ * with ojf_segconv_forward: h, w are the INPUT size, out_dev is the [h*stride, w*stride] NHWC tensor; no residual /
+ * gate.  Deterministic (MIOpen's transposed convolution sums with atomics). */
+int ojf_segdeconv_create(ojf_segconv **out, const float *weight_host, const float *scale_host, const float *bias_host,
+                         int c_in, int c_out, int stride);
 void ojf_segconv_destroy(ojf_segconv *conv);
 int ojf_segconv_forward(const ojf_segconv *conv, const float *in_dev, int in_stride, float *out_dev, int out_stride,
                         const float *res_dev, int res_stride, const float *mul_dev, int mul_stride, int act, int h,

@@ -59,6 +59,7 @@ SIGNATURES = {
     'ojf_volume_median5_u8': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'ojf_volume_evaluate': (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
     'ojf_segconv_create': (_i, [_c.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
+    'ojf_segdeconv_create': (_i, [_c.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i]),
     'ojf_segconv_destroy': (None, [_vp]),
     'ojf_segconv_forward': (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'ojf_points_within': (_i, [_vp, _sz, _vp, _vp, _vp, _d, _i, _i, _i, _d, _vp, _vp, _vp]),

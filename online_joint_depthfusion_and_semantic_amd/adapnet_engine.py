@@ -4,9 +4,9 @@
 state_dict), prepacks every ``Conv2d`` together with the eval-mode ``BatchNorm2d`` that follows it, and runs the
 forward pass of ``AdapNet.forward`` (adapnet.py:390-415) for inference: activations stay NHWC (torch channels_last)
 fp32, every convolution + BN + residual + ReLU / sigmoid(+gate) is ONE HIP launch, concatenations are written in
-place through channel slices.  What remains on torch ops: max-pool, the two global average pools, the three
-transposed convolutions of the decoder (BN folded into their weights here), the always-on dropout quirk of
-layer3[2] (adapnet.py:80-82) and the final softmax.  The auxiliary heads (adapnet.py:299-305) do not feed the result
+place through channel slices, the three transposed convolutions of the decoder run on the same kernel (phase
+expansion + pixel-shuffle store: deterministic, unlike MIOpen's atomics).  What remains on torch ops: max-pool, the
+global average pools, the always-on dropout quirk of the multi-scale units (adapnet.py:80-82) and the final softmax.  The auxiliary heads (adapnet.py:299-305) do not feed the result
 and are skipped.  ~772 launches of the torch forward become ~165.
 
 The engine snapshots the weights: build it after ``load_state_dict`` (``Pipeline`` rebuilds it when the
@@ -16,15 +16,7 @@ import torch
 import torch.nn.functional as F
 
 from . import adapnet
-from .segconv import SegConv, nhwc
-
-
-def _folded_deconv(deconv, bn):
-    """(weight, bias) of ``bn(deconv(x))`` in eval mode; ConvTranspose2d weights are [c_in, c_out, k, k]."""
-    inv = (bn.running_var.detach() + bn.eps).rsqrt() * bn.weight.detach()
-    w = (deconv.weight.detach() * inv.view(1, -1, 1, 1)).contiguous(memory_format=torch.channels_last)
-    b = (deconv.bias.detach() - bn.running_mean.detach()) * inv + bn.bias.detach()
-    return w, b.contiguous()
+from .segconv import SegConv, SegDeconv, nhwc
 
 
 class _Unit:
@@ -126,19 +118,12 @@ class SegEngine:
         else:
             self.aspp1 = _EASPP(net.eASPP)
         d = net.decoder
-        self.deconv1 = (_folded_deconv(d.deconv1, d.deconv1_bn), d.deconv1)
+        self.deconv1 = SegDeconv(d.deconv1, d.deconv1_bn)
         self.stage2 = [SegConv(d.stage2[0], d.stage2[1]), SegConv(d.stage2[3], d.stage2[4])]
-        self.deconv2 = (_folded_deconv(d.stage2[6], d.stage2[7]), d.stage2[6])
+        self.deconv2 = SegDeconv(d.stage2[6], d.stage2[7])
         self.stage3 = [SegConv(d.stage3[0], d.stage3[1]), SegConv(d.stage3[3], d.stage3[4]), SegConv(d.stage3[6], d.stage3[7])]
-        self.deconv3 = (_folded_deconv(d.stage3[8], d.stage3[9]), d.stage3[8])
+        self.deconv3 = SegDeconv(d.stage3[8], d.stage3[9])
         self.fuse1, self.fuse2 = SegConv(d.fuse_conv1), SegConv(d.fuse_conv2)
-
-    @staticmethod
-    def _deconv(x, packed, relu):
-        (w, b), m = packed
-        y = F.conv_transpose2d(x, w, b, stride=m.stride, padding=m.padding)
-        y = y.contiguous(memory_format=torch.channels_last)
-        return y.relu_() if relu else y
 
     def _skip(self, x, skip, conv, out):
         """Decoder._skip (adapnet.py:292-296): with two modalities the skip is gated by the pooled decoder state."""
@@ -170,13 +155,13 @@ class SegEngine:
             x = self.ssma_res(top)
         else:
             skip2, skip1, x = s2, s1, top
-        cat2[:, :256] = self._deconv(x, self.deconv1, relu=True)
+        self.deconv1(x, out=cat2[:, :256], act='relu')
         self._skip(cat2[:, :256], skip1, self.fuse1, cat2[:, 256:])
         y = self.stage2[1](self.stage2[0](cat2, act='relu'), act='relu')
-        cat3[:, :256] = self._deconv(y, self.deconv2, relu=False)
+        self.deconv2(y, out=cat3[:, :256])
         self._skip(cat3[:, :256], skip2, self.fuse2, cat3[:, 256:])
         y = self.stage3[1](self.stage3[0](cat3, act='relu'), act='relu')
         y = self.stage3[2](y)
-        return self._deconv(y, self.deconv3, relu=False)
+        return self.deconv3(y)
 
     __call__ = forward

@@ -69,6 +69,7 @@ struct SegArgs {
     int vec_store;         // rows are 16-byte aligned: float4 stores
     unsigned in_bytes;
     int *ovf;
+    int up, up_c, up_cp;   // transposed convolution: upscale factor (1: none), real / padded channels per phase
 };
 
 
@@ -203,6 +204,17 @@ __global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void segconv_kernel(SegArgs
         const int c = (ct0 + m) * 16 + kg * 4;
         if (c >= a.c_out) continue;
         const f32x4 rv = *reinterpret_cast<const f32x4 *>(a.rinv + c), bv = *reinterpret_cast<const f32x4 *>(a.bias + c);
+        // transposed convolution: GEMM row c = (phase, channel); phase (ay, ax) of input pixel (y, x) is output pixel
+        // (y*up + ay, x*up + ax).  up_cp is a multiple of 4, so a lane's four rows share the phase.
+        int co = c, n_co = a.c_out, ay = 0, ax = 0;
+        if (a.up > 1) {
+            const int phase = c / a.up_cp;
+            co = c - phase * a.up_cp;
+            n_co = a.up_c;
+            ay = phase / a.up;
+            ax = phase - ay * a.up;
+            if (co >= n_co) continue;
+        }
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
             const int p = (pt0 + n) * 16 + col;
@@ -210,12 +222,12 @@ __global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void segconv_kernel(SegArgs
             f32x4 v;
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(acc[m][n][i], rv[i], bv[i]);
-            const bool full = c + 3 < a.c_out;
+            const bool full = co + 3 < n_co;
             if (a.res) {
                 const float *r = a.res + (size_t)p * a.res_stride + c;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (full || c + i < a.c_out) v[i] += r[i];
+                    if (full || co + i < n_co) v[i] += r[i];
             }
             gmax = fmaxf(fmaxf(fmaxf(gmax, fabsf(v[0])), fmaxf(fabsf(v[1]), fabsf(v[2]))), fabsf(v[3]));
             if (a.act == 1) {
@@ -229,15 +241,20 @@ __global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void segconv_kernel(SegArgs
                 const float *g = a.mul + (size_t)p * a.mul_stride + c;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (full || c + i < a.c_out) v[i] *= g[i];
+                    if (full || co + i < n_co) v[i] *= g[i];
             }
-            float *o = a.out + (size_t)p * a.out_stride + c;
+            size_t row = (size_t)p;
+            if (a.up > 1) {
+                const int oy = p / a.Wo, ox = p - oy * a.Wo;
+                row = ((size_t)oy * a.up + ay) * ((size_t)a.Wo * a.up) + (size_t)ox * a.up + ax;
+            }
+            float *o = a.out + row * a.out_stride + co;
             if (full && a.vec_store) {
                 *reinterpret_cast<f32x4 *>(o) = v;
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (c + i < a.c_out) o[i] = v[i];
+                    if (co + i < n_co) o[i] = v[i];
             }
         }
     }
@@ -264,6 +281,7 @@ struct ojf_segconv {
     int c8, n_kb, n_ct;
     ojf::f32x4 *wp;
     float *rinv, *bias;
+    int up, up_c, up_cp;  // ojf_segdeconv_create: upscale factor, channels per phase (real / padded to 4)
 };
 
 OJF_API int ojf_segconv_create(ojf_segconv **out, const float *weight, const float *scale, const float *bias, int c_in, int c_out,
@@ -300,7 +318,7 @@ OJF_API int ojf_segconv_create(ojf_segconv **out, const float *weight, const flo
                 packed[(base + 64 + lane) * 8 + j] = lo;
             }
     }
-    ojf_segconv *c = new ojf_segconv{c_in, c_out, ksize, stride, dilation, padding, c8, n_kb, n_ct, nullptr, nullptr, nullptr};
+    ojf_segconv *c = new ojf_segconv{c_in, c_out, ksize, stride, dilation, padding, c8, n_kb, n_ct, nullptr, nullptr, nullptr, 1, 0, 0};
     int rc = check_hip(hipMalloc(&c->wp, packed.size() * sizeof(_Float16)), "hipMalloc(segconv weights)");
     if (!rc) rc = check_hip(hipMalloc(&c->rinv, rinv.size() * sizeof(float)), "hipMalloc(segconv rinv)");
     if (!rc) rc = check_hip(hipMalloc(&c->bias, b.size() * sizeof(float)), "hipMalloc(segconv bias)");
@@ -313,6 +331,39 @@ OJF_API int ojf_segconv_create(ojf_segconv **out, const float *weight, const flo
         return rc;
     }
     *out = c;
+    return 0;
+}
+
+// ConvTranspose2d(kernel 2s, stride s, padding s/2) = a 3x3 convolution (padding 1) of the input to s*s "phase" copies
+// of the channels + a pixel shuffle (done by the kernel's store): output row oy = s*y + ay of phase ay takes input rows
+// y + dy, dy in {-1, 0, 1}, through kernel row ky = ay + s/2 - s*dy when that exists (two of the three dy do).
+OJF_API int ojf_segdeconv_create(ojf_segconv **out, const float *weight, const float *scale, const float *bias, int c_in, int c_out,
+                                 int stride)
+{
+    using namespace ojf;
+    if (!out || !weight) return fail("ojf_segdeconv_create: null pointer argument");
+    if (c_in < 1 || c_out < 1 || stride < 2 || stride % 2 || stride > 8) return fail("ojf_segdeconv_create: stride must be 2, 4, 6 or 8");
+    const int s = stride, k = 2 * s, pad = s / 2, cp = round_up(c_out, 4), rows = s * s * cp;
+    std::vector<float> w((size_t)rows * c_in * 9, 0.0f), sc((size_t)rows, 1.0f), b((size_t)rows, 0.0f);
+    for (int ay = 0; ay < s; ++ay)
+        for (int ax = 0; ax < s; ++ax)
+            for (int co = 0; co < c_out; ++co) {
+                const int r = (ay * s + ax) * cp + co;
+                sc[r] = scale ? scale[co] : 1.0f;
+                b[r] = bias ? bias[co] : 0.0f;
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int ky = ay + pad - s * dy, kx = ax + pad - s * dx;
+                        if (ky < 0 || ky >= k || kx < 0 || kx >= k) continue;
+                        for (int ci = 0; ci < c_in; ++ci)  // torch layout [c_in][c_out][k][k]
+                            w[((size_t)r * c_in + ci) * 9 + (dy + 1) * 3 + (dx + 1)] = weight[(((size_t)ci * c_out + co) * k + ky) * k + kx];
+                    }
+            }
+    int rc = ojf_segconv_create(out, w.data(), sc.data(), b.data(), c_in, rows, 3, 1, 1, 1);
+    if (rc) return rc;
+    (*out)->up = s;
+    (*out)->up_c = c_out;
+    (*out)->up_cp = cp;
     return 0;
 }
 
@@ -331,8 +382,8 @@ OJF_API int ojf_segconv_forward(const ojf_segconv *c, const float *in, int in_st
     if (h < 1 || w < 1 || act < 0 || act > 2) return fail("ojf_segconv_forward: bad size or activation");
     if (in_stride < c->c8 * 8 || in_stride % 4 || (reinterpret_cast<uintptr_t>(in) & 15))
         return fail("ojf_segconv_forward: input rows must hold round_up(c_in, 8) channels, 16-byte aligned");
-    if (out_stride < c->c_out || (res && res_stride < c->c_out) || (mul && mul_stride < c->c_out))
-        return fail("ojf_segconv_forward: row stride smaller than c_out");
+    if (c->up > 1 ? (out_stride < c->up_c || res || mul) : (out_stride < c->c_out || (res && res_stride < c->c_out) || (mul && mul_stride < c->c_out)))
+        return fail("ojf_segconv_forward: row stride smaller than c_out (or residual / gate given to a transposed convolution)");
     const int span = c->dil * (c->ksize - 1) + 1;
     const int Ho = (h + 2 * c->pad - span) / c->stride + 1, Wo = (w + 2 * c->pad - span) / c->stride + 1;
     if (Ho < 1 || Wo < 1) return fail("ojf_segconv_forward: empty output");
@@ -346,6 +397,7 @@ OJF_API int ojf_segconv_forward(const ojf_segconv *c, const float *in, int in_st
     a.vec_store = (out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) ? 1 : 0;
     a.in_bytes = (unsigned)in_bytes;
     a.ovf = range_flag_device();
+    a.up = c->up; a.up_c = c->up_c; a.up_cp = c->up_cp;
     hipStream_t st = as_stream(stream);
     const int n_pt = (Ho * Wo + 15) / 16, groups = c->n_ct / kMW;  // pixel tiles, 64-channel groups
     // Enough independent waves (>= 4 per CU) to hide the operand latency: waves own their (channels, pixels) pair.

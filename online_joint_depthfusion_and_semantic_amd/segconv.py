@@ -28,6 +28,18 @@ def _rows(t):
     return t.data_ptr(), row
 
 
+def _folded(bias, bn, n):
+    """(scale or None, bias) of eval-mode ``bn`` applied after a layer with ``bias``: y = (x + b - mean) * g / sqrt(var + eps) + beta."""
+    bias = bias.detach().to('cpu', torch.float32) if bias is not None else torch.zeros(n)
+    if bn is None:
+        return None, bias.contiguous()
+    inv = (bn.running_var.detach().cpu().float() + bn.eps).rsqrt()
+    gamma = bn.weight.detach().cpu().float() if bn.weight is not None else torch.ones_like(inv)
+    beta = bn.bias.detach().cpu().float() if bn.bias is not None else torch.zeros_like(inv)
+    scale = (gamma * inv).contiguous()
+    return scale, ((bias - bn.running_mean.detach().cpu().float()) * scale + beta).contiguous()
+
+
 class SegConv:
     """``conv`` [+ ``bn`` in eval mode] prepacked for the device; call with NHWC tensors."""
 
@@ -38,15 +50,7 @@ class SegConv:
         k, s, d, p = conv.kernel_size, conv.stride, conv.dilation, conv.padding
         assert k[0] == k[1] and s[0] == s[1] and d[0] == d[1] and p[0] == p[1], 'square geometry only'
         w = conv.weight.detach().to('cpu', torch.float32).contiguous()
-        bias = conv.bias.detach().to('cpu', torch.float32) if conv.bias is not None else torch.zeros(w.shape[0])
-        scale = None
-        if bn is not None:  # y = (conv + b - mean) * gamma / sqrt(var + eps) + beta
-            inv = (bn.running_var.detach().cpu().float() + bn.eps).rsqrt()
-            gamma = bn.weight.detach().cpu().float() if bn.weight is not None else torch.ones_like(inv)
-            beta = bn.bias.detach().cpu().float() if bn.bias is not None else torch.zeros_like(inv)
-            scale = (gamma * inv).contiguous()
-            bias = (bias - bn.running_mean.detach().cpu().float()) * scale + beta
-        bias = bias.contiguous()
+        scale, bias = _folded(conv.bias, bn, w.shape[0])
         self.c_out, self.c_in = int(w.shape[0]), int(w.shape[1])
         self.k, self.stride, self.dil, self.pad = int(k[0]), int(s[0]), int(d[0]), int(p[0])
         handle = ctypes.c_void_p()
@@ -77,5 +81,42 @@ class SegConv:
         rp, rs = _rows(residual) if residual is not None else (None, 0)
         mp, ms = _rows(mul) if mul is not None else (None, 0)
         rc = self._lib.ojf_segconv_forward(self._h, xp, xs, op, os_, rp, rs, mp, ms, ACT[act], H, W, _lib.stream_ptr(x.device))
+        _lib.check(rc, 'ojf_segconv_forward')
+        return out
+
+
+class SegDeconv:
+    """``nn.ConvTranspose2d(c_in, c_out, 2*s, stride=s, padding=s//2)`` [+ eval ``bn``] on the SEGCONV kernel
+    (``ojf_segdeconv_create``: 3x3 convolution to s*s phase copies + pixel-shuffle store).  Deterministic."""
+
+    def __init__(self, deconv, bn=None):
+        _lib.require_gpu()
+        lib = _lib.load()
+        assert isinstance(deconv, torch.nn.ConvTranspose2d) and deconv.groups == 1
+        s = deconv.stride[0]
+        assert deconv.stride == (s, s) and deconv.kernel_size == (2 * s, 2 * s) and deconv.padding == (s // 2, s // 2) \
+            and deconv.output_padding == (0, 0) and deconv.dilation == (1, 1), 'kernel 2s, stride s, padding s/2 only'
+        w = deconv.weight.detach().to('cpu', torch.float32).contiguous()  # [c_in, c_out, k, k]
+        self.c_in, self.c_out, self.up = int(w.shape[0]), int(w.shape[1]), int(s)
+        scale, bias = _folded(deconv.bias, bn, self.c_out)
+        handle = ctypes.c_void_p()
+        rc = lib.ojf_segdeconv_create(ctypes.byref(handle), w.data_ptr(), None if scale is None else scale.data_ptr(),
+                                      bias.data_ptr(), self.c_in, self.c_out, self.up)
+        _lib.check(rc, 'ojf_segdeconv_create')
+        self._h, self._lib = handle, lib
+
+    def __del__(self):
+        if getattr(self, '_h', None):
+            self._lib.ojf_segconv_destroy(self._h)
+            self._h = None
+
+    def __call__(self, x, out=None, act=None):
+        H, W = x.shape[2:]
+        if out is None:
+            out = nhwc((self.c_out + 7) // 8 * 8, H * self.up, W * self.up, x.device, zero=self.c_out % 8 != 0)[:, :self.c_out]
+        assert out.shape[1] == self.c_out and tuple(out.shape[2:]) == (H * self.up, W * self.up)
+        xp, xs = _rows(x)
+        op, os_ = _rows(out)
+        rc = self._lib.ojf_segconv_forward(self._h, xp, xs, op, os_, None, 0, None, 0, ACT[act], H, W, _lib.stream_ptr(x.device))
         _lib.check(rc, 'ojf_segconv_forward')
         return out

@@ -88,8 +88,7 @@ def test_dropout_quirk_is_kept():
             if hasattr(m, 'dropout') and isinstance(m.dropout, bool):
                 m.dropout = False  # the flags are read at call time, like the module does
         a, b = eng(img, dep), eng(img, dep)
-        # equal up to the transposed convolutions, which stay on MIOpen (its split-K kernels sum with atomics)
-        assert (a - b).abs().max().item() <= 1e-5 * a.abs().max().item()
+        assert torch.equal(a, b)  # every kernel of the engine sums in a fixed order
 
 
 def test_pipeline_uses_the_engine_and_follows_weight_updates(cuda):
@@ -125,8 +124,7 @@ def test_pipeline_uses_the_engine_and_follows_weight_updates(cuda):
             s, i = pipe._segmentation_graph(batch)
             assert pipe._seg_graph['graph'] is not None
             es, ei = pipe._segmentation(batch).max(dim=-1)
-            # the transposed convolutions (MIOpen, atomics) are not run-to-run reproducible: scores agree to ~1e-4
-            assert (s - es).abs().max().item() < 3e-4 and (i == ei).float().mean().item() > 0.999
+            assert torch.equal(s, es) and torch.equal(i, ei)  # same kernels, fixed summation order
             for p in pipe._semantic_2d_network.decoder.parameters():
                 p.mul_(0.9)
     with pytest.raises(Exception):  # training mode never routes through the inference engine silently

@@ -71,6 +71,35 @@ def test_conv_bn_act_matches_torch(shape):
     assert _lib.load().ojf_net_check(_lib.stream_ptr(x.device)) == 0  # range guard silent
 
 
+@pytest.mark.parametrize('cin,cout,stride,h,w', [(256, 256, 2, 15, 20), (256, 256, 2, 30, 40), (30, 30, 4, 60, 80), (12, 12, 4, 16, 24),
+                                                 (40, 40, 4, 9, 7), (8, 6, 2, 5, 3), (16, 5, 8, 4, 6)])
+def test_transposed_conv_matches_torch(cin, cout, stride, h, w):
+    """ojf_segdeconv_create: ConvTranspose2d(kernel 2s, stride s, padding s/2) (+ eval BN, ReLU) - the decoder's
+    upsampling layers (adapnet.py:226,236,247) and odd sizes."""
+    from online_joint_depthfusion_and_semantic_amd.segconv import SegDeconv, nhwc
+    g = torch.Generator().manual_seed(cin + 7 * cout + stride)
+    dc = nn.ConvTranspose2d(cin, cout, 2 * stride, stride=stride, padding=stride // 2).cuda()
+    bn = nn.BatchNorm2d(cout).cuda().eval()
+    with torch.no_grad():
+        dc.weight.copy_(torch.randn(dc.weight.shape, generator=g) / np.sqrt(cin * 4))
+        dc.bias.copy_(torch.randn(cout, generator=g) * 0.2)
+        bn.weight.copy_(torch.rand(cout, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(cout, generator=g) * 0.3)
+        bn.running_mean.copy_(torch.randn(cout, generator=g) * 0.2)
+        bn.running_var.copy_(torch.rand(cout, generator=g) * 2 + 0.1)
+        x = (torch.randn((1, cin, h, w), generator=g) * 2).cuda()
+        xin = to_nhwc(x)
+        for op, want, act in ((SegDeconv(dc), dc(x), None), (SegDeconv(dc, bn), F.relu(bn(dc(x))), 'relu')):
+            got = op(xin, act=act)
+            assert got.shape == want.shape
+            assert (got - want).abs().max().item() <= 3e-5 * want.abs().max().item() + 1e-6
+            assert torch.equal(got, op(xin, act=act))  # fixed summation order
+        # into a channel slice of a wider buffer (the decoder's concatenations)
+        cat = nhwc(cout + 24, h * stride, w * stride, x.device)
+        SegDeconv(dc, bn)(xin, out=cat[:, :cout], act='relu')
+        assert (cat[:, :cout] - want).abs().max().item() <= 3e-5 * want.abs().max().item() + 1e-6 and float(cat[:, cout:].abs().max()) == 0
+
+
 def test_channel_slices_and_guard():
     """Concatenation by pointer + stride: two convs write halves of one buffer, a third reads a slice of it."""
     from online_joint_depthfusion_and_semantic_amd import _lib
