@@ -143,13 +143,24 @@ class SegEngine:
         s2 = nhwc(24 * k, h4, w4, dev, zero=False)   # skip2 of both modalities side by side = SSMA's concatenation
         s1 = nhwc(24 * k, h8, w8, dev, zero=False)
         top = nhwc(256 * k, h16, w16, dev, zero=False)
-        x = self.enc1(mod1, s2[:, :24], s1[:, :24])
-        self.aspp1(x, top[:, :256])
         cat2 = nhwc(280, h8, w8, dev, zero=False)    # decoder stage 2 input: (deconv1 output, skip1)
         cat3 = nhwc(280, h4, w4, dev, zero=False)    # decoder stage 3 input: (stage 2 output, skip2)
         if self.fusion:
-            x2 = self.enc2(mod2, s2[:, 24:], s1[:, 24:])
-            self.aspp2(x2, top[:, 256:])
+            # the two modality encoders are independent and their 15x20 / 30x40 layers leave most CUs idle: the second
+            # one runs on a side stream (also inside a graph capture, where the fork / join become graph edges)
+            main = torch.cuda.current_stream(dev)
+            side = self.__dict__.get('_side')
+            if side is None or side.device != dev:
+                side = self.__dict__['_side'] = torch.cuda.Stream(device=dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                x2 = self.enc2(mod2, s2[:, 24:], s1[:, 24:])
+                self.aspp2(x2, top[:, 256:])
+                del x2
+        x = self.enc1(mod1, s2[:, :24], s1[:, :24])
+        self.aspp1(x, top[:, :256])
+        if self.fusion:
+            main.wait_stream(side)
             skip2 = self.ssma_s2(s2)
             skip1 = self.ssma_s1(s1)
             x = self.ssma_res(top)
