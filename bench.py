@@ -122,7 +122,9 @@ def main():
     ap.add_argument('--grid', type=int, default=256)
     ap.add_argument('--semantics', action='store_true', help='BASELINE configs[2]-style: gt labels + semantic head')
     ap.add_argument('--semantic-strategy', default='gt', choices=['gt', 'predict'],
-                    help="with --semantics: 'predict' runs AdapNet++ (random init, torch ops on the GPU) on every frame")
+                    help="with --semantics: 'predict' runs AdapNet++ (random init) on every frame")
+    ap.add_argument('--seg-engine', default='hip', choices=['hip', 'torch'],
+                    help="AdapNet++ convolutions: 'hip' = SEGCONV MFMA kernels (default), 'torch' = module forward on MIOpen")
     ap.add_argument('--mode', default='fast', choices=['fast', 'parity'])
     ap.add_argument('--arith', default='f16x3', choices=['f16x3', 'f32'], help='net MFMA arithmetic (include/ojf.h OJF_ARITH_*)')
     ap.add_argument('--cpu-frames', type=int, default=4, help='timed frames of the CPU baseline (0 = skip)')
@@ -152,6 +154,7 @@ def main():
     cfg.FUSION_MODEL.arithmetic = args.arith
     if args.semantics:
         cfg.DATA.semantic_strategy = args.semantic_strategy
+        cfg.SEMANTIC_2D_MODEL.engine = args.seg_engine
     n_frames = args.steps + args.warmup
     st = SyntheticStream(h, w, grid, n_frames, scene='room_%d' % rank, seed=1911 + rank)
     db = Database(st, database_config(cfg))
@@ -220,7 +223,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': ARITH[args.arith][0], 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: geometry-only fusion, %dx%d depth into a %d^3 fp16 TSDF grid, '
-                                   'FusionNet_v3%s, one scene per GPU' % (w, h, grid, (' + %s semantics' % ('AdapNet++ (predict)' if predict else 'gt')) if args.semantics else ''),
+                                   'FusionNet_v3%s, one scene per GPU' % (w, h, grid, (' + %s semantics' % ('AdapNet++ (predict, %s convolutions)' % args.seg_engine if predict else 'gt')) if args.semantics else ''),
                        'frame': [h, w], 'grid': grid, 'n_points': P, 'n_tail_points': T, 'integrate_mode': args.mode,
                        'volume_dtype': 'f16', 'net_arithmetic': ARITH[args.arith][1], 'parallelism': 'scene-sharded x%d' % world},
             'stages_ms': stages,

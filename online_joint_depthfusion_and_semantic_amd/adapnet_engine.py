@@ -147,7 +147,10 @@ class SegEngine:
         cat3 = nhwc(280, h4, w4, dev, zero=False)    # decoder stage 3 input: (stage 2 output, skip2)
         if self.fusion:
             # the two modality encoders are independent and their 15x20 / 30x40 layers leave most CUs idle: the second
-            # one runs on a side stream (also inside a graph capture, where the fork / join become graph edges)
+            # one runs on a side stream (also inside a graph capture, where the fork / join become graph edges): 2.06 ->
+            # 1.60 ms.  Finer forks (the halves of a multi-scale unit, shortcuts, eASPP branches) were measured too: every
+            # fork / join edge costs more than the ~8 us launch it hides (2.06 -> 2.56 ms without the encoder fork), and
+            # forks nested inside the side stream crash hipStreamEndCapture of this ROCm build.
             main = torch.cuda.current_stream(dev)
             side = self.__dict__.get('_side')
             if side is None or side.device != dev:

@@ -14,3 +14,9 @@ python bench.py --height 120 --width 160 --grid 64 --cpu-frames 0 > gpurun_out/f
 python bench.py --mode parity --steps 100 --cpu-frames 0 > gpurun_out/final/bench_parity.json 2>/dev/null
 python bench.py --height 480 --width 640 --grid 512 --semantics --steps 60 --warmup 5 --cpu-frames 0 > gpurun_out/final/bench_C.json 2>/dev/null
 python bench.py --height 480 --width 640 --grid 512 --steps 60 --warmup 5 --cpu-frames 0 > gpurun_out/final/bench_Cgeo.json 2>/dev/null
+python bench.py --semantics --semantic-strategy predict --steps 100 --cpu-frames 0 > gpurun_out/final/bench_predict.json 2>/dev/null
+python bench.py --semantics --semantic-strategy predict --seg-engine torch --steps 100 --cpu-frames 0 > gpurun_out/final/bench_predict_torch.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/kp -o kp -- python bench.py --semantics --semantic-strategy predict --steps 50 --warmup 10 --cpu-frames 0 > /dev/null 2> gpurun_out/final/kp.err
+python tests/adapnet_engine_probe.py 2>&1 | grep -v MIOpen > gpurun_out/final/adapnet_engine_probe.txt
+python tests/mesh_timing.py 256 > gpurun_out/final/mesh_timing.txt 2>&1
+python tests/mesh_timing.py 512 >> gpurun_out/final/mesh_timing.txt 2>&1
