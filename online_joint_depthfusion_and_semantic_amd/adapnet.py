@@ -6,8 +6,9 @@ torchvision is not available in this environment, so the ResNet-50 v1.5 backbone
 torchvision's key layout (``conv1, bn1, layer{1..4}.{i}.{conv1,bn1,conv2,bn2,conv3,bn3,downsample},
 fc``; reference call site adapnet.py:4,101-130).  Parity status: ``BottleneckSSMA``, ``eASPP``,
 ``Decoder`` and ``SSMA`` are pinned against the reference's own classes (tests/test_adapnet.py); the
-backbone has no reference fixture ("parity unpinned").  This module runs on torch ops
-(plumbing); its dense 3x3 / eASPP contractions are next in line for the MFMA conv kernel.
+backbone has no reference fixture ("parity unpinned").  This module tree is what trains and what
+holds the weights; at inference ``Pipeline`` runs it through ``adapnet_engine.SegEngine`` - every convolution on
+the SEGCONV MFMA kernels (csrc/ojf_seg.hip) - unless ``SEMANTIC_2D_MODEL.engine: torch`` asks for this forward.
 """
 import torch
 import torch.nn as nn
