@@ -58,3 +58,29 @@ def test_argument_validation_without_device():
     # header + 4 B/voxel head table + one 32-B record per entry + touched list
     # FAST: header + head table + (32-B records + 4-B first touches) x tiles x (2048 + 64 * n_tail * 8) + tile counts
     assert lib.ojf_integrate_workspace_bytes(8, 8, 8, 4, 4, 7, 0) == 256 + 512 * 4 + 1 * (2048 + 3584) * 36 + 1 * 4
+
+
+def test_segconv_and_mesh_argument_validation_without_device():
+    """The SEGCONV / mesh entry points reject bad descriptions before they touch the device."""
+    import ctypes
+    import numpy as np
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    w = np.ones((4, 8, 3, 3), dtype=np.float32)
+    assert lib.ojf_segconv_create(ctypes.byref(h), None, None, None, 8, 4, 3, 1, 1, 1) != 0 and b'null' in lib.ojf_last_error()
+    assert lib.ojf_segconv_create(ctypes.byref(h), w.ctypes.data, None, None, 8, 4, 9, 1, 1, 1) != 0  # kernel > 7
+    assert lib.ojf_segconv_create(ctypes.byref(h), w.ctypes.data, None, None, 8, 4, 3, 0, 1, 1) != 0  # stride 0
+    bad = w.copy()
+    bad[1, 2, 0, 1] = np.nan
+    assert lib.ojf_segconv_create(ctypes.byref(h), bad.ctypes.data, None, None, 8, 4, 3, 1, 1, 1) != 0
+    assert b'non-finite' in lib.ojf_last_error()
+    scale = np.array([1, np.inf, 1, 1], dtype=np.float32)
+    assert lib.ojf_segconv_create(ctypes.byref(h), w.ctypes.data, scale.ctypes.data, None, 8, 4, 3, 1, 1, 1) != 0
+    assert lib.ojf_segdeconv_create(ctypes.byref(h), w.ctypes.data, None, None, 4, 8, 3) != 0  # odd stride
+    assert lib.ojf_segdeconv_create(ctypes.byref(h), None, None, None, 4, 8, 2) != 0
+    assert h.value is None
+    assert lib.ojf_segconv_forward(None, None, 8, None, 8, None, 0, None, 0, 0, 4, 4, None) != 0
+    lib.ojf_segconv_destroy(None)  # a no-op, like free(NULL)
+    assert lib.ojf_mesh_workspace_bytes(1, 4, 4) == 0 and lib.ojf_mesh_workspace_bytes(65, 5, 3) == 4 * 1 * 1 * 64
+    assert lib.ojf_mesh_extract(None, None, None, 4, 4, 4, 0.0, None, 1.0, None, 0, None, None, None, 0, None, None) != 0
+    assert lib.ojf_points_within(None, 0, None, None, None, 1.0, 1, 1, 1, 0.5, None, None, None) != 0

@@ -47,7 +47,7 @@ def build(stage, n_classes, seed=0):
     return lively(AdapNet(AttrDict({'stage': stage, 'n_classes': n_classes})), seed).cuda().eval()
 
 
-@pytest.mark.parametrize('stage,n_classes,h,w', [(2, 30, 64, 96), (1, 12, 48, 64), (2, 40, 240, 320)])
+@pytest.mark.parametrize('stage,n_classes,h,w', [(2, 30, 64, 96), (1, 12, 48, 64), (2, 40, 240, 320), (2, 40, 480, 640), (1, 5, 16, 16)])
 def test_engine_matches_module(stage, n_classes, h, w):
     from online_joint_depthfusion_and_semantic_amd import _lib
     from online_joint_depthfusion_and_semantic_amd.adapnet_engine import SegEngine
