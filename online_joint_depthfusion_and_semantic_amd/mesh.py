@@ -143,8 +143,9 @@ def points_within(query, points, tau):
     cell = max(float(tau), 1e-30)
     lo = p.min(dim=0).values
     span = p.max(dim=0).values - lo
-    # coarsen the bins when tau is tiny against the extent: the cell list must stay addressable
-    cell = max(cell, float(span.max().item()) / 1024.0)
+    # coarsen the bins when tau is tiny against the extent: at most ~2^24 cells (64 MB of offsets)
+    extent = [max(float(v), 0.0) for v in span.tolist()]
+    cell = max(cell, (max(extent[0], cell) * max(extent[1], cell) * max(extent[2], cell) / float(1 << 24)) ** (1.0 / 3.0))
     c = torch.floor((p - lo) / cell).to(torch.int64)
     G = [int(v) + 1 for v in c.max(dim=0).values.tolist()]
     key = (c[:, 0] * G[1] + c[:, 1]) * G[2] + c[:, 2]

@@ -286,7 +286,8 @@ def test_database_mesh_modes(tmp_path):
 
 
 # ---- reconstruction F-score on the device ---------------------------------------------------------------------------
-@pytest.mark.parametrize('n_q,n_p,tau', [(5000, 7000, 0.05), (3000, 100, 0.3), (1, 1, 0.01), (4000, 4000, 1e-4), (2000, 3000, 2.5)])
+@pytest.mark.parametrize('n_q,n_p,tau', [(5000, 7000, 0.05), (3000, 100, 0.3), (1, 1, 0.01), (4000, 4000, 1e-4), (2000, 3000, 2.5),
+                                         (3000, 3000, 1e-7), (500, 800, 0.0)])
 def test_points_within_matches_kdtree(n_q, n_p, tau):
     from scipy.spatial import cKDTree
     from online_joint_depthfusion_and_semantic_amd import mesh
