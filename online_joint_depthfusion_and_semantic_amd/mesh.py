@@ -51,16 +51,29 @@ def extract_triangles(tsdf, weights=None, ids=None, iso=0., origin=(0., 0., 0.),
     return (tri, labels, edge) if keys else (tri, labels)
 
 
-def weld(tri, labels=None, keys=None):
-    """Indexed mesh from a triangle list.  With the kernel's edge keys: one integer sort, vertices ordered by grid
-    edge.  Without: vertices that are bit-equal merge (the kernel guarantees that for shared edges) and faces that
+def weld(tri, labels=None, keys=None, n_voxels=None):
+    """Indexed mesh from a triangle list.  With the kernel's edge keys: vertices ordered by grid edge, ranked by a
+    prefix sum over the dense key space when ``n_voxels`` is given (no sort), else by one integer sort.  Without: vertices that are bit-equal merge (the kernel guarantees that for shared edges) and faces that
     collapse are dropped.  Returns (vertices [V,3], faces int64 [F,3], vertex_labels or None)."""
     flat = tri.reshape(-1, 3)
     if flat.shape[0] == 0:
         return flat, torch.zeros((0, 3), dtype=torch.int64, device=tri.device), (None if labels is None else labels.reshape(-1))
     if keys is not None:
-        uniq, inverse = torch.unique(keys.reshape(-1), return_inverse=True)
-        verts = torch.empty((uniq.shape[0], 3), dtype=flat.dtype, device=flat.device)
+        k = keys.reshape(-1)
+        if n_voxels is not None and 8 * int(n_voxels) < (1 << 31):
+            # rank of a key among the keys present = position in a prefix sum over the dense key space (8 per voxel):
+            # scatter, scan, gather - no sort; same vertex order as the sorted-unique path below
+            present = torch.zeros(8 * int(n_voxels), dtype=torch.uint8, device=flat.device)
+            present[k] = 1
+            rank = torch.cumsum(present, dim=0, dtype=torch.int32)
+            del present
+            inverse = rank[k].to(torch.int64) - 1
+            n_verts = int(rank[-1].item())
+            del rank
+        else:
+            uniq, inverse = torch.unique(k, return_inverse=True)
+            n_verts = uniq.shape[0]
+        verts = torch.empty((n_verts, 3), dtype=flat.dtype, device=flat.device)
         verts[inverse] = flat  # duplicates carry identical bits
         faces = inverse.reshape(-1, 3)
     else:
@@ -98,7 +111,7 @@ def extract_mesh(tsdf, weights=None, ids=None, iso=0., origin=(0., 0., 0.), reso
     """Database.get_mesh equivalent: dict(vertices, faces, normals, labels, rgb) of numpy arrays.  rgb in [0,1] with
     id 0 shown grey as database.py:132-135 does; None without ids."""
     tri, labels, keys = extract_triangles(tsdf, weights, ids, iso, origin, resolution, keys=True)
-    verts, faces, vlab = weld(tri, labels, keys)
+    verts, faces, vlab = weld(tri, labels, keys, n_voxels=tsdf.numel())
     normals = vertex_normals(verts, faces) if faces.shape[0] else torch.zeros_like(verts)
     out = {'vertices': verts.cpu().numpy(), 'faces': faces.to(torch.int32).cpu().numpy(), 'normals': normals.cpu().numpy(),
            'labels': None, 'rgb': None}

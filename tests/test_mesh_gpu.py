@@ -250,6 +250,8 @@ def test_order_is_deterministic_and_keys_identify_vertices():
     vb, fb, _ = mesh.weld(t1)
     assert va.shape == vb.shape and fa.shape == fb.shape
     assert torch.equal(va[fa], vb[fb])
+    vc, fc, _ = mesh.weld(t1, None, k1, n_voxels=vol.numel())  # prefix-sum ranking instead of the sort: same mesh
+    assert torch.equal(vc, va) and torch.equal(fc, fa)
 
 
 def test_database_mesh_modes(tmp_path):
