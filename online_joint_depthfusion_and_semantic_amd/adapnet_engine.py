@@ -15,7 +15,6 @@ parameters change).  No fallback path: it needs libojf and a GPU.
 import torch
 import torch.nn.functional as F
 
-from . import adapnet
 from .segconv import SegConv, SegDeconv, nhwc
 
 
@@ -23,7 +22,7 @@ class _Unit:
     """Bottleneck / BottleneckSSMA of the encoder."""
 
     def __init__(self, m):
-        self.multi = isinstance(m, adapnet.BottleneckSSMA)
+        self.multi = hasattr(m, 'conv2a')  # BottleneckSSMA (adapnet.py:12-84) vs torchvision-style Bottleneck, by shape not class
         self.c1 = SegConv(m.conv1, m.bn1)
         if self.multi:
             self.c2a, self.c2b = SegConv(m.conv2a, m.bn2a), SegConv(m.conv2b, m.bn2b)
@@ -108,7 +107,9 @@ class _SSMA:
 
 class SegEngine:
     def __init__(self, net):
-        assert isinstance(net, adapnet.AdapNet) and not net.training, 'SegEngine: an AdapNet in eval() mode'
+        # duck-typed on the attribute names of modules/adapnet.py:356-415, so the reference's own AdapNet instance
+        # (torchvision backbone included) can be handed over as well as adapnet.AdapNet
+        assert hasattr(net, 'encoder_mod1') and hasattr(net, 'decoder') and not net.training, 'SegEngine: an AdapNet in eval() mode'
         self.fusion, self.n_classes = net.fusion, net.n_classes
         self.enc1 = _Encoder(net.encoder_mod1)
         if self.fusion:
