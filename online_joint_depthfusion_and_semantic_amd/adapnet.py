@@ -5,8 +5,10 @@ that the checkpoints its ``train_segmentation.py`` writes load unchanged.
 torchvision is not available in this environment, so the ResNet-50 v1.5 backbone is defined here with
 torchvision's key layout (``conv1, bn1, layer{1..4}.{i}.{conv1,bn1,conv2,bn2,conv3,bn3,downsample},
 fc``; reference call site adapnet.py:4,101-130).  Parity status: ``BottleneckSSMA``, ``eASPP``,
-``Decoder`` and ``SSMA`` are pinned against the reference's own classes (tests/test_adapnet.py); the
-backbone has no reference fixture ("parity unpinned").  This module tree is what trains and what
+``Decoder`` and ``SSMA`` are pinned against the reference's own classes, and so is the whole network: the
+reference's ``AdapNet`` built around this file's ``ResNet50`` (standing in for torchvision's class) gives the golden
+outputs this tree reproduces bit for bit (tests/test_adapnet.py, tests/golden/make_golden_adapnet.py).  Only
+torchvision's own ``Bottleneck`` arithmetic has no fixture.  This module tree is what trains and what
 holds the weights; at inference ``Pipeline`` runs it through ``adapnet_engine.SegEngine`` - every convolution on
 the SEGCONV MFMA kernels (csrc/ojf_seg.hip) - unless ``SEMANTIC_2D_MODEL.engine: torch`` asks for this forward.
 """

@@ -63,3 +63,58 @@ with torch.no_grad():
     out['bott_out_dropout'] = m(x).numpy()
 np.savez_compressed(os.path.join(HERE, 'adapnet_blocks.npz'), **out)
 print('written', os.path.join(HERE, 'adapnet_blocks.npz'))
+
+
+# ---- whole network: the reference's AdapNet / Encoder wiring (adapnet.py:87-149,356-415) around a ResNet-50 ---------
+# torchvision is absent, so the backbone object handed to the reference's Encoder is the package's ResNet50 (public
+# v1.5 layout, torchvision's attribute names).  What this pins: the unit swaps and stride edit of Encoder.__init__,
+# Encoder / AdapNet / Decoder forward wiring, the state_dict key list and parameter order of the whole tree.  What it
+# cannot pin: torchvision's own Bottleneck arithmetic (the "backbone unpinned" note in DESIGN.md).
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from online_joint_depthfusion_and_semantic_amd import adapnet as pkg  # noqa: E402
+from types import SimpleNamespace  # noqa: E402
+
+ref.resnet50 = lambda *a, **k: pkg.ResNet50()  # the name modules/adapnet.py:4 imported, used at :101
+
+
+def randomise_net(m, seed):
+    """Signal-preserving seeded initialisation, consuming ONE RNG stream in module order."""
+    g = torch.Generator().manual_seed(seed)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Conv2d):
+            mod.weight.data.copy_(torch.randn(mod.weight.shape, generator=g) * (2.0 / mod.weight[0].numel()) ** 0.5)
+        elif isinstance(mod, torch.nn.ConvTranspose2d):
+            fan = mod.weight.shape[0] * (mod.kernel_size[0] / mod.stride[0]) ** 2
+            mod.weight.data.copy_(torch.randn(mod.weight.shape, generator=g) * (2.0 / fan) ** 0.5)
+        if isinstance(mod, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)) and mod.bias is not None:
+            mod.bias.data.copy_(torch.randn(mod.bias.shape, generator=g) * 0.1)
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.weight.data.copy_(torch.rand(mod.weight.shape, generator=g) * 0.5 + 0.5)
+            mod.bias.data.copy_(torch.randn(mod.bias.shape, generator=g) * 0.1)
+            mod.running_mean.copy_(torch.randn(mod.bias.shape, generator=g) * 0.1)
+            mod.running_var.copy_(torch.rand(mod.bias.shape, generator=g) + 0.5)
+    for mod in m.modules():
+        if hasattr(mod, 'bn3'):
+            mod.bn3.weight.data.mul_(0.4)
+        if hasattr(mod, 'dropout') and isinstance(mod.dropout, bool):
+            mod.dropout = False
+    return m.eval()
+
+
+net_out = {}
+with torch.no_grad():
+    g = torch.Generator().manual_seed(11)
+    for stage, n_classes, h, w in ((2, 12, 32, 48), (1, 7, 16, 32)):
+        m = randomise_net(ref.AdapNet(SimpleNamespace(stage=stage, n_classes=n_classes)), 20 + stage)
+        tag = 'stage%d.' % stage
+        net_out[tag + 'keys'] = np.array(list(m.state_dict().keys()))
+        net_out[tag + 'modules'] = np.array([type(x).__name__ for x in m.modules()])
+        a = torch.randn(1, 3, h, w, generator=g)
+        b = torch.rand(1, 3, h, w, generator=g) * 3
+        net_out[tag + 'in1'], net_out[tag + 'in2'] = a.numpy(), b.numpy()
+        outs = m(a, b) if stage != 1 else m(a)
+        for i, o in enumerate(outs):
+            net_out[tag + 'out%d' % i] = o.numpy()
+        print(tag, [tuple(o.shape) for o in outs], 'max |logit| %.3f' % float(outs[0].abs().max()))
+np.savez_compressed(os.path.join(HERE, 'adapnet_net.npz'), **net_out)
+print('written', os.path.join(HERE, 'adapnet_net.npz'))

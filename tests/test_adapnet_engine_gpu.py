@@ -131,3 +131,19 @@ def test_pipeline_uses_the_engine_and_follows_weight_updates(cuda):
         pipe._semantic_2d_network.train()
         assert pipe._seg_engine((1, 3, h, w)) is None
         raise RuntimeError('ok')
+
+
+@pytest.mark.parametrize('stage', [2, 1])
+def test_engine_matches_reference_whole_network_golden(stage):
+    """SegEngine against the REFERENCE's whole-network output (tests/golden/adapnet_net.npz, generated by importing
+    modules/adapnet.py): main head within 5e-4 of the logit range, same arg-max."""
+    from adapnet_golden_util import golden_net
+    from online_joint_depthfusion_and_semantic_amd.adapnet_engine import SegEngine
+    net, ins, outs = golden_net(stage)
+    net = net.cuda()
+    with torch.no_grad():
+        got = SegEngine(net)(*[x.cuda() for x in ins]).cpu()
+    want = outs[0]
+    err, top = float((got - want).abs().max()), float(want.abs().max())
+    assert err <= 5e-4 * top, (err, top)
+    assert float((got.argmax(1) == want.argmax(1)).float().mean()) > 0.995
