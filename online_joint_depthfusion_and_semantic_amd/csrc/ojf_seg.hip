@@ -77,6 +77,73 @@ struct SegArgs {
 // KS = 4 | 8 (layers with few pixels: too few waves to hide the weight stream otherwise): the KS waves of a block share
 // ONE pair and each walks 1/KS of K; partial sums meet in LDS and wave 0 runs the epilogue.  Fixed order: deterministic.
 // Measured on the 15x20 maps of layer3/4: parallelism beats operand reuse (NW = 1: 2.33 ms per frame, 2: 2.69, 4: 3.69).
+template <int MW, int NW>
+__device__ __forceinline__ void seg_epilogue(const SegArgs &a, const f32x4 (&acc)[MW][NW], int ct0, int pt0, int n_pix, int col, int kg)
+{
+    // epilogue: lane holds output channels c .. c+3 of pixel (pt0+n)*16 + col
+    float gmax = 0.0f;
+#pragma unroll
+    for (int m = 0; m < MW; ++m) {
+        const int c = (ct0 + m) * 16 + kg * 4;
+        if (c >= a.c_out) continue;
+        const f32x4 rv = *reinterpret_cast<const f32x4 *>(a.rinv + c), bv = *reinterpret_cast<const f32x4 *>(a.bias + c);
+        // transposed convolution: GEMM row c = (phase, channel); phase (ay, ax) of input pixel (y, x) is output pixel
+        // (y*up + ay, x*up + ax).  up_cp is a multiple of 4, so a lane's four rows share the phase.
+        int co = c, n_co = a.c_out, ay = 0, ax = 0;
+        if (a.up > 1) {
+            const int phase = c / a.up_cp;
+            co = c - phase * a.up_cp;
+            n_co = a.up_c;
+            ay = phase / a.up;
+            ax = phase - ay * a.up;
+            if (co >= n_co) continue;
+        }
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            const int p = (pt0 + n) * 16 + col;
+            if (p >= n_pix) continue;
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(acc[m][n][i], rv[i], bv[i]);
+            const bool full = co + 3 < n_co;
+            if (a.res) {
+                const float *r = a.res + (size_t)p * a.res_stride + c;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (full || co + i < n_co) v[i] += r[i];
+            }
+            gmax = fmaxf(fmaxf(fmaxf(gmax, fabsf(v[0])), fmaxf(fabsf(v[1]), fabsf(v[2]))), fabsf(v[3]));
+            if (a.act == 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = v[i] < 0.0f ? 0.0f : v[i];  // keeps NaN, like torch.relu
+            } else if (a.act == 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = 1.0f / (1.0f + expf(-v[i]));
+            }
+            if (a.mul) {
+                const float *g = a.mul + (size_t)p * a.mul_stride + c;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (full || co + i < n_co) v[i] *= g[i];
+            }
+            size_t row = (size_t)p;
+            if (a.up > 1) {
+                const int oy = p / a.Wo, ox = p - oy * a.Wo;
+                row = ((size_t)oy * a.up + ay) * ((size_t)a.Wo * a.up) + (size_t)ox * a.up + ax;
+            }
+            float *o = a.out + row * a.out_stride + co;
+            if (full && a.vec_store) {
+                *reinterpret_cast<f32x4 *>(o) = v;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (co + i < n_co) o[i] = v[i];
+            }
+        }
+    }
+    if (a.ovf && gmax > 65504.0f) *a.ovf = 1;  // a later layer would split this value: outside the fp16 range
+}
+
 // kDepth = K blocks in flight per wave (a cold weight fetch costs ~1 us, the MFMAs of a block ~0.1 us).
 template <int MW, int NW, int WM, int KS, int kDepth>
 __global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void segconv_kernel(SegArgs a)
@@ -197,68 +264,112 @@ __global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void segconv_kernel(SegArgs
                 }
     }
 
-    // epilogue: lane holds output channels c .. c+3 of pixel (pt0+n)*16 + col
-    float gmax = 0.0f;
+    seg_epilogue<MW, NW>(a, acc, ct0, pt0, n_pix, col, kg);
+}
+
+// Many-pixel layers (decoder 3x3 stacks, layer1): the four waves of a block work on the SAME 64 output channels and
+// 32 pixels each, and the weight fragments of a K block reach them through LDS (LDS-DMA, 8 KB per K block, three
+// stages): one global fetch per block instead of one per wave.  With per-wave fetches these layers were bound by
+// L1 (12 KB per wave per K block against 24 MFMAs); B operands stay per-wave buffer loads.
+template <int NW>
+__global__ __launch_bounds__(256) void segconv_wide_kernel(SegArgs a)
+{
+    constexpr int MW = 4, D = 3;
+    __shared__ f32x4 wtile[D][MW * 2 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ct0 = (int)blockIdx.y * MW;
+    const int pt0 = ((int)blockIdx.x * 4 + wave) * NW;
+    const int n_pix = a.Ho * a.Wo;
+    const int col = lane & 15, kg = lane >> 4;
+    const int n_kb = a.n_kb;
+
+    int iy0[NW], ix0[NW];
+    bool live[NW];
 #pragma unroll
-    for (int m = 0; m < MW; ++m) {
-        const int c = (ct0 + m) * 16 + kg * 4;
-        if (c >= a.c_out) continue;
-        const f32x4 rv = *reinterpret_cast<const f32x4 *>(a.rinv + c), bv = *reinterpret_cast<const f32x4 *>(a.bias + c);
-        // transposed convolution: GEMM row c = (phase, channel); phase (ay, ax) of input pixel (y, x) is output pixel
-        // (y*up + ay, x*up + ax).  up_cp is a multiple of 4, so a lane's four rows share the phase.
-        int co = c, n_co = a.c_out, ay = 0, ax = 0;
-        if (a.up > 1) {
-            const int phase = c / a.up_cp;
-            co = c - phase * a.up_cp;
-            n_co = a.up_c;
-            ay = phase / a.up;
-            ax = phase - ay * a.up;
-            if (co >= n_co) continue;
+    for (int n = 0; n < NW; ++n) {
+        const int p = (pt0 + n) * 16 + col;
+        live[n] = p < n_pix;
+        const int oy = p / a.Wo, ox = p - oy * a.Wo;
+        iy0[n] = oy * a.stride - a.pad;
+        ix0[n] = ox * a.stride - a.pad;
+    }
+    int tap = kg / a.c8, cg = kg - tap * a.c8;
+    int ty = tap / a.ksize, tx = tap - ty * a.ksize;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in), 0, a.in_bytes, 0x00020000);
+
+    f32x4 acc[MW][NW];
+#pragma unroll
+    for (int m = 0; m < MW; ++m)
+#pragma unroll
+        for (int n = 0; n < NW; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // wave w moves chunks w and w + 4 of the 8 one-KB chunks (channel tile m, half h) of a K block
+    auto stream_weights = [&](int kb, int stage) {
+        const int kbc = kb < n_kb ? kb : n_kb - 1;  // past the end: refetch the last block (multiplied by zeros)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int c = wave + 4 * r, m = c >> 1, h = c & 1;
+            const f32x4 *src = a.wp + ((size_t)(ct0 + m) * n_kb + kbc) * 128 + h * 64 + lane;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)src,
+                                             (void __attribute__((address_space(3))) *)(&wtile[stage][c * 64]), 16, 0, 0);
         }
+    };
+    f32x4 xa[D][NW], xb[D][NW];
+    auto fetch_pixels = [&](int kb, f32x4 (&fa)[NW], f32x4 (&fb)[NW]) {
+        const int dy = ty * a.dil, dx = tx * a.dil;
+        const bool in_range = kb < n_kb;
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
-            const int p = (pt0 + n) * 16 + col;
-            if (p >= n_pix) continue;
-            f32x4 v;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(acc[m][n][i], rv[i], bv[i]);
-            const bool full = co + 3 < n_co;
-            if (a.res) {
-                const float *r = a.res + (size_t)p * a.res_stride + c;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (full || co + i < n_co) v[i] += r[i];
-            }
-            gmax = fmaxf(fmaxf(fmaxf(gmax, fabsf(v[0])), fmaxf(fabsf(v[1]), fabsf(v[2]))), fabsf(v[3]));
-            if (a.act == 1) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = v[i] < 0.0f ? 0.0f : v[i];  // keeps NaN, like torch.relu
-            } else if (a.act == 2) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = 1.0f / (1.0f + expf(-v[i]));
-            }
-            if (a.mul) {
-                const float *g = a.mul + (size_t)p * a.mul_stride + c;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (full || co + i < n_co) v[i] *= g[i];
-            }
-            size_t row = (size_t)p;
-            if (a.up > 1) {
-                const int oy = p / a.Wo, ox = p - oy * a.Wo;
-                row = ((size_t)oy * a.up + ay) * ((size_t)a.Wo * a.up) + (size_t)ox * a.up + ax;
-            }
-            float *o = a.out + row * a.out_stride + co;
-            if (full && a.vec_store) {
-                *reinterpret_cast<f32x4 *>(o) = v;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (co + i < n_co) o[i] = v[i];
+            const int iy = iy0[n] + dy, ix = ix0[n] + dx;
+            const bool ok = in_range && live[n] && ty < a.ksize && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const unsigned off = ok ? (unsigned)(((iy * a.W + ix) * a.in_stride + cg * 8) * 4) : 0xfffffff0u;
+            fa[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+            fb[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off + 16u : 0xfffffff0u, 0, 0));
+        }
+        cg += 4;
+        while (cg >= a.c8) {
+            cg -= a.c8;
+            if (++tx == a.ksize) {
+                tx = 0;
+                ++ty;
             }
         }
+    };
+    auto multiply = [&](int stage, const f32x4 (&fa)[NW], const f32x4 (&fb)[NW]) {
+        f16x8 xh[NW], xl[NW];
+#pragma unroll
+        for (int n = 0; n < NW; ++n) split8(fa[n], fb[n], xh[n], xl[n]);
+#pragma unroll
+        for (int m = 0; m < MW; ++m) {
+            const f32x4 wh = wtile[stage][(m * 2) * 64 + lane], wl = wtile[stage][(m * 2 + 1) * 64 + lane];
+#pragma unroll
+            for (int n = 0; n < NW; ++n) acc[m][n] = mfma3(wh, wl, xh[n], xl[n], acc[m][n]);
+        }
+    };
+
+    // every wave issues exactly 2 + 2*NW memory operations per K block, weights first: when the pixel operands of
+    // block kb have arrived, so have this wave's weight chunks of block kb (in-order return); the barrier then makes
+    // the other waves' chunks visible and guarantees that nobody still reads the stage refilled next
+    const int rounds = (n_kb + D - 1) / D;
+#pragma unroll
+    for (int s = 0; s < D - 1; ++s) {
+        stream_weights(s, s);
+        fetch_pixels(s, xa[s], xb[s]);
     }
-    if (a.ovf && gmax > 65504.0f) *a.ovf = 1;  // a later layer would split this value: outside the fp16 range
+    for (int r = 0; r < rounds; ++r) {
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            const int kb = r * D + s;
+            if constexpr (NW == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // all but the newest K block's operations
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __syncthreads();
+            stream_weights(kb + D - 1, (s + D - 1) % D);
+            fetch_pixels(kb + D - 1, xa[(s + D - 1) % D], xb[(s + D - 1) % D]);
+            multiply(s, xa[s], xb[s]);
+        }
+    }
+    if (pt0 * 16 >= n_pix) return;
+    seg_epilogue<MW, NW>(a, acc, ct0, pt0, n_pix, col, kg);
 }
 
 inline float pow2_row_scale(float row_max)
@@ -404,7 +515,11 @@ OJF_API int ojf_segconv_forward(const ojf_segconv *c, const float *in, int in_st
     // Otherwise the four waves of a block split K (when K is long enough to be worth the LDS reduction).
     const long waves2 = (long)groups * ((n_pt + 1) / 2);
     static const int force_mw = getenv("OJF_SEG_MW") ? atoi(getenv("OJF_SEG_MW")) : 0;  // tuning only
-    if (waves2 >= 1024 || c->n_kb < 8) {
+    static const int no_wide = getenv("OJF_SEG_NO_WIDE") ? atoi(getenv("OJF_SEG_NO_WIDE")) : 0;  // tuning only
+    static const int wide_min = getenv("OJF_SEG_WIDE_MIN") ? atoi(getenv("OJF_SEG_WIDE_MIN")) : 256;  // tuning only
+    if (!no_wide && c->n_kb >= 6 && (long)groups * ((n_pt + 7) / 8) >= wide_min) {
+        hipLaunchKernelGGL((segconv_wide_kernel<2>), dim3((n_pt + 7) / 8, groups), dim3(256), 0, st, a);
+    } else if (waves2 >= 1024 || c->n_kb < 8) {
         if (groups == 1) hipLaunchKernelGGL((segconv_kernel<4, 2, 1, 1, 3>), dim3((n_pt + 7) / 8, 1), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((segconv_kernel<4, 2, 2, 1, 3>), dim3((n_pt + 3) / 4, (groups + 1) / 2), dim3(256), 0, st, a);
     } else {
