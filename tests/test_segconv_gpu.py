@@ -36,6 +36,9 @@ SHAPES = [
     (48, 4, 3, 1, 1, 1, 30, 40), (4, 48, 3, 1, 1, 1, 30, 40), (48, 24, 3, 1, 1, 1, 60, 80),         # SSMA skips
     (280, 256, 3, 1, 1, 1, 30, 40), (256, 256, 3, 1, 1, 1, 60, 80), (256, 30, 1, 1, 1, 0, 60, 80), (256, 24, 1, 1, 1, 0, 1, 1),
     (24, 40, 3, 1, 1, 1, 7, 5), (8, 8, 5, 3, 2, 4, 33, 17),  # odd geometry: ragged tiles, 5x5, stride 3
+    # >= 256 blocks of 64 channels x 128 pixels: the LDS-shared-weights kernel (640x480 frames)
+    (256, 256, 3, 1, 1, 1, 120, 160), (64, 64, 3, 1, 1, 1, 240, 320), (64, 128, 3, 2, 1, 1, 240, 320), (40, 72, 3, 1, 2, 2, 131, 157),
+    (256, 30, 1, 1, 1, 0, 240, 320),
 ]
 
 
