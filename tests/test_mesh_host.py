@@ -35,3 +35,31 @@ def test_palette_and_gpu_requirement():
     if not torch.cuda.is_available():  # the product path never falls back to a CPU mesher
         with pytest.raises(RuntimeError):
             mesh.extract_triangles(torch.zeros((4, 4, 4), dtype=torch.float16))
+
+
+def test_weld_paths_agree_on_host_tensors():
+    """mesh.weld is plain torch: the prefix-sum ranking over the dense key space, the integer sort and the
+    position-based merge give the same indexed mesh (vertices ordered by edge key)."""
+    import torch
+    rng = np.random.default_rng(2)
+    n_vox = 6 * 5 * 4
+    pool_keys = rng.choice(np.arange(8 * n_vox), size=40, replace=False)           # distinct grid edges
+    pool_pos = rng.normal(size=(40, 3)).astype(np.float32)                          # one position per edge
+    pick = np.stack([rng.choice(40, size=3, replace=False) for _ in range(70)])    # 70 triangles, 3 distinct corners
+    tri = torch.from_numpy(pool_pos[pick])
+    keys = torch.from_numpy(pool_keys[pick].astype(np.int64))
+    labels = torch.from_numpy((pool_keys[pick] % 7).astype(np.uint8))
+    v_sort, f_sort, l_sort = mesh.weld(tri, labels, keys)
+    v_scan, f_scan, l_scan = mesh.weld(tri, labels, keys, n_voxels=n_vox)
+    assert torch.equal(v_sort, v_scan) and torch.equal(f_sort, f_scan) and torch.equal(l_sort, l_scan)
+    used = np.unique(pool_keys[pick])
+    assert v_scan.shape[0] == used.size and torch.equal(v_scan[f_scan], tri)
+    order = np.argsort(pool_keys)
+    assert np.array_equal(v_scan.numpy(), pool_pos[order][np.isin(pool_keys[order], used)])  # vertices in key order
+    assert np.array_equal(l_scan.numpy(), (np.sort(used) % 7).astype(np.uint8))
+    v_pos, f_pos, _ = mesh.weld(tri)
+    assert v_pos.shape == v_scan.shape and torch.equal(v_pos[f_pos], tri)
+    e_v, e_f, e_l = mesh.weld(torch.zeros((0, 3, 3)), torch.zeros((0, 3), dtype=torch.uint8), torch.zeros((0, 3), dtype=torch.int64), n_voxels=8)
+    assert e_v.shape == (0, 3) and e_f.shape == (0, 3)
+    n = mesh.vertex_normals(torch.tensor([[0., 0, 0], [1, 0, 0], [0, 1, 0]]), torch.tensor([[0, 1, 2]]))
+    assert torch.allclose(n, torch.tensor([[0., 0, 1]] * 3))
