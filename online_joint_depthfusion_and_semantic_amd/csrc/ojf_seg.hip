@@ -10,10 +10,15 @@
 // ojf_net.hip: x*w = wl*xh + wh*xl + wh*xh, fp32 accumulate, rows equilibrated by a power of two).  A lane's
 // accumulator holds 4 consecutive output channels of one pixel: one 16-byte NHWC store.
 //
-// A wave computes 4 output-channel tiles (64 channels) x NW pixel tiles (16 pixels each); a block is 4 waves, either
-// laid out WM along the channels x 4/WM along the pixels, or - for the layers with few pixels - sharing one tile pair
-// and splitting K four ways (LDS reduction, fixed order).  Operands come straight from global memory through L1
-// (buffer loads, out-of-image taps are out-of-range offsets that return zeros), three K blocks in flight per wave.  Channel slices of a wider tensor (concatenations) are addressed by pointer + row stride.
+// Three shapes of the same loop (ojf_segconv_forward picks by the size of the layer):
+//   * many independent waves: a wave owns 64 output channels x 32 pixels, 4 waves per block over (channels x pixels);
+//   * few pixels (15x20 .. 60x80 maps): the 4 waves of a block share one (channels, pixels) pair and split K four
+//     ways (LDS reduction in fixed order); 16 / 32 / 64 channels per block so that at least ~150 blocks exist;
+//   * many pixels (>= 256 blocks of 64 channels x 128 pixels): segconv_wide_kernel, weights through LDS (LDS-DMA).
+// Operands come straight from global memory through L1 (buffer loads; out-of-image taps are out-of-range offsets that
+// return zeros), three K blocks in flight per wave in a branch-free loop.  Channel slices of a wider tensor
+// (concatenations) are addressed by pointer + row stride.  Transposed convolutions: see ojf_segdeconv_create.
+// Tuning-only environment switches: OJF_SEG_MW, OJF_SEG_NO_WIDE, OJF_SEG_WIDE_MIN.
 #include <cmath>
 #include <cstdlib>
 #include <vector>
