@@ -1080,6 +1080,14 @@ static int *overflow_flag()
 
 int *range_flag_device() { return overflow_flag(); }  // shared with ojf_seg.hip
 
+// Fork / join events between streams of the same device: no timing, and (OJF_EVENT_FENCE=1 restores it) no system-scope
+// fence - nothing here is read by the host or another device through these events.
+static unsigned event_flags()
+{
+    static const bool fence = getenv("OJF_EVENT_FENCE") && atoi(getenv("OJF_EVENT_FENCE"));
+    return fence ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
+}
+
 static const char *kOverflowMsg =
     "split-fp16 arithmetic: an activation or input left the fp16 range (|x| > 65504 or NaN); results since the last "
     "ojf_net_check are invalid - use ojf_net_set_arithmetic(OJF_ARITH_F32) for this network";
@@ -1799,14 +1807,14 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
         if (!rc) rc = alloc_planes(&sc.V, np, 4 * cs);
         if (!rc) rc = alloc_planes(&sc.partial, kSumBlocks, 256);
         if (!rc) rc = check_hip(hipStreamCreateWithFlags(&sc.side, hipStreamNonBlocking), "hipStreamCreate");
-        if (!rc) rc = check_hip(hipEventCreateWithFlags(&sc.ev_fork, hipEventDisableTiming), "hipEventCreate");
-        if (!rc) rc = check_hip(hipEventCreateWithFlags(&sc.ev_join, hipEventDisableTiming), "hipEventCreate");
-        if (!rc) rc = check_hip(hipEventCreateWithFlags(&sc.ev_entry, hipEventDisableTiming), "hipEventCreate");
+        if (!rc) rc = check_hip(hipEventCreateWithFlags(&sc.ev_fork, event_flags()), "hipEventCreate");
+        if (!rc) rc = check_hip(hipEventCreateWithFlags(&sc.ev_join, event_flags()), "hipEventCreate");
+        if (!rc) rc = check_hip(hipEventCreateWithFlags(&sc.ev_entry, event_flags()), "hipEventCreate");
     }
     if (!rc && net->heads == 2) {
         rc = check_hip(hipStreamCreateWithFlags(&net->head1, hipStreamNonBlocking), "hipStreamCreate");
-        if (!rc) rc = check_hip(hipEventCreateWithFlags(&net->ev_head_fork, hipEventDisableTiming), "hipEventCreate");
-        if (!rc) rc = check_hip(hipEventCreateWithFlags(&net->ev_head_join, hipEventDisableTiming), "hipEventCreate");
+        if (!rc) rc = check_hip(hipEventCreateWithFlags(&net->ev_head_fork, event_flags()), "hipEventCreate");
+        if (!rc) rc = check_hip(hipEventCreateWithFlags(&net->ev_head_join, event_flags()), "hipEventCreate");
     }
     if (!rc) rc = alloc_planes(&net->YY, np, net->heads * os);
     if (!rc) rc = alloc_planes(&net->Y3, np, os);
