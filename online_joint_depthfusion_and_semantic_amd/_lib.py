@@ -115,3 +115,45 @@ def ptr(t):
 def stream_ptr(device=None):
     import torch
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class TimingEvent:
+    """HIP event for stage timing, created with ``hipEventDisableSystemFence``: a default event (torch.cuda.Event)
+    makes the stream write back and invalidate caches at system scope when it is recorded - ~5 us of idle queue per
+    record, four records per frame - which distorts what it measures.  Elapsed times only; not for host synchronisation
+    of memory."""
+    _hip = None
+    FLAGS = 0x20000000  # hipEventDisableSystemFence (timing stays enabled)
+
+    @classmethod
+    def _rt(cls):
+        if cls._hip is None:
+            hip = _c.CDLL('libamdhip64.so')
+            hip.hipEventCreateWithFlags.argtypes = [_c.POINTER(_vp), _c.c_uint]
+            hip.hipEventRecord.argtypes = [_vp, _vp]
+            hip.hipEventElapsedTime.argtypes = [_c.POINTER(_f), _vp, _vp]
+            hip.hipEventDestroy.argtypes = [_vp]
+            hip.hipEventSynchronize.argtypes = [_vp]
+            cls._hip = hip
+        return cls._hip
+
+    def __init__(self):
+        self._e = _vp()
+        if self._rt().hipEventCreateWithFlags(_c.byref(self._e), self.FLAGS) != 0:
+            raise OjfError('hipEventCreateWithFlags failed')
+
+    def record(self, stream):
+        if self._rt().hipEventRecord(self._e, _vp(stream)) != 0:
+            raise OjfError('hipEventRecord failed')
+
+    def elapsed_time(self, later):
+        self._rt().hipEventSynchronize(later._e)
+        ms = _f()
+        if self._rt().hipEventElapsedTime(_c.byref(ms), self._e, later._e) != 0:
+            raise OjfError('hipEventElapsedTime failed')
+        return ms.value
+
+    def __del__(self):
+        if getattr(self, '_e', None) and self._hip is not None:
+            self._hip.hipEventDestroy(self._e)
+            self._e = None

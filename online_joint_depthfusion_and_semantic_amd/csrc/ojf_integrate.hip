@@ -19,6 +19,9 @@
 // update and zeroes the head entries, so every call leaves the workspace clean.
 //
 // PARITY mode (ojf_integrate_parity.hip) reproduces the reference's sequential fp32 sums bit for bit.
+#include <mutex>
+#include <unordered_map>
+
 #include "ojf_integrate.h"
 
 namespace ojf {
@@ -284,8 +287,31 @@ __global__ __launch_bounds__(256) void integrate_finalize_kernel(IntegrateArgs a
     for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x)
         finalize_voxel(a, a.touched[a.list_base + t], per_pixel, sem);
     if (a.stats && blockIdx.x == 0 && threadIdx.x == 0 && count) atomicAdd(&a.stats[0], count);
+    // the counter set the NEXT call will use (nobody touches it during this one): clean it here instead of a memset
+    // launch in front of every frame's accumulate kernel
+    if (a.counters_next && blockIdx.x == 0 && threadIdx.x < 32) a.counters_next[threadIdx.x] = 0;
 }
 
+}  // namespace ojf
+
+namespace ojf {
+// FAST frame path: the header holds two counter sets used alternately; a call counts in one and its finalize kernel
+// zeroes the other, so no memset launch sits between the net and the accumulate kernel (~8 us per frame).  Which
+// set comes next is host state per workspace address.  Any phase is valid on a zeroed header (fresh workspace,
+// ojf_integrate_workspace_init), and after a call exactly the other set is clean - the invariant survives address
+// reuse by the caller's allocator.
+static std::mutex g_phase_mutex;
+static std::unordered_map<const void *, unsigned> g_phase;
+static unsigned next_phase(const void *ws)
+{
+    std::lock_guard<std::mutex> lock(g_phase_mutex);
+    return g_phase[ws]++ & 1u;
+}
+static void reset_phase(const void *ws)
+{
+    std::lock_guard<std::mutex> lock(g_phase_mutex);
+    g_phase.erase(ws);
+}
 }  // namespace ojf
 
 OJF_API size_t ojf_integrate_workspace_bytes(int X, int Y, int Z, int h, int w, int n_tail, int mode)
@@ -308,6 +334,7 @@ OJF_API int ojf_integrate_workspace_init(void *ws, size_t ws_bytes, int X, int Y
     // FAST: header + dense head table must start zeroed (every call restores that invariant)
     const size_t zero_bytes = mode == OJF_MODE_FAST ? kHeaderBytes + (size_t)X * Y * Z * sizeof(unsigned int)
                                                     : kHeaderBytes;
+    reset_phase(ws);
     return check_hip(hipMemsetAsync(ws, 0, zero_bytes, as_stream(stream)), "workspace memset");
 }
 
@@ -340,13 +367,21 @@ OJF_API int ojf_integrate(const float *depth_filtered, const float *Ki, const fl
     a.depth = depth_filtered; a.est = est; a.tsdf = tsdf; a.wgt = wgt;
     a.sem_ids = sem_ids; a.sem_scores = sem_scores; a.id_vol = id_vol; a.score_vol = score_vol;
     a.counters = reinterpret_cast<unsigned int *>(base);
+    a.counters_next = nullptr;
     a.head = nullptr; a.recs = nullptr; a.touched = nullptr; a.tile_new = nullptr; a.list_base = 0; a.n_tiles = 0; a.stats = stats;
     a.X = X; a.Y = Y; a.Z = Z; a.h = h; a.w = w; a.n_points = n_points; a.n_tail = n_tail;
     a.est_stride = est_stride; a.trunc = trunc;
     const Camera cam = make_camera(Ki, E, origin, res);
 
-    OJF_HIP(hipMemsetAsync(a.counters, 0, kHeaderBytes, st));
-    if (mode == OJF_MODE_PARITY) return integrate_parity(a, cam, base + kHeaderBytes, ws_bytes - kHeaderBytes, st);
+    if (mode == OJF_MODE_PARITY) {
+        OJF_HIP(hipMemsetAsync(a.counters, 0, kHeaderBytes, st));
+        return integrate_parity(a, cam, base + kHeaderBytes, ws_bytes - kHeaderBytes, st);
+    }
+    {
+        const unsigned phase = next_phase(ws);
+        a.counters = reinterpret_cast<unsigned int *>(base) + 32 * phase;
+        a.counters_next = reinterpret_cast<unsigned int *>(base) + 32 * (1 - phase);
+    }
 
     const int tiles = (int)tile_count(h, w);
     {
@@ -394,10 +429,15 @@ OJF_API int ojf_integrate_entries(const float *values, const int64_t *indices, c
     a.head = reinterpret_cast<unsigned int *>(base + kHeaderBytes);
     a.recs = reinterpret_cast<VoxelRec *>(base + kHeaderBytes + nvox * sizeof(unsigned int));
     a.touched = reinterpret_cast<unsigned int *>(base + kHeaderBytes + nvox * sizeof(unsigned int) + entries * sizeof(VoxelRec));
-    a.stats = stats; a.tile_new = nullptr; a.list_base = 0; a.n_tiles = 0;
+    a.stats = stats; a.tile_new = nullptr; a.list_base = 0; a.n_tiles = 0; a.counters_next = nullptr;
     a.X = X; a.Y = Y; a.Z = Z; a.h = 1; a.w = 1; a.n_points = 1; a.est_stride = 0; a.trunc = 0.0f;
     a.n_tail = 1;  // finalize maps entry id -> row as (id - 1) / (n_tail * 8)
-    OJF_HIP(hipMemsetAsync(a.counters, 0, kHeaderBytes, st));
+    OJF_HIP(hipMemsetAsync(base, 0, kHeaderBytes, st));
+    {   // same alternation as the frame path (the two may share a workspace): count in one set, leave the other clean
+        const unsigned phase = next_phase(ws);
+        a.counters = reinterpret_cast<unsigned int *>(base) + 32 * phase;
+        a.counters_next = reinterpret_cast<unsigned int *>(base) + 32 * (1 - phase);
+    }
     if (stats) OJF_HIP(hipMemsetAsync(stats, 0, 4 * sizeof(uint32_t), st));
     if (n_rows > 0) {
         EntryArgs e{values, indices, weights, row_ids, (int)n_rows};

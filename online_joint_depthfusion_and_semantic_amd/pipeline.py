@@ -16,6 +16,7 @@ fancy-index slices of valid pixels: pipeline.py:74-171) never exist here.
 import torch
 
 from . import ops
+from . import _lib
 from ._lib import MODE_FAST, MODE_PARITY
 from .engine import FusionNetEngine
 from .extractor import Extractor
@@ -62,8 +63,8 @@ class Pipeline(torch.nn.Module):
     # ---- live stage timing (HIP events on the launch stream; bench.py) ---------------------------
     def _mark(self):
         if self.profile:
-            e = torch.cuda.Event(enable_timing=True)
-            e.record(torch.cuda.current_stream(self.device))
+            e = _lib.TimingEvent()  # no system-scope fence: a default event costs ~5 us of idle queue per record
+            e.record(torch.cuda.current_stream(self.device).cuda_stream)
             self._marks.append(e)
 
     def reset_profile(self):
