@@ -92,6 +92,15 @@ int ojf_integrate(const float *depth_filtered_dev, const float *Kinv_host, const
                   uint8_t *id_vol_dev, uint16_t *score_vol_dev, int X, int Y, int Z, int h, int w,
                   int mode, void *workspace_dev, size_t workspace_bytes, uint32_t *stats_dev,
                   ojf_stream_t stream);
+/* Same, with the validity mask of modules/pipeline.py:196 applied inside the kernels: depth_dev is the RAW frame and
+ * mask_dev u8[h*w] (torch bool; NULL = none) marks the valid pixels - torch.where(mask == 0, 0, frame) without its
+ * launch.  Bit-identical to ojf_integrate on the filtered frame. */
+int ojf_integrate_masked(const float *depth_dev, const uint8_t *mask_dev, const float *Kinv_host, const float *E_host,
+                         const double *origin_host, double resolution, const float *est_dev, int est_stride,
+                         int n_points, int n_tail, float trunc, uint16_t *tsdf_dev, uint16_t *weights_dev,
+                         const uint8_t *sem_ids_dev, const float *sem_scores_dev, uint8_t *id_vol_dev,
+                         uint16_t *score_vol_dev, int X, int Y, int Z, int h, int w, int mode, void *workspace_dev,
+                         size_t workspace_bytes, uint32_t *stats_dev, ojf_stream_t stream);
 
 /* Entry-list variant with the reference Integrator's own inputs (modules/integrator.py:15-126 fed by
  * Pipeline._prepare_volume_update, modules/pipeline.py:137-171): n_rows = valid pixels x n_tail rows, each

@@ -42,6 +42,8 @@ SIGNATURES = {
     'ojf_integrate_workspace_init': (_i, [_vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ojf_integrate': (_i, [_vp, _vp, _vp, _vp, _d, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp,
                            _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
+    'ojf_integrate_masked': (_i, [_vp, _vp, _vp, _vp, _vp, _d, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp,
+                                  _i, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
     'ojf_integrate_entries': (_i, [_vp, _vp, _vp, _vp, _vp, _c.c_int64, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp, _vp]),
     'ojf_net_create': (_i, [_c.POINTER(_vp), _i, _i, _i, _i, _f, _c.POINTER(ConvLayer), _i, _i, _i]),
     'ojf_net_destroy': (None, [_vp]),

@@ -25,7 +25,8 @@ constexpr double kFixInv = 1.0 / 17592186044416.0;
 constexpr size_t kHeaderBytes = 256;                  // two sets of 32 counters: [0] counter-allocated touched voxels, [2] counter-allocated records
 
 struct IntegrateArgs {
-    const float *depth;  // filtered frame
+    const float *depth;  // filtered frame, or the raw frame when `mask` is set
+    const unsigned char *mask;  // optional validity mask (pipeline.py:196): depth counts as 0 where it is 0
     const float *est;
     uint16_t *tsdf;
     uint16_t *wgt;
@@ -45,6 +46,12 @@ struct IntegrateArgs {
     int X, Y, Z, h, w, n_points, n_tail, est_stride;
     float trunc;
 };
+
+__device__ __forceinline__ float frame_depth(const IntegrateArgs &a, int n)
+{
+    const float z = a.depth[n];
+    return (a.mask && !a.mask[n]) ? 0.0f : z;  // torch.where(mask == 0, 0, frame)
+}
 
 size_t fast_workspace_bytes(int X, int Y, int Z, int h, int w, int n_tail);
 size_t parity_workspace_bytes(int X, int Y, int Z, int h, int w, int n_tail);

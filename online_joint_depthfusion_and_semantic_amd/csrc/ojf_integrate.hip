@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(Integra
         if (r < a.h && c < a.w) {
             float pw[3];
             double cv[3], dir[3];
-            unproject(r, c, a.depth[r * a.w + c], cam, pw);
+            unproject(r, c, frame_depth(a, r * a.w + c), cam, pw);
             ray_frame(pw, cam, cv, dir);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(Integra
         const int r = ty * 8 + (p >> 3), c = tx * 8 + (p & 7);
         if (r >= a.h || c >= a.w) continue;
         const int n = r * a.w + c;
-        const float z = a.depth[n];
+        const float z = frame_depth(a, n);
         if (!(z != 0.0f)) continue;  // modules/pipeline.py:145-146
         const double cv[3] = {frame[0][p], frame[1][p], frame[2][p]};
         const double dir[3] = {frame[3][p], frame[4][p], frame[5][p]};
@@ -344,6 +344,16 @@ OJF_API int ojf_integrate(const float *depth_filtered, const float *Ki, const fl
                           uint8_t *id_vol, uint16_t *score_vol, int X, int Y, int Z, int h, int w, int mode,
                           void *ws, size_t ws_bytes, uint32_t *stats, ojf_stream_t stream)
 {
+    return ojf_integrate_masked(depth_filtered, nullptr, Ki, E, origin, res, est, est_stride, n_points, n_tail, trunc, tsdf, wgt,
+                                sem_ids, sem_scores, id_vol, score_vol, X, Y, Z, h, w, mode, ws, ws_bytes, stats, stream);
+}
+
+OJF_API int ojf_integrate_masked(const float *depth_filtered, const uint8_t *mask, const float *Ki, const float *E,
+                                 const double *origin, double res, const float *est, int est_stride, int n_points, int n_tail,
+                                 float trunc, uint16_t *tsdf, uint16_t *wgt, const uint8_t *sem_ids, const float *sem_scores,
+                                 uint8_t *id_vol, uint16_t *score_vol, int X, int Y, int Z, int h, int w, int mode, void *ws,
+                                 size_t ws_bytes, uint32_t *stats, ojf_stream_t stream)
+{
     using namespace ojf;
     if (!depth_filtered || !Ki || !E || !origin || !est || !tsdf || !wgt || !ws)
         return fail("ojf_integrate: null pointer argument");
@@ -364,7 +374,7 @@ OJF_API int ojf_integrate(const float *depth_filtered, const float *Ki, const fl
     hipStream_t st = as_stream(stream);
     char *base = static_cast<char *>(ws);
     IntegrateArgs a;
-    a.depth = depth_filtered; a.est = est; a.tsdf = tsdf; a.wgt = wgt;
+    a.depth = depth_filtered; a.mask = mask; a.est = est; a.tsdf = tsdf; a.wgt = wgt;
     a.sem_ids = sem_ids; a.sem_scores = sem_scores; a.id_vol = id_vol; a.score_vol = score_vol;
     a.counters = reinterpret_cast<unsigned int *>(base);
     a.counters_next = nullptr;
@@ -423,7 +433,7 @@ OJF_API int ojf_integrate_entries(const float *values, const int64_t *indices, c
     hipStream_t st = as_stream(stream);
     char *base = static_cast<char *>(ws);
     IntegrateArgs a;
-    a.depth = nullptr; a.est = nullptr; a.tsdf = tsdf; a.wgt = wgt;
+    a.depth = nullptr; a.mask = nullptr; a.est = nullptr; a.tsdf = tsdf; a.wgt = wgt;
     a.sem_ids = row_ids; a.sem_scores = row_scores; a.id_vol = id_vol; a.score_vol = score_vol;
     a.counters = reinterpret_cast<unsigned int *>(base);
     a.head = reinterpret_cast<unsigned int *>(base + kHeaderBytes);

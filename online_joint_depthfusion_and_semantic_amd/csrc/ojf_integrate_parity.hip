@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void parity_emit_kernel(IntegrateArgs a, Camer
     const int n = item / a.n_tail;   // pixel-major so that slot order == entry order
     const int k = item - n * a.n_tail;
     const size_t slot0 = (size_t)item * 8;
-    const float z = a.depth[n];
+    const float z = frame_depth(a, n);
     const bool valid = (z != 0.0f);
     RaySample s;
     if (valid) {

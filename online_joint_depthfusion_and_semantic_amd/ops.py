@@ -99,10 +99,12 @@ class IntegrateWorkspace:
 
 def integrate(depth_filtered, Ki, E, origin, resolution, est, tsdf, weights, workspace,
               n_points=9, n_tail=7, trunc=0.1, est_stride=None, sem_ids=None, sem_scores=None,
-              id_vol=None, score_vol=None, mode=MODE_FAST, stats=False):
+              id_vol=None, score_vol=None, mode=MODE_FAST, stats=False, mask=None):
     """Scatter the clamped net output into the volumes, in place.  est: cuda f32 rows with
     ``est_stride`` floats per pixel (default: est.shape[-1]).  stats=True fills ``workspace.stats``
-    ({touched voxels, scatter entries, records, 0}; costs ~14 us per frame of same-line atomics)."""
+    ({touched voxels, scatter entries, records, 0}; costs ~14 us per frame of same-line atomics).
+    mask: optional cuda bool [h, w]; then ``depth_filtered`` is the RAW frame and the kernels apply
+    ``torch.where(mask == 0, 0, frame)`` (pipeline.py:196) themselves - same result, one launch less."""
     _lib.require_gpu()
     lib = _lib.load()
     depth_filtered = depth_filtered.reshape(depth_filtered.shape[-2], depth_filtered.shape[-1])
@@ -120,7 +122,10 @@ def integrate(depth_filtered, Ki, E, origin, resolution, est, tsdf, weights, wor
         assert score_vol.dtype == torch.float16 and score_vol.is_contiguous() and score_vol.shape == tsdf.shape
     assert workspace.key == ((X, Y, Z), h, w, n_tail, mode), 'workspace built for another configuration'
     origin = _origin_array(origin)
-    rc = lib.ojf_integrate(_lib.ptr(depth_filtered), _lib.ptr(Ki), _lib.ptr(E), _lib.ptr(origin),
+    if mask is not None:
+        mask = mask.reshape(h, w)
+        assert mask.is_cuda and mask.dtype == torch.bool and mask.is_contiguous()
+    rc = lib.ojf_integrate_masked(_lib.ptr(depth_filtered), _lib.ptr(mask), _lib.ptr(Ki), _lib.ptr(E), _lib.ptr(origin),
                            float(resolution), _lib.ptr(est), int(est_stride), n_points, n_tail,
                            float(trunc), _lib.ptr(tsdf), _lib.ptr(weights), _lib.ptr(sem_ids),
                            _lib.ptr(sem_scores), _lib.ptr(id_vol), _lib.ptr(score_vol), X, Y, Z, h, w,

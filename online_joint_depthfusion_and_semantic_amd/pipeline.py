@@ -221,13 +221,19 @@ class Pipeline(torch.nn.Module):
         scores = scores.to(self.device).float().reshape(h * w).contiguous()
         return sem_ids, scores
 
-    def _frames(self, batch):
+    def _frames(self, batch, filtered=True):
+        """(frame, filtered frame) of pipeline.py:194-199; with ``filtered=False`` the second item is the bool mask
+        instead and the integrate kernels apply it themselves (ojf_integrate_masked)."""
         frame = batch[self.config.DATA.input]
         frame = frame.reshape(frame.shape[0], frame.shape[-2], frame.shape[-1])  # squeeze_(1) of [b,1,h,w]
         if frame.shape[0] != 1:
             raise ValueError('Pipeline: batch size 1 only (one scene per frame, pipeline.py:199)')
         frame = frame.to(self.device).float().contiguous()
         mask = batch['mask'].to(self.device).reshape(frame.shape)
+        if not filtered:
+            if mask.dtype != torch.bool:
+                mask = mask != 0
+            return frame[0], mask[0].contiguous()
         zero = self.__dict__.get('_zero')
         if zero is None or zero.device != frame.device:
             zero = self.__dict__['_zero'] = torch.zeros((), dtype=torch.float32, device=frame.device)
@@ -239,7 +245,7 @@ class Pipeline(torch.nn.Module):
         self.device = torch.device(device)
         self._shape = batch['image'].shape
         sem_ids, scores = self._frame_semantics(batch)
-        frame, filtered = self._frames(batch)
+        frame, mask = self._frames(batch, filtered=False)
         h, w = frame.shape
 
         scene_id = batch['frame_id'][0].split('/')[0]
@@ -261,12 +267,12 @@ class Pipeline(torch.nn.Module):
 
         sem = bool(self.config.DATA.semantics)
         ws = self._get_workspace(tsdf.shape, h, w, self.device)
-        ops.integrate(filtered, Ki, E, volume['origin'], volume['resolution'], self._est, tsdf, weights, ws,
+        ops.integrate(frame, Ki, E, volume['origin'], volume['resolution'], self._est, tsdf, weights, ws,
                       n_points=P, n_tail=self.config.FUSION_MODEL.n_tail_points,
                       trunc=self.config.DATA.init_value,
                       sem_ids=sem_ids if sem else None, sem_scores=scores if sem else None,
                       id_vol=volume['ids_est'] if sem else None, score_vol=volume['scores'] if sem else None,
-                      mode=self._integrate_mode)
+                      mode=self._integrate_mode, mask=mask)  # filtered frame of pipeline.py:196 formed in the kernels
         self._mark()
 
         database.state[scene_id] = True  # volumes were updated in place (pipeline.py:239-244)

@@ -348,3 +348,35 @@ def test_integrate_hash_overflow_path(cuda, semantics):
             if semantics:
                 assert n_mismatch(g['ids'].cpu().numpy(), ref['ids']) == 0
                 assert n_mismatch(g['scores'].cpu().numpy(), ref['scores']) == 0
+
+
+@pytest.mark.parametrize('mode', [ops.MODE_FAST, ops.MODE_PARITY])
+@pytest.mark.parametrize('semantics', [False, True])
+def test_masked_integrate_equals_filtered_frame(cuda, mode, semantics):
+    """ojf_integrate_masked (raw frame + validity mask, pipeline.py:196 formed inside the kernels) is bit-identical to
+    ojf_integrate on torch.where(mask, frame, 0), in both modes, over several frames."""
+    h, w, grid = 29, 37, 32
+    st = make_stream(h, w, grid)
+    vols = fresh_volumes(grid, semantics)
+    a, b = to_cuda(vols, cuda), to_cuda(vols, cuda)
+    ws = ops.IntegrateWorkspace((grid,) * 3, h, w, 7, mode, cuda)
+    rng = np.random.default_rng(4)
+    for i in range(3):
+        fi = frame_inputs(st, i)
+        raw = fi['depth'].astype(np.float32).copy()
+        mask = rng.random((h, w)) > 0.3
+        raw[~mask & (rng.random((h, w)) > 0.5)] = np.nan  # what the mask hides may be anything
+        filt = np.where(mask, raw, np.float32(0)).astype(np.float32)
+        kw_a, kw_b = {}, {}
+        if semantics:
+            ids, sc = _t(fi['sem_ids'].reshape(-1), cuda), _t(fi['sem_scores'].reshape(-1), cuda)
+            kw_a = dict(sem_ids=ids, sem_scores=sc, id_vol=a['ids'], score_vol=a['scores'])
+            kw_b = dict(sem_ids=ids, sem_scores=sc, id_vol=b['ids'], score_vol=b['scores'])
+        est = _t(fi['est'], cuda)
+        ops.integrate(_t(filt, cuda), fi['Ki'], fi['E'], st.origin, st.resolution, est, a['tsdf'], a['wgt'], ws, mode=mode, **kw_a)
+        ops.integrate(_t(raw, cuda), fi['Ki'], fi['E'], st.origin, st.resolution, est, b['tsdf'], b['wgt'], ws, mode=mode,
+                      mask=torch.from_numpy(mask).to(cuda), **kw_b)
+    assert int((a['wgt'].float() > 0).sum()) > 200
+    for key in a:
+        x, y = a[key], b[key]
+        assert torch.equal(x.view(torch.uint8) if x.dtype != torch.uint8 else x, y.view(torch.uint8) if y.dtype != torch.uint8 else y), key
