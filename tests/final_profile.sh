@@ -20,3 +20,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/kp -o k
 python tests/adapnet_engine_probe.py 2>&1 | grep -v MIOpen > gpurun_out/final/adapnet_engine_probe.txt
 python tests/mesh_timing.py 256 > gpurun_out/final/mesh_timing.txt 2>&1
 python tests/mesh_timing.py 512 >> gpurun_out/final/mesh_timing.txt 2>&1
+python tests/pmc_traffic.py $(find gpurun_out/final/pf -name '*counter_collection.csv' | head -1) $(find gpurun_out/final/pw -name '*counter_collection.csv' | head -1) 22 gpurun_out/final/traffic_pmc.json > gpurun_out/final/traffic_pmc.txt 2>&1
