@@ -2,7 +2,7 @@
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from online_joint_depthfusion_and_semantic_amd import ops
 from helpers import frame_inputs, make_stream, fresh_volumes, to_cuda
 

@@ -17,7 +17,7 @@ python bench.py --height 480 --width 640 --grid 512 --steps 60 --warmup 5 --cpu-
 python bench.py --semantics --semantic-strategy predict --steps 100 --cpu-frames 0 > gpurun_out/final/bench_predict.json 2>/dev/null
 python bench.py --semantics --semantic-strategy predict --seg-engine torch --steps 100 --cpu-frames 0 > gpurun_out/final/bench_predict_torch.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/kp -o kp -- python bench.py --semantics --semantic-strategy predict --steps 50 --warmup 10 --cpu-frames 0 > /dev/null 2> gpurun_out/final/kp.err
-python tests/adapnet_engine_probe.py 2>&1 | grep -v MIOpen > gpurun_out/final/adapnet_engine_probe.txt
-python tests/mesh_timing.py 256 > gpurun_out/final/mesh_timing.txt 2>&1
-python tests/mesh_timing.py 512 >> gpurun_out/final/mesh_timing.txt 2>&1
-python tests/pmc_traffic.py $(find gpurun_out/final/pf -name '*counter_collection.csv' | head -1) $(find gpurun_out/final/pw -name '*counter_collection.csv' | head -1) 22 gpurun_out/final/traffic_pmc.json > gpurun_out/final/traffic_pmc.txt 2>&1
+python tools/adapnet_engine_probe.py 2>&1 | grep -v MIOpen > gpurun_out/final/adapnet_engine_probe.txt
+python tools/mesh_timing.py 256 > gpurun_out/final/mesh_timing.txt 2>&1
+python tools/mesh_timing.py 512 >> gpurun_out/final/mesh_timing.txt 2>&1
+python tools/pmc_traffic.py $(find gpurun_out/final/pf -name '*counter_collection.csv' | head -1) $(find gpurun_out/final/pw -name '*counter_collection.csv' | head -1) 22 gpurun_out/final/traffic_pmc.json > gpurun_out/final/traffic_pmc.txt 2>&1

@@ -9,7 +9,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 cp online_joint_depthfusion_and_semantic_amd/libojf.so /tmp/libojf_keep.so
 for a in 0 1 2 4 3 7; do
-  cp tests/microbench/libojf_abl$a.bin online_joint_depthfusion_and_semantic_amd/libojf.so
+  cp tools/microbench/libojf_abl$a.bin online_joint_depthfusion_and_semantic_amd/libojf.so
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abl$a -o kt -- python bench.py --steps 40 --warmup 5 --cpu-frames 0 > /dev/null 2>&1
   python -c "
 import csv
