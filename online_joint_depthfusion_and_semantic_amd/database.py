@@ -243,7 +243,26 @@ class Database(torch.utils.data.Dataset):
                               resolution=float(self.resolution[scene_id]), palette=palette)
         return m['vertices'], m['faces'], m['normals'], m['rgb']
 
-    def save(self, path, save_mode='tsdf', scene_id=None, palette=None):
+    def save_to_workspace(self, workspace, mode, save_mode='ply'):
+        """database.py:141-177: every scene that holds integrated frames goes to the workspace's output directory as
+        ``<scene>.tsdf_<mode>.hf5`` / ``.weights_<mode>.hf5`` / ``.semantic_<mode>.hf5`` ('tsdf'), ``<scene>_<mode>.ply``
+        ('ply'), or all of them ('test').  ``workspace`` offers save_tsdf_data / save_weights_data /
+        save_semantic_data / save_ply_data(file, volume) (utils/setup.py:253-267; drivers.Workspace)."""
+        if save_mode not in ('tsdf', 'ply', 'test'):
+            return  # the reference's if / elif chain falls through silently
+        for s in self.scenes:
+            if not self.state[s]:
+                continue
+            base = s.replace('/', '.')
+            if save_mode in ('tsdf', 'test'):
+                workspace.save_tsdf_data('{}.tsdf_{}.hf5'.format(base, mode), self.scenes_est[s].volume)
+                workspace.save_weights_data('{}.weights_{}.hf5'.format(base, mode), self.fusion_weights[s])
+                if self.semantics:
+                    workspace.save_semantic_data('{}.semantic_{}.hf5'.format(base, mode), self.ids_est[s].volume)
+            if save_mode in ('ply', 'test'):
+                workspace.save_ply_data('{}_{}.ply'.format(base, mode), self.scenes_est[s].volume)
+
+    def save(self, path, save_mode='ply', scene_id=None, palette=None):
         """database.py:172-261: 'tsdf' (volumes), 'ply' (mesh), 'test' (volumes + mesh + label-coloured mesh whose
         alpha channel carries the label id)."""
         if scene_id is None:
@@ -271,13 +290,6 @@ class Database(torch.utils.data.Dataset):
                   'weights': ('weights', host(self.fusion_weights[scene_id]))}
         if self.semantics:
             arrays['semantics'] = ('semantics', host(self.ids_est[scene_id].volume))
-        try:
-            import h5py
-        except ImportError:
-            h5py = None
-        for name, (key, arr) in arrays.items():
-            if h5py is not None:  # same file names / dataset names as database.py:184-201
-                with h5py.File(os.path.join(path, '{}.{}.hf5'.format(base, name)), 'w') as hf:
-                    hf.create_dataset(key, shape=arr.shape, data=arr)
-            else:
-                np.save(os.path.join(path, '{}.{}.npy'.format(base, name)), arr)
+        from .datasets import save_volume_hdf
+        for name, (key, arr) in arrays.items():  # same file / dataset names as database.py:184-201 (npz without h5py)
+            save_volume_hdf(os.path.join(path, '{}.{}.hf5'.format(base, name)), key, arr)

@@ -85,6 +85,22 @@ def export_grid_npz(path, sdf, bbox, voxel_size, labels=None):
     return out
 
 
+def save_volume_hdf(path, key, data):
+    """utils/saving.py:16-39 / modules/database.py:184-201: one gzip-compressed dataset ``key`` ('TSDF' | 'weights' |
+    'semantics') per ``*.hf5`` file.  Without h5py the same array goes to ``<path stem>.npz`` under the same key."""
+    import torch
+    arr = data.detach().cpu().numpy() if torch.is_tensor(data) else np.asarray(data)
+    try:
+        import h5py
+    except ImportError:
+        out = os.path.splitext(path)[0] + '.npz'
+        np.savez_compressed(out, **{key: arr})
+        return out
+    with h5py.File(path, 'w') as f:
+        f.create_dataset(key, shape=arr.shape, data=arr, compression='gzip', compression_opts=9)
+    return path
+
+
 class ToTensor:
     """utils/transform.py:5-30: ndarrays -> tensors, the image HWC -> CHW."""
 

@@ -48,9 +48,68 @@ def _loader(dataset, scenes, shuffle=False):
     return torch.utils.data.DataLoader(torch.utils.data.Subset(dataset, idx), batch_size=1, shuffle=shuffle)
 
 
+class Workspace:
+    """utils/setup.py:224-274: experiment directory with model / logs / output sub-directories, the two text loggers
+    and the data writers ``Database.save_to_workspace`` calls.  Scalars go to ``logs/scalars.csv`` (tag, step, value)
+    instead of a tensorboard event file (tensorboard glue is out of scope); ``writer.add_scalar`` keeps
+    the SummaryWriter call shape so the loop reads like train_fusion.py:178-224."""
+
+    class _Scalars:
+        def __init__(self, path):
+            self.path = path
+
+        def add_scalar(self, tag, value, global_step=None):
+            with open(self.path, 'a') as f:
+                f.write('{},{},{}\n'.format(tag, global_step, float(value)))
+
+    def __init__(self, path):
+        self.workspace_path = path
+        self.model_path = os.path.join(path, 'model')
+        self.log_path = os.path.join(path, 'logs')
+        self.output_path = os.path.join(path, 'output')
+        for d in (self.workspace_path, self.model_path, self.log_path, self.output_path):
+            os.makedirs(d, exist_ok=True)
+        self.writer = Workspace._Scalars(os.path.join(self.log_path, 'scalars.csv'))
+
+    def log(self, message, mode='train'):
+        name = {'train': 'training', 'val': 'validation'}.get(mode, mode)
+        with open(os.path.join(self.log_path, name + '.logs'), 'a') as f:
+            f.write(str(message) + '\n')
+
+    def save_config(self, config):
+        import json
+        with open(os.path.join(self.workspace_path, 'config.json'), 'w') as f:
+            json.dump(config, f, default=str)
+
+    def save_model_state(self, state, is_best=False, name=None):
+        """utils/saving.py:67-91: 'last.pth.tar', or ``name`` / 'best.pth.tar' when ``is_best``."""
+        torch.save(state, os.path.join(self.model_path, (name or 'best.pth.tar') if is_best else 'last.pth.tar'))
+
+    def _save_volume(self, file, key, data):
+        from .datasets import save_volume_hdf
+        save_volume_hdf(os.path.join(self.output_path, file), key, data)
+
+    def save_tsdf_data(self, file, data):
+        self._save_volume(file, 'TSDF', data)
+
+    def save_weights_data(self, file, data):
+        self._save_volume(file, 'weights', data)
+
+    def save_semantic_data(self, file, data):
+        self._save_volume(file, 'semantics', data)
+
+    def save_ply_data(self, file, data, resolution=0.01):
+        """utils/saving.py:42-48 (hard-coded 1 cm spacing there); the mesh comes from the HIP kernel (mesh.py)."""
+        from . import mesh
+        vol = data if torch.is_tensor(data) else torch.from_numpy(np.ascontiguousarray(data))
+        m = mesh.extract_mesh(vol.to(device='cuda', dtype=torch.float16).contiguous(), resolution=float(resolution))
+        mesh.save_ply(os.path.join(self.output_path, file), m['vertices'], m['faces'], m['normals'])
+
+
 def test_fusion(config, dataset, device, rank=0, world=1, state_dict=None, log=print, test_dir=None):
-    """Fuses this rank's scenes frame by frame, then filter -> evaluate (test_fusion.py:73-118) and, when ``test_dir``
-    is given, exports every scene with ``SETTINGS.save_mode`` ('test' | 'ply' | 'tsdf', test_fusion.py:120-122)."""
+    """Fuses this rank's scenes frame by frame, then filter -> filter_semantics -> evaluate -> evaluate_semantics
+    (test_fusion.py:73-118, written to ``test_dir``/test.logs like the reference's logger) and, when ``test_dir`` is
+    given, exports every scene with ``SETTINGS.save_mode`` ('test' | 'ply' | 'tsdf', test_fusion.py:120-122)."""
     shard = ShardedScenes(dataset, rank, world)
     database = Database(shard, database_config(config))
     pipeline = Pipeline(config)
@@ -64,69 +123,260 @@ def test_fusion(config, dataset, device, rank=0, world=1, state_dict=None, log=p
             pipeline.fuse(_host_pose_batch(batch, device), database, device)
     pipeline.check()  # loud if the split-fp16 range guard fired
     database.filter(value=config.TESTING.outlier_filter_val)  # on device; to_numpy() only for export
+    semantics = bool(config.DATA.semantics)
+    if semantics:
+        database.filter_semantics(value=5)  # test_fusion.py:88-89
+
+    lines = []
+
+    def emit(msg):
+        lines.append(msg)
+        log('rank {} {}'.format(rank, msg))
     results, per_scene = database.evaluate(mode='test')
+    emit('Average test results over test scenes:')
     for k, v in results.items():
-        log('rank {} {}: {}'.format(rank, k, v))
+        emit('{}: {}'.format(k, v))
+    emit('Per scene results')
+    for scene, r in per_scene.items():
+        emit('Scene: ' + scene)
+        for k, v in r.items():
+            emit('{}: {}'.format(k, v))
+    if semantics and config.DATA.get('semantic_grid', False):  # test_fusion.py:108-118
+        sem_results, class_iou = database.evaluate_semantics(mode='test')
+        emit('Average semantic results over test scenes')
+        for k, v in sem_results.items():
+            emit('{:12}:\t{}'.format(k, v))
+        emit('Per scene semantic results:')
+        for scene, r in class_iou.items():
+            emit('Scene: ' + scene)
+            for k, v in r.items():
+                emit('{}: {}'.format(k, v))
+        results = dict(results, **sem_results)
     if test_dir is not None:
         os.makedirs(test_dir, exist_ok=True)
+        with open(os.path.join(test_dir, 'test.logs' if world == 1 else 'test.rank%d.logs' % rank), 'a') as f:
+            f.write('\n'.join(lines) + '\n')
         for scene_id in database.scenes_est.keys():
             database.save(path=test_dir, save_mode=config.SETTINGS.get('save_mode', 'test'), scene_id=scene_id)
     return results, per_scene, database
 
 
-def train_fusion(config, dataset, device, rank=0, world=1, max_steps=None, log=print, checkpoint_dir=None):
-    """Online learning loop (train_fusion.py:133-189) on this rank's scenes."""
+def _dist_on():
+    d = torch.distributed
+    return d.is_available() and d.is_initialized() and d.get_world_size() > 1
+
+
+def _agree(values, op='max'):
+    """A number (or a fixed-length list of numbers) agreed on by all ranks in ONE all-reduce (gloo: CPU tensor,
+    RCCL: device tensor)."""
+    scalar = not isinstance(values, (list, tuple))
+    vals = [float(values)] if scalar else [float(v) for v in values]
+    if _dist_on():
+        d = torch.distributed
+        dev = torch.device('cuda', torch.cuda.current_device()) if d.get_backend() == 'nccl' else torch.device('cpu')
+        t = torch.tensor(vals, dtype=torch.float64, device=dev)
+        d.all_reduce(t, op={'max': d.ReduceOp.MAX, 'sum': d.ReduceOp.SUM, 'min': d.ReduceOp.MIN}[op])
+        vals = t.tolist()
+    return vals[0] if scalar else vals
+
+
+def sync_buffers(net):
+    """BatchNorm running statistics drift apart across ranks (batch 1, per-rank frames): average the float buffers
+    (one flat all-reduce) and take the max of the step counters before anything is checkpointed or validated, so
+    that every rank holds - and rank 0 saves - the same network."""
+    if not _dist_on():
+        return
+    d = torch.distributed
+    fl = [b for b in net.buffers() if b.is_floating_point()]
+    if fl:
+        flat = torch.cat([b.detach().reshape(-1).float() for b in fl])
+        d.all_reduce(flat, op=d.ReduceOp.SUM)
+        flat /= d.get_world_size()
+        off = 0
+        for b in fl:
+            b.copy_(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
+    for b in net.buffers():
+        if not b.is_floating_point():
+            d.all_reduce(b, op=d.ReduceOp.MAX)
+
+
+def _default_frame_step(pipeline, criterion, batch, database, device):
+    out = pipeline.fuse_training(_host_pose_batch(batch, device), database, device)
+    return criterion(out['tsdf_fused'], out['tsdf_target'])
+
+
+VAL_KEYS = ('mse', 'mad', 'iou', 'acc')
+
+
+def validate(config, pipeline, dataset, database, scenes, device, workspace=None):
+    """train_fusion.py:201-214: fuse the validation frames in eval mode, filter(0.5), evaluate.  Returns the metric
+    SUMS over this rank's scenes (always the four VAL_KEYS, so that the cross-rank reduction has one shape) and the
+    scene count (the caller averages over all ranks' scenes, like database.py:304 does over one process's)."""
+    database.reset()
+    pipeline.eval()
+    with torch.no_grad():
+        for batch in _loader(dataset, scenes):
+            if not torch.all(torch.isfinite(batch['extrinsics'])):
+                continue
+            pipeline.fuse(_host_pose_batch(batch, device), database, device)
+    pipeline.check()
+    database.filter(value=0.5)
+    ev = database.evaluate(mode='val', workspace=workspace)
+    n = len(database.scenes_est.keys())
+    return [ev.get(k, 0.) * n for k in VAL_KEYS], n
+
+
+def train_fusion(config, dataset, device, rank=0, world=1, max_steps=None, log=print, checkpoint_dir=None,
+                 val_dataset=None, workspace=None, frame_step=None):
+    """Online learning loop (train_fusion.py:35-255) on this rank's scenes.
+
+    Collective schedule: the reference is single-process; here every rank walks ITS OWN frame stream, so shards
+    of different length, ranks without scenes and frames skipped for a non-finite pose must not change how often
+    ``grads.reduce()`` is called.  Every epoch the ranks agree on ``n_steps = max(len(local loader))``; step ``i``
+    runs on every rank (a rank that has no frame i, or skips it, contributes its zero / partial gradient), and the
+    accumulation boundary ``(i + 1) % accumulation_steps == 0 or i == n_steps - 1`` (train_fusion.py:186) as well as
+    the evaluation boundary (:191) are functions of the common ``i`` alone.
+
+    ``val_dataset``: validation frames (fused every ``SETTINGS.eval_freq`` steps and at the end of the epoch, best /
+    last checkpoints, train_fusion.py:191-251); ``workspace``: a ``Workspace`` (default: ``checkpoint_dir`` when
+    given); ``frame_step(pipeline, criterion, batch, database, device) -> loss`` replaces the default
+    ``fuse_training`` + criterion (tests, custom losses)."""
     if config.SETTINGS.seed:
         np.random.seed(config.SETTINGS.seed + rank)
         torch.manual_seed(config.SETTINGS.seed)  # identical replicas on every rank
+    frame_step = frame_step or _default_frame_step
     shard = ShardedScenes(dataset, rank, world)
     database = Database(shard, database_config(config))
+    val_shard = val_database = None
+    if val_dataset is not None:
+        val_shard = ShardedScenes(val_dataset, rank, world)
+        val_database = Database(val_shard, database_config(config))
+    if workspace is None and checkpoint_dir:  # every rank exports its own validation scenes into the shared directory
+        workspace = Workspace(checkpoint_dir)
+        workspace.model_path = checkpoint_dir  # checkpoints directly under checkpoint_dir
+    chief = workspace is not None and rank == 0  # rank 0 alone writes logs, scalars and model checkpoints
     pipeline = Pipeline(config)
     pipeline.apply(weights_init)
-    pipeline = pipeline.to(device)
     net = pipeline._fusion_network
+    if config.FUSION_MODEL.get('pretrained'):  # train_fusion.py:84-86
+        net.load_state_dict(torch.load(config.FUSION_MODEL.pretrained, map_location='cpu')['model_state'])
+    pipeline = pipeline.to(device)
     opt_cfg = config.TRAINING.optimizer
     optimizer = torch.optim.RMSprop(net.parameters(), lr=opt_cfg.lr, momentum=opt_cfg.momentum,
                                     weight_decay=opt_cfg.weight_decay, eps=opt_cfg.eps)
     scheduler = PolynomialLR(optimizer, config.TRAINING.scheduler.max_iter)
     criterion = FusionLoss(w_l1=config.TRAINING.loss.w_l1, w_l2=config.TRAINING.loss.w_l2, w_cos=config.TRAINING.loss.w_cos)
+
+    start_epoch = 0
+    resume = config.TRAINING.get('resume')
+    if resume:  # train_fusion.py:110-122
+        if os.path.isfile(resume):
+            log('Loading model and optimizer from checkpoint {}'.format(resume))
+            ck = torch.load(resume, map_location=device)
+            net.load_state_dict(remove_parent(ck['model_state'], '_fusion_network'))
+            optimizer.load_state_dict(ck['optimizer_state'])
+            scheduler.load_state_dict(ck['scheduler_state'])
+            start_epoch = ck['epoch']
+        else:
+            log('No checkpoint found at {}'.format(resume))
+
     grads = FlatGradientAllReduce(net)  # p.grad are views into one flat buffer
-    accum = config.TRAINING.optimization.accumulation_steps
-    losses, step = [], 0
-    for epoch in range(config.TRAINING.n_epochs):
+    opt = config.TRAINING.optimization
+    accum = opt.accumulation_steps
+    eval_freq = int(config.SETTINGS.get('eval_freq', 0) or 0)
+    log_freq = int(config.SETTINGS.get('log_freq', 0) or 0)
+    hybrid = config.DATA.get('data_load_strategy', None) == 'hybrid'
+    save_mode = config.SETTINGS.get('save_mode', 'tsdf')
+    best_score = 0.
+    losses, step, window = [], 0, 0.
+    done = False
+    for epoch in range(start_epoch, config.TRAINING.n_epochs):
+        if chief:
+            workspace.log('Training epoch {}/{}'.format(epoch, config.TRAINING.n_epochs), mode='train')
         database.reset()
         net.train()
         loader = _loader(dataset, shard.scenes)
-        n_batches = len(loader)
-        for i, batch in enumerate(loader):
-            if not torch.all(torch.isfinite(batch['extrinsics'])):
-                continue
-            opt = config.TRAINING.optimization
-            if opt.reset_strategy and np.random.random_sample() <= opt.reset_prob:
-                database.reset(batch['frame_id'][0].split('/')[0])
-            out = pipeline.fuse_training(_host_pose_batch(batch, device), database, device)
-            loss = criterion(out['tsdf_fused'], out['tsdf_target'])
-            if loss.grad_fn is not None:
-                loss.backward()
-                losses.append(float(loss.item()))
+        n_steps = int(_agree(len(loader), 'max'))  # the common step count of this epoch
+        frames = iter(loader)
+        for i in range(n_steps):
+            batch = next(frames, None)
+            boundary = (i + 1) % accum == 0 or i == n_steps - 1  # decided on the common counter, before any skip
+            evaluate_now = (eval_freq > 0 and (i + 1) % eval_freq == 0) or i == n_steps - 1
+            if batch is not None and torch.all(torch.isfinite(batch['extrinsics'])):
+                scene = batch['frame_id'][0].split('/')[0]
+                if hybrid and batch['frame_id'][0].split('/')[-1] == '0':  # new trajectory (train_fusion.py:154-157)
+                    if chief:
+                        workspace.log('Resetting grid for scene {} at step {}'.format(scene, i), mode='train')
+                    database.reset(scene)
+                if opt.reset_strategy and np.random.random_sample() <= opt.reset_prob:
+                    database.reset(scene)
+                loss = frame_step(pipeline, criterion, batch, database, device)
+                if loss.grad_fn is not None:
+                    loss.backward()
+                    losses.append(float(loss.item()))
+                    window += losses[-1]
+            if log_freq and (i + 1) % log_freq == 0:
+                if chief:
+                    workspace.writer.add_scalar('Train/loss', window / log_freq, global_step=i + 1 + epoch * n_steps)
+                window = 0.
             if opt.clipping:
                 torch.nn.utils.clip_grad_norm_(net.parameters(), max_norm=1., norm_type=2)
-            if (i + 1) % accum == 0 or i == n_batches - 1:
-                grads.reduce()  # the single exchange step of the whole training path
+            if boundary:
+                grads.reduce()  # the single exchange step of the whole training path: every rank, every boundary
                 optimizer.step()
                 grads.zero()    # keeps p.grad aliased to the flat buffer (no set_to_none)
                 scheduler.step()
             step += 1
-            if max_steps is not None and step >= max_steps:
+            done = max_steps is not None and step >= max_steps
+            if evaluate_now or done:
+                grads.zero()
+                sync_buffers(net)
+                gstep = i + 1 + epoch * n_steps
+                train_eval = database.evaluate(mode='train', workspace=workspace if chief else _Quiet)  # on device
+                if chief:
+                    for k in ('mse', 'acc', 'iou', 'mad'):
+                        if k in train_eval:
+                            workspace.writer.add_scalar('Train/' + k, train_eval[k], global_step=gstep)
+                score = None
+                if val_dataset is not None:
+                    sums, n = validate(config, pipeline, val_dataset, val_database, val_shard.scenes, device,
+                                       workspace if chief else _Quiet)
+                    tot = _agree(sums + [n], 'sum')
+                    val_eval = {k: tot[j] / max(tot[-1], 1) for j, k in enumerate(VAL_KEYS)}
+                    if chief:
+                        for k, v in val_eval.items():
+                            workspace.writer.add_scalar('Val/' + k, v, global_step=gstep)
+                    score = (val_eval.get('iou', 0.) + val_eval.get('acc', 0.)) / 2
+                    if score >= best_score:  # train_fusion.py:226-240
+                        best_score = score
+                        if workspace is not None:
+                            val_database.save_to_workspace(workspace, mode='best_val', save_mode=save_mode)
+                        if chief:
+                            workspace.log('Found new best model with score {} at epoch {}'.format(best_score, epoch), mode='val')
+                            workspace.save_model_state({'epoch': epoch + 1, 'model_state': net.state_dict(),
+                                                        'best_iou': best_score}, is_best=True, name='best.pth.tar')
+                    if workspace is not None:
+                        val_database.save_to_workspace(workspace, mode='latest_val', save_mode=save_mode)
+                if chief:  # train_fusion.py:245-251
+                    workspace.save_model_state({'epoch': epoch + 1, 'model_state': net.state_dict(),
+                                                'optimizer_state': optimizer.state_dict(),
+                                                'scheduler_state': scheduler.state_dict()}, is_best=False)
+                net.train()
+            if done:
                 break
-        if checkpoint_dir and rank == 0:
-            os.makedirs(checkpoint_dir, exist_ok=True)
-            torch.save({'epoch': epoch + 1, 'model_state': net.state_dict(), 'optimizer_state': optimizer.state_dict(),
-                        'scheduler_state': scheduler.state_dict()}, os.path.join(checkpoint_dir, 'last.pth.tar'))
-        if max_steps is not None and step >= max_steps:
+        if done:
             break
     log('rank {} mean loss {:.6f} over {} frames'.format(rank, float(np.mean(losses)) if losses else float('nan'), len(losses)))
     return pipeline, database, losses
+
+
+class _Quiet:
+    """Workspace stand-in for the ranks that do not log."""
+
+    @staticmethod
+    def log(message, mode='train'):
+        pass
 
 
 def _training_defaults(config):

@@ -187,6 +187,41 @@ def run_pipeline(h, w, grid, frames, use_semantics):
     return out
 
 
+def run_pipeline_full_size(h, w, grid, frames, use_semantics, small):
+    """Reference Pipeline.fuse at a BASELINE size (configs[1] / [2]: 320x240 -> 256^3).  Whole volumes would be
+    134 MB per frame, so the fixture keeps, per frame, sha256 of the weight / id / score volumes (net-independent:
+    a HIP PARITY-mode run must reproduce them bit for bit) and, for the last frame, the fp16 TSDF at the touched
+    voxels (C order of ``wgt > 0``) plus the reference's volume metrics.  The net state is the small fixture's
+    (same seed, asserted)."""
+    from online_joint_depthfusion_and_semantic_amd.synthetic import gt_volumes
+    sys.path.insert(0, REF)
+    from utils import metrics as ref_metrics
+    cfg = ref_config(h, w, True, use_semantics)
+    pipe = RefPipeline(cfg)
+    seeded_state(pipe._fusion_network, 11)
+    pipe.eval()
+    for k, v in pipe._fusion_network.state_dict().items():
+        assert np.array_equal(v.numpy(), small['state_' + k]), k
+    st = SyntheticStream(h, w, grid, 20)
+    gt, _ = gt_volumes(grid)
+    db = DuckDatabase(st, True, gt)
+    s = st.scene
+    out = {}
+    with torch.no_grad():
+        for i in range(frames):
+            pipe.fuse(st.batch(i), db, torch.device('cpu'))
+            for k, v in (('wgt', db.fusion_weights[s]), ('ids', db.ids_est[s].volume), ('scores', db.scores[s].volume),
+                         ('tsdf', db.scenes_est[s].volume)):
+                out['f%d_%s_sha256' % (i, k)] = np.array(sha(v.numpy()))
+            out['f%d_touched' % i] = np.array(int((db.fusion_weights[s] > 0).sum()))
+    tsdf, wgt = db.scenes_est[s].volume.numpy(), db.fusion_weights[s].numpy()
+    out['last_tsdf_touched'] = tsdf[wgt > 0]
+    ev = ref_metrics.evaluation(tsdf, gt, wgt > 0)  # utils/metrics.py:111-127 on the reference's own volumes
+    for k, v in ev.items():
+        out['metric_' + k] = np.array(float(v))
+    return out
+
+
 def probe_matmul():
     """Documents the fp32 accumulation order of the reference's two torch.matmul calls here."""
     from oracle import oracle
@@ -206,9 +241,20 @@ def probe_matmul():
     return res
 
 
+def full_size():
+    """BASELINE configs[1] / [2] end to end through the reference's Pipeline.fuse (about 2 minutes, one thread)."""
+    for tag, use_sem in (('sem', True), ('nosem', False)):
+        small = np.load(os.path.join(HERE, 'pipeline_v3_%s_24x32_g32.npz' % tag))
+        np.savez_compressed(os.path.join(HERE, 'pipeline_v3_%s_240x320_g256.npz' % tag),
+                            **run_pipeline_full_size(240, 320, 256, 3, use_sem, small))
+
+
 def main():
     if '--probe-matmul' in sys.argv:
         print(probe_matmul())
+        return
+    if '--full-size' in sys.argv:  # only the 320x240 -> 256^3 pipeline fixtures
+        full_size()
         return
     tiny = run_extract_integrate(12, 16, 32, 4, keep_arrays=True)
     np.savez_compressed(os.path.join(HERE, 'extract_integrate_12x16_g32.npz'), **tiny)
@@ -218,6 +264,7 @@ def main():
         json.dump(digests, f, indent=1, sort_keys=True)
     np.savez_compressed(os.path.join(HERE, 'pipeline_v3_sem_24x32_g32.npz'), **run_pipeline(24, 32, 32, 3, True))
     np.savez_compressed(os.path.join(HERE, 'pipeline_v3_nosem_24x32_g32.npz'), **run_pipeline(24, 32, 32, 3, False))
+    full_size()
     print('golden vectors written to', HERE)
 
 

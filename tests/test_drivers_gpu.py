@@ -30,6 +30,68 @@ def test_train_then_test_round_trip(cuda, tmp_path):
     assert set(per_scene) == {'room_0', 'room_1'}
 
 
+def test_train_with_validation_best_last_resume(cuda, tmp_path):
+    """train_fusion.py:110-122 (resume), :154-157 (hybrid trajectory reset), :191-251 (validation pass every eval_freq
+    steps, best / last checkpoints, validation volumes saved to the workspace)."""
+    h, w, grid = 48, 64, 32
+    cfg = _training_defaults(default_config(h, w))
+    cfg.SETTINGS.device = str(cuda)
+    cfg.SETTINGS.eval_freq = 4
+    cfg.SETTINGS.log_freq = 2
+    cfg.SETTINGS.save_mode = 'tsdf'
+    cfg.DATA.data_load_strategy = 'hybrid'
+    cfg.TRAINING.optimization.accumulation_steps = 2
+    cfg.TRAINING.optimization.reset_strategy = False
+    cfg.TRAINING.optimizer.lr = 1e-3
+    train = SyntheticDataset(h, w, grid, 8, scenes=['room_0'])
+    val = SyntheticDataset(h, w, grid, 4, scenes=['room_9'], seed=7)
+    resets = []
+    from online_joint_depthfusion_and_semantic_amd.database import Database
+    orig_reset = Database.reset
+
+    def spy(self, scene_id=None):
+        resets.append(scene_id)
+        return orig_reset(self, scene_id)
+    Database.reset = spy
+    try:
+        out = str(tmp_path / 'run')
+        pipe, db, losses = train_fusion(cfg, train, cuda, checkpoint_dir=out, val_dataset=val, log=lambda *a: None)
+    finally:
+        Database.reset = orig_reset
+    assert len(losses) == 8
+    assert 'room_0' in resets  # frame '.../000000' of a hybrid stream resets its scene's grid
+    files = sorted(os.listdir(out))
+    assert 'best.pth.tar' in files and 'last.pth.tar' in files
+    best = torch.load(os.path.join(out, 'best.pth.tar'), map_location='cpu')
+    last = torch.load(os.path.join(out, 'last.pth.tar'), map_location='cpu')
+    assert set(best) == {'epoch', 'model_state', 'best_iou'} and 0 <= best['best_iou'] <= 1  # train_fusion.py:234-238
+    assert set(last) == {'epoch', 'model_state', 'optimizer_state', 'scheduler_state'}
+    exported = os.listdir(os.path.join(out, 'output'))
+    assert any(n.startswith('room_9.tsdf_latest_val') for n in exported) and any(n.startswith('room_9.tsdf_best_val') for n in exported)
+    scal = open(os.path.join(out, 'logs', 'scalars.csv')).read()
+    assert 'Val/iou,4,' in scal and 'Val/iou,8,' in scal and 'Train/loss,2,' in scal and 'Train/iou,8,' in scal
+    # resume: epoch counter, optimizer and scheduler state come back; one more epoch runs
+    cfg.TRAINING.resume = os.path.join(out, 'last.pth.tar')
+    cfg.TRAINING.n_epochs = 2
+    pipe2, _, losses2 = train_fusion(cfg, train, cuda, checkpoint_dir=out, val_dataset=val, log=lambda *a: None)
+    assert len(losses2) == 8  # epochs [1, 2) only
+    again = torch.load(os.path.join(out, 'last.pth.tar'), map_location='cpu')
+    assert again['epoch'] == 2 and again['scheduler_state']['last_epoch'] == 2 * last['scheduler_state']['last_epoch']
+
+
+def test_test_fusion_reports_semantics(cuda, tmp_path):
+    """test_fusion.py:88-118 with DATA.semantics: median-filtered labels, evaluate + evaluate_semantics, the text log."""
+    h, w, grid = 48, 64, 32
+    cfg = _training_defaults(default_config(h, w, semantics=True))
+    cfg.SETTINGS.device = str(cuda)
+    cfg.SETTINGS.save_mode = 'tsdf'
+    ds = SyntheticDataset(h, w, grid, 6, scenes=['room_0'])
+    results, per_scene, db = run_test_fusion(cfg, ds, cuda, log=lambda *a: None, test_dir=str(tmp_path))
+    assert {'mse', 'mad', 'iou', 'acc', 'Mean Acc', 'Mean IoU'} <= set(results)
+    text = open(os.path.join(str(tmp_path), 'test.logs')).read()
+    assert 'Average semantic results over test scenes' in text and 'Scene: room_0' in text and 'Mean IoU' in text
+
+
 def test_test_fusion_on_a_replica_layout(cuda, tmp_path):
     """The Replica adapter (datasets.py) feeding the test driver end to end: frames written to disk in the
     reference's layout (16-bit millimetre depth, camera-matrix files, npz GT grid) are fused and evaluated; the

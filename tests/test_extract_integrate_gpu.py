@@ -1,6 +1,6 @@
 """-m gpu parity tests proper: HIP extract / integrate through the C ABI vs the CPU oracle on the
 same seeded inputs.  Bars: indices, corner weights, fusion_values/weights bit-exact;
-PARITY-mode volumes bit-exact; FAST-mode TSDF/weights <= 1 fp16 ulp on <= 0.2 % of touched voxels
+PARITY-mode volumes bit-exact; FAST-mode TSDF/weights <= 1 fp16 ulp on <= 0.05 % (256^3) / 0.1 % (coarse grids) of touched voxels
 from a common pre-frame state; semantic ids / scores bit-exact in both modes."""
 import numpy as np
 import pytest
@@ -13,6 +13,11 @@ from helpers import (bits, n_mismatch, f16_ulp_distance, fresh_volumes, frame_in
 pytestmark = pytest.mark.gpu
 
 CASES = [(12, 16, 32, 4), (120, 160, 64, 4), (240, 320, 256, 3)]
+# FAST-mode budget: <= 1 fp16 ulp on a small fraction of the touched voxels per frame from a common pre-frame state.
+# Measured: TSDF 0.034 % at 256^3 (53 of 155 780), 0.06 % at 64^3, <= 1 voxel at 32^3; weights 0.036 % at 64^3.  (SURVEY.md
+# §8c hoped for < 0.01 %: the exact fixed-point sum rounds once where the reference rounds after each of the ~10 fp32
+# adds of a voxel, so P(move) ~ n * 2^-24 / 2^-11.)  Bars = measured + margin.
+FAST_MOVED_FRACTION = {32: 1e-3, 64: 1e-3, 256: 5e-4}
 
 
 def _t(a, dev):
@@ -103,9 +108,8 @@ def test_integrate_fast_mode_tolerance(cuda, h, w, grid, frames, semantics):
             assert not nan_mismatch.any(), (key, i)
             ulp = np.where(np.isnan(got), 0, ulp)
             assert ulp.max() <= 1, (key, i, int(ulp.max()))
-            # stated tolerance: at most 0.2 % of the touched voxels move, each by one fp16 ulp
-            # (measured: 0.05 % at 64^3 where ~100 entries hit a voxel, < 0.01 % at 256^3)
-            assert (ulp > 0).sum() <= max(2, 2e-3 * touched), (key, i, int((ulp > 0).sum()), touched)
+            print('fast-mode %s %dx%d->%d^3 frame %d: %d of %d touched voxels moved by one ulp' % (key, w, h, grid, i, int((ulp > 0).sum()), touched))
+            assert (ulp > 0).sum() <= max(2, FAST_MOVED_FRACTION[grid] * touched), (key, i, int((ulp > 0).sum()), touched)
         if semantics:
             assert n_mismatch(g['ids'].cpu().numpy(), vols['ids']) == 0, i
             assert n_mismatch(g['scores'].cpu().numpy(), vols['scores']) == 0, i

@@ -1,5 +1,7 @@
 """CPU: host-side logic of the package (no kernels): config, synthetic streams, the state_dict
 schema / BN folding of the fusion nets, metrics, Database bookkeeping on host tensors."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -108,6 +110,45 @@ def test_database_on_host_tensors():
     db.to_torch()
     db.reset(s)
     assert db.state[s] is False and float(db.fusion_weights[s].abs().sum()) == 0
+
+
+def test_database_save_to_workspace_file_layout(tmp_path):
+    """modules/database.py:141-177 + utils/setup.py:224-274: file names and dataset keys of the workspace export
+    ('tsdf' mode needs no device); only scenes with integrated frames are written; the default save mode of ``save`` /
+    ``save_to_workspace`` is 'ply' like the reference's (:141, :180)."""
+    import inspect
+    from online_joint_depthfusion_and_semantic_amd.drivers import Workspace
+    cfg = default_config(24, 32, semantics=True)
+    cfg.SETTINGS.device = 'cpu'
+
+    class Two(SyntheticStream):
+        pass
+    st = Two(24, 32, 16, 5)
+    st.scenes = ['room_0', 'room_1/extra']
+    db = Database(st, database_config(cfg))
+    db.state['room_1/extra'] = True
+    db.fusion_weights['room_1/extra'][:3] = 2.0
+    ws = Workspace(str(tmp_path / 'exp'))
+    db.save_to_workspace(ws, mode='latest_val', save_mode='tsdf')
+    names = sorted(os.listdir(ws.output_path))
+    stems = sorted({n.rsplit('.', 1)[0] for n in names})
+    assert stems == ['room_1.extra.semantic_latest_val', 'room_1.extra.tsdf_latest_val', 'room_1.extra.weights_latest_val']
+    wname = [n for n in names if '.weights_' in n][0]
+    if wname.endswith('.npz'):  # no h5py in this image: same key, npz container
+        got = np.load(os.path.join(ws.output_path, wname))['weights']
+    else:
+        import h5py
+        got = np.array(h5py.File(os.path.join(ws.output_path, wname), 'r')['weights'])
+    assert got.dtype == np.float16 and got[:3].min() == 2.0 and got[3:].max() == 0
+    assert inspect.signature(Database.save).parameters['save_mode'].default == 'ply'
+    assert inspect.signature(Database.save_to_workspace).parameters['save_mode'].default == 'ply'
+    ws.save_model_state({'epoch': 1}, is_best=True, name='best.pth.tar')
+    ws.save_model_state({'epoch': 2})
+    assert sorted(os.listdir(ws.model_path)) == ['best.pth.tar', 'last.pth.tar']
+    ws.log('hello', mode='val')
+    ws.writer.add_scalar('Val/iou', 0.5, global_step=3)
+    assert open(os.path.join(ws.log_path, 'validation.logs')).read() == 'hello\n'
+    assert open(os.path.join(ws.log_path, 'scalars.csv')).read() == 'Val/iou,3,0.5\n'
 
 
 def test_camera_arrays_follow_reference_host_math():

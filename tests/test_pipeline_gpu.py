@@ -1,9 +1,10 @@
 """-m gpu: Pipeline.fuse / fuse_training (the drop-in boundary) on the HIP path against
  (a) golden volumes produced by the reference's own Pipeline.fuse (tests/golden/make_golden.py),
  (b) the CPU oracle frame step at config A, including the reference's volume metrics.
-Stated tolerances: semantic ids/scores and (parity mode) weights bit-exact; |dTSDF| <= 1.25e-4 (2 fp16 ulps)
-(the fp32-MFMA net differs from the CPU net by <= 1e-5 in tsdf_est, which can move the fp16
-rounding of U/W by one step, plus FAST mode's own single-ulp budget); metrics within 1e-4."""
+Stated tolerances: semantic ids/scores and (parity mode) weights bit-exact; against the reference's golden volumes
+|dTSDF| <= 6.2e-5 (one fp16 ulp of the top binade of the +-0.1 band) on <= 1 % of the touched voxels (the HIP net
+differs from the CPU net by < 1e-6 in tsdf_est, which can move the fp16 rounding of U/W by one step; FAST mode has its
+own single-ulp budget); over a six-frame stream against the oracle <= 2 ulps; metrics within 1e-3 relative."""
 import numpy as np
 import pytest
 import torch
@@ -17,6 +18,10 @@ from helpers import (n_mismatch, f16_ulp_distance, golden, net_from_golden, orac
 pytestmark = pytest.mark.gpu
 # 2 fp16 ulps at the top of the +-0.1 truncation band (ulp(0.0625..0.125) = 6.1e-5)
 TSDF_ABS_TOL = 1.25e-4
+# against the reference's own volumes, frame by frame: one ulp of the band's top binade (measured max 6.1e-5) on at
+# most 1 % of the touched voxels (measured <= 0.63 %)
+GOLDEN_ABS_TOL = 6.2e-5
+TSDF_MOVED_FRACTION = 0.01
 
 
 def _setup(h, w, grid, sem, use_sem, mode, cuda, state=None):
@@ -55,13 +60,18 @@ def test_fuse_matches_reference_pipeline_golden(cuda, use_sem, mode):
             assert n_mismatch(got['ids'], g['f%d_ids' % i]) == 0, i
             assert n_mismatch(got['scores'], g['f%d_scores' % i]) == 0, i
             wd = f16_ulp_distance(got['wgt'], g['f%d_wgt' % i])
-            assert wd.max() <= (0 if mode == 'parity' and i == 0 else 1), (i, int(wd.max()))
+            touched = int((g['f%d_wgt' % i] > 0).sum())
+            # the weight path never sees the net: PARITY reproduces the reference bit for bit on every frame; FAST
+            # rounds the per-voxel sum once instead of after every add (<= 1 fp16 ulp on a few voxels)
+            assert wd.max() <= (0 if mode == 'parity' else 1), (i, int(wd.max()))
+            assert (wd > 0).sum() <= 0.002 * touched, (i, int((wd > 0).sum()), touched)
             nan_eq = np.isnan(got['tsdf']) == np.isnan(g['f%d_tsdf' % i])
             assert nan_eq.all()
             td = np.nan_to_num(np.abs(got['tsdf'].astype(np.float32) - g['f%d_tsdf' % i].astype(np.float32)))
-            assert td.max() <= TSDF_ABS_TOL, (i, float(td.max()))
-            touched = int((g['f%d_wgt' % i] > 0).sum())
-            assert (td > 0).sum() <= 0.1 * touched, (i, int((td > 0).sum()), touched)
+            print('golden 24x32 sem=%s %s frame %d: max |dTSDF| %.2e, %d of %d touched voxels differ, %d weight ulps'
+                  % (use_sem, mode, i, float(td.max()), int((td > 0).sum()), touched, int((wd > 0).sum())))
+            assert td.max() <= GOLDEN_ABS_TOL, (i, float(td.max()))
+            assert (td > 0).sum() <= TSDF_MOVED_FRACTION * touched, (i, int((td > 0).sum()), touched)
     assert db.state[st.scene] is True
 
 
