@@ -199,6 +199,10 @@ int ojf_segconv_forward(const ojf_segconv *conv, const float *in_dev, int in_str
  * ojf_volume_evaluate: utils/metrics.py:111-127 evaluation() on device: with mask = weights > 0 and
  *   est/gt clipped to +-0.04, sums_dev f64[8] receives {n_mask, sum_sq_err, sum_abs_err,
  *   n_intersection(est<0 & gt<0), n_union(est<0 | gt<0), n_sign_equal, 0, 0}.
+ * ojf_volume_confusion: Database.evaluate_semantics (:311-349) -> utils/metrics.py:69-108 semantic_evaluation on
+ *   device: with mask = weights > 0 and est' = est * mask, gt' = gt * mask, hist_dev u64[n_classes^2] receives the
+ *   confusion counts (row = gt', column = est'; flat index gt' * n_classes + est' as in the reference's bincount) and
+ *   present_dev u32[512] the label presence flags of est' ([0, 256)) and gt' ([256, 512)).
  * ojf_volume_median5_u8: Database.filter_semantics (:114-116) = scipy.ndimage.median_filter(ids, size=5):
  *   5x5x5 window, 'reflect' boundary, rank-62 element; out must differ from in. */
 int ojf_volume_median5_u8(const uint8_t *in_dev, uint8_t *out_dev, int X, int Y, int Z, ojf_stream_t stream);
@@ -208,6 +212,8 @@ int ojf_volume_filter(uint16_t *tsdf_dev, uint16_t *weights_dev, size_t n, float
                       float init_value, ojf_stream_t stream);
 int ojf_volume_evaluate(const uint16_t *est_dev, const uint16_t *gt_dev, const uint16_t *weights_dev,
                         size_t n, double *sums_dev, ojf_stream_t stream);
+int ojf_volume_confusion(const uint8_t *ids_est_dev, const uint8_t *ids_gt_dev, const uint16_t *weights_dev, size_t n,
+                         int n_classes, unsigned long long *hist_dev, uint32_t *present_dev, ojf_stream_t stream);
 
 /* ---- MESH (Database.get_mesh / save 'ply' and 'test' modes) ------------------------------------
  * ojf_mesh_extract: iso-surface of a fused volume as a triangle list, replacing the host-side

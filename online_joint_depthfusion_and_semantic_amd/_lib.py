@@ -60,6 +60,7 @@ SIGNATURES = {
     'ojf_volume_filter': (_i, [_vp, _vp, _sz, _f, _f, _vp]),
     'ojf_volume_median5_u8': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'ojf_volume_evaluate': (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
+    'ojf_volume_confusion': (_i, [_vp, _vp, _vp, _sz, _i, _vp, _vp, _vp]),
     'ojf_segconv_create': (_i, [_c.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     'ojf_segdeconv_create': (_i, [_c.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i]),
     'ojf_segconv_destroy': (None, [_vp]),

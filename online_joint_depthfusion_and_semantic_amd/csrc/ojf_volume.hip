@@ -82,6 +82,75 @@ __global__ __launch_bounds__(256) void evaluate_kernel(const uint16_t *est, cons
 }
 
 
+// Database.evaluate_semantics (modules/database.py:311-349) -> utils/metrics.py:69-108 semantic_evaluation: with
+// mask = weights > 0, est' = est * mask, gt' = gt * mask (masked-out voxels count as the pair (0, 0)),
+//   hist[gt' * C + est'] += 1  for gt' < C   (np.bincount of the flattened pair index; an est' >= C spills into the
+//                                              next row exactly like the reference's flat index does, and is dropped
+//                                              beyond C*C where the reference's reshape would raise),
+//   present_est[c] / present_gt[c] = 1 if label c occurs in est' / gt' (np.unique, no class bound).
+// One pass over 5 B/voxel.  Per-block LDS histogram for C <= 64 (the reference's 30 / 40 classes), the dominant
+// (0, 0) pair is counted in a register; u64 global accumulation.
+template <bool LDS_HIST>
+__global__ __launch_bounds__(256) void confusion_kernel(const uint8_t *est, const uint8_t *gt, const uint16_t *wgt,
+                                                         size_t n, int C, unsigned long long *hist, uint32_t *present)
+{
+    __shared__ uint32_t lh[LDS_HIST ? 64 * 64 : 1];
+    __shared__ uint32_t lp[512];
+    const int cc = C * C;
+    if (LDS_HIST)
+        for (int i = threadIdx.x; i < cc; i += 256) lh[i] = 0;
+    for (int i = threadIdx.x; i < 512; i += 256) lp[i] = 0;
+    __syncthreads();
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    unsigned long long zero_pairs = 0;
+    auto one = [&](uint32_t e, uint32_t g, uint16_t wbits) {
+        const bool m = h2f(wbits) > 0.0f;
+        e = m ? e : 0u;
+        g = m ? g : 0u;
+        if ((e | g) == 0u) {
+            ++zero_pairs;
+            return;
+        }
+        lp[e] = 1u;        // benign race: every writer stores 1
+        lp[256 + g] = 1u;
+        if ((int)g < C) {
+            const int idx = (int)g * C + (int)e;
+            if (idx < cc) {
+                if (LDS_HIST) atomicAdd(&lh[idx], 1u);
+                else atomicAdd(&hist[idx], 1ull);
+            }
+        }
+    };
+    const bool aligned = (((uintptr_t)est | (uintptr_t)gt) & 7) == 0 && ((uintptr_t)wgt & 15) == 0;
+    const size_t nvec = aligned ? n / 8 : 0;
+    for (size_t i = tid; i < nvec; i += step) {
+        const uint2 e8 = reinterpret_cast<const uint2 *>(est)[i];
+        const uint2 g8 = reinterpret_cast<const uint2 *>(gt)[i];
+        const uint4 w8 = reinterpret_cast<const uint4 *>(wgt)[i];
+        const uint32_t ew[2] = {e8.x, e8.y}, gw[2] = {g8.x, g8.y}, ww[4] = {w8.x, w8.y, w8.z, w8.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            one((ew[k >> 2] >> (8 * (k & 3))) & 0xffu, (gw[k >> 2] >> (8 * (k & 3))) & 0xffu,
+                (uint16_t)(ww[k >> 1] >> (16 * (k & 1))));
+    }
+    for (size_t i = nvec * 8 + tid; i < n; i += step) one(est[i], gt[i], wgt[i]);
+    // (0, 0) pairs: wave reduction, one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) zero_pairs += __shfl_down(zero_pairs, off, 64);
+    if ((threadIdx.x & 63) == 0 && zero_pairs) {
+        atomicAdd(&hist[0], zero_pairs);
+        lp[0] = 1u;
+        lp[256] = 1u;
+    }
+    __syncthreads();
+    if (LDS_HIST)
+        for (int i = threadIdx.x; i < cc; i += 256)
+            if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
+    for (int i = threadIdx.x; i < 512; i += 256)
+        if (lp[i]) present[i] = 1u;
+}
+
+
 // Database.filter_semantics (modules/database.py:114-116): scipy.ndimage.median_filter(ids, size=5) on the
 // u8 label volume - 5x5x5 window, 'reflect' boundary (d c b a | a b c d | d c b a), median = element of
 // rank 62 of the 125 sorted values.  One block filters an 8x8x8 brick: the 12^3 neighbourhood is staged in
@@ -174,6 +243,23 @@ OJF_API int ojf_volume_evaluate(const uint16_t *est, const uint16_t *gt, const u
     hipLaunchKernelGGL(evaluate_kernel, dim3(stream_grid(n)), dim3(256), 0, as_stream(stream), est, gt, wgt, n,
                        sums);
     return check_hip(hipGetLastError(), "ojf_volume_evaluate launch");
+}
+
+OJF_API int ojf_volume_confusion(const uint8_t *est, const uint8_t *gt, const uint16_t *wgt, size_t n, int n_classes,
+                                 unsigned long long *hist, uint32_t *present, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (!est || !gt || !wgt || !hist || !present) return fail("ojf_volume_confusion: null pointer argument");
+    if (n_classes < 1 || n_classes > 256) return fail("ojf_volume_confusion: n_classes must be in [1, 256]");
+    OJF_HIP(hipMemsetAsync(hist, 0, (size_t)n_classes * n_classes * sizeof(unsigned long long), as_stream(stream)));
+    OJF_HIP(hipMemsetAsync(present, 0, 512 * sizeof(uint32_t), as_stream(stream)));
+    if (n == 0) return 0;
+    const dim3 grid(stream_grid(n / 8 + 1));
+    if (n_classes <= 64)
+        hipLaunchKernelGGL(confusion_kernel<true>, grid, dim3(256), 0, as_stream(stream), est, gt, wgt, n, n_classes, hist, present);
+    else
+        hipLaunchKernelGGL(confusion_kernel<false>, grid, dim3(256), 0, as_stream(stream), est, gt, wgt, n, n_classes, hist, present);
+    return check_hip(hipGetLastError(), "ojf_volume_confusion launch");
 }
 
 OJF_API int ojf_volume_median5_u8(const uint8_t *in, uint8_t *out, int X, int Y, int Z, ojf_stream_t stream)

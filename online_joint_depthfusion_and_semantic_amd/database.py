@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .metrics import evaluation, semantic_evaluation
+from .metrics import evaluation, semantic_evaluation, semantic_metrics_from_counts
 
 
 class Voxelgrid:
@@ -211,6 +211,8 @@ class Database(torch.utils.data.Dataset):
         return (results, per_scene) if mode == 'test' else results
 
     def evaluate_semantics(self, mode='train', workspace=None):
+        """database.py:311-349.  Device-resident volumes are reduced to the C x C confusion counts by one HIP pass
+        (ojf_volume_confusion, 5 B/voxel); only those counts come to the host."""
         results, per_scene = {}, {}
 
         def host(a):
@@ -218,10 +220,22 @@ class Database(torch.utils.data.Dataset):
         for s in self.scenes:
             if not self.state[s]:
                 continue
-            mask = host(self.fusion_weights[s]) > 0
-            r, cls_iou = semantic_evaluation(host(self.ids_est[s].volume), host(self.ids_gt[s].volume), mask, self.n_classes)
+            est, gt, w = self.ids_est[s].volume, self.ids_gt[s].volume, self.fusion_weights[s]
+            if _is_dev(est) and _is_dev(w):
+                gt_dev = gt if _is_dev(gt) else self._device_volume(gt, torch.uint8)
+                hist, e_ids, g_ids = ops.volume_confusion(est, gt_dev, w, self.n_classes)
+                n = self.n_classes  # np.bincount(np.unique(x), minlength=n): at least n entries, more if a label >= n occurs
+                e_ids = e_ids[:max(n, int(np.flatnonzero(e_ids).max(initial=0)) + 1)]
+                g_ids = g_ids[:max(n, int(np.flatnonzero(g_ids).max(initial=0)) + 1)]
+                k = max(len(e_ids), len(g_ids))
+                e_ids, g_ids = np.pad(e_ids, (0, k - len(e_ids))), np.pad(g_ids, (0, k - len(g_ids)))
+                r, cls_iou = semantic_metrics_from_counts(hist, e_ids, g_ids)
+            else:
+                r, cls_iou = semantic_evaluation(host(est), host(gt), host(w) > 0, self.n_classes)
             per_scene[s] = cls_iou
             for k, v in r.items():
+                msg = '{} {}'.format(k, v)
+                workspace.log(msg, mode) if workspace is not None else print(msg)
                 results[k] = results.get(k, 0) + v
         for k in results:
             results[k] /= len(self.scenes_est.keys())

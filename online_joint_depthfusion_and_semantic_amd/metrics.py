@@ -26,7 +26,6 @@ def evaluation(est, target, mask=None):
 def semantic_evaluation(est, target, mask, n_class):
     """Mean accuracy / mean IoU over the classes present in the scene, class 0 excluded
     (metrics.py:69-108)."""
-    eps = np.finfo(np.float32).eps
     est = est.flatten() * mask.flatten()
     target = target.flatten() * mask.flatten()
     est_ids = np.bincount(np.unique(est), minlength=n_class)
@@ -34,6 +33,14 @@ def semantic_evaluation(est, target, mask, n_class):
     ok = (target >= 0) & (target < n_class)
     hist = np.bincount(n_class * target[ok].astype(np.uint16) + est[ok], minlength=n_class * n_class)
     hist = hist.reshape(n_class, n_class)  # rows: target, cols: estimate
+    return semantic_metrics_from_counts(hist, est_ids, gt_ids)
+
+
+def semantic_metrics_from_counts(hist, est_ids, gt_ids):
+    """The arithmetic of metrics.py:89-108 on a confusion matrix (rows = target) and the label-presence vectors;
+    shared by the host path above and the device path (ops.volume_confusion)."""
+    eps = np.finfo(np.float32).eps
+    est_ids, gt_ids = np.asarray(est_ids).astype(np.int64), np.asarray(gt_ids).astype(np.int64)
     tp = np.diag(hist)
     fp = hist.sum(axis=0) - tp
     fn = hist.sum(axis=1) - tp

@@ -204,6 +204,23 @@ def volume_evaluate(est, gt, weights):
     return {'mse': sq / (n + eps), 'mad': ab / (n + eps), 'iou': inter / (union + eps), 'acc': same / (n + eps)}
 
 
+def volume_confusion(ids_est, ids_gt, weights, n_classes):
+    """Confusion counts of Database.evaluate_semantics on device: (hist int64 [C, C] rows = gt, est_present bool[256],
+    gt_present bool[256]) as numpy arrays (the only D2H traffic: C*C*8 + 2 KB)."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    for t in (ids_est, ids_gt):
+        assert t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()
+    assert ids_est.shape == ids_gt.shape == _vol16(weights).shape
+    hist = torch.empty(n_classes * n_classes, dtype=torch.int64, device=ids_est.device)
+    present = torch.empty(512, dtype=torch.int32, device=ids_est.device)
+    rc = lib.ojf_volume_confusion(_lib.ptr(ids_est), _lib.ptr(ids_gt), _lib.ptr(weights), ids_est.numel(), int(n_classes),
+                                  _lib.ptr(hist), _lib.ptr(present), _lib.stream_ptr(ids_est.device))
+    _lib.check(rc, 'ojf_volume_confusion')
+    p = present.cpu().numpy() != 0
+    return hist.cpu().numpy().reshape(n_classes, n_classes), p[:256], p[256:]
+
+
 def volume_median5(ids):
     """scipy.ndimage.median_filter(ids, size=5) on a cuda u8 volume (Database.filter_semantics)."""
     _lib.require_gpu()

@@ -43,7 +43,13 @@ def test_train_with_validation_best_last_resume(cuda, tmp_path):
     cfg.TRAINING.optimization.accumulation_steps = 2
     cfg.TRAINING.optimization.reset_strategy = False
     cfg.TRAINING.optimizer.lr = 1e-3
-    train = SyntheticDataset(h, w, grid, 8, scenes=['room_0'])
+    class PlainFrameNumbers(SyntheticDataset):  # the reference's loaders name frames 'scene/trajectory/<int>'
+        def __getitem__(self, item):
+            d = super().__getitem__(item)
+            parts = d['frame_id'].split('/')
+            d['frame_id'] = '/'.join(parts[:-1] + [str(int(parts[-1]))])
+            return d
+    train = PlainFrameNumbers(h, w, grid, 8, scenes=['room_0'])
     val = SyntheticDataset(h, w, grid, 4, scenes=['room_9'], seed=7)
     resets = []
     from online_joint_depthfusion_and_semantic_amd.database import Database
