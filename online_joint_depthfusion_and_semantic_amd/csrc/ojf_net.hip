@@ -1046,6 +1046,10 @@ __global__ __launch_bounds__(256) void planes_to_rows_kernel(const f32x4 *planes
     for (int j = 0; j < 4; ++j) rows[(size_t)p * stride + off + 4 * cg + j] = v[j];
 }
 
+}  // namespace ojf
+#include "ojf_net_pair.h"
+namespace ojf {
+
 // ------------------------------------------------------------------------------------------------
 // host side: packing and the layer schedule
 // ------------------------------------------------------------------------------------------------
@@ -1215,6 +1219,107 @@ static void release(PackedConv &pc)
 static inline f32x4 *planes(float *p) { return reinterpret_cast<f32x4 *>(p); }
 static inline const f32x4 *planes(const float *p) { return reinterpret_cast<const f32x4 *>(p); }
 
+// ---- fused 3x3 -> 3x3 pair (dense_pair_kernel, ojf_net_pair.h) ----------------------------------------------------
+struct PackedPair {
+    float *wa = nullptr, *wb = nullptr, *vec = nullptr;  // vec: bias_a | rinv_a | bias_b | rinv_b (32 floats each)
+    int c4_in = 0, n_chunks = 0, np_last = 0, np_b = 0, og_store = 0;
+};
+
+static void release(PackedPair &pp)
+{
+    float *ptrs[] = {pp.wa, pp.wb, pp.vec};
+    for (float *p : ptrs)
+        if (p) (void)hipFree(p);
+    pp.wa = pp.wb = pp.vec = nullptr;
+}
+
+// K blocks of `np_chunk`-pair chunks: unit u = 4S + g -> (tap = u / np, pair = u % np), K slot j = channel 8*pair + j
+static void pack_pair_conv(const ConvBuilder &b, const std::vector<float> &rs, std::vector<float> &dst)
+{
+    const int npairs = (b.c_in_phys + 7) / 8, n_chunks = (npairs + 3) / 4;
+    for (int c = 0; c < n_chunks; ++c) {
+        const int np = c == n_chunks - 1 ? npairs - 4 * c : 4, nkb = (9 * np + 3) / 4;
+        const size_t base = dst.size();
+        dst.resize(base + (size_t)nkb * 256 * 4, 0.0f);
+        _Float16 *hp = reinterpret_cast<_Float16 *>(dst.data() + base);
+        for (int S = 0; S < nkb; ++S)
+            for (int nt = 0; nt < 2; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int oc = nt * 16 + (lane & 15), u = 4 * S + (lane >> 4);
+                        if (oc >= b.c_out_phys || u >= 9 * np) continue;
+                        const int tap = u / np, ch = 8 * (4 * c + u % np) + j;
+                        if (ch >= b.c_in_phys) continue;
+                        const float v = rs[oc] * b.W[((size_t)oc * b.taps + tap) * b.c_in_phys + ch];
+                        const size_t ub = ((size_t)S * 2 + nt) * 2 * 64 * 8;
+                        split_weight(v, hp[ub + (size_t)lane * 8 + j], hp[ub + 64 * 8 + (size_t)lane * 8 + j]);
+                    }
+    }
+}
+
+static int finish_pair(const ConvBuilder &ba, const ConvBuilder &bb, PackedPair &pp)
+{
+    if (ba.taps != 9 || bb.taps != 9 || ba.dil != 1 || bb.dil != 1 || ba.c_out_phys > 24 || bb.c_in_phys != ba.c_out_phys ||
+        bb.c_out_phys > 32 || ba.c_in_phys % 4)
+        return fail("pair packing: unsupported layer shapes");
+    std::vector<float> vec(128, 0.0f), wa, wb;
+    auto scales = [&](const ConvBuilder &b, int off) {
+        std::vector<float> rs(32, 1.0f);
+        for (int oc = 0; oc < b.c_out_phys; ++oc) {
+            float mx = 0.0f;
+            const float *row = b.W.data() + (size_t)oc * b.taps * b.c_in_phys;
+            for (int i = 0; i < b.taps * b.c_in_phys; ++i) mx = std::fmax(mx, std::fabs(row[i]));
+            rs[oc] = row_scale(mx);
+            vec[off + oc] = b.B[oc];
+        }
+        for (int oc = 0; oc < 32; ++oc) vec[off + 32 + oc] = 1.0f / rs[oc];
+        return rs;
+    };
+    const std::vector<float> ra = scales(ba, 0), rb = scales(bb, 64);
+    pack_pair_conv(ba, ra, wa);
+    pack_pair_conv(bb, rb, wb);
+    pp.np_b = (bb.c_in_phys + 7) / 8;
+    const int npairs = (ba.c_in_phys + 7) / 8;
+    pp.c4_in = ba.c_in_phys / 4;
+    pp.n_chunks = (npairs + 3) / 4;
+    pp.np_last = npairs - 4 * (pp.n_chunks - 1);
+    pp.og_store = round_up(bb.c_out_phys, 4) / 4;
+    if (upload(wa, &pp.wa) || upload(wb, &pp.wb) || upload(vec, &pp.vec)) return -2;
+    return 0;
+}
+
+template <int TW, int TH>
+static int launch_pair_t(PairArgs &a, hipStream_t st)
+{
+    using G = PairGeom<TW, TH>;
+    static bool configured = false;
+    if (!configured) {
+        OJF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_pair_kernel<TW, TH>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+        configured = true;
+    }
+    a.tiles_x = (a.w + TW - 1) / TW;
+    const int tiles = a.tiles_x * ((a.h + TH - 1) / TH);
+    hipLaunchKernelGGL((dense_pair_kernel<TW, TH>), dim3(tiles), dim3(G::THREADS), G::LDS_BYTES, st, a);
+    return check_hip(hipGetLastError(), "dense_pair_kernel launch");
+}
+
+// in / out: plane buffers (may be the same allocation: the output groups are not part of the input window)
+static int launch_pair(const PackedPair &pp, const float *in, int in_g0, float *out, int out_g0, int h, int w, hipStream_t st)
+{
+    PairArgs a;
+    a.in = planes(in); a.out = planes(out);
+    a.wa = planes(pp.wa); a.wb = planes(pp.wb);
+    a.bias_a = pp.vec; a.rinv_a = pp.vec + 32; a.bias_b = pp.vec + 64; a.rinv_b = pp.vec + 96;
+    a.in_g0 = in_g0; a.c4_in = pp.c4_in; a.out_g0 = out_g0; a.og_store = pp.og_store;
+    a.h = h; a.w = w; a.npix = h * w; a.tiles_x = 0;
+    a.n_chunks = pp.n_chunks; a.np_last = pp.np_last; a.np_b = pp.np_b;
+    a.ovf = overflow_flag();
+    // one block per tile, 8 waves: the large tile when it still gives every CU a block (320x240: 240 blocks)
+    if (((w + 19) / 20) * ((h + 15) / 16) >= 200) return launch_pair_t<20, 16>(a, st);
+    return launch_pair_t<12, 8>(a, st);
+}
+
 // Launches n (<= 4) independent convolutions with the same number of output tiles as ONE grid
 // (blockIdx.y = problem): the four branches of a VortexPooling run together instead of as four
 // under-filled launches with their own ramp-up and tail.
@@ -1381,6 +1486,7 @@ struct ojf_net {
     float scale;
     int64_t macs_per_pixel;
     std::vector<ojf::PackedConv> dense[2];  // block0 / block2 (or v2's block): 2*gf convs each
+    std::vector<ojf::PackedPair> pairs[2];  // split-fp16: the same layers packed for dense_pair_kernel (one launch per Block)
     ojf::Vortex vortex[3];                  // v3: vortex0, vortex2, vortex3 ; v2: vortex, -, vortex_final
     std::vector<ojf::PackedConv> pred;
     float *chain_w = nullptr, *chain_b = nullptr;  // fused prediction head (when the topology is supported)
@@ -1627,6 +1733,12 @@ static int run_dense(ojf_net *net, int head, hipStream_t st)
 {
     const int c4 = net->cs / 4;
     float *T = net->sc[head].T;
+    static const bool no_pair = getenv("OJF_NO_PAIR") != nullptr;  // ablation switch only
+    if (!no_pair && (int)net->pairs[head].size() == net->gf) {  // one fused launch per Block (ojf_net_pair.h)
+        for (int i = 0; i < net->gf; ++i)
+            if (launch_pair(net->pairs[head][i], net->X[head], 0, net->X[head], (i + 1) * c4, net->h, net->w, st)) return -2;
+        return 0;
+    }
     for (int i = 0; i < net->gf; ++i) {
         if (launch_conv(net->dense[head][2 * i], net->X[head], 0, T, 0, nullptr, OJF_ACT_LEAKY, net->cs, 1.0f,
                         net->h, net->w, st)) return -2;
@@ -1658,8 +1770,10 @@ OJF_API void ojf_net_destroy(ojf_net *net)
 {
     using namespace ojf;
     if (!net) return;
-    for (int hd = 0; hd < 2; ++hd)
+    for (int hd = 0; hd < 2; ++hd) {
         for (auto &pc : net->dense[hd]) release(pc);
+        for (auto &pp : net->pairs[hd]) release(pp);
+    }
     for (auto &pc : net->pred) release(pc);
     for (auto &v : net->vortex) free_vortex(v);
     float *bufs[] = {net->X[0], net->X[1], net->YY, net->Y3, net->PA, net->PB};
@@ -1732,6 +1846,11 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
             if (finish(ba, pa, net->arith) || finish(bb, pb, net->arith)) return -2;
             net->dense[head].push_back(pa);
             net->dense[head].push_back(pb);
+            if (net->arith == OJF_ARITH_F16X3 && cs <= 24) {
+                PackedPair pp;
+                if (finish_pair(ba, bb, pp)) return -2;
+                net->pairs[head].push_back(pp);
+            }
         }
         return 0;
     };

@@ -1,0 +1,285 @@
+// Fused 3x3 -> 3x3 convolution pair on split-fp16 MFMA (included by ojf_net.hip only).
+//
+// A dense Block of the fusion net (modules/model.py:4-21) is  slot[i+1] = act(conv3x3_b(act(conv3x3_a(slots 0..i)))):
+// the intermediate T (19 channels) is consumed by nobody else.  The generic kernel ran the two convolutions as two
+// launches with T round-tripping through HBM/L2 and fetched every input once per tap (the wide first convolutions were
+// L1-bound: 265 MB through L1 for 95 -> 19).  Here ONE launch does both, LDS-resident:
+//
+//   block = 8 waves, one TW x TH output tile (20 x 16 at 320x240: 240 blocks = one round over the 256 CUs)
+//   window   X: (TH+4) x (TW+4) input pixels, 32 channels (4 channel PAIRS of 8) at a time, fetched ONCE from global
+//               memory, split into fp16 halves ONCE (not once per tap) and kept as hi / lo planes in LDS
+//   conv a   over the (TH+2) x (TW+2) region the second convolution needs (1.3x recompute instead of a round trip),
+//            MFMA B operands = one ds_read_b128 (hi) + one (lo) per (tap, channel pair); result -> bias, LeakyReLU,
+//            zero outside the image (the second convolution's zero padding), split, into the T planes in LDS
+//   conv b   from the T planes; epilogue writes the fp32 C4 planes of slot i+1.
+//
+// "Pitch-linear" slots: every region is addressed with the window's row pitch PW = TW + 4, slot s = row * PW + col.
+// A 16-pixel MFMA tile is 16 consecutive slots (it may wrap over a row end; the (PW - TW - 2) junk columns cost 9 %
+// more MFMAs at TW = 20), and a tap is a CONSTANT slot offset (dy * PW + dx): no per-lane index math, no bounds
+// tests in the loop, 16 consecutive 16-byte LDS reads per lane group = conflict-free (plane lengths are multiples
+// of 16 slots, so the four lane groups of a K block, which read four different channel pairs, stay on distinct banks).
+//
+// K blocks (32 wide) are built from units = (tap, channel pair): lane group g of K block S owns unit 4S + g.  A chunk
+// with 4 pairs has 36 units = 9 K blocks (K block = tap, lane group = pair); the last chunk of a layer may hold
+// 1..3 pairs (ceil(9 np / 4) K blocks, unit -> (tap, pair) through a 36-entry LDS table); conv b: 3 pairs, 7 K blocks.
+// Weights ([K block][oc tile][hi|lo][lane] x 8 halfs, row-equilibrated like every split-fp16 layer) reach LDS per
+// chunk; the next chunk's window and weights travel through registers while the current chunk computes.
+#pragma once
+
+namespace ojf {
+
+constexpr int pair_round16(int x) { return (x + 15) / 16 * 16; }
+constexpr int pair_max(int a, int b) { return a > b ? a : b; }
+
+template <int TW, int TH>
+struct PairGeom {
+    static constexpr int WAVES = 8, THREADS = 512;
+    static constexpr int PW = TW + 4;                      // slot pitch = window width
+    static constexpr int XS = (TH + 4) * PW;               // window slots
+    static constexpr int TS = (TH + 2) * PW;               // slots of the intermediate
+    static constexpr int OS = TH * PW;                     // output slots
+    static constexpr int TILES_A = (TS + 15) / 16, TILES_B = (OS + 15) / 16;
+    static constexpr int MT_A = (TILES_A + WAVES - 1) / WAVES, MT_B = (TILES_B + WAVES - 1) / WAVES;
+    // plane lengths in slots: reads of junk columns / junk tiles must stay inside the plane
+    static constexpr int XP = pair_round16(pair_max(XS, TILES_A * 16 + 2 * PW + 2));
+    static constexpr int TP = pair_round16(pair_max(TILES_A * 16, TILES_B * 16 + 2 * PW + 2));
+    static constexpr int X_F4 = 4 * 2 * XP, T_F4 = 3 * 2 * TP, W_F4 = 9 * 256;  // float4 counts of the three LDS areas
+    static constexpr int NXI = (4 * XS + THREADS - 1) / THREADS;   // window items (pair, slot) per thread and chunk
+    static constexpr int NWI = (W_F4 + THREADS - 1) / THREADS;     // weight float4 per thread and chunk
+    static constexpr size_t LDS_BYTES = (size_t)(X_F4 + T_F4 + W_F4) * 16 + 3 * 36 * sizeof(int);
+};
+
+struct PairArgs {
+    const f32x4 *in;  // input planes (window = groups [in_g0, in_g0 + c4_in))
+    f32x4 *out;       // output planes, groups [out_g0, out_g0 + og_store)
+    const f32x4 *wa;  // conv a: chunks back to back, each [K block][2][hi|lo][lane]
+    const f32x4 *wb;  // conv b: [ceil(9 np_b / 4)][2][hi|lo][lane]
+    const float *bias_a, *rinv_a, *bias_b, *rinv_b;  // 32 floats each
+    int in_g0, c4_in, out_g0, og_store;
+    int h, w, npix, tiles_x;
+    int n_chunks, np_last;  // chunks of 4 channel pairs; pairs in the last chunk (1..4)
+    int np_b;               // channel pairs of the intermediate (1..3)
+    int *ovf;               // split-fp16 range guard flag
+};
+
+// 8 values of one channel pair -> fp16 halves (same rounding as split_f16)
+__device__ __forceinline__ void pair_split(const f32x4 &a, const f32x4 &b, f32x4 &hi, f32x4 &lo)
+{
+    f16x8 h, l;
+    split_f16(a, b, h, l);
+    hi = __builtin_bit_cast(f32x4, h);
+    lo = __builtin_bit_cast(f32x4, l);
+}
+
+// acc[m][n] += W[K block][n] * act[unit(K block, g)][slot[m] + tap] over `nkb` K blocks
+template <int MT, int PLANE>
+__device__ __forceinline__ void pair_mac(f32x4 (&acc)[MT][2], const f32x4 *act, const int *uo, int nkb, const f32x4 *wl,
+                                         const int (&slot)[MT], int mt_wave, int lane, int g)
+{
+    for (int S = 0; S < nkb; ++S) {
+        const int off = uo[4 * S + g];
+        f32x4 wh[2], wlo[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            wh[n] = wl[(S * 2 + n) * 128 + lane];
+            wlo[n] = wl[(S * 2 + n) * 128 + 64 + lane];
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (m < mt_wave) {  // wave-uniform
+                const f16x8 xh = __builtin_bit_cast(f16x8, act[off + slot[m]]);
+                const f16x8 xl = __builtin_bit_cast(f16x8, act[off + PLANE + slot[m]]);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = mfma_f16x3(wh[n], wlo[n], xh, xl, acc[m][n]);
+            }
+        }
+    }
+}
+
+template <int TW, int TH>
+__global__ __launch_bounds__(512) void dense_pair_kernel(const PairArgs a)
+{
+    using G = PairGeom<TW, TH>;
+    constexpr int PW = G::PW, XP = G::XP, TP = G::TP;
+    extern __shared__ f32x4 pair_lds[];
+    f32x4 *xl = pair_lds;               // [4 pairs][hi | lo][XP]
+    f32x4 *tl = xl + G::X_F4;           // [3 pairs][hi | lo][TP]
+    f32x4 *wl = tl + G::T_F4;           // one chunk of weights
+    int *uo = reinterpret_cast<int *>(wl + G::W_F4);  // unit tables: [0] full chunk, [1] last chunk, [2] conv b
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, g = lane >> 4;
+    const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const int last = a.n_chunks - 1, nkb_b = (9 * a.np_b + 3) >> 2;
+
+    if (tid < 3 * 36) {  // unit -> slot offset (float4 units) of its (tap, pair) inside the window / T planes
+        const int type = tid / 36, u = tid - type * 36;
+        const int np = type == 0 ? 4 : (type == 1 ? a.np_last : a.np_b);
+        int off = 0;
+        if (u < 9 * np) {
+            const int tap = u / np, pr = u - tap * np;
+            off = pr * 2 * (type == 2 ? TP : XP) + (tap / 3) * PW + (tap % 3);
+        }
+        uo[tid] = off;
+    }
+    // the T planes' tail (slots a junk output column may read) must hold finite values
+    for (int i = tid; i < G::T_F4; i += G::THREADS) tl[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- window items of this thread: (pair, slot) -> byte offset of the pixel (or out of range) -----------------
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<f32x4 *>(a.in), 0, (a.in_g0 + a.c4_in) * a.npix * 16, 0x00020000);
+    unsigned poff[G::NXI];
+    int xdst[G::NXI];  // float4 index of the hi element in xl (-1: no item)
+#pragma unroll
+    for (int k = 0; k < G::NXI; ++k) {
+        const int item = k * G::THREADS + tid;
+        const int pr = item / G::XS, s = item - pr * G::XS;
+        const int sy = s / PW, sx = s - sy * PW;
+        const int gy = y0 - 2 + sy, gx = x0 - 2 + sx;
+        const bool ok = item < 4 * G::XS && (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
+        poff[k] = ok ? (unsigned)(((a.in_g0 + 2 * pr) * a.npix + gy * a.w + gx) * 16) : 0xffffffffu;
+        xdst[k] = item < 4 * G::XS ? pr * 2 * XP + s : -1;
+    }
+    const unsigned chunk_bytes = (unsigned)(8 * a.npix * 16), group_bytes = (unsigned)(a.npix * 16);
+    f32x4 xpa[G::NXI], xpb[G::NXI], wpre[G::NWI];
+    auto prefetch_x = [&](int c) {
+#pragma unroll
+        for (int k = 0; k < G::NXI; ++k) {
+            // groups beyond the window lie beyond num_records -> zeros (odd group counts, partial last chunk)
+            const unsigned o = poff[k] == 0xffffffffu ? 0xffffffffu : poff[k] + (unsigned)c * chunk_bytes;
+            const unsigned o2 = poff[k] == 0xffffffffu ? 0xffffffffu : o + group_bytes;
+            xpa[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0));
+            xpb[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o2, 0, 0));
+        }
+    };
+    auto prefetch_w = [&](const f32x4 *src, int n_f4) {
+#pragma unroll
+        for (int k = 0; k < G::NWI; ++k)
+            if (k * G::THREADS + tid < n_f4) wpre[k] = src[k * G::THREADS + tid];
+    };
+    auto nkb_of = [&](int c) { return c == last ? (9 * a.np_last + 3) >> 2 : 9; };
+
+    // ---- conv a ----------------------------------------------------------------------------------------------
+    const int mt_a = (G::TILES_A - wave + G::WAVES - 1) / G::WAVES;  // tiles wave, wave + 8, ... < TILES_A
+    int slot_a[G::MT_A];
+#pragma unroll
+    for (int m = 0; m < G::MT_A; ++m) slot_a[m] = (wave + G::WAVES * (m < mt_a ? m : 0)) * 16 + i16;
+    f32x4 acc[G::MT_A][2];
+#pragma unroll
+    for (int m = 0; m < G::MT_A; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    prefetch_x(0);
+    prefetch_w(a.wa, nkb_of(0) * 256);
+    const f32x4 *wsrc = a.wa;
+    for (int c = 0; c <= last; ++c) {
+        const int nkb = nkb_of(c);
+        if (c) __syncthreads();  // readers of the previous chunk are done
+#pragma unroll
+        for (int k = 0; k < G::NXI; ++k) {
+            if (xdst[k] >= 0) {
+                f32x4 hi, lo;
+                pair_split(xpa[k], xpb[k], hi, lo);
+                xl[xdst[k]] = hi;
+                xl[xdst[k] + XP] = lo;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < G::NWI; ++k)
+            if (k * G::THREADS + tid < nkb * 256) wl[k * G::THREADS + tid] = wpre[k];
+        __syncthreads();
+        wsrc += nkb * 256;
+        if (c < last) {
+            prefetch_x(c + 1);
+            prefetch_w(wsrc, nkb_of(c + 1) * 256);
+        } else {
+            prefetch_w(a.wb, nkb_b * 256);
+        }
+        pair_mac<G::MT_A, XP>(acc, xl, uo + (c == last ? 36 : 0), nkb, wl, slot_a, mt_a, lane, g);
+    }
+
+    // epilogue a: bias, LeakyReLU, zero outside the image / the needed region, split, into the T planes
+    float gmax = 0.0f;
+    {
+        f32x4 bv[2], rv[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            bv[n] = *reinterpret_cast<const f32x4 *>(a.bias_a + n * 16 + 4 * g);
+            rv[n] = *reinterpret_cast<const f32x4 *>(a.rinv_a + n * 16 + 4 * g);
+        }
+#pragma unroll
+        for (int m = 0; m < G::MT_A; ++m) {
+            if (m >= mt_a) continue;
+            const int s = slot_a[m];
+            const int ry = s / PW, rx = s - ry * PW;
+            const int gy = y0 - 1 + ry, gx = x0 - 1 + rx;
+            const bool ok = s < G::TS && rx < TW + 2 && (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int pr = 2 * n + (g >> 1);
+                if (pr >= 3) continue;
+                const f32x4 lin = fma4(acc[m][n], rv[n], bv[n]);
+                if (ok) gmax = guard_max(gmax, lin);
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = ok ? (lin[j] > 0.0f ? lin[j] : 0.01f * lin[j]) : 0.0f;
+                typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                const f16x4 h4 = __builtin_convertvector(v, f16x4);
+                f32x4 r;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[j] = __builtin_fmaf((float)h4[j], -1.0f, v[j]);
+                const f16x4 l4 = __builtin_convertvector(r, f16x4);
+                uint2 *dh = reinterpret_cast<uint2 *>(tl + pr * 2 * TP + s) + (g & 1);
+                uint2 *dl = reinterpret_cast<uint2 *>(tl + pr * 2 * TP + TP + s) + (g & 1);
+                *dh = __builtin_bit_cast(uint2, h4);
+                *dl = __builtin_bit_cast(uint2, l4);
+            }
+        }
+    }
+    __syncthreads();  // T complete, conv a's weights no longer read
+#pragma unroll
+    for (int k = 0; k < G::NWI; ++k)
+        if (k * G::THREADS + tid < nkb_b * 256) wl[k * G::THREADS + tid] = wpre[k];
+    __syncthreads();
+
+    // ---- conv b ----------------------------------------------------------------------------------------------
+    const int mt_b = (G::TILES_B - wave + G::WAVES - 1) / G::WAVES;
+    int slot_b[G::MT_B];
+#pragma unroll
+    for (int m = 0; m < G::MT_B; ++m) slot_b[m] = (wave + G::WAVES * (m < mt_b ? m : 0)) * 16 + i16;
+    f32x4 accb[G::MT_B][2];
+#pragma unroll
+    for (int m = 0; m < G::MT_B; ++m) accb[m][0] = accb[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    pair_mac<G::MT_B, TP>(accb, tl, uo + 72, nkb_b, wl, slot_b, mt_b, lane, g);
+    {
+        f32x4 bv[2], rv[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            bv[n] = *reinterpret_cast<const f32x4 *>(a.bias_b + n * 16 + 4 * g);
+            rv[n] = *reinterpret_cast<const f32x4 *>(a.rinv_b + n * 16 + 4 * g);
+        }
+#pragma unroll
+        for (int m = 0; m < G::MT_B; ++m) {
+            if (m >= mt_b) continue;
+            const int s = slot_b[m];
+            const int oy = s / PW, ox = s - oy * PW;
+            const int gy = y0 + oy, gx = x0 + ox;
+            if (!(s < G::OS && ox < TW && gy < a.h && gx < a.w)) continue;
+            const int p = gy * a.w + gx;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int og = 4 * n + g;
+                if (og >= a.og_store) continue;
+                const f32x4 lin = fma4(accb[m][n], rv[n], bv[n]);
+                gmax = guard_max(gmax, lin);
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = lin[j] > 0.0f ? lin[j] : 0.01f * lin[j];
+                a.out[(size_t)(a.out_g0 + og) * a.npix + p] = v;
+            }
+        }
+    }
+    if (gmax > 65504.0f && a.ovf) *a.ovf = 1;
+}
+
+}  // namespace ojf
