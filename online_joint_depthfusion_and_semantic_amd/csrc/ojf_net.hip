@@ -1220,6 +1220,9 @@ static inline f32x4 *planes(float *p) { return reinterpret_cast<f32x4 *>(p); }
 static inline const f32x4 *planes(const float *p) { return reinterpret_cast<const f32x4 *>(p); }
 
 // ---- fused 3x3 -> 3x3 pair (dense_pair_kernel, ojf_net_pair.h) ----------------------------------------------------
+#ifdef OJF_PAIR_TIMING
+static long long *g_pair_dbg = nullptr;
+#endif
 struct PackedPair {
     float *wa = nullptr, *wb = nullptr, *vec = nullptr;  // vec: bias_a | rinv_a | bias_b | rinv_b (32 floats each)
     int c4_in = 0, n_chunks = 0, np_last = 0, np_b = 0, og_store = 0;
@@ -1315,6 +1318,9 @@ static int launch_pair(const PackedPair &pp, const float *in, int in_g0, float *
     a.h = h; a.w = w; a.npix = h * w; a.tiles_x = 0;
     a.n_chunks = pp.n_chunks; a.np_last = pp.np_last; a.np_b = pp.np_b;
     a.ovf = overflow_flag();
+#ifdef OJF_PAIR_TIMING
+    a.dbg = g_pair_dbg;
+#endif
     // one block per tile, 8 waves: the large tile when it still gives every CU a block (320x240: 240 blocks)
     if (((w + 19) / 20) * ((h + 15) / 16) >= 200) return launch_pair_t<20, 16>(a, st);
     return launch_pair_t<12, 8>(a, st);

@@ -46,7 +46,8 @@ struct PairGeom {
     static constexpr int X_F4 = 4 * 2 * XP, T_F4 = 3 * 2 * TP, W_F4 = 9 * 256;  // float4 counts of the three LDS areas
     static constexpr int NXI = (4 * XS + THREADS - 1) / THREADS;   // window items (pair, slot) per thread and chunk
     static constexpr int NWI = (W_F4 + THREADS - 1) / THREADS;     // weight float4 per thread and chunk
-    static constexpr size_t LDS_BYTES = (size_t)(X_F4 + T_F4 + W_F4) * 16 + 3 * 36 * sizeof(int);
+    static constexpr int NPRE = NXI > NWI ? NXI : NWI;
+    static constexpr size_t LDS_BYTES = (size_t)(X_F4 + T_F4 + W_F4) * 16 + 128 * sizeof(int) + 128 * sizeof(float);
 };
 
 struct PairArgs {
@@ -60,6 +61,9 @@ struct PairArgs {
     int n_chunks, np_last;  // chunks of 4 channel pairs; pairs in the last chunk (1..4)
     int np_b;               // channel pairs of the intermediate (1..3)
     int *ovf;               // split-fp16 range guard flag
+#ifdef OJF_PAIR_TIMING
+    long long *dbg;         // profiling builds only (tools/microbench/pair_bench.hip): s_memtime stamps of block 0
+#endif
 };
 
 // 8 values of one channel pair -> fp16 halves (same rounding as split_f16)
@@ -72,11 +76,14 @@ __device__ __forceinline__ void pair_split(const f32x4 &a, const f32x4 &b, f32x4
 }
 
 // acc[m][n] += W[K block][n] * act[unit(K block, g)][slot[m] + tap] over `nkb` K blocks
-template <int MT, int PLANE>
+// `hook(S)` runs once per K block before its MFMAs: the caller trickles the next chunk's global loads through it (a
+// burst of 13 loads per lane at the top of the loop stalled the in-order waves at issue until the memory queue drained)
+template <int MT, int PLANE, class Hook>
 __device__ __forceinline__ void pair_mac(f32x4 (&acc)[MT][2], const f32x4 *act, const int *uo, int nkb, const f32x4 *wl,
-                                         const int (&slot)[MT], int mt_wave, int lane, int g)
+                                         const int (&slot)[MT], int mt_wave, int lane, int g, Hook hook)
 {
     for (int S = 0; S < nkb; ++S) {
+        hook(S);
         const int off = uo[4 * S + g];
         f32x4 wh[2], wlo[2];
 #pragma unroll
@@ -106,12 +113,20 @@ __global__ __launch_bounds__(512) void dense_pair_kernel(const PairArgs a)
     f32x4 *tl = xl + G::X_F4;           // [3 pairs][hi | lo][TP]
     f32x4 *wl = tl + G::T_F4;           // one chunk of weights
     int *uo = reinterpret_cast<int *>(wl + G::W_F4);  // unit tables: [0] full chunk, [1] last chunk, [2] conv b
+    float *vl = reinterpret_cast<float *>(uo + 128);  // bias_a | rinv_a | bias_b | rinv_b (their global latency hides behind conv a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, g = lane >> 4;
     const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
     const int x0 = tx * TW, y0 = ty * TH;
     const int last = a.n_chunks - 1, nkb_b = (9 * a.np_b + 3) >> 2;
+#ifdef OJF_PAIR_TIMING
+    int stamp_i = 0;
+#define OJF_STAMP() do { if (blockIdx.x == 37 && tid == 0) a.dbg[stamp_i] = (long long)__builtin_amdgcn_s_memtime(); ++stamp_i; } while (0)
+#else
+#define OJF_STAMP() do {} while (0)
+#endif
+    OJF_STAMP();  // 0: start
 
     if (tid < 3 * 36) {  // unit -> slot offset (float4 units) of its (tap, pair) inside the window / T planes
         const int type = tid / 36, u = tid - type * 36;
@@ -123,8 +138,13 @@ __global__ __launch_bounds__(512) void dense_pair_kernel(const PairArgs a)
         }
         uo[tid] = off;
     }
-    // the T planes' tail (slots a junk output column may read) must hold finite values
-    for (int i = tid; i < G::T_F4; i += G::THREADS) tl[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid >= 128 && tid < 160)  // the four epilogue vectors are contiguous (PackedPair::vec)
+        reinterpret_cast<f32x4 *>(vl)[tid - 128] = reinterpret_cast<const f32x4 *>(a.bias_a)[tid - 128];
+    // the T planes' tails (slots a junk output column may read; conv a writes every slot below) must hold finite values
+    if (tid >= 192 && tid < 192 + 6 * (TP - G::TILES_A * 16)) {
+        const int i = tid - 192, pl = i / (TP - G::TILES_A * 16), sl = i - pl * (TP - G::TILES_A * 16);
+        tl[pl * TP + G::TILES_A * 16 + sl] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     // ---- window items of this thread: (pair, slot) -> byte offset of the pixel (or out of range) -----------------
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -143,20 +163,20 @@ __global__ __launch_bounds__(512) void dense_pair_kernel(const PairArgs a)
     }
     const unsigned chunk_bytes = (unsigned)(8 * a.npix * 16), group_bytes = (unsigned)(a.npix * 16);
     f32x4 xpa[G::NXI], xpb[G::NXI], wpre[G::NWI];
-    auto prefetch_x = [&](int c) {
+    // piece k of the next chunk: window item k (two float4) and weight float4 k of this thread
+    auto prefetch_piece = [&](int k, int c, bool with_x, const f32x4 *wsrc_, int n_f4) {
 #pragma unroll
-        for (int k = 0; k < G::NXI; ++k) {
-            // groups beyond the window lie beyond num_records -> zeros (odd group counts, partial last chunk)
-            const unsigned o = poff[k] == 0xffffffffu ? 0xffffffffu : poff[k] + (unsigned)c * chunk_bytes;
-            const unsigned o2 = poff[k] == 0xffffffffu ? 0xffffffffu : o + group_bytes;
-            xpa[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0));
-            xpb[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o2, 0, 0));
+        for (int kk = 0; kk < G::NPRE; ++kk) {
+            if (kk != k) continue;
+            if (kk < G::NXI && with_x) {
+                // groups beyond the window lie beyond num_records -> zeros (odd group counts, partial last chunk)
+                const unsigned o = poff[kk] == 0xffffffffu ? 0xffffffffu : poff[kk] + (unsigned)c * chunk_bytes;
+                const unsigned o2 = poff[kk] == 0xffffffffu ? 0xffffffffu : o + group_bytes;
+                xpa[kk] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0));
+                xpb[kk] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o2, 0, 0));
+            }
+            if (kk < G::NWI && kk * G::THREADS + tid < n_f4) wpre[kk] = wsrc_[kk * G::THREADS + tid];
         }
-    };
-    auto prefetch_w = [&](const f32x4 *src, int n_f4) {
-#pragma unroll
-        for (int k = 0; k < G::NWI; ++k)
-            if (k * G::THREADS + tid < n_f4) wpre[k] = src[k * G::THREADS + tid];
     };
     auto nkb_of = [&](int c) { return c == last ? (9 * a.np_last + 3) >> 2 : 9; };
 
@@ -169,12 +189,14 @@ __global__ __launch_bounds__(512) void dense_pair_kernel(const PairArgs a)
 #pragma unroll
     for (int m = 0; m < G::MT_A; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    prefetch_x(0);
-    prefetch_w(a.wa, nkb_of(0) * 256);
+    OJF_STAMP();  // 1: setup done
+#pragma unroll
+    for (int k = 0; k < G::NPRE; ++k) prefetch_piece(k, 0, true, a.wa, nkb_of(0) * 256);
     const f32x4 *wsrc = a.wa;
     for (int c = 0; c <= last; ++c) {
         const int nkb = nkb_of(c);
         if (c) __syncthreads();  // readers of the previous chunk are done
+        OJF_STAMP();  // 2 + 3c: chunk c: previous compute done
 #pragma unroll
         for (int k = 0; k < G::NXI; ++k) {
             if (xdst[k] >= 0) {
@@ -187,25 +209,30 @@ __global__ __launch_bounds__(512) void dense_pair_kernel(const PairArgs a)
 #pragma unroll
         for (int k = 0; k < G::NWI; ++k)
             if (k * G::THREADS + tid < nkb * 256) wl[k * G::THREADS + tid] = wpre[k];
+        OJF_STAMP();  // 3 + 3c: operands arrived and written
         __syncthreads();
+        OJF_STAMP();  // 4 + 3c: barrier passed
         wsrc += nkb * 256;
-        if (c < last) {
-            prefetch_x(c + 1);
-            prefetch_w(wsrc, nkb_of(c + 1) * 256);
-        } else {
-            prefetch_w(a.wb, nkb_b * 256);
-        }
-        pair_mac<G::MT_A, XP>(acc, xl, uo + (c == last ? 36 : 0), nkb, wl, slot_a, mt_a, lane, g);
+        // the next chunk's window and weights (or conv b's weights), one piece per K block
+        const bool more = c < last;
+        const f32x4 *nsrc = more ? wsrc : a.wb;
+        const int n_f4 = more ? nkb_of(c + 1) * 256 : nkb_b * 256;
+        pair_mac<G::MT_A, XP>(acc, xl, uo + (c == last ? 36 : 0), nkb, wl, slot_a, mt_a, lane, g,
+                              [&](int S) { if (S < G::NPRE) prefetch_piece(S, c + 1, more, nsrc, n_f4); });
+#pragma unroll
+        for (int k = 0; k < G::NPRE; ++k)
+            if (k >= nkb) prefetch_piece(k, c + 1, more, nsrc, n_f4);  // short chunks: the rest
     }
 
+    OJF_STAMP();  // conv a done
     // epilogue a: bias, LeakyReLU, zero outside the image / the needed region, split, into the T planes
     float gmax = 0.0f;
     {
         f32x4 bv[2], rv[2];
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-            bv[n] = *reinterpret_cast<const f32x4 *>(a.bias_a + n * 16 + 4 * g);
-            rv[n] = *reinterpret_cast<const f32x4 *>(a.rinv_a + n * 16 + 4 * g);
+            bv[n] = *reinterpret_cast<const f32x4 *>(vl + n * 16 + 4 * g);
+            rv[n] = *reinterpret_cast<const f32x4 *>(vl + 32 + n * 16 + 4 * g);
         }
 #pragma unroll
         for (int m = 0; m < G::MT_A; ++m) {
@@ -236,12 +263,14 @@ __global__ __launch_bounds__(512) void dense_pair_kernel(const PairArgs a)
             }
         }
     }
+    OJF_STAMP();  // epilogue a done
     __syncthreads();  // T complete, conv a's weights no longer read
 #pragma unroll
     for (int k = 0; k < G::NWI; ++k)
         if (k * G::THREADS + tid < nkb_b * 256) wl[k * G::THREADS + tid] = wpre[k];
     __syncthreads();
 
+    OJF_STAMP();  // conv b weights in place
     // ---- conv b ----------------------------------------------------------------------------------------------
     const int mt_b = (G::TILES_B - wave + G::WAVES - 1) / G::WAVES;
     int slot_b[G::MT_B];
@@ -250,13 +279,14 @@ __global__ __launch_bounds__(512) void dense_pair_kernel(const PairArgs a)
     f32x4 accb[G::MT_B][2];
 #pragma unroll
     for (int m = 0; m < G::MT_B; ++m) accb[m][0] = accb[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    pair_mac<G::MT_B, TP>(accb, tl, uo + 72, nkb_b, wl, slot_b, mt_b, lane, g);
+    pair_mac<G::MT_B, TP>(accb, tl, uo + 72, nkb_b, wl, slot_b, mt_b, lane, g, [](int) {});
+    OJF_STAMP();  // conv b done
     {
         f32x4 bv[2], rv[2];
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-            bv[n] = *reinterpret_cast<const f32x4 *>(a.bias_b + n * 16 + 4 * g);
-            rv[n] = *reinterpret_cast<const f32x4 *>(a.rinv_b + n * 16 + 4 * g);
+            bv[n] = *reinterpret_cast<const f32x4 *>(vl + 64 + n * 16 + 4 * g);
+            rv[n] = *reinterpret_cast<const f32x4 *>(vl + 96 + n * 16 + 4 * g);
         }
 #pragma unroll
         for (int m = 0; m < G::MT_B; ++m) {
@@ -280,6 +310,8 @@ __global__ __launch_bounds__(512) void dense_pair_kernel(const PairArgs a)
         }
     }
     if (gmax > 65504.0f && a.ovf) *a.ovf = 1;
+    OJF_STAMP();  // stores issued
+#undef OJF_STAMP
 }
 
 }  // namespace ojf
