@@ -508,6 +508,10 @@ struct ChainArgs {
     int in_g0, c4_in, npix, rows_stride, rows_n;
     float scale;
     int *ovf;  // split-fp16 range guard flag (see ConvArgs)
+    // kChainEntry (branch-entry GEMM of a VortexPooling run on register-resident input): result planes
+    f32x4 *out_planes;
+    int out_g0, og_store, act_n;  // ReLU on channels < act_n (branch 0), the pooled branches stay linear
+    struct ColSums *colsum;       // channel sums of the entry layer's INPUT (global-average branch), see block_colsum
 };
 
 // Weight fragments of one (output tile, K block) pair.  fp32: K block = one 16-channel input tile, 64 float4
@@ -555,7 +559,7 @@ __device__ __forceinline__ void dma_part(const f32x4 *src, f32x4 *dst, int size,
     }
 }
 
-enum { kChainLeaky = 0, kChainRelu = 1, kChainAccumulate = 2, kChainLastRows = 3 };
+enum { kChainLeaky = 0, kChainRelu = 1, kChainAccumulate = 2, kChainLastRows = 3, kChainEntry = 4 };
 
 // One pointwise layer on register-resident activations: out[n2] (+)= sum_K W[n2][K] * in[K], then (unless
 // accumulating) bias + activation in place.  `in` and `out` are distinct, statically indexed register arrays
@@ -660,6 +664,14 @@ __device__ __forceinline__ void chain_layer(const f32x4 (&in)[MT][NA], f32x4 (&o
                         if (oc < a.rows_n && p[m] < a.npix)
                             a.out_rows[(size_t)p[m] * a.rows_stride + oc] = tanhf(v[j]) * a.scale;
                     }
+                } else if constexpr (MODE == kChainEntry) {
+                    const int og = n2 * 4 + g;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (og * 4 + j < a.act_n && !(v[j] > 0.0f)) ? (v[j] != v[j] ? v[j] : 0.0f) : v[j];
+                    if (p[m] < a.npix && og < a.og_store) {
+                        a.out_planes[(size_t)(a.out_g0 + og) * a.npix + p[m]] = v;
+                        if constexpr (ARITH == OJF_ARITH_F16X3) gmax = guard_max(gmax, lin4);
+                    }
                 } else {
                     constexpr float slope = MODE == kChainRelu ? 0.0f : 0.01f;
 #pragma unroll
@@ -729,6 +741,98 @@ __global__ __launch_bounds__(256, 3) void chain1x1_kernel(const ChainArgs a)
     chain_run<ARITH, MT, NT0, NTS...>(x, y, wlds, a.w, a.bias, a, p, lane, pre, buf);
 }
 
+// Channel sums of a register-resident activation tile set (the global-average branch of the NEXT VortexPooling,
+// model.py:107-112): x[m][S] of lane (pixel i16, g) holds channels 16S+4g..+3 of pixel p[m].  Within a block the sum
+// is formed in fp32 in a fixed order (butterfly over the 16 pixels of a tile, tiles, then the four waves through LDS);
+// across blocks it is accumulated as 2^-20 fixed point in int64 (associative: the result does not depend on the
+// arrival order, like the integrate kernels' sums) with atomics spread over kColShards rows, so that the block which
+// folds the branch into the final convolution's bias (gave_bias_block) reads 16 x 128 words instead of one row per
+// block (1200 rows took one block 25 us).  A non-finite block sum sets the channel's flag instead: its mean is NaN,
+// as the reference's would be.
+constexpr int kColShards = 16;
+constexpr float kColScale = 1048576.0f;  // 2^20; |block sum| <= 64 * 65504 -> 4.4e12, 1200 blocks: far inside int64
+
+struct ColSums {
+    long long fix[kColShards][128];
+    unsigned bad[128];
+};
+
+template <int MT, int NT, int NA>
+__device__ __forceinline__ void block_colsum(const f32x4 (&x)[MT][NA], const int (&p)[MT], int npix, float *red /* LDS [4][128] */,
+                                             ColSums *out, int lane, int wave)
+{
+    const int g = lane >> 4;
+#pragma unroll
+    for (int S = 0; S < NT; ++S) {
+        f32x4 s{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            if (p[m] < npix) s += x[m][S];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = s[j];
+            v += __shfl_xor(v, 8, 64);
+            v += __shfl_xor(v, 4, 64);
+            v += __shfl_xor(v, 2, 64);
+            v += __shfl_xor(v, 1, 64);
+            s[j] = v;
+        }
+        if ((lane & 15) == 0) *reinterpret_cast<f32x4 *>(red + wave * 128 + S * 16 + 4 * g) = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < NT * 16) {
+        const int t = threadIdx.x;
+        const float v = (red[t] + red[128 + t]) + (red[256 + t] + red[384 + t]);
+        if (v - v == 0.0f) {  // finite
+            const long long q = (long long)__builtin_rintf(v * kColScale);  // |v| < 2^23: the product is exact up to the rounding of rintf
+            if (q) atomicAdd(reinterpret_cast<unsigned long long *>(&out->fix[blockIdx.x % kColShards][t]), (unsigned long long)q);
+        } else {
+            atomicOr(&out->bad[t], 1u);
+        }
+    }
+}
+
+// Branch-entry GEMM of a VortexPooling (the four branches' first 1x1 convolutions stacked: c_in -> 4 slots of cs
+// channels; branch 0 gets bias + ReLU, the pooled branches stay linear) as ONE chain layer on register-resident
+// input, plus the per-block channel sums of that input.  Stand-alone form: input = activation planes.  The generic
+// convolution kernel needed 25 us for this launch (tap table, masks, 6 output tiles per wave) and a separate
+// column-sum launch re-read the same 37 MB.
+template <int ARITH, int MT, int NTIN, int NTOUT>
+__global__ __launch_bounds__(256, 3) void entry1x1_kernel(const ChainArgs a)
+{
+    __shared__ f32x4 wlds[kChainLdsFloat4];
+    __shared__ float red[4 * 128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int strip = (blockIdx.x * 4 + wave) * (MT * 16);
+    f32x4 pre[kChainPre];
+    int buf = 0;
+    {
+        constexpr int size0 = chain_first_size(ARITH, NTIN, NTOUT);
+        if constexpr (chain_dma(ARITH)) {
+            dma_part(a.w, wlds, size0, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane);
+        } else {
+#pragma unroll
+            for (int k = 0; k < kChainPre; ++k)
+                if ((int)threadIdx.x + 256 * k < size0) pre[k] = a.w[threadIdx.x + 256 * k];
+        }
+    }
+    int p[MT];
+    f32x4 x[MT][NTIN], y[MT][NTOUT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        p[m] = strip + m * 16 + i16;  // waves past the image still take part in the barriers
+#pragma unroll
+        for (int S = 0; S < NTIN; ++S) {
+            const int G = 4 * S + g;
+            const bool ok = p[m] < a.npix && G < a.c4_in;
+            x[m][S] = a.in[ok ? (a.in_g0 + G) * a.npix + p[m] : -1];
+        }
+    }
+    if (a.colsum) block_colsum<MT, NTIN>(x, p, a.npix, red, a.colsum, lane, wave);
+    chain_layer<ARITH, MT, NTIN, NTOUT, kChainEntry, 0>(x, y, wlds, a.w, a.bias, a, p, lane, pre, buf);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Fused VortexPooling tail (model.py:131-141,157-159): for each of the four branches
 //   t_b = ReLU(W1_b v_b + b1_b)   (mid -> out channels, the branch's closing 1x1 + BN + ReLU)
@@ -752,7 +856,16 @@ struct TailArgs {
     float *out_rows;
     int rows_stride, rows_n;
     float scale;
+    // CHAIN = kTailEntry (a VortexPooling that feeds the next one): the next branch-entry GEMM runs on the register-
+    // resident result, which is never written: planes of 4*cs channels + per-block channel sums come out instead
+    const f32x4 *entry_w;
+    const float *entry_b;
+    f32x4 *entry_out;
+    int entry_og, entry_act_n;
+    struct ColSums *colsum;
 };
+
+constexpr int kTailEntry = 1;
 
 // the prediction-head topologies chain_run is instantiated for (growth channels 19 / 20)
 template <int ARITH, int MT, int KIND>
@@ -769,8 +882,9 @@ constexpr int head_first_size(int arith, int kind) { return chain_first_size(ari
 template <int ARITH, int MT, int NV, int NO, int CHAIN = 0>
 __global__ __launch_bounds__(256, 3) void vortex_tail_kernel(const TailArgs a)
 {
-    static_assert(CHAIN == 0 || NO == 8, "the fused prediction head expects 8 input tiles");
+    static_assert(CHAIN == 0 || NO == 8, "the fused prediction head / entry layer expects 8 input tiles");
     __shared__ f32x4 wlds[kChainLdsFloat4];
+    __shared__ float red[CHAIN == kTailEntry ? 4 * 128 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
     const int strip = (blockIdx.x * 4 + wave) * (MT * 16);
@@ -816,8 +930,9 @@ __global__ __launch_bounds__(256, 3) void vortex_tail_kernel(const TailArgs a)
             chain_layer<ARITH, MT, NO, NO, kChainAccumulate, chain_first_size(ARITH, NV, NO)>(t, y, wlds, wf, nullptr, ca, p,
                                                                                             lane, pre, buf);
         else
-            chain_layer<ARITH, MT, NO, NO, kChainAccumulate, CHAIN ? head_first_size(ARITH, CHAIN) : 0>(
-                t, y, wlds, wf, nullptr, ca, p, lane, pre, buf, a.chain_w);
+            chain_layer<ARITH, MT, NO, NO, kChainAccumulate,
+                        CHAIN == kTailEntry ? chain_first_size(ARITH, 8, 5) : (CHAIN ? head_first_size(ARITH, CHAIN) : 0)>(
+                t, y, wlds, wf, nullptr, ca, p, lane, pre, buf, CHAIN == kTailEntry ? a.entry_w : a.chain_w);
     }
     float gmax = 0.0f;
 #pragma unroll
@@ -836,7 +951,11 @@ __global__ __launch_bounds__(256, 3) void vortex_tail_kernel(const TailArgs a)
     }
     if constexpr (ARITH == OJF_ARITH_F16X3)
         if (gmax > 65504.0f && a.ovf) *a.ovf = 1;
-    if constexpr (CHAIN) {
+    if constexpr (CHAIN == kTailEntry) {
+        block_colsum<MT, NO>(y, p, a.npix, red, a.colsum, lane, wave);
+        ca.out_planes = a.entry_out; ca.out_g0 = 0; ca.og_store = a.entry_og; ca.act_n = a.entry_act_n;
+        chain_layer<ARITH, MT, 8, 5, kChainEntry, 0>(y, t, wlds, a.entry_w, a.entry_b, ca, p, lane, pre, buf);
+    } else if constexpr (CHAIN) {
         ca.out_rows = a.out_rows; ca.rows_stride = a.rows_stride; ca.rows_n = a.rows_n; ca.scale = a.scale;
         head_run<ARITH, MT, CHAIN>(y, t, wlds, a.chain_w, a.chain_b, ca, p, lane, pre, buf);
     }
@@ -847,11 +966,24 @@ __global__ __launch_bounds__(256, 3) void vortex_tail_kernel(const TailArgs a)
 // a block takes a 32x8-pixel tile of ONE channel group, stages it with a halo of b pixels in LDS and applies the b
 // pooling levels there (every level is zero outside the image, like the padded intermediate tensors of the
 // reference); the intermediate levels never reach HBM.  Summation order per level = row-major taps, as before.
+// (used by gave_bias_block below; declared here because the pyramid launch carries one)
+struct GaveArgs {
+    const float *partial;   // legacy flow: nparts rows of pstride floats, added in row order
+    struct ColSums *fixed;  // chain flow: fixed-point sums (read, then zeroed for the next frame)
+    int nparts, pstride, cphys, npix;
+    const float *WgT, *bg, *WfgT, *bf;  // WgT [cphys][c_out], WfgT [c_out(j)][c_out(o)]: lane o reads consecutive addresses
+    int c_out;
+    float *bias_out;
+    int bias_len;
+};
+
 struct PyramidArgs {
     const f32x4 *z;        // entry-conv output planes; branch b's pre-activation = groups [b*c4, (b+1)*c4)
     f32x4 *q[3];           // branch inputs out: planes of c4 groups each
     const float *bias[3];  // per branch: c4*4 floats
     int h, w, c4;
+    int tiles;      // pixel tiles; block column `tiles` (when launched) folds the global-average branch instead
+    GaveArgs gave;
 };
 
 constexpr int kPoolTW = 32, kPoolTH = 8, kPoolStride = kPoolTW + 6;
@@ -910,9 +1042,15 @@ __device__ __forceinline__ void pool_pyramid_body(const PyramidArgs &a, f32x4 (&
     }
 }
 
+__device__ __forceinline__ void gave_bias_block(const GaveArgs &a, float *mean, float *gv);
+
 __global__ __launch_bounds__(256) void pool_pyramid_kernel(const PyramidArgs a)
 {
     __shared__ f32x4 buf[2][kPoolStride * (kPoolTH + 6)];
+    if ((int)blockIdx.x >= a.tiles) {  // one extra block: the global-average branch -> bias of the final conv (hidden behind the pools)
+        if (blockIdx.y == 0) gave_bias_block(a.gave, reinterpret_cast<float *>(buf), reinterpret_cast<float *>(buf) + 256);
+        return;
+    }
     const int lv = blockIdx.y / a.c4 + 1, cg = blockIdx.y - (lv - 1) * a.c4;  // levels of this block's group
     if (lv == 1) pool_pyramid_body<1>(a, buf, cg);
     else if (lv == 2) pool_pyramid_body<2>(a, buf, cg);
@@ -945,36 +1083,69 @@ __global__ __launch_bounds__(256) void colsum_kernel(const f32x4 *in, int g0, in
 
 // gave_pool branch (model.py:107-112) folded into the bias of the final 1x1 conv:
 //   mean -> 1x1 conv (+BN folded) -> g[c_out];  bias' = bias_final + W_final[:, gave columns] @ g
-__global__ __launch_bounds__(256) void gave_bias_kernel(const float *partial, int cphys, int npix, const float *WgT,
-                                                         const float *bg, const float *WfgT, const float *bf, int c_out,
-                                                         float *bias_out, int bias_len)
-{   // WgT [cphys][c_out], WfgT [c_out(j)][c_out(o)]: lane o reads consecutive addresses
+// `partial`: nparts rows of pstride floats (per-block channel sums), added in row order.
+
+__device__ __forceinline__ void gave_bias_block(const GaveArgs &a, float *mean /* LDS [256] */, float *gv /* LDS [256] */)
+{
+    const int t = threadIdx.x;
+    if (a.fixed) {
+        if (t < 128) {
+            long long q = 0;
+#pragma unroll
+            for (int sh = 0; sh < kColShards; ++sh) {
+                q += a.fixed->fix[sh][t];
+                a.fixed->fix[sh][t] = 0;  // this block is the only reader; the next writers come later in stream order
+            }
+            const bool bad = a.fixed->bad[t] != 0;
+            a.fixed->bad[t] = 0;
+            const float sum = (float)((double)q * (1.0 / (double)kColScale));
+            mean[t] = t < a.cphys ? (bad ? __builtin_nanf("") : sum / (float)a.npix) : 0.0f;
+        }
+    } else if (a.cphys <= 128) {  // two threads per channel (rows split in halves) keep 256 loads in flight; fixed order
+        const int ch = t & 127, half = t >> 7;
+        float s = 0.0f;
+        if (ch < a.cphys) {
+            const int r0 = half ? (a.nparts + 1) / 2 : 0, r1 = half ? a.nparts : (a.nparts + 1) / 2;
+#pragma unroll 8
+            for (int b = r0; b < r1; ++b) s += a.partial[(size_t)b * a.pstride + ch];
+        }
+        gv[t] = s;
+        __syncthreads();
+        mean[t] = t < a.cphys ? (gv[t] + gv[128 + t]) / (float)a.npix : 0.0f;
+    } else {
+        float s = 0.0f;
+        if (t < a.cphys) {
+#pragma unroll 8
+            for (int b = 0; b < a.nparts; ++b) s += a.partial[(size_t)b * a.pstride + t];
+        }
+        mean[t] = s / (float)a.npix;
+    }
+    __syncthreads();
+    float s1 = 0.0f;
+    if (t < a.c_out) {
+        s1 = a.bg[t];
+#pragma unroll 8
+        for (int c = 0; c < a.cphys; ++c) s1 = __builtin_fmaf(a.WgT[(size_t)c * a.c_out + t], mean[c], s1);
+    }
+    __syncthreads();
+    gv[t] = s1;
+    __syncthreads();
+    if (t < a.bias_len) {
+        float s = 0.0f;
+        if (t < a.c_out) {
+            s = a.bf[t];
+#pragma unroll 8
+            for (int j = 0; j < a.c_out; ++j) s = __builtin_fmaf(a.WfgT[(size_t)j * a.c_out + t], gv[j], s);
+        }
+        a.bias_out[t] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void gave_bias_kernel(const GaveArgs a)
+{
     __shared__ float mean[256];
     __shared__ float gv[256];
-    const int t = threadIdx.x;
-    if (t < cphys) {
-        float s = 0.0f;
-#pragma unroll 8
-        for (int b = 0; b < kSumBlocks; ++b) s += partial[b * 256 + t];
-        mean[t] = s / (float)npix;
-    }
-    __syncthreads();
-    if (t < c_out) {
-        float s = bg[t];
-#pragma unroll 8
-        for (int c = 0; c < cphys; ++c) s = __builtin_fmaf(WgT[(size_t)c * c_out + t], mean[c], s);
-        gv[t] = s;
-    }
-    __syncthreads();
-    if (t < bias_len) {
-        float s = 0.0f;
-        if (t < c_out) {
-            s = bf[t];
-#pragma unroll 8
-            for (int j = 0; j < c_out; ++j) s = __builtin_fmaf(WfgT[(size_t)j * c_out + t], gv[j], s);
-        }
-        bias_out[t] = s;
-    }
+    gave_bias_block(a, mean, gv);
 }
 
 struct PrepArgs {
@@ -1481,6 +1652,7 @@ struct Vortex {
     float *pool_bias[4] = {nullptr, nullptr, nullptr, nullptr};
     float *Wg = nullptr, *bg = nullptr, *Wfg = nullptr, *bf = nullptr, *bias_final = nullptr;
     float *tail_w = nullptr, *tail_b1 = nullptr, *tail_rinv = nullptr;  // fused tail (closing 1x1s + final conv), when supported
+    float *entry_w = nullptr, *entry_b = nullptr;  // the stacked entry GEMM as one chain layer (8 input tiles -> 5), when supported
 };
 
 }  // namespace ojf
@@ -1505,6 +1677,7 @@ struct ojf_net {
     struct Scratch {
         float *T = nullptr, *Z = nullptr, *Q1 = nullptr, *Q2 = nullptr, *Q3 = nullptr, *U = nullptr, *V = nullptr;
         float *partial = nullptr;
+        ojf::ColSums *colsum = nullptr;  // chain flow: fixed-point channel sums of the entry layer's input (zero between frames)
         float *CAT = nullptr;  // 4*os, unfused tail only (allocated at first use)
         hipStream_t side = nullptr;
         hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_entry = nullptr;
@@ -1580,6 +1753,14 @@ static int build_vortex(ojf_net *net, Vortex &v, const ojf_conv_layer *L, int c_
             }
         }
         if (finish(b, v.stacked, net->arith)) return -2;
+        if (c_in_phys <= 128 && 4 * cs <= 80) {  // chain-layer form (entry1x1_kernel / the previous tail): 8 tiles -> 5
+            auto we = [&](int oc, int k) { return oc < 4 * cs && k < c_in_phys ? b.W[(size_t)oc * c_in_phys + k] : 0.0f; };
+            const std::vector<float> re = chain_row_scales(net->arith, 5, c_in_phys, we);
+            std::vector<float> ew, eb;
+            pack_chain_layer(ew, net->arith, 5, 8, re, we);
+            append_chain_bias(eb, net->arith, 5, 4 * cs, b.B.data(), re);
+            if (upload(ew, &v.entry_w) || upload(eb, &v.entry_b)) return -2;
+        }
     }
     const std::vector<int> id_c = slot_map(c, c, cs);
     for (int br = 0; br < 4; ++br) {
@@ -1644,36 +1825,70 @@ static void free_vortex(Vortex &v)
         release(v.b1[b]);
         if (v.pool_bias[b]) (void)hipFree(v.pool_bias[b]);
     }
-    float *ptrs[] = {v.Wg, v.bg, v.Wfg, v.bf, v.bias_final, v.tail_w, v.tail_b1, v.tail_rinv};
+    float *ptrs[] = {v.Wg, v.bg, v.Wfg, v.bf, v.bias_final, v.tail_w, v.tail_b1, v.tail_rinv, v.entry_w, v.entry_b};
     for (float *p : ptrs)
         if (p) (void)hipFree(p);
 }
 
 // in: planes, window starting at group in_g0 (c_in_phys/4 groups); out: planes at group out_g0
+static GaveArgs gave_args(const ojf_net *net, const Vortex &v, const float *partial, int nparts, int pstride, ColSums *fixed = nullptr)
+{
+    GaveArgs ga;
+    ga.partial = partial; ga.fixed = fixed; ga.nparts = nparts; ga.pstride = pstride; ga.cphys = v.c_in_phys; ga.npix = net->npix;
+    ga.WgT = v.Wg; ga.bg = v.bg; ga.WfgT = v.Wfg; ga.bf = v.bf; ga.c_out = net->pool_in;
+    ga.bias_out = v.bias_final; ga.bias_len = v.fin.n_ot * 16;
+    return ga;
+}
+
+static int chain_blocks(const ojf_net *net) { return ((net->npix + 15) / 16 + 3) / 4; }  // blocks of the MT = 1 chain kernels
+
+// in: planes, window starting at group in_g0 (c_in_phys/4 groups); out: planes at group out_g0.
+// entry_done: the previous VortexPooling's tail already left this one's entry planes (sc.Z) and column sums (sc.colsum).
+// next: when given (and supported), this tail runs the NEXT VortexPooling's entry GEMM on its register-resident result
+//       instead of writing `out`; *next_done reports it.
 static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float *out, int out_g0, hipStream_t st,
-                      ojf_net::Scratch &sc, const ChainArgs *head = nullptr, bool *head_done = nullptr)
+                      ojf_net::Scratch &sc, const ChainArgs *head = nullptr, bool *head_done = nullptr,
+                      bool entry_done = false, const Vortex *next = nullptr, bool *next_done = nullptr)
 {
     const int h = net->h, w = net->w, c4 = net->cs / 4, o4 = net->os / 4;
-    // global-average branch -> bias of the final conv, on the side stream (fork here, join before the tail)
-    OJF_HIP(hipEventRecord(sc.ev_fork, st));
-    OJF_HIP(hipStreamWaitEvent(sc.side, sc.ev_fork, 0));
-    hipLaunchKernelGGL(colsum_kernel, dim3(kSumBlocks, v.c_in_phys / 4), dim3(256), 0, sc.side, planes(in), in_g0,
-                       net->npix, sc.partial);
-    OJF_HIP(hipGetLastError());
-    hipLaunchKernelGGL(gave_bias_kernel, dim3(1), dim3(256), 0, sc.side, sc.partial, v.c_in_phys, net->npix, v.Wg,
-                       v.bg, v.Wfg, v.bf, net->pool_in, v.bias_final, v.fin.n_ot * 16);
-    OJF_HIP(hipGetLastError());
-    // branch entries: one GEMM, branch 0 gets bias + ReLU in the epilogue
-    if (launch_conv(v.stacked, in, in_g0, sc.Z, 0, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w, st)) return -2;
-    OJF_HIP(hipEventRecord(sc.ev_entry, st));
+    const bool h16 = net->arith == OJF_ARITH_F16X3;
+    static const bool legacy_env = getenv("OJF_LEGACY_VORTEX") != nullptr;  // ablation switch only
+    // Chain flow (no side stream, no events): entry GEMM + column sums in one chain-layer launch (or inside the previous
+    // tail), the global-average fold as one extra block of the pyramid launch, all four branches in the grouped launches.
+    const bool chain_flow = v.entry_w && v.tail_w && !legacy_env;
+    if (!chain_flow) {
+        if (entry_done) return fail("run_vortex: internal error (entry planes without the chain flow)");
+        // global-average branch -> bias of the final conv, on the side stream (fork here, join before the tail)
+        OJF_HIP(hipEventRecord(sc.ev_fork, st));
+        OJF_HIP(hipStreamWaitEvent(sc.side, sc.ev_fork, 0));
+        hipLaunchKernelGGL(colsum_kernel, dim3(kSumBlocks, v.c_in_phys / 4), dim3(256), 0, sc.side, planes(in), in_g0,
+                           net->npix, sc.partial);
+        OJF_HIP(hipGetLastError());
+        hipLaunchKernelGGL(gave_bias_kernel, dim3(1), dim3(256), 0, sc.side, gave_args(net, v, sc.partial, kSumBlocks, 256));
+        OJF_HIP(hipGetLastError());
+        // branch entries: one GEMM, branch 0 gets bias + ReLU in the epilogue
+        if (launch_conv(v.stacked, in, in_g0, sc.Z, 0, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w, st)) return -2;
+        OJF_HIP(hipEventRecord(sc.ev_entry, st));
+    } else if (!entry_done) {
+        ChainArgs ea;
+        ea.in = planes(in); ea.w = planes(v.entry_w); ea.bias = v.entry_b; ea.out_rows = nullptr;
+        ea.in_g0 = in_g0; ea.c4_in = v.c_in_phys / 4; ea.npix = net->npix; ea.rows_stride = 0; ea.rows_n = 0; ea.scale = 1.0f;
+        ea.ovf = h16 ? overflow_flag() : nullptr;
+        ea.out_planes = planes(sc.Z); ea.out_g0 = 0; ea.og_store = 4 * c4; ea.act_n = net->cs; ea.colsum = sc.colsum;
+        const dim3 grid(chain_blocks(net)), block(256);
+        if (h16) hipLaunchKernelGGL((entry1x1_kernel<OJF_ARITH_F16X3, 1, 8, 5>), grid, block, 0, st, ea);
+        else hipLaunchKernelGGL((entry1x1_kernel<OJF_ARITH_F32, 1, 8, 5>), grid, block, 0, st, ea);
+        OJF_HIP(hipGetLastError());
+    }
     {   // pool pyramid on the pre-activations of branches 1..3: Q_b = ReLU(pool^b(Z[slot b]) + bias_b), one launch
         PyramidArgs pa;
         pa.z = planes(sc.Z);
         pa.q[0] = planes(sc.Q1); pa.q[1] = planes(sc.Q2); pa.q[2] = planes(sc.Q3);
         for (int b = 0; b < 3; ++b) pa.bias[b] = v.pool_bias[b + 1];
         pa.h = h; pa.w = w; pa.c4 = c4;
-        const int tiles = ((w + kPoolTW - 1) / kPoolTW) * ((h + kPoolTH - 1) / kPoolTH);
-        hipLaunchKernelGGL(pool_pyramid_kernel, dim3(tiles, 3 * c4), dim3(256), 0, st, pa);
+        pa.tiles = ((w + kPoolTW - 1) / kPoolTW) * ((h + kPoolTH - 1) / kPoolTH);
+        pa.gave = gave_args(net, v, nullptr, 0, 0, sc.colsum);
+        hipLaunchKernelGGL(pool_pyramid_kernel, dim3(pa.tiles + (chain_flow ? 1 : 0), 3 * c4), dim3(256), 0, st, pa);
         OJF_HIP(hipGetLastError());
     }
     const float *bin[4] = {sc.Z, sc.Q1, sc.Q2, sc.Q3};
@@ -1685,10 +1900,9 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
             fill_conv_args(ga[br], v.b3a[br], bin[br], 0, sc.U, br * c4, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w);
             fill_conv_args(gb[br], v.b3b[br], sc.U, br * c4, sc.V, br * c4, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w);
         }
-        // Branch 0 needs no pooling: its 3x3 pair follows the global-average kernels on the side stream (37 us of tiny
-        // kernels + 2 x 9 us there against pyramid + two grouped launches of the other three branches here).
+        // Legacy flow: branch 0 needs no pooling, its 3x3 pair follows the global-average kernels on the side stream
         static const bool b0_main = getenv("OJF_BRANCH0_MAIN") != nullptr;  // ablation switch only
-        if (b0_main || net->npix < 32768) {  // small frames: the extra stream hand-over costs more than it hides (160x120: +12 %)
+        if (chain_flow || b0_main || net->npix < 32768) {  // (small frames: the stream hand-over costs more than it hides)
             if (launch_conv_args(ga, 4, v.b3a[0].n_ot, st, net->arith)) return -2;
             if (launch_conv_args(gb, 4, v.b3b[0].n_ot, st, net->arith)) return -2;
         } else {
@@ -1699,8 +1913,10 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
             if (launch_conv_args(gb + 1, 3, v.b3b[1].n_ot, st, net->arith)) return -2;
         }
     }
-    OJF_HIP(hipEventRecord(sc.ev_join, sc.side));
-    OJF_HIP(hipStreamWaitEvent(st, sc.ev_join, 0));  // bias of the final conv is ready
+    if (!chain_flow) {
+        OJF_HIP(hipEventRecord(sc.ev_join, sc.side));
+        OJF_HIP(hipStreamWaitEvent(st, sc.ev_join, 0));  // bias of the final conv is ready
+    }
     if (!fused) {
         if (ensure_planes(&sc.CAT, (size_t)net->npix, 4 * net->os)) return -2;
         for (int br = 0; br < 4; ++br)
@@ -1712,13 +1928,13 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
     for (int br = 0; br < 4; ++br) ta.v[br] = planes(sc.V) + (size_t)br * c4 * net->npix;
     ta.w = planes(v.tail_w); ta.b1 = v.tail_b1; ta.bias_final = v.bias_final; ta.rinv_final = v.tail_rinv;
     ta.out = planes(out); ta.c4 = c4; ta.out_g0 = out_g0; ta.og_store = o4; ta.npix = net->npix;
-    ta.ovf = net->arith == OJF_ARITH_F16X3 ? overflow_flag() : nullptr;
+    ta.ovf = h16 ? overflow_flag() : nullptr;
     ta.chain_w = nullptr; ta.chain_b = nullptr; ta.out_rows = nullptr; ta.rows_stride = 0; ta.rows_n = 0; ta.scale = 1.0f;
+    ta.entry_w = nullptr; ta.entry_b = nullptr; ta.entry_out = nullptr; ta.entry_og = 0; ta.entry_act_n = 0; ta.colsum = nullptr;
     // MT = 1: two pixel tiles per wave (324 VGPRs, one wave per SIMD) measured slower (0.624 vs 0.609 ms net)
-    const int strips = (net->npix + 15) / 16;
-    const dim3 grid((strips + 3) / 4), block(256);
-    const bool h16 = net->arith == OJF_ARITH_F16X3;
+    const dim3 grid(chain_blocks(net)), block(256);
     static const bool no_head_fusion = getenv("OJF_NO_HEAD_FUSION") != nullptr;  // ablation switch only
+    static const bool no_entry_fusion = getenv("OJF_NO_ENTRY_FUSION") != nullptr;  // ablation switch only
     if (head && net->chain_kind && !no_head_fusion) {  // last VortexPooling: the prediction head rides along
         ta.chain_w = head->w; ta.chain_b = head->bias; ta.out_rows = head->out_rows;
         ta.rows_stride = head->rows_stride; ta.rows_n = head->rows_n; ta.scale = head->scale;
@@ -1727,6 +1943,13 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
         else if (h16) hipLaunchKernelGGL((vortex_tail_kernel<OJF_ARITH_F16X3, 1, 2, 8, 20>), grid, block, 0, st, ta);
         else hipLaunchKernelGGL((vortex_tail_kernel<OJF_ARITH_F32, 1, 2, 8, 20>), grid, block, 0, st, ta);
         if (head_done) *head_done = true;
+    } else if (chain_flow && next && next->entry_w && next->tail_w && next->c_in_phys == net->os && !legacy_env && !no_entry_fusion) {
+        // this VortexPooling feeds the next one: its entry GEMM and column sums ride along, `out` is never written
+        ta.entry_w = planes(next->entry_w); ta.entry_b = next->entry_b; ta.entry_out = planes(sc.Z);
+        ta.entry_og = 4 * c4; ta.entry_act_n = net->cs; ta.colsum = sc.colsum;
+        if (h16) hipLaunchKernelGGL((vortex_tail_kernel<OJF_ARITH_F16X3, 1, 2, 8, kTailEntry>), grid, block, 0, st, ta);
+        else hipLaunchKernelGGL((vortex_tail_kernel<OJF_ARITH_F32, 1, 2, 8, kTailEntry>), grid, block, 0, st, ta);
+        if (next_done) *next_done = true;
     } else if (h16) {
         hipLaunchKernelGGL((vortex_tail_kernel<OJF_ARITH_F16X3, 1, 2, 8>), grid, block, 0, st, ta);
     } else {
@@ -1786,6 +2009,7 @@ OJF_API void ojf_net_destroy(ojf_net *net)
     for (float *p : bufs) free_planes(p);
     for (auto &sc : net->sc) {
         float *sb[] = {sc.T, sc.Z, sc.Q1, sc.Q2, sc.Q3, sc.U, sc.V, sc.partial, sc.CAT};
+        if (sc.colsum) (void)hipFree(sc.colsum);
         for (float *p : sb) free_planes(p);
         if (sc.ev_fork) (void)hipEventDestroy(sc.ev_fork);
         if (sc.ev_join) (void)hipEventDestroy(sc.ev_join);
@@ -1931,6 +2155,8 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
         if (!rc) rc = alloc_planes(&sc.U, np, 4 * cs);
         if (!rc) rc = alloc_planes(&sc.V, np, 4 * cs);
         if (!rc) rc = alloc_planes(&sc.partial, kSumBlocks, 256);
+        if (!rc) rc = check_hip(hipMalloc(reinterpret_cast<void **>(&sc.colsum), sizeof(ColSums)), "hipMalloc");
+        if (!rc) rc = check_hip(hipMemset(sc.colsum, 0, sizeof(ColSums)), "hipMemset");
         if (!rc) rc = check_hip(hipStreamCreateWithFlags(&sc.side, hipStreamNonBlocking), "hipStreamCreate");
         if (!rc) rc = check_hip(hipEventCreateWithFlags(&sc.ev_fork, event_flags()), "hipEventCreate");
         if (!rc) rc = check_hip(hipEventCreateWithFlags(&sc.ev_join, event_flags()), "hipEventCreate");
@@ -2009,16 +2235,20 @@ static int forward_launches(ojf_net *net, float *est, int est_stride, hipStream_
             if (run_vortex(net, net->vortex[1], net->X[1], 0, net->YY, o4, s1, net->sc[1])) return -2;
         }
         if (run_dense(net, 0, st)) return -2;
-        if (run_vortex(net, net->vortex[0], net->X[0], 0, net->YY, 0, st, net->sc[0])) return -2;
+        bool entry_done = false;  // single head: vortex0's tail runs vortex3's entry GEMM (its own output is never written)
+        if (run_vortex(net, net->vortex[0], net->X[0], 0, net->YY, 0, st, net->sc[0], nullptr, nullptr, false,
+                       two ? nullptr : &net->vortex[2], &entry_done)) return -2;
         if (two && s1 != st) {
             OJF_HIP(hipEventRecord(net->ev_head_join, s1));
             OJF_HIP(hipStreamWaitEvent(st, net->ev_head_join, 0));
         }
-        if (run_vortex(net, net->vortex[2], net->YY, 0, net->Y3, 0, st, net->sc[0], head, &head_done)) return -2;
+        if (run_vortex(net, net->vortex[2], net->YY, 0, net->Y3, 0, st, net->sc[0], head, &head_done, entry_done)) return -2;
     } else {
         if (run_dense(net, 0, st)) return -2;
-        if (run_vortex(net, net->vortex[0], net->X[0], 0, net->YY, 0, st, net->sc[0])) return -2;
-        if (run_vortex(net, net->vortex[2], net->YY, 0, net->Y3, 0, st, net->sc[0], head, &head_done)) return -2;
+        bool entry_done = false;
+        if (run_vortex(net, net->vortex[0], net->X[0], 0, net->YY, 0, st, net->sc[0], nullptr, nullptr, false, &net->vortex[2],
+                       &entry_done)) return -2;
+        if (run_vortex(net, net->vortex[2], net->YY, 0, net->Y3, 0, st, net->sc[0], head, &head_done, entry_done)) return -2;
     }
     if (head_done) return 0;
     if (net->chain_kind && !unfused) {
