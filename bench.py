@@ -5,16 +5,25 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one Pipeline.fuse call: one 320x240 synthetic depth frame fused into a 256^3 fp16
-volume resident in HBM (BASELINE.json configs[1], geometry-only, FusionNet_v3 without semantics).
-Frames (depth, mask) are resident in HBM before the timed region; poses stay on the host like any
-small per-frame metadata.  With N > 1 every rank owns one scene (its volumes + its own frame stream,
-SURVEY.md §8e): no data-path collective, weak scaling, value = N*K / max-over-ranks time.
+One "step" = one Pipeline.fuse call: one synthetic depth frame fused into an fp16 volume resident in HBM.  Default
+workload = BASELINE.json configs[1] (320x240 depth into 256^3, geometry-only, FusionNet_v3); flags select the other
+configurations and `config.workload` says which one ran.  Frames (depth, mask) are resident in HBM before the timed
+region; poses stay on the host like any small per-frame metadata.  With N > 1 every rank owns one scene (its volumes
++ its own frame stream): no data-path collective, weak scaling, value = N*K / max-over-ranks time.
 
 Rank 0 prints ONE JSON line with the driver's contract fields plus
-  roofline      dominant kernel (conv_mfma_kernel, fp32 MFMA): algorithmic flops / live HIP-event time
-  roofline_hbm  extract + integrate against the HBM roofline (algorithmic bytes of SURVEY.md §8d)
-  cpu_baseline  the op-for-op torch-CPU port of the reference path timed on this node's host cores
+  stages_ms            extract / net / integrate from fence-free HIP events on the launch stream, sampled on every 4th
+                       frame INSIDE the timed region (an event record is a marker packet that idles the queue ~4.5 us)
+  stages_ms_all_frames the same from a separate UNTIMED pass with events on every frame
+  kernels              per-kernel table of the fusion net from a profiled forward (ojf_net_profile: one event behind
+                       every launch): launches, us per frame, algorithmic GFLOP, TFLOP/s, fraction of the MFMA peak
+  roofline             the kernel that takes most of the frame (from that table), against the dense MFMA peak of the
+                       arithmetic; roofline_net = all MFMA launches of the frame over the net stage time
+  roofline_hbm         extract + integrate against the HBM roofline (algorithmic bytes of SURVEY.md §8d)
+  cpu_baseline         the op-for-op torch-CPU port of the reference path timed on this node's host cores
+  secondary            (N = 1, default flags only) short runs of the other BASELINE configurations in the same process:
+                       fp32-input MFMA arithmetic, + semantics (gt labels), + semantics predicted by AdapNet++,
+                       640x480 -> 512^3 (configs[4] size) without / with semantics
 """
 import argparse
 import json
@@ -30,7 +39,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from online_joint_depthfusion_and_semantic_amd.config import default_config, database_config  # noqa: E402
-from online_joint_depthfusion_and_semantic_amd.database import Database  # noqa: E402
+from online_joint_depthfusion_and_semantic_amd.database import Database, Voxelgrid  # noqa: E402
 from online_joint_depthfusion_and_semantic_amd.pipeline import Pipeline  # noqa: E402
 from online_joint_depthfusion_and_semantic_amd.synthetic import SyntheticStream  # noqa: E402
 
@@ -42,6 +51,21 @@ F16_MFMA_PEAK_TF = 2516.6  # dense fp16 MFMA peak (v_mfma_f32_16x16x32_f16)
 ARITH = {'f32': ('f32', 'f32-input MFMA (v_mfma_f32_16x16x4_f32)', F32_MFMA_PEAK_TF),
          'f16x3': ('f16x3', 'split-fp16: 3 x v_mfma_f32_16x16x32_f16 per product block, fp32 accumulate, fp32 activations',
                    F16_MFMA_PEAK_TF / 3.0)}
+DISTINCT_FRAMES = 64  # distinct synthetic frames kept resident per case (cycled when steps + warmup exceed it)
+
+
+class BenchStream(SyntheticStream):
+    """Synthetic stream whose ground-truth grid is a constant volume: Pipeline.fuse never reads the GT grid, and
+    sampling the analytic scene at 512^3 voxel centres would take a minute of host time per case."""
+
+    def get_grid(self, scene, truncation, semantic_grid=True):
+        g = Voxelgrid(self.resolution)
+        g.from_array(np.full((self.grid,) * 3, truncation, dtype=np.float16), self.bbox)
+        if semantic_grid:
+            s = Voxelgrid(self.resolution)
+            s.from_array(np.zeros((self.grid,) * 3, dtype=np.uint8), self.bbox)
+            return (g, s)
+        return (g,)
 
 
 def seeded_weights(pipe, seed=1911):
@@ -54,41 +78,68 @@ def seeded_weights(pipe, seed=1911):
             m.running_var.uniform_(0.5, 1.5)
 
 
+def workload_name(c):
+    sem = ''
+    if c['semantics']:
+        sem = ' + semantics (%s, %d classes)' % ('AdapNet++ predicted per frame, %s convolutions' % c['seg_engine']
+                                                 if c['strategy'] == 'predict' else 'gt labels, two-head net', c['n_classes'])
+    base = {(240, 320, 256): 'BASELINE configs[%d]' % (2 if c['semantics'] else 1),
+            (480, 640, 512): 'BASELINE configs[4] size',
+            (120, 160, 64): 'BASELINE configs[0] size'}.get((c['h'], c['w'], c['grid']), 'custom size')
+    return '%s: %dx%d depth into a %d^3 fp16 TSDF grid, FusionNet_v3%s, %s integrate, %s arithmetic, one scene per GPU' % (
+        base, c['w'], c['h'], c['grid'], sem if sem else ', geometry-only', c['mode'], c['arith'])
+
+
 def cpu_baseline(args, h, w, grid, semantics):
-    """Times oracle/torch_port.fuse (the reference's op sequence on torch-CPU) on a bounded sample."""
+    """Times oracle/torch_port.fuse (the reference's op sequence on torch-CPU) on a bounded sample, on a stated number
+    of threads: min(16, cores) - with all 128 host threads the oneDNN / ATen calls of this size oversubscribe and run
+    3-4x SLOWER (7.2 s/frame on 128 threads vs 1.9 s on 8 in the build container)."""
     from oracle import torch_port  # checker / baseline only - never on the product path
     from online_joint_depthfusion_and_semantic_amd.model import FusionNet_v3
-    cfg = default_config(h, w, semantics=semantics)
-    cfg.FUSION_MODEL.resx, cfg.FUSION_MODEL.resy = w, h
-    net = FusionNet_v3(cfg.FUSION_MODEL).eval()
-    st = SyntheticStream(h, w, grid, 40, scene='cpu_scene')
-    vols = dict(tsdf=torch.full((grid,) * 3, 0.1, dtype=torch.float16), wgt=torch.zeros((grid,) * 3, dtype=torch.float16))
-    if semantics:
-        vols.update(ids=torch.zeros((grid,) * 3, dtype=torch.uint8), scores=torch.zeros((grid,) * 3, dtype=torch.float16))
-    origin = torch.from_numpy(st.origin)
-    times = []
-    with torch.no_grad():
-        for i in range(args.cpu_frames + 1):
-            b = st.batch(i)
-            t0 = time.perf_counter()
-            torch_port.fuse(b, vols, net, origin, st.resolution, semantics=semantics)
-            times.append(time.perf_counter() - t0)
+    nproc = os.cpu_count() or 1
+    before = torch.get_num_threads()
+    threads = min(16, nproc)
+    torch.set_num_threads(threads)
+    try:
+        cfg = default_config(h, w, semantics=semantics)
+        cfg.FUSION_MODEL.resx, cfg.FUSION_MODEL.resy = w, h
+        net = FusionNet_v3(cfg.FUSION_MODEL).eval()
+        st = SyntheticStream(h, w, grid, 40, scene='cpu_scene')
+        vols = dict(tsdf=torch.full((grid,) * 3, 0.1, dtype=torch.float16), wgt=torch.zeros((grid,) * 3, dtype=torch.float16))
+        if semantics:
+            vols.update(ids=torch.zeros((grid,) * 3, dtype=torch.uint8), scores=torch.zeros((grid,) * 3, dtype=torch.float16))
+        origin = torch.from_numpy(st.origin)
+        times = []
+        with torch.no_grad():
+            for i in range(args.cpu_frames + 1):
+                b = st.batch(i)
+                t0 = time.perf_counter()
+                torch_port.fuse(b, vols, net, origin, st.resolution, semantics=semantics)
+                times.append(time.perf_counter() - t0)
+    finally:
+        torch.set_num_threads(before)
     t = float(np.mean(times[1:]))
-    return {'value': 1.0 / t, 'unit': 'frames/sec', 'cores': int(torch.get_num_threads()), 'kind': 'port',
-            'sample': '%d frames of the %dx%d -> %d^3 workload after 1 warm-up frame, torch-CPU op-for-op port of '
-                      'the reference (oracle/torch_port.py), %.2f s/frame' % (args.cpu_frames, w, h, grid, t)}
+    return {'value': 1.0 / t, 'unit': 'frames/sec', 'cores': threads, 'host_cores': nproc, 'torch_threads_default': before,
+            'kind': 'port',
+            'sample': '%d frames of the %dx%d -> %d^3 workload after 1 warm-up frame, torch-CPU op-for-op port of the reference '
+                      '(oracle/torch_port.py) on %d threads (torch.set_num_threads; %d host cores), %.2f s/frame'
+                      % (args.cpu_frames, w, h, grid, threads, nproc, t)}
 
 
-def pmc_traffic(h, w, grid, semantics):
-    """HBM bytes per frame per kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
-    collected in separate runs of this bench, tools/pmc_traffic.py; FETCH_SIZE doubled as
-    MI355X_MICROARCH.md §HBM prescribes for wide coalesced reads on gfx950).  Only valid for the
-    default workload it was measured on; otherwise None."""
-    path = os.path.join(ROOT, 'profiles', 'r01_traffic_pmc.json')
-    if (h, w, grid, semantics) != (240, 320, 256, False) or not os.path.exists(path):
-        return None
+def pmc_traffic(c):
+    """HBM bytes per frame per kernel REPLAYED from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in
+    separate runs of this bench, tools/pmc_traffic.py; FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes) - not
+    observed by this run.  Only valid for the workload the passes were taken on; otherwise None."""
+    for name in ('r02_traffic_pmc.json', 'r01_traffic_pmc.json'):
+        path = os.path.join(ROOT, 'profiles', name)
+        if os.path.exists(path):
+            break
+    else:
+        return None, None
+    if (c['h'], c['w'], c['grid'], c['semantics'], c['arith']) != (240, 320, 256, False, 'f16x3'):
+        return None, None
     with open(path) as f:
-        return json.load(f)
+        return json.load(f), 'profiles/' + name
 
 
 def algorithmic_bytes(st, frames, n_points, n_tail, semantics):
@@ -112,6 +163,176 @@ def algorithmic_bytes(st, frames, n_points, n_tail, semantics):
     return tot / k, ug_s / k, us_s / k
 
 
+def net_kernel_macs(c_ch=19, gf=5):
+    """Algorithmic MAC per pixel of every kernel class of the single-head net (channel padding excluded; c = 2 * n_points
+    + 1 = 19); the classes add up to the library's ojf_net_macs_per_pixel (326 876)."""
+    out = c_ch * (gf + 1)
+    dense = sum(9 * c_ch * (i + 1) * c_ch + 9 * c_ch * c_ch for i in range(gf))
+    branches = 8 * 9 * c_ch * c_ch              # per VortexPooling: four branches x two dilated 3x3 (19 -> 19)
+    entry = out * 4 * c_ch                      # per VortexPooling: the four branch-entry 1x1 (114 -> 19) stacked
+    # closing 1x1s + the final 1x1 over the 5 * 114 concat (the global-average columns are folded into its bias here,
+    # but they are per-pixel MACs of the reference's layer)
+    tail = 4 * (c_ch * out + out * out) + out * out
+    widths = [out] + [c_ch * k for k in range(gf, 0, -1)]
+    head = sum(a * b + b * b for a, b in zip(widths[:-1], widths[1:])) + c_ch * 9
+    return {'dense': dense, 'branches': branches, 'entry': entry, 'tail': tail, 'head': head}
+
+
+class Case:
+    """One workload: pipeline + volumes + resident frames."""
+
+    def __init__(self, c, dev, rank, n_frames):
+        self.c = c
+        h, w, grid = c['h'], c['w'], c['grid']
+        cfg = default_config(h, w, semantics=c['semantics'], integrate_mode=c['mode'], n_classes=c['n_classes'])
+        cfg.SETTINGS.device = str(dev)
+        cfg.FUSION_MODEL.arithmetic = c['arith']
+        if c['semantics']:
+            cfg.DATA.semantic_strategy = c['strategy']
+            cfg.SEMANTIC_2D_MODEL.engine = c['seg_engine']
+        self.cfg = cfg
+        n_distinct = min(n_frames, DISTINCT_FRAMES)
+        self.st = BenchStream(h, w, grid, max(n_distinct, 40), scene='room_%d' % rank, seed=1911 + rank, n_classes=c['n_classes'])
+        self.db = Database(self.st, database_config(cfg))
+        pipe = Pipeline(cfg)
+        seeded_weights(pipe)
+        self.pipe = pipe.to(dev).eval()
+        self.dev = dev
+        # frames resident in HBM before the clock starts; poses and ids stay host-side metadata
+        self.batches = []
+        image = torch.zeros((1, 3, h, w), device=dev)  # only its shape is read on the geometry / gt-label paths
+        predict = c['semantics'] and c['strategy'] == 'predict'
+        for i in range(n_distinct):
+            f = self.st.frame(i)
+            b = {'image': torch.from_numpy(f['image']).unsqueeze(0).to(dev) if predict else image, 'frame_id': [f['frame_id']],
+                 self.st.depth_key: torch.from_numpy(f[self.st.depth_key]).unsqueeze(0).to(dev),
+                 'mask': torch.from_numpy(f['mask']).unsqueeze(0).to(dev),
+                 'extrinsics': torch.from_numpy(f['extrinsics']).unsqueeze(0),
+                 'intrinsics': torch.from_numpy(f['intrinsics']).unsqueeze(0)}
+            if c['semantics']:
+                b['semantic_gt'] = torch.from_numpy(f['semantic_gt']).unsqueeze(0).to(dev)
+            self.batches.append(b)
+
+    def fuse(self, i):
+        self.pipe.fuse(self.batches[i % len(self.batches)], self.db, self.dev)
+
+    def run(self, steps, warmup, sync, profile_frames=32):
+        pipe = self.pipe
+        with torch.no_grad():
+            pipe.profile = False
+            for i in range(warmup):
+                self.fuse(i)
+            pipe.profile = 4  # stage events on every 4th frame of the timed region
+            pipe.reset_profile()
+            sync()
+            t0 = time.perf_counter()
+            for i in range(warmup, warmup + steps):
+                self.fuse(i)
+            sync()
+            elapsed = time.perf_counter() - t0
+            pipe.check()  # outside the timed region: raises if the split-fp16 range guard fired on any frame
+            stages = pipe.stage_times_ms()
+            n_samples = len(pipe._marks) // 4
+            # separate UNTIMED pass: stage events on every frame
+            pipe.profile = True
+            pipe.reset_profile()
+            for i in range(profile_frames):
+                self.fuse(warmup + steps + i)
+            stages_all = pipe.stage_times_ms()
+            pipe.profile = False
+            # per-kernel table of the fusion net: profiled forwards on the last frame's packed input
+            table = {}
+            reps = 5
+            for _ in range(reps):
+                for k, (name, us) in enumerate(pipe._engine.profile(pipe._est)):
+                    ent = table.setdefault(name, [0, 0.0])
+                    ent[0] += 1
+                    ent[1] += max(us, 0.0)
+            kernels = {name: {'launches_per_frame': n / reps, 'us_per_frame': us / reps} for name, (n, us) in table.items()}
+            pipe.check()
+        return {'elapsed': elapsed, 'stages': stages, 'stage_samples': n_samples, 'stages_all': stages_all,
+                'stages_all_frames': profile_frames, 'kernels': kernels, 'launches': pipe._engine.launches}
+
+
+def kernel_table(kernels, c, N, peak_tf, total_macs):
+    """Adds algorithmic GFLOP / TFLOP/s / fraction of the arithmetic's MFMA peak to the profiled per-kernel times
+    (geometry-only net; with the semantic head the table carries times only)."""
+    flops = {}
+    if not c['semantics']:
+        m = net_kernel_macs()
+        flops = {'dense_pair_kernel': m['dense'], 'conv_f16x3_kernel (grouped)': 2 * m['branches'], 'conv_mfma_kernel': None,
+                 'entry1x1_kernel': m['entry'], 'vortex_tail_kernel (+ next entry GEMM)': m['tail'] + m['entry'],
+                 'vortex_tail_kernel (+ prediction head)': m['tail'] + m['head']}
+        assert m['dense'] + 2 * m['branches'] + 2 * m['entry'] + 2 * m['tail'] + m['head'] == total_macs, (m, total_macs)
+    rows = []
+    for name, k in sorted(kernels.items(), key=lambda kv: -kv[1]['us_per_frame']):
+        row = {'kernel': name, 'launches_per_frame': k['launches_per_frame'], 'us_per_frame': round(k['us_per_frame'], 2)}
+        if flops.get(name) and k['us_per_frame'] > 0:
+            gf = 2.0 * flops[name] * N / 1e9
+            row['gflop'] = round(gf, 3)
+            row['tflops'] = round(gf / (k['us_per_frame'] * 1e-6) / 1e3, 2)
+            row['frac_of_mfma_peak'] = round(row['tflops'] / peak_tf, 4)
+        rows.append(row)
+    return rows
+
+
+def report(case, res, steps, warmup, world, args_cpu_frames=0, full=True):
+    c, cfg, st = case.c, case.cfg, case.st
+    h, w, grid = c['h'], c['w'], c['grid']
+    fps = world * steps / res['elapsed']
+    N = h * w
+    peak = ARITH[c['arith']][2]
+    stages = res['stages']
+    out = {'workload': workload_name(c), 'value': fps, 'unit': 'frames/sec', 'ms_per_step': 1e3 * res['elapsed'] / steps,
+           'steps': steps, 'warmup': warmup, 'stages_ms': stages, 'stage_samples_in_timed_region': res['stage_samples'],
+           'stages_ms_all_frames': res['stages_all'], 'stages_all_frames_pass': '%d untimed frames, events on every frame' % res['stages_all_frames'],
+           'net_launches_per_frame': res['launches']}
+    if not full:
+        return out
+    P, T = cfg.FUSION_MODEL.n_points, cfg.FUSION_MODEL.n_tail_points
+    flops = 2.0 * case.pipe._engine.macs_per_pixel * N  # useful flops, channel padding excluded
+    net_s = stages['net'] / 1e3
+    rows = kernel_table(res['kernels'], c, N, peak, case.pipe._engine.macs_per_pixel)
+    out['kernels'] = rows
+    dom = next((r for r in rows if 'tflops' in r), None)
+    tr, tr_src = pmc_traffic(c)
+    net_traffic = hbm_traffic = None
+    if tr:
+        net_k = [k for k in tr if k.startswith(('conv_mfma', 'conv_f16x3', 'chain1x1', 'vortex_tail', 'dense_pair', 'entry1x1'))]
+        net_traffic = sum(tr[k]['fetch_bytes_per_frame_x2'] + tr[k]['write_bytes_per_frame'] for k in net_k)
+        hbm_traffic = sum(tr[k]['fetch_bytes_per_frame_x2'] + tr[k]['write_bytes_per_frame'] for k in tr if 'extract' in k or 'integrate' in k)
+    if dom:
+        per_launch_us = dom['us_per_frame'] / dom['launches_per_frame']
+        dom_traffic = None
+        if tr:
+            key = [k for k in tr if k.startswith(dom['kernel'].split(' ')[0])]
+            if key:
+                dom_traffic = sum(tr[k]['fetch_bytes_per_frame_x2'] + tr[k]['write_bytes_per_frame'] for k in key) / dom['launches_per_frame']
+        out['roofline'] = {'bound': 'mfma', 'kernel': dom['kernel'], 'launches_per_frame': dom['launches_per_frame'],
+                           'avg_launch_us': per_launch_us, 'flops_per_launch': dom['gflop'] * 1e9 / dom['launches_per_frame'],
+                           'achieved': dom['tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': dom['tflops'] / peak,
+                           'traffic': dom_traffic, 'traffic_source': ('replayed from ' + tr_src) if dom_traffic is not None else None,
+                           'note': 'the net kernel with the largest share of the frame (kernels[] lists all): algorithmic '
+                                   '(fp32-equivalent, padding excluded) flops per launch / its launch duration from HIP events behind '
+                                   'every launch on the launch stream (ojf_net_profile); peak = dense MFMA peak of the arithmetic '
+                                   '(f16x3: 2516.6/3 TFLOP/s because every product block costs three fp16 MFMAs; f32: 157.3)'}
+    out['roofline_net'] = {'bound': 'mfma', 'kernel': 'all MFMA launches of the frame', 'achieved': flops / net_s / 1e12, 'peak': peak,
+                           'unit': 'TFLOP/s', 'frac': flops / net_s / 1e12 / peak, 'flops_per_frame': flops,
+                           'frac_of_f32_mfma_peak': flops / net_s / 1e12 / F32_MFMA_PEAK_TF, 'traffic': net_traffic,
+                           'traffic_source': ('replayed from ' + tr_src) if net_traffic is not None else None,
+                           'note': 'useful flops of the whole net / HIP-event time of the net stage inside the timed region'}
+    n_b = len(case.batches)
+    sample = [(warmup + k * max(1, steps // 4)) % n_b for k in range(4)]
+    bytes_frame, ug, us = algorithmic_bytes(st, sample, P, T, c['semantics'])
+    ei_s = (stages['extract'] + stages['integrate']) / 1e3
+    out['roofline_hbm'] = {'bound': 'hbm', 'kernel': 'extract_tile_kernel + integrate_*_kernel',
+                           'achieved': bytes_frame / ei_s / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                           'frac': bytes_frame / ei_s / 1e9 / HBM_PEAK_GBS, 'traffic': hbm_traffic,
+                           'traffic_source': ('replayed from ' + tr_src) if hbm_traffic is not None else None,
+                           'bytes_per_frame': bytes_frame, 'unique_gather_voxels': ug, 'unique_scatter_voxels': us}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -123,11 +344,14 @@ def main():
     ap.add_argument('--semantics', action='store_true', help='BASELINE configs[2]-style: gt labels + semantic head')
     ap.add_argument('--semantic-strategy', default='gt', choices=['gt', 'predict'],
                     help="with --semantics: 'predict' runs AdapNet++ (random init) on every frame")
+    ap.add_argument('--n-classes', type=int, default=30)
     ap.add_argument('--seg-engine', default='hip', choices=['hip', 'torch'],
                     help="AdapNet++ convolutions: 'hip' = SEGCONV MFMA kernels (default), 'torch' = module forward on MIOpen")
     ap.add_argument('--mode', default='fast', choices=['fast', 'parity'])
     ap.add_argument('--arith', default='f16x3', choices=['f16x3', 'f32'], help='net MFMA arithmetic (include/ojf.h OJF_ARITH_*)')
     ap.add_argument('--cpu-frames', type=int, default=4, help='timed frames of the CPU baseline (0 = skip)')
+    ap.add_argument('--secondary', type=int, default=None,
+                    help='steps of each secondary workload (default: 60 when the headline runs with default flags on 1 GPU, else 0)')
     ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL, default) | gloo (validation of the N>1 path on a 1-GPU box)')
     args = ap.parse_args()
 
@@ -148,103 +372,62 @@ def main():
         else:
             dist.init_process_group(args.dist_backend)
 
-    h, w, grid = args.height, args.width, args.grid
-    cfg = default_config(h, w, semantics=args.semantics, integrate_mode=args.mode)
-    cfg.SETTINGS.device = str(dev)
-    cfg.FUSION_MODEL.arithmetic = args.arith
-    if args.semantics:
-        cfg.DATA.semantic_strategy = args.semantic_strategy
-        cfg.SEMANTIC_2D_MODEL.engine = args.seg_engine
-    n_frames = args.steps + args.warmup
-    st = SyntheticStream(h, w, grid, n_frames, scene='room_%d' % rank, seed=1911 + rank)
-    db = Database(st, database_config(cfg))
-    pipe = Pipeline(cfg)
-    seeded_weights(pipe)
-    pipe = pipe.to(dev).eval()
-    pipe.profile = 8  # stage events on every 8th frame of the timed region: a record is a marker packet (~4.5 us of idle queue)
-
-    # frames resident in HBM before the clock starts; poses and ids stay host-side metadata
-    batches = []
-    image = torch.zeros((1, 3, h, w), device=dev)  # only its shape is read on this path
-    predict = args.semantics and args.semantic_strategy == 'predict'
-    for i in range(n_frames):
-        f = st.frame(i)
-        b = {'image': torch.from_numpy(f['image']).unsqueeze(0).to(dev) if predict else image, 'frame_id': [f['frame_id']],
-             st.depth_key: torch.from_numpy(f[st.depth_key]).unsqueeze(0).to(dev),
-             'mask': torch.from_numpy(f['mask']).unsqueeze(0).to(dev),
-             'extrinsics': torch.from_numpy(f['extrinsics']).unsqueeze(0),
-             'intrinsics': torch.from_numpy(f['intrinsics']).unsqueeze(0)}
-        if args.semantics:
-            b['semantic_gt'] = torch.from_numpy(f['semantic_gt']).unsqueeze(0).to(dev)
-        batches.append(b)
-
     def sync():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
-    with torch.no_grad():
-        for i in range(args.warmup):
-            pipe.fuse(batches[i], db, dev)
-        pipe.reset_profile()
-        sync()
-        t0 = time.perf_counter()
-        for i in range(args.warmup, n_frames):
-            pipe.fuse(batches[i], db, dev)
-        sync()
-        elapsed = time.perf_counter() - t0
-    pipe.check()  # outside the timed region: raises if the split-fp16 range guard fired on any frame
-
+    head = dict(h=args.height, w=args.width, grid=args.grid, semantics=args.semantics, strategy=args.semantic_strategy,
+                seg_engine=args.seg_engine, mode=args.mode, arith=args.arith, n_classes=args.n_classes)
+    default_flags = head == dict(h=240, w=320, grid=256, semantics=False, strategy='gt', seg_engine='hip', mode='fast',
+                                 arith='f16x3', n_classes=30)
+    case = Case(head, dev, rank, args.steps + args.warmup)
+    res = case.run(args.steps, args.warmup, sync)
+    elapsed = res['elapsed']
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == 'nccl' else 'cpu')
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    stages = pipe.stage_times_ms()  # live HIP events recorded on the launch stream inside the timed region
+        res['elapsed'] = float(t.item())
 
     if rank == 0:
-        fps = world * args.steps / elapsed
-        P, T = cfg.FUSION_MODEL.n_points, cfg.FUSION_MODEL.n_tail_points
-        N = h * w
-        flops = 2.0 * pipe._engine.macs_per_pixel * N  # useful flops, channel padding excluded
-        net_s = stages['net'] / 1e3
-        n_conv = pipe._engine.conv_launches
-        sample = list(range(args.warmup, n_frames, max(1, args.steps // 4)))[:4]
-        bytes_frame, ug, us = algorithmic_bytes(st, sample, P, T, args.semantics)
-        ei_s = (stages['extract'] + stages['integrate']) / 1e3
-        tr = pmc_traffic(h, w, grid, args.semantics)
-        net_traffic = hbm_traffic = None
-        if tr:
-            net_k = [k for k in tr if k.startswith(('conv_mfma', 'conv_f16x3', 'chain1x1', 'vortex_tail'))]
-            net_traffic = sum(tr[k]['fetch_bytes_per_frame_x2'] + tr[k]['write_bytes_per_frame'] for k in net_k) / n_conv
-            hbm_traffic = sum(tr[k]['fetch_bytes_per_frame_x2'] + tr[k]['write_bytes_per_frame']
-                              for k in tr if 'extract' in k or 'integrate' in k)
+        r = report(case, res, args.steps, args.warmup, world)
+        cfg = case.cfg
         out = {
-            'metric': 'frames/sec fused (%dx%d, %d^3 grid)' % (w, h, grid), 'value': fps, 'unit': 'frames/sec',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'metric': 'frames/sec fused (%dx%d, %d^3 grid)' % (args.width, args.height, args.grid), 'value': r['value'], 'unit': 'frames/sec',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': r['ms_per_step'],
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': ARITH[args.arith][0], 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: geometry-only fusion, %dx%d depth into a %d^3 fp16 TSDF grid, '
-                                   'FusionNet_v3%s, one scene per GPU' % (w, h, grid, (' + %s semantics' % ('AdapNet++ (predict, %s convolutions)' % args.seg_engine if predict else 'gt')) if args.semantics else ''),
-                       'frame': [h, w], 'grid': grid, 'n_points': P, 'n_tail_points': T, 'integrate_mode': args.mode,
-                       'volume_dtype': 'f16', 'net_arithmetic': ARITH[args.arith][1], 'parallelism': 'scene-sharded x%d' % world},
-            'stages_ms': stages,
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_f16x3_kernel' if args.arith == 'f16x3' else 'conv_mfma_kernel',
-                         'launches_per_frame': n_conv,
-                         'achieved': flops / net_s / 1e12, 'peak': ARITH[args.arith][2], 'unit': 'TFLOP/s',
-                         'frac': flops / net_s / 1e12 / ARITH[args.arith][2], 'traffic': net_traffic,
-                         'flops_per_frame': flops, 'avg_launch_us': 1e6 * net_s / n_conv,
-                         'frac_of_f32_mfma_peak': flops / net_s / 1e12 / F32_MFMA_PEAK_TF,
-                         'note': 'useful (fp32-equivalent, padding excluded) flops of all MFMA launches of one frame / HIP-event '
-                                 'time of the net stage; peak = dense MFMA peak of the arithmetic (f16x3: 2516.6/3 TFLOP/s because '
-                                 'every product block costs three fp16 MFMAs; f32: 157.3); traffic = PMC HBM bytes per launch '
-                                 '(profiles/r01_traffic_pmc.json)'},
-            'roofline_hbm': {'bound': 'hbm', 'kernel': 'extract_kernel + integrate_*_kernel',
-                             'achieved': bytes_frame / ei_s / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                             'frac': bytes_frame / ei_s / 1e9 / HBM_PEAK_GBS, 'traffic': hbm_traffic,
-                             'bytes_per_frame': bytes_frame, 'unique_gather_voxels': ug, 'unique_scatter_voxels': us},
+            'config': {'workload': r['workload'], 'frame': [args.height, args.width], 'grid': args.grid,
+                       'n_points': cfg.FUSION_MODEL.n_points, 'n_tail_points': cfg.FUSION_MODEL.n_tail_points,
+                       'integrate_mode': args.mode, 'volume_dtype': 'f16', 'net_arithmetic': ARITH[args.arith][1],
+                       'parallelism': 'scene-sharded x%d' % world},
         }
+        for k in ('stages_ms', 'stage_samples_in_timed_region', 'stages_ms_all_frames', 'stages_all_frames_pass', 'net_launches_per_frame',
+                  'kernels', 'roofline', 'roofline_net', 'roofline_hbm'):
+            if k in r:
+                out[k] = r[k]
+        del case
+        torch.cuda.empty_cache()
+        n_sec = args.secondary if args.secondary is not None else (60 if (world == 1 and default_flags) else 0)
+        if world == 1 and n_sec > 0:
+            secondary = []
+            for extra in (dict(arith='f32'),
+                          dict(semantics=True),
+                          dict(semantics=True, strategy='predict'),
+                          dict(h=480, w=640, grid=512),
+                          dict(h=480, w=640, grid=512, semantics=True, n_classes=40)):
+                c2 = dict(head, **extra)
+                try:
+                    case2 = Case(c2, dev, rank, n_sec + 10)
+                    r2 = report(case2, case2.run(n_sec, 10, sync, profile_frames=16), n_sec, 10, 1, full=False)
+                    del case2
+                except Exception as e:  # a secondary workload must not take the headline line down with it
+                    r2 = {'workload': workload_name(c2), 'error': repr(e)}
+                torch.cuda.empty_cache()
+                secondary.append(r2)
+            out['secondary'] = secondary
         if world == 1 and args.cpu_frames > 0:
-            out['cpu_baseline'] = cpu_baseline(args, h, w, grid, args.semantics)
-            out['speedup_vs_cpu_baseline'] = fps / out['cpu_baseline']['value']
+            out['cpu_baseline'] = cpu_baseline(args, args.height, args.width, args.grid, args.semantics)
+            out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

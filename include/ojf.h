@@ -147,6 +147,14 @@ int ojf_net_prepare_input(ojf_net *net, const float *values_dev, const float *we
 int ojf_net_forward(ojf_net *net, float *est_dev, int est_stride, ojf_stream_t stream);
 /* useful multiply-accumulates per pixel of this topology (padding excluded) */
 int64_t ojf_net_macs_per_pixel(const ojf_net *net);
+/* Kernel launches of the most recent ojf_net_forward on this net (all streams; 0 before the first call). */
+int ojf_net_launch_count(const ojf_net *net);
+/* Profiling run of one forward pass (same launches as ojf_net_forward, plus one fence-free HIP event behind every
+ * launch): kernel names ('\n'-separated, in launch order) into `names` and each launch's duration in microseconds as
+ * its stream saw it (time since the previous launch of that stream completed) into `micros`.  Synchronises the
+ * stream.  Returns the number of entries (<= max_entries) or < 0.  For bench.py's per-kernel table; not a hot path. */
+int ojf_net_profile(ojf_net *net, float *est_dev, int est_stride, ojf_stream_t stream, char *names, int names_cap,
+                    float *micros, int max_entries);
 /* Arithmetic used by nets created (and ojf_conv2d calls made) AFTER this call: OJF_ARITH_F32 | OJF_ARITH_F16X3.
  * A net keeps the arithmetic it was created with.  Not thread-safe against concurrent ojf_net_create. */
 int ojf_net_set_arithmetic(int arithmetic);

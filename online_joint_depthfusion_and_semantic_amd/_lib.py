@@ -51,6 +51,8 @@ SIGNATURES = {
     'ojf_net_prepare_input': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp]),
     'ojf_net_forward': (_i, [_vp, _vp, _i, _vp]),
     'ojf_net_macs_per_pixel': (_c.c_int64, [_vp]),
+    'ojf_net_launch_count': (_i, [_vp]),
+    'ojf_net_profile': (_i, [_vp, _vp, _i, _vp, _c.c_char_p, _i, _c.POINTER(_f), _i]),
     'ojf_net_set_arithmetic': (_i, [_i]),
     'ojf_net_get_arithmetic': (_i, [_vp]),
     'ojf_net_check': (_i, [_vp]),

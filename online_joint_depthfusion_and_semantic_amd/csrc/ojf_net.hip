@@ -49,6 +49,7 @@
 // OJF_CONV_MT, OJF_NO_TAIL, OJF_NO_CHAIN, OJF_NO_HEAD_FUSION, OJF_NET_GRAPH=1 (opt-in hipGraph replay).
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "ojf_common.h"
@@ -1255,6 +1256,24 @@ static int *overflow_flag()
 
 int *range_flag_device() { return overflow_flag(); }  // shared with ojf_seg.hip
 
+// Launch log of a forward pass: every launch site calls mark_launch(name, stream) right after its launch.  It counts the
+// launches (ojf_net_launch_count) and, in profile mode (ojf_net_profile), records a fence-free timing event behind the
+// launch, so that the time between consecutive marks of one stream is that kernel's duration as the stream sees it.
+struct LaunchMark { const char *name; hipStream_t st; hipEvent_t ev; };
+static thread_local int g_launches = 0;
+static thread_local bool g_profile = false;
+static thread_local std::vector<LaunchMark> g_marks;
+
+static inline void mark_launch(const char *name, hipStream_t st)
+{
+    ++g_launches;
+    if (!g_profile) return;
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) return;
+    (void)hipEventRecord(e, st);
+    g_marks.push_back(LaunchMark{name, st, e});
+}
+
 // Fork / join events between streams of the same device: no timing, and (OJF_EVENT_FENCE=1 restores it) no system-scope
 // fence - nothing here is read by the host or another device through these events.
 static unsigned event_flags()
@@ -1475,6 +1494,7 @@ static int launch_pair_t(PairArgs &a, hipStream_t st)
     a.tiles_x = (a.w + TW - 1) / TW;
     const int tiles = a.tiles_x * ((a.h + TH - 1) / TH);
     hipLaunchKernelGGL((dense_pair_kernel<TW, TH>), dim3(tiles), dim3(G::THREADS), G::LDS_BYTES, st, a);
+    mark_launch("dense_pair_kernel", st);
     return check_hip(hipGetLastError(), "dense_pair_kernel launch");
 }
 
@@ -1547,6 +1567,7 @@ static int launch_conv_args(const ConvArgs *args, int n, int nt, hipStream_t st,
     }
 #undef OJF_LAUNCH32
 #undef OJF_LAUNCH16
+    mark_launch(arith == OJF_ARITH_F16X3 ? (n > 1 ? "conv_f16x3_kernel (grouped)" : "conv_f16x3_kernel") : "conv_mfma_kernel", st);
     return check_hip(hipGetLastError(), "conv kernel launch");
 }
 
@@ -1663,6 +1684,7 @@ struct ojf_net {
     int pool_in, os;  // (gf+1)*c and its padded slot
     float scale;
     int64_t macs_per_pixel;
+    int last_launches = 0;  // kernel launches of the most recent ojf_net_forward (all streams)
     std::vector<ojf::PackedConv> dense[2];  // block0 / block2 (or v2's block): 2*gf convs each
     std::vector<ojf::PackedPair> pairs[2];  // split-fp16: the same layers packed for dense_pair_kernel (one launch per Block)
     ojf::Vortex vortex[3];                  // v3: vortex0, vortex2, vortex3 ; v2: vortex, -, vortex_final
@@ -1863,8 +1885,10 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
         OJF_HIP(hipStreamWaitEvent(sc.side, sc.ev_fork, 0));
         hipLaunchKernelGGL(colsum_kernel, dim3(kSumBlocks, v.c_in_phys / 4), dim3(256), 0, sc.side, planes(in), in_g0,
                            net->npix, sc.partial);
+        mark_launch("colsum_kernel", sc.side);
         OJF_HIP(hipGetLastError());
         hipLaunchKernelGGL(gave_bias_kernel, dim3(1), dim3(256), 0, sc.side, gave_args(net, v, sc.partial, kSumBlocks, 256));
+        mark_launch("gave_bias_kernel", sc.side);
         OJF_HIP(hipGetLastError());
         // branch entries: one GEMM, branch 0 gets bias + ReLU in the epilogue
         if (launch_conv(v.stacked, in, in_g0, sc.Z, 0, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w, st)) return -2;
@@ -1878,6 +1902,7 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
         const dim3 grid(chain_blocks(net)), block(256);
         if (h16) hipLaunchKernelGGL((entry1x1_kernel<OJF_ARITH_F16X3, 1, 8, 5>), grid, block, 0, st, ea);
         else hipLaunchKernelGGL((entry1x1_kernel<OJF_ARITH_F32, 1, 8, 5>), grid, block, 0, st, ea);
+        mark_launch("entry1x1_kernel", st);
         OJF_HIP(hipGetLastError());
     }
     {   // pool pyramid on the pre-activations of branches 1..3: Q_b = ReLU(pool^b(Z[slot b]) + bias_b), one launch
@@ -1889,6 +1914,7 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
         pa.tiles = ((w + kPoolTW - 1) / kPoolTW) * ((h + kPoolTH - 1) / kPoolTH);
         pa.gave = gave_args(net, v, nullptr, 0, 0, sc.colsum);
         hipLaunchKernelGGL(pool_pyramid_kernel, dim3(pa.tiles + (chain_flow ? 1 : 0), 3 * c4), dim3(256), 0, st, pa);
+        mark_launch("pool_pyramid_kernel", st);
         OJF_HIP(hipGetLastError());
     }
     const float *bin[4] = {sc.Z, sc.Q1, sc.Q2, sc.Q3};
@@ -1942,6 +1968,7 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
         else if (net->chain_kind == 19) hipLaunchKernelGGL((vortex_tail_kernel<OJF_ARITH_F32, 1, 2, 8, 19>), grid, block, 0, st, ta);
         else if (h16) hipLaunchKernelGGL((vortex_tail_kernel<OJF_ARITH_F16X3, 1, 2, 8, 20>), grid, block, 0, st, ta);
         else hipLaunchKernelGGL((vortex_tail_kernel<OJF_ARITH_F32, 1, 2, 8, 20>), grid, block, 0, st, ta);
+        mark_launch("vortex_tail_kernel (+ prediction head)", st);
         if (head_done) *head_done = true;
     } else if (chain_flow && next && next->entry_w && next->tail_w && next->c_in_phys == net->os && !legacy_env && !no_entry_fusion) {
         // this VortexPooling feeds the next one: its entry GEMM and column sums ride along, `out` is never written
@@ -1949,11 +1976,14 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
         ta.entry_og = 4 * c4; ta.entry_act_n = net->cs; ta.colsum = sc.colsum;
         if (h16) hipLaunchKernelGGL((vortex_tail_kernel<OJF_ARITH_F16X3, 1, 2, 8, kTailEntry>), grid, block, 0, st, ta);
         else hipLaunchKernelGGL((vortex_tail_kernel<OJF_ARITH_F32, 1, 2, 8, kTailEntry>), grid, block, 0, st, ta);
+        mark_launch("vortex_tail_kernel (+ next entry GEMM)", st);
         if (next_done) *next_done = true;
     } else if (h16) {
         hipLaunchKernelGGL((vortex_tail_kernel<OJF_ARITH_F16X3, 1, 2, 8>), grid, block, 0, st, ta);
+        mark_launch("vortex_tail_kernel", st);
     } else {
         hipLaunchKernelGGL((vortex_tail_kernel<OJF_ARITH_F32, 1, 2, 8>), grid, block, 0, st, ta);
+        mark_launch("vortex_tail_kernel", st);
     }
     return check_hip(hipGetLastError(), "vortex_tail_kernel launch");
 }
@@ -2264,6 +2294,7 @@ static int forward_launches(ojf_net *net, float *est, int est_stride, hipStream_
             hipLaunchKernelGGL((chain1x1_kernel<OJF_ARITH_F16X3, 1, 8, 7, 7, 5, 5, 4, 4, 3, 3, 2, 2, 1>), grid, block, 0, st, ca);
         else
             hipLaunchKernelGGL((chain1x1_kernel<OJF_ARITH_F32, 1, 8, 7, 7, 5, 5, 4, 4, 3, 3, 2, 2, 1>), grid, block, 0, st, ca);
+        mark_launch("chain1x1_kernel", st);
         return check_hip(hipGetLastError(), "chain1x1_kernel launch");
     }
     const float *pin = net->Y3;
@@ -2333,10 +2364,56 @@ OJF_API int ojf_net_forward(ojf_net *net, float *est, int est_stride, ojf_stream
         if (!net->gexec || net->g_est != est || net->g_stride != est_stride) capture_graph(net, est, est_stride);
         if (net->gexec) return check_hip(hipGraphLaunch(net->gexec, st), "hipGraphLaunch (net forward)");
     }
-    return forward_launches(net, est, est_stride, st);
+    const int before = g_launches;
+    const int rc = forward_launches(net, est, est_stride, st);
+    net->last_launches = g_launches - before;
+    return rc;
 }
 
 OJF_API int64_t ojf_net_macs_per_pixel(const ojf_net *net) { return net ? net->macs_per_pixel : -1; }
+
+OJF_API int ojf_net_launch_count(const ojf_net *net) { return net ? net->last_launches : -1; }
+
+OJF_API int ojf_net_profile(ojf_net *net, float *est, int est_stride, ojf_stream_t stream, char *names, int names_cap,
+                            float *micros, int max_entries)
+{
+    using namespace ojf;
+    if (!net || !est || !names || !micros || names_cap < 1 || max_entries < 1) return fail("ojf_net_profile: bad argument");
+    hipStream_t st = as_stream(stream);
+    hipEvent_t e0 = nullptr;
+    OJF_HIP(hipEventCreateWithFlags(&e0, hipEventDisableSystemFence));
+    g_marks.clear();
+    g_profile = true;
+    (void)hipEventRecord(e0, st);
+    const int rc = forward_launches(net, est, est_stride, st);
+    g_profile = false;
+    int n = 0;
+    size_t used = 0;
+    names[0] = 0;
+    if (!rc && hipStreamSynchronize(st) == hipSuccess) {
+        for (size_t i = 0; i < g_marks.size() && n < max_entries; ++i) {
+            // previous mark on the same stream (the start mark for the first launch of the caller's stream)
+            hipEvent_t prev = nullptr;
+            for (size_t j = i; j-- > 0;)
+                if (g_marks[j].st == g_marks[i].st) { prev = g_marks[j].ev; break; }
+            if (!prev && g_marks[i].st == st) prev = e0;
+            float ms = 0.0f;
+            (void)hipEventSynchronize(g_marks[i].ev);
+            if (!prev || hipEventElapsedTime(&ms, prev, g_marks[i].ev) != hipSuccess) ms = -1e-3f;  // first launch of a side stream
+            const size_t len = strlen(g_marks[i].name);
+            if (used + len + 2 > (size_t)names_cap) break;
+            memcpy(names + used, g_marks[i].name, len);
+            names[used + len] = '\n';
+            used += len + 1;
+            names[used] = 0;
+            micros[n++] = ms * 1e3f;
+        }
+    }
+    for (auto &m : g_marks) (void)hipEventDestroy(m.ev);
+    g_marks.clear();
+    (void)hipEventDestroy(e0);
+    return rc ? rc : n;
+}
 
 OJF_API int ojf_net_set_arithmetic(int arithmetic)
 {

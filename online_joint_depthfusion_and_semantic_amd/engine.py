@@ -56,11 +56,6 @@ class FusionNetEngine:
         _lib.check(rc, 'ojf_net_create')
         self.handle = handle
         self.macs_per_pixel = int(self.lib.ojf_net_macs_per_pixel(self.handle))
-        heads = 2 if (version == 3 and self.use_semantics) else 1
-        n_vortex = heads + 1 if version == 3 else 2
-        # MFMA launches per forward: 2 per dense block; per VortexPooling 1 stacked entry conv + 2 grouped
-        # launches (the four branches' dilated 3x3 pairs) + 1 fused tail (the last one also runs the prediction head)
-        self.conv_launches = 2 * net.gf * heads + 4 * n_vortex
 
     def prepare_input(self, values, weights, depth, sem_ids=None, n_classes=0, planes=False):
         """values / weights: cuda f32 from the extractor, rows [h*w, stride] or (planes=True) sample planes
@@ -82,6 +77,20 @@ class FusionNetEngine:
         rc = self.lib.ojf_net_forward(self.handle, _lib.ptr(est), est.shape[-1], _lib.stream_ptr(self.device))
         _lib.check(rc, 'ojf_net_forward')
         return est
+
+    @property
+    def launches(self):
+        """Kernel launches of the most recent forward (counted by the library at its launch sites)."""
+        return int(self.lib.ojf_net_launch_count(self.handle))
+
+    def profile(self, est):
+        """One profiled forward: [(kernel name, microseconds)] in launch order (ojf_net_profile)."""
+        names = ctypes.create_string_buffer(8192)
+        us = (ctypes.c_float * 256)()
+        n = self.lib.ojf_net_profile(self.handle, _lib.ptr(est), est.shape[-1], _lib.stream_ptr(self.device), names, 8192, us, 256)
+        if n < 0:
+            _lib.check(n, 'ojf_net_profile')
+        return list(zip(names.value.decode().split('\n')[:n], [float(us[i]) for i in range(n)]))
 
     def check(self):
         """Synchronise the stream and raise OjfError if the split-fp16 range guard fired (include/ojf.h)."""
