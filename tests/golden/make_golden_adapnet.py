@@ -118,3 +118,50 @@ with torch.no_grad():
         print(tag, [tuple(o.shape) for o in outs], 'max |logit| %.3f' % float(outs[0].abs().max()))
 np.savez_compressed(os.path.join(HERE, 'adapnet_net.npz'), **net_out)
 print('written', os.path.join(HERE, 'adapnet_net.npz'))
+
+
+# ---- semantic_strategy 'predict' end to end: the reference's Pipeline.fuse with its own AdapNet in front ------------
+# (modules/pipeline.py:42-60,181-185: image / 255, depth replicated to three channels, softmax, max over classes).  The
+# backbone is the same stand-in as above; dropout flags off (the reference leaves its ResNet dropout ON at inference,
+# adapnet.py:80-82 - that randomness cannot be pinned); fusion-net weights = the seeded state of make_golden.py.
+def predict_pipeline(h=64, w=96, grid=32, frames=2, n_classes=12):
+    import importlib
+    mg = importlib.import_module('make_golden')  # same directory; brings RefPipeline, DuckDatabase, seeded_state
+    from online_joint_depthfusion_and_semantic_amd.synthetic import SyntheticStream, gt_volumes
+    cfg = mg.ref_config(h, w, True, True)
+    cfg.DATA.semantic_strategy = 'predict'
+    cfg.SEMANTIC_2D_MODEL = mg.NS(stage=2, n_classes=n_classes)
+    import modules.pipeline as ref_pipeline
+    ref_pipeline.AdapNet = ref.AdapNet  # the class object whose resnet50 name was redirected to the stand-in above
+    pipe = mg.RefPipeline(cfg)
+    mg.seeded_state(pipe._fusion_network, 11)
+    randomise_net(pipe._semantic_2d_network, 31)
+    pipe.eval()
+    small = np.load(os.path.join(HERE, 'pipeline_v3_sem_24x32_g32.npz'))
+    for k, v in pipe._fusion_network.state_dict().items():
+        assert np.array_equal(v.numpy(), small['state_' + k]), k
+    st = SyntheticStream(h, w, grid, 20, n_classes=n_classes)
+    gt, _ = gt_volumes(grid, n_classes=n_classes)
+    db = mg.DuckDatabase(st, True, gt)
+    s = st.scene
+    out = {'keys': np.array(list(pipe._semantic_2d_network.state_dict().keys()))}
+    with torch.no_grad():
+        for i in range(frames):
+            b = st.batch(i)
+            pipe.device = torch.device('cpu')
+            hist = pipe._segmentation({k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()})
+            scores, ids = hist.max(dim=-1)
+            out['f%d_seg_scores' % i], out['f%d_seg_ids' % i] = scores[0].numpy(), ids[0].numpy().astype(np.uint8)
+            srt = torch.sort(hist[0], dim=-1, descending=True)[0]
+            out['f%d_seg_margin' % i] = (srt[..., 0] - srt[..., 1]).numpy()  # top-1 minus top-2 probability
+            pipe.fuse(b, db, torch.device('cpu'))
+            for k, v in (('tsdf', db.scenes_est[s].volume), ('wgt', db.fusion_weights[s]), ('ids', db.ids_est[s].volume),
+                         ('scores', db.scores[s].volume)):
+                out['f%d_%s' % (i, k)] = v.numpy().copy()
+    return out
+
+
+if '--no-predict' not in sys.argv:
+    sys.path.insert(0, HERE)
+    np.savez_compressed(os.path.join(HERE, 'pipeline_predict_64x96_g32.npz'), **predict_pipeline())
+    print('written', os.path.join(HERE, 'pipeline_predict_64x96_g32.npz'))
