@@ -201,6 +201,25 @@ int ojf_segconv_forward(const ojf_segconv *conv, const float *in_dev, int in_str
                         const float *res_dev, int res_stride, const float *mul_dev, int mul_stride, int act, int h,
                         int w, ojf_stream_t stream);
 
+/* ---- AdapNet++ front end: the operators around the convolutions (csrc/ojf_seg_ops.hip) --------------------
+ * NHWC fp32 rows of batch 1 like ojf_segconv_forward (pointer to channel 0 of pixel 0 + floats per pixel row).
+ * ojf_seg_pack_input: modules/pipeline.py:44,50 - three source planes (src[c * chan_stride + p]; chan_stride 0 =
+ *   the depth map replicated to three channels) divided by `divisor` (255 for the colour image, 1 for depth) into the
+ *   8-channel rows the stem convolution reads (channels 3..7 zero).
+ * ojf_seg_maxpool: nn.MaxPool2d(3, 2, 1) of the ResNet stem (modules/adapnet.py:101, torchvision layout).
+ * ojf_seg_mean: mean over the pixels per channel (eASPP branch 5 :204-208, Decoder._skip :292-296) -> out[c].
+ * ojf_seg_broadcast: out[p][c] = vec[c] (* mul[p][c]): the bilinear upsampling of a 1x1 map / the gated skip.
+ * ojf_seg_softmax_max: pipeline.py:57,183 softmax over the classes then max: scores f32[npix], ids u8[npix]. */
+int ojf_seg_pack_input(const float *src_dev, int chan_stride, float divisor, int h, int w, float *out_dev, int out_stride,
+                       ojf_stream_t stream);
+int ojf_seg_maxpool(const float *in_dev, int in_stride, int c, int h, int w, float *out_dev, int out_stride, ojf_stream_t stream);
+int ojf_seg_mean(const float *in_dev, int in_stride, int c, int npix, float *partial_dev /* 32 * c floats of scratch */,
+                 float *out_dev, ojf_stream_t stream);
+int ojf_seg_broadcast(const float *vec_dev, const float *mul_dev, int mul_stride, int c, int npix, float *out_dev, int out_stride,
+                      ojf_stream_t stream);
+int ojf_seg_softmax_max(const float *logits_dev, int stride, int n_classes, int npix, float *scores_dev, uint8_t *ids_dev,
+                        ojf_stream_t stream);
+
 /* ---- VOLUME HELPERS (Database) -------------------------------------------------------------
  * ojf_volume_fill_*: Database.reset (modules/database.py:351-370).
  * ojf_volume_filter: Database.filter (:108-112): where weights < value: tsdf = init_value, weights = 0.

@@ -67,6 +67,11 @@ SIGNATURES = {
     'ojf_segdeconv_create': (_i, [_c.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i]),
     'ojf_segconv_destroy': (None, [_vp]),
     'ojf_segconv_forward': (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    'ojf_seg_pack_input': (_i, [_vp, _i, _f, _i, _i, _vp, _i, _vp]),
+    'ojf_seg_maxpool': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    'ojf_seg_mean': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    'ojf_seg_broadcast': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp]),
+    'ojf_seg_softmax_max': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     'ojf_points_within': (_i, [_vp, _sz, _vp, _vp, _vp, _d, _i, _i, _i, _d, _vp, _vp, _vp]),
     'ojf_mesh_workspace_bytes': (_sz, [_i, _i, _i]),
     'ojf_mesh_extract': (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _d, _vp, _sz, _vp, _vp, _vp, _c.c_uint32, _vp, _vp]),

@@ -5,9 +5,11 @@ state_dict), prepacks every ``Conv2d`` together with the eval-mode ``BatchNorm2d
 forward pass of ``AdapNet.forward`` (adapnet.py:390-415) for inference: activations stay NHWC (torch channels_last)
 fp32, every convolution + BN + residual + ReLU / sigmoid(+gate) is ONE HIP launch, concatenations are written in
 place through channel slices, the three transposed convolutions of the decoder run on the same kernel (phase
-expansion + pixel-shuffle store: deterministic, unlike MIOpen's atomics).  What remains on torch ops: max-pool, the
-global average pools, the always-on dropout quirk of the multi-scale units (adapnet.py:80-82) and the final softmax.  The auxiliary heads (adapnet.py:299-305) do not feed the result
-and are skipped.  ~772 launches of the torch forward become ~165.
+expansion + pixel-shuffle store: deterministic, unlike MIOpen's atomics).  Input packing (image / 255, depth x 3),
+the stem's max-pool, the global average pools with their broadcasts / gates and the final softmax + max are libojf
+launches too (csrc/ojf_seg_ops.hip); the only torch op left is the reference's always-on dropout quirk of the
+multi-scale units (adapnet.py:80-82: its random stream IS torch's), off under ``no_resn50_dropout``.  The auxiliary
+heads (adapnet.py:299-305) do not feed the result and are skipped.  ~772 launches of the torch forward become ~165.
 
 The engine snapshots the weights: build it after ``load_state_dict`` (``Pipeline`` rebuilds it when the
 parameters change).  No fallback path: it needs libojf and a GPU.
@@ -15,6 +17,7 @@ parameters change).  No fallback path: it needs libojf and a GPU.
 import torch
 import torch.nn.functional as F
 
+from . import segconv
 from .segconv import SegConv, SegDeconv, nhwc
 
 
@@ -55,11 +58,11 @@ class _Encoder:
         self.skip1 = SegConv(m.enc_skip1_conv, m.enc_skip1_conv_bn)
 
     def __call__(self, image, skip2_out, skip1_out):
-        """image [1,3,H,W] (any layout).  The two skip tensors are written into the given NHWC slices."""
-        x = nhwc(8, image.shape[2], image.shape[3], image.device)  # stem reads groups of 8 channels: 3 + 5 zeros
-        x[:, :3] = image
+        """image: the stem's packed rows (segconv.pack_input: [1,8,H,W] NHWC, 3 channels + 5 zeros) or a plain
+        [1,3,H,W] tensor.  The two skip tensors are written into the given NHWC slices."""
+        x = image if image.shape[1] == 8 else segconv.pack_input(image.contiguous())
         x = self.stem(x[:, :3], act='relu')
-        x = F.max_pool2d(x, 3, stride=2, padding=1).contiguous(memory_format=torch.channels_last)
+        x = segconv.maxpool(x)
         for u in self.layers[0]:
             x = u(x)
         self.skip2(x, out=skip2_out)
@@ -89,8 +92,7 @@ class _EASPP:
             for c in convs[:-1]:
                 y = c(y, act='relu')
             convs[-1](y, out=cat[:, (i + 1) * n:(i + 2) * n], act='relu')
-        pooled = x.mean(dim=(2, 3), keepdim=True).contiguous(memory_format=torch.channels_last)
-        cat[:, 4 * n:] = self.b5(pooled, act='relu')  # bilinear upsampling of a 1x1 map = broadcast
+        segconv.broadcast(self.b5(segconv.mean(x), act='relu'), cat[:, 4 * n:])  # bilinear upsampling of a 1x1 map = broadcast
         return self.fin(cat, out=out, act='relu')
 
 
@@ -131,8 +133,7 @@ class SegEngine:
         if not self.fusion:
             out.copy_(skip)
             return
-        pooled = x.mean(dim=(2, 3), keepdim=True).contiguous(memory_format=torch.channels_last)
-        torch.mul(conv(pooled, act='relu'), skip, out=out)
+        segconv.broadcast(conv(segconv.mean(x), act='relu'), out, mul=skip)
 
     def forward(self, mod1, mod2=None):
         """Logits [1, n_classes, H, W] (channels_last memory) = AdapNet.forward(...)[0]."""
@@ -157,6 +158,9 @@ class SegEngine:
             if side is None or side.device != dev:
                 side = self.__dict__['_side'] = torch.cuda.Stream(device=dev)
             side.wait_stream(main)
+            if not torch.cuda.is_current_stream_capturing():  # (inside a capture the fork / join are graph edges)
+                for t in (mod2, s2, s1, top):  # allocated on the main stream, used on the side stream
+                    t.record_stream(side)
             with torch.cuda.stream(side):
                 x2 = self.enc2(mod2, s2[:, 24:], s1[:, 24:])
                 self.aspp2(x2, top[:, 256:])
@@ -180,3 +184,15 @@ class SegEngine:
         return self.deconv3(y)
 
     __call__ = forward
+
+    def predict(self, image, depth=None):
+        """Pipeline._segmentation(...).max(-1) (modules/pipeline.py:42-60,183): raw batch tensors in - ``image`` [1,3,H,W]
+        as the dataset hands it over (divided by 255 here, pipeline.py:44), ``depth`` [1,H,W] / [1,1,H,W] replicated to three
+        channels (:50) - per-pixel (scores f32 [H*W], ids u8 [H*W]) out.  Every step is a libojf launch."""
+        if self.fusion:
+            logits = self.forward(segconv.pack_input(image.contiguous(), 255.0), segconv.pack_input(depth.contiguous(), 1.0))
+        elif depth is not None:  # stage 1 nets see the DATA.input modality only (pipeline.py:52-53)
+            logits = self.forward(segconv.pack_input(depth.contiguous(), 1.0))
+        else:
+            logits = self.forward(segconv.pack_input(image.contiguous(), 255.0))
+        return segconv.softmax_max(logits)

@@ -142,6 +142,19 @@ class Pipeline(torch.nn.Module):
         logits = output if torch.is_tensor(output) else output[0]  # the engine returns the main head only
         return torch.softmax(logits, dim=1).permute(0, 2, 3, 1)
 
+    def _segment_max(self, data):
+        """``_segmentation(data).max(dim=-1)`` -> (scores, ids).  With the HIP engine the whole chain - image / 255,
+        depth x 3, AdapNet++, softmax, max - is libojf launches (SegEngine.predict); ids come back as uint8."""
+        image = data['image']
+        engine = self._seg_engine(image.shape)
+        if engine is None:
+            return self._segmentation(data).max(dim=-1)
+        in_ = self.config.DATA.input
+        depth = data[in_].to(self.device).float() if in_ != 'image' else None
+        h, w = image.shape[-2:]
+        scores, ids = engine.predict(image.to(self.device).float(), depth)
+        return scores.view(1, h, w), ids.view(1, h, w)
+
     def _seg_engine(self, shape):
         """The AdapNet++ convolutions on the SEGCONV HIP kernels (adapnet_engine.SegEngine) when the front-end runs
         inference on the GPU: ``SEMANTIC_2D_MODEL.engine: hip`` (default) | ``torch`` (module forward, MIOpen).
@@ -188,16 +201,16 @@ class Pipeline(torch.nn.Module):
                 side.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(side):  # library workspaces and autotuning must be settled before the capture
                     for _ in range(3):
-                        self._segmentation(batch).max(dim=-1)
+                        self._segment_max(batch)
                 torch.cuda.current_stream(self.device).wait_stream(side)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    st['scores'], st['ids'] = self._segmentation(batch).max(dim=-1)
+                    st['scores'], st['ids'] = self._segment_max(batch)
                 st['graph'] = graph
             except Exception:  # capture is an optimisation only
                 st['graph'] = None
         if st['graph'] is None:
-            return self._segmentation(data).max(dim=-1)
+            return self._segment_max(data)
         st['image'].copy_(image, non_blocking=True)
         if depth is not None:
             st['depth'].copy_(depth.reshape(st['depth'].shape), non_blocking=True)
@@ -215,7 +228,7 @@ class Pipeline(torch.nn.Module):
                 if use_graph:
                     scores, sem_ids = self._segmentation_graph(batch)
                 else:
-                    scores, sem_ids = self._segmentation(batch).max(dim=-1)
+                    scores, sem_ids = self._segment_max(batch)
         elif strategy == 'gt':
             sem_ids = batch['semantic_gt']
             scores = torch.ones_like(sem_ids, dtype=torch.float32)

@@ -120,3 +120,67 @@ class SegDeconv:
         rc = self._lib.ojf_segconv_forward(self._h, xp, xs, op, os_, None, 0, None, 0, ACT[act], H, W, _lib.stream_ptr(x.device))
         _lib.check(rc, 'ojf_segconv_forward')
         return out
+
+
+# ---- the operators around the convolutions (csrc/ojf_seg_ops.hip) -------------------------------------------------
+def pack_input(src, divisor=1.0):
+    """[1, 3, H, W] (contiguous NCHW) or a single [H, W] plane replicated three times (the depth modality,
+    pipeline.py:50) divided by ``divisor`` -> the stem's NHWC rows: an [1, 8, H, W] channels_last tensor, channels 3..7 zero."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    src = src.float()
+    H, W = src.shape[-2:]
+    planes = src.reshape(-1, H, W)
+    assert planes.is_cuda and planes.is_contiguous() and planes.shape[0] in (1, 3)
+    out = nhwc(8, H, W, src.device, zero=False)
+    op, os_ = _rows(out)
+    rc = lib.ojf_seg_pack_input(planes.data_ptr(), H * W if planes.shape[0] == 3 else 0, float(divisor), H, W, op, os_,
+                                _lib.stream_ptr(src.device))
+    _lib.check(rc, 'ojf_seg_pack_input')
+    return out
+
+
+def maxpool(x):
+    """nn.MaxPool2d(3, stride 2, padding 1) on an NHWC view."""
+    lib = _lib.load()
+    C, H, W = x.shape[1:]
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = nhwc((C + 7) // 8 * 8, Ho, Wo, x.device, zero=C % 8 != 0)[:, :C]
+    xp, xs = _rows(x)
+    op, os_ = _rows(out)
+    _lib.check(lib.ojf_seg_maxpool(xp, xs, C, H, W, op, os_, _lib.stream_ptr(x.device)), 'ojf_seg_maxpool')
+    return out
+
+
+def mean(x):
+    """Global average over the pixels: NHWC view [1, C, H, W] -> [1, C, 1, 1] (rows padded to a multiple of 8 channels)."""
+    lib = _lib.load()
+    C, H, W = x.shape[1:]
+    out = nhwc((C + 7) // 8 * 8, 1, 1, x.device, zero=C % 8 != 0)[:, :C]
+    xp, xs = _rows(x)
+    partial = torch.empty(32 * C, dtype=torch.float32, device=x.device)  # two fixed-order stages (include/ojf.h)
+    _lib.check(lib.ojf_seg_mean(xp, xs, C, H * W, partial.data_ptr(), out.data_ptr(), _lib.stream_ptr(x.device)), 'ojf_seg_mean')
+    return out
+
+
+def broadcast(vec, out, mul=None):
+    """out[:, c, y, x] = vec[0, c, 0, 0] (* mul[:, c, y, x]): bilinear upsampling of a 1x1 map / Decoder._skip's gate."""
+    lib = _lib.load()
+    C, H, W = out.shape[1:]
+    assert vec.shape[1] == C and vec.shape[2] == vec.shape[3] == 1
+    op, os_ = _rows(out)
+    mp, ms = _rows(mul) if mul is not None else (None, 0)
+    _lib.check(lib.ojf_seg_broadcast(vec.data_ptr(), mp, ms, C, H * W, op, os_, _lib.stream_ptr(out.device)), 'ojf_seg_broadcast')
+    return out
+
+
+def softmax_max(logits):
+    """torch.softmax(logits, 1).max(1) of an NHWC view [1, C, H, W] -> (scores f32 [H*W], ids u8 [H*W])."""
+    lib = _lib.load()
+    C, H, W = logits.shape[1:]
+    scores = torch.empty(H * W, dtype=torch.float32, device=logits.device)
+    ids = torch.empty(H * W, dtype=torch.uint8, device=logits.device)
+    lp, ls = _rows(logits)
+    _lib.check(lib.ojf_seg_softmax_max(lp, ls, C, H * W, scores.data_ptr(), ids.data_ptr(), _lib.stream_ptr(logits.device)),
+               'ojf_seg_softmax_max')
+    return scores, ids

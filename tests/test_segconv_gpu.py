@@ -132,3 +132,37 @@ def test_channel_slices_and_guard():
         SegConv(a)(x)  # NCHW-contiguous input is refused
     with pytest.raises(RuntimeError):
         SegConv(a)(nhwc(12, 5, 5, x.device)[:, :16] if False else nhwc(20, 5, 5, x.device)[:, 1:17])  # misaligned rows
+
+
+def test_front_end_operators_match_torch(cuda):
+    """csrc/ojf_seg_ops.hip against the torch operators they replace in the AdapNet++ front end: input packing
+    (image / 255, depth x 3: pipeline.py:44,50), MaxPool2d(3, 2, 1), global average + broadcast / gate, softmax + max."""
+    from online_joint_depthfusion_and_semantic_amd import segconv
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(3)
+    img = (torch.randn(1, 3, 37, 53, generator=g) * 60 + 100).to(cuda)
+    packed = segconv.pack_input(img, 255.0)  # a true division like the reference's CPU path (torch's GPU kernel multiplies by 1/255)
+    assert packed.shape == (1, 8, 37, 53) and torch.equal(packed[:, :3].cpu(), img.cpu() / 255.0) and float(packed[:, 3:].abs().max()) == 0
+    depth = (torch.rand(1, 37, 53, generator=g) * 4).to(cuda)
+    pd = segconv.pack_input(depth, 1.0)
+    assert torch.equal(pd[:, :3], depth.view(1, 1, 37, 53).repeat(1, 3, 1, 1))
+    for C, H, W in ((64, 37, 53), (5, 8, 8), (24, 1, 7)):
+        x = segconv.nhwc((C + 7) // 8 * 8, H, W, cuda)[:, :C]
+        x.copy_(torch.randn(1, C, H, W, generator=g))
+        assert torch.equal(segconv.maxpool(x), F.max_pool2d(x, 3, stride=2, padding=1))
+        m = segconv.mean(x)
+        want = x.mean(dim=(2, 3), keepdim=True)
+        assert m.shape == want.shape and torch.allclose(m, want, rtol=0, atol=2e-6)
+        out = segconv.nhwc(C + 8, H, W, cuda)
+        segconv.broadcast(m, out[:, 8:])
+        assert torch.equal(out[:, 8:], m.expand(1, C, H, W)) and float(out[:, :8].abs().max()) == 0
+        segconv.broadcast(m, out[:, 8:], mul=x)
+        assert torch.equal(out[:, 8:], m * x)
+    for C in (12, 30, 40):
+        logits = segconv.nhwc((C + 7) // 8 * 8, 19, 23, cuda)[:, :C]
+        logits.copy_(torch.randn(1, C, 19, 23, generator=g) * 3)
+        logits[0, 1, 0, 0] = logits[0, 4, 0, 0] = 9.0  # a tie: the first maximum wins (torch.max on the CPU)
+        s, i = segconv.softmax_max(logits)
+        ws, wi = torch.softmax(logits.cpu(), dim=1).max(dim=1)
+        assert i.dtype == torch.uint8 and torch.equal(i.cpu().long().view(19, 23), wi[0])
+        assert torch.allclose(s.cpu().view(19, 23), ws[0], rtol=0, atol=1e-6)
