@@ -67,6 +67,17 @@ SIGNATURES = {
     'ojf_segdeconv_create': (_i, [_c.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i]),
     'ojf_segconv_destroy': (None, [_vp]),
     'ojf_segconv_forward': (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    'ojf_train_packed_floats': (_sz, [_i, _i, _i]),
+    'ojf_train_pack': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'ojf_train_conv': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'ojf_train_avgpool3': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'ojf_train_partial_doubles': (_sz, [_i]),
+    'ojf_train_bn_stats': (_i, [_vp, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'ojf_train_bn_act': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _vp]),
+    'ojf_train_bn_act_bwd': (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _i, _vp, _vp,
+                                  _vp, _vp, _vp, _vp]),
+    'ojf_train_wgrad_partial_floats': (_sz, [_i, _i, _i, _i, _i]),
+    'ojf_train_wgrad': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'ojf_seg_pack_input': (_i, [_vp, _i, _f, _i, _i, _vp, _i, _vp]),
     'ojf_seg_maxpool': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
     'ojf_seg_mean': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),

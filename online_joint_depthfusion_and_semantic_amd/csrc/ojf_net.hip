@@ -259,6 +259,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGroup grp)
     const f32x4 *wb[NT];  // packed weights carry kPadSteps zero supersteps at the end as well
 #pragma unroll
     for (int n = 0; n < NT; ++n) wb[n] = a.wp + (size_t)(ot0 + n) * (a.nsteps + kPadSteps) * 64 + lane;
+    // activations through a buffer resource: an invalid tap selects an out-of-range offset, which loads zeros - the
+    // input needs no zero float4 in front of its planes (the training path feeds plain torch allocations)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<f32x4 *>(a.in), 0, (a.in_g0 + a.c4) * a.npix * 16, 0x00020000);
 
     // Operand fetch of superstep S.  Nothing consumes the loaded values before the MFMAs (invalid
     // taps select the INDEX of the zero float4 instead of masking data), so three stages stay in
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGroup grp)
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 if constexpr (ABL & 1) xv[m] = f32x4{1.f, 2.f, 3.f, 4.f};
-                else xv[m] = a.in[plin[m]];
+                else xv[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)plin[m] * 16u, 0, 0));
             }
         } else {
             const int2 e = tab[S * 4 + g];
@@ -278,12 +282,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGroup grp)
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const bool ok = (unsigned)(py[m] + dy) < (unsigned)a.h && (unsigned)(px[m] + dx) < (unsigned)a.w;
-                const int idx = ok ? e.x + plin[m] : -1;
+                const unsigned boff = ok ? (unsigned)(e.x + plin[m]) * 16u : 0xffffffffu;
                 if constexpr (ABL & 1) {
                     xv[m] = f32x4{1.f, 2.f, 3.f, 4.f};
-                    asm volatile("" ::"v"(idx));
+                    asm volatile("" ::"v"(boff));
                 } else {
-                    xv[m] = a.in[idx];
+                    xv[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, boff, 0, 0));
                 }
                 any_ok |= ok;
             }
@@ -2473,3 +2477,5 @@ OJF_API int ojf_conv2d(const float *in, int in_stride, int in_off, float *out, i
     release(pc);
     return rc;
 }
+
+#include "ojf_net_train.h"

@@ -1,0 +1,577 @@
+// TRAINING path of the fusion net (modules/pipeline.py:301-363 fuse_training with the net in train() mode; included by
+// ojf_net.hip only).  One fused layer unit of the reference's Sequentials (modules/model.py:4-52,115-141)
+//
+//     conv (1x1 / dilated 3x3, bias) -> BatchNorm2d with BATCH statistics -> ReLU / LeakyReLU / Tanh -> Dropout2d
+//
+// as device kernels for forward and backward; Python (train.py) wraps a unit as ONE torch.autograd.Function and leaves the
+// glue of the net (concatenations, average pools, the 1x1 global-average map, loss) to torch on the same C4-planar
+// tensors, so that autograd accumulates the fan-out gradients and the reference's optimizer / checkpoint code runs
+// unchanged.  All convolutions here use the fp32-input MFMA kernel (conv_mfma_kernel: bitwise a k-ordered fmaf chain):
+// gradients are tiny (d loss / d est ~ 1e-6) and of unbounded dynamic range - the split-fp16 arithmetic of the
+// inference path would need loss scaling; fp32 MFMA runs at the fp32 vector rate, which is also what the weight-
+// gradient kernel (plain v_fma_f32, register-tiled) reaches.
+//
+//   ojf_train_pack          torch weights [oc][ic][k][k] -> the conv kernel's fragment layout, on the device, every step:
+//                           forward form, or transposed + tap-flipped form (backward-data IS a convolution with it)
+//   ojf_train_conv          convolution on C4 planes (any c_out: chunks of 8 output tiles per launch)
+//   ojf_train_bn_stats      per-channel batch mean / 1 / sqrt(var + eps) (fp64 sums, fixed order) + running-stat update
+//   ojf_train_bn_act        out = drop_c * act(gamma_c * (y - mean_c) * invstd_c + beta_c)
+//   ojf_train_bn_act_bwd    dgamma, dbeta, dbias and dy = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat))
+//   ojf_train_wgrad         dW[oc][ic][tap] = sum_p dy[oc][p] * x[ic][p + tap]  (pixel slabs -> partial sums -> fixed-order sum)
+#pragma once
+
+namespace ojf {
+
+constexpr int kTrainSlabs = 64;  // pixel slabs of the per-channel reductions (partial sums added in slab order)
+
+// ---- weight packing on the device ----------------------------------------------------------------------------------
+// Packed element (row r, K group G = tap * c4 + cg, component j) <- weight(oc, ic, tap'):
+//   forward:     oc = r,            ic = unslot(4 cg + j),  tap' = tap
+//   transposed:  ic = unslot(r),    oc = 4 cg + j,          tap' = taps - 1 - tap   (backward-data)
+// unslot: physical channel of a concatenation of `group`-wide tensors stored in `slot`-wide slots -> logical channel.
+struct PackArgs {
+    const float *w;     // [OC][IC][taps]
+    const float *bias;  // [OC] or NULL
+    float *wp;          // [n_ot][nsteps + kPadSteps][64][4]
+    float *bp;          // [n_ot * 16] (forward form only; NULL otherwise)
+    int OC, IC, taps, group, slot, c4, nsteps, n_ot, transposed;
+};
+
+__device__ __forceinline__ int train_unslot(int x, int group, int slot, int n_logical)
+{
+    const int s = x / slot, in = x - s * slot;
+    const int l = s * group + in;
+    return (in < group && l < n_logical) ? l : -1;
+}
+
+__global__ __launch_bounds__(256) void train_pack_kernel(const PackArgs a)
+{
+    const int nsp = a.nsteps + kPadSteps;
+    const long total = (long)a.n_ot * nsp * 256;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (long)a.n_ot * 16 && a.bp) a.bp[i] = (a.bias && i < a.OC) ? a.bias[i] : 0.0f;
+    if (i >= total) return;
+    const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    const long rest = i >> 8;
+    const int S = (int)(rest % nsp), ot = (int)(rest / nsp);
+    const int r = ot * 16 + (lane & 15), G = 4 * S + (lane >> 4);
+    float v = 0.0f;
+    if (S < a.nsteps && G < a.taps * a.c4) {
+        const int tap = G / a.c4, ch = 4 * (G - tap * a.c4) + j;
+        int oc, ic, t;
+        if (!a.transposed) { oc = r; ic = train_unslot(ch, a.group, a.slot, a.IC); t = tap; }
+        else { ic = train_unslot(r, a.group, a.slot, a.IC); oc = ch; t = a.taps - 1 - tap; }
+        if (oc < a.OC && ic >= 0) v = a.w[((size_t)oc * a.IC + ic) * a.taps + t];
+    }
+    a.wp[i] = v;
+}
+
+// ---- BatchNorm statistics ------------------------------------------------------------------------------------------
+// block (slab, channel group): fp64 sums of y and y^2 over the slab's pixels of the group's four channels
+__global__ __launch_bounds__(256) void train_stats_partial_kernel(const f32x4 *y, int g0, int npix, double *partial /* [slabs][c4][8] */)
+{
+    __shared__ double red[4][8];
+    const int cg = blockIdx.y, c4 = gridDim.y;
+    const int per = (npix + kTrainSlabs - 1) / kTrainSlabs;
+    const int p0 = blockIdx.x * per, p1 = min(npix, p0 + per);
+    const f32x4 *plane = y + (size_t)(g0 + cg) * npix;
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+        const f32x4 v = plane[p];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s[j] += (double)v[j]; s[4 + j] += (double)v[j] * (double)v[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        double v = s[j];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8)
+        partial[((size_t)blockIdx.x * c4 + cg) * 8 + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+struct StatsArgs {
+    const double *partial;  // [slabs][c4][8]
+    int c4, C, npix, training;
+    float momentum, eps;
+    float *running_mean, *running_var;  // [C] (updated when training; read in eval mode)
+    float *mean, *invstd;               // [c4 * 4] out
+};
+
+__global__ __launch_bounds__(256) void train_stats_finish_kernel(const StatsArgs a)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.c4 * 4) return;
+    if (c >= a.C) { a.mean[c] = 0.0f; a.invstd[c] = 0.0f; return; }  // padding channels stay exactly zero
+    if (!a.training) {
+        a.mean[c] = a.running_mean[c];
+        a.invstd[c] = 1.0f / sqrtf(a.running_var[c] + a.eps);
+        return;
+    }
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < kTrainSlabs; ++b) {
+        const double *row = a.partial + ((size_t)b * a.c4 + (c >> 2)) * 8;
+        s += row[c & 3];
+        q += row[4 + (c & 3)];
+    }
+    const double n = (double)a.npix, m = s / n;
+    double var = q / n - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    a.mean[c] = (float)m;
+    a.invstd[c] = (float)(1.0 / sqrt(var + (double)a.eps));
+    // nn.BatchNorm2d: running = (1 - momentum) * running + momentum * batch (variance: the unbiased estimate)
+    a.running_mean[c] = (1.0f - a.momentum) * a.running_mean[c] + a.momentum * (float)m;
+    const double unbiased = a.npix > 1 ? var * n / (n - 1.0) : var;
+    a.running_var[c] = (1.0f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
+}
+
+// ---- normalise + activation + channel dropout ----------------------------------------------------------------------
+struct BnActArgs {
+    const f32x4 *y;      // conv output planes (window at y_g0)
+    f32x4 *out;          // result planes (window at out_g0)
+    const f32x4 *dout;   // backward: gradient of `out`
+    f32x4 *dy;           // backward: gradient of y
+    const float *mean, *invstd;       // [c4 * 4] (identity when has_bn == 0)
+    const float *gamma, *beta;        // [C] or NULL
+    const float *drop;                // [C] per-channel Dropout2d scale (0 or 1 / (1 - p)) or NULL
+    const float *red;                 // backward apply: [c4 * 4][2] = {mean(dz), mean(dz * xhat)}
+    double *partial;                  // backward reduce: [slabs][c4][8]
+    int y_g0, out_g0, dout_g0, dy_g0, c4, C, npix, act, has_bn, training;
+    float scale;                      // output scale of the last layer (tanh(.) * output_scale)
+};
+
+__device__ __forceinline__ float train_act(float z, int act)
+{
+    if (act == OJF_ACT_RELU) return z > 0.0f ? z : (z != z ? z : 0.0f);
+    if (act == OJF_ACT_LEAKY) return z > 0.0f ? z : 0.01f * z;
+    if (act == OJF_ACT_TANH) return tanhf(z);
+    return z;
+}
+__device__ __forceinline__ float train_act_grad(float z, int act)
+{
+    if (act == OJF_ACT_RELU) return z > 0.0f ? 1.0f : 0.0f;
+    if (act == OJF_ACT_LEAKY) return z > 0.0f ? 1.0f : 0.01f;
+    if (act == OJF_ACT_TANH) { const float t = tanhf(z); return 1.0f - t * t; }
+    return 1.0f;
+}
+
+// per-lane channel constants of group cg: (scale, shift) with z = y * scale + shift, drop, gamma * invstd
+__device__ __forceinline__ void train_channel_consts(const BnActArgs &a, int cg, f32x4 &mu, f32x4 &is, f32x4 &ga, f32x4 &be, f32x4 &dr)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = 4 * cg + j;
+        const bool real = c < a.C;
+        mu[j] = a.has_bn ? a.mean[c] : 0.0f;
+        is[j] = real ? (a.has_bn ? a.invstd[c] : 1.0f) : 0.0f;
+        ga[j] = real ? (a.gamma ? a.gamma[c] : 1.0f) : 0.0f;
+        be[j] = real ? (a.beta ? a.beta[c] : 0.0f) : 0.0f;
+        dr[j] = real ? (a.drop ? a.drop[c] : 1.0f) : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void train_bn_act_fwd_kernel(const BnActArgs a)
+{
+    const int cg = blockIdx.y;
+    f32x4 mu, is, ga, be, dr;
+    train_channel_consts(a, cg, mu, is, ga, be, dr);
+    const f32x4 *yp = a.y + (size_t)(a.y_g0 + cg) * a.npix;
+    f32x4 *op = a.out + (size_t)(a.out_g0 + cg) * a.npix;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < a.npix; p += gridDim.x * blockDim.x) {
+        const f32x4 y = yp[p];
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xh = (y[j] - mu[j]) * is[j];
+            const float z = xh * ga[j] + be[j];
+            o[j] = 4 * cg + j < a.C ? train_act(z, a.act) * a.scale * dr[j] : 0.0f;
+        }
+        op[p] = o;
+    }
+}
+
+// dz = dout * scale * drop * act'(z); partial sums of dz and dz * xhat per channel (fp64, fixed order)
+__global__ __launch_bounds__(256) void train_bn_bwd_reduce_kernel(const BnActArgs a)
+{
+    __shared__ double red[4][8];
+    const int cg = blockIdx.y;
+    f32x4 mu, is, ga, be, dr;
+    train_channel_consts(a, cg, mu, is, ga, be, dr);
+    const int per = (a.npix + kTrainSlabs - 1) / kTrainSlabs;
+    const int p0 = blockIdx.x * per, p1 = min(a.npix, p0 + per);
+    const f32x4 *yp = a.y + (size_t)(a.y_g0 + cg) * a.npix;
+    const f32x4 *gp = a.dout + (size_t)(a.dout_g0 + cg) * a.npix;
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+        const f32x4 y = yp[p], g = gp[p];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xh = (y[j] - mu[j]) * is[j];
+            const float z = xh * ga[j] + be[j];
+            const float dz = g[j] * a.scale * dr[j] * train_act_grad(z, a.act);
+            s[j] += (double)dz;
+            s[4 + j] += (double)dz * (double)xh;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        double v = s[j];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8)
+        a.partial[((size_t)blockIdx.x * a.c4 + cg) * 8 + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+struct BnBwdFinishArgs {
+    const double *partial;
+    int c4, C, npix, has_bn, training;
+    const float *gamma, *invstd;
+    float *dgamma, *dbeta, *dbias;  // [C] each (NULL: skip)
+    float *red;                     // [c4 * 4][2] means for the apply kernel
+};
+
+__global__ __launch_bounds__(256) void train_bn_bwd_finish_kernel(const BnBwdFinishArgs a)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.c4 * 4) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < kTrainSlabs; ++b) {
+        const double *row = a.partial + ((size_t)b * a.c4 + (c >> 2)) * 8;
+        s1 += row[c & 3];
+        s2 += row[4 + (c & 3)];
+    }
+    const bool batch = a.has_bn && a.training;
+    a.red[2 * c] = batch ? (float)(s1 / (double)a.npix) : 0.0f;
+    a.red[2 * c + 1] = batch ? (float)(s2 / (double)a.npix) : 0.0f;
+    if (c >= a.C) return;
+    if (a.dgamma) a.dgamma[c] = (float)s2;
+    if (a.dbeta) a.dbeta[c] = (float)s1;
+    if (a.dbias) {
+        // sum_p dy: zero under batch statistics (the normalisation removes the mean), gamma * invstd * sum(dz) otherwise
+        const float gi = a.has_bn ? (a.gamma ? a.gamma[c] : 1.0f) * a.invstd[c] : 1.0f;
+        a.dbias[c] = batch ? 0.0f : (float)(s1 * (double)gi);
+    }
+}
+
+__global__ __launch_bounds__(256) void train_bn_bwd_apply_kernel(const BnActArgs a)
+{
+    const int cg = blockIdx.y;
+    f32x4 mu, is, ga, be, dr;
+    train_channel_consts(a, cg, mu, is, ga, be, dr);
+    f32x4 m1, m2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { m1[j] = a.red[2 * (4 * cg + j)]; m2[j] = a.red[2 * (4 * cg + j) + 1]; }
+    const f32x4 *yp = a.y + (size_t)(a.y_g0 + cg) * a.npix;
+    const f32x4 *gp = a.dout + (size_t)(a.dout_g0 + cg) * a.npix;
+    f32x4 *dp = a.dy + (size_t)(a.dy_g0 + cg) * a.npix;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < a.npix; p += gridDim.x * blockDim.x) {
+        const f32x4 y = yp[p], g = gp[p];
+        f32x4 d;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xh = (y[j] - mu[j]) * is[j];
+            const float z = xh * ga[j] + be[j];
+            const float dz = g[j] * a.scale * dr[j] * train_act_grad(z, a.act);
+            d[j] = ga[j] * is[j] * (dz - m1[j] - xh * m2[j]);  // m1 = m2 = 0 without batch statistics
+        }
+        dp[p] = d;
+    }
+}
+
+// ---- weight gradient -----------------------------------------------------------------------------------------------
+// dW[oc][ic][tap] = sum_p dy[oc][p] * x[ic][p + offset(tap)] (zero outside the image).  Block = TY x TX threads, each a
+// 4 x 4 (oc, ic) register tile, one tap and one pixel slab per block; the slab is staged through LDS 32 pixels at a time
+// in the planes' own [pixel][channel] order (float4 = 4 channels), so a thread's operands are two broadcast-friendly
+// ds_read_b128 per pixel for 16 FMAs.  Partial sums per slab go to `partial`; wgrad_reduce_kernel adds the slabs in
+// order and writes torch's [OC][IC][k][k] layout (physical input channels un-slotted).
+struct WgradArgs {
+    const f32x4 *x;   // input planes of the forward conv (window at x_g0, c4_in groups)
+    const f32x4 *dy;  // gradient planes of its output (window at dy_g0, c4_out groups)
+    float *partial;   // [slabs][taps][ocp][icp], ocp = oc blocks * TY * 4, icp = ic blocks * TX * 4
+    int x_g0, c4_in, dy_g0, c4_out, h, w, npix, taps, dil, slabs, ocp, icp;
+};
+
+constexpr int kWgPix = 32;
+
+template <int TY, int TX>
+__global__ __launch_bounds__(TY * TX) void train_wgrad_kernel(const WgradArgs a)
+{
+    constexpr int NT = TY * TX, OCB = TY * 4, ICB = TX * 4;
+    __shared__ f32x4 dyl[kWgPix * TY];  // [pixel][oc group]
+    __shared__ f32x4 xl[kWgPix * TX];   // [pixel][ic group]
+    const int tid = threadIdx.x, ty = tid / TX, tx = tid - ty * TX;
+    const int n_icb = a.icp / ICB;
+    const int ob = blockIdx.y / n_icb, ib = blockIdx.y - ob * n_icb;
+    const int tap = blockIdx.z;
+    int dyo = 0, dxo = 0;
+    if (a.taps == 9) { dyo = (tap / 3 - 1) * a.dil; dxo = (tap % 3 - 1) * a.dil; }
+    const int per = (a.npix + a.slabs - 1) / a.slabs;
+    const int p0 = blockIdx.x * per, p1 = min(a.npix, p0 + per);
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+    const f32x4 zero{0.f, 0.f, 0.f, 0.f};
+    for (int pc = p0; pc < p1; pc += kWgPix) {
+        __syncthreads();
+        for (int e = tid; e < kWgPix * TY; e += NT) {
+            const int px = e / TY, g = e - px * TY, p = pc + px, cg = ob * TY + g;
+            dyl[e] = (p < p1 && cg < a.c4_out) ? a.dy[(size_t)(a.dy_g0 + cg) * a.npix + p] : zero;
+        }
+        for (int e = tid; e < kWgPix * TX; e += NT) {
+            const int px = e / TX, g = e - px * TX, p = pc + px, cg = ib * TX + g;
+            f32x4 v = zero;
+            if (p < p1 && cg < a.c4_in) {
+                const int py = p / a.w, pxx = p - py * a.w;
+                const int sy = py + dyo, sx = pxx + dxo;
+                if ((unsigned)sy < (unsigned)a.h && (unsigned)sx < (unsigned)a.w)
+                    v = a.x[(size_t)(a.x_g0 + cg) * a.npix + sy * a.w + sx];
+            }
+            xl[e] = v;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int px = 0; px < kWgPix; ++px) {
+            const f32x4 d = dyl[px * TY + ty], v = xl[px * TX + tx];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(d[i], v[j], acc[i][j]);
+        }
+    }
+    float *dst = a.partial + (((size_t)blockIdx.x * a.taps + tap) * a.ocp + (size_t)ob * OCB + ty * 4) * a.icp + (size_t)ib * ICB + tx * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<f32x4 *>(dst + (size_t)i * a.icp) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+}
+
+struct WgradReduceArgs {
+    const float *partial;
+    float *dw;  // [OC][IC][taps]
+    int slabs, taps, ocp, icp, OC, IC, group, slot, c_in_phys;
+};
+
+__global__ __launch_bounds__(256) void train_wgrad_reduce_kernel(const WgradReduceArgs a)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)a.taps * a.OC * a.c_in_phys;
+    if (i >= total) return;
+    const int icp_i = (int)(i % a.c_in_phys);
+    const long r = i / a.c_in_phys;
+    const int oc = (int)(r % a.OC), tap = (int)(r / a.OC);
+    const int ic = train_unslot(icp_i, a.group, a.slot, a.IC);
+    if (ic < 0) return;
+    float s = 0.0f;
+    for (int b = 0; b < a.slabs; ++b) s += a.partial[(((size_t)b * a.taps + tap) * a.ocp + oc) * a.icp + icp_i];
+    a.dw[((size_t)oc * a.IC + ic) * a.taps + tap] = s;
+}
+
+// nn.AvgPool2d(3, stride 1, padding 1), count_include_pad: out = (sum of the 3x3 neighbourhood inside the image) / 9.  The
+// operator is symmetric, so its backward pass is the same kernel applied to the gradient.
+__global__ __launch_bounds__(256) void train_avgpool3_kernel(const f32x4 *in, f32x4 *out, int h, int w)
+{
+    const int npix = h * w;
+    const f32x4 *ip = in + (size_t)blockIdx.y * npix;
+    f32x4 *op = out + (size_t)blockIdx.y * npix;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        const int y = p / w, x = p - y * w;
+        f32x4 s{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx)
+                if ((unsigned)(y + dy) < (unsigned)h && (unsigned)(x + dx) < (unsigned)w) s += ip[(y + dy) * w + x + dx];
+        op[p] = s / 9.0f;
+    }
+}
+
+static float *g_train_zero_bias = nullptr;  // 4096 zero floats: the conv kernel always reads a bias vector
+
+}  // namespace ojf
+
+// ---- C ABI ----------------------------------------------------------------------------------------------------------
+OJF_API size_t ojf_train_packed_floats(int c_out_phys, int c_in_phys, int ksize)
+{
+    using namespace ojf;
+    if (c_out_phys < 1 || c_in_phys < 4 || c_in_phys % 4 || (ksize != 1 && ksize != 3)) return 0;
+    const int n_ot = round_up(round_up(c_out_phys, 16) / 16, kNT), nsteps = (ksize * ksize * (c_in_phys / 4) + 3) / 4;
+    if (nsteps > kMaxSteps) return 0;
+    return (size_t)n_ot * (nsteps + kPadSteps) * 256;
+}
+
+OJF_API int ojf_train_pack(const float *w, const float *bias, int OC, int IC, int ksize, int group, int slot, int c_in_phys,
+                           int c_out_phys, int transposed, float *packed, float *bias_packed, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (!w || !packed || OC < 1 || IC < 1 || group < 1 || slot < group) return fail("ojf_train_pack: bad argument");
+    // forward: rows = output channels (c_out_phys), K = input planes (c_in_phys); transposed: rows = input planes, K = output channels
+    const int rows = transposed ? c_in_phys : c_out_phys, kch = transposed ? c_out_phys : c_in_phys;
+    if (ojf_train_packed_floats(rows, kch, ksize) == 0) return fail("ojf_train_pack: unsupported layer shape (K too long or channels not padded to 4)");
+    PackArgs a;
+    a.w = w; a.bias = transposed ? nullptr : bias; a.wp = packed; a.bp = transposed ? nullptr : bias_packed;
+    a.OC = OC; a.IC = IC; a.taps = ksize * ksize; a.group = group; a.slot = slot;
+    a.c4 = kch / 4; a.nsteps = (a.taps * a.c4 + 3) / 4; a.n_ot = round_up(round_up(rows, 16) / 16, kNT); a.transposed = transposed ? 1 : 0;
+    const long total = (long)a.n_ot * (a.nsteps + kPadSteps) * 256;
+    hipLaunchKernelGGL(train_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), a);
+    return check_hip(hipGetLastError(), "train_pack_kernel launch");
+}
+
+OJF_API int ojf_train_conv(const float *in, int in_g0, int c_in_phys, float *out, int out_g0, int c_out_phys, const float *packed,
+                           const float *bias_packed, int ksize, int dil, int h, int w, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (!in || !out || !packed) return fail("ojf_train_conv: null pointer argument");
+    if (ojf_train_packed_floats(c_out_phys, c_in_phys, ksize) == 0 || dil < 1 || h < 1 || w < 1) return fail("ojf_train_conv: unsupported shape");
+    if (!g_train_zero_bias) {
+        OJF_HIP(hipMalloc(reinterpret_cast<void **>(&g_train_zero_bias), 4096 * sizeof(float)));
+        OJF_HIP(hipMemset(g_train_zero_bias, 0, 4096 * sizeof(float)));
+    }
+    const int taps = ksize * ksize, c4 = c_in_phys / 4, nsteps = (taps * c4 + 3) / 4;
+    const int n_ot = round_up(round_up(c_out_phys, 16) / 16, kNT), og_total = round_up(c_out_phys, 4) / 4;
+    if (n_ot * 16 > 4096) return fail("ojf_train_conv: too many output channels");
+    for (int ot0 = 0; ot0 < n_ot; ot0 += 8) {  // a launch covers up to 8 output tiles per wave
+        const int nt = n_ot - ot0 < 8 ? n_ot - ot0 : 8;
+        ConvArgs a;
+        a.ovf = nullptr;
+        a.in = planes(in); a.out = planes(out); a.out_rows = nullptr;
+        a.wp = planes(packed) + (size_t)ot0 * (nsteps + kPadSteps) * 64;
+        a.bias = (bias_packed ? bias_packed : g_train_zero_bias) + (size_t)ot0 * 16; a.rinv = nullptr;
+        a.in_g0 = in_g0; a.out_g0 = out_g0 + ot0 * 4; a.rows_stride = 0; a.rows_n = 0;
+        a.h = h; a.w = w; a.npix = h * w; a.taps = taps; a.dil = dil; a.c4 = c4; a.nsteps = nsteps;
+        a.w_magic = 0; a.c4_magic = 0;
+        const int left = og_total - ot0 * 4;
+        a.og_store = left < nt * 4 ? left : nt * 4;
+        a.act = OJF_ACT_NONE; a.act_n = 0; a.scale = 1.0f;
+        if (launch_conv_args(&a, 1, nt, as_stream(stream), OJF_ARITH_F32)) return -2;
+    }
+    return 0;
+}
+
+OJF_API int ojf_train_avgpool3(const float *in, float *out, int c_phys, int h, int w, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (!in || !out || in == out || c_phys < 4 || c_phys % 4 || h < 1 || w < 1) return fail("ojf_train_avgpool3: bad argument");
+    const int bx = (h * w + 255) / 256 < 256 ? (h * w + 255) / 256 : 256;
+    hipLaunchKernelGGL(train_avgpool3_kernel, dim3(bx, c_phys / 4), dim3(256), 0, as_stream(stream), planes(in), planes(out), h, w);
+    return check_hip(hipGetLastError(), "train_avgpool3_kernel launch");
+}
+
+OJF_API size_t ojf_train_partial_doubles(int c_phys) { return (size_t)ojf::kTrainSlabs * (c_phys / 4) * 8; }
+
+OJF_API int ojf_train_bn_stats(const float *y, int y_g0, int c_phys, int C, int h, int w, int training, float momentum, float eps,
+                               float *running_mean, float *running_var, double *partial, float *mean, float *invstd, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (!y || !mean || !invstd || !partial || c_phys % 4 || C > c_phys) return fail("ojf_train_bn_stats: bad argument");
+    if (!running_mean || !running_var) return fail("ojf_train_bn_stats: running statistics are required");
+    hipStream_t st = as_stream(stream);
+    if (training) hipLaunchKernelGGL(train_stats_partial_kernel, dim3(kTrainSlabs, c_phys / 4), dim3(256), 0, st, planes(y), y_g0, h * w, partial);
+    StatsArgs a;
+    a.partial = partial; a.c4 = c_phys / 4; a.C = C; a.npix = h * w; a.training = training ? 1 : 0; a.momentum = momentum; a.eps = eps;
+    a.running_mean = running_mean; a.running_var = running_var; a.mean = mean; a.invstd = invstd;
+    hipLaunchKernelGGL(train_stats_finish_kernel, dim3((c_phys + 255) / 256), dim3(256), 0, st, a);
+    return check_hip(hipGetLastError(), "train_stats kernels launch");
+}
+
+static ojf::BnActArgs train_bn_args(const float *y, int y_g0, int c_phys, int C, int h, int w, const float *mean, const float *invstd,
+                                    const float *gamma, const float *beta, const float *drop, int act, float scale, int has_bn, int training)
+{
+    ojf::BnActArgs a;
+    a.y = ojf::planes(y); a.out = nullptr; a.dout = nullptr; a.dy = nullptr;
+    a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.drop = drop; a.red = nullptr; a.partial = nullptr;
+    a.y_g0 = y_g0; a.out_g0 = 0; a.dout_g0 = 0; a.dy_g0 = 0; a.c4 = c_phys / 4; a.C = C; a.npix = h * w; a.act = act;
+    a.has_bn = has_bn; a.training = training; a.scale = scale;
+    return a;
+}
+
+OJF_API int ojf_train_bn_act(const float *y, int y_g0, float *out, int out_g0, int c_phys, int C, int h, int w, const float *mean,
+                             const float *invstd, const float *gamma, const float *beta, const float *drop, int act, float scale,
+                             int has_bn, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (!y || !out || c_phys % 4 || C > c_phys || (has_bn && (!mean || !invstd))) return fail("ojf_train_bn_act: bad argument");
+    BnActArgs a = train_bn_args(y, y_g0, c_phys, C, h, w, mean, invstd, gamma, beta, drop, act, scale, has_bn, 0);
+    a.out = planes(out); a.out_g0 = out_g0;
+    const int bx = (h * w + 255) / 256 < 128 ? (h * w + 255) / 256 : 128;
+    hipLaunchKernelGGL(train_bn_act_fwd_kernel, dim3(bx, c_phys / 4), dim3(256), 0, as_stream(stream), a);
+    return check_hip(hipGetLastError(), "train_bn_act_fwd_kernel launch");
+}
+
+OJF_API int ojf_train_bn_act_bwd(const float *y, int y_g0, const float *dout, int dout_g0, float *dy, int dy_g0, int c_phys, int C,
+                                 int h, int w, const float *mean, const float *invstd, const float *gamma, const float *beta,
+                                 const float *drop, int act, float scale, int has_bn, int training, double *partial, float *red,
+                                 float *dgamma, float *dbeta, float *dbias, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (!y || !dout || !dy || !partial || !red || c_phys % 4 || C > c_phys || (has_bn && (!mean || !invstd)))
+        return fail("ojf_train_bn_act_bwd: bad argument");
+    hipStream_t st = as_stream(stream);
+    BnActArgs a = train_bn_args(y, y_g0, c_phys, C, h, w, mean, invstd, gamma, beta, drop, act, scale, has_bn, training);
+    a.dout = planes(dout); a.dout_g0 = dout_g0; a.dy = planes(dy); a.dy_g0 = dy_g0; a.partial = partial; a.red = red;
+    hipLaunchKernelGGL(train_bn_bwd_reduce_kernel, dim3(kTrainSlabs, c_phys / 4), dim3(256), 0, st, a);
+    BnBwdFinishArgs f;
+    f.partial = partial; f.c4 = c_phys / 4; f.C = C; f.npix = h * w; f.has_bn = has_bn; f.training = training;
+    f.gamma = gamma; f.invstd = invstd; f.dgamma = dgamma; f.dbeta = dbeta; f.dbias = dbias; f.red = red;
+    hipLaunchKernelGGL(train_bn_bwd_finish_kernel, dim3((c_phys + 255) / 256), dim3(256), 0, st, f);
+    const int bx = (h * w + 255) / 256 < 128 ? (h * w + 255) / 256 : 128;
+    hipLaunchKernelGGL(train_bn_bwd_apply_kernel, dim3(bx, c_phys / 4), dim3(256), 0, st, a);
+    return check_hip(hipGetLastError(), "train_bn_bwd kernels launch");
+}
+
+namespace ojf {
+struct WgradPlan { int ty, tx, ocp, icp, slabs; };
+static WgradPlan wgrad_plan(int c_out_phys, int c_in_phys, int taps, int npix)
+{
+    WgradPlan p;
+    if (c_out_phys <= 32 && c_in_phys <= 32) { p.ty = 8; p.tx = 8; }
+    else if (c_out_phys <= 32) { p.ty = 8; p.tx = 32; }
+    else if (c_in_phys <= 32) { p.ty = 32; p.tx = 8; }
+    else { p.ty = 16; p.tx = 16; }
+    p.ocp = round_up(c_out_phys, p.ty * 4);
+    p.icp = round_up(c_in_phys, p.tx * 4);
+    const int tiles = taps * (p.ocp / (p.ty * 4)) * (p.icp / (p.tx * 4));
+    int slabs = (2048 + tiles - 1) / tiles;  // enough blocks to fill the chip, few enough to keep the partial sums small
+    const int max_slabs = (npix + 4 * kWgPix - 1) / (4 * kWgPix);
+    slabs = slabs > max_slabs ? max_slabs : slabs;
+    p.slabs = slabs < 1 ? 1 : slabs;
+    return p;
+}
+}  // namespace ojf
+
+OJF_API size_t ojf_train_wgrad_partial_floats(int c_out_phys, int c_in_phys, int ksize, int h, int w)
+{
+    const ojf::WgradPlan p = ojf::wgrad_plan(c_out_phys, c_in_phys, ksize * ksize, h * w);
+    return (size_t)p.slabs * ksize * ksize * p.ocp * p.icp;
+}
+
+OJF_API int ojf_train_wgrad(const float *x, int x_g0, int c_in_phys, const float *dy, int dy_g0, int c_out_phys, int OC, int IC,
+                            int ksize, int dil, int group, int slot, int h, int w, float *partial, float *dw, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (!x || !dy || !partial || !dw || c_in_phys % 4 || c_out_phys % 4 || (ksize != 1 && ksize != 3) || OC > c_out_phys)
+        return fail("ojf_train_wgrad: bad argument");
+    hipStream_t st = as_stream(stream);
+    const int taps = ksize * ksize;
+    const WgradPlan p = wgrad_plan(c_out_phys, c_in_phys, taps, h * w);
+    WgradArgs a;
+    a.x = planes(x); a.dy = planes(dy); a.partial = partial; a.x_g0 = x_g0; a.c4_in = c_in_phys / 4; a.dy_g0 = dy_g0; a.c4_out = c_out_phys / 4;
+    a.h = h; a.w = w; a.npix = h * w; a.taps = taps; a.dil = dil; a.slabs = p.slabs; a.ocp = p.ocp; a.icp = p.icp;
+    const dim3 grid(p.slabs, (p.ocp / (p.ty * 4)) * (p.icp / (p.tx * 4)), taps);
+    if (p.ty == 8 && p.tx == 8) hipLaunchKernelGGL((train_wgrad_kernel<8, 8>), grid, dim3(64), 0, st, a);
+    else if (p.ty == 8) hipLaunchKernelGGL((train_wgrad_kernel<8, 32>), grid, dim3(256), 0, st, a);
+    else if (p.tx == 8) hipLaunchKernelGGL((train_wgrad_kernel<32, 8>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((train_wgrad_kernel<16, 16>), grid, dim3(256), 0, st, a);
+    WgradReduceArgs r;
+    r.partial = partial; r.dw = dw; r.slabs = p.slabs; r.taps = taps; r.ocp = p.ocp; r.icp = p.icp; r.OC = OC; r.IC = IC;
+    r.group = group; r.slot = slot; r.c_in_phys = c_in_phys;
+    const long total = (long)taps * OC * c_in_phys;
+    hipLaunchKernelGGL(train_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r);
+    return check_hip(hipGetLastError(), "train_wgrad kernels launch");
+}

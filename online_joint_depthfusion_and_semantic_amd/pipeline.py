@@ -298,6 +298,17 @@ class Pipeline(torch.nn.Module):
         database.fusion_weights[scene_id] = weights
         return
 
+    def _training_forward(self, inputs):
+        """The net forward of pipeline.py:322 with a graph for ``loss.backward()``: on the libojf training kernels
+        (train.HipTrainNet: ``FUSION_MODEL.train_engine: hip``, default on a GPU) or on torch autograd (``torch``)."""
+        if self.config.FUSION_MODEL.get('train_engine', 'hip') == 'hip' and torch.device(self.device).type == 'cuda':
+            tn = self.__dict__.get('_hip_train')
+            if tn is None or tn.net is not self._fusion_network:
+                from .train import HipTrainNet
+                tn = self.__dict__['_hip_train'] = HipTrainNet(self._fusion_network)
+            return tn(inputs)
+        return self._fusion_network.forward(inputs)
+
     # ---- training frame step (pipeline.py:251-363) -----------------------------------------------
     def fuse_training(self, batch, database, device):
         self.device = torch.device(device)
@@ -321,7 +332,7 @@ class Pipeline(torch.nn.Module):
                   'tsdf_frame': frame.view(1, 1, h, w)}
         if self.config.FUSION_MODEL.use_semantics:
             inputs['semantic_frame'] = ((1 + sem_ids.float()) / self.n_classes).view(1, 1, h, w)
-        tsdf_est = self._fusion_network.forward(inputs)  # autograd path (BN in train mode when .train())
+        tsdf_est = self._training_forward(inputs)  # differentiable; BN / dropout follow the module's train() / eval() mode
         tsdf_est = tsdf_est.permute(0, 2, 3, 1)[..., :P].reshape(1, n, P)
 
         # pipeline.py:104-135

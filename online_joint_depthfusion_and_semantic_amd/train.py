@@ -1,0 +1,264 @@
+"""HIP training path of the fusion net: ``Pipeline.fuse_training``'s network forward / backward
+(modules/pipeline.py:322, driven by train_fusion.py:166-189) on libojf kernels instead of torch autograd + MIOpen.
+
+The unit of the reference's Sequentials (modules/model.py:4-52,115-141)
+
+    Conv2d (1x1 / dilated 3x3) -> BatchNorm2d -> ReLU | LeakyReLU | Tanh -> Dropout2d
+
+is ONE autograd node (``LayerUnit``): forward = device-side weight packing, fp32-MFMA convolution, batch statistics
+(+ running-stat update), fused normalise / activation / channel dropout; backward = fused activation / BatchNorm
+backward with its two reductions, the weight-gradient kernel, and backward-data as a convolution with the transposed,
+tap-flipped weights (include/ojf.h ``ojf_train_*``).  Activations are "C4 planes" tensors ``[C/4, H, W, 4]`` (19
+channels in a 20-wide slot, 114 in 116; padding channels are exactly zero), so a concatenation is a ``torch.cat`` along
+dim 0.  Everything around the units - concatenations, the 3x3 average pools, the 1x1 global-average map, the loss - is
+torch on those tensors, and autograd adds up the fan-out gradients.  Parameters, BatchNorm buffers and therefore
+``state_dict`` / optimizer / checkpoint code are the module's own (``model.FusionNet_v3`` / ``_v2``): ``HipTrainNet``
+only walks them.
+
+There is no fallback inside this module: it needs libojf and a GPU.  ``Pipeline.fuse_training`` selects it with
+``FUSION_MODEL.train_engine: hip`` (default) | ``torch``.
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib
+
+_ACT = {None: _lib.ACT_NONE, 'relu': _lib.ACT_RELU, 'leaky': _lib.ACT_LEAKY, 'tanh': _lib.ACT_TANH}
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class LayerUnit(torch.autograd.Function):
+    """conv (+ bias) -> [BatchNorm2d] -> activation -> [Dropout2d scale per channel] on C4 planes."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, meta):
+        lib = _lib.load()
+        dev = x.device
+        st = _lib.stream_ptr(dev)
+        x = x.contiguous()
+        c4_in, H, W, _ = x.shape
+        OC, IC, k, _ = weight.shape
+        c_in_phys, c_out_phys = 4 * c4_in, (OC + 3) // 4 * 4
+        group, slot, dil = meta['group'], meta['slot'], meta['dil']
+        n_packed = lib.ojf_train_packed_floats(c_out_phys, c_in_phys, k)
+        if n_packed == 0:
+            raise _lib.OjfError('LayerUnit: unsupported layer shape %r on %d input planes' % (tuple(weight.shape), c4_in))
+        w = weight.detach().contiguous()
+        packed = torch.empty(n_packed, dtype=torch.float32, device=dev)
+        n_ot = (((c_out_phys + 15) // 16) + 1) // 2 * 2
+        bias_packed = torch.empty(n_ot * 16, dtype=torch.float32, device=dev)
+        _lib.check(lib.ojf_train_pack(w.data_ptr(), _p(bias), OC, IC, k, group, slot, c_in_phys, c_out_phys, 0,
+                                      packed.data_ptr(), bias_packed.data_ptr(), st), 'ojf_train_pack')
+        y = torch.empty((c_out_phys // 4, H, W, 4), dtype=torch.float32, device=dev)
+        _lib.check(lib.ojf_train_conv(x.data_ptr(), 0, c_in_phys, y.data_ptr(), 0, c_out_phys, packed.data_ptr(),
+                                      bias_packed.data_ptr(), k, dil, H, W, st), 'ojf_train_conv')
+        bn = meta['bn']
+        mean = invstd = None
+        training = bool(meta['training'])
+        if bn is not None:
+            mean = torch.empty(c_out_phys, dtype=torch.float32, device=dev)
+            invstd = torch.empty(c_out_phys, dtype=torch.float32, device=dev)
+            partial = torch.empty(lib.ojf_train_partial_doubles(c_out_phys), dtype=torch.float64, device=dev)
+            momentum = 0.1 if bn.momentum is None else float(bn.momentum)
+            _lib.check(lib.ojf_train_bn_stats(y.data_ptr(), 0, c_out_phys, OC, H, W, int(training), momentum, float(bn.eps),
+                                              bn.running_mean.data_ptr(), bn.running_var.data_ptr(), partial.data_ptr(),
+                                              mean.data_ptr(), invstd.data_ptr(), st), 'ojf_train_bn_stats')
+            if training:
+                bn.num_batches_tracked += 1
+        drop = meta['drop']
+        out = torch.empty_like(y)
+        _lib.check(lib.ojf_train_bn_act(y.data_ptr(), 0, out.data_ptr(), 0, c_out_phys, OC, H, W, _p(mean), _p(invstd), _p(gamma), _p(beta),
+                                        _p(drop), _ACT[meta['act']], float(meta['scale']), int(bn is not None), st), 'ojf_train_bn_act')
+        ctx.save_for_backward(x, y, w, gamma, beta, mean, invstd, drop)
+        ctx.meta = dict(meta, training=training, has_bias=bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, y, w, gamma, beta, mean, invstd, drop = ctx.saved_tensors
+        meta = ctx.meta
+        dev = x.device
+        st = _lib.stream_ptr(dev)
+        dout = dout.contiguous()
+        c4_in, H, W, _ = x.shape
+        OC, IC, k, _ = w.shape
+        c_in_phys, c_out_phys = 4 * c4_in, (OC + 3) // 4 * 4
+        group, slot, dil = meta['group'], meta['slot'], meta['dil']
+        has_bn = meta['bn'] is not None
+        dy = torch.empty_like(y)
+        partial = torch.empty(lib.ojf_train_partial_doubles(c_out_phys), dtype=torch.float64, device=dev)
+        red = torch.empty(2 * c_out_phys, dtype=torch.float32, device=dev)
+        dgamma = torch.empty(OC, dtype=torch.float32, device=dev) if gamma is not None else None
+        dbeta = torch.empty(OC, dtype=torch.float32, device=dev) if beta is not None else None
+        dbias = torch.empty(OC, dtype=torch.float32, device=dev) if meta['has_bias'] else None
+        _lib.check(lib.ojf_train_bn_act_bwd(y.data_ptr(), 0, dout.data_ptr(), 0, dy.data_ptr(), 0, c_out_phys, OC, H, W, _p(mean), _p(invstd),
+                                            _p(gamma), _p(beta), _p(drop), _ACT[meta['act']], float(meta['scale']), int(has_bn),
+                                            int(meta['training']), partial.data_ptr(), red.data_ptr(), _p(dgamma), _p(dbeta), _p(dbias), st),
+                   'ojf_train_bn_act_bwd')
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            wpart = torch.empty(lib.ojf_train_wgrad_partial_floats(c_out_phys, c_in_phys, k, H, W), dtype=torch.float32, device=dev)
+            _lib.check(lib.ojf_train_wgrad(x.data_ptr(), 0, c_in_phys, dy.data_ptr(), 0, c_out_phys, OC, IC, k, dil, group, slot, H, W,
+                                           wpart.data_ptr(), dw.data_ptr(), st), 'ojf_train_wgrad')
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # backward-data = convolution of dy with the transposed, tap-flipped weights
+            packed = torch.empty(lib.ojf_train_packed_floats(c_in_phys, c_out_phys, k), dtype=torch.float32, device=dev)
+            _lib.check(lib.ojf_train_pack(w.data_ptr(), None, OC, IC, k, group, slot, c_in_phys, c_out_phys, 1, packed.data_ptr(), None, st),
+                       'ojf_train_pack (transposed)')
+            dx = torch.empty_like(x)
+            _lib.check(lib.ojf_train_conv(dy.data_ptr(), 0, c_out_phys, dx.data_ptr(), 0, c_in_phys, packed.data_ptr(), None, k, dil, H, W, st),
+                       'ojf_train_conv (backward-data)')
+        return dx, dw, dbias, dgamma, dbeta, None
+
+
+class AvgPool3(torch.autograd.Function):
+    """nn.AvgPool2d(3, stride 1, padding 1) (count_include_pad) on C4 planes; the operator is symmetric, so backward is
+    the same launch on the gradient.  (torch's own pooling on the permuted planes view returned wrong input gradients
+    on this ROCm build.)"""
+
+    @staticmethod
+    def _run(x):
+        lib = _lib.load()
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        c4, H, W, _ = x.shape
+        _lib.check(lib.ojf_train_avgpool3(x.data_ptr(), out.data_ptr(), 4 * c4, H, W, _lib.stream_ptr(x.device)), 'ojf_train_avgpool3')
+        return out
+
+    @staticmethod
+    def forward(ctx, x):
+        return AvgPool3._run(x)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return AvgPool3._run(dout)
+
+
+def to_c4(t):
+    """[1, C, H, W] -> C4 planes [ceil(C/4), H, W, 4] (padding channels zero)."""
+    _, C, H, W = t.shape
+    cp = (C + 3) // 4 * 4
+    if cp != C:
+        t = torch.cat([t, t.new_zeros(1, cp - C, H, W)], dim=1)
+    return t.view(cp // 4, 4, H, W).permute(0, 2, 3, 1).contiguous()
+
+
+def from_c4(t, C):
+    """C4 planes -> [1, C, H, W]."""
+    c4, H, W, _ = t.shape
+    return t.permute(0, 3, 1, 2).reshape(1, 4 * c4, H, W)[:, :C]
+
+
+class HipTrainNet:
+    """Runs ``net`` (model.FusionNet_v3 / FusionNet_v2) through ``LayerUnit`` nodes.  ``net.training`` selects batch
+    statistics + dropout (train) or running statistics, no dropout (eval), exactly like the module's own forward."""
+
+    def __init__(self, net):
+        _lib.require_gpu()
+        self.net = net
+
+    # ---- one Sequential of conv/BN/act/dropout slots -> units ------------------------------------------------------
+    def _unit(self, x, conv, bn, act, dropout, group, slot, scale=1.0):
+        training = self.net.training
+        drop = None
+        if dropout is not None and training and dropout.p > 0:
+            keep = 1.0 - dropout.p
+            drop = (torch.rand(conv.out_channels, device=x.device) < keep).float() / keep  # Dropout2d: whole channels
+        meta = dict(group=group, slot=slot, dil=int(conv.dilation[0]), act=act, scale=scale, bn=bn, drop=drop, training=training)
+        return LayerUnit.apply(x, conv.weight, conv.bias, bn.weight if bn is not None else None, bn.bias if bn is not None else None, meta)
+
+    def _sequential(self, x, seq, group, slot, scale=1.0):
+        mods = list(seq)
+        i = 0
+        first = True
+        while i < len(mods):
+            conv = mods[i]
+            assert isinstance(conv, nn.Conv2d), 'HipTrainNet: unexpected module order in a Sequential'
+            i += 1
+            bn = act = drop = None
+            if i < len(mods) and isinstance(mods[i], nn.BatchNorm2d):
+                bn = mods[i]; i += 1
+            if i < len(mods) and isinstance(mods[i], (nn.ReLU, nn.LeakyReLU, nn.Tanh)):
+                act = {nn.ReLU: 'relu', nn.LeakyReLU: 'leaky', nn.Tanh: 'tanh'}[type(mods[i])]; i += 1
+            if i < len(mods) and isinstance(mods[i], nn.Dropout2d):
+                drop = mods[i]; i += 1
+            last = i >= len(mods)
+            g, s = (group, slot) if first else (conv.in_channels, (conv.in_channels + 3) // 4 * 4)
+            x = self._unit(x, conv, bn, act, drop, g, s, scale if last else 1.0)
+            first = False
+        return x
+
+    def _dense(self, x, blocks, c):
+        slot = (c + 3) // 4 * 4
+        for blk in blocks:
+            x = torch.cat([x, self._sequential(x, blk.block, c, slot)], dim=0)
+        return x
+
+    def _vortex(self, x, v, group, slot):
+        """modules/model.py:143-161.  x: C4 planes of in_chs logical channels (`group`-wide tensors in `slot`-wide slots)."""
+        c4, H, W, _ = x.shape
+        dev = x.device
+        # global-average branch: 1x1 map -> conv -> (bilinear up-sampling = broadcast) -> BatchNorm2d.  The BatchNorm
+        # sees a constant map: statistics, running-stat update and gradients are those of any constant map, so a
+        # 2-pixel stand-in gives them (batch variance 0 either way) without materialising the full-size tensor.
+        idx = self._logical_index(group, slot, v.gave_pool[1].in_channels, dev)
+        pooled = x.mean(dim=(1, 2)).reshape(-1)[idx]                       # [in_chs]
+        g = F.conv2d(pooled.view(1, -1, 1, 1), v.gave_pool[1].weight, v.gave_pool[1].bias)
+        bn = v.gave_pool[3]
+        g = F.batch_norm(g.expand(1, -1, 2, 1), bn.running_mean, bn.running_var, bn.weight, bn.bias, self.net.training,
+                         0.1 if bn.momentum is None else bn.momentum, bn.eps)[:, :, :1]
+        if self.net.training:
+            bn.num_batches_tracked += 1
+        out_c = g.shape[1]
+        o4 = (out_c + 3) // 4
+        gp = torch.cat([g.reshape(-1), g.new_zeros(4 * o4 - out_c)]).view(o4, 1, 1, 4).expand(o4, H, W, 4)
+        outs = [gp, self._sequential(x, v.branches[0], group, slot)]
+        xp = x
+        for i in (1, 2, 3):  # nn.AvgPool2d(3, 1, 1), count_include_pad
+            xp = AvgPool3.apply(xp)
+            outs.append(self._sequential(xp, v.branches[i], group, slot))
+        cat = torch.cat(outs, dim=0)
+        return self._sequential(cat, v.final, out_c, 4 * o4)
+
+    def _logical_index(self, group, slot, n_logical, dev):
+        key = (group, slot, n_logical, str(dev))
+        cache = self.__dict__.setdefault('_idx', {})
+        if key not in cache:
+            j = torch.arange(n_logical, device=dev)
+            cache[key] = (j // group) * slot + j % group
+        return cache[key]
+
+    def forward(self, x):
+        """Same contract as the module's forward: dict of NCHW tensors -> [1, n_points, H, W] (times output_scale)."""
+        net = self.net
+        from .model import FusionNet_v3
+        c = net.n_channels
+        slot = (c + 3) // 4 * 4
+        out_c = c * (net.gf + 1)
+        out_slot = (out_c + 3) // 4 * 4
+        if isinstance(net, FusionNet_v3):
+            y = self._vortex(self._dense(to_c4(torch.cat([x['tsdf_values'], x['tsdf_weights'], x['tsdf_frame']], 1)), net.block0, c),
+                             net.vortex0, c, slot)
+            if net.config.use_semantics:
+                s = to_c4(torch.cat([x['tsdf_values'], x['tsdf_weights'], x['semantic_frame']], 1))
+                y = torch.cat([y, self._vortex(self._dense(s, net.block2, c), net.vortex2, c, slot)], dim=0)
+            y = self._vortex(y, net.vortex3, out_c, out_slot)
+        else:
+            parts = [x['tsdf_values'], x['tsdf_weights'], x['tsdf_frame']]
+            if net.config.use_semantics:
+                parts.append(x['semantic_frame'])
+            y = self._vortex(self._dense(to_c4(torch.cat(parts, 1)), net.block, c), net.vortex, c, slot)
+            y = self._vortex(y, net.vortex_final, out_c, out_slot)
+        preds = list(net.pred)
+        for i, p in enumerate(preds):
+            y = self._sequential(y, p.pred, p.pred[0].in_channels, y.shape[0] * 4, net.scale if i == len(preds) - 1 else 1.0)
+        return from_c4(y, net.n_points)
+
+    __call__ = forward

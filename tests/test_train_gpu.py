@@ -1,0 +1,195 @@
+"""-m gpu: the HIP training path of the fusion net (train.py / include/ojf.h ojf_train_*) against torch autograd.
+
+ * ``LayerUnit`` (conv -> BatchNorm2d -> activation -> Dropout2d scale): output, input gradient, weight / bias / gamma /
+   beta gradients and the running-statistics update vs the same unit written with torch ops in float64, for every
+   layer geometry of the net (1x1, dilated 3x3, slotted concatenations, wide outputs).
+ * whole nets (v3 with / without the semantic head, v2): est and ALL parameter gradients vs ``loss.backward()`` through
+   the module's own forward (float64 on the CPU) in train() mode (batch statistics; dropout probability 0, its random
+   stream cannot be shared) and in eval() mode; running statistics after the step.
+Stated tolerance: 1e-4 of the largest magnitude of each tensor, measured ~1e-6."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from online_joint_depthfusion_and_semantic_amd import model
+from online_joint_depthfusion_and_semantic_amd.train import HipTrainNet, LayerUnit, to_c4, from_c4
+
+pytestmark = pytest.mark.gpu
+REL = 1e-4
+
+
+def close(got, want, what):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    scale = float(want.abs().max())
+    err = float((got - want).abs().max())
+    assert err <= REL * max(scale, 1e-30) + 1e-12, (what, err, scale)
+    return err / max(scale, 1e-30)
+
+
+def slotted(x, group, slot):
+    """logical [1, C, H, W] -> physical channels: `group`-wide tensors in `slot`-wide slots."""
+    _, C, H, W = x.shape
+    n = (C + group - 1) // group
+    out = x.new_zeros(1, n * slot, H, W)
+    for s in range(n):
+        k = min(group, C - s * group)
+        out[:, s * slot:s * slot + k] = x[:, s * group:s * group + k]
+    return out
+
+
+@pytest.mark.parametrize('IC,OC,k,dil,group,slot,act,bn,training', [
+    (19, 19, 3, 1, 19, 20, 'leaky', True, True), (57, 19, 3, 1, 19, 20, 'leaky', True, True), (95, 19, 3, 1, 19, 20, 'leaky', True, False),
+    (19, 19, 3, 27, 19, 20, 'relu', True, True), (19, 19, 3, 9, 19, 20, 'relu', True, True), (114, 19, 1, 1, 19, 20, 'relu', True, True),
+    (114, 19, 1, 1, 114, 116, 'relu', True, True), (19, 114, 1, 1, 19, 20, 'relu', True, True), (570, 114, 1, 1, 114, 116, None, True, True),
+    (114, 95, 1, 1, 114, 116, 'leaky', True, True), (19, 19, 1, 1, 19, 20, 'leaky', False, True), (19, 9, 1, 1, 19, 20, 'tanh', False, True),
+    (228, 19, 1, 1, 114, 116, 'relu', True, False)])
+def test_layer_unit_against_torch(cuda, IC, OC, k, dil, group, slot, act, bn, training):
+    H, W = 37, 45
+    g = torch.Generator().manual_seed(IC * 7 + OC + k + dil)
+    x = torch.randn(1, IC, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(OC, IC, k, k, generator=g, dtype=torch.float64) / np.sqrt(IC * k * k)
+    b = torch.randn(OC, generator=g, dtype=torch.float64) * 0.1
+    gamma = torch.rand(OC, generator=g, dtype=torch.float64) + 0.5
+    beta = torch.randn(OC, generator=g, dtype=torch.float64) * 0.1
+    rm, rv = torch.randn(OC, generator=g, dtype=torch.float64) * 0.1, torch.rand(OC, generator=g, dtype=torch.float64) + 0.5
+    drop = ((torch.rand(OC, generator=g) < 0.8).double() / 0.8) if act != 'tanh' else None
+    dout = torch.randn(1, OC, H, W, generator=g, dtype=torch.float64) * 1e-5  # loss gradients are tiny
+    scale = 0.7 if act == 'tanh' else 1.0
+
+    # torch reference in float64
+    xr, wr, br, gr, ber = (t.clone().requires_grad_(True) for t in (x, w, b, gamma, beta))
+    rmr, rvr = rm.clone(), rv.clone()
+    y = F.conv2d(xr, wr, br, padding=dil * (k // 2), dilation=dil)
+    if bn:
+        y = F.batch_norm(y, rmr, rvr, gr, ber, training, 0.1, 1e-5)
+    y = {'relu': F.relu, 'leaky': lambda t: F.leaky_relu(t, 0.01), 'tanh': torch.tanh, None: lambda t: t}[act](y) * scale
+    if drop is not None:
+        y = y * drop.view(1, -1, 1, 1)
+    y.backward(dout)
+
+    f = lambda t: t.float().to(cuda)
+    xs = to_c4(f(slotted(x, group, slot))).requires_grad_(True)
+    wp, bp = f(w).requires_grad_(True), f(b).requires_grad_(True)
+    gp, bep = (f(gamma).requires_grad_(True), f(beta).requires_grad_(True)) if bn else (None, None)
+    bnm = None
+    if bn:
+        bnm = torch.nn.BatchNorm2d(OC).to(cuda)
+        bnm.running_mean.copy_(f(rm)); bnm.running_var.copy_(f(rv))
+    meta = dict(group=group, slot=slot, dil=dil, act=act, scale=scale, bn=bnm, drop=f(drop) if drop is not None else None, training=training)
+    out = LayerUnit.apply(xs, wp, bp, gp, bep, meta)
+    out.backward(to_c4(f(dout)))
+    close(from_c4(out, OC), y, 'out')
+    if out.shape[0] * 4 > OC:  # padding channels stay exactly zero
+        assert float(out.detach().permute(0, 3, 1, 2).reshape(-1, H, W)[OC:].abs().max()) == 0
+    dx_log = from_c4(xs.grad, xs.shape[0] * 4)
+    close(dx_log, slotted(xr.grad, group, slot), 'dx')
+    close(wp.grad, wr.grad, 'dW')
+    if bn and training:  # sum of dy vanishes under batch statistics: compare on the scale of the unnormalised sum
+        assert float(bp.grad.abs().max()) <= 1e-4 * float(dout.abs().sum() / OC) + 1e-12
+    else:
+        close(bp.grad, br.grad, 'db')
+    if bn:
+        close(gp.grad, gr.grad, 'dgamma')
+        close(bep.grad, ber.grad, 'dbeta')
+        close(bnm.running_mean, rmr, 'running_mean')
+        close(bnm.running_var, rvr, 'running_var')
+        assert int(bnm.num_batches_tracked) == (1 if training else 0)
+
+
+def _net(version, sem, h, w, seed=3):
+    cfg = type('C', (), dict(n_points=9, growth_factor=6, use_semantics=sem, output_scale=0.9, resx=w, resy=h))()
+    torch.manual_seed(seed)
+    net = getattr(model, 'FusionNet_' + version)(cfg)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            torch.nn.init.xavier_normal_(m.weight)
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.1)
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0  # the random stream of torch's dropout cannot be shared: parity runs without it
+    return net
+
+
+@pytest.mark.parametrize('training', [True, False])
+@pytest.mark.parametrize('version,sem', [('v3', False), ('v3', True), ('v2', True)])
+def test_whole_net_gradients_against_torch_autograd(cuda, version, sem, training):
+    """est, every parameter gradient and every BatchNorm buffer after one loss.backward() through the whole net.  Truth =
+    the module's own forward in float64.  A 46-layer net with batch statistics amplifies rounding: torch's OWN fp32
+    autograd (the module on the CPU) deviates from float64 by 1e-2 of a gradient's scale in train() mode and 2e-4 in
+    eval() mode (the L1 term's sign flips), so the bar per tensor is: within 1e-4 of its scale, or no further from the
+    float64 truth than 2.5x torch's fp32 deviation on that tensor, or than twice torch fp32's worst relative deviation over
+    all gradients (the rounding-noise level of the net; GPU torch fp32 sits at 1x - 1.5x of it, tools/dbg_train.py)."""
+    h, w = 40, 56
+    net = _net(version, sem, h, w)
+    ref, ref32 = copy.deepcopy(net).double(), copy.deepcopy(net)
+    net = net.to(cuda)
+    for m in (net, ref, ref32):
+        m.train(training)
+    g = torch.Generator().manual_seed(11)
+    x = dict(tsdf_values=(torch.rand(1, 9, h, w, generator=g) - 0.5) * 0.2, tsdf_weights=torch.rand(1, 9, h, w, generator=g) * 4,
+             tsdf_frame=torch.rand(1, 1, h, w, generator=g) * 4, semantic_frame=torch.randint(1, 31, (1, 1, h, w), generator=g).float() / 30)
+    target = (torch.rand(1, 9, h, w, generator=g) - 0.5) * 0.2
+
+    def loss(e, t):
+        return (e - t).abs().mean() + 10 * ((e - t) ** 2).mean()
+    est_ref = ref({k: v.double() for k, v in x.items()})
+    loss(est_ref, target.double()).backward()
+    est32 = ref32(x)
+    loss(est32, target).backward()
+    est = HipTrainNet(net)({k: v.to(cuda) for k, v in x.items()})
+    loss(est, target.to(cuda)).backward()
+
+    gmax = max(float(p.grad.abs().max()) for p in ref.parameters() if p.grad is not None)
+    # torch fp32's own worst relative deviation over all gradients: the rounding noise level of this net
+    noise = max(float((q32.grad.double() - q.grad).abs().max()) / max(float(q.grad.abs().max()), 1e-3 * gmax)
+                for q32, q in zip(ref32.parameters(), ref.parameters()) if q.grad is not None)
+
+    def bar(got, fp32, truth, floor, what):
+        got, fp32, truth = got.detach().cpu().double(), fp32.detach().double(), truth.detach()
+        e, e32 = float((got - truth).abs().max()), float((fp32 - truth).abs().max())
+        assert e <= max(REL * floor, 2.5 * e32, 2.0 * noise * floor), (what, e, e32, floor, noise)
+        return e / max(e32, REL * floor)
+    worst = bar(est, est32, est_ref, float(est_ref.abs().max()), 'est')
+    for (name, p), (_, q32), (_, q) in zip(net.named_parameters(), ref32.named_parameters(), ref.named_parameters()):
+        assert (p.grad is None) == (q.grad is None), name
+        if q.grad is None:
+            continue
+        # gradients that vanish analytically (conv biases in front of a batch-statistics BatchNorm, the global-average
+        # branch's conv) are judged on the scale of the largest gradient of the net
+        worst = max(worst, bar(p.grad, q32.grad, q.grad, max(float(q.grad.abs().max()), 1e-3 * gmax), name))
+    for (name, b), (_, c32), (_, c) in zip(net.named_buffers(), ref32.named_buffers(), ref.named_buffers()):
+        if b.dtype.is_floating_point:
+            bar(b, c32, c, float(c.abs().max()), name)
+        else:
+            assert int(b) == int(c), name
+    print('whole net %s sem=%s training=%s: worst deviation = %.2f x torch fp32\'s own' % (version, sem, training, worst))
+
+
+def test_dropout_channels_in_train_mode(cuda):
+    """Dropout2d semantics of a unit in train() mode: whole channels are zeroed with probability p, survivors scaled by
+    1 / (1 - p); eval() mode is deterministic."""
+    h, w = 24, 32
+    net = _net('v3', False, h, w).to(cuda)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.2
+    x = dict(tsdf_values=torch.rand(1, 9, h, w, device=cuda) * 0.1, tsdf_weights=torch.rand(1, 9, h, w, device=cuda), tsdf_frame=torch.rand(1, 1, h, w, device=cuda))
+    tn = HipTrainNet(net.train())
+    torch.manual_seed(1)
+    a = tn(x)
+    b = tn(x)
+    assert not torch.equal(a, b)  # fresh masks per call
+    blk = net.block0[0].block
+    zeros = 0
+    for _ in range(50):
+        y = tn._sequential(to_c4(torch.cat([x['tsdf_values'], x['tsdf_weights'], x['tsdf_frame']], 1)), blk, 19, 20)
+        per_channel = from_c4(y, 19).abs().amax(dim=(0, 2, 3))
+        zeros += int((per_channel == 0).sum())
+    assert 0.12 <= zeros / (50 * 19) <= 0.28  # p = 0.2 on the second stage's 19 channels
+    tn2 = HipTrainNet(net.eval())
+    assert torch.equal(tn2(x), tn2(x))
