@@ -305,7 +305,7 @@ class Pipeline(torch.nn.Module):
             tn = self.__dict__.get('_hip_train')
             if tn is None or tn.net is not self._fusion_network:
                 from .train import HipTrainNet
-                tn = self.__dict__['_hip_train'] = HipTrainNet(self._fusion_network)
+                tn = self.__dict__['_hip_train'] = HipTrainNet(self._fusion_network, graph=self.config.FUSION_MODEL.get('train_graph', False))
             return tn(inputs)
         return self._fusion_network.forward(inputs)
 

@@ -31,6 +31,31 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+def _packed(lib, cache, w, bias, group, slot, c_in_phys, c_out_phys, transposed, st):
+    """Fragment-layout copy of a weight tensor (ojf_train_pack).  With a cache (HipTrainNet) the packing launch is
+    skipped while the parameter's version counter stands still - weights change once per accumulation window
+    (train_fusion.py:186), not once per frame.  Keyed by storage address, layout and version."""
+    OC, IC, k, _ = w.shape
+    key = ver = None
+    if cache is not None:
+        key = (w.data_ptr(), _p(bias), group, slot, c_in_phys, c_out_phys, transposed)
+        ver = (w._version, bias._version if bias is not None else -1)
+        hit = cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1], hit[2]
+    rows, kch = (c_in_phys, c_out_phys) if transposed else (c_out_phys, c_in_phys)
+    packed = torch.empty(lib.ojf_train_packed_floats(rows, kch, k), dtype=torch.float32, device=w.device)
+    bias_packed = None
+    if not transposed:
+        n_ot = (((c_out_phys + 15) // 16) + 1) // 2 * 2
+        bias_packed = torch.empty(n_ot * 16, dtype=torch.float32, device=w.device)
+    _lib.check(lib.ojf_train_pack(w.data_ptr(), None if transposed else _p(bias), OC, IC, k, group, slot, c_in_phys, c_out_phys,
+                                  int(transposed), packed.data_ptr(), _p(bias_packed), st), 'ojf_train_pack')
+    if cache is not None:
+        cache[key] = (ver, packed, bias_packed)
+    return packed, bias_packed
+
+
 class LayerUnit(torch.autograd.Function):
     """conv (+ bias) -> [BatchNorm2d] -> activation -> [Dropout2d scale per channel] on C4 planes."""
 
@@ -44,15 +69,10 @@ class LayerUnit(torch.autograd.Function):
         OC, IC, k, _ = weight.shape
         c_in_phys, c_out_phys = 4 * c4_in, (OC + 3) // 4 * 4
         group, slot, dil = meta['group'], meta['slot'], meta['dil']
-        n_packed = lib.ojf_train_packed_floats(c_out_phys, c_in_phys, k)
-        if n_packed == 0:
+        if lib.ojf_train_packed_floats(c_out_phys, c_in_phys, k) == 0:
             raise _lib.OjfError('LayerUnit: unsupported layer shape %r on %d input planes' % (tuple(weight.shape), c4_in))
         w = weight.detach().contiguous()
-        packed = torch.empty(n_packed, dtype=torch.float32, device=dev)
-        n_ot = (((c_out_phys + 15) // 16) + 1) // 2 * 2
-        bias_packed = torch.empty(n_ot * 16, dtype=torch.float32, device=dev)
-        _lib.check(lib.ojf_train_pack(w.data_ptr(), _p(bias), OC, IC, k, group, slot, c_in_phys, c_out_phys, 0,
-                                      packed.data_ptr(), bias_packed.data_ptr(), st), 'ojf_train_pack')
+        packed, bias_packed = _packed(lib, meta.get('cache'), w, bias, group, slot, c_in_phys, c_out_phys, False, st)
         y = torch.empty((c_out_phys // 4, H, W, 4), dtype=torch.float32, device=dev)
         _lib.check(lib.ojf_train_conv(x.data_ptr(), 0, c_in_phys, y.data_ptr(), 0, c_out_phys, packed.data_ptr(),
                                       bias_packed.data_ptr(), k, dil, H, W, st), 'ojf_train_conv')
@@ -68,7 +88,11 @@ class LayerUnit(torch.autograd.Function):
                                               bn.running_mean.data_ptr(), bn.running_var.data_ptr(), partial.data_ptr(),
                                               mean.data_ptr(), invstd.data_ptr(), st), 'ojf_train_bn_stats')
             if training:
-                bn.num_batches_tracked += 1
+                counters = meta.get('counters')
+                if counters is not None:
+                    counters.append(bn.num_batches_tracked)  # incremented together after the forward pass
+                else:
+                    bn.num_batches_tracked += 1
         drop = meta['drop']
         out = torch.empty_like(y)
         _lib.check(lib.ojf_train_bn_act(y.data_ptr(), 0, out.data_ptr(), 0, c_out_phys, OC, H, W, _p(mean), _p(invstd), _p(gamma), _p(beta),
@@ -109,9 +133,7 @@ class LayerUnit(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             # backward-data = convolution of dy with the transposed, tap-flipped weights
-            packed = torch.empty(lib.ojf_train_packed_floats(c_in_phys, c_out_phys, k), dtype=torch.float32, device=dev)
-            _lib.check(lib.ojf_train_pack(w.data_ptr(), None, OC, IC, k, group, slot, c_in_phys, c_out_phys, 1, packed.data_ptr(), None, st),
-                       'ojf_train_pack (transposed)')
+            packed, _ = _packed(lib, meta.get('cache'), w, None, group, slot, c_in_phys, c_out_phys, True, st)
             dx = torch.empty_like(x)
             _lib.check(lib.ojf_train_conv(dy.data_ptr(), 0, c_out_phys, dx.data_ptr(), 0, c_in_phys, packed.data_ptr(), None, k, dil, H, W, st),
                        'ojf_train_conv (backward-data)')
@@ -160,18 +182,30 @@ class HipTrainNet:
     """Runs ``net`` (model.FusionNet_v3 / FusionNet_v2) through ``LayerUnit`` nodes.  ``net.training`` selects batch
     statistics + dropout (train) or running statistics, no dropout (eval), exactly like the module's own forward."""
 
-    def __init__(self, net):
+    def __init__(self, net, graph=False):
         _lib.require_gpu()
         self.net = net
+        self._cache = {}      # packed weights by (address, layout) -> (version, tensors)
+        self._counters = []   # num_batches_tracked of the BatchNorms that saw batch statistics in this forward
+        self._rand = None     # one uniform draw per forward for all Dropout2d masks
+        self._rand_at = 0
+        self._masks = {}
+        self.graph = bool(graph)  # capture forward / backward into device graphs (falls back to eager launches if a capture fails)
+        self._graphs = {}
 
     # ---- one Sequential of conv/BN/act/dropout slots -> units ------------------------------------------------------
     def _unit(self, x, conv, bn, act, dropout, group, slot, scale=1.0):
         training = self.net.training
         drop = None
-        if dropout is not None and training and dropout.p > 0:
+        if dropout is not None and training and dropout.p > 0:  # Dropout2d: whole channels, survivors scaled by 1 / keep
+            n = conv.out_channels
             keep = 1.0 - dropout.p
-            drop = (torch.rand(conv.out_channels, device=x.device) < keep).float() / keep  # Dropout2d: whole channels
-        meta = dict(group=group, slot=slot, dil=int(conv.dilation[0]), act=act, scale=scale, bn=bn, drop=drop, training=training)
+            if keep not in self._masks:  # one compare / scale launch per distinct p and forward pass, sliced per layer
+                self._masks[keep] = (self._rand < keep).float() / keep
+            drop = self._masks[keep][self._rand_at:self._rand_at + n]
+            self._rand_at += n
+        meta = dict(group=group, slot=slot, dil=int(conv.dilation[0]), act=act, scale=scale, bn=bn, drop=drop, training=training,
+                    cache=None if torch.cuda.is_current_stream_capturing() else self._cache, counters=self._counters)
         return LayerUnit.apply(x, conv.weight, conv.bias, bn.weight if bn is not None else None, bn.bias if bn is not None else None, meta)
 
     def _sequential(self, x, seq, group, slot, scale=1.0):
@@ -210,15 +244,23 @@ class HipTrainNet:
         # 2-pixel stand-in gives them (batch variance 0 either way) without materialising the full-size tensor.
         idx = self._logical_index(group, slot, v.gave_pool[1].in_channels, dev)
         pooled = x.mean(dim=(1, 2)).reshape(-1)[idx]                       # [in_chs]
-        g = F.conv2d(pooled.view(1, -1, 1, 1), v.gave_pool[1].weight, v.gave_pool[1].bias)
+        gc = v.gave_pool[1]
+        g = torch.addmv(gc.bias, gc.weight.view(gc.out_channels, -1), pooled)  # the 1x1 conv on the 1x1 map
         bn = v.gave_pool[3]
-        g = F.batch_norm(g.expand(1, -1, 2, 1), bn.running_mean, bn.running_var, bn.weight, bn.bias, self.net.training,
-                         0.1 if bn.momentum is None else bn.momentum, bn.eps)[:, :, :1]
         if self.net.training:
-            bn.num_batches_tracked += 1
-        out_c = g.shape[1]
+            # batch statistics of a constant map: mean = the value, variance = 0 -> the output is beta, the gradients
+            # towards g and gamma vanish; running_mean moves towards g, running_var towards 0 (unbiased estimate of 0)
+            m = 0.1 if bn.momentum is None else bn.momentum
+            with torch.no_grad():
+                bn.running_mean.mul_(1 - m).add_(g, alpha=m)
+                bn.running_var.mul_(1 - m)
+            g = bn.bias + (g - g) * bn.weight
+            self._counters.append(bn.num_batches_tracked)
+        else:
+            g = (g - bn.running_mean) * torch.rsqrt(bn.running_var + bn.eps) * bn.weight + bn.bias
+        out_c = g.shape[0]
         o4 = (out_c + 3) // 4
-        gp = torch.cat([g.reshape(-1), g.new_zeros(4 * o4 - out_c)]).view(o4, 1, 1, 4).expand(o4, H, W, 4)
+        gp = torch.cat([g, g.new_zeros(4 * o4 - out_c)]).view(o4, 1, 1, 4).expand(o4, H, W, 4)
         outs = [gp, self._sequential(x, v.branches[0], group, slot)]
         xp = x
         for i in (1, 2, 3):  # nn.AvgPool2d(3, 1, 1), count_include_pad
@@ -236,9 +278,35 @@ class HipTrainNet:
         return cache[key]
 
     def forward(self, x):
-        """Same contract as the module's forward: dict of NCHW tensors -> [1, n_points, H, W] (times output_scale)."""
+        """Same contract as the module's forward: dict of NCHW tensors -> [1, n_points, H, W] (times output_scale).
+        With ``graph=True`` the ~1300 launches of a forward + backward pass are captured once per frame shape and mode
+        into two device graphs and replayed; parameters, BatchNorm buffers and dropout randomness are read / written in
+        place by the replays, so optimizer steps and checkpoints see the same tensors as ever.  Off by default: on ROCm
+        7.2 the replay of that many kernel nodes is SLOWER than launching them (25.0 vs 17.8 ms per 320x240 frame)."""
+        if self.graph and torch.is_grad_enabled():
+            out = self._graphed(x)
+            if out is not None:
+                return out
+        return self._forward_impl(x)
+
+    def _graphed(self, x):
+        net = self.net
+        keys = ['tsdf_values', 'tsdf_weights', 'tsdf_frame'] + (['semantic_frame'] if net.config.use_semantics else [])
+        sig = (net.training, tuple((k, tuple(x[k].shape)) for k in keys), str(x[keys[0]].device))
+        g = self._graphs.get(sig)
+        if g is None:
+            g = self._graphs[sig] = _GraphedPass(self, {k: x[k] for k in keys})
+        if not g.ok:
+            return None
+        return _GraphedFn.apply(g, *([x[k] for k in keys] + g.params))
+
+    def _forward_impl(self, x):
         net = self.net
         from .model import FusionNet_v3
+        self._counters = []
+        if net.training:  # every Dropout2d mask of this pass from one draw (sliced per layer)
+            total = sum(m.out_channels for m in net.modules() if isinstance(m, nn.Conv2d))
+            self._rand, self._rand_at, self._masks = torch.rand(total, device=x['tsdf_values'].device), 0, {}
         c = net.n_channels
         slot = (c + 3) // 4 * 4
         out_c = c * (net.gf + 1)
@@ -259,6 +327,65 @@ class HipTrainNet:
         preds = list(net.pred)
         for i, p in enumerate(preds):
             y = self._sequential(y, p.pred, p.pred[0].in_channels, y.shape[0] * 4, net.scale if i == len(preds) - 1 else 1.0)
+        if self._counters:
+            torch._foreach_add_(self._counters, 1)  # nn.BatchNorm2d.num_batches_tracked, all at once
         return from_c4(y, net.n_points)
 
     __call__ = forward
+
+
+class _GraphedPass:
+    """Forward and backward of a HipTrainNet for one (mode, frame shape) as two device graphs on static tensors (the
+    recipe of torch.cuda.make_graphed_callables, for a callable that walks another module's parameters)."""
+
+    def __init__(self, tn, sample):
+        self.ok = False
+        net = tn.net
+        self.params = [p for p in net.parameters() if p.requires_grad]
+        dev = self.params[0].device
+        try:
+            self.static_in = {k: torch.zeros_like(v, device=dev) for k, v in sample.items()}
+            for k, v in sample.items():
+                self.static_in[k].copy_(v)
+            buffers = [b.clone() for b in net.buffers()]  # the warm-up passes must not count as training steps
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):  # settles lazy allocations (zero-bias vector, rocBLAS handles) outside the capture
+                    out = tn._forward_impl(self.static_in)
+                    torch.autograd.grad(out, self.params, grad_outputs=torch.ones_like(out), allow_unused=True)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            pool = torch.cuda.graph_pool_handle()
+            self.fwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.fwd, pool=pool):
+                self.static_out = tn._forward_impl(self.static_in)
+            self.static_dout = torch.zeros_like(self.static_out)
+            self.bwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.bwd, pool=pool):
+                self.static_grads = torch.autograd.grad(self.static_out, self.params, grad_outputs=self.static_dout, allow_unused=True)
+            with torch.no_grad():
+                for b, saved in zip(net.buffers(), buffers):
+                    b.copy_(saved)
+            self.ok = True
+        except Exception as e:  # capture is an optimisation only; the eager launches remain
+            self.error = e
+            torch.cuda.synchronize(dev)
+
+
+class _GraphedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, *tensors):
+        n_in = len(g.static_in)
+        for dst, src in zip(g.static_in.values(), tensors[:n_in]):
+            dst.copy_(src)
+        g.fwd.replay()
+        ctx.g = g
+        ctx.n_in = n_in
+        return g.static_out.detach().clone()
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = ctx.g
+        g.static_dout.copy_(dout)
+        g.bwd.replay()
+        return (None,) * (1 + ctx.n_in) + tuple(None if t is None else t.clone() for t in g.static_grads)

@@ -115,9 +115,10 @@ def _net(version, sem, h, w, seed=3):
     return net
 
 
+@pytest.mark.parametrize('graph', [True, False])
 @pytest.mark.parametrize('training', [True, False])
 @pytest.mark.parametrize('version,sem', [('v3', False), ('v3', True), ('v2', True)])
-def test_whole_net_gradients_against_torch_autograd(cuda, version, sem, training):
+def test_whole_net_gradients_against_torch_autograd(cuda, version, sem, training, graph):
     """est, every parameter gradient and every BatchNorm buffer after one loss.backward() through the whole net.  Truth =
     the module's own forward in float64.  A 46-layer net with batch statistics amplifies rounding: torch's OWN fp32
     autograd (the module on the CPU) deviates from float64 by 1e-2 of a gradient's scale in train() mode and 2e-4 in
