@@ -245,18 +245,33 @@ __device__ __forceinline__ void finalize_voxel(const IntegrateArgs &a, size_t li
 {
     unsigned int ri = a.head[lin];
     a.head[lin] = 0;  // leave the workspace clean
+    const unsigned int first = ri;
     long long sw = 0, su = 0;
+    bool wrapped = false;
     unsigned int e_last = 0, e_diff = 0;
     while (ri) {  // 2-3 records per voxel; integer sums: any order gives the same bits
         const VoxelRec r = a.recs[ri - 1];
-        sw += (long long)r.w;
-        su += (long long)r.u;
+        wrapped |= __builtin_add_overflow(sw, (long long)r.w, &sw);
+        wrapped |= __builtin_add_overflow(su, (long long)r.u, &su);
         e_last = r.e_last > e_last ? r.e_last : e_last;
         e_diff = r.e_diff > e_diff ? r.e_diff : e_diff;
         ri = r.next;
     }
-    const float W = (float)((double)sw * kFixInv);
-    const float U = (float)((double)su * kFixInv);
+    double Wd = (double)sw * kFixInv, Ud = (double)su * kFixInv;
+    if (wrapped) {
+        // > 5e5 of per-frame weight on one voxel (a degenerate frame: 19 integer bits of the 2^-44 fixed point): the
+        // 64-bit sum wrapped.  Redo it in fp64 over the records - each of them is exact, a tile cannot overflow on its
+        // own - so that the weight saturates to fp16 infinity like the reference's instead of coming out garbage.
+        Wd = 0.0; Ud = 0.0;
+        for (unsigned int rj = first; rj;) {
+            const VoxelRec r = a.recs[rj - 1];
+            Wd += (double)(long long)r.w * kFixInv;
+            Ud += (double)(long long)r.u * kFixInv;
+            rj = r.next;
+        }
+    }
+    const float W = (float)Wd;
+    const float U = (float)Ud;
     const float w_old = h2f(a.wgt[lin]), v_old = h2f(a.tsdf[lin]);  // integrator.py:72-75
     const float w_new = w_old + W;                                   // :77
     const float num = w_old * v_old + U;                             // :82
@@ -388,6 +403,12 @@ OJF_API int ojf_integrate_masked(const float *depth_filtered, const uint8_t *mas
         return integrate_parity(a, cam, base + kHeaderBytes, ws_bytes - kHeaderBytes, st);
     }
     {
+        // The counter-set alternation is host-call-order state: a stream capture would freeze one phase into the graph and
+        // every replay would reuse it (stale `touched` entries after a hash-full frame).  Refuse instead of corrupting.
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+            return fail("ojf_integrate (FAST): not capturable into a HIP graph (the two counter sets alternate per host call); "
+                        "use OJF_MODE_PARITY inside a capture or launch the frame step directly");
         const unsigned phase = next_phase(ws);
         a.counters = reinterpret_cast<unsigned int *>(base) + 32 * phase;
         a.counters_next = reinterpret_cast<unsigned int *>(base) + 32 * (1 - phase);

@@ -51,6 +51,11 @@ class Pipeline(torch.nn.Module):
 
         self._extractor = Extractor(config)
         self._integrator = Integrator(config)
+        # a load_state_dict into the fusion net (any flavour, assign=True included) drops the cached tensor list of the
+        # engine-staleness check at once
+        def _drop_fingerprint(module, incompatible):
+            self.__dict__.pop('_fp_cache', None)  # (a post hook must return None)
+        self._fusion_network.register_load_state_dict_post_hook(_drop_fingerprint)
         mode = getattr(config.SETTINGS, 'integrate_mode', 'fast')
         self._integrate_mode = MODE_PARITY if mode == 'parity' else MODE_FAST
         self._engine = None
@@ -105,7 +110,10 @@ class Pipeline(torch.nn.Module):
             cache = [id(net), list(net.parameters()) + list(net.buffers()), 0]
             self.__dict__['_fp_cache'] = cache
         cache[2] += 1
-        return (len(cache[1]), sum(t._version for t in cache[1]))
+        # version counters see in-place updates (optimizer steps, load_state_dict); storage addresses see
+        # ``p.data = ...``; replaced Parameter objects (load_state_dict(assign=True), swapped sub-modules) are seen by
+        # the load_state_dict hook below at once and by the re-collection within 64 frames otherwise
+        return (len(cache[1]), sum(t._version for t in cache[1]), sum(t.data_ptr() for t in cache[1]) & 0xffffffffffff)
 
     def _get_engine(self, h, w, device):
         arith = self.config.FUSION_MODEL.get('arithmetic', 'f16x3')

@@ -384,3 +384,48 @@ def test_masked_integrate_equals_filtered_frame(cuda, mode, semantics):
     for key in a:
         x, y = a[key], b[key]
         assert torch.equal(x.view(torch.uint8) if x.dtype != torch.uint8 else x, y.view(torch.uint8) if y.dtype != torch.uint8 else y), key
+
+
+def test_fast_mode_weight_overflow_saturates_like_the_reference(cuda):
+    """a degenerate frame (voxels far larger than the scene: every ray lands in the same few voxels) pushes a
+    voxel's per-frame weight beyond the 19 integer bits of the 2^-44 fixed point.  The 64-bit sums wrap; finalize
+    detects it and redoes them in fp64, so the weight saturates to fp16 infinity exactly where the reference's does
+    and the TSDF stays a weighted mean."""
+    h, w, grid, P, T = 480, 640, 4, 17, 15
+    st = make_stream(h, w, grid)
+    st.resolution = 40.0                      # 4^3 voxels of 40 m ...
+    st.origin = np.array([-60.0, -60.0, -60.0])  # ... with the whole room at the centre of voxel (1, 1, 1): corner weights ~1
+    vols = fresh_volumes(grid, False)
+    fi = frame_inputs(st, 1, n_points=P)
+    ref = {k: v.copy() for k, v in vols.items()}
+    oracle.integrate(fi['fd'], fi['Ki'], fi['E'], st.origin, st.resolution, fi['est'], ref['tsdf'], ref['wgt'], n_points=P, n_tail=T)
+    assert np.isinf(ref['wgt'].astype(np.float32)).any()  # 4.6e6 entries of weight ~0.9 on one voxel: beyond 2^19 and beyond fp16
+    g = to_cuda(vols, cuda)
+    ws = ops.IntegrateWorkspace((grid,) * 3, h, w, T, ops.MODE_FAST, cuda)
+    ops.integrate(_t(fi['fd'], cuda), fi['Ki'], fi['E'], st.origin, st.resolution, _t(fi['est'], cuda), g['tsdf'], g['wgt'], ws,
+                  n_points=P, n_tail=T, mode=ops.MODE_FAST)
+    got_w, got_t = g['wgt'].cpu().numpy(), g['tsdf'].cpu().numpy()
+    assert (np.isinf(got_w.astype(np.float32)) == np.isinf(ref['wgt'].astype(np.float32))).all()
+    fin = np.isfinite(ref['wgt'].astype(np.float32))
+    assert f16_ulp_distance(got_w[fin], ref['wgt'][fin]).max() <= 1
+    touched = ref['wgt'] > 0
+    # the reference's sequential fp32 sum of 5e5 terms carries ~1e-3 relative error of its own; ours is the exact sum
+    assert np.abs(got_t[touched].astype(np.float32) - ref['tsdf'][touched].astype(np.float32)).max() <= 2e-3
+
+
+def test_fast_integrate_refuses_stream_capture(cuda):
+    """include/ojf.h: OJF_MODE_FAST alternates two counter sets per HOST call - inside a graph capture it fails loudly
+    instead of freezing one phase into the graph."""
+    from online_joint_depthfusion_and_semantic_amd._lib import OjfError
+    h, w, grid = 24, 32, 16
+    st = make_stream(h, w, grid)
+    fi = frame_inputs(st, 0)
+    g = to_cuda(fresh_volumes(grid, False), cuda)
+    ws = ops.IntegrateWorkspace((grid,) * 3, h, w, 7, ops.MODE_FAST, cuda)
+    fd, est = _t(fi['fd'], cuda), _t(fi['est'], cuda)
+    ops.integrate(fd, fi['Ki'], fi['E'], st.origin, st.resolution, est, g['tsdf'], g['wgt'], ws, mode=ops.MODE_FAST)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with pytest.raises(OjfError, match='not capturable'):
+        with torch.cuda.graph(graph):
+            ops.integrate(fd, fi['Ki'], fi['E'], st.origin, st.resolution, est, g['tsdf'], g['wgt'], ws, mode=ops.MODE_FAST)

@@ -263,3 +263,22 @@ def test_fuse_predict_strategy_matches_reference_golden(cuda, engine):
             assert id_bad <= 56 * flips and sc_ulp.max() <= 1
             assert (np.isnan(got['tsdf']) == np.isnan(g['f%d_tsdf' % i])).all()
             assert td.max() <= (6.2e-5 if flips == 0 else 2e-3)
+
+
+def test_engine_follows_replaced_parameters(cuda):
+    """weights swapped in with load_state_dict(assign=True) (new Parameter objects, version counters reset)
+    or by rebinding ``param.data`` must reach the folded HIP engine on the very next frame."""
+    h, w, grid = 24, 32, 32
+    cfg, st, db, pipe = _setup(h, w, grid, False, False, 'fast', cuda)
+    with torch.no_grad():
+        pipe.fuse(_batch(st, 0, cuda), db, cuda)
+        first = pipe._engine
+        other = Pipeline(cfg)._fusion_network.to(cuda).state_dict()
+        pipe._fusion_network.load_state_dict(other, assign=True)
+        pipe.fuse(_batch(st, 1, cuda), db, cuda)
+        second = pipe._engine
+        assert second is not first
+        for p in pipe._fusion_network.parameters():
+            p.data = p.data.clone() * 1.0001
+        pipe.fuse(_batch(st, 2, cuda), db, cuda)
+        assert pipe._engine is not second
