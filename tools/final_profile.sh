@@ -1,23 +1,29 @@
+# Round profile run (on the GPU box, through gpurun): everything the numbers in DESIGN.md / profiles/ come from.
+# Results land in gpurun_out/final/; tools/collect_profiles.sh copies the summaries into profiles/rNN_*.
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-mkdir -p gpurun_out/final
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > gpurun_out/final/pytest_gpu.txt
-python bench.py > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err
-python bench.py --semantics --steps 100 > gpurun_out/final/bench_sem.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/kt -o kt -- python bench.py --steps 100 --warmup 10 > gpurun_out/final/bench_prof.json 2> gpurun_out/final/kt.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/final/pf -o pf -- python bench.py --steps 20 --warmup 2 > /dev/null 2> gpurun_out/final/pf.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/final/pw -o pw -- python bench.py --steps 20 --warmup 2 > /dev/null 2> gpurun_out/final/pw.err
-find gpurun_out/final -name '*.csv' | head -20
-python bench.py --arith f32 --cpu-frames 0 > gpurun_out/final/bench_f32.json 2>/dev/null
-python bench.py --height 120 --width 160 --grid 64 --cpu-frames 0 > gpurun_out/final/bench_A.json 2>/dev/null
-python bench.py --mode parity --steps 100 --cpu-frames 0 > gpurun_out/final/bench_parity.json 2>/dev/null
-python bench.py --height 480 --width 640 --grid 512 --semantics --steps 60 --warmup 5 --cpu-frames 0 > gpurun_out/final/bench_C.json 2>/dev/null
-python bench.py --height 480 --width 640 --grid 512 --steps 60 --warmup 5 --cpu-frames 0 > gpurun_out/final/bench_Cgeo.json 2>/dev/null
-python bench.py --semantics --semantic-strategy predict --steps 100 --cpu-frames 0 > gpurun_out/final/bench_predict.json 2>/dev/null
-python bench.py --semantics --semantic-strategy predict --seg-engine torch --steps 100 --cpu-frames 0 > gpurun_out/final/bench_predict_torch.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/kp -o kp -- python bench.py --semantics --semantic-strategy predict --steps 50 --warmup 10 --cpu-frames 0 > /dev/null 2> gpurun_out/final/kp.err
-python tools/adapnet_engine_probe.py 2>&1 | grep -v MIOpen > gpurun_out/final/adapnet_engine_probe.txt
-python tools/mesh_timing.py 256 > gpurun_out/final/mesh_timing.txt 2>&1
-python tools/mesh_timing.py 512 >> gpurun_out/final/mesh_timing.txt 2>&1
-python tools/pmc_traffic.py $(find gpurun_out/final/pf -name '*counter_collection.csv' | head -1) $(find gpurun_out/final/pw -name '*counter_collection.csv' | head -1) 22 gpurun_out/final/traffic_pmc.json > gpurun_out/final/traffic_pmc.txt 2>&1
+O=gpurun_out/final
+rm -rf $O; mkdir -p $O
+python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/pytest_gpu.txt
+python bench.py > $O/bench.json 2> $O/bench.err
+B="python bench.py --steps 100 --warmup 10 --cpu-frames 0 --secondary 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- $B > $O/bench_under_rocprof.json 2> $O/kt.err
+python tools/kernel_trace_summary.py $(find $O/kt -name '*kernel_trace.csv' | head -1) 110 60 > $O/kernel_trace_summary.txt 2>&1
+cp $(find $O/kt -name '*kernel_stats.csv' | head -1) $O/bench_kernel_stats.csv
+S="python bench.py --steps 20 --warmup 2 --cpu-frames 0 --secondary 0"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pf -o pf -- $S > /dev/null 2> $O/pf.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pw -o pw -- $S > /dev/null 2> $O/pw.err
+python tools/pmc_traffic.py $(find $O/pf -name '*counter_collection.csv' | head -1) $(find $O/pw -name '*counter_collection.csv' | head -1) 22 $O/traffic_pmc.json > $O/traffic_pmc.txt 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $O/sq -o sq -- $S > /dev/null 2> $O/sq.err
+python tools/pmc_sq_summary.py $(find $O/sq -name '*counter_collection.csv' | head -1) $O/sq_counters.json > $O/sq_counters.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kp -o kp -- python bench.py --semantics --semantic-strategy predict --steps 50 --warmup 10 --cpu-frames 0 --secondary 0 > $O/bench_predict.json 2> $O/kp.err
+cp $(find $O/kp -name '*kernel_stats.csv' | head -1) $O/predict_kernel_stats.csv
+python tools/train_throughput.py > $O/train_throughput.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktr -o ktr -- python tools/train_throughput.py > /dev/null 2> $O/ktr.err
+cp $(find $O/ktr -name '*kernel_stats.csv' | head -1) $O/train_kernel_stats.csv
+python tools/adapnet_engine_probe.py 2>&1 | grep -v MIOpen > $O/adapnet_engine_probe.txt
+python bench.py --mode parity --steps 100 --cpu-frames 0 --secondary 0 > $O/bench_parity.json 2>/dev/null
+python bench.py --height 120 --width 160 --grid 64 --cpu-frames 0 --secondary 0 > $O/bench_A.json 2>/dev/null
+rm -rf $O/kt $O/pf $O/pw $O/sq $O/kp $O/ktr
+ls -la $O
