@@ -35,6 +35,18 @@ struct Camera {
 Camera make_camera(const float *Ki, const float *E, const double *origin, double res);
 
 // fp16 bit pattern <-> fp32 (round-to-nearest-even on the way down, like torch .half())
+// Low halves of the split-fp16 operands: fp16(x0 - hi.lo), fp16(x1 - hi.hi) packed like `hpair` (the two fp16 high
+// halves of x0, x1).  v_fma_mix{lo,hi}_f16 forms x - hi exactly in fp32 and rounds once to fp16: the same bits as
+// converting, subtracting and converting again, in 2 instructions instead of 5 (clang folds the source-level
+// fma(hi, -1, x) into a subtraction before it can select the mix form, hence the assembly).
+__device__ __forceinline__ unsigned split_lo_pair(unsigned hpair, float x0, float x1)
+{
+    unsigned r;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpair), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(hpair), "v"(x1));
+    return r;
+}
+
 __device__ __forceinline__ float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 __device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
 

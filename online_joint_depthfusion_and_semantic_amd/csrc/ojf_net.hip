@@ -61,14 +61,16 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // x (8 fp32 values) -> fp16 halves xh + xl, both rounded to nearest; x - xh is exact in fp32
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split_f16(const f32x4 &a, const f32x4 &b, f16x8 &hi, f16x8 &lo)
 {
     const f32x8 x = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-    hi = __builtin_convertvector(x, f16x8);
-    f32x8 r;  // x - hi, exact; written as an fma so that the fp16 -> fp32 conversion folds into v_fma_mix_f32
+    hi = __builtin_convertvector(x, f16x8);  // 4 x v_cvt_pk_f16_f32
+    const u32x4 h = __builtin_bit_cast(u32x4, hi);
+    u32x4 l;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r[i] = __builtin_fmaf((float)hi[i], -1.0f, x[i]);
-    lo = __builtin_convertvector(r, f16x8);
+    for (int i = 0; i < 4; ++i) l[i] = split_lo_pair(h[i], x[2 * i], x[2 * i + 1]);
+    lo = __builtin_bit_cast(f16x8, l);
 }
 
 // acc += W * X for one 16x16 tile over a 32-wide K block, W and X given as split halves
@@ -220,7 +222,16 @@ __device__ __forceinline__ void build_tap_table16(int2 *tab, const ConvArgs &a, 
 // loads, 4 = no MFMA, 8 = no per-superstep index math.  Product launches always use ABL = 0.
 struct ConvGroup {
     ConvArgs g[4];  // independent convolutions of identical tile shape run as one launch (blockIdx.y)
+    int nblocks;    // XCD-banded launches: pixel blocks of the image (gridDim.x is that rounded up to 8); 0 = plain order
 };
+
+// Block b of a launch is observed to run on XCD b % 8 (private 4 MB L2 each).  With gridDim.x a multiple of 8 this
+// hands every XCD one contiguous band of the image, so that the rows the 3x3 taps of neighbouring blocks share are
+// fetched into ONE L2 instead of eight.  A pure speed choice: any placement computes the same result.
+__device__ __forceinline__ int xcd_band_block(int b, int n8) { return (b & 7) * (n8 >> 3) + (b >> 3); }
+// 1-D pixel-block grids (the pointwise kernels): banded whenever the grid is a multiple of 8, so that every kernel of
+// the frame maps the same band of the image to the same XCD (a producer's lines are still in the consumer's L2)
+__device__ __forceinline__ int banded_block_x() { return (gridDim.x & 7) == 0 ? xcd_band_block(blockIdx.x, gridDim.x) : (int)blockIdx.x; }
 
 // SKIP: skip supersteps whose every source pixel lies outside the image (worth it for dilation 9 / 27);
 // without it the loop body is one basic block and the scheduler interleaves the next fetch's address
@@ -358,13 +369,15 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const ConvGroup grp)
 {
     constexpr int CS = conv16_chunk(NT);
     const ConvArgs &a = grp.g[blockIdx.y];
+    const int sb = grp.nblocks ? xcd_band_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    if (grp.nblocks && sb >= grp.nblocks) return;  // padding block of a banded launch
     extern __shared__ int2 tab[];  // (nsteps + kPad16) * 8 entries, sized by the launch: LDS per block bounds the waves in flight
     __shared__ f32x4 wl[CS * NT * 128];
     build_tap_table16(tab, a, (a.nsteps + kPad16) * 8);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
-    const int strip = (blockIdx.x * 4 + wave) * (MT * 16);  // waves past the image still take part in the barriers
+    const int strip = (sb * 4 + wave) * (MT * 16);  // waves past the image still take part in the barriers
 
     // vm: bit t set <=> tap t of this lane's pixel lies inside the image (bit 0 only for 1x1); p16: byte offset
     int p16[MT];
@@ -717,7 +730,7 @@ __global__ __launch_bounds__(256, 3) void chain1x1_kernel(const ChainArgs a)
     __shared__ f32x4 wlds[kChainLdsFloat4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
-    const int strip = (blockIdx.x * 4 + wave) * (MT * 16);
+    const int strip = (banded_block_x() * 4 + wave) * (MT * 16);
     int p[MT];
     f32x4 x[MT][8], y[MT][8];
 #pragma unroll
@@ -809,7 +822,7 @@ __global__ __launch_bounds__(256, 3) void entry1x1_kernel(const ChainArgs a)
     __shared__ float red[4 * 128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
-    const int strip = (blockIdx.x * 4 + wave) * (MT * 16);
+    const int strip = (banded_block_x() * 4 + wave) * (MT * 16);
     f32x4 pre[kChainPre];
     int buf = 0;
     {
@@ -892,7 +905,7 @@ __global__ __launch_bounds__(256, 3) void vortex_tail_kernel(const TailArgs a)
     __shared__ float red[CHAIN == kTailEntry ? 4 * 128 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
-    const int strip = (blockIdx.x * 4 + wave) * (MT * 16);
+    const int strip = (banded_block_x() * 4 + wave) * (MT * 16);
     int p[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) p[m] = strip + m * 16 + i16;
@@ -987,7 +1000,8 @@ struct PyramidArgs {
     f32x4 *q[3];           // branch inputs out: planes of c4 groups each
     const float *bias[3];  // per branch: c4*4 floats
     int h, w, c4;
-    int tiles;      // pixel tiles; block column `tiles` (when launched) folds the global-average branch instead
+    int tiles;      // pixel tiles; with fold_gave, block column `tiles` folds the global-average branch instead
+    int fold_gave;
     GaveArgs gave;
 };
 
@@ -999,7 +1013,8 @@ template <int LV>
 __device__ __forceinline__ void pool_pyramid_body(const PyramidArgs &a, f32x4 (&buf)[2][kPoolStride * (kPoolTH + 6)], int cg)
 {
     const int tiles_x = (a.w + kPoolTW - 1) / kPoolTW;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int tile = banded_block_x();
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int x0 = tx * kPoolTW, y0 = ty * kPoolTH, npix = a.h * a.w;
     const f32x4 *plane = a.z + (size_t)(LV * a.c4 + cg) * npix;
     const f32x4 zero{0.f, 0.f, 0.f, 0.f};
@@ -1052,8 +1067,9 @@ __device__ __forceinline__ void gave_bias_block(const GaveArgs &a, float *mean, 
 __global__ __launch_bounds__(256) void pool_pyramid_kernel(const PyramidArgs a)
 {
     __shared__ f32x4 buf[2][kPoolStride * (kPoolTH + 6)];
-    if ((int)blockIdx.x >= a.tiles) {  // one extra block: the global-average branch -> bias of the final conv (hidden behind the pools)
-        if (blockIdx.y == 0) gave_bias_block(a.gave, reinterpret_cast<float *>(buf), reinterpret_cast<float *>(buf) + 256);
+    if (banded_block_x() >= a.tiles) {  // one of the padding blocks: the global-average branch -> bias of the final conv (hidden behind the pools)
+        if (blockIdx.y == 0 && banded_block_x() == a.tiles && a.fold_gave)
+            gave_bias_block(a.gave, reinterpret_cast<float *>(buf), reinterpret_cast<float *>(buf) + 256);
         return;
     }
     const int lv = blockIdx.y / a.c4 + 1, cg = blockIdx.y - (lv - 1) * a.c4;  // levels of this block's group
@@ -1512,6 +1528,8 @@ static int launch_pair(const PackedPair &pp, const float *in, int in_g0, float *
     a.in_g0 = in_g0; a.c4_in = pp.c4_in; a.out_g0 = out_g0; a.og_store = pp.og_store;
     a.h = h; a.w = w; a.npix = h * w; a.tiles_x = 0;
     a.n_chunks = pp.n_chunks; a.np_last = pp.np_last; a.np_b = pp.np_b;
+    static const bool no_band = getenv("OJF_NO_XCD_BAND") != nullptr;  // tuning switch only
+    a.xcd_bands = no_band ? 0 : 1;
     a.ovf = overflow_flag();
 #ifdef OJF_PAIR_TIMING
     a.dbg = g_pair_dbg;
@@ -1529,6 +1547,7 @@ static int launch_conv_args(const ConvArgs *args, int n, int nt, hipStream_t st,
     ConvGroup grp;
     for (int i = 0; i < n; ++i) grp.g[i] = args[i];
     for (int i = n; i < 4; ++i) grp.g[i] = args[0];
+    grp.nblocks = 0;
     // one wave computes ALL output-channel tiles of its pixel strip (activations are fetched once);
     // MT (16-pixel tiles per wave) trades operand reuse against the number of waves in flight.
     // fp32: MT = 1 everywhere: 4800 waves over 1024 SIMDs quantise to 5 rounds where MT = 2 (2400 waves) needs 3
@@ -1543,7 +1562,14 @@ static int launch_conv_args(const ConvArgs *args, int n, int nt, hipStream_t st,
     int max_steps = 0;
     for (int i = 0; i < n; ++i) max_steps = args[i].nsteps > max_steps ? args[i].nsteps : max_steps;
     const size_t tab_bytes = (size_t)(max_steps + kPad16) * 8 * sizeof(int2);  // (no measurable effect vs the full 8.6 KB)
-#define OJF_LAUNCH16(MT_, NT_) hipLaunchKernelGGL((conv_f16x3_kernel<MT_, NT_>), grid, block, tab_bytes, st, grp)
+    // split-fp16 launches hand every XCD one band of the image (xcd_band_block)
+    static const bool no_band = getenv("OJF_NO_XCD_BAND") != nullptr;  // tuning switch only
+    dim3 grid16 = grid;
+    if (arith == OJF_ARITH_F16X3 && !no_band && grid.x >= 64) {
+        grp.nblocks = (int)grid.x;
+        grid16.x = round_up((int)grid.x, 8);
+    }
+#define OJF_LAUNCH16(MT_, NT_) hipLaunchKernelGGL((conv_f16x3_kernel<MT_, NT_>), grid16, block, tab_bytes, st, grp)
     if (arith == OJF_ARITH_F16X3 && mt == 2) {
         switch (nt) {
             case 2: OJF_LAUNCH16(2, 2); break;
@@ -1917,7 +1943,9 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
         pa.h = h; pa.w = w; pa.c4 = c4;
         pa.tiles = ((w + kPoolTW - 1) / kPoolTW) * ((h + kPoolTH - 1) / kPoolTH);
         pa.gave = gave_args(net, v, nullptr, 0, 0, sc.colsum);
-        hipLaunchKernelGGL(pool_pyramid_kernel, dim3(pa.tiles + (chain_flow ? 1 : 0), 3 * c4), dim3(256), 0, st, pa);
+        pa.fold_gave = chain_flow ? 1 : 0;
+        // grid.x: the tiles (+ the global-average block of the chain flow) rounded up to a multiple of 8 (XCD bands)
+        hipLaunchKernelGGL(pool_pyramid_kernel, dim3(round_up(pa.tiles + (chain_flow ? 1 : 0), 8), 3 * c4), dim3(256), 0, st, pa);
         mark_launch("pool_pyramid_kernel", st);
         OJF_HIP(hipGetLastError());
     }

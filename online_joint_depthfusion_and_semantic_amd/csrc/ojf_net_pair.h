@@ -60,6 +60,7 @@ struct PairArgs {
     int h, w, npix, tiles_x;
     int n_chunks, np_last;  // chunks of 4 channel pairs; pairs in the last chunk (1..4)
     int np_b;               // channel pairs of the intermediate (1..3)
+    int xcd_bands;          // 1: tile = xcd_band_block(blockIdx.x) (tuning switch)
     int *ovf;               // split-fp16 range guard flag
 #ifdef OJF_PAIR_TIMING
     long long *dbg;         // profiling builds only (tools/microbench/pair_bench.hip): s_memtime stamps of block 0
@@ -117,7 +118,9 @@ __global__ __launch_bounds__(512) void dense_pair_kernel(const PairArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, g = lane >> 4;
-    const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
+    // (tile rows banded over the XCDs when the grid allows it: neighbouring tiles share their halo rows in one L2)
+    const int tile = (gridDim.x & 7) == 0 && a.xcd_bands ? xcd_band_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     const int x0 = tx * TW, y0 = ty * TH;
     const int last = a.n_chunks - 1, nkb_b = (9 * a.np_b + 3) >> 2;
 #ifdef OJF_PAIR_TIMING
@@ -252,14 +255,12 @@ __global__ __launch_bounds__(512) void dense_pair_kernel(const PairArgs a)
                 for (int j = 0; j < 4; ++j) v[j] = ok ? (lin[j] > 0.0f ? lin[j] : 0.01f * lin[j]) : 0.0f;
                 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
                 const f16x4 h4 = __builtin_convertvector(v, f16x4);
-                f32x4 r;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) r[j] = __builtin_fmaf((float)h4[j], -1.0f, v[j]);
-                const f16x4 l4 = __builtin_convertvector(r, f16x4);
+                const uint2 hp = __builtin_bit_cast(uint2, h4);
+                const uint2 l4 = uint2{split_lo_pair(hp.x, v[0], v[1]), split_lo_pair(hp.y, v[2], v[3])};
                 uint2 *dh = reinterpret_cast<uint2 *>(tl + pr * 2 * TP + s) + (g & 1);
                 uint2 *dl = reinterpret_cast<uint2 *>(tl + pr * 2 * TP + TP + s) + (g & 1);
                 *dh = __builtin_bit_cast(uint2, h4);
-                *dl = __builtin_bit_cast(uint2, l4);
+                *dl = l4;
             }
         }
     }

@@ -35,14 +35,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split8(const f32x4 &a, const f32x4 &b, f16x8 &hi, f16x8 &lo)
 {
     const f32x8 x = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
     hi = __builtin_convertvector(x, f16x8);
-    f32x8 r;
+    const u32x4 h = __builtin_bit_cast(u32x4, hi);
+    u32x4 l;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r[i] = __builtin_fmaf((float)hi[i], -1.0f, x[i]);  // exact remainder
-    lo = __builtin_convertvector(r, f16x8);
+    for (int i = 0; i < 4; ++i) l[i] = ojf::split_lo_pair(h[i], x[2 * i], x[2 * i + 1]);  // exact remainder, rounded once
+    lo = __builtin_bit_cast(f16x8, l);
 }
 
 __device__ __forceinline__ f32x4 mfma3(const f32x4 &wh, const f32x4 &wl, const f16x8 &xh, const f16x8 &xl, f32x4 acc)

@@ -18,6 +18,7 @@ static float time_variant(const PackedConv &pc, float *in, float *out, int h, in
     a.c4 = pc.c_in_phys / 4; a.nsteps = (pc.taps * a.c4 + 3) / 4;
     a.og_store = pc.c_out_phys / 4; a.act = OJF_ACT_RELU; a.act_n = pc.c_out_phys; a.scale = 1.0f;
     ConvGroup grp;
+    grp.nblocks = 0;
     for (int i = 0; i < 4; ++i) grp.g[i] = a;
     const int strips = (a.npix + MT * 16 - 1) / (MT * 16);
     dim3 grid((strips + 3) / 4, 1), block(256);

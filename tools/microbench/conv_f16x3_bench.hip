@@ -51,6 +51,7 @@ static void run_shape(const char *name, int cin, int cout, int k, int dil, int h
     fill_conv_args(a32, p32, in, 0, out, 0, nullptr, OJF_ACT_LEAKY, cout_p, 1.0f, h, w);
     fill_conv_args(a16, p16, in, 0, out, 0, nullptr, OJF_ACT_LEAKY, cout_p, 1.0f, h, w);
     ConvGroup g32, g16;
+    g32.nblocks = g16.nblocks = 0;
     for (int i = 0; i < 4; ++i) { g32.g[i] = a32; g16.g[i] = a16; }
     const int strips1 = (npix + 15) / 16, strips = (npix + MT * 16 - 1) / (MT * 16);
     const dim3 grid1((strips1 + 3) / 4, ngroup), grid((strips + 3) / 4, ngroup), block(256);
@@ -69,6 +70,8 @@ int main()
     const int h = 240, w = 320;
     // dense block today: K grows
     run_shape<2, 2>("3x3 19->19", 19, 19, 3, 1, h, w, 1);
+    run_shape<2, 2>("3x3 19->19", 19, 19, 3, 1, h, w, 4);
+    run_shape<2, 2>("3x3 19->19 d9", 19, 19, 3, 9, h, w, 4);
     run_shape<2, 2>("3x3 38->19", 38, 19, 3, 1, h, w, 1);
     run_shape<2, 2>("3x3 57->19", 57, 19, 3, 1, h, w, 1);
     run_shape<2, 2>("3x3 76->19", 76, 19, 3, 1, h, w, 1);
