@@ -35,6 +35,13 @@ struct Camera {
 Camera make_camera(const float *Ki, const float *E, const double *origin, double res);
 
 // fp16 bit pattern <-> fp32 (round-to-nearest-even on the way down, like torch .half())
+// Block b of a launch is observed to run on XCD b % 8 (8 XCDs with a private 4 MB L2 each).  For a 1-D grid that is a
+// multiple of 8 this renumbers the blocks so that every XCD works on ONE contiguous eighth of the range - for pixel
+// tiles: one band of the image, the same band in every kernel of the frame, so that what neighbouring tiles share and
+// what the previous kernel wrote is found in the XCD's own L2.  A pure speed choice: any placement computes the same.
+__device__ __forceinline__ int xcd_band_block(int b, int n8) { return (b & 7) * (n8 >> 3) + (b >> 3); }
+__device__ __forceinline__ int banded_block_x() { return (gridDim.x & 7) == 0 ? xcd_band_block(blockIdx.x, gridDim.x) : (int)blockIdx.x; }
+
 // Low halves of the split-fp16 operands: fp16(x0 - hi.lo), fp16(x1 - hi.hi) packed like `hpair` (the two fp16 high
 // halves of x0, x1).  v_fma_mix{lo,hi}_f16 forms x - hi exactly in fp32 and rounds once to fp16: the same bits as
 // converting, subtracting and converting again, in 2 instructions instead of 5 (clang folds the source-level

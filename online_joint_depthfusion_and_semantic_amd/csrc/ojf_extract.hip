@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64 * kMaxTilePoints) void extract_tile_kernel(Extra
     __shared__ float pcl[3][64];
     const int N = a.h * a.w;
     const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
-    const int n = blockIdx.x * 64 + lane;
+    const int n = banded_block_x() * 64 + lane;  // one band of the image per XCD: neighbouring rays gather the same lines
     if (k == 0 && n < N) {
         const int r = n / a.w, c = n - r * a.w;
         float pw[3];

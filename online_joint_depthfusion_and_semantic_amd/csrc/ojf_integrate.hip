@@ -80,7 +80,8 @@ __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(Integra
     }
     if (threadIdx.x == 0) { n_entries = 0; n_new = 0; n_rec = 0; }
     const int tiles_x = (a.w + 7) >> 3;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int tile = banded_block_x();  // one band of the image per XCD: neighbouring tiles hit the same voxels
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     if (threadIdx.x < 64) {  // once per pixel instead of once per (pixel, sample): three fp64 divisions and a sqrt each
         const int p = threadIdx.x;
         const int r = ty * 8 + (p >> 3), c = tx * 8 + (p & 7);
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(Integra
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        base_rec = blockIdx.x * kSlots;
+        base_rec = tile * kSlots;
         if (a.stats) {  // test / profiling only: same-line atomics cost 14 us per frame
             atomicAdd(&a.stats[1], n_entries);
             atomicAdd(&a.stats[2], n_rec);
@@ -186,8 +187,8 @@ __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(Integra
         if (prev[j] == 0) newlist[atomicAdd(&n_new, 1u)] = r.lin;
     }
     __syncthreads();
-    if (threadIdx.x == 0) a.tile_new[blockIdx.x] = n_new;
-    for (unsigned int i = threadIdx.x; i < n_new; i += 256) a.touched[blockIdx.x * kSlots + i] = newlist[i];
+    if (threadIdx.x == 0) a.tile_new[tile] = n_new;
+    for (unsigned int i = threadIdx.x; i < n_new; i += 256) a.touched[tile * kSlots + i] = newlist[i];
 }
 
 // Entry-list variant for the reference's own Integrator.forward signature (modules/integrator.py:15-126):
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(256) void integrate_finalize_kernel(IntegrateArgs a
 {
     const unsigned int per_pixel = (unsigned int)a.n_tail * 8u;  // entries per sem_ids / sem_scores element
     const bool sem = a.id_vol != nullptr;
-    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    for (int tile = banded_block_x(); tile < a.n_tiles; tile += gridDim.x) {  // (the XCD that accumulated the tile)
         const unsigned int n = a.tile_new[tile];
         for (unsigned int i = threadIdx.x; i < n; i += blockDim.x) finalize_voxel(a, a.touched[(size_t)tile * kSlots + i], per_pixel, sem);
         if (a.stats && threadIdx.x == 0 && n) atomicAdd(&a.stats[0], n);

@@ -225,13 +225,7 @@ struct ConvGroup {
     int nblocks;    // XCD-banded launches: pixel blocks of the image (gridDim.x is that rounded up to 8); 0 = plain order
 };
 
-// Block b of a launch is observed to run on XCD b % 8 (private 4 MB L2 each).  With gridDim.x a multiple of 8 this
-// hands every XCD one contiguous band of the image, so that the rows the 3x3 taps of neighbouring blocks share are
-// fetched into ONE L2 instead of eight.  A pure speed choice: any placement computes the same result.
-__device__ __forceinline__ int xcd_band_block(int b, int n8) { return (b & 7) * (n8 >> 3) + (b >> 3); }
-// 1-D pixel-block grids (the pointwise kernels): banded whenever the grid is a multiple of 8, so that every kernel of
-// the frame maps the same band of the image to the same XCD (a producer's lines are still in the consumer's L2)
-__device__ __forceinline__ int banded_block_x() { return (gridDim.x & 7) == 0 ? xcd_band_block(blockIdx.x, gridDim.x) : (int)blockIdx.x; }
+// (xcd_band_block / banded_block_x: ojf_common.h)
 
 // SKIP: skip supersteps whose every source pixel lies outside the image (worth it for dilation 9 / 27);
 // without it the loop body is one basic block and the scheduler interleaves the next fetch's address
