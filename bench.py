@@ -130,12 +130,12 @@ def pmc_traffic(c):
     """HBM bytes per frame per kernel REPLAYED from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in
     separate runs of this bench, tools/pmc_traffic.py; FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes) - not
     observed by this run.  Only valid for the workload the passes were taken on; otherwise None."""
-    for name in ('r02_traffic_pmc.json', 'r01_traffic_pmc.json'):
-        path = os.path.join(ROOT, 'profiles', name)
-        if os.path.exists(path):
-            break
-    else:
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_*traffic_pmc.json')))
+    if not found:
         return None, None
+    path = found[-1]  # the latest round's passes
+    name = os.path.basename(path)
     if (c['h'], c['w'], c['grid'], c['semantics'], c['arith']) != (240, 320, 256, False, 'f16x3'):
         return None, None
     with open(path) as f:

@@ -20,8 +20,10 @@ for k, c in sorted(acc.items()):
               'wait_any_share': c['SQ_WAIT_ANY'] / wc, 'wait_inst_share': c['SQ_WAIT_INST_ANY'] / wc,
               'active_inst_share': c['SQ_ACTIVE_INST_ANY'] / wc, 'active_valu_share': c['SQ_ACTIVE_INST_VALU'] / wc,
               'mfma_busy_cycles_per_dispatch': c['SQ_VALU_MFMA_BUSY_CYCLES'] / max(n[k], 1),
-              'sq_busy_cycles_per_dispatch': c['SQ_BUSY_CYCLES'] / max(n[k], 1)}
+              'sq_busy_cycles_per_dispatch': c['SQ_BUSY_CYCLES'] / max(n[k], 1),
+              # MFMA pipe time per dispatch if spread evenly over the 1024 SIMDs at the nominal 2.4 GHz: compare with the launch's duration
+              'mfma_busy_us_per_simd_per_dispatch': c['SQ_VALU_MFMA_BUSY_CYCLES'] / max(n[k], 1) / 1024 / 2400.0}
     o = out[k]
-    print('%-44s parked %.2f  issue-stall %.2f  issuing %.2f (VALU %.2f)' %
-          (k[:44], o['wait_any_share'], o['wait_inst_share'], o['active_inst_share'], o['active_valu_share']))
+    print('%-44s parked %.2f  issue-stall %.2f  issuing %.2f (VALU %.2f)  MFMA pipe %.2f us/SIMD/dispatch' %
+          (k[:44], o['wait_any_share'], o['wait_inst_share'], o['active_inst_share'], o['active_valu_share'], o['mfma_busy_us_per_simd_per_dispatch']))
 json.dump(out, open(sys.argv[2], 'w'), indent=1, sort_keys=True)
