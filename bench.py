@@ -216,7 +216,7 @@ class Case:
     def fuse(self, i):
         self.pipe.fuse(self.batches[i % len(self.batches)], self.db, self.dev)
 
-    def run(self, steps, warmup, sync, profile_frames=32):
+    def run(self, steps, warmup, sync, profile_frames=32, kernel_reps=5):
         pipe = self.pipe
         with torch.no_grad():
             pipe.profile = False
@@ -238,11 +238,11 @@ class Case:
             pipe.reset_profile()
             for i in range(profile_frames):
                 self.fuse(warmup + steps + i)
-            stages_all = pipe.stage_times_ms()
+            stages_all = pipe.stage_times_ms() if profile_frames else {}
             pipe.profile = False
             # per-kernel table of the fusion net: profiled forwards on the last frame's packed input
             table = {}
-            reps = 5
+            reps = kernel_reps
             for _ in range(reps):
                 for k, (name, us) in enumerate(pipe._engine.profile(pipe._est)):
                     ent = table.setdefault(name, [0, 0.0])
@@ -352,6 +352,9 @@ def main():
     ap.add_argument('--cpu-frames', type=int, default=4, help='timed frames of the CPU baseline (0 = skip)')
     ap.add_argument('--secondary', type=int, default=None,
                     help='steps of each secondary workload (default: 60 when the headline runs with default flags on 1 GPU, else 0)')
+    ap.add_argument('--lean', action='store_true',
+                    help='counter-collection runs (tools/final_profile.sh): only warm-up + timed frames are fused - no stage-mark '
+                         'pass, no profiled forwards, no secondary / CPU legs - so every kernel runs exactly steps + warmup times per launch site')
     ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL, default) | gloo (validation of the N>1 path on a 1-GPU box)')
     args = ap.parse_args()
 
@@ -382,6 +385,14 @@ def main():
     default_flags = head == dict(h=240, w=320, grid=256, semantics=False, strategy='gt', seg_engine='hip', mode='fast',
                                  arith='f16x3', n_classes=30)
     case = Case(head, dev, rank, args.steps + args.warmup)
+    if args.lean:
+        res = case.run(args.steps, args.warmup, sync, profile_frames=0, kernel_reps=0)
+        if rank == 0:
+            r = report(case, res, args.steps, args.warmup, world, full=False)
+            print(json.dumps({'metric': 'frames/sec fused (%dx%d, %d^3 grid)' % (args.width, args.height, args.grid), 'value': r['value'],
+                              'unit': 'frames/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': r['ms_per_step'],
+                              'lean': True, 'frames_fused': args.steps + args.warmup, 'stages_ms': r['stages_ms']}))
+        return
     res = case.run(args.steps, args.warmup, sync)
     elapsed = res['elapsed']
     if world > 1:

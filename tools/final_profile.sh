@@ -7,16 +7,11 @@ O=gpurun_out/final
 rm -rf $O; mkdir -p $O
 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/pytest_gpu.txt
 python bench.py > $O/bench.json 2> $O/bench.err
-B="python bench.py --steps 100 --warmup 10 --cpu-frames 0 --secondary 0"
+B="python bench.py --steps 100 --warmup 10 --lean"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- $B > $O/bench_under_rocprof.json 2> $O/kt.err
-python tools/kernel_trace_summary.py $(find $O/kt -name '*kernel_trace.csv' | head -1) 110 60 > $O/kernel_trace_summary.txt 2>&1
+python tools/kernel_trace_summary.py $(find $O/kt -name '*kernel_trace.csv' | head -1) 0 60 > $O/kernel_trace_summary.txt 2>&1
 cp $(find $O/kt -name '*kernel_stats.csv' | head -1) $O/bench_kernel_stats.csv
-S="python bench.py --steps 20 --warmup 2 --cpu-frames 0 --secondary 0"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pf -o pf -- $S > /dev/null 2> $O/pf.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pw -o pw -- $S > /dev/null 2> $O/pw.err
-python tools/pmc_traffic.py $(find $O/pf -name '*counter_collection.csv' | head -1) $(find $O/pw -name '*counter_collection.csv' | head -1) 0 $O/traffic_pmc.json > $O/traffic_pmc.txt 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $O/sq -o sq -- $S > /dev/null 2> $O/sq.err
-python tools/pmc_sq_summary.py $(find $O/sq -name '*counter_collection.csv' | head -1) $O/sq_counters.json > $O/sq_counters.txt 2>&1
+bash tools/pmc_profile.sh $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kp -o kp -- python bench.py --semantics --semantic-strategy predict --steps 50 --warmup 10 --cpu-frames 0 --secondary 0 > $O/bench_predict.json 2> $O/kp.err
 cp $(find $O/kp -name '*kernel_stats.csv' | head -1) $O/predict_kernel_stats.csv
 python tools/train_throughput.py > $O/train_throughput.txt 2>&1

@@ -1,11 +1,14 @@
 """Per-kernel time per frame from a rocprofv3 --kernel-trace CSV: groups the dispatches of the steady-state frames by
-kernel name AND grid size (the dense_pair / conv launches of different layers share a name), prints mean microseconds."""
+kernel name AND grid size (the dense_pair / conv launches of different layers share a name), prints mean microseconds.
+usage: kernel_trace_summary.py kernel_trace.csv n_frames(0 = count the extract dispatches) [index of the frame to list]"""
 import csv
 import sys
 from collections import defaultdict
 
 path, frames = sys.argv[1], int(sys.argv[2])
 rows = list(csv.DictReader(open(path)))
+if frames == 0:  # the frames the traced run fused = its extract dispatches (one per frame on the inference path)
+    frames = sum(1 for r in rows if 'extract_tile_kernel' in r['Kernel_Name'])
 acc = defaultdict(list)
 for r in rows:
     name = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('ojf::', '')
