@@ -47,7 +47,9 @@
 // GEMM, pool pyramid, two grouped launches of the four branches' dilated 3x3, fused tail}; the last tail also runs
 // the 11-layer prediction head: 22 launches on the main stream.  Environment switches (tuning / ablation only):
 // OJF_CONV_MT, OJF_NO_TAIL, OJF_NO_CHAIN, OJF_NO_HEAD_FUSION, OJF_NET_GRAPH=1 (opt-in hipGraph replay).
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -1729,6 +1731,8 @@ struct ojf_net {
         hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_entry = nullptr;
     } sc[2];
     hipStream_t head1 = nullptr;  // stream of the second head
+    hipStream_t head_paired_with = nullptr;  // launch stream head1 was tested against (pair_head_stream)
+    bool head_paired = false;
     hipEvent_t ev_head_fork = nullptr, ev_head_join = nullptr;
     // (per set: T cs | Z 4*cs entry-conv output | Q1..Q3 cs pool-pyramid outputs | U, V 4*cs outputs of the branches'
     //  first / closing 3x3 | partial kSumBlocks*256 | side stream + events of the global-average branch)
@@ -2265,6 +2269,68 @@ OJF_API int ojf_net_prepare_input(ojf_net *net, const float *values, const float
 
 namespace ojf {
 
+// Two HIP streams only run concurrently when the runtime maps them to different hardware queues (a small round-robin
+// pool): a second-head stream that aliases the launch stream's queue silently serialises the two heads (measured:
+// net stage 0.60 -> 0.70 ms for the two-head net when the library is used by the third engine of a process).  The
+// pairing is therefore TESTED once per (net, launch stream): two 150 us spin kernels, one per stream, take ~150 us
+// when the streams overlap and ~300 us when they do not; up to 8 fresh streams are tried per role.
+__global__ void spin_kernel(long long cycles)
+{
+    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+    while ((long long)__builtin_amdgcn_s_memtime() - t0 < cycles) __builtin_amdgcn_s_sleep(32);
+}
+
+static double spin_pair_us(hipStream_t a, hipStream_t b, long long cycles)
+{
+    (void)hipStreamSynchronize(a);
+    (void)hipStreamSynchronize(b);
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, cycles);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, cycles);
+    (void)hipStreamSynchronize(a);
+    (void)hipStreamSynchronize(b);
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// makes `s` a stream that overlaps with every stream of `others` (replaces it by fresh ones until the test passes)
+static void pair_stream(hipStream_t &s, const hipStream_t *others, int n, double alone, long long cycles, const char *what)
+{
+    static const bool dbg = getenv("OJF_DEBUG_STREAMS") != nullptr;
+    std::vector<hipStream_t> rejected;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        double worst = 0.0;
+        for (int k = 0; k < n; ++k) {
+            const double both = spin_pair_us(others[k], s, cycles);
+            worst = both > worst ? both : worst;
+        }
+        if (dbg) fprintf(stderr, "ojf: %s stream, attempt %d: one spin %.0f us, one per stream %.0f us\n", what, attempt, alone, worst);
+        if (worst < 1.5 * alone) break;  // overlaps with all of them
+        // the replacement is created while the rejected streams still exist: a stream created right after a destroy
+        // gets the freed queue slot again
+        hipStream_t fresh = nullptr;
+        if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) break;
+        rejected.push_back(s);
+        s = fresh;
+    }
+    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+}
+
+static void pair_head_stream(ojf_net *net, hipStream_t st)
+{
+    if (net->heads != 2 || (net->head_paired && net->head_paired_with == st) || !net->head1) return;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;  // not inside a capture
+    net->head_paired_with = st;
+    net->head_paired = true;
+    const long long cycles = 300000;  // ~130 us
+    const double alone = spin_pair_us(st, st, cycles) * 0.5;  // two spins back to back on one stream
+    pair_stream(net->head1, &st, 1, alone, cycles, "second head");
+    // the side streams of the legacy VortexPooling flow (global-average branch, branch 0): each must overlap with the
+    // stream of ITS head (only three queues ran concurrently in every test, so four-way distinctness is not asked for)
+    if (net->sc[1].side) pair_stream(net->sc[1].side, &net->head1, 1, alone, cycles, "head 1 side");
+    if (net->sc[0].side) pair_stream(net->sc[0].side, &st, 1, alone, cycles, "head 0 side");
+}
+
 // every launch of one forward pass, in order, on `st` (+ the side stream, forked and joined with events)
 static int forward_launches(ojf_net *net, float *est, int est_stride, hipStream_t st)
 {
@@ -2281,6 +2347,7 @@ static int forward_launches(ojf_net *net, float *est, int est_stride, hipStream_
     static const bool serial_heads = getenv("OJF_SERIAL_HEADS") != nullptr;  // ablation switch only
     if (net->version == 3) {
         const bool two = net->heads == 2;
+        if (two && !serial_heads) pair_head_stream(net, st);
         hipStream_t s1 = (two && !serial_heads) ? net->head1 : st;
         if (two && s1 != st) {  // the semantic head runs beside the geometric one
             OJF_HIP(hipEventRecord(net->ev_head_fork, st));

@@ -7,4 +7,4 @@ if not line:
     print(out.stdout[-2000:], out.stderr[-2000:]); sys.exit(1)
 d = json.loads(line[-1])
 print(' | '.join('%s %.1f' % (k['kernel'][:28], k['us_per_frame']) for k in d.get('kernels', [])))
-print('fps %.1f ms/step %.3f stages %s mfma_frac %.3f hbm_frac %.4f' % (d['value'], d['ms_per_step'], {k: round(v, 3) for k, v in d['stages_ms'].items()}, d['roofline']['frac'], d['roofline_hbm']['frac']), os.environ.get('OJF_CONV_MT'))
+print('fps %.1f ms/step %.3f stages %s' % (d['value'], d['ms_per_step'], {k: round(v, 3) for k, v in d['stages_ms'].items()}), os.environ.get('OJF_CONV_MT') or '')
