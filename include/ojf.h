@@ -217,12 +217,13 @@ int ojf_segconv_forward(const ojf_segconv *conv, const float *in_dev, int in_str
  * ojf_train_pack: torch weights [OC][IC][k][k] (+ bias [OC]) -> fragment layout of the fp32-MFMA conv kernel, on the
  *   device; transposed != 0 packs the transposed, tap-flipped form whose convolution is the backward-data pass.
  * ojf_train_conv: y = conv(x) + bias on planes (c_out_phys of any size; dilation for 3x3).
- * ojf_train_bn_stats: batch mean and 1/sqrt(var + eps) per channel (biased variance, fp64 sums in a fixed order) and
- *   the running-statistics update of nn.BatchNorm2d (momentum, unbiased variance); training == 0: from the running
- *   statistics instead.  partial: ojf_train_partial_doubles(c_phys) doubles of scratch.
  * ojf_train_bn_act: out = drop[c] * scale * act(gamma[c] * (y - mean[c]) * invstd[c] + beta[c]) (has_bn == 0: act(y)).
+ *   With has_bn: mean and 1/sqrt(var + eps) per channel are computed here - training != 0: batch statistics (biased
+ *   variance, fp64 sums over pixel slabs added in a fixed order) plus the running-statistics update of nn.BatchNorm2d
+ *   (momentum, unbiased variance); training == 0: from the running statistics - and returned in mean / invstd for the
+ *   backward pass.  partial: ojf_train_partial_doubles(c_phys) doubles of scratch.
  * ojf_train_bn_act_bwd: gradient of that w.r.t. y (batch-statistics form when training != 0), gamma, beta and the
- *   convolution's bias.  red: 2 * c_phys floats of scratch.
+ *   convolution's bias.
  * ojf_train_wgrad: dW[oc][ic][tap] = sum_p dy[oc][p] * x[ic][p + tap] into torch's layout; partial:
  *   ojf_train_wgrad_partial_floats(...) floats of scratch (pixel slabs, added in slab order: deterministic). */
 size_t ojf_train_packed_floats(int c_out_phys, int c_in_phys, int ksize);
@@ -233,15 +234,13 @@ int ojf_train_conv(const float *in_dev, int in_g0, int c_in_phys, float *out_dev
 /* nn.AvgPool2d(3, 1, 1) on planes (count_include_pad); symmetric: the same call is its backward pass. */
 int ojf_train_avgpool3(const float *in_dev, float *out_dev, int c_phys, int h, int w, ojf_stream_t stream);
 size_t ojf_train_partial_doubles(int c_phys);
-int ojf_train_bn_stats(const float *y_dev, int y_g0, int c_phys, int c, int h, int w, int training, float momentum, float eps,
-                       float *running_mean_dev, float *running_var_dev, double *partial_dev, float *mean_dev, float *invstd_dev,
-                       ojf_stream_t stream);
-int ojf_train_bn_act(const float *y_dev, int y_g0, float *out_dev, int out_g0, int c_phys, int c, int h, int w, const float *mean_dev,
-                     const float *invstd_dev, const float *gamma_dev, const float *beta_dev, const float *drop_dev, int act,
-                     float scale, int has_bn, ojf_stream_t stream);
+int ojf_train_bn_act(const float *y_dev, int y_g0, float *out_dev, int out_g0, int c_phys, int c, int h, int w, const float *gamma_dev,
+                     const float *beta_dev, const float *drop_dev, int act, float scale, int has_bn, int training, float momentum,
+                     float eps, float *running_mean_dev, float *running_var_dev, double *partial_dev, float *mean_dev,
+                     float *invstd_dev, ojf_stream_t stream);
 int ojf_train_bn_act_bwd(const float *y_dev, int y_g0, const float *dout_dev, int dout_g0, float *dy_dev, int dy_g0, int c_phys, int c,
                          int h, int w, const float *mean_dev, const float *invstd_dev, const float *gamma_dev, const float *beta_dev,
-                         const float *drop_dev, int act, float scale, int has_bn, int training, double *partial_dev, float *red_dev,
+                         const float *drop_dev, int act, float scale, int has_bn, int training, double *partial_dev,
                          float *dgamma_dev, float *dbeta_dev, float *dbias_dev, ojf_stream_t stream);
 size_t ojf_train_wgrad_partial_floats(int c_out_phys, int c_in_phys, int ksize, int h, int w);
 int ojf_train_wgrad(const float *x_dev, int x_g0, int c_in_phys, const float *dy_dev, int dy_g0, int c_out_phys, int oc, int ic,

@@ -8,14 +8,13 @@
 // tensors, so that autograd accumulates the fan-out gradients and the reference's optimizer / checkpoint code runs
 // unchanged.  All convolutions here use the fp32-input MFMA kernel (conv_mfma_kernel: bitwise a k-ordered fmaf chain):
 // gradients are tiny (d loss / d est ~ 1e-6) and of unbounded dynamic range - the split-fp16 arithmetic of the
-// inference path would need loss scaling; fp32 MFMA runs at the fp32 vector rate, which is also what the weight-
-// gradient kernel (plain v_fma_f32, register-tiled) reaches.
+// inference path would need loss scaling; the weight gradient runs on the fp32 MFMA as well (K = pixels).
 //
 //   ojf_train_pack          torch weights [oc][ic][k][k] -> the conv kernel's fragment layout, on the device, every step:
 //                           forward form, or transposed + tap-flipped form (backward-data IS a convolution with it)
 //   ojf_train_conv          convolution on C4 planes (any c_out: chunks of 8 output tiles per launch)
-//   ojf_train_bn_stats      per-channel batch mean / 1 / sqrt(var + eps) (fp64 sums, fixed order) + running-stat update
-//   ojf_train_bn_act        out = drop_c * act(gamma_c * (y - mean_c) * invstd_c + beta_c)
+//   ojf_train_bn_act        per-channel batch mean / 1 / sqrt(var + eps) (fp64 sums, fixed order) + running-stat update, then
+//                           out = drop_c * act(gamma_c * (y - mean_c) * invstd_c + beta_c)
 //   ojf_train_bn_act_bwd    dgamma, dbeta, dbias and dy = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat))
 //   ojf_train_wgrad         dW[oc][ic][tap] = sum_p dy[oc][p] * x[ic][p + tap]  (pixel slabs -> partial sums -> fixed-order sum)
 #pragma once
@@ -93,39 +92,20 @@ __global__ __launch_bounds__(256) void train_stats_partial_kernel(const f32x4 *y
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-struct StatsArgs {
-    const double *partial;  // [slabs][c4][8]
-    int c4, C, npix, training;
-    float momentum, eps;
-    float *running_mean, *running_var;  // [C] (updated when training; read in eval mode)
-    float *mean, *invstd;               // [c4 * 4] out
-};
-
-__global__ __launch_bounds__(256) void train_stats_finish_kernel(const StatsArgs a)
+// Totals of the kTrainSlabs partial rows of channel group cg (8 doubles each: what the partial kernels wrote), formed
+// by every block that needs them instead of a one-block "finish" launch per layer (two of the six small kernels a layer
+// used to cost): lane b of the calling wave takes row b, an xor butterfly adds them - a fixed tree, every lane and
+// every block get bit-identical totals.
+static_assert(kTrainSlabs == 64, "one partial row per lane");
+__device__ __forceinline__ void train_group_totals(const double *partial, int c4, int cg, double (&tot)[8])
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= a.c4 * 4) return;
-    if (c >= a.C) { a.mean[c] = 0.0f; a.invstd[c] = 0.0f; return; }  // padding channels stay exactly zero
-    if (!a.training) {
-        a.mean[c] = a.running_mean[c];
-        a.invstd[c] = 1.0f / sqrtf(a.running_var[c] + a.eps);
-        return;
+    const double *row = partial + ((size_t)(threadIdx.x & 63) * c4 + cg) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        double v = row[j];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        tot[j] = v;
     }
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < kTrainSlabs; ++b) {
-        const double *row = a.partial + ((size_t)b * a.c4 + (c >> 2)) * 8;
-        s += row[c & 3];
-        q += row[4 + (c & 3)];
-    }
-    const double n = (double)a.npix, m = s / n;
-    double var = q / n - m * m;
-    var = var < 0.0 ? 0.0 : var;
-    a.mean[c] = (float)m;
-    a.invstd[c] = (float)(1.0 / sqrt(var + (double)a.eps));
-    // nn.BatchNorm2d: running = (1 - momentum) * running + momentum * batch (variance: the unbiased estimate)
-    a.running_mean[c] = (1.0f - a.momentum) * a.running_mean[c] + a.momentum * (float)m;
-    const double unbiased = a.npix > 1 ? var * n / (n - 1.0) : var;
-    a.running_var[c] = (1.0f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
 }
 
 // ---- normalise + activation + channel dropout ----------------------------------------------------------------------
@@ -137,10 +117,15 @@ struct BnActArgs {
     const float *mean, *invstd;       // [c4 * 4] (identity when has_bn == 0)
     const float *gamma, *beta;        // [C] or NULL
     const float *drop;                // [C] per-channel Dropout2d scale (0 or 1 / (1 - p)) or NULL
-    const float *red;                 // backward apply: [c4 * 4][2] = {mean(dz), mean(dz * xhat)}
     double *partial;                  // backward reduce: [slabs][c4][8]
     int y_g0, out_g0, dout_g0, dy_g0, c4, C, npix, act, has_bn, training;
     float scale;                      // output scale of the last layer (tanh(.) * output_scale)
+    // forward with BatchNorm: statistics are finished in the kernel's prologue (train_group_totals of `partial`, or the
+    // running statistics in eval mode); block column 0 publishes mean / invstd and updates the running statistics
+    float *mean_out, *invstd_out, *running_mean, *running_var;
+    float momentum, eps;
+    // backward: block column 0 publishes the parameter gradients
+    float *dgamma, *dbeta, *dbias;
 };
 
 __device__ __forceinline__ float train_act(float z, int act)
@@ -165,8 +150,8 @@ __device__ __forceinline__ void train_channel_consts(const BnActArgs &a, int cg,
     for (int j = 0; j < 4; ++j) {
         const int c = 4 * cg + j;
         const bool real = c < a.C;
-        mu[j] = a.has_bn ? a.mean[c] : 0.0f;
-        is[j] = real ? (a.has_bn ? a.invstd[c] : 1.0f) : 0.0f;
+        mu[j] = (a.has_bn && a.mean) ? a.mean[c] : 0.0f;  // (forward: overwritten from the prologue's statistics)
+        is[j] = real ? ((a.has_bn && a.invstd) ? a.invstd[c] : 1.0f) : 0.0f;
         ga[j] = real ? (a.gamma ? a.gamma[c] : 1.0f) : 0.0f;
         be[j] = real ? (a.beta ? a.beta[c] : 0.0f) : 0.0f;
         dr[j] = real ? (a.drop ? a.drop[c] : 1.0f) : 0.0f;
@@ -176,8 +161,42 @@ __device__ __forceinline__ void train_channel_consts(const BnActArgs &a, int cg,
 __global__ __launch_bounds__(256) void train_bn_act_fwd_kernel(const BnActArgs a)
 {
     const int cg = blockIdx.y;
+    __shared__ float stat[8];  // mean[4], invstd[4] of this group
+    if (a.has_bn) {
+        if (threadIdx.x < 64) {
+            double tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (a.training) train_group_totals(a.partial, a.c4, cg, tot);
+            if (threadIdx.x < 4) {
+                const int j = threadIdx.x, c = 4 * cg + j;
+                float m = 0.0f, is = 0.0f;  // padding channels stay exactly zero
+                if (c < a.C && !a.training) {
+                    m = a.running_mean[c];
+                    is = 1.0f / sqrtf(a.running_var[c] + a.eps);
+                } else if (c < a.C) {
+                    const double n = (double)a.npix, md = tot[j] / n;
+                    double var = tot[4 + j] / n - md * md;
+                    var = var < 0.0 ? 0.0 : var;
+                    m = (float)md;
+                    is = (float)(1.0 / sqrt(var + (double)a.eps));
+                    if (blockIdx.x == 0) {
+                        // nn.BatchNorm2d: running = (1 - momentum) * running + momentum * batch (variance: the unbiased estimate)
+                        a.running_mean[c] = (1.0f - a.momentum) * a.running_mean[c] + a.momentum * m;
+                        const double unbiased = a.npix > 1 ? var * n / (n - 1.0) : var;
+                        a.running_var[c] = (1.0f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
+                    }
+                }
+                stat[j] = m; stat[4 + j] = is;
+                if (blockIdx.x == 0) { a.mean_out[c] = m; a.invstd_out[c] = is; }
+            }
+        }
+        __syncthreads();
+    }
     f32x4 mu, is, ga, be, dr;
     train_channel_consts(a, cg, mu, is, ga, be, dr);
+    if (a.has_bn) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { mu[j] = stat[j]; is[j] = 4 * cg + j < a.C ? stat[4 + j] : 0.0f; }
+    }
     const f32x4 *yp = a.y + (size_t)(a.y_g0 + cg) * a.npix;
     f32x4 *op = a.out + (size_t)(a.out_g0 + cg) * a.npix;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < a.npix; p += gridDim.x * blockDim.x) {
@@ -228,45 +247,36 @@ __global__ __launch_bounds__(256) void train_bn_bwd_reduce_kernel(const BnActArg
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-struct BnBwdFinishArgs {
-    const double *partial;
-    int c4, C, npix, has_bn, training;
-    const float *gamma, *invstd;
-    float *dgamma, *dbeta, *dbias;  // [C] each (NULL: skip)
-    float *red;                     // [c4 * 4][2] means for the apply kernel
-};
-
-__global__ __launch_bounds__(256) void train_bn_bwd_finish_kernel(const BnBwdFinishArgs a)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= a.c4 * 4) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < kTrainSlabs; ++b) {
-        const double *row = a.partial + ((size_t)b * a.c4 + (c >> 2)) * 8;
-        s1 += row[c & 3];
-        s2 += row[4 + (c & 3)];
-    }
-    const bool batch = a.has_bn && a.training;
-    a.red[2 * c] = batch ? (float)(s1 / (double)a.npix) : 0.0f;
-    a.red[2 * c + 1] = batch ? (float)(s2 / (double)a.npix) : 0.0f;
-    if (c >= a.C) return;
-    if (a.dgamma) a.dgamma[c] = (float)s2;
-    if (a.dbeta) a.dbeta[c] = (float)s1;
-    if (a.dbias) {
-        // sum_p dy: zero under batch statistics (the normalisation removes the mean), gamma * invstd * sum(dz) otherwise
-        const float gi = a.has_bn ? (a.gamma ? a.gamma[c] : 1.0f) * a.invstd[c] : 1.0f;
-        a.dbias[c] = batch ? 0.0f : (float)(s1 * (double)gi);
-    }
-}
-
 __global__ __launch_bounds__(256) void train_bn_bwd_apply_kernel(const BnActArgs a)
 {
     const int cg = blockIdx.y;
     f32x4 mu, is, ga, be, dr;
     train_channel_consts(a, cg, mu, is, ga, be, dr);
+    // the two reductions are finished here (see train_group_totals); block column 0 publishes the parameter gradients
+    __shared__ float means[8];
+    if (threadIdx.x < 64) {
+        double tot[8];
+        train_group_totals(a.partial, a.c4, cg, tot);
+        if (threadIdx.x < 4) {
+            const int j = threadIdx.x, c = 4 * cg + j;
+            const bool batch = a.has_bn && a.training;
+            means[j] = batch ? (float)(tot[j] / (double)a.npix) : 0.0f;          // mean(dz)
+            means[4 + j] = batch ? (float)(tot[4 + j] / (double)a.npix) : 0.0f;  // mean(dz * xhat)
+            if (blockIdx.x == 0 && c < a.C) {
+                if (a.dgamma) a.dgamma[c] = (float)tot[4 + j];
+                if (a.dbeta) a.dbeta[c] = (float)tot[j];
+                if (a.dbias) {
+                    // sum_p dy: zero under batch statistics (the normalisation removes the mean), gamma * invstd * sum(dz) otherwise
+                    const float gi = a.has_bn ? (a.gamma ? a.gamma[c] : 1.0f) * a.invstd[c] : 1.0f;
+                    a.dbias[c] = batch ? 0.0f : (float)(tot[j] * (double)gi);
+                }
+            }
+        }
+    }
+    __syncthreads();
     f32x4 m1, m2;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { m1[j] = a.red[2 * (4 * cg + j)]; m2[j] = a.red[2 * (4 * cg + j) + 1]; }
+    for (int j = 0; j < 4; ++j) { m1[j] = means[j]; m2[j] = means[4 + j]; }
     const f32x4 *yp = a.y + (size_t)(a.y_g0 + cg) * a.npix;
     const f32x4 *gp = a.dout + (size_t)(a.dout_g0 + cg) * a.npix;
     f32x4 *dp = a.dy + (size_t)(a.dy_g0 + cg) * a.npix;
@@ -285,71 +295,93 @@ __global__ __launch_bounds__(256) void train_bn_bwd_apply_kernel(const BnActArgs
 }
 
 // ---- weight gradient -----------------------------------------------------------------------------------------------
-// dW[oc][ic][tap] = sum_p dy[oc][p] * x[ic][p + offset(tap)] (zero outside the image).  Block = TY x TX threads, each a
-// 4 x 4 (oc, ic) register tile, one tap and one pixel slab per block; the slab is staged through LDS 32 pixels at a time
-// in the planes' own [pixel][channel] order (float4 = 4 channels), so a thread's operands are two broadcast-friendly
-// ds_read_b128 per pixel for 16 FMAs.  Partial sums per slab go to `partial`; wgrad_reduce_kernel adds the slabs in
-// order and writes torch's [OC][IC][k][k] layout (physical input channels un-slotted).
+// dW[oc][ic][tap] = sum_p dy[oc][p] * x[ic][p + offset(tap)] (zero outside the image) on the fp32 MFMA, K = pixels.
+// Partial sums per pixel slab go to `partial`; wgrad_reduce_kernel adds the slabs in order and writes torch's
+// [OC][IC][k][k] layout (physical input channels un-slotted).  (Round 2 started with a register-tiled fp32 FMA kernel -
+// 4 x 4 (oc, ic) tile per thread, 40-80 us per layer; the MFMA form takes 12-36 us on the same layers.)
 struct WgradArgs {
     const f32x4 *x;   // input planes of the forward conv (window at x_g0, c4_in groups)
     const f32x4 *dy;  // gradient planes of its output (window at dy_g0, c4_out groups)
-    float *partial;   // [slabs][taps][ocp][icp], ocp = oc blocks * TY * 4, icp = ic blocks * TX * 4
+    float *partial;   // [slabs][taps][ocp][icp], ocp / icp = channel counts rounded up to 32
     int x_g0, c4_in, dy_g0, c4_out, h, w, npix, taps, dil, slabs, ocp, icp;
 };
 
-constexpr int kWgPix = 32;
+// One wave (= one block) = one 32 x 32 (oc, ic) tile of ONE tap over one
+// pixel slab, D += A * B with v_mfma_f32_32x32x2_f32, K = 2 pixels per instruction: lane (r = lane % 32, k = lane / 32)
+// supplies A[r][k] = dy[oc0 + r][p + k] and B[k][r] = x[ic0 + r][p + k + tap offset].  The C4 planes hold 4 channels
+// per 16 bytes, so those scalars are transposed through LDS: per 64-pixel chunk every lane fetches ITS pixel's eight
+// float4 of dy and of x (1 KB contiguous per wave instruction; taps outside the image, channels outside the tensor and
+// pixels outside the slab become zeros here) and writes them as a [pixel][32 channels] row (pitch 36 floats:
+// conflict-free float4 writes), then 32 K steps read one float per lane and operand.  (Fetching the scalars straight
+// from global memory - 16 sixteen-byte segments per wave load - ran at a quarter of the MFMA rate: the L1 address
+// path, not the pipe, was the bound.)  Same `partial` layout as the VALU kernel ([slab][tap][ocp][icp], ocp / icp
+// multiples of 32), same fixed-order reduction afterwards.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kWgChunk = 64, kWgPitch = 36;
 
-template <int TY, int TX>
-__global__ __launch_bounds__(TY * TX) void train_wgrad_kernel(const WgradArgs a)
+__global__ __launch_bounds__(64) void train_wgrad_mfma_kernel(const WgradArgs a, unsigned w_magic)
 {
-    constexpr int NT = TY * TX, OCB = TY * 4, ICB = TX * 4;
-    __shared__ f32x4 dyl[kWgPix * TY];  // [pixel][oc group]
-    __shared__ f32x4 xl[kWgPix * TX];   // [pixel][ic group]
-    const int tid = threadIdx.x, ty = tid / TX, tx = tid - ty * TX;
-    const int n_icb = a.icp / ICB;
-    const int ob = blockIdx.y / n_icb, ib = blockIdx.y - ob * n_icb;
+    __shared__ __attribute__((aligned(16))) float tile[2][kWgChunk * kWgPitch];
+    const int lane = threadIdx.x, r = lane & 31, k = lane >> 5;
+    const int n_it = a.icp / 32;
+    const int ot = blockIdx.y / n_it, it = blockIdx.y - ot * n_it;
     const int tap = blockIdx.z;
     int dyo = 0, dxo = 0;
     if (a.taps == 9) { dyo = (tap / 3 - 1) * a.dil; dxo = (tap % 3 - 1) * a.dil; }
-    const int per = (a.npix + a.slabs - 1) / a.slabs;
+    const int per = ((a.npix + a.slabs - 1) / a.slabs + 1) & ~1;  // even: a K step never straddles two slabs
     const int p0 = blockIdx.x * per, p1 = min(a.npix, p0 + per);
-    float acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+    const int shift = dyo * a.w + dxo;
     const f32x4 zero{0.f, 0.f, 0.f, 0.f};
-    for (int pc = p0; pc < p1; pc += kWgPix) {
-        __syncthreads();
-        for (int e = tid; e < kWgPix * TY; e += NT) {
-            const int px = e / TY, g = e - px * TY, p = pc + px, cg = ob * TY + g;
-            dyl[e] = (p < p1 && cg < a.c4_out) ? a.dy[(size_t)(a.dy_g0 + cg) * a.npix + p] : zero;
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+    f32x4 dv[8], xv[8];
+    auto fetch = [&](int pc) {  // this lane's pixel of the chunk at pc: its eight channel groups of dy and of x
+        const int p = pc + lane;
+        const int py = fast_div(p, a.w, w_magic), px = p - py * a.w;
+        const bool in = p < p1;
+        const bool tap_ok = in && (unsigned)(py + dyo) < (unsigned)a.h && (unsigned)(px + dxo) < (unsigned)a.w;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int og = ot * 8 + g, ig = it * 8 + g;
+            dv[g] = (in && og < a.c4_out) ? a.dy[(size_t)(a.dy_g0 + og) * a.npix + p] : zero;
+            xv[g] = (tap_ok && ig < a.c4_in) ? a.x[(size_t)(a.x_g0 + ig) * a.npix + p + shift] : zero;
         }
-        for (int e = tid; e < kWgPix * TX; e += NT) {
-            const int px = e / TX, g = e - px * TX, p = pc + px, cg = ib * TX + g;
-            f32x4 v = zero;
-            if (p < p1 && cg < a.c4_in) {
-                const int py = p / a.w, pxx = p - py * a.w;
-                const int sy = py + dyo, sx = pxx + dxo;
-                if ((unsigned)sy < (unsigned)a.h && (unsigned)sx < (unsigned)a.w)
-                    v = a.x[(size_t)(a.x_g0 + cg) * a.npix + sy * a.w + sx];
+    };
+    fetch(p0);
+    for (int pc = p0; pc < p1; pc += kWgChunk) {
+        __syncthreads();  // (one wave per block: orders the previous chunk's reads before these writes)
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            *reinterpret_cast<f32x4 *>(&tile[0][lane * kWgPitch + 4 * g]) = dv[g];
+            *reinterpret_cast<f32x4 *>(&tile[1][lane * kWgPitch + 4 * g]) = xv[g];
+        }
+        __syncthreads();
+        fetch(pc + kWgChunk);  // the next chunk travels while this one is multiplied (past the slab: all zeros, no traffic)
+        // operands of eight K steps per register block; the next block's LDS reads are issued before this block's
+        // MFMAs (read -> wait -> 2 MFMAs, as the compiler schedules the plain loop, exposes the LDS latency 16 times)
+        float av[2][8], bv[2][8];
+        auto read_block = [&](int blk, float (&ar)[8], float (&br)[8]) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                ar[u] = tile[0][(2 * (8 * blk + u) + k) * kWgPitch + r];
+                br[u] = tile[1][(2 * (8 * blk + u) + k) * kWgPitch + r];
             }
-            xl[e] = v;
-        }
-        __syncthreads();
-#pragma unroll 8
-        for (int px = 0; px < kWgPix; ++px) {
-            const f32x4 d = dyl[px * TY + ty], v = xl[px * TX + tx];
+        };
+        read_block(0, av[0], bv[0]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+        for (int blk = 0; blk < kWgChunk / 16; ++blk) {
+            if (blk + 1 < kWgChunk / 16) read_block(blk + 1, av[(blk + 1) & 1], bv[(blk + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks every read next to its MFMA again)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(d[i], v[j], acc[i][j]);
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[blk & 1][u], bv[blk & 1][u], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
-    float *dst = a.partial + (((size_t)blockIdx.x * a.taps + tap) * a.ocp + (size_t)ob * OCB + ty * 4) * a.icp + (size_t)ib * ICB + tx * 4;
+    // D layout: acc[v] = D[i][j], j = lane % 32 (ic), i = 8 * (v / 4) + 4 * (lane / 32) + v % 4 (oc)
+    float *dst = a.partial + (((size_t)blockIdx.x * a.taps + tap) * a.ocp + (size_t)ot * 32) * a.icp + (size_t)it * 32 + r;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        *reinterpret_cast<f32x4 *>(dst + (size_t)i * a.icp) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+    for (int v = 0; v < 16; ++v) dst[(size_t)(8 * (v / 4) + 4 * k + (v % 4)) * a.icp] = acc[v];
 }
 
 struct WgradReduceArgs {
@@ -473,83 +505,69 @@ OJF_API int ojf_train_avgpool3(const float *in, float *out, int c_phys, int h, i
 
 OJF_API size_t ojf_train_partial_doubles(int c_phys) { return (size_t)ojf::kTrainSlabs * (c_phys / 4) * 8; }
 
-OJF_API int ojf_train_bn_stats(const float *y, int y_g0, int c_phys, int C, int h, int w, int training, float momentum, float eps,
-                               float *running_mean, float *running_var, double *partial, float *mean, float *invstd, ojf_stream_t stream)
-{
-    using namespace ojf;
-    if (!y || !mean || !invstd || !partial || c_phys % 4 || C > c_phys) return fail("ojf_train_bn_stats: bad argument");
-    if (!running_mean || !running_var) return fail("ojf_train_bn_stats: running statistics are required");
-    hipStream_t st = as_stream(stream);
-    if (training) hipLaunchKernelGGL(train_stats_partial_kernel, dim3(kTrainSlabs, c_phys / 4), dim3(256), 0, st, planes(y), y_g0, h * w, partial);
-    StatsArgs a;
-    a.partial = partial; a.c4 = c_phys / 4; a.C = C; a.npix = h * w; a.training = training ? 1 : 0; a.momentum = momentum; a.eps = eps;
-    a.running_mean = running_mean; a.running_var = running_var; a.mean = mean; a.invstd = invstd;
-    hipLaunchKernelGGL(train_stats_finish_kernel, dim3((c_phys + 255) / 256), dim3(256), 0, st, a);
-    return check_hip(hipGetLastError(), "train_stats kernels launch");
-}
-
 static ojf::BnActArgs train_bn_args(const float *y, int y_g0, int c_phys, int C, int h, int w, const float *mean, const float *invstd,
                                     const float *gamma, const float *beta, const float *drop, int act, float scale, int has_bn, int training)
 {
     ojf::BnActArgs a;
     a.y = ojf::planes(y); a.out = nullptr; a.dout = nullptr; a.dy = nullptr;
-    a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.drop = drop; a.red = nullptr; a.partial = nullptr;
+    a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.drop = drop; a.partial = nullptr;
     a.y_g0 = y_g0; a.out_g0 = 0; a.dout_g0 = 0; a.dy_g0 = 0; a.c4 = c_phys / 4; a.C = C; a.npix = h * w; a.act = act;
     a.has_bn = has_bn; a.training = training; a.scale = scale;
+    a.mean_out = a.invstd_out = a.running_mean = a.running_var = nullptr; a.momentum = 0.0f; a.eps = 0.0f;
+    a.dgamma = a.dbeta = a.dbias = nullptr;
     return a;
 }
 
-OJF_API int ojf_train_bn_act(const float *y, int y_g0, float *out, int out_g0, int c_phys, int C, int h, int w, const float *mean,
-                             const float *invstd, const float *gamma, const float *beta, const float *drop, int act, float scale,
-                             int has_bn, ojf_stream_t stream)
+OJF_API int ojf_train_bn_act(const float *y, int y_g0, float *out, int out_g0, int c_phys, int C, int h, int w, const float *gamma,
+                             const float *beta, const float *drop, int act, float scale, int has_bn, int training, float momentum,
+                             float eps, float *running_mean, float *running_var, double *partial, float *mean, float *invstd,
+                             ojf_stream_t stream)
 {
     using namespace ojf;
-    if (!y || !out || c_phys % 4 || C > c_phys || (has_bn && (!mean || !invstd))) return fail("ojf_train_bn_act: bad argument");
-    BnActArgs a = train_bn_args(y, y_g0, c_phys, C, h, w, mean, invstd, gamma, beta, drop, act, scale, has_bn, 0);
-    a.out = planes(out); a.out_g0 = out_g0;
+    if (!y || !out || c_phys % 4 || C > c_phys) return fail("ojf_train_bn_act: bad argument");
+    if (has_bn && (!mean || !invstd || !partial || !running_mean || !running_var))
+        return fail("ojf_train_bn_act: BatchNorm needs mean / invstd outputs, the partial-sum scratch and the running statistics");
+    hipStream_t st = as_stream(stream);
+    if (has_bn && training)
+        hipLaunchKernelGGL(train_stats_partial_kernel, dim3(kTrainSlabs, c_phys / 4), dim3(256), 0, st, planes(y), y_g0, h * w, partial);
+    BnActArgs a = train_bn_args(y, y_g0, c_phys, C, h, w, nullptr, nullptr, gamma, beta, drop, act, scale, has_bn, training ? 1 : 0);
+    a.out = planes(out); a.out_g0 = out_g0; a.partial = partial;
+    a.mean_out = mean; a.invstd_out = invstd; a.running_mean = running_mean; a.running_var = running_var; a.momentum = momentum; a.eps = eps;
     const int bx = (h * w + 255) / 256 < 128 ? (h * w + 255) / 256 : 128;
-    hipLaunchKernelGGL(train_bn_act_fwd_kernel, dim3(bx, c_phys / 4), dim3(256), 0, as_stream(stream), a);
-    return check_hip(hipGetLastError(), "train_bn_act_fwd_kernel launch");
+    hipLaunchKernelGGL(train_bn_act_fwd_kernel, dim3(bx, c_phys / 4), dim3(256), 0, st, a);
+    return check_hip(hipGetLastError(), "train_bn_act kernels launch");
 }
 
 OJF_API int ojf_train_bn_act_bwd(const float *y, int y_g0, const float *dout, int dout_g0, float *dy, int dy_g0, int c_phys, int C,
                                  int h, int w, const float *mean, const float *invstd, const float *gamma, const float *beta,
-                                 const float *drop, int act, float scale, int has_bn, int training, double *partial, float *red,
+                                 const float *drop, int act, float scale, int has_bn, int training, double *partial,
                                  float *dgamma, float *dbeta, float *dbias, ojf_stream_t stream)
 {
     using namespace ojf;
-    if (!y || !dout || !dy || !partial || !red || c_phys % 4 || C > c_phys || (has_bn && (!mean || !invstd)))
+    if (!y || !dout || !dy || !partial || c_phys % 4 || C > c_phys || (has_bn && (!mean || !invstd)))
         return fail("ojf_train_bn_act_bwd: bad argument");
     hipStream_t st = as_stream(stream);
     BnActArgs a = train_bn_args(y, y_g0, c_phys, C, h, w, mean, invstd, gamma, beta, drop, act, scale, has_bn, training);
-    a.dout = planes(dout); a.dout_g0 = dout_g0; a.dy = planes(dy); a.dy_g0 = dy_g0; a.partial = partial; a.red = red;
+    a.dout = planes(dout); a.dout_g0 = dout_g0; a.dy = planes(dy); a.dy_g0 = dy_g0; a.partial = partial;
+    a.dgamma = dgamma; a.dbeta = dbeta; a.dbias = dbias;
     hipLaunchKernelGGL(train_bn_bwd_reduce_kernel, dim3(kTrainSlabs, c_phys / 4), dim3(256), 0, st, a);
-    BnBwdFinishArgs f;
-    f.partial = partial; f.c4 = c_phys / 4; f.C = C; f.npix = h * w; f.has_bn = has_bn; f.training = training;
-    f.gamma = gamma; f.invstd = invstd; f.dgamma = dgamma; f.dbeta = dbeta; f.dbias = dbias; f.red = red;
-    hipLaunchKernelGGL(train_bn_bwd_finish_kernel, dim3((c_phys + 255) / 256), dim3(256), 0, st, f);
     const int bx = (h * w + 255) / 256 < 128 ? (h * w + 255) / 256 : 128;
     hipLaunchKernelGGL(train_bn_bwd_apply_kernel, dim3(bx, c_phys / 4), dim3(256), 0, st, a);
     return check_hip(hipGetLastError(), "train_bn_bwd kernels launch");
 }
 
 namespace ojf {
-struct WgradPlan { int ty, tx, ocp, icp, slabs; };
+struct WgradPlan { int ocp, icp, slabs; };
 static WgradPlan wgrad_plan(int c_out_phys, int c_in_phys, int taps, int npix)
 {
     WgradPlan p;
-    if (c_out_phys <= 32 && c_in_phys <= 32) { p.ty = 8; p.tx = 8; }
-    else if (c_out_phys <= 32) { p.ty = 8; p.tx = 32; }
-    else if (c_in_phys <= 32) { p.ty = 32; p.tx = 8; }
-    else { p.ty = 16; p.tx = 16; }
-    p.ocp = round_up(c_out_phys, p.ty * 4);
-    p.icp = round_up(c_in_phys, p.tx * 4);
-    const int tiles = taps * (p.ocp / (p.ty * 4)) * (p.icp / (p.tx * 4));
-    // enough blocks to fill the chip (the kernel is latency-bound: 48 slabs made the 19 -> 19 layers 174 us instead of 49);
-    // the partial sums are added up by eight lanes per weight (train_wgrad_reduce_kernel)
-    int slabs = (2048 + tiles - 1) / tiles;
+    p.ocp = round_up(c_out_phys, 32);
+    p.icp = round_up(c_in_phys, 32);
+    // two waves per SIMD (2048 one-wave blocks) hide the load latency; at most 256 slabs for the reduction
+    const int waves = taps * (p.ocp / 32) * (p.icp / 32);
+    int slabs = (2048 + waves - 1) / waves;
     slabs = slabs > 256 ? 256 : slabs;
-    const int max_slabs = (npix + 4 * kWgPix - 1) / (4 * kWgPix);
+    const int max_slabs = (npix + 63) / 64;
     slabs = slabs > max_slabs ? max_slabs : slabs;
     p.slabs = slabs < 1 ? 1 : slabs;
     return p;
@@ -574,11 +592,8 @@ OJF_API int ojf_train_wgrad(const float *x, int x_g0, int c_in_phys, const float
     WgradArgs a;
     a.x = planes(x); a.dy = planes(dy); a.partial = partial; a.x_g0 = x_g0; a.c4_in = c_in_phys / 4; a.dy_g0 = dy_g0; a.c4_out = c_out_phys / 4;
     a.h = h; a.w = w; a.npix = h * w; a.taps = taps; a.dil = dil; a.slabs = p.slabs; a.ocp = p.ocp; a.icp = p.icp;
-    const dim3 grid(p.slabs, (p.ocp / (p.ty * 4)) * (p.icp / (p.tx * 4)), taps);
-    if (p.ty == 8 && p.tx == 8) hipLaunchKernelGGL((train_wgrad_kernel<8, 8>), grid, dim3(64), 0, st, a);
-    else if (p.ty == 8) hipLaunchKernelGGL((train_wgrad_kernel<8, 32>), grid, dim3(256), 0, st, a);
-    else if (p.tx == 8) hipLaunchKernelGGL((train_wgrad_kernel<32, 8>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((train_wgrad_kernel<16, 16>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(train_wgrad_mfma_kernel, dim3(p.slabs, (p.ocp / 32) * (p.icp / 32), taps), dim3(64), 0, st, a,
+                       div_magic(w, (uint64_t)h * w + 2 * kWgChunk));
     WgradReduceArgs r;
     r.partial = partial; r.dw = dw; r.slabs = p.slabs; r.taps = taps; r.ocp = p.ocp; r.icp = p.icp; r.OC = OC; r.IC = IC;
     r.group = group; r.slot = slot; r.c_in_phys = c_in_phys;

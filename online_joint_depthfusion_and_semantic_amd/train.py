@@ -77,16 +77,15 @@ class LayerUnit(torch.autograd.Function):
         _lib.check(lib.ojf_train_conv(x.data_ptr(), 0, c_in_phys, y.data_ptr(), 0, c_out_phys, packed.data_ptr(),
                                       bias_packed.data_ptr(), k, dil, H, W, st), 'ojf_train_conv')
         bn = meta['bn']
-        mean = invstd = None
+        mean = invstd = partial = None
         training = bool(meta['training'])
+        momentum, eps = 0.0, 0.0
         if bn is not None:
             mean = torch.empty(c_out_phys, dtype=torch.float32, device=dev)
             invstd = torch.empty(c_out_phys, dtype=torch.float32, device=dev)
             partial = torch.empty(lib.ojf_train_partial_doubles(c_out_phys), dtype=torch.float64, device=dev)
             momentum = 0.1 if bn.momentum is None else float(bn.momentum)
-            _lib.check(lib.ojf_train_bn_stats(y.data_ptr(), 0, c_out_phys, OC, H, W, int(training), momentum, float(bn.eps),
-                                              bn.running_mean.data_ptr(), bn.running_var.data_ptr(), partial.data_ptr(),
-                                              mean.data_ptr(), invstd.data_ptr(), st), 'ojf_train_bn_stats')
+            eps = float(bn.eps)
             if training:
                 counters = meta.get('counters')
                 if counters is not None:
@@ -95,8 +94,11 @@ class LayerUnit(torch.autograd.Function):
                     bn.num_batches_tracked += 1
         drop = meta['drop']
         out = torch.empty_like(y)
-        _lib.check(lib.ojf_train_bn_act(y.data_ptr(), 0, out.data_ptr(), 0, c_out_phys, OC, H, W, _p(mean), _p(invstd), _p(gamma), _p(beta),
-                                        _p(drop), _ACT[meta['act']], float(meta['scale']), int(bn is not None), st), 'ojf_train_bn_act')
+        # statistics (batch or running), running-stat update, normalisation, activation and dropout scale: two launches
+        _lib.check(lib.ojf_train_bn_act(y.data_ptr(), 0, out.data_ptr(), 0, c_out_phys, OC, H, W, _p(gamma), _p(beta), _p(drop),
+                                        _ACT[meta['act']], float(meta['scale']), int(bn is not None), int(training), momentum, eps,
+                                        _p(bn.running_mean if bn is not None else None), _p(bn.running_var if bn is not None else None),
+                                        _p(partial), _p(mean), _p(invstd), st), 'ojf_train_bn_act')
         ctx.save_for_backward(x, y, w, gamma, beta, mean, invstd, drop)
         ctx.meta = dict(meta, training=training, has_bias=bias is not None)
         return out
@@ -116,13 +118,12 @@ class LayerUnit(torch.autograd.Function):
         has_bn = meta['bn'] is not None
         dy = torch.empty_like(y)
         partial = torch.empty(lib.ojf_train_partial_doubles(c_out_phys), dtype=torch.float64, device=dev)
-        red = torch.empty(2 * c_out_phys, dtype=torch.float32, device=dev)
         dgamma = torch.empty(OC, dtype=torch.float32, device=dev) if gamma is not None else None
         dbeta = torch.empty(OC, dtype=torch.float32, device=dev) if beta is not None else None
         dbias = torch.empty(OC, dtype=torch.float32, device=dev) if meta['has_bias'] else None
         _lib.check(lib.ojf_train_bn_act_bwd(y.data_ptr(), 0, dout.data_ptr(), 0, dy.data_ptr(), 0, c_out_phys, OC, H, W, _p(mean), _p(invstd),
                                             _p(gamma), _p(beta), _p(drop), _ACT[meta['act']], float(meta['scale']), int(has_bn),
-                                            int(meta['training']), partial.data_ptr(), red.data_ptr(), _p(dgamma), _p(dbeta), _p(dbias), st),
+                                            int(meta['training']), partial.data_ptr(), _p(dgamma), _p(dbeta), _p(dbias), st),
                    'ojf_train_bn_act_bwd')
         dw = None
         if ctx.needs_input_grad[1]:
