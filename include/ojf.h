@@ -223,7 +223,8 @@ int ojf_segconv_forward(const ojf_segconv *conv, const float *in_dev, int in_str
  *   (momentum, unbiased variance); training == 0: from the running statistics - and returned in mean / invstd for the
  *   backward pass.  partial: ojf_train_partial_doubles(c_phys) doubles of scratch.
  * ojf_train_bn_act_bwd: gradient of that w.r.t. y (batch-statistics form when training != 0), gamma, beta and the
- *   convolution's bias.
+ *   convolution's bias.  accumulate != 0 (here and in ojf_train_wgrad): the parameter gradients are ADDED to the buffers
+ *   (gradient accumulation over frames, train_fusion.py:174-189, without a torch add per parameter).
  * ojf_train_wgrad: dW[oc][ic][tap] = sum_p dy[oc][p] * x[ic][p + tap] into torch's layout; partial:
  *   ojf_train_wgrad_partial_floats(...) floats of scratch (pixel slabs, added in slab order: deterministic). */
 size_t ojf_train_packed_floats(int c_out_phys, int c_in_phys, int ksize);
@@ -234,6 +235,8 @@ int ojf_train_conv(const float *in_dev, int in_g0, int c_in_phys, float *out_dev
 /* nn.AvgPool2d(3, 1, 1) on planes (count_include_pad); symmetric: the same call is its backward pass. */
 int ojf_train_avgpool3(const float *in_dev, float *out_dev, int c_phys, int h, int w, ojf_stream_t stream);
 size_t ojf_train_partial_doubles(int c_phys);
+/* per-channel sums of a plane tensor as 64 partial rows [slab][c_phys / 4][8] (sums, then sums of squares), fixed order */
+int ojf_train_channel_sums(const float *y_dev, int y_g0, int c_phys, int h, int w, double *partial_dev, ojf_stream_t stream);
 int ojf_train_bn_act(const float *y_dev, int y_g0, float *out_dev, int out_g0, int c_phys, int c, int h, int w, const float *gamma_dev,
                      const float *beta_dev, const float *drop_dev, int act, float scale, int has_bn, int training, float momentum,
                      float eps, float *running_mean_dev, float *running_var_dev, double *partial_dev, float *mean_dev,
@@ -241,10 +244,11 @@ int ojf_train_bn_act(const float *y_dev, int y_g0, float *out_dev, int out_g0, i
 int ojf_train_bn_act_bwd(const float *y_dev, int y_g0, const float *dout_dev, int dout_g0, float *dy_dev, int dy_g0, int c_phys, int c,
                          int h, int w, const float *mean_dev, const float *invstd_dev, const float *gamma_dev, const float *beta_dev,
                          const float *drop_dev, int act, float scale, int has_bn, int training, double *partial_dev,
-                         float *dgamma_dev, float *dbeta_dev, float *dbias_dev, ojf_stream_t stream);
+                         float *dgamma_dev, float *dbeta_dev, float *dbias_dev, int accumulate, ojf_stream_t stream);
 size_t ojf_train_wgrad_partial_floats(int c_out_phys, int c_in_phys, int ksize, int h, int w);
 int ojf_train_wgrad(const float *x_dev, int x_g0, int c_in_phys, const float *dy_dev, int dy_g0, int c_out_phys, int oc, int ic,
-                    int ksize, int dilation, int group, int slot, int h, int w, float *partial_dev, float *dw_dev, ojf_stream_t stream);
+                    int ksize, int dilation, int group, int slot, int h, int w, float *partial_dev, float *dw_dev, int accumulate,
+                    ojf_stream_t stream);
 
 /* ---- AdapNet++ front end: the operators around the convolutions (csrc/ojf_seg_ops.hip) --------------------
  * NHWC fp32 rows of batch 1 like ojf_segconv_forward (pointer to channel 0 of pixel 0 + floats per pixel row).

@@ -72,15 +72,16 @@ SIGNATURES = {
     'ojf_train_conv': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     'ojf_train_avgpool3': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'ojf_train_partial_doubles': (_sz, [_i]),
+    'ojf_train_channel_sums': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     # y, y_g0, out, out_g0, c_phys, c, h, w, gamma, beta, drop, act, scale, has_bn, training, momentum, eps, running_mean,
     # running_var, partial, mean, invstd, stream
     'ojf_train_bn_act': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     # y, y_g0, dout, dout_g0, dy, dy_g0, c_phys, c, h, w, mean, invstd, gamma, beta, drop, act, scale, has_bn, training, partial,
-    # dgamma, dbeta, dbias, stream
+    # dgamma, dbeta, dbias, accumulate, stream
     'ojf_train_bn_act_bwd': (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _i, _vp,
-                                  _vp, _vp, _vp, _vp]),
+                                  _vp, _vp, _vp, _i, _vp]),
     'ojf_train_wgrad_partial_floats': (_sz, [_i, _i, _i, _i, _i]),
-    'ojf_train_wgrad': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'ojf_train_wgrad': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     'ojf_seg_pack_input': (_i, [_vp, _i, _f, _i, _i, _vp, _i, _vp]),
     'ojf_seg_maxpool': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
     'ojf_seg_mean': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),

@@ -124,8 +124,9 @@ struct BnActArgs {
     // running statistics in eval mode); block column 0 publishes mean / invstd and updates the running statistics
     float *mean_out, *invstd_out, *running_mean, *running_var;
     float momentum, eps;
-    // backward: block column 0 publishes the parameter gradients
+    // backward: block column 0 publishes the parameter gradients (added to what is there when `accumulate`)
     float *dgamma, *dbeta, *dbias;
+    int accumulate;
 };
 
 __device__ __forceinline__ float train_act(float z, int act)
@@ -263,12 +264,12 @@ __global__ __launch_bounds__(256) void train_bn_bwd_apply_kernel(const BnActArgs
             means[j] = batch ? (float)(tot[j] / (double)a.npix) : 0.0f;          // mean(dz)
             means[4 + j] = batch ? (float)(tot[4 + j] / (double)a.npix) : 0.0f;  // mean(dz * xhat)
             if (blockIdx.x == 0 && c < a.C) {
-                if (a.dgamma) a.dgamma[c] = (float)tot[4 + j];
-                if (a.dbeta) a.dbeta[c] = (float)tot[j];
+                if (a.dgamma) a.dgamma[c] = (a.accumulate ? a.dgamma[c] : 0.0f) + (float)tot[4 + j];
+                if (a.dbeta) a.dbeta[c] = (a.accumulate ? a.dbeta[c] : 0.0f) + (float)tot[j];
                 if (a.dbias) {
                     // sum_p dy: zero under batch statistics (the normalisation removes the mean), gamma * invstd * sum(dz) otherwise
                     const float gi = a.has_bn ? (a.gamma ? a.gamma[c] : 1.0f) * a.invstd[c] : 1.0f;
-                    a.dbias[c] = batch ? 0.0f : (float)(tot[j] * (double)gi);
+                    a.dbias[c] = (a.accumulate ? a.dbias[c] : 0.0f) + (batch ? 0.0f : (float)(tot[j] * (double)gi));
                 }
             }
         }
@@ -388,6 +389,7 @@ struct WgradReduceArgs {
     const float *partial;
     float *dw;  // [OC][IC][taps]
     int slabs, taps, ocp, icp, OC, IC, group, slot, c_in_phys;
+    int accumulate;  // dw += (gradient accumulation over frames happens here instead of in a torch add per parameter)
 };
 
 // eight lanes per weight: lane `sub` adds slabs sub, sub + 8, ... in order, then a fixed xor tree joins the eight sums
@@ -410,7 +412,10 @@ __global__ __launch_bounds__(256) void train_wgrad_reduce_kernel(const WgradRedu
     s += __shfl_xor(s, 1, 64);
     if (!live || sub) return;
     const int ic = train_unslot(icp_i, a.group, a.slot, a.IC);
-    if (ic >= 0) a.dw[((size_t)oc * a.IC + ic) * a.taps + tap] = s;
+    if (ic >= 0) {
+        float *d = a.dw + ((size_t)oc * a.IC + ic) * a.taps + tap;
+        *d = a.accumulate ? *d + s : s;
+    }
 }
 
 // nn.AvgPool2d(3, stride 1, padding 1), count_include_pad: out = (sum of the 3x3 neighbourhood inside the image) / 9.  The
@@ -503,6 +508,16 @@ OJF_API int ojf_train_avgpool3(const float *in, float *out, int c_phys, int h, i
     return check_hip(hipGetLastError(), "train_avgpool3_kernel launch");
 }
 
+// Per-channel sums over the frame as kTrainSlabs partial rows ([slab][c_phys / 4][8] doubles: sums in [0..3], sums of
+// squares in [4..7]; the caller adds the rows): the global-average pooling of a VortexPooling in the training path.
+OJF_API int ojf_train_channel_sums(const float *y, int y_g0, int c_phys, int h, int w, double *partial, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (!y || !partial || c_phys < 4 || c_phys % 4 || h < 1 || w < 1) return fail("ojf_train_channel_sums: bad argument");
+    hipLaunchKernelGGL(train_stats_partial_kernel, dim3(kTrainSlabs, c_phys / 4), dim3(256), 0, as_stream(stream), planes(y), y_g0, h * w, partial);
+    return check_hip(hipGetLastError(), "train_stats_partial_kernel launch");
+}
+
 OJF_API size_t ojf_train_partial_doubles(int c_phys) { return (size_t)ojf::kTrainSlabs * (c_phys / 4) * 8; }
 
 static ojf::BnActArgs train_bn_args(const float *y, int y_g0, int c_phys, int C, int h, int w, const float *mean, const float *invstd,
@@ -514,7 +529,7 @@ static ojf::BnActArgs train_bn_args(const float *y, int y_g0, int c_phys, int C,
     a.y_g0 = y_g0; a.out_g0 = 0; a.dout_g0 = 0; a.dy_g0 = 0; a.c4 = c_phys / 4; a.C = C; a.npix = h * w; a.act = act;
     a.has_bn = has_bn; a.training = training; a.scale = scale;
     a.mean_out = a.invstd_out = a.running_mean = a.running_var = nullptr; a.momentum = 0.0f; a.eps = 0.0f;
-    a.dgamma = a.dbeta = a.dbias = nullptr;
+    a.dgamma = a.dbeta = a.dbias = nullptr; a.accumulate = 0;
     return a;
 }
 
@@ -541,7 +556,7 @@ OJF_API int ojf_train_bn_act(const float *y, int y_g0, float *out, int out_g0, i
 OJF_API int ojf_train_bn_act_bwd(const float *y, int y_g0, const float *dout, int dout_g0, float *dy, int dy_g0, int c_phys, int C,
                                  int h, int w, const float *mean, const float *invstd, const float *gamma, const float *beta,
                                  const float *drop, int act, float scale, int has_bn, int training, double *partial,
-                                 float *dgamma, float *dbeta, float *dbias, ojf_stream_t stream)
+                                 float *dgamma, float *dbeta, float *dbias, int accumulate, ojf_stream_t stream)
 {
     using namespace ojf;
     if (!y || !dout || !dy || !partial || c_phys % 4 || C > c_phys || (has_bn && (!mean || !invstd)))
@@ -549,7 +564,7 @@ OJF_API int ojf_train_bn_act_bwd(const float *y, int y_g0, const float *dout, in
     hipStream_t st = as_stream(stream);
     BnActArgs a = train_bn_args(y, y_g0, c_phys, C, h, w, mean, invstd, gamma, beta, drop, act, scale, has_bn, training);
     a.dout = planes(dout); a.dout_g0 = dout_g0; a.dy = planes(dy); a.dy_g0 = dy_g0; a.partial = partial;
-    a.dgamma = dgamma; a.dbeta = dbeta; a.dbias = dbias;
+    a.dgamma = dgamma; a.dbeta = dbeta; a.dbias = dbias; a.accumulate = accumulate ? 1 : 0;
     hipLaunchKernelGGL(train_bn_bwd_reduce_kernel, dim3(kTrainSlabs, c_phys / 4), dim3(256), 0, st, a);
     const int bx = (h * w + 255) / 256 < 128 ? (h * w + 255) / 256 : 128;
     hipLaunchKernelGGL(train_bn_bwd_apply_kernel, dim3(bx, c_phys / 4), dim3(256), 0, st, a);
@@ -581,7 +596,7 @@ OJF_API size_t ojf_train_wgrad_partial_floats(int c_out_phys, int c_in_phys, int
 }
 
 OJF_API int ojf_train_wgrad(const float *x, int x_g0, int c_in_phys, const float *dy, int dy_g0, int c_out_phys, int OC, int IC,
-                            int ksize, int dil, int group, int slot, int h, int w, float *partial, float *dw, ojf_stream_t stream)
+                            int ksize, int dil, int group, int slot, int h, int w, float *partial, float *dw, int accumulate, ojf_stream_t stream)
 {
     using namespace ojf;
     if (!x || !dy || !partial || !dw || c_in_phys % 4 || c_out_phys % 4 || (ksize != 1 && ksize != 3) || OC > c_out_phys)
@@ -596,7 +611,7 @@ OJF_API int ojf_train_wgrad(const float *x, int x_g0, int c_in_phys, const float
                        div_magic(w, (uint64_t)h * w + 2 * kWgChunk));
     WgradReduceArgs r;
     r.partial = partial; r.dw = dw; r.slabs = p.slabs; r.taps = taps; r.ocp = p.ocp; r.icp = p.icp; r.OC = OC; r.IC = IC;
-    r.group = group; r.slot = slot; r.c_in_phys = c_in_phys;
+    r.group = group; r.slot = slot; r.c_in_phys = c_in_phys; r.accumulate = accumulate ? 1 : 0;
     const long total = (long)taps * OC * c_in_phys * 8;
     hipLaunchKernelGGL(train_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r);
     return check_hip(hipGetLastError(), "train_wgrad kernels launch");

@@ -56,6 +56,24 @@ def _packed(lib, cache, w, bias, group, slot, c_in_phys, c_out_phys, transposed,
     return packed, bias_packed
 
 
+def _grad_target(p, needed, capturing):
+    """Where a parameter gradient of this backward pass goes: (tensor the kernel writes, accumulate flag, value returned
+    to autograd).  For a leaf parameter the kernels write / add straight into ``p.grad`` and autograd gets None - the
+    engine's AccumulateGrad would otherwise launch one add per parameter and frame (224 launches, 0.9 ms per 320x240
+    frame with gradients accumulated over 8 frames, train_fusion.py:174-189).  The sums are formed in the same order
+    (grad = (g1 + g2) + ...).  Non-leaf tensors, exotic ``.grad`` layouts and graph capture take the ordinary route."""
+    if p is None or not needed:
+        return None, 0, None
+    if p.is_leaf and p.requires_grad and not capturing:
+        if p.grad is None:
+            p.grad = torch.empty_like(p, memory_format=torch.contiguous_format)
+            return p.grad, 0, None
+        if p.grad.is_contiguous() and p.grad.dtype == torch.float32 and p.grad.device == p.device and p.grad.shape == p.shape:
+            return p.grad, 1, None
+    g = torch.empty_like(p, memory_format=torch.contiguous_format)
+    return g, 0, g
+
+
 class LayerUnit(torch.autograd.Function):
     """conv (+ bias) -> [BatchNorm2d] -> activation -> [Dropout2d scale per channel] on C4 planes."""
 
@@ -101,6 +119,7 @@ class LayerUnit(torch.autograd.Function):
                                         _p(partial), _p(mean), _p(invstd), st), 'ojf_train_bn_act')
         ctx.save_for_backward(x, y, w, gamma, beta, mean, invstd, drop)
         ctx.meta = dict(meta, training=training, has_bias=bias is not None)
+        ctx.params = (weight, bias, gamma, beta)  # the tensors autograd would accumulate into (see _grad_target)
         return out
 
     @staticmethod
@@ -118,19 +137,31 @@ class LayerUnit(torch.autograd.Function):
         has_bn = meta['bn'] is not None
         dy = torch.empty_like(y)
         partial = torch.empty(lib.ojf_train_partial_doubles(c_out_phys), dtype=torch.float64, device=dev)
-        dgamma = torch.empty(OC, dtype=torch.float32, device=dev) if gamma is not None else None
-        dbeta = torch.empty(OC, dtype=torch.float32, device=dev) if beta is not None else None
-        dbias = torch.empty(OC, dtype=torch.float32, device=dev) if meta['has_bias'] else None
+        capturing = torch.cuda.is_current_stream_capturing()
+        p_w, p_b, p_g, p_be = ctx.params
+        gw, aw, rw = _grad_target(p_w, ctx.needs_input_grad[1], capturing)
+        gb, ab, rb = _grad_target(p_b, p_b is not None and ctx.needs_input_grad[2], capturing)
+        gg, ag, rg = _grad_target(p_g, p_g is not None and ctx.needs_input_grad[3], capturing)
+        gbe, abe, rbe = _grad_target(p_be, p_be is not None and ctx.needs_input_grad[4], capturing)
+        # gamma, beta and the bias share one launch and one accumulate flag: in a mixed state (one gradient fresh, another
+        # accumulating) the accumulating ones go through autograd instead
+        small = [[gb, ab, rb, p_b], [gg, ag, rg, p_g], [gbe, abe, rbe, p_be]]
+        live = [t for t in small if t[0] is not None]
+        acc_small = int(bool(live) and all(t[1] for t in live))
+        if not acc_small:
+            for t in live:
+                if t[1]:
+                    t[0] = t[2] = torch.empty_like(t[3], memory_format=torch.contiguous_format)
+                    t[1] = 0
+        (gb, ab, rb, _), (gg, ag, rg, _), (gbe, abe, rbe, _) = small
         _lib.check(lib.ojf_train_bn_act_bwd(y.data_ptr(), 0, dout.data_ptr(), 0, dy.data_ptr(), 0, c_out_phys, OC, H, W, _p(mean), _p(invstd),
                                             _p(gamma), _p(beta), _p(drop), _ACT[meta['act']], float(meta['scale']), int(has_bn),
-                                            int(meta['training']), partial.data_ptr(), _p(dgamma), _p(dbeta), _p(dbias), st),
+                                            int(meta['training']), partial.data_ptr(), _p(gg), _p(gbe), _p(gb), acc_small, st),
                    'ojf_train_bn_act_bwd')
-        dw = None
-        if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
+        if gw is not None:
             wpart = torch.empty(lib.ojf_train_wgrad_partial_floats(c_out_phys, c_in_phys, k, H, W), dtype=torch.float32, device=dev)
             _lib.check(lib.ojf_train_wgrad(x.data_ptr(), 0, c_in_phys, dy.data_ptr(), 0, c_out_phys, OC, IC, k, dil, group, slot, H, W,
-                                           wpart.data_ptr(), dw.data_ptr(), st), 'ojf_train_wgrad')
+                                           wpart.data_ptr(), gw.data_ptr(), int(aw), st), 'ojf_train_wgrad')
         dx = None
         if ctx.needs_input_grad[0]:
             # backward-data = convolution of dy with the transposed, tap-flipped weights
@@ -138,7 +169,28 @@ class LayerUnit(torch.autograd.Function):
             dx = torch.empty_like(x)
             _lib.check(lib.ojf_train_conv(dy.data_ptr(), 0, c_out_phys, dx.data_ptr(), 0, c_in_phys, packed.data_ptr(), None, k, dil, H, W, st),
                        'ojf_train_conv (backward-data)')
-        return dx, dw, dbias, dgamma, dbeta, None
+        return dx, rw, rb, rg, rbe, None
+
+
+class BroadcastPlanes(torch.autograd.Function):
+    """A per-channel vector [4 * o4] as constant C4 planes [o4, H, W, 4] (the up-sampled 1x1 map of the global-average
+    branch).  Forward is a view; backward = per-channel sums of the gradient planes by a libojf launch (fp64 slab sums
+    in fixed order) - torch's reduction of an expanded view over (H, W) with the 4-wide inner stride took 200 us."""
+
+    @staticmethod
+    def forward(ctx, vec, H, W):
+        o4 = vec.shape[0] // 4
+        return vec.view(o4, 1, 1, 4).expand(o4, H, W, 4)
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        dout = dout.contiguous()
+        o4, H, W, _ = dout.shape
+        part = torch.empty(lib.ojf_train_partial_doubles(4 * o4), dtype=torch.float64, device=dout.device)
+        _lib.check(lib.ojf_train_channel_sums(dout.data_ptr(), 0, 4 * o4, H, W, part.data_ptr(), _lib.stream_ptr(dout.device)),
+                   'ojf_train_channel_sums')
+        return part.view(-1, o4, 8)[:, :, :4].sum(0).reshape(-1).float(), None, None
 
 
 class AvgPool3(torch.autograd.Function):
@@ -244,24 +296,35 @@ class HipTrainNet:
         # sees a constant map: statistics, running-stat update and gradients are those of any constant map, so a
         # 2-pixel stand-in gives them (batch variance 0 either way) without materialising the full-size tensor.
         idx = self._logical_index(group, slot, v.gave_pool[1].in_channels, dev)
-        pooled = x.mean(dim=(1, 2)).reshape(-1)[idx]                       # [in_chs]
         gc = v.gave_pool[1]
-        g = torch.addmv(gc.bias, gc.weight.view(gc.out_channels, -1), pooled)  # the 1x1 conv on the 1x1 map
         bn = v.gave_pool[3]
         if self.net.training:
             # batch statistics of a constant map: mean = the value, variance = 0 -> the output is beta, the gradients
-            # towards g and gamma vanish; running_mean moves towards g, running_var towards 0 (unbiased estimate of 0)
+            # towards g, gamma and x vanish; running_mean moves towards g, running_var towards 0 (unbiased estimate
+            # of 0).  Nothing of this branch is differentiated, so the pooled input comes from a libojf launch (fp64
+            # slab sums in fixed order) outside autograd instead of torch's strided mean and its broadcast backward.
             m = 0.1 if bn.momentum is None else bn.momentum
             with torch.no_grad():
+                lib = _lib.load()
+                xc = x.contiguous()
+                part = torch.empty(lib.ojf_train_partial_doubles(4 * c4), dtype=torch.float64, device=dev)
+                _lib.check(lib.ojf_train_channel_sums(xc.data_ptr(), 0, 4 * c4, H, W, part.data_ptr(), _lib.stream_ptr(dev)),
+                           'ojf_train_channel_sums')
+                pooled = (part.view(-1, c4, 8)[:, :, :4].sum(0).reshape(-1)[idx] / float(H * W)).float()
+                g = torch.addmv(gc.bias, gc.weight.view(gc.out_channels, -1), pooled)  # the 1x1 conv on the 1x1 map
                 bn.running_mean.mul_(1 - m).add_(g, alpha=m)
                 bn.running_var.mul_(1 - m)
-            g = bn.bias + (g - g) * bn.weight
+                zero = torch.zeros_like(g)
+            # (gamma and the 1x1 conv's parameters still receive their - exactly zero - gradients, like under autograd)
+            g = bn.bias + zero * bn.weight + (gc.weight.sum() + gc.bias.sum()) * 0.0
             self._counters.append(bn.num_batches_tracked)
         else:
+            pooled = x.mean(dim=(1, 2)).reshape(-1)[idx]                       # [in_chs]
+            g = torch.addmv(gc.bias, gc.weight.view(gc.out_channels, -1), pooled)
             g = (g - bn.running_mean) * torch.rsqrt(bn.running_var + bn.eps) * bn.weight + bn.bias
         out_c = g.shape[0]
         o4 = (out_c + 3) // 4
-        gp = torch.cat([g, g.new_zeros(4 * o4 - out_c)]).view(o4, 1, 1, 4).expand(o4, H, W, 4)
+        gp = BroadcastPlanes.apply(torch.cat([g, g.new_zeros(4 * o4 - out_c)]), H, W)
         outs = [gp, self._sequential(x, v.branches[0], group, slot)]
         xp = x
         for i in (1, 2, 3):  # nn.AvgPool2d(3, 1, 1), count_include_pad
