@@ -171,6 +171,34 @@ def test_whole_net_gradients_against_torch_autograd(cuda, version, sem, training
     print('whole net %s sem=%s training=%s: worst deviation = %.2f x torch fp32\'s own' % (version, sem, training, worst))
 
 
+def test_gradients_accumulate_in_place_like_autograd(cuda):
+    """The kernels write parameter gradients into ``p.grad`` themselves (first backward: plain store, later ones: add;
+    train.py::_grad_target).  Two backward passes of the same frame in eval() mode (no state changes between them) must
+    leave exactly twice the gradient of one pass, in the SAME tensors (optimizers and the flat all-reduce buffer hold on
+    to them), and ``zero_grad(set_to_none=True)`` must start over."""
+    h, w = 24, 32
+    net = _net('v3', True, h, w).to(cuda).eval()
+    g = torch.Generator().manual_seed(5)
+    x = dict(tsdf_values=((torch.rand(1, 9, h, w, generator=g) - 0.5) * 0.2).to(cuda), tsdf_weights=(torch.rand(1, 9, h, w, generator=g) * 4).to(cuda),
+             tsdf_frame=(torch.rand(1, 1, h, w, generator=g) * 4).to(cuda),
+             semantic_frame=(torch.randint(1, 31, (1, 1, h, w), generator=g).float() / 30).to(cuda))
+    eng = HipTrainNet(net)
+    eng(x).pow(2).mean().backward()
+    once = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    holders = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
+    assert len(once) > 100 and all(float(v.abs().max()) >= 0 for v in once.values())
+    eng(x).pow(2).mean().backward()
+    for n, p in net.named_parameters():
+        if n in once:
+            assert p.grad is holders[n], n                      # accumulated in place
+            assert torch.equal(p.grad, once[n] + once[n]), n    # g + g, bit for bit
+    net.zero_grad(set_to_none=True)
+    eng(x).pow(2).mean().backward()
+    for n, p in net.named_parameters():
+        if n in once:
+            assert torch.equal(p.grad, once[n]), n
+
+
 def test_dropout_channels_in_train_mode(cuda):
     """Dropout2d semantics of a unit in train() mode: whole channels are zeroed with probability p, survivors scaled by
     1 / (1 - p); eval() mode is deterministic."""
