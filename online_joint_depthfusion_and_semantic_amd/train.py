@@ -10,8 +10,10 @@ is ONE autograd node (``LayerUnit``): forward = device-side weight packing, fp32
 backward with its two reductions, the weight-gradient kernel, and backward-data as a convolution with the transposed,
 tap-flipped weights (include/ojf.h ``ojf_train_*``).  Activations are "C4 planes" tensors ``[C/4, H, W, 4]`` (19
 channels in a 20-wide slot, 114 in 116; padding channels are exactly zero), so a concatenation is a ``torch.cat`` along
-dim 0.  Everything around the units - concatenations, the 3x3 average pools, the 1x1 global-average map, the loss - is
-torch on those tensors, and autograd adds up the fan-out gradients.  Parameters, BatchNorm buffers and therefore
+dim 0.  Around the units: concatenations and the loss are torch on those tensors (autograd adds up the fan-out
+gradients); the 3x3 average pools, the global-average branch's pooling and the backward of its broadcast are libojf
+launches (``AvgPool3``, ``BroadcastPlanes``).  Parameter gradients do not travel through autograd's AccumulateGrad: the
+kernels write / add them straight into ``p.grad`` (``_grad_target``).  Parameters, BatchNorm buffers and therefore
 ``state_dict`` / optimizer / checkpoint code are the module's own (``model.FusionNet_v3`` / ``_v2``): ``HipTrainNet``
 only walks them.
 
