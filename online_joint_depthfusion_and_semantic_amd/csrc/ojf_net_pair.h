@@ -31,7 +31,9 @@ namespace ojf {
 constexpr int pair_round16(int x) { return (x + 15) / 16 * 16; }
 constexpr int pair_max(int a, int b) { return a > b ? a : b; }
 
-template <int TW, int TH>
+// ALIAS: the T planes reuse the window's LDS (the window is dead once conv a is done; one more barrier): a 20 x 8 tile then
+// needs 77 KB instead of 100 KB, i.e. TWO blocks per CU whose load / epilogue / MFMA phases overlap each other.
+template <int TW, int TH, bool ALIAS = false>
 struct PairGeom {
     static constexpr int WAVES = 8, THREADS = 512;
     static constexpr int PW = TW + 4;                      // slot pitch = window width
@@ -47,7 +49,8 @@ struct PairGeom {
     static constexpr int NXI = (4 * XS + THREADS - 1) / THREADS;   // window items (pair, slot) per thread and chunk
     static constexpr int NWI = (W_F4 + THREADS - 1) / THREADS;     // weight float4 per thread and chunk
     static constexpr int NPRE = NXI > NWI ? NXI : NWI;
-    static constexpr size_t LDS_BYTES = (size_t)(X_F4 + T_F4 + W_F4) * 16 + 128 * sizeof(int) + 128 * sizeof(float);
+    static constexpr int XT_F4 = ALIAS ? pair_max(X_F4, T_F4) : X_F4 + T_F4;  // float4 of the window + T areas
+    static constexpr size_t LDS_BYTES = (size_t)(XT_F4 + W_F4) * 16 + 128 * sizeof(int) + 128 * sizeof(float);
 };
 
 struct PairArgs {
@@ -104,15 +107,15 @@ __device__ __forceinline__ void pair_mac(f32x4 (&acc)[MT][2], const f32x4 *act, 
     }
 }
 
-template <int TW, int TH>
-__global__ __launch_bounds__(512) void dense_pair_kernel(const PairArgs a)
+template <int TW, int TH, bool ALIAS = false>
+__global__ __launch_bounds__(512, ALIAS ? 2 : 1) void dense_pair_kernel(const PairArgs a)
 {
-    using G = PairGeom<TW, TH>;
+    using G = PairGeom<TW, TH, ALIAS>;
     constexpr int PW = G::PW, XP = G::XP, TP = G::TP;
     extern __shared__ f32x4 pair_lds[];
     f32x4 *xl = pair_lds;               // [4 pairs][hi | lo][XP]
-    f32x4 *tl = xl + G::X_F4;           // [3 pairs][hi | lo][TP]
-    f32x4 *wl = tl + G::T_F4;           // one chunk of weights
+    f32x4 *tl = ALIAS ? xl : xl + G::X_F4;  // [3 pairs][hi | lo][TP] (ALIAS: over the window, written after a barrier)
+    f32x4 *wl = xl + G::XT_F4;          // one chunk of weights
     int *uo = reinterpret_cast<int *>(wl + G::W_F4);  // unit tables: [0] full chunk, [1] last chunk, [2] conv b
     float *vl = reinterpret_cast<float *>(uo + 128);  // bias_a | rinv_a | bias_b | rinv_b (their global latency hides behind conv a)
 
@@ -144,10 +147,13 @@ __global__ __launch_bounds__(512) void dense_pair_kernel(const PairArgs a)
     if (tid >= 128 && tid < 160)  // the four epilogue vectors are contiguous (PackedPair::vec)
         reinterpret_cast<f32x4 *>(vl)[tid - 128] = reinterpret_cast<const f32x4 *>(a.bias_a)[tid - 128];
     // the T planes' tails (slots a junk output column may read; conv a writes every slot below) must hold finite values
-    if (tid >= 192 && tid < 192 + 6 * (TP - G::TILES_A * 16)) {
-        const int i = tid - 192, pl = i / (TP - G::TILES_A * 16), sl = i - pl * (TP - G::TILES_A * 16);
-        tl[pl * TP + G::TILES_A * 16 + sl] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    auto zero_t_tails = [&]() {
+        if (tid >= 192 && tid < 192 + 6 * (TP - G::TILES_A * 16)) {
+            const int i = tid - 192, pl = i / (TP - G::TILES_A * 16), sl = i - pl * (TP - G::TILES_A * 16);
+            tl[pl * TP + G::TILES_A * 16 + sl] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    if constexpr (!ALIAS) zero_t_tails();
 
     // ---- window items of this thread: (pair, slot) -> byte offset of the pixel (or out of range) -----------------
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -228,6 +234,10 @@ __global__ __launch_bounds__(512) void dense_pair_kernel(const PairArgs a)
     }
 
     OJF_STAMP();  // conv a done
+    if constexpr (ALIAS) {
+        __syncthreads();  // every wave is done with the window: T takes its place
+        zero_t_tails();
+    }
     // epilogue a: bias, LeakyReLU, zero outside the image / the needed region, split, into the T planes
     float gmax = 0.0f;
     {
