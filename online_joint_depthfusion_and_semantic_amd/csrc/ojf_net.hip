@@ -575,6 +575,39 @@ __device__ __forceinline__ void dma_part(const f32x4 *src, f32x4 *dst, int size,
 
 enum { kChainLeaky = 0, kChainRelu = 1, kChainAccumulate = 2, kChainLastRows = 3, kChainEntry = 4 };
 
+// Epilogue vectors (bias | inverse row scale, chain_bias_stride floats per layer) travel one layer ahead of their use:
+// threads < n fetch one float4 each of the NEXT epilogue-bearing layer while the current layer computes (vec_issue),
+// write it into one half of a 2 x 1 KB LDS buffer at that layer's entry (vec_commit; the layer's first barrier publishes
+// it), and the epilogue reads its four float4 per output tile from LDS.  Fetching them from global memory inside the
+// epilogue put an L2 round trip at the end of every layer of every wave (measured with the loads ablated: tail + head
+// 84 -> 73 us, tail + entry 64 -> 59 us).
+constexpr int kVecF4 = 64;  // float4 per half: 8 output tiles x (4 bias + 4 scale)
+struct VecStage {
+    f32x4 *lds;  // [2][kVecF4]
+    f32x4 reg;   // this thread's float4 of the staged layer (threads < its float4 count)
+    int half;    // half the next commit writes
+};
+struct VecNext {  // where the next layer's vectors come from: na float4 at a, then nb float4 at b (either may be empty)
+    const float *a = nullptr;
+    int na = 0;
+    const float *b = nullptr;
+    int nb = 0;
+};
+__device__ __forceinline__ void vec_issue(VecStage &vs, const VecNext &nx)
+{
+    const int t = threadIdx.x;
+    if (t < nx.na) vs.reg = reinterpret_cast<const f32x4 *>(nx.a)[t];
+    else if (t < nx.na + nx.nb) vs.reg = reinterpret_cast<const f32x4 *>(nx.b)[t - nx.na];
+}
+// returns the base of the half now holding the vectors (valid for every thread after the next barrier)
+__device__ __forceinline__ const f32x4 *vec_commit(VecStage &vs, int n)
+{
+    f32x4 *dst = vs.lds + vs.half * kVecF4;
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = vs.reg;
+    vs.half ^= 1;
+    return dst;
+}
+
 // One pointwise layer on register-resident activations: out[n2] (+)= sum_K W[n2][K] * in[K], then (unless
 // accumulating) bias + activation in place.  `in` and `out` are distinct, statically indexed register arrays
 // (callers ping-pong two of them), so no staging copy exists.
@@ -583,10 +616,14 @@ enum { kChainLeaky = 0, kChainRelu = 1, kChainAccumulate = 2, kChainLastRows = 3
 // compute phases, only the two barriers around the LDS refill do.
 template <int ARITH, int MT, int NTIN, int NTOUT, int MODE, int NEXT_FIRST, int NA, int NB>
 __device__ __forceinline__ void chain_layer(const f32x4 (&in)[MT][NA], f32x4 (&out)[MT][NB], f32x4 *wlds, const f32x4 *wg,
-                                            const float *bias, const ChainArgs &a, const int (&p)[MT], int lane,
-                                            f32x4 (&pre)[kChainPre], int &buf, const f32x4 *next_src = nullptr)
+                                            const ChainArgs &a, const int (&p)[MT], int lane,
+                                            f32x4 (&pre)[kChainPre], int &buf, VecStage &vs, const VecNext nx = VecNext(),
+                                            const f32x4 *next_src = nullptr, int commit_extra = 0)
 {
     static_assert(NTIN <= NA && NTOUT <= NB, "register arrays too small for this layer");
+    // this layer's epilogue vectors (issued one layer ago) go to LDS now; an accumulating layer may carry the vectors of
+    // the code that follows it (commit_extra).  The first barrier below publishes them.
+    const f32x4 *vec = vec_commit(vs, MODE != kChainAccumulate ? chain_bias_stride(ARITH, NTOUT) / 4 : commit_extra);
     constexpr int parts = chain_parts(ARITH, NTIN, NTOUT);
     constexpr int per = chain_per(ARITH, NTIN, NTOUT);
     constexpr int KB = chain_kblocks(ARITH, NTIN);
@@ -621,6 +658,7 @@ __device__ __forceinline__ void chain_layer(const f32x4 (&in)[MT][NA], f32x4 (&o
             wpart = wlds + buf * chain_cap(ARITH);
             buf ^= 1;
             dma_part(nsrc, wlds + buf * chain_cap(ARITH), nsize, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane);
+            if (part == 0) vec_issue(vs, nx);
         } else {
             __syncthreads();  // readers of the previous part are done
 #pragma unroll
@@ -630,6 +668,7 @@ __device__ __forceinline__ void chain_layer(const f32x4 (&in)[MT][NA], f32x4 (&o
 #pragma unroll
             for (int k = 0; k < kChainPre; ++k)
                 if ((int)threadIdx.x + 256 * k < nsize) pre[k] = nsrc[threadIdx.x + 256 * k];
+            if (part == 0) vec_issue(vs, nx);
         }
         if constexpr (MODE != kChainAccumulate) {
 #pragma unroll
@@ -664,9 +703,9 @@ __device__ __forceinline__ void chain_layer(const f32x4 (&in)[MT][NA], f32x4 (&o
         float gmax = 0.0f;
 #pragma unroll
         for (int n2 = 0; n2 < NTOUT; ++n2) {
-            const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + n2 * 16 + 4 * g);
+            const f32x4 b = vec[n2 * 4 + g];
             f32x4 ri{1.f, 1.f, 1.f, 1.f};
-            if constexpr (ARITH == OJF_ARITH_F16X3) ri = *reinterpret_cast<const f32x4 *>(bias + (NTOUT + n2) * 16 + 4 * g);
+            if constexpr (ARITH == OJF_ARITH_F16X3) ri = vec[(NTOUT + n2) * 4 + g];
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const f32x4 lin4 = ARITH == OJF_ARITH_F16X3 ? fma4(out[m][n2], ri, b) : out[m][n2] + b;
@@ -704,31 +743,44 @@ __device__ __forceinline__ void chain_layer(const f32x4 (&in)[MT][NA], f32x4 (&o
 template <int ARITH, int MT, int NTIN, int NTOUT>
 __device__ __forceinline__ void chain_run(f32x4 (&x)[MT][8], f32x4 (&y)[MT][8], f32x4 *wlds, const f32x4 *wg,
                                           const float *bias, const ChainArgs &a, const int (&p)[MT], int lane,
-                                          f32x4 (&pre)[kChainPre], int &buf)
+                                          f32x4 (&pre)[kChainPre], int &buf, VecStage &vs)
 {
-    chain_layer<ARITH, MT, NTIN, NTOUT, kChainLastRows, 0>(x, y, wlds, wg, bias, a, p, lane, pre, buf);
+    chain_layer<ARITH, MT, NTIN, NTOUT, kChainLastRows, 0>(x, y, wlds, wg, a, p, lane, pre, buf, vs);
 }
 
 template <int ARITH, int MT, int NTIN, int NTOUT, int NTNEXT, int... REST>
 __device__ __forceinline__ void chain_run(f32x4 (&x)[MT][8], f32x4 (&y)[MT][8], f32x4 *wlds, const f32x4 *wg,
                                           const float *bias, const ChainArgs &a, const int (&p)[MT], int lane,
-                                          f32x4 (&pre)[kChainPre], int &buf)
+                                          f32x4 (&pre)[kChainPre], int &buf, VecStage &vs)
 {
-    chain_layer<ARITH, MT, NTIN, NTOUT, kChainLeaky, chain_first_size(ARITH, NTOUT, NTNEXT)>(x, y, wlds, wg, bias, a, p,
-                                                                                             lane, pre, buf);
+    // `bias` = this layer's vectors (already issued by the caller / the previous layer); the next layer's follow them
+    VecNext nx;
+    nx.a = bias + chain_bias_stride(ARITH, NTOUT);
+    nx.na = chain_bias_stride(ARITH, NTNEXT) / 4;
+    chain_layer<ARITH, MT, NTIN, NTOUT, kChainLeaky, chain_first_size(ARITH, NTOUT, NTNEXT)>(x, y, wlds, wg, a, p, lane, pre,
+                                                                                             buf, vs, nx);
     chain_run<ARITH, MT, NTOUT, NTNEXT, REST...>(y, x, wlds, wg + (size_t)chain_layer_size(ARITH, NTIN, NTOUT),
-                                                 bias + chain_bias_stride(ARITH, NTOUT), a, p, lane, pre, buf);
+                                                 bias + chain_bias_stride(ARITH, NTOUT), a, p, lane, pre, buf, vs);
 }
 
 template <int ARITH, int MT, int NT0, int... NTS>
 __global__ __launch_bounds__(256, 3) void chain1x1_kernel(const ChainArgs a)
 {
     __shared__ f32x4 wlds[kChainLdsFloat4];
+    __shared__ f32x4 vec_lds[2 * kVecF4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
     const int strip = (banded_block_x() * 4 + wave) * (MT * 16);
     int p[MT];
     f32x4 x[MT][8], y[MT][8];
+    VecStage vs;
+    vs.lds = vec_lds; vs.half = 0;
+    {
+        constexpr int first[] = {NTS...};
+        VecNext nx;
+        nx.a = a.bias; nx.na = chain_bias_stride(ARITH, first[0]) / 4;
+        vec_issue(vs, nx);  // the first layer's epilogue vectors
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         p[m] = strip + m * 16 + i16;  // waves past the image still take part in the barriers
@@ -752,7 +804,7 @@ __global__ __launch_bounds__(256, 3) void chain1x1_kernel(const ChainArgs a)
                 if ((int)threadIdx.x + 256 * k < size0) pre[k] = a.w[threadIdx.x + 256 * k];
         }
     }
-    chain_run<ARITH, MT, NT0, NTS...>(x, y, wlds, a.w, a.bias, a, p, lane, pre, buf);
+    chain_run<ARITH, MT, NT0, NTS...>(x, y, wlds, a.w, a.bias, a, p, lane, pre, buf, vs);
 }
 
 // Channel sums of a register-resident activation tile set (the global-average branch of the NEXT VortexPooling,
@@ -815,12 +867,20 @@ template <int ARITH, int MT, int NTIN, int NTOUT>
 __global__ __launch_bounds__(256, 3) void entry1x1_kernel(const ChainArgs a)
 {
     __shared__ f32x4 wlds[kChainLdsFloat4];
+    __shared__ f32x4 vec_lds[2 * kVecF4];
     __shared__ float red[4 * 128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
     const int strip = (banded_block_x() * 4 + wave) * (MT * 16);
     f32x4 pre[kChainPre];
     int buf = 0;
+    VecStage vs;
+    vs.lds = vec_lds; vs.half = 0;
+    {
+        VecNext nx;
+        nx.a = a.bias; nx.na = chain_bias_stride(ARITH, NTOUT) / 4;
+        vec_issue(vs, nx);
+    }
     {
         constexpr int size0 = chain_first_size(ARITH, NTIN, NTOUT);
         if constexpr (chain_dma(ARITH)) {
@@ -844,7 +904,7 @@ __global__ __launch_bounds__(256, 3) void entry1x1_kernel(const ChainArgs a)
         }
     }
     if (a.colsum) block_colsum<MT, NTIN>(x, p, a.npix, red, a.colsum, lane, wave);
-    chain_layer<ARITH, MT, NTIN, NTOUT, kChainEntry, 0>(x, y, wlds, a.w, a.bias, a, p, lane, pre, buf);
+    chain_layer<ARITH, MT, NTIN, NTOUT, kChainEntry, 0>(x, y, wlds, a.w, a, p, lane, pre, buf, vs);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -884,11 +944,13 @@ constexpr int kTailEntry = 1;
 // the prediction-head topologies chain_run is instantiated for (growth channels 19 / 20)
 template <int ARITH, int MT, int KIND>
 __device__ __forceinline__ void head_run(f32x4 (&x)[MT][8], f32x4 (&y)[MT][8], f32x4 *wlds, const f32x4 *wg, const float *bias,
-                                         const ChainArgs &a, const int (&p)[MT], int lane, f32x4 (&pre)[kChainPre], int &buf)
+                                         const ChainArgs &a, const int (&p)[MT], int lane, f32x4 (&pre)[kChainPre], int &buf,
+                                         VecStage &vs)
 {
-    if constexpr (KIND == 19) chain_run<ARITH, MT, 8, 6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1>(x, y, wlds, wg, bias, a, p, lane, pre, buf);
-    else chain_run<ARITH, MT, 8, 7, 7, 5, 5, 4, 4, 3, 3, 2, 2, 1>(x, y, wlds, wg, bias, a, p, lane, pre, buf);
+    if constexpr (KIND == 19) chain_run<ARITH, MT, 8, 6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1>(x, y, wlds, wg, bias, a, p, lane, pre, buf, vs);
+    else chain_run<ARITH, MT, 8, 7, 7, 5, 5, 4, 4, 3, 3, 2, 2, 1>(x, y, wlds, wg, bias, a, p, lane, pre, buf, vs);
 }
+constexpr int head_first_ntout(int kind) { return kind == 19 ? 6 : 7; }
 constexpr int head_first_size(int arith, int kind) { return chain_first_size(arith, 8, kind == 19 ? 6 : 7); }
 
 // CHAIN = 0: write the VortexPooling result planes.  CHAIN = 19 / 20: feed it straight into the prediction head
@@ -898,6 +960,7 @@ __global__ __launch_bounds__(256, 3) void vortex_tail_kernel(const TailArgs a)
 {
     static_assert(CHAIN == 0 || NO == 8, "the fused prediction head / entry layer expects 8 input tiles");
     __shared__ f32x4 wlds[kChainLdsFloat4];
+    __shared__ f32x4 vec_lds[2 * kVecF4];
     __shared__ float red[CHAIN == kTailEntry ? 4 * 128 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
@@ -905,6 +968,16 @@ __global__ __launch_bounds__(256, 3) void vortex_tail_kernel(const TailArgs a)
     int p[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) p[m] = strip + m * 16 + i16;
+    // epilogue vectors one layer ahead (VecStage): branch b's closing-1x1 vectors travel during branch b - 1, the final
+    // bias / scale during the last branch, the fused entry layer's / head's first vectors during the last accumulation
+    constexpr int kVec1 = chain_bias_stride(ARITH, NO) / 4, kVecFin = NO * 4 * (ARITH == OJF_ARITH_F16X3 ? 2 : 1);
+    VecStage vs;
+    vs.lds = vec_lds; vs.half = 0;
+    {
+        VecNext nx;
+        nx.a = a.b1; nx.na = kVec1;
+        vec_issue(vs, nx);
+    }
     ChainArgs ca;  // only npix is read by the layer code in these modes
     ca.npix = a.npix; ca.out_rows = nullptr; ca.rows_n = 0; ca.rows_stride = 0; ca.scale = 1.0f; ca.ovf = a.ovf;
     f32x4 y[MT][NO];
@@ -926,6 +999,7 @@ __global__ __launch_bounds__(256, 3) void vortex_tail_kernel(const TailArgs a)
     }
     constexpr size_t per_branch = (size_t)chain_layer_size(ARITH, NV, NO) + chain_layer_size(ARITH, NO, NO);
     f32x4 t[MT][NO];
+    const f32x4 *vfin = vec_lds;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         f32x4 vin[MT][NV];
@@ -938,26 +1012,35 @@ __global__ __launch_bounds__(256, 3) void vortex_tail_kernel(const TailArgs a)
                 vin[m][S] = a.v[b][ok ? G * a.npix + p[m] : -1];
             }
         const f32x4 *w1 = a.w + b * per_branch, *wf = w1 + (size_t)chain_layer_size(ARITH, NV, NO);
-        chain_layer<ARITH, MT, NV, NO, kChainRelu, chain_first_size(ARITH, NO, NO)>(vin, t, wlds, w1, a.b1 + b * chain_bias_stride(ARITH, NO), ca, p,
-                                                                                   lane, pre, buf);
-        if (b < 3)
-            chain_layer<ARITH, MT, NO, NO, kChainAccumulate, chain_first_size(ARITH, NV, NO)>(t, y, wlds, wf, nullptr, ca, p,
-                                                                                            lane, pre, buf);
-        else
+        VecNext nx;  // what travels during this branch's closing 1x1
+        if (b < 3) {
+            nx.a = a.b1 + (b + 1) * chain_bias_stride(ARITH, NO); nx.na = kVec1;
+        } else {
+            nx.a = a.bias_final; nx.na = NO * 4;
+            if constexpr (ARITH == OJF_ARITH_F16X3) { nx.b = a.rinv_final; nx.nb = NO * 4; }
+        }
+        chain_layer<ARITH, MT, NV, NO, kChainRelu, chain_first_size(ARITH, NO, NO)>(vin, t, wlds, w1, ca, p, lane, pre, buf, vs, nx);
+        if (b < 3) {
+            chain_layer<ARITH, MT, NO, NO, kChainAccumulate, chain_first_size(ARITH, NV, NO)>(t, y, wlds, wf, ca, p, lane, pre, buf, vs);
+        } else {
+            vfin = vs.lds + vs.half * kVecF4;  // the half the last accumulation commits the final vectors to
+            VecNext nf;
+            if constexpr (CHAIN == kTailEntry) { nf.a = a.entry_b; nf.na = chain_bias_stride(ARITH, 5) / 4; }
+            else if constexpr (CHAIN != 0) { nf.a = a.chain_b; nf.na = chain_bias_stride(ARITH, head_first_ntout(CHAIN)) / 4; }
             chain_layer<ARITH, MT, NO, NO, kChainAccumulate,
                         CHAIN == kTailEntry ? chain_first_size(ARITH, 8, 5) : (CHAIN ? head_first_size(ARITH, CHAIN) : 0)>(
-                t, y, wlds, wf, nullptr, ca, p, lane, pre, buf, CHAIN == kTailEntry ? a.entry_w : a.chain_w);
+                t, y, wlds, wf, ca, p, lane, pre, buf, vs, nf, CHAIN == kTailEntry ? a.entry_w : a.chain_w, kVecFin);
+        }
     }
     float gmax = 0.0f;
 #pragma unroll
     for (int n = 0; n < NO; ++n) {
         const int og = n * 4 + g;
-        const f32x4 bf = *reinterpret_cast<const f32x4 *>(a.bias_final + n * 16 + 4 * g);
+        const f32x4 bf = vfin[n * 4 + g];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             f32x4 v = y[m][n] + bf;
-            if constexpr (ARITH == OJF_ARITH_F16X3)
-                v = fma4(y[m][n], *reinterpret_cast<const f32x4 *>(a.rinv_final + n * 16 + 4 * g), bf);
+            if constexpr (ARITH == OJF_ARITH_F16X3) v = fma4(y[m][n], vfin[NO * 4 + n * 4 + g], bf);
             if constexpr (ARITH == OJF_ARITH_F16X3) gmax = guard_max(gmax, v);
             if constexpr (CHAIN) y[m][n] = v;
             else if (p[m] < a.npix && og < a.og_store) a.out[(size_t)(a.out_g0 + og) * a.npix + p[m]] = v;
@@ -968,10 +1051,10 @@ __global__ __launch_bounds__(256, 3) void vortex_tail_kernel(const TailArgs a)
     if constexpr (CHAIN == kTailEntry) {
         block_colsum<MT, NO>(y, p, a.npix, red, a.colsum, lane, wave);
         ca.out_planes = a.entry_out; ca.out_g0 = 0; ca.og_store = a.entry_og; ca.act_n = a.entry_act_n;
-        chain_layer<ARITH, MT, 8, 5, kChainEntry, 0>(y, t, wlds, a.entry_w, a.entry_b, ca, p, lane, pre, buf);
+        chain_layer<ARITH, MT, 8, 5, kChainEntry, 0>(y, t, wlds, a.entry_w, ca, p, lane, pre, buf, vs);
     } else if constexpr (CHAIN) {
         ca.out_rows = a.out_rows; ca.rows_stride = a.rows_stride; ca.rows_n = a.rows_n; ca.scale = a.scale;
-        head_run<ARITH, MT, CHAIN>(y, t, wlds, a.chain_w, a.chain_b, ca, p, lane, pre, buf);
+        head_run<ARITH, MT, CHAIN>(y, t, wlds, a.chain_w, a.chain_b, ca, p, lane, pre, buf, vs);
     }
 }
 
