@@ -84,8 +84,24 @@ struct SegArgs {
 // KS = 4 | 8 (layers with few pixels: too few waves to hide the weight stream otherwise): the KS waves of a block share
 // ONE pair and each walks 1/KS of K; partial sums meet in LDS and wave 0 runs the epilogue.  Fixed order: deterministic.
 // Measured on the 15x20 maps of layer3/4: parallelism beats operand reuse (NW = 1: 2.33 ms per frame, 2: 2.69, 4: 3.69).
+// the epilogue's per-channel vectors: requested before the K loop (seg_vectors), so that their L2 round trip does not
+// sit at the end of a kernel that is all latency (the small layers run 10 us, a dependent chain of ~95 per frame):
+// 1.58 -> 1.49 ms per replayed forward pass.  (Requesting the residual tile up front as well changed nothing.)
+template <int MW>
+__device__ __forceinline__ void seg_vectors(const SegArgs &a, int ct0, int kg, f32x4 (&rv)[MW], f32x4 (&bv)[MW])
+{
+#pragma unroll
+    for (int m = 0; m < MW; ++m) {
+        const int c = (ct0 + m) * 16 + kg * 4;
+        const bool ok = c < a.c_out;
+        rv[m] = *reinterpret_cast<const f32x4 *>(a.rinv + (ok ? c : 0));
+        bv[m] = *reinterpret_cast<const f32x4 *>(a.bias + (ok ? c : 0));
+    }
+}
+
 template <int MW, int NW>
-__device__ __forceinline__ void seg_epilogue(const SegArgs &a, const f32x4 (&acc)[MW][NW], int ct0, int pt0, int n_pix, int col, int kg)
+__device__ __forceinline__ void seg_epilogue(const SegArgs &a, const f32x4 (&acc)[MW][NW], int ct0, int pt0, int n_pix, int col, int kg,
+                                             const f32x4 (&rvs)[MW], const f32x4 (&bvs)[MW])
 {
     // epilogue: lane holds output channels c .. c+3 of pixel (pt0+n)*16 + col
     float gmax = 0.0f;
@@ -93,7 +109,7 @@ __device__ __forceinline__ void seg_epilogue(const SegArgs &a, const f32x4 (&acc
     for (int m = 0; m < MW; ++m) {
         const int c = (ct0 + m) * 16 + kg * 4;
         if (c >= a.c_out) continue;
-        const f32x4 rv = *reinterpret_cast<const f32x4 *>(a.rinv + c), bv = *reinterpret_cast<const f32x4 *>(a.bias + c);
+        const f32x4 rv = rvs[m], bv = bvs[m];
         // transposed convolution: GEMM row c = (phase, channel); phase (ay, ax) of input pixel (y, x) is output pixel
         // (y*up + ay, x*up + ax).  up_cp is a multiple of 4, so a lane's four rows share the phase.
         int co = c, n_co = a.c_out, ay = 0, ax = 0;
@@ -189,6 +205,8 @@ __global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void segconv_kernel(SegArgs
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in), 0, a.in_bytes, 0x00020000);
     const f32x4 *wlane = a.wp + (size_t)ct0 * a.n_kb * 128 + lane;
 
+    f32x4 rvs[MW], bvs[MW];
+    seg_vectors<MW>(a, ct0, kg, rvs, bvs);
     f32x4 acc[MW][NW];
 #pragma unroll
     for (int m = 0; m < MW; ++m)
@@ -271,7 +289,7 @@ __global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void segconv_kernel(SegArgs
                 }
     }
 
-    seg_epilogue<MW, NW>(a, acc, ct0, pt0, n_pix, col, kg);
+    seg_epilogue<MW, NW>(a, acc, ct0, pt0, n_pix, col, kg, rvs, bvs);
 }
 
 // Many-pixel layers (decoder 3x3 stacks, layer1): the four waves of a block work on the SAME 64 output channels and
@@ -304,6 +322,8 @@ __global__ __launch_bounds__(256) void segconv_wide_kernel(SegArgs a)
     int ty = tap / a.ksize, tx = tap - ty * a.ksize;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in), 0, a.in_bytes, 0x00020000);
 
+    f32x4 rvs[MW], bvs[MW];
+    seg_vectors<MW>(a, ct0, kg, rvs, bvs);
     f32x4 acc[MW][NW];
 #pragma unroll
     for (int m = 0; m < MW; ++m)
@@ -376,7 +396,7 @@ __global__ __launch_bounds__(256) void segconv_wide_kernel(SegArgs a)
         }
     }
     if (pt0 * 16 >= n_pix) return;
-    seg_epilogue<MW, NW>(a, acc, ct0, pt0, n_pix, col, kg);
+    seg_epilogue<MW, NW>(a, acc, ct0, pt0, n_pix, col, kg, rvs, bvs);
 }
 
 inline float pow2_row_scale(float row_max)
