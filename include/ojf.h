@@ -250,6 +250,13 @@ int ojf_train_wgrad(const float *x_dev, int x_g0, int c_in_phys, const float *dy
                     int ksize, int dilation, int group, int slot, int h, int w, float *partial_dev, float *dw_dev, int accumulate,
                     ojf_stream_t stream);
 
+/* ojf_extract writing straight into the fusion net's input planes (values | weights | depth of
+ * modules/pipeline.py:74-102), bit-identical to ojf_extract + ojf_net_prepare_input, for nets without a semantic
+ * channel and with one head (others: error - use the two calls): no sample planes, no prepare launch. */
+int ojf_extract_to_net(const float *depth_dev, const float *Kinv_host, const float *E_host, const double *origin_host,
+                       double resolution, const uint16_t *tsdf_dev, const uint16_t *weights_dev, int X, int Y, int Z, int h,
+                       int w, int n_points, float pad_value, ojf_net *net, ojf_stream_t stream);
+
 /* ---- AdapNet++ front end: the operators around the convolutions (csrc/ojf_seg_ops.hip) --------------------
  * NHWC fp32 rows of batch 1 like ojf_segconv_forward (pointer to channel 0 of pixel 0 + floats per pixel row).
  * ojf_seg_pack_input: modules/pipeline.py:44,50 - three source planes (src[c * chan_stride + p]; chan_stride 0 =

@@ -38,6 +38,7 @@ SIGNATURES = {
     'ojf_device_count': (_i, []),
     'ojf_extract': (_i, [_vp, _vp, _vp, _vp, _d, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _i,
                          _vp, _vp, _vp, _vp, _vp]),
+    'ojf_extract_to_net': (_i, [_vp, _vp, _vp, _vp, _d, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     'ojf_integrate_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     'ojf_integrate_workspace_init': (_i, [_vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ojf_integrate': (_i, [_vp, _vp, _vp, _vp, _d, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp,

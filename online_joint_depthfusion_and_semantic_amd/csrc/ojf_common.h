@@ -146,4 +146,10 @@ __device__ __forceinline__ bool in_volume(const int64_t idx[3], int X, int Y, in
     return idx[0] >= 0 && idx[0] < X && idx[1] >= 0 && idx[1] < Y && idx[2] >= 0 && idx[2] < Z;
 }
 
+// (ojf_net.hip) where a single-head geometry net keeps the first slot of its dense block, for ojf_extract_to_net:
+// plane buffer ([cs4][h*w] float4), its group count, n_points, frame size and the split-fp16 range flag (or NULL).
+// Returns nonzero when the net needs ojf_net_prepare_input (semantic channel, two heads).
+struct NetInputSlot { float *x0; int cs4, P, h, w; int *ovf; };
+int net_input_slot(::ojf_net *net, NetInputSlot *slot);
+
 }  // namespace ojf

@@ -24,13 +24,20 @@ struct ExtractArgs {
     float *dbg_pcl;
     int X, Y, Z, h, w, n_points, out_stride, out_layout;
     float pad_value;
+    // out_layout == 2 (ojf_extract_to_net): the results go straight into the fusion net's input planes - channels
+    // [0, P) values, [P, 2P) weights, 2P the raw depth, zeros up to 4 * net_cs4 (modules/pipeline.py:74-102)
+    float4 *net_x0;
+    int net_cs4;
+    int *ovf;  // split-fp16 range flag of the net (or NULL)
 };
+
+constexpr int kNetPitch = 36;  // floats per pixel of the LDS transpose tile (<= 8 channel groups + padding against bank conflicts)
 
 constexpr int kMaxTilePoints = 16;  // 64 * n_points threads per block
 
 // body shared by the two mappings: sample k of pixel n on the ray frame (cv, dir)
 __device__ __forceinline__ void extract_item(const ExtractArgs &a, int n, int k, const double cv[3], const double dir[3],
-                                             const float pw[3])
+                                             const float pw[3], float *net_tile = nullptr)
 {
     const int half = (a.n_points - 1) / 2;
     RaySample s;
@@ -87,9 +94,14 @@ __device__ __forceinline__ void extract_item(const ExtractArgs &a, int n, int k,
         sv += (double)val[q] * wq[q];
         sw += (double)wt[q] * wq[q];
     }
-    const size_t o = a.out_layout ? (size_t)k * a.out_stride + n : (size_t)n * a.out_stride + k;
-    a.out_values[o] = (float)sv;
-    a.out_weights[o] = (float)sw;
+    if (a.out_layout == 2) {
+        net_tile[0] = (float)sv;            // caller-provided LDS slots of (pixel, k) and (pixel, P + k)
+        net_tile[a.n_points] = (float)sw;
+    } else {
+        const size_t o = a.out_layout ? (size_t)k * a.out_stride + n : (size_t)n * a.out_stride + k;
+        a.out_values[o] = (float)sv;
+        a.out_weights[o] = (float)sw;
+    }
 
     if (a.dbg_w) {
         double *o = a.dbg_w + ((size_t)n * a.n_points + k) * 8;
@@ -128,11 +140,38 @@ __global__ __launch_bounds__(64 * kMaxTilePoints) void extract_tile_kernel(Extra
         }
     }
     __syncthreads();
-    if (n >= N) return;
-    const double cv[3] = {frame[0][lane], frame[1][lane], frame[2][lane]};
-    const double dir[3] = {frame[3][lane], frame[4][lane], frame[5][lane]};
-    const float pw[3] = {pcl[0][lane], pcl[1][lane], pcl[2][lane]};
-    extract_item(a, n, k, cv, dir, pw);
+    if (a.out_layout != 2) {
+        if (n >= N) return;
+        const double cv[3] = {frame[0][lane], frame[1][lane], frame[2][lane]};
+        const double dir[3] = {frame[3][lane], frame[4][lane], frame[5][lane]};
+        const float pw[3] = {pcl[0][lane], pcl[1][lane], pcl[2][lane]};
+        extract_item(a, n, k, cv, dir, pw);
+        return;
+    }
+    // net-input form: the block's 64 x (2P + 1) results are transposed through LDS into the net's float4 channel planes
+    // (64 consecutive pixels of a plane = 1 KB per wave store) - no sample planes, no prepare_input launch
+    __shared__ __attribute__((aligned(16))) float tile[64 * kNetPitch];
+    if (n < N) {
+        const double cv[3] = {frame[0][lane], frame[1][lane], frame[2][lane]};
+        const double dir[3] = {frame[3][lane], frame[4][lane], frame[5][lane]};
+        const float pw[3] = {pcl[0][lane], pcl[1][lane], pcl[2][lane]};
+        extract_item(a, n, k, cv, dir, pw, tile + lane * kNetPitch + k);
+        if (k == 0) {
+            tile[lane * kNetPitch + 2 * a.n_points] = a.depth[n];
+            for (int c = 2 * a.n_points + 1; c < 4 * a.net_cs4; ++c) tile[lane * kNetPitch + c] = 0.0f;
+        }
+    }
+    __syncthreads();
+    const int n0 = n - lane;  // first pixel of the block
+    bool bad = false;
+    for (int t = threadIdx.x; t < 64 * a.net_cs4; t += blockDim.x) {
+        const int cg = t >> 6, px = t & 63;
+        if (n0 + px >= N) continue;
+        const float4 v = *reinterpret_cast<const float4 *>(tile + px * kNetPitch + 4 * cg);
+        a.net_x0[(size_t)cg * N + n0 + px] = v;
+        bad = bad || fabsf(v.x) > 65504.0f || fabsf(v.y) > 65504.0f || fabsf(v.z) > 65504.0f || fabsf(v.w) > 65504.0f;
+    }
+    if (bad && a.ovf) *a.ovf = 1;  // split-fp16 range guard of the net input (NaN passes, like everywhere else)
 }
 
 // any n_points: one lane per (sample k, pixel n), k-major; every item computes its own ray frame
@@ -171,7 +210,7 @@ OJF_API int ojf_extract(const float *depth, const float *Ki, const float *E, con
     if ((int64_t)h * w * n_points > 0x7fffffffLL) return fail("ojf_extract: frame too large");
     if (!(res > 0.0)) return fail("ojf_extract: resolution must be > 0");
     ExtractArgs a{depth, tsdf, wgt, out_values, out_weights, dbg_idx, dbg_w, dbg_pts, dbg_pcl,
-                  X, Y, Z, h, w, n_points, out_stride, out_layout, pad_value};
+                  X, Y, Z, h, w, n_points, out_stride, out_layout, pad_value, nullptr, 0, nullptr};
     const Camera cam = make_camera(Ki, E, origin, res);
     if (n_points <= kMaxTilePoints) {
         hipLaunchKernelGGL(extract_tile_kernel, dim3((h * w + 63) / 64), dim3(64 * n_points), 0, as_stream(stream), a, cam);
@@ -180,4 +219,25 @@ OJF_API int ojf_extract(const float *depth, const float *Ki, const float *E, con
         hipLaunchKernelGGL(extract_kernel, dim3((items + 255) / 256), dim3(256), 0, as_stream(stream), a, cam);
     }
     return check_hip(hipGetLastError(), "ojf_extract launch");
+}
+
+OJF_API int ojf_extract_to_net(const float *depth, const float *Ki, const float *E, const double *origin, double res,
+                               const uint16_t *tsdf, const uint16_t *wgt, int X, int Y, int Z, int h, int w, int n_points,
+                               float pad_value, ojf_net *net, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (!depth || !Ki || !E || !origin || !tsdf || !wgt || !net) return fail("ojf_extract_to_net: null pointer argument");
+    if (X <= 0 || Y <= 0 || Z <= 0 || h <= 0 || w <= 0) return fail("ojf_extract_to_net: non-positive volume or frame size");
+    if (!(res > 0.0)) return fail("ojf_extract_to_net: resolution must be > 0");
+    NetInputSlot slot;
+    if (net_input_slot(net, &slot))
+        return fail("ojf_extract_to_net: this net takes a semantic channel or has two heads: use ojf_extract + ojf_net_prepare_input");
+    if (slot.h != h || slot.w != w || slot.P != n_points) return fail("ojf_extract_to_net: frame size / n_points differ from the net's");
+    if (n_points < 1 || (n_points & 1) == 0 || n_points > kMaxTilePoints || 4 * slot.cs4 > kNetPitch || 2 * n_points + 1 > 4 * slot.cs4)
+        return fail("ojf_extract_to_net: unsupported n_points / slot width");
+    ExtractArgs a{depth, tsdf, wgt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                  X, Y, Z, h, w, n_points, h * w, 2, pad_value, reinterpret_cast<float4 *>(slot.x0), slot.cs4, slot.ovf};
+    const Camera cam = make_camera(Ki, E, origin, res);
+    hipLaunchKernelGGL(extract_tile_kernel, dim3((h * w + 63) / 64), dim3(64 * n_points), 0, as_stream(stream), a, cam);
+    return check_hip(hipGetLastError(), "ojf_extract_to_net launch");
 }

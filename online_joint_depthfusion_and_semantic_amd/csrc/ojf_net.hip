@@ -2329,6 +2329,16 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
     return 0;
 }
 
+namespace ojf {
+int net_input_slot(::ojf_net *net, NetInputSlot *slot)
+{
+    if (!net || !slot || net->sem || net->heads != 1) return 1;
+    slot->x0 = net->X[0]; slot->cs4 = net->cs / 4; slot->P = net->P; slot->h = net->h; slot->w = net->w;
+    slot->ovf = net->arith == OJF_ARITH_F16X3 ? overflow_flag() : nullptr;
+    return 0;
+}
+}  // namespace ojf
+
 OJF_API int ojf_net_prepare_input(ojf_net *net, const float *values, const float *weights, int rows_stride,
                                   int in_layout, const float *depth, const uint8_t *sem_ids, int n_classes, ojf_stream_t stream)
 {

@@ -46,6 +46,8 @@ class FusionNetEngine:
         self.h, self.w = h, w
         self.n_points = net.n_points
         self.use_semantics = bool(net.config.use_semantics)
+        # nets without a semantic channel have one head: ops.extract_to_net can fill their input planes directly
+        self.fused_input = not self.use_semantics
         layers = fold_layers(net)
         arr, keep = _layer_array(layers)
         handle = ctypes.c_void_p()

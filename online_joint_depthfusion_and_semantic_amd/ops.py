@@ -97,6 +97,20 @@ class IntegrateWorkspace:
         _lib.check(rc, 'ojf_integrate_workspace_init')
 
 
+def extract_to_net(depth, Ki, E, origin, resolution, tsdf, weights, engine, *, pad_value=-0.1):
+    """``extract`` + ``engine.prepare_input`` in one launch (ojf_extract_to_net): the gathered values / weights and the raw
+    depth land in the fusion net's input planes; nothing else is written.  Only for engines with ``fused_input``."""
+    lib = _lib.load()
+    assert depth.is_cuda and depth.dtype == torch.float32 and depth.is_contiguous()
+    h, w = depth.shape
+    X, Y, Z = _vol16(tsdf).shape
+    assert _vol16(weights).shape == tsdf.shape
+    rc = lib.ojf_extract_to_net(_lib.ptr(depth), _lib.ptr(Ki), _lib.ptr(E), _lib.ptr(_origin_array(origin)), float(resolution),
+                                _lib.ptr(tsdf), _lib.ptr(weights), X, Y, Z, h, w, int(engine.n_points), float(pad_value),
+                                engine.handle, _lib.stream_ptr(depth.device))
+    _lib.check(rc, 'ojf_extract_to_net')
+
+
 def integrate(depth_filtered, Ki, E, origin, resolution, est, tsdf, weights, workspace,
               n_points=9, n_tail=7, trunc=0.1, est_stride=None, sem_ids=None, sem_scores=None,
               id_vol=None, score_vol=None, mode=MODE_FAST, stats=False, mask=None):

@@ -282,12 +282,17 @@ class Pipeline(torch.nn.Module):
         eng = self._get_engine(h, w, self.device)
         P = self.n_points
         self._mark(first=True)
-        ops.extract(frame, Ki, E, volume['origin'], volume['resolution'], tsdf, weights, n_points=P,
-                    out_values=self._fv, out_weights=self._fw, out_stride=h * w, planes=True)
-        self._mark()
         use_sem = self.config.FUSION_MODEL.use_semantics
-        eng.prepare_input(self._fv, self._fw, frame, sem_ids if use_sem else None, self.n_classes if use_sem else 0,
-                          planes=True)
+        if eng.fused_input:
+            # geometry-only net: the extractor writes the net's input planes itself (one launch less, no sample planes)
+            ops.extract_to_net(frame, Ki, E, volume['origin'], volume['resolution'], tsdf, weights, eng)
+            self._mark()
+        else:
+            ops.extract(frame, Ki, E, volume['origin'], volume['resolution'], tsdf, weights, n_points=P,
+                        out_values=self._fv, out_weights=self._fw, out_stride=h * w, planes=True)
+            self._mark()
+            eng.prepare_input(self._fv, self._fw, frame, sem_ids if use_sem else None, self.n_classes if use_sem else 0,
+                              planes=True)
         eng.forward(self._est)
         self._mark()
 

@@ -267,3 +267,41 @@ def test_nan_inputs_propagate_like_the_reference(cuda, arith):
     eng.check()  # NaN in -> NaN out is not an error
     assert torch.isnan(got).all()
     eng.close()
+
+
+@pytest.mark.parametrize('version', ['v3', 'v2'])
+@pytest.mark.parametrize('h,w,grid', [(60, 80, 64), (37, 53, 32), (240, 320, 128)])
+def test_extract_to_net_equals_extract_plus_prepare(cuda, version, h, w, grid):
+    """ojf_extract_to_net (the extractor writes the net's input planes itself) against ojf_extract + ojf_net_prepare_input on
+    a partly filled volume: the net output must be identical bit for bit (ragged frame sizes: the last block of 64
+    pixels is partial; rays leaving the volume: pad values)."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import make_stream, frame_inputs
+    from online_joint_depthfusion_and_semantic_amd import ops
+    st = make_stream(h, w, grid, 4)
+    fi = frame_inputs(st, 1)
+    g = torch.Generator().manual_seed(grid)
+    tsdf = ((torch.rand(grid, grid, grid, generator=g) - 0.5) * 0.2).half().to(cuda)
+    wgt = (torch.rand(grid, grid, grid, generator=g) * 3).half().to(cuda)
+    wgt[:, :, ::3] = 0
+    depth = torch.from_numpy(fi['depth']).to(cuda).contiguous()
+    net = seeded_net(version, False, h, w)
+    eng = FusionNetEngine(net, h, w, cuda)
+    assert eng.fused_input
+    Ki, E = fi['Ki'], fi['E']
+    origin, res = st.origin, st.resolution
+    fv = torch.empty((9, h * w), device=cuda)
+    fw = torch.empty((9, h * w), device=cuda)
+    ops.extract(depth, Ki, E, origin, res, tsdf, wgt, n_points=9, out_values=fv, out_weights=fw, out_stride=h * w, planes=True)
+    eng.prepare_input(fv, fw, depth, planes=True)
+    a = eng.forward(torch.zeros((h * w, 9), device=cuda)).clone()
+    eng.prepare_input(torch.zeros_like(fv), torch.zeros_like(fw), torch.zeros_like(depth), planes=True)  # wipe the slot
+    ops.extract_to_net(depth, Ki, E, origin, res, tsdf, wgt, eng)
+    b = eng.forward(torch.zeros((h * w, 9), device=cuda))
+    assert torch.isfinite(a).all() and float(a.abs().max()) > 0
+    assert torch.equal(a, b)
+    sem_eng = FusionNetEngine(seeded_net(version, True, h, w), h, w, cuda)
+    assert not sem_eng.fused_input
+    with pytest.raises(_lib.OjfError):
+        ops.extract_to_net(depth, Ki, E, origin, res, tsdf, wgt, sem_eng)
