@@ -47,6 +47,12 @@
 // GEMM, pool pyramid, two grouped launches of the four branches' dilated 3x3, fused tail}; the last tail also runs
 // the 11-layer prediction head: 22 launches on the main stream.  Environment switches (tuning / ablation only):
 // OJF_CONV_MT, OJF_NO_TAIL, OJF_NO_CHAIN, OJF_NO_HEAD_FUSION, OJF_NET_GRAPH=1 (opt-in hipGraph replay).
+#ifndef OJF_CHAIN_DMA_HALF
+#define OJF_CHAIN_DMA_HALF 1536
+#endif
+#ifndef OJF_CHAIN_BLOCKS
+#define OJF_CHAIN_BLOCKS 3
+#endif
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -513,6 +519,7 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const ConvGroup grp)
 // 19- and 20-channel growth), so every register array is statically indexed.
 // ------------------------------------------------------------------------------------------------
 constexpr int kChainLdsFloat4 = 48 * 1024 / 16;
+constexpr int kChainDmaHalf = OJF_CHAIN_DMA_HALF;  // float4 per half of the split-fp16 weight double buffer
 
 struct ChainArgs {
     const f32x4 *in;  // input planes, c4_in groups starting at in_g0
@@ -542,13 +549,18 @@ constexpr int chain_layer_size(int arith, int ntin, int ntout) { return ntout * 
 //               is what lets more waves hide the LDS latency of the 5x faster MFMA phase), no ds_write pass, one
 //               barrier per part.
 constexpr bool chain_dma(int arith) { return arith == OJF_ARITH_F16X3; }
-constexpr int chain_cap(int arith) { return chain_dma(arith) ? kChainLdsFloat4 / 2 : kChainLdsFloat4; }  // float4 per part
+constexpr int chain_cap(int arith) { return chain_dma(arith) ? kChainDmaHalf : kChainLdsFloat4; }  // float4 per part
+// output tiles per LDS part: as many whole tiles as fit; parts = the number of such groups
+constexpr int chain_tiles_fit(int arith, int ntin)
+{
+    return chain_cap(arith) / (chain_kblocks(arith, ntin) * chain_unit(arith));
+}
 constexpr int chain_parts(int arith, int ntin, int ntout)
 {
-    return (chain_layer_size(arith, ntin, ntout) + chain_cap(arith) - 1) / chain_cap(arith);
+    return (ntout + chain_tiles_fit(arith, ntin) - 1) / chain_tiles_fit(arith, ntin);
 }
 constexpr int chain_per(int arith, int ntin, int ntout)
-{
+{   // balanced over the parts (a part never exceeds chain_tiles_fit)
     return (ntout + chain_parts(arith, ntin, ntout) - 1) / chain_parts(arith, ntin, ntout);
 }
 constexpr int chain_first_size(int arith, int ntin, int ntout)
@@ -565,7 +577,7 @@ constexpr int kChainPre = kChainLdsFloat4 / 256;  // float4 registers per thread
 __device__ __forceinline__ void dma_part(const f32x4 *src, f32x4 *dst, int size, int wave, int lane)
 {
 #pragma unroll
-    for (int c0 = 0; c0 < kChainLdsFloat4 / 2 / 64; c0 += 4) {
+    for (int c0 = 0; c0 < kChainDmaHalf / 64; c0 += 4) {
         const int c = c0 + wave;
         if (c * 64 < size)
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + c * 64 + lane),
@@ -764,9 +776,9 @@ __device__ __forceinline__ void chain_run(f32x4 (&x)[MT][8], f32x4 (&y)[MT][8], 
 }
 
 template <int ARITH, int MT, int NT0, int... NTS>
-__global__ __launch_bounds__(256, 3) void chain1x1_kernel(const ChainArgs a)
+__global__ __launch_bounds__(256, OJF_CHAIN_BLOCKS) void chain1x1_kernel(const ChainArgs a)
 {
-    __shared__ f32x4 wlds[kChainLdsFloat4];
+    __shared__ f32x4 wlds[chain_dma(ARITH) ? 2 * kChainDmaHalf : kChainLdsFloat4];
     __shared__ f32x4 vec_lds[2 * kVecF4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
@@ -864,9 +876,9 @@ __device__ __forceinline__ void block_colsum(const f32x4 (&x)[MT][NA], const int
 // convolution kernel needed 25 us for this launch (tap table, masks, 6 output tiles per wave) and a separate
 // column-sum launch re-read the same 37 MB.
 template <int ARITH, int MT, int NTIN, int NTOUT>
-__global__ __launch_bounds__(256, 3) void entry1x1_kernel(const ChainArgs a)
+__global__ __launch_bounds__(256, OJF_CHAIN_BLOCKS) void entry1x1_kernel(const ChainArgs a)
 {
-    __shared__ f32x4 wlds[kChainLdsFloat4];
+    __shared__ f32x4 wlds[chain_dma(ARITH) ? 2 * kChainDmaHalf : kChainLdsFloat4];
     __shared__ f32x4 vec_lds[2 * kVecF4];
     __shared__ float red[4 * 128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -956,10 +968,10 @@ constexpr int head_first_size(int arith, int kind) { return chain_first_size(ari
 // CHAIN = 0: write the VortexPooling result planes.  CHAIN = 19 / 20: feed it straight into the prediction head
 // (same accumulator -> operand identity) and write est rows; the 114-channel tensor between them never exists.
 template <int ARITH, int MT, int NV, int NO, int CHAIN = 0>
-__global__ __launch_bounds__(256, 3) void vortex_tail_kernel(const TailArgs a)
+__global__ __launch_bounds__(256, OJF_CHAIN_BLOCKS) void vortex_tail_kernel(const TailArgs a)
 {
     static_assert(CHAIN == 0 || NO == 8, "the fused prediction head / entry layer expects 8 input tiles");
-    __shared__ f32x4 wlds[kChainLdsFloat4];
+    __shared__ f32x4 wlds[chain_dma(ARITH) ? 2 * kChainDmaHalf : kChainLdsFloat4];
     __shared__ f32x4 vec_lds[2 * kVecF4];
     __shared__ float red[CHAIN == kTailEntry ? 4 * 128 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
