@@ -1592,19 +1592,19 @@ static int finish_pair(const ConvBuilder &ba, const ConvBuilder &bb, PackedPair 
     return 0;
 }
 
-template <int TW, int TH, bool ALIAS = false>
+template <int TW, int TH>
 static int launch_pair_t(PairArgs &a, hipStream_t st)
 {
-    using G = PairGeom<TW, TH, ALIAS>;
+    using G = PairGeom<TW, TH>;
     static bool configured = false;
     if (!configured) {
-        OJF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_pair_kernel<TW, TH, ALIAS>),
+        OJF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_pair_kernel<TW, TH>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
         configured = true;
     }
     a.tiles_x = (a.w + TW - 1) / TW;
     const int tiles = a.tiles_x * ((a.h + TH - 1) / TH);
-    hipLaunchKernelGGL((dense_pair_kernel<TW, TH, ALIAS>), dim3(tiles), dim3(G::THREADS), G::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((dense_pair_kernel<TW, TH>), dim3(tiles), dim3(G::THREADS), G::LDS_BYTES, st, a);
     mark_launch("dense_pair_kernel", st);
     return check_hip(hipGetLastError(), "dense_pair_kernel launch");
 }
@@ -1625,9 +1625,7 @@ static int launch_pair(const PackedPair &pp, const float *in, int in_g0, float *
 #ifdef OJF_PAIR_TIMING
     a.dbg = g_pair_dbg;
 #endif
-    // one block per tile, 8 waves: the large tile when it still gives every CU a block (320x240: 240 blocks)
-    static const int tile_env = getenv("OJF_PAIR_TILE") ? atoi(getenv("OJF_PAIR_TILE")) : 0;  // tuning switch only
-    if (tile_env == 8 && ((w + 19) / 20) * ((h + 7) / 8) >= 400) return launch_pair_t<20, 8, true>(a, st);
+    // one block per tile, 16 waves: the large tile when it still gives every CU a block (320x240: 240 blocks)
     if (((w + 19) / 20) * ((h + 15) / 16) >= 200) return launch_pair_t<20, 16>(a, st);
     return launch_pair_t<12, 8>(a, st);
 }

@@ -5,7 +5,7 @@
 // launches with T round-tripping through HBM/L2 and fetched every input once per tap (the wide first convolutions were
 // L1-bound: 265 MB through L1 for 95 -> 19).  Here ONE launch does both, LDS-resident:
 //
-//   block = 8 waves, one TW x TH output tile (20 x 16 at 320x240: 240 blocks = one round over the 256 CUs)
+//   block = 16 waves, one TW x TH output tile (20 x 16 at 320x240: 240 blocks = one round over the 256 CUs)
 //   window   X: (TH+4) x (TW+4) input pixels, 32 channels (4 channel PAIRS of 8) at a time, fetched ONCE from global
 //               memory, split into fp16 halves ONCE (not once per tap) and kept as hi / lo planes in LDS
 //   conv a   over the (TH+2) x (TW+2) region the second convolution needs (1.3x recompute instead of a round trip),
@@ -31,11 +31,11 @@ namespace ojf {
 constexpr int pair_round16(int x) { return (x + 15) / 16 * 16; }
 constexpr int pair_max(int a, int b) { return a > b ? a : b; }
 
-// ALIAS: the T planes reuse the window's LDS (the window is dead once conv a is done; one more barrier): a 20 x 8 tile then
-// needs 77 KB instead of 100 KB, i.e. TWO blocks per CU whose load / epilogue / MFMA phases overlap each other.
-template <int TW, int TH, bool ALIAS = false>
+template <int TW, int TH>
 struct PairGeom {
-    static constexpr int WAVES = 8, THREADS = 512;
+    // 16 waves (the largest block): four per SIMD take turns through the load / split / epilogue phases of the ONE block a
+    // CU holds (measured per frame: 8 waves 101 us, 12 waves 95 us, 16 waves 90 us)
+    static constexpr int WAVES = 16, THREADS = 64 * WAVES;
     static constexpr int PW = TW + 4;                      // slot pitch = window width
     static constexpr int XS = (TH + 4) * PW;               // window slots
     static constexpr int TS = (TH + 2) * PW;               // slots of the intermediate
@@ -49,8 +49,7 @@ struct PairGeom {
     static constexpr int NXI = (4 * XS + THREADS - 1) / THREADS;   // window items (pair, slot) per thread and chunk
     static constexpr int NWI = (W_F4 + THREADS - 1) / THREADS;     // weight float4 per thread and chunk
     static constexpr int NPRE = NXI > NWI ? NXI : NWI;
-    static constexpr int XT_F4 = ALIAS ? pair_max(X_F4, T_F4) : X_F4 + T_F4;  // float4 of the window + T areas
-    static constexpr size_t LDS_BYTES = (size_t)(XT_F4 + W_F4) * 16 + 128 * sizeof(int) + 128 * sizeof(float);
+    static constexpr size_t LDS_BYTES = (size_t)(X_F4 + T_F4 + W_F4) * 16 + 128 * sizeof(int) + 128 * sizeof(float);
 };
 
 struct PairArgs {
@@ -107,15 +106,15 @@ __device__ __forceinline__ void pair_mac(f32x4 (&acc)[MT][2], const f32x4 *act, 
     }
 }
 
-template <int TW, int TH, bool ALIAS = false>
-__global__ __launch_bounds__(512, ALIAS ? 2 : 1) void dense_pair_kernel(const PairArgs a)
+template <int TW, int TH>
+__global__ __launch_bounds__(1024) void dense_pair_kernel(const PairArgs a)
 {
-    using G = PairGeom<TW, TH, ALIAS>;
+    using G = PairGeom<TW, TH>;
     constexpr int PW = G::PW, XP = G::XP, TP = G::TP;
     extern __shared__ f32x4 pair_lds[];
     f32x4 *xl = pair_lds;               // [4 pairs][hi | lo][XP]
-    f32x4 *tl = ALIAS ? xl : xl + G::X_F4;  // [3 pairs][hi | lo][TP] (ALIAS: over the window, written after a barrier)
-    f32x4 *wl = xl + G::XT_F4;          // one chunk of weights
+    f32x4 *tl = xl + G::X_F4;           // [3 pairs][hi | lo][TP]
+    f32x4 *wl = tl + G::T_F4;           // one chunk of weights
     int *uo = reinterpret_cast<int *>(wl + G::W_F4);  // unit tables: [0] full chunk, [1] last chunk, [2] conv b
     float *vl = reinterpret_cast<float *>(uo + 128);  // bias_a | rinv_a | bias_b | rinv_b (their global latency hides behind conv a)
 
@@ -147,13 +146,10 @@ __global__ __launch_bounds__(512, ALIAS ? 2 : 1) void dense_pair_kernel(const Pa
     if (tid >= 128 && tid < 160)  // the four epilogue vectors are contiguous (PackedPair::vec)
         reinterpret_cast<f32x4 *>(vl)[tid - 128] = reinterpret_cast<const f32x4 *>(a.bias_a)[tid - 128];
     // the T planes' tails (slots a junk output column may read; conv a writes every slot below) must hold finite values
-    auto zero_t_tails = [&]() {
-        if (tid >= 192 && tid < 192 + 6 * (TP - G::TILES_A * 16)) {
-            const int i = tid - 192, pl = i / (TP - G::TILES_A * 16), sl = i - pl * (TP - G::TILES_A * 16);
-            tl[pl * TP + G::TILES_A * 16 + sl] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    if constexpr (!ALIAS) zero_t_tails();
+    if (tid >= 192 && tid < 192 + 6 * (TP - G::TILES_A * 16)) {
+        const int i = tid - 192, pl = i / (TP - G::TILES_A * 16), sl = i - pl * (TP - G::TILES_A * 16);
+        tl[pl * TP + G::TILES_A * 16 + sl] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     // ---- window items of this thread: (pair, slot) -> byte offset of the pixel (or out of range) -----------------
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -190,7 +186,7 @@ __global__ __launch_bounds__(512, ALIAS ? 2 : 1) void dense_pair_kernel(const Pa
     auto nkb_of = [&](int c) { return c == last ? (9 * a.np_last + 3) >> 2 : 9; };
 
     // ---- conv a ----------------------------------------------------------------------------------------------
-    const int mt_a = (G::TILES_A - wave + G::WAVES - 1) / G::WAVES;  // tiles wave, wave + 8, ... < TILES_A
+    const int mt_a = (G::TILES_A - wave + G::WAVES - 1) / G::WAVES;  // tiles wave, wave + WAVES, ... < TILES_A
     int slot_a[G::MT_A];
 #pragma unroll
     for (int m = 0; m < G::MT_A; ++m) slot_a[m] = (wave + G::WAVES * (m < mt_a ? m : 0)) * 16 + i16;
@@ -234,10 +230,6 @@ __global__ __launch_bounds__(512, ALIAS ? 2 : 1) void dense_pair_kernel(const Pa
     }
 
     OJF_STAMP();  // conv a done
-    if constexpr (ALIAS) {
-        __syncthreads();  // every wave is done with the window: T takes its place
-        zero_t_tails();
-    }
     // epilogue a: bias, LeakyReLU, zero outside the image / the needed region, split, into the T planes
     float gmax = 0.0f;
     {
