@@ -63,8 +63,11 @@ __device__ __forceinline__ bool link_record(const IntegrateArgs &a, unsigned int
 // hash full become single-entry records.
 // SEM = false (geometry only) drops the two entry-id tables: 51 KB instead of 67 KB of LDS per block, i.e. three
 // blocks per CU instead of two for a kernel that is bound by the latency of its atomics.
+// threads of an accumulate block (one 8x8 tile): eight waves - the tile's 448 items in one pass, four slots per thread
+// to publish; LDS allows three blocks per CU either way (measured: 256 threads 62 us, 512 56 us, 1024 68 us per frame)
+constexpr int kAccThreads = 512;
 template <bool SEM>
-__global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(IntegrateArgs a, Camera cam)
+__global__ __launch_bounds__(kAccThreads) void integrate_accumulate_tiled_kernel(IntegrateArgs a, Camera cam)
 {
     __shared__ unsigned int keys[kSlots];
     __shared__ unsigned long long accw[kSlots];
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(Integra
     __shared__ unsigned int newlist[kSlots];  // voxels this tile touched first
     __shared__ unsigned int n_entries, n_new, n_rec, base_rec;
     __shared__ double frame[6][64];  // ray frame (voxel-space point, unit direction) of the tile's 64 pixels
-    for (int s = threadIdx.x; s < kSlots; s += 256) {
+    for (int s = threadIdx.x; s < kSlots; s += kAccThreads) {
         keys[s] = kEmpty; accw[s] = 0; accu[s] = 0;
         if constexpr (SEM) { elast[s] = 0; ediff[s] = 0; }
     }
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(Integra
     constexpr bool sem = SEM;
     const int half = (a.n_points - 1) / 2;
     unsigned int n_in = 0;
-    for (int item = threadIdx.x; item < 64 * a.n_tail; item += 256) {
+    for (int item = threadIdx.x; item < 64 * a.n_tail; item += kAccThreads) {
         const int k = item >> 6, p = item & 63;
         const int r = ty * 8 + (p >> 3), c = tx * 8 + (p & 7);
         if (r >= a.h || c >= a.w) continue;
@@ -155,10 +158,10 @@ __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(Integra
     if (n_in) atomicAdd(&n_entries, n_in);
     __syncthreads();
     // number this tile's records inside its own slice of the record array, then publish them
-    unsigned int mine[kSlots / 256];
+    unsigned int mine[kSlots / kAccThreads];
 #pragma unroll
-    for (int j = 0; j < kSlots / 256; ++j) {
-        const int s = threadIdx.x + 256 * j;
+    for (int j = 0; j < kSlots / kAccThreads; ++j) {
+        const int s = threadIdx.x + kAccThreads * j;
         mine[j] = keys[s] != kEmpty ? atomicAdd(&n_rec, 1u) : kEmpty;
     }
     __syncthreads();
@@ -172,14 +175,14 @@ __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(Integra
     __syncthreads();
     // All of a thread's list-head exchanges are issued before any of their results is used: the returning
     // atomics' round trips (~1.5 us each) overlap instead of adding up (8 slots per thread).
-    unsigned int prev[kSlots / 256];
+    unsigned int prev[kSlots / kAccThreads];
 #pragma unroll
-    for (int j = 0; j < kSlots / 256; ++j)
-        if (mine[j] != kEmpty) prev[j] = atomicExch(&a.head[keys[threadIdx.x + 256 * j]], base_rec + mine[j] + 1u);
+    for (int j = 0; j < kSlots / kAccThreads; ++j)
+        if (mine[j] != kEmpty) prev[j] = atomicExch(&a.head[keys[threadIdx.x + kAccThreads * j]], base_rec + mine[j] + 1u);
 #pragma unroll
-    for (int j = 0; j < kSlots / 256; ++j) {
+    for (int j = 0; j < kSlots / kAccThreads; ++j) {
         if (mine[j] == kEmpty) continue;
-        const int s = threadIdx.x + 256 * j;
+        const int s = threadIdx.x + kAccThreads * j;
         VoxelRec r;
         r.lin = keys[s]; r.next = prev[j]; r.w = accw[s]; r.u = accu[s];
         r.e_last = SEM ? elast[s] : 0u; r.e_diff = SEM ? ediff[s] : 0u;
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256) void integrate_accumulate_tiled_kernel(Integra
     }
     __syncthreads();
     if (threadIdx.x == 0) a.tile_new[tile] = n_new;
-    for (unsigned int i = threadIdx.x; i < n_new; i += 256) a.touched[tile * kSlots + i] = newlist[i];
+    for (unsigned int i = threadIdx.x; i < n_new; i += kAccThreads) a.touched[tile * kSlots + i] = newlist[i];
 }
 
 // Entry-list variant for the reference's own Integrator.forward signature (modules/integrator.py:15-126):
@@ -427,8 +430,8 @@ OJF_API int ojf_integrate_masked(const float *depth_filtered, const uint8_t *mas
         a.list_base = (unsigned int)tiles * kSlots;
     }
     if (stats) OJF_HIP(hipMemsetAsync(stats, 0, 4 * sizeof(uint32_t), st));
-    if (id_vol) hipLaunchKernelGGL(integrate_accumulate_tiled_kernel<true>, dim3(tiles), dim3(256), 0, st, a, cam);
-    else hipLaunchKernelGGL(integrate_accumulate_tiled_kernel<false>, dim3(tiles), dim3(256), 0, st, a, cam);
+    if (id_vol) hipLaunchKernelGGL(integrate_accumulate_tiled_kernel<true>, dim3(tiles), dim3(kAccThreads), 0, st, a, cam);
+    else hipLaunchKernelGGL(integrate_accumulate_tiled_kernel<false>, dim3(tiles), dim3(kAccThreads), 0, st, a, cam);
     OJF_HIP(hipGetLastError());
     hipLaunchKernelGGL(integrate_finalize_kernel, dim3(tiles < 1024 ? 1024 : tiles), dim3(256), 0, st, a);
     return check_hip(hipGetLastError(), "ojf_integrate launch");
