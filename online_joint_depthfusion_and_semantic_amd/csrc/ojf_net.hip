@@ -53,6 +53,9 @@
 #ifndef OJF_CHAIN_BLOCKS
 #define OJF_CHAIN_BLOCKS 3
 #endif
+#ifndef OJF_CHAIN_WAVES
+#define OJF_CHAIN_WAVES 4
+#endif
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -570,14 +573,15 @@ constexpr int chain_first_size(int arith, int ntin, int ntout)
 }
 // per-layer floats in the bias stream: bias[NTOUT*16], and for split-fp16 the inverse row scales behind it
 constexpr int chain_bias_stride(int arith, int ntout) { return (arith == OJF_ARITH_F16X3 ? 2 : 1) * ntout * 16; }
-constexpr int kChainPre = kChainLdsFloat4 / 256;  // float4 registers per thread holding the prefetched next part
+constexpr int kChainWaves = OJF_CHAIN_WAVES, kChainThreads = 64 * kChainWaves;  // waves of a chain / tail / entry block
+constexpr int kChainPre = kChainLdsFloat4 / kChainThreads;  // float4 registers per thread holding the prefetched next part
 
 // LDS-DMA of `size` float4 (a multiple of 64) from src to the LDS address dst: wave w moves the 1 KB chunks
 // w, w+4, ...; completion = this wave's vmcnt reaching 0, visibility to the block = the barrier after that
 __device__ __forceinline__ void dma_part(const f32x4 *src, f32x4 *dst, int size, int wave, int lane)
 {
 #pragma unroll
-    for (int c0 = 0; c0 < kChainDmaHalf / 64; c0 += 4) {
+    for (int c0 = 0; c0 < kChainDmaHalf / 64; c0 += kChainWaves) {
         const int c = c0 + wave;
         if (c * 64 < size)
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + c * 64 + lane),
@@ -675,11 +679,11 @@ __device__ __forceinline__ void chain_layer(const f32x4 (&in)[MT][NA], f32x4 (&o
             __syncthreads();  // readers of the previous part are done
 #pragma unroll
             for (int k = 0; k < kChainPre; ++k)
-                if ((int)threadIdx.x + 256 * k < size) wlds[threadIdx.x + 256 * k] = pre[k];
+                if ((int)threadIdx.x + kChainThreads * k < size) wlds[threadIdx.x + kChainThreads * k] = pre[k];
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < kChainPre; ++k)
-                if ((int)threadIdx.x + 256 * k < nsize) pre[k] = nsrc[threadIdx.x + 256 * k];
+                if ((int)threadIdx.x + kChainThreads * k < nsize) pre[k] = nsrc[threadIdx.x + kChainThreads * k];
             if (part == 0) vec_issue(vs, nx);
         }
         if constexpr (MODE != kChainAccumulate) {
@@ -776,13 +780,13 @@ __device__ __forceinline__ void chain_run(f32x4 (&x)[MT][8], f32x4 (&y)[MT][8], 
 }
 
 template <int ARITH, int MT, int NT0, int... NTS>
-__global__ __launch_bounds__(256, OJF_CHAIN_BLOCKS) void chain1x1_kernel(const ChainArgs a)
+__global__ __launch_bounds__(kChainThreads, OJF_CHAIN_BLOCKS) void chain1x1_kernel(const ChainArgs a)
 {
     __shared__ f32x4 wlds[chain_dma(ARITH) ? 2 * kChainDmaHalf : kChainLdsFloat4];
     __shared__ f32x4 vec_lds[2 * kVecF4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
-    const int strip = (banded_block_x() * 4 + wave) * (MT * 16);
+    const int strip = (banded_block_x() * kChainWaves + wave) * (MT * 16);
     int p[MT];
     f32x4 x[MT][8], y[MT][8];
     VecStage vs;
@@ -813,7 +817,7 @@ __global__ __launch_bounds__(256, OJF_CHAIN_BLOCKS) void chain1x1_kernel(const C
         } else {
 #pragma unroll
             for (int k = 0; k < kChainPre; ++k)
-                if ((int)threadIdx.x + 256 * k < size0) pre[k] = a.w[threadIdx.x + 256 * k];
+                if ((int)threadIdx.x + kChainThreads * k < size0) pre[k] = a.w[threadIdx.x + kChainThreads * k];
         }
     }
     chain_run<ARITH, MT, NT0, NTS...>(x, y, wlds, a.w, a.bias, a, p, lane, pre, buf, vs);
@@ -860,7 +864,10 @@ __device__ __forceinline__ void block_colsum(const f32x4 (&x)[MT][NA], const int
     __syncthreads();
     if ((int)threadIdx.x < NT * 16) {
         const int t = threadIdx.x;
-        const float v = (red[t] + red[128 + t]) + (red[256 + t] + red[384 + t]);
+        float v = (red[t] + red[128 + t]) + (red[256 + t] + red[384 + t]);
+#pragma unroll
+        for (int w4 = 4; w4 < kChainWaves; w4 += 4)  // further waves of the block, four at a time in the same fixed order
+            v += (red[w4 * 128 + t] + red[(w4 + 1) * 128 + t]) + (red[(w4 + 2) * 128 + t] + red[(w4 + 3) * 128 + t]);
         if (v - v == 0.0f) {  // finite
             const long long q = (long long)__builtin_rintf(v * kColScale);  // |v| < 2^23: the product is exact up to the rounding of rintf
             if (q) atomicAdd(reinterpret_cast<unsigned long long *>(&out->fix[blockIdx.x % kColShards][t]), (unsigned long long)q);
@@ -876,14 +883,14 @@ __device__ __forceinline__ void block_colsum(const f32x4 (&x)[MT][NA], const int
 // convolution kernel needed 25 us for this launch (tap table, masks, 6 output tiles per wave) and a separate
 // column-sum launch re-read the same 37 MB.
 template <int ARITH, int MT, int NTIN, int NTOUT>
-__global__ __launch_bounds__(256, OJF_CHAIN_BLOCKS) void entry1x1_kernel(const ChainArgs a)
+__global__ __launch_bounds__(kChainThreads, OJF_CHAIN_BLOCKS) void entry1x1_kernel(const ChainArgs a)
 {
     __shared__ f32x4 wlds[chain_dma(ARITH) ? 2 * kChainDmaHalf : kChainLdsFloat4];
     __shared__ f32x4 vec_lds[2 * kVecF4];
-    __shared__ float red[4 * 128];
+    __shared__ float red[kChainWaves * 128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
-    const int strip = (banded_block_x() * 4 + wave) * (MT * 16);
+    const int strip = (banded_block_x() * kChainWaves + wave) * (MT * 16);
     f32x4 pre[kChainPre];
     int buf = 0;
     VecStage vs;
@@ -900,7 +907,7 @@ __global__ __launch_bounds__(256, OJF_CHAIN_BLOCKS) void entry1x1_kernel(const C
         } else {
 #pragma unroll
             for (int k = 0; k < kChainPre; ++k)
-                if ((int)threadIdx.x + 256 * k < size0) pre[k] = a.w[threadIdx.x + 256 * k];
+                if ((int)threadIdx.x + kChainThreads * k < size0) pre[k] = a.w[threadIdx.x + kChainThreads * k];
         }
     }
     int p[MT];
@@ -968,15 +975,15 @@ constexpr int head_first_size(int arith, int kind) { return chain_first_size(ari
 // CHAIN = 0: write the VortexPooling result planes.  CHAIN = 19 / 20: feed it straight into the prediction head
 // (same accumulator -> operand identity) and write est rows; the 114-channel tensor between them never exists.
 template <int ARITH, int MT, int NV, int NO, int CHAIN = 0>
-__global__ __launch_bounds__(256, OJF_CHAIN_BLOCKS) void vortex_tail_kernel(const TailArgs a)
+__global__ __launch_bounds__(kChainThreads, OJF_CHAIN_BLOCKS) void vortex_tail_kernel(const TailArgs a)
 {
     static_assert(CHAIN == 0 || NO == 8, "the fused prediction head / entry layer expects 8 input tiles");
     __shared__ f32x4 wlds[chain_dma(ARITH) ? 2 * kChainDmaHalf : kChainLdsFloat4];
     __shared__ f32x4 vec_lds[2 * kVecF4];
-    __shared__ float red[CHAIN == kTailEntry ? 4 * 128 : 1];
+    __shared__ float red[CHAIN == kTailEntry ? kChainWaves * 128 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
-    const int strip = (banded_block_x() * 4 + wave) * (MT * 16);
+    const int strip = (banded_block_x() * kChainWaves + wave) * (MT * 16);
     int p[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) p[m] = strip + m * 16 + i16;
@@ -1006,7 +1013,7 @@ __global__ __launch_bounds__(256, OJF_CHAIN_BLOCKS) void vortex_tail_kernel(cons
         } else {
 #pragma unroll
             for (int k = 0; k < kChainPre; ++k)
-                if ((int)threadIdx.x + 256 * k < size0) pre[k] = a.w[threadIdx.x + 256 * k];
+                if ((int)threadIdx.x + kChainThreads * k < size0) pre[k] = a.w[threadIdx.x + kChainThreads * k];
         }
     }
     constexpr size_t per_branch = (size_t)chain_layer_size(ARITH, NV, NO) + chain_layer_size(ARITH, NO, NO);
@@ -1985,7 +1992,7 @@ static GaveArgs gave_args(const ojf_net *net, const Vortex &v, const float *part
     return ga;
 }
 
-static int chain_blocks(const ojf_net *net) { return ((net->npix + 15) / 16 + 3) / 4; }  // blocks of the MT = 1 chain kernels
+static int chain_blocks(const ojf_net *net) { return ((net->npix + 15) / 16 + ojf::kChainWaves - 1) / ojf::kChainWaves; }  // blocks of the MT = 1 chain kernels
 
 // in: planes, window starting at group in_g0 (c_in_phys/4 groups); out: planes at group out_g0.
 // entry_done: the previous VortexPooling's tail already left this one's entry planes (sc.Z) and column sums (sc.colsum).
@@ -2022,7 +2029,7 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
         ea.in_g0 = in_g0; ea.c4_in = v.c_in_phys / 4; ea.npix = net->npix; ea.rows_stride = 0; ea.rows_n = 0; ea.scale = 1.0f;
         ea.ovf = h16 ? overflow_flag() : nullptr;
         ea.out_planes = planes(sc.Z); ea.out_g0 = 0; ea.og_store = 4 * c4; ea.act_n = net->cs; ea.colsum = sc.colsum;
-        const dim3 grid(chain_blocks(net)), block(256);
+        const dim3 grid(chain_blocks(net)), block(ojf::kChainThreads);
         if (h16) hipLaunchKernelGGL((entry1x1_kernel<OJF_ARITH_F16X3, 1, 8, 5>), grid, block, 0, st, ea);
         else hipLaunchKernelGGL((entry1x1_kernel<OJF_ARITH_F32, 1, 8, 5>), grid, block, 0, st, ea);
         mark_launch("entry1x1_kernel", st);
@@ -2083,7 +2090,7 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
     ta.chain_w = nullptr; ta.chain_b = nullptr; ta.out_rows = nullptr; ta.rows_stride = 0; ta.rows_n = 0; ta.scale = 1.0f;
     ta.entry_w = nullptr; ta.entry_b = nullptr; ta.entry_out = nullptr; ta.entry_og = 0; ta.entry_act_n = 0; ta.colsum = nullptr;
     // MT = 1: two pixel tiles per wave (324 VGPRs, one wave per SIMD) measured slower (0.624 vs 0.609 ms net)
-    const dim3 grid(chain_blocks(net)), block(256);
+    const dim3 grid(chain_blocks(net)), block(ojf::kChainThreads);
     static const bool no_head_fusion = getenv("OJF_NO_HEAD_FUSION") != nullptr;  // ablation switch only
     static const bool no_entry_fusion = getenv("OJF_NO_ENTRY_FUSION") != nullptr;  // ablation switch only
     if (head && net->chain_kind && !no_head_fusion) {  // last VortexPooling: the prediction head rides along
@@ -2482,8 +2489,7 @@ static int forward_launches(ojf_net *net, float *est, int est_stride, hipStream_
     if (net->chain_kind && !unfused) {
         // stand-alone head (the tail fusion is off or unavailable); one pixel tile per wave: two measured slower
         const bool h16 = net->arith == OJF_ARITH_F16X3;
-        const int strips = (net->npix + 15) / 16;
-        const dim3 grid((strips + 3) / 4), block(256);
+        const dim3 grid(chain_blocks(net)), block(ojf::kChainThreads);
         if (net->chain_kind == 19 && h16)
             hipLaunchKernelGGL((chain1x1_kernel<OJF_ARITH_F16X3, 1, 8, 6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1>), grid, block, 0, st, ca);
         else if (net->chain_kind == 19)
