@@ -56,6 +56,9 @@
 #ifndef OJF_CHAIN_WAVES
 #define OJF_CHAIN_WAVES 4
 #endif
+#ifndef OJF_CHAIN_AHEAD
+#define OJF_CHAIN_AHEAD 2
+#endif
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -573,6 +576,7 @@ constexpr int chain_first_size(int arith, int ntin, int ntout)
 }
 // per-layer floats in the bias stream: bias[NTOUT*16], and for split-fp16 the inverse row scales behind it
 constexpr int chain_bias_stride(int arith, int ntout) { return (arith == OJF_ARITH_F16X3 ? 2 : 1) * ntout * 16; }
+constexpr int kChainAhead = OJF_CHAIN_AHEAD;  // weight fragments requested ahead of their MFMAs (split-fp16 chain layers)
 constexpr int kChainWaves = OJF_CHAIN_WAVES, kChainThreads = 64 * kChainWaves;  // waves of a chain / tail / entry block
 constexpr int kChainPre = kChainLdsFloat4 / kChainThreads;  // float4 registers per thread holding the prefetched next part
 
@@ -694,17 +698,41 @@ __device__ __forceinline__ void chain_layer(const f32x4 (&in)[MT][NA], f32x4 (&o
                     if (n2 >= nb && n2 < ne) out[m][n2] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         // K block outer, output tiles inner: (ne - nb) * MT independent accumulators per MFMA round
+        if constexpr (ARITH == OJF_ARITH_F16X3) {
+            // Software pipeline over the part's (K block, output tile) steps: the weight fragments of step t + kChainAhead
+            // are requested from LDS before the MFMAs of step t are issued.  Left alone, the compiler sinks every
+            // ds_read next to its use (read -> s_waitcnt lgkmcnt(0) -> 3 MFMAs): ~100 cycles of LDS latency per 48
+            // cycles of matrix work, the "parked" half of this kernel's wave-cycles.
+            const int cnt = ne - nb, steps = KB * cnt;
+            f32x4 rh[kChainAhead], rl[kChainAhead];
+            auto frag = [&](int t) { return ((t % cnt) * KB + t / cnt) * 128; };  // step t = (S = t / cnt, tile nb + t % cnt)
+#pragma unroll
+            for (int t = 0; t < kChainAhead; ++t)
+                if (t < steps) {
+                    rh[t] = wpart[frag(t) + lane];
+                    rl[t] = wpart[frag(t) + 64 + lane];
+                }
+#pragma unroll
+            for (int t = 0; t < KB * NTOUT; ++t) {
+                if (t >= steps) break;
+                const f32x4 wh = rh[t % kChainAhead], wl = rl[t % kChainAhead];
+                if (t + kChainAhead < steps) {
+                    rh[t % kChainAhead] = wpart[frag(t + kChainAhead) + lane];
+                    rl[t % kChainAhead] = wpart[frag(t + kChainAhead) + 64 + lane];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int S = t / cnt, n2 = nb + t % cnt;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) out[m][n2] = mfma_f16x3(wh, wl, xh[m][S], xl[m][S], out[m][n2]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
         for (int S = 0; S < KB; ++S)
 #pragma unroll
             for (int n2 = 0; n2 < NTOUT; ++n2) {
                 if (n2 < nb || n2 >= ne) continue;
-                if constexpr (ARITH == OJF_ARITH_F16X3) {
-                    const f32x4 wh = wpart[((n2 - nb) * KB + S) * 128 + lane];
-                    const f32x4 wl = wpart[((n2 - nb) * KB + S) * 128 + 64 + lane];
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) out[m][n2] = mfma_f16x3(wh, wl, xh[m][S], xl[m][S], out[m][n2]);
-                } else {
+                {
                     const f32x4 wv = wpart[((n2 - nb) * KB + S) * 64 + lane];
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
@@ -713,6 +741,7 @@ __device__ __forceinline__ void chain_layer(const f32x4 (&in)[MT][NA], f32x4 (&o
                             out[m][n2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], in[m][S][j], out[m][n2], 0, 0, 0);
                 }
             }
+        }
     }
     if constexpr (MODE != kChainAccumulate) {
         const int g = lane >> 4;
