@@ -23,7 +23,18 @@ Rank 0 prints ONE JSON line with the driver's contract fields plus
   cpu_baseline         the op-for-op torch-CPU port of the reference path timed on this node's host cores
   secondary            (N = 1, default flags only) short runs of the other BASELINE configurations in the same process:
                        fp32-input MFMA arithmetic, + semantics (gt labels), + semantics predicted by AdapNet++,
-                       640x480 -> 512^3 (configs[4] size) without / with semantics
+                       640x480 -> 512^3 (configs[4] size) without / with semantics, and the configs[3] TRAINING frame step
+
+Timing: after W warm-up steps the K-step timed loop (barrier + synchronize on both sides, max over ranks) is run
+``--repeats`` times (default 5) back to back; ``value`` / ``ms_per_step`` are the MEDIAN repeat, ``value_min`` / ``value_max``
+the slowest / fastest one (a single 9 ms region moves by a percent with one slow launch).
+
+``--train`` times BASELINE configs[3]'s frame step instead (train_fusion.py:145-189): fuse_training + FusionLoss + backward
+on every frame, and at every accumulation boundary (8 frames) the flat-gradient all-reduce over RCCL + the RMSprop step;
+``allreduce_us`` is the mean duration of that collective from events on the launch stream.
+
+Launching: ``python bench.py --gpus N`` with N > 1 and no WORLD_SIZE in the environment starts its own N ranks (one
+process per GPU, rendezvous on 127.0.0.1) and waits for them; under ``torch.distributed.run`` the ranks are used as given.
 """
 import argparse
 import json
@@ -216,7 +227,7 @@ class Case:
     def fuse(self, i):
         self.pipe.fuse(self.batches[i % len(self.batches)], self.db, self.dev)
 
-    def run(self, steps, warmup, sync, profile_frames=32, kernel_reps=5):
+    def run(self, steps, warmup, sync, profile_frames=32, kernel_reps=5, repeats=1):
         pipe = self.pipe
         with torch.no_grad():
             pipe.profile = False
@@ -224,12 +235,17 @@ class Case:
                 self.fuse(i)
             pipe.profile = 4  # stage events on every 4th frame of the timed region
             pipe.reset_profile()
-            sync()
-            t0 = time.perf_counter()
-            for i in range(warmup, warmup + steps):
-                self.fuse(i)
-            sync()
-            elapsed = time.perf_counter() - t0
+            times = []
+            at = warmup
+            for _ in range(repeats):  # each repeat: EXACTLY `steps` frames between two barrier + synchronize points
+                sync()
+                t0 = time.perf_counter()
+                for i in range(at, at + steps):
+                    self.fuse(i)
+                sync()
+                times.append(time.perf_counter() - t0)
+                at += steps
+            steps_done = at - warmup
             pipe.check()  # outside the timed region: raises if the split-fp16 range guard fired on any frame
             stages = pipe.stage_times_ms()
             n_samples = len(pipe._marks) // 4
@@ -237,7 +253,7 @@ class Case:
             pipe.profile = True
             pipe.reset_profile()
             for i in range(profile_frames):
-                self.fuse(warmup + steps + i)
+                self.fuse(warmup + steps_done + i)
             stages_all = pipe.stage_times_ms() if profile_frames else {}
             pipe.profile = False
             # per-kernel table of the fusion net: profiled forwards on the last frame's packed input
@@ -250,7 +266,7 @@ class Case:
                     ent[1] += max(us, 0.0)
             kernels = {name: {'launches_per_frame': n / reps, 'us_per_frame': us / reps} for name, (n, us) in table.items()}
             pipe.check()
-        return {'elapsed': elapsed, 'stages': stages, 'stage_samples': n_samples, 'stages_all': stages_all,
+        return {'times': times, 'stages': stages, 'stage_samples': n_samples, 'stages_all': stages_all,
                 'stages_all_frames': profile_frames, 'kernels': kernels, 'launches': pipe._engine.launches}
 
 
@@ -279,12 +295,15 @@ def kernel_table(kernels, c, N, peak_tf, total_macs):
 def report(case, res, steps, warmup, world, args_cpu_frames=0, full=True):
     c, cfg, st = case.c, case.cfg, case.st
     h, w, grid = c['h'], c['w'], c['grid']
-    fps = world * steps / res['elapsed']
+    times = sorted(res['times'])
+    med = times[len(times) // 2] if len(times) % 2 else 0.5 * (times[len(times) // 2 - 1] + times[len(times) // 2])
+    fps = world * steps / med
     N = h * w
     peak = ARITH[c['arith']][2]
     stages = res['stages']
-    out = {'workload': workload_name(c), 'value': fps, 'unit': 'frames/sec', 'ms_per_step': 1e3 * res['elapsed'] / steps,
-           'steps': steps, 'warmup': warmup, 'stages_ms': stages, 'stage_samples_in_timed_region': res['stage_samples'],
+    out = {'workload': workload_name(c), 'value': fps, 'unit': 'frames/sec', 'ms_per_step': 1e3 * med / steps,
+           'steps': steps, 'warmup': warmup, 'repeats': len(times), 'value_min': world * steps / times[-1],
+           'value_max': world * steps / times[0], 'stages_ms': stages, 'stage_samples_in_timed_region': res['stage_samples'],
            'stages_ms_all_frames': res['stages_all'], 'stages_all_frames_pass': '%d untimed frames, events on every frame' % res['stages_all_frames'],
            'net_launches_per_frame': res['launches']}
     if not full:
@@ -333,14 +352,128 @@ def report(case, res, steps, warmup, world, args_cpu_frames=0, full=True):
     return out
 
 
+class TrainCase:
+    """BASELINE configs[3] on this rank: one scene, Pipeline.fuse_training + FusionLoss + backward per frame, and at every
+    accumulation boundary the flat-gradient all-reduce (RCCL when world > 1) + RMSprop step (train_fusion.py:145-189;
+    drivers.train_fusion is the full driver, this is its inner loop without logging / validation / host reads of the loss)."""
+
+    def __init__(self, h, w, grid, dev, rank, n_frames, accum=8):
+        from online_joint_depthfusion_and_semantic_amd.distributed import FlatGradientAllReduce
+        from online_joint_depthfusion_and_semantic_amd.drivers import _training_defaults
+        from online_joint_depthfusion_and_semantic_amd.loss import FusionLoss
+        cfg = _training_defaults(default_config(h, w))
+        cfg.SETTINGS.device = str(dev)
+        self.cfg, self.dev, self.accum = cfg, dev, accum
+        n_distinct = min(n_frames, DISTINCT_FRAMES)
+        self.st = SyntheticStream(h, w, grid, max(n_distinct, 40), scene='room_%d' % rank, seed=1911 + rank)
+        self.db = Database(self.st, database_config(cfg))
+        pipe = Pipeline(cfg)
+        seeded_weights(pipe)  # the same on every rank (a replica), like train_fusion's broadcast initial state
+        self.pipe = pipe.to(dev).train()
+        self.crit = FusionLoss(w_l1=cfg.TRAINING.loss.w_l1, w_l2=cfg.TRAINING.loss.w_l2, w_cos=cfg.TRAINING.loss.w_cos)
+        self.grads = FlatGradientAllReduce(self.pipe._fusion_network)
+        o = cfg.TRAINING.optimizer
+        self.opt = torch.optim.RMSprop(self.pipe._fusion_network.parameters(), lr=o['lr'], momentum=o['momentum'],
+                                       weight_decay=o['weight_decay'], eps=o['eps'])
+        self.batches = []
+        image = torch.zeros((1, 3, h, w), device=dev)
+        for i in range(n_distinct):
+            f = self.st.frame(i)
+            self.batches.append({'image': image, 'frame_id': [f['frame_id']],
+                                 self.st.depth_key: torch.from_numpy(f[self.st.depth_key]).unsqueeze(0).to(dev),
+                                 'mask': torch.from_numpy(f['mask']).unsqueeze(0).to(dev),
+                                 'extrinsics': torch.from_numpy(f['extrinsics']).unsqueeze(0),
+                                 'intrinsics': torch.from_numpy(f['intrinsics']).unsqueeze(0)})
+        self.reduce_events = []
+        self.loss_sum = None
+
+    def step(self, i):
+        out = self.pipe.fuse_training(self.batches[i % len(self.batches)], self.db, self.dev)
+        if out['tsdf_fused'].shape[1]:
+            loss = self.crit.forward(out['tsdf_fused'], out['tsdf_target'])
+            loss.backward()
+            # train_fusion.py:172 adds loss.item() to a window that is read every log_freq frames; summed on the device
+            # and read once per timed loop here (the same numbers, without a host round trip per frame)
+            self.loss_sum = loss.detach() if self.loss_sum is None else self.loss_sum + loss.detach()
+        if (i + 1) % self.accum == 0:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            self.grads.reduce()  # the only collective of the training path
+            b.record()
+            self.reduce_events.append((a, b))
+            self.opt.step()
+            self.grads.zero()
+
+    def run(self, steps, warmup, sync, repeats):
+        for i in range(warmup):
+            self.step(i)
+        self.reduce_events = []
+        times, at = [], warmup
+        for _ in range(repeats):
+            sync()
+            t0 = time.perf_counter()
+            self.loss_sum = None
+            for i in range(at, at + steps):
+                self.step(i)
+            mean_loss = float(self.loss_sum) / steps if self.loss_sum is not None else float('nan')  # the log window's read
+            sync()
+            times.append(time.perf_counter() - t0)
+            at += steps
+        loss_ok = bool(torch.isfinite(self.grads.flat).all()) and mean_loss == mean_loss
+        ar = [a.elapsed_time(b) * 1e3 for a, b in self.reduce_events]
+        return {'times': times, 'allreduce_us': float(np.mean(ar)) if ar else None, 'allreduce_calls': len(ar),
+                'gradient_bytes': self.grads.nbytes, 'finite': loss_ok, 'mean_loss': mean_loss}
+
+
+def train_report(case, res, steps, warmup, world, h, w, grid):
+    times = sorted(res['times'])
+    med = times[len(times) // 2] if len(times) % 2 else 0.5 * (times[len(times) // 2 - 1] + times[len(times) // 2])
+    return {'workload': 'BASELINE configs[3]: training frame step (fuse_training + FusionLoss + backward per frame; flat-gradient '
+                        'all-reduce + RMSprop step every %d frames), %dx%d depth into a %d^3 grid, FusionNet_v3 train() mode '
+                        '(batch statistics, dropout), fp32-MFMA training kernels, one scene per GPU' % (case.accum, w, h, grid),
+            'value': world * steps / med, 'unit': 'frames/sec', 'ms_per_step': 1e3 * med / steps, 'steps': steps, 'warmup': warmup,
+            'repeats': len(times), 'value_min': world * steps / times[-1], 'value_max': world * steps / times[0],
+            'allreduce_us': res['allreduce_us'], 'allreduce_calls_in_timed_region': res['allreduce_calls'],
+            'allreduce_backend': ('rccl' if world > 1 else 'none (one rank)'), 'gradient_bytes': res['gradient_bytes'],
+            'gradients_finite': res['finite'], 'mean_loss_last_repeat': res['mean_loss']}
+
+
+def launch_ranks(n, argv):
+    """``python bench.py --gpus N`` without a launcher: start N ranks of this script (one process per GPU, rendezvous on
+    127.0.0.1) and wait for them.  Rank 0 prints the JSON line on the shared stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    codes = []
+    try:
+        for pr in procs:
+            codes.append(pr.wait())
+    finally:
+        for pr in procs:  # a rank that died must not leave the others waiting in a collective
+            if pr.poll() is None:
+                pr.kill()
+    bad = [c for c in codes if c != 0]
+    if bad or len(codes) != n:
+        raise SystemExit('bench.py: rank exit codes %r' % codes)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--repeats', type=int, default=5, help='how many times the K-step timed loop runs; value = the median repeat')
     ap.add_argument('--height', type=int, default=240)
     ap.add_argument('--width', type=int, default=320)
     ap.add_argument('--grid', type=int, default=256)
+    ap.add_argument('--train', action='store_true', help='BASELINE configs[3]: time the training frame step (incl. the gradient all-reduce)')
     ap.add_argument('--semantics', action='store_true', help='BASELINE configs[2]-style: gt labels + semantic head')
     ap.add_argument('--semantic-strategy', default='gt', choices=['gt', 'predict'],
                     help="with --semantics: 'predict' runs AdapNet++ (random init) on every frame")
@@ -357,19 +490,30 @@ def main():
                          'pass, no profiled forwards, no secondary / CPU legs - so every kernel runs exactly steps + warmup times per launch site')
     ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL, default) | gloo (validation of the N>1 path on a 1-GPU box)')
     args = ap.parse_args()
+    if args.gpus < 1 or args.steps < 1 or args.repeats < 1:
+        raise SystemExit('bench.py: --gpus, --steps and --repeats must be positive')
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # no launcher: this process becomes the launcher of N ranks of itself
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)')
+        if args.dist_backend == 'nccl' and torch.cuda.device_count() < args.gpus:
+            raise SystemExit('bench.py: --gpus %d but only %d HIP device(s) visible (RCCL needs one device per rank; '
+                             '--dist-backend gloo lets several ranks share a device for validation)' % (args.gpus, torch.cuda.device_count()))
+        launch_ranks(args.gpus, sys.argv[1:])
+        return
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
     if world != args.gpus:
-        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)' % (args.gpus, world))
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)')
     dev = torch.device('cuda', local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
-        # RCCL; used only for the barrier + max-reduce of the time (no data-path collective)
+        # RCCL: barrier + max-reduce of the times; with --train also the gradient all-reduce (the path's only collective)
         if args.dist_backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
         else:
@@ -380,40 +524,68 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
+    def max_over_ranks(times):
+        if world > 1:
+            t = torch.tensor(times, dtype=torch.float64, device=dev if args.dist_backend == 'nccl' else 'cpu')
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            return [float(x) for x in t.tolist()]
+        return times
+
     head = dict(h=args.height, w=args.width, grid=args.grid, semantics=args.semantics, strategy=args.semantic_strategy,
                 seg_engine=args.seg_engine, mode=args.mode, arith=args.arith, n_classes=args.n_classes)
-    default_flags = head == dict(h=240, w=320, grid=256, semantics=False, strategy='gt', seg_engine='hip', mode='fast',
-                                 arith='f16x3', n_classes=30)
-    case = Case(head, dev, rank, args.steps + args.warmup)
+    default_flags = (not args.train) and head == dict(h=240, w=320, grid=256, semantics=False, strategy='gt', seg_engine='hip',
+                                                       mode='fast', arith='f16x3', n_classes=30)
+    metric = 'frames/sec fused (%dx%d, %d^3 grid)' % (args.width, args.height, args.grid)
+    total = args.warmup + args.steps * args.repeats
+    if args.train:
+        if world > 1 and args.dist_backend != 'nccl':
+            # gloo validates the launch / barrier / schedule on one device; its all-reduce needs host tensors
+            raise SystemExit('bench.py --train with N > 1 needs --dist-backend nccl (the gradient buffer lives in HBM)')
+        tc = TrainCase(args.height, args.width, args.grid, dev, rank, total)
+        res = tc.run(args.steps, args.warmup, sync, args.repeats)
+        res['times'] = max_over_ranks(res['times'])
+        if rank == 0:
+            r = train_report(tc, res, args.steps, args.warmup, world, args.height, args.width, args.grid)
+            print(json.dumps({'metric': metric + ', training frame step', 'value': r['value'], 'unit': 'frames/sec', 'n_gpus': world,
+                              'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': r['ms_per_step'], 'higher_is_better': True,
+                              'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                              'config': {'workload': r['workload'], 'frame': [args.height, args.width], 'grid': args.grid,
+                                         'parallelism': 'scene-sharded x%d, gradient all-reduce every %d frames' % (world, tc.accum)},
+                              **{k: r[k] for k in ('repeats', 'value_min', 'value_max', 'allreduce_us', 'allreduce_calls_in_timed_region',
+                                                   'allreduce_backend', 'gradient_bytes', 'gradients_finite')}}))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+    case = Case(head, dev, rank, total)
     if args.lean:
-        res = case.run(args.steps, args.warmup, sync, profile_frames=0, kernel_reps=0)
+        res = case.run(args.steps, args.warmup, sync, profile_frames=0, kernel_reps=0, repeats=1)
         if rank == 0:
             r = report(case, res, args.steps, args.warmup, world, full=False)
-            print(json.dumps({'metric': 'frames/sec fused (%dx%d, %d^3 grid)' % (args.width, args.height, args.grid), 'value': r['value'],
+            print(json.dumps({'metric': metric, 'value': r['value'],
                               'unit': 'frames/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': r['ms_per_step'],
                               'lean': True, 'frames_fused': args.steps + args.warmup, 'stages_ms': r['stages_ms']}))
+        if world > 1:
+            torch.distributed.destroy_process_group()
         return
-    res = case.run(args.steps, args.warmup, sync)
-    elapsed = res['elapsed']
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == 'nccl' else 'cpu')
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        res['elapsed'] = float(t.item())
+    res = case.run(args.steps, args.warmup, sync, repeats=args.repeats)
+    res['times'] = max_over_ranks(res['times'])
 
     if rank == 0:
         r = report(case, res, args.steps, args.warmup, world)
         cfg = case.cfg
         out = {
-            'metric': 'frames/sec fused (%dx%d, %d^3 grid)' % (args.width, args.height, args.grid), 'value': r['value'], 'unit': 'frames/sec',
+            'metric': metric, 'value': r['value'], 'unit': 'frames/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': r['ms_per_step'],
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': ARITH[args.arith][0], 'data': 'synthetic',
             'config': {'workload': r['workload'], 'frame': [args.height, args.width], 'grid': args.grid,
                        'n_points': cfg.FUSION_MODEL.n_points, 'n_tail_points': cfg.FUSION_MODEL.n_tail_points,
                        'integrate_mode': args.mode, 'volume_dtype': 'f16', 'net_arithmetic': ARITH[args.arith][1],
                        'parallelism': 'scene-sharded x%d' % world},
+            'timing': 'median of %d back-to-back repeats of the %d-step timed loop (each bracketed by barrier + synchronize, max over ranks)'
+                      % (args.repeats, args.steps),
         }
-        for k in ('stages_ms', 'stage_samples_in_timed_region', 'stages_ms_all_frames', 'stages_all_frames_pass', 'net_launches_per_frame',
-                  'kernels', 'roofline', 'roofline_net', 'roofline_hbm'):
+        for k in ('repeats', 'value_min', 'value_max', 'stages_ms', 'stage_samples_in_timed_region', 'stages_ms_all_frames',
+                  'stages_all_frames_pass', 'net_launches_per_frame', 'kernels', 'roofline', 'roofline_net', 'roofline_hbm'):
             if k in r:
                 out[k] = r[k]
         del case
@@ -428,13 +600,21 @@ def main():
                           dict(h=480, w=640, grid=512, semantics=True, n_classes=40)):
                 c2 = dict(head, **extra)
                 try:
-                    case2 = Case(c2, dev, rank, n_sec + 10)
-                    r2 = report(case2, case2.run(n_sec, 10, sync, profile_frames=16), n_sec, 10, 1, full=False)
+                    case2 = Case(c2, dev, rank, 3 * n_sec + 10)
+                    r2 = report(case2, case2.run(n_sec, 10, sync, profile_frames=16, repeats=3), n_sec, 10, 1, full=False)
                     del case2
                 except Exception as e:  # a secondary workload must not take the headline line down with it
                     r2 = {'workload': workload_name(c2), 'error': repr(e)}
                 torch.cuda.empty_cache()
                 secondary.append(r2)
+            try:  # BASELINE configs[3]: the training frame step on this GPU (no collective at N = 1)
+                n_tr = max(8, (n_sec // 2) // 8 * 8)
+                tc = TrainCase(240, 320, 256, dev, rank, 8 + 3 * n_tr)
+                secondary.append(train_report(tc, tc.run(n_tr, 8, sync, 3), n_tr, 8, 1, 240, 320, 256))
+                del tc
+            except Exception as e:
+                secondary.append({'workload': 'BASELINE configs[3]: training frame step', 'error': repr(e)})
+            torch.cuda.empty_cache()
             out['secondary'] = secondary
         if world == 1 and args.cpu_frames > 0:
             out['cpu_baseline'] = cpu_baseline(args, args.height, args.width, args.grid, args.semantics)

@@ -190,7 +190,10 @@ class SegEngine:
         as the dataset hands it over (divided by 255 here, pipeline.py:44), ``depth`` [1,H,W] / [1,1,H,W] replicated to three
         channels (:50) - per-pixel (scores f32 [H*W], ids u8 [H*W]) out.  Every step is a libojf launch."""
         if self.fusion:
-            logits = self.forward(segconv.pack_input(image.contiguous(), 255.0), segconv.pack_input(depth.contiguous(), 1.0))
+            first = segconv.pack_input(image.contiguous(), 255.0)
+            # DATA.input == 'image': the reference feeds the image to both encoders (modules/pipeline.py:52-55)
+            second = segconv.pack_input(depth.contiguous(), 1.0) if depth is not None else first
+            logits = self.forward(first, second)
         elif depth is not None:  # stage 1 nets see the DATA.input modality only (pipeline.py:52-53)
             logits = self.forward(segconv.pack_input(depth.contiguous(), 1.0))
         else:

@@ -318,7 +318,8 @@ class Pipeline(torch.nn.Module):
             tn = self.__dict__.get('_hip_train')
             if tn is None or tn.net is not self._fusion_network:
                 from .train import HipTrainNet
-                tn = self.__dict__['_hip_train'] = HipTrainNet(self._fusion_network, graph=self.config.FUSION_MODEL.get('train_graph', False))
+                tn = self.__dict__['_hip_train'] = HipTrainNet(self._fusion_network, graph=self.config.FUSION_MODEL.get('train_graph', False),
+                                                               inplace_grads=True)
             return tn(inputs)
         return self._fusion_network.forward(inputs)
 

@@ -60,10 +60,13 @@ def _packed(lib, cache, w, bias, group, slot, c_in_phys, c_out_phys, transposed,
 
 def _grad_target(p, needed, capturing):
     """Where a parameter gradient of this backward pass goes: (tensor the kernel writes, accumulate flag, value returned
-    to autograd).  For a leaf parameter the kernels write / add straight into ``p.grad`` and autograd gets None - the
-    engine's AccumulateGrad would otherwise launch one add per parameter and frame (224 launches, 0.9 ms per 320x240
-    frame with gradients accumulated over 8 frames, train_fusion.py:174-189).  The sums are formed in the same order
-    (grad = (g1 + g2) + ...).  Non-leaf tensors, exotic ``.grad`` layouts and graph capture take the ordinary route."""
+    to autograd).  With ``HipTrainNet(inplace_grads=True)`` (what Pipeline.fuse_training asks for) the kernels write /
+    add a leaf parameter's gradient straight into ``p.grad`` and autograd gets None - the engine's AccumulateGrad would
+    otherwise launch one add per parameter and frame (224 launches, 0.9 ms per 320x240 frame with gradients accumulated
+    over 8 frames, train_fusion.py:174-189).  The sums are formed in the same order (grad = (g1 + g2) + ...).  Without
+    the flag (``capturing`` then carries "take the ordinary route"), for non-leaf tensors, exotic ``.grad`` layouts and
+    under graph capture the gradient is returned to autograd like from any other Function, so
+    ``torch.autograd.grad(loss, net.parameters())`` works and nothing is mutated behind autograd's back."""
     if p is None or not needed:
         return None, 0, None
     if p.is_leaf and p.requires_grad and not capturing:
@@ -104,7 +107,9 @@ class LayerUnit(torch.autograd.Function):
             mean = torch.empty(c_out_phys, dtype=torch.float32, device=dev)
             invstd = torch.empty(c_out_phys, dtype=torch.float32, device=dev)
             partial = torch.empty(lib.ojf_train_partial_doubles(c_out_phys), dtype=torch.float64, device=dev)
-            momentum = 0.1 if bn.momentum is None else float(bn.momentum)
+            if bn.momentum is None:  # cumulative average: the factor 1 / num_batches_tracked lives on the device
+                raise _lib.OjfError('HipTrainNet: BatchNorm2d(momentum=None) is not supported (use train_engine: torch)')
+            momentum = float(bn.momentum)
             eps = float(bn.eps)
             if training:
                 counters = meta.get('counters')
@@ -139,7 +144,7 @@ class LayerUnit(torch.autograd.Function):
         has_bn = meta['bn'] is not None
         dy = torch.empty_like(y)
         partial = torch.empty(lib.ojf_train_partial_doubles(c_out_phys), dtype=torch.float64, device=dev)
-        capturing = torch.cuda.is_current_stream_capturing()
+        capturing = torch.cuda.is_current_stream_capturing() or not meta.get('inplace_grads', False)
         p_w, p_b, p_g, p_be = ctx.params
         gw, aw, rw = _grad_target(p_w, ctx.needs_input_grad[1], capturing)
         gb, ab, rb = _grad_target(p_b, p_b is not None and ctx.needs_input_grad[2], capturing)
@@ -237,9 +242,10 @@ class HipTrainNet:
     """Runs ``net`` (model.FusionNet_v3 / FusionNet_v2) through ``LayerUnit`` nodes.  ``net.training`` selects batch
     statistics + dropout (train) or running statistics, no dropout (eval), exactly like the module's own forward."""
 
-    def __init__(self, net, graph=False):
+    def __init__(self, net, graph=False, inplace_grads=False):
         _lib.require_gpu()
         self.net = net
+        self.inplace_grads = bool(inplace_grads)  # see _grad_target
         self._cache = {}      # packed weights by (address, layout) -> (version, tensors)
         self._counters = []   # num_batches_tracked of the BatchNorms that saw batch statistics in this forward
         self._rand = None     # one uniform draw per forward for all Dropout2d masks
@@ -250,9 +256,11 @@ class HipTrainNet:
 
     # ---- one Sequential of conv/BN/act/dropout slots -> units ------------------------------------------------------
     def _unit(self, x, conv, bn, act, dropout, group, slot, scale=1.0):
-        training = self.net.training
+        # batch vs running statistics and dropout follow the INDIVIDUAL modules' flags like nn.Sequential's forward does
+        # (a BatchNorm frozen with bn.eval() inside a net in train() mode keeps its running statistics)
+        training = bn.training if bn is not None else False
         drop = None
-        if dropout is not None and training and dropout.p > 0:  # Dropout2d: whole channels, survivors scaled by 1 / keep
+        if dropout is not None and dropout.training and dropout.p > 0:  # Dropout2d: whole channels, survivors scaled by 1 / keep
             n = conv.out_channels
             keep = 1.0 - dropout.p
             if keep not in self._masks:  # one compare / scale launch per distinct p and forward pass, sliced per layer
@@ -260,6 +268,7 @@ class HipTrainNet:
             drop = self._masks[keep][self._rand_at:self._rand_at + n]
             self._rand_at += n
         meta = dict(group=group, slot=slot, dil=int(conv.dilation[0]), act=act, scale=scale, bn=bn, drop=drop, training=training,
+                    inplace_grads=self.inplace_grads,
                     cache=None if torch.cuda.is_current_stream_capturing() else self._cache, counters=self._counters)
         return LayerUnit.apply(x, conv.weight, conv.bias, bn.weight if bn is not None else None, bn.bias if bn is not None else None, meta)
 
@@ -300,12 +309,14 @@ class HipTrainNet:
         idx = self._logical_index(group, slot, v.gave_pool[1].in_channels, dev)
         gc = v.gave_pool[1]
         bn = v.gave_pool[3]
-        if self.net.training:
+        if bn.training:
             # batch statistics of a constant map: mean = the value, variance = 0 -> the output is beta, the gradients
             # towards g, gamma and x vanish; running_mean moves towards g, running_var towards 0 (unbiased estimate
             # of 0).  Nothing of this branch is differentiated, so the pooled input comes from a libojf launch (fp64
             # slab sums in fixed order) outside autograd instead of torch's strided mean and its broadcast backward.
-            m = 0.1 if bn.momentum is None else bn.momentum
+            if bn.momentum is None:
+                raise _lib.OjfError('HipTrainNet: BatchNorm2d(momentum=None) is not supported (use train_engine: torch)')
+            m = bn.momentum
             with torch.no_grad():
                 lib = _lib.load()
                 xc = x.contiguous()
@@ -370,7 +381,8 @@ class HipTrainNet:
         net = self.net
         from .model import FusionNet_v3
         self._counters = []
-        if net.training:  # every Dropout2d mask of this pass from one draw (sliced per layer)
+        if any(m.training and m.p > 0 for m in net.modules() if isinstance(m, nn.Dropout2d)):
+            # every Dropout2d mask of this pass from one draw (sliced per layer)
             total = sum(m.out_channels for m in net.modules() if isinstance(m, nn.Conv2d))
             self._rand, self._rand_at, self._masks = torch.rand(total, device=x['tsdf_values'].device), 0, {}
         c = net.n_channels
@@ -414,6 +426,12 @@ class _GraphedPass:
             for k, v in sample.items():
                 self.static_in[k].copy_(v)
             buffers = [b.clone() for b in net.buffers()]  # the warm-up passes must not count as training steps
+            # ... nor leave anything in the parameters' .grad (with in-place gradients the warm-up's backward
+            # wrote into p.grad - views of the flat all-reduce buffer in train_fusion - and the first optimizer step
+            # saw it): the warm-up runs against detached .grad slots, the original tensors come back afterwards
+            saved_grads = [p.grad for p in self.params]
+            for p in self.params:
+                p.grad = None
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
@@ -436,6 +454,10 @@ class _GraphedPass:
         except Exception as e:  # capture is an optimisation only; the eager launches remain
             self.error = e
             torch.cuda.synchronize(dev)
+        finally:
+            if 'saved_grads' in locals():
+                for p, gsaved in zip(self.params, saved_grads):
+                    p.grad = gsaved
 
 
 class _GraphedFn(torch.autograd.Function):

@@ -222,6 +222,68 @@ def run_pipeline_full_size(h, w, grid, frames, use_semantics, small):
     return out
 
 
+def run_training_full_size(h=240, w=320, grid=256):
+    """BASELINE configs[3]'s frame step at its own size: ONE ``fuse_training`` call of the reference
+    (modules/pipeline.py:251-363) at 320x240 -> 256^3, followed by ``loss.backward()``.
+
+    Pre-frame state = two frames of the reference's Extractor + Integrator fed with the seeded stand-in of
+    tests/helpers.py::frame_inputs (rng [7, i], uniform +-0.15) - a state the C oracle reproduces bit for bit on the GPU
+    box (sha256 kept here), so the fixture does not depend on any net.  Then frame 2 through the reference's
+    ``Pipeline.fuse_training`` with the seeded state_dict of the small fixtures, eval() mode (dropout and batch statistics
+    cannot be pinned), and the gradients of  mean|fused - target| + 10 mean (fused - target)^2  (utils/loss.py's
+    FusionLoss raises under this torch; any differentiable scalar pins the backward pass).
+    Kept: every 7th row of tsdf_est / tsdf_fused + float64 column sums of all rows, sha256 of tsdf_target, the valid
+    count, ALL parameter gradients (fp32, 1.4 MB), sha256 of the post-frame weight volume and the post-frame TSDF at
+    the touched voxels."""
+    from online_joint_depthfusion_and_semantic_amd.synthetic import gt_volumes
+    cfg = ref_config(h, w, False, False)
+    ex, ig = Extractor(cfg), Integrator(cfg)
+    st = SyntheticStream(h, w, grid, 20)
+    gt, _ = gt_volumes(grid)
+    db = DuckDatabase(st, False, gt)
+    s = st.scene
+    origin = torch.from_numpy(st.origin)
+    tsdf, wgt = db.scenes_est[s].volume, db.fusion_weights[s]
+    for i in range(2):
+        b = st.batch(i)
+        depth = b['tof_depth']
+        values = ex.forward(depth, b['extrinsics'], b['intrinsics'], tsdf, wgt, origin, st.resolution)
+        rng = np.random.default_rng([7, i])
+        est = torch.from_numpy(rng.uniform(-0.15, 0.15, (1, h * w, 9)).astype(np.float32))
+        fd = torch.where(b['mask'], depth, torch.zeros_like(depth)).view(1, h * w, 1)
+        valid = (fd != 0.).nonzero()[:, 1]
+        updates = dict(values=torch.clamp(est[:, valid, :7], -0.1, 0.1), indices=values['indices'][:, valid, :7],
+                       weights=values['weights'][:, valid, :7])
+        tsdf, wgt, _, _ = ig.forward(updates, tsdf, wgt, None, None)
+    db.scenes_est[s].volume, db.fusion_weights[s] = tsdf, wgt
+    out = {'pre_tsdf_sha256': np.array(sha(tsdf.numpy())), 'pre_wgt_sha256': np.array(sha(wgt.numpy()))}
+    pipe = RefPipeline(cfg)
+    seeded_state(pipe._fusion_network, 11)
+    small = np.load(os.path.join(HERE, 'pipeline_v3_nosem_24x32_g32.npz'))
+    for k, v in pipe._fusion_network.state_dict().items():
+        assert np.array_equal(v.numpy(), small['state_' + k]), k
+    pipe.eval()
+    o = pipe.fuse_training(st.batch(2), db, torch.device('cpu'))
+    diff = o['tsdf_fused'] - o['tsdf_target']
+    loss = diff.abs().mean() + 10 * (diff ** 2).mean()
+    loss.backward()
+    out['loss'] = np.array(float(loss))
+    out['n_valid'] = np.array(int(o['tsdf_fused'].shape[1]))
+    for k in ('tsdf_est', 'tsdf_fused'):
+        a = o[k].detach()[0].numpy()
+        out[k + '_rows7'] = a[::7].copy()
+        out[k + '_colsum'] = a.astype(np.float64).sum(0)
+        out[k + '_abssum'] = np.array(np.abs(a.astype(np.float64)).sum())
+    out['tsdf_target_sha256'] = np.array(sha(o['tsdf_target'].detach()[0].numpy()))
+    for name, p in pipe._fusion_network.named_parameters():
+        out['grad_' + name] = p.grad.numpy().copy() if p.grad is not None else np.zeros(0, np.float32)
+    tsdf, wgt = db.scenes_est[s].volume.numpy(), db.fusion_weights[s].numpy()
+    out['post_wgt_sha256'] = np.array(sha(wgt))
+    out['post_touched'] = np.array(int((wgt > 0).sum()))
+    out['post_tsdf_touched'] = tsdf[wgt > 0]
+    return out
+
+
 def probe_matmul():
     """Documents the fp32 accumulation order of the reference's two torch.matmul calls here."""
     from oracle import oracle
@@ -256,6 +318,9 @@ def main():
     if '--full-size' in sys.argv:  # only the 320x240 -> 256^3 pipeline fixtures
         full_size()
         return
+    if '--train-full-size' in sys.argv:  # only the configs[3] frame step at 320x240 -> 256^3
+        np.savez_compressed(os.path.join(HERE, 'train_v3_nosem_240x320_g256.npz'), **run_training_full_size())
+        return
     tiny = run_extract_integrate(12, 16, 32, 4, keep_arrays=True)
     np.savez_compressed(os.path.join(HERE, 'extract_integrate_12x16_g32.npz'), **tiny)
     digests = {'A_120x160_g64': run_extract_integrate(120, 160, 64, 3, keep_arrays=False),
@@ -265,6 +330,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, 'pipeline_v3_sem_24x32_g32.npz'), **run_pipeline(24, 32, 32, 3, True))
     np.savez_compressed(os.path.join(HERE, 'pipeline_v3_nosem_24x32_g32.npz'), **run_pipeline(24, 32, 32, 3, False))
     full_size()
+    np.savez_compressed(os.path.join(HERE, 'train_v3_nosem_240x320_g256.npz'), **run_training_full_size())
     print('golden vectors written to', HERE)
 
 

@@ -165,3 +165,54 @@ if '--no-predict' not in sys.argv:
     sys.path.insert(0, HERE)
     np.savez_compressed(os.path.join(HERE, 'pipeline_predict_64x96_g32.npz'), **predict_pipeline())
     print('written', os.path.join(HERE, 'pipeline_predict_64x96_g32.npz'))
+
+
+# ---- the same composition at BASELINE configs[2]'s own size: 320x240 -> 256^3, 30 classes, two frames -------------------
+# Digest form (whole volumes would be 134 MB per frame): per frame the (score, id, margin) images of the 2-D network and
+# sha256 of the weight volume; after the last frame the TSDF / id / score volumes at the touched voxels (C order of
+# ``wgt > 0``) - an arg-max flip at a near-tie pixel may legitimately change a few ids, so those are kept as values.
+def predict_pipeline_full_size(h=240, w=320, grid=256, frames=2, n_classes=30):
+    import hashlib
+    import importlib
+    mg = importlib.import_module('make_golden')
+    from online_joint_depthfusion_and_semantic_amd.synthetic import SyntheticStream, gt_volumes
+    cfg = mg.ref_config(h, w, True, True)
+    cfg.DATA.semantic_strategy = 'predict'
+    cfg.SEMANTIC_2D_MODEL = mg.NS(stage=2, n_classes=n_classes)
+    import modules.pipeline as ref_pipeline
+    ref_pipeline.AdapNet = ref.AdapNet
+    pipe = mg.RefPipeline(cfg)
+    mg.seeded_state(pipe._fusion_network, 11)
+    randomise_net(pipe._semantic_2d_network, 31)
+    pipe.eval()
+    small = np.load(os.path.join(HERE, 'pipeline_v3_sem_24x32_g32.npz'))
+    for k, v in pipe._fusion_network.state_dict().items():
+        assert np.array_equal(v.numpy(), small['state_' + k]), k
+    st = SyntheticStream(h, w, grid, 20, n_classes=n_classes)
+    gt, _ = gt_volumes(grid, n_classes=n_classes)
+    db = mg.DuckDatabase(st, True, gt)
+    s = st.scene
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    out = {}
+    with torch.no_grad():
+        for i in range(frames):
+            b = st.batch(i)
+            pipe.device = torch.device('cpu')
+            hist = pipe._segmentation({k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()})
+            scores, ids = hist.max(dim=-1)
+            out['f%d_seg_scores' % i], out['f%d_seg_ids' % i] = scores[0].numpy(), ids[0].numpy().astype(np.uint8)
+            srt = torch.sort(hist[0], dim=-1, descending=True)[0]
+            out['f%d_seg_margin' % i] = (srt[..., 0] - srt[..., 1]).numpy().astype(np.float16)
+            pipe.fuse(b, db, torch.device('cpu'))
+            out['f%d_wgt_sha256' % i] = np.array(sha(db.fusion_weights[s].numpy()))
+            out['f%d_touched' % i] = np.array(int((db.fusion_weights[s] > 0).sum()))
+    touched = db.fusion_weights[s].numpy() > 0
+    out['last_tsdf_touched'] = db.scenes_est[s].volume.numpy()[touched]
+    out['last_ids_touched'] = db.ids_est[s].volume.numpy()[touched]
+    out['last_scores_touched'] = db.scores[s].volume.numpy()[touched]
+    return out
+
+
+if '--no-predict' not in sys.argv:
+    np.savez_compressed(os.path.join(HERE, 'pipeline_predict_240x320_g256.npz'), **predict_pipeline_full_size())
+    print('written', os.path.join(HERE, 'pipeline_predict_240x320_g256.npz'))

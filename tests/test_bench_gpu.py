@@ -1,0 +1,66 @@
+"""-m gpu: bench.py's launch paths.  ``python bench.py --gpus N`` must start its own N ranks when no
+launcher did (the driver's SCALE command is the plain ``python bench.py --gpus N ...``), print exactly one JSON line
+from rank 0, and ``--train`` must time BASELINE configs[3]'s frame step including the gradient all-reduce.  Two ranks on
+RCCL need two devices: those cases skip on a one-GPU box, where the same code path is exercised over gloo (both ranks
+share device 0 - what is validated is launch / rendezvous / barrier / max-over-ranks, not the wire)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ['--height', '120', '--width', '160', '--grid', '64', '--cpu-frames', '0', '--secondary', '0']
+
+
+def _bench(*flags, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(flags), capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]  # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_contract_fields_and_repeats(cuda):
+    out = _bench('--steps', '6', '--warmup', '3', '--repeats', '3', *SMALL)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'roofline_net', 'roofline_hbm', 'kernels'):
+        assert k in out, k
+    assert out['n_gpus'] == 1 and out['steps'] == 6 and out['warmup'] == 3 and out['repeats'] == 3
+    assert out['value_min'] <= out['value'] <= out['value_max']
+    assert abs(out['value'] * out['ms_per_step'] / 1e3 - 1.0) < 1e-6
+
+
+def test_gpus_2_launches_its_own_ranks_over_gloo_on_one_device(cuda):
+    out = _bench('--gpus', '2', '--dist-backend', 'gloo', '--steps', '6', '--warmup', '3', '--repeats', '2', *SMALL)
+    assert out['n_gpus'] == 2 and out['scaling'] == 'weak'
+    assert out['config']['parallelism'] == 'scene-sharded x2'
+    assert abs(out['value'] * out['ms_per_step'] / 1e3 - 2.0) < 1e-6  # whole-job frames/s = 2 ranks x steps / max time
+
+
+def test_gpus_more_than_devices_fails_loudly_on_rccl(cuda):
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and 'HIP device(s) visible' in r.stderr
+
+
+def test_train_flag_times_the_configs3_frame_step(cuda):
+    out = _bench('--train', '--steps', '8', '--warmup', '8', '--repeats', '2', '--height', '48', '--width', '64', '--grid', '64')
+    assert out['n_gpus'] == 1 and 'configs[3]' in out['config']['workload']
+    assert out['allreduce_calls_in_timed_region'] == 2 and out['gradients_finite'] is True
+    assert out['value'] > 0 and out['gradient_bytes'] > 1e6
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='two ranks on RCCL need two HIP devices')
+@pytest.mark.parametrize('train', [False, True])
+def test_gpus_2_over_rccl(cuda, train):
+    flags = ['--gpus', '2', '--steps', '8', '--warmup', '8', '--repeats', '2'] + SMALL + (['--train'] if train else [])
+    out = _bench(*flags)
+    assert out['n_gpus'] == 2
+    if train:
+        assert out['allreduce_backend'] == 'rccl' and out['allreduce_us'] > 0 and out['gradients_finite'] is True

@@ -225,3 +225,135 @@ def test_config_C_frame_with_semantics_against_oracle(cuda):
             else:  # <= 1 fp16 ulp on <= 0.05 % of the touched voxels (the FAST budget of test_extract_integrate_gpu.py)
                 assert ulp.max() <= 1 and (ulp > 0).sum() <= 5e-4 * touched, (key, int((ulp > 0).sum()))
         del ws, g
+
+
+# ---- configs[3]: the training frame step at 320x240 -> 256^3 against the reference's own fuse_training -----------
+@pytest.mark.parametrize('engine', ['hip', 'torch'])
+def test_fuse_training_at_B_matches_reference_golden(cuda, engine):
+    """modules/pipeline.py:251-363 driven as train_fusion.py:166-177 does, at BASELINE configs[3]'s frame and grid size.
+    Fixture = tests/golden/make_golden.py::run_training_full_size: the reference's ``Pipeline.fuse_training`` (eval()
+    mode) on frame 2 of the stream, from a pre-frame state that the C oracle reproduces bit for bit (two frames with
+    the seeded stand-in of helpers.frame_inputs; sha256 asserted), then ``loss.backward()`` of
+    mean|fused - target| + 10 mean (fused - target)^2.  Compared: tsdf_target bit for bit, tsdf_est / tsdf_fused within
+    2e-5 (every 7th row + float64 column sums over all 76 800 rows), the valid-pixel count, EVERY parameter gradient
+    (per tensor <= 2e-3 of max(its own scale, 1e-3 of the largest gradient): eval()-mode fp32 nets differ among
+    themselves by ~2e-4 there because |fused - target| changes sign under rounding; measured figures are printed),
+    the post-frame weight volume bit for bit (PARITY integrate) and the post-frame TSDF within one fp16 ulp."""
+    g = golden('train_v3_nosem_240x320_g256.npz')
+    g_small = golden('pipeline_v3_nosem_24x32_g32.npz')
+    h, w, grid = 240, 320, 256
+    cfg = default_config(h, w, semantics=False, use_semantics=False, integrate_mode='parity')
+    cfg.SETTINGS.device = str(cuda)
+    cfg.FUSION_MODEL.train_engine = engine
+    st = make_stream(h, w, grid)
+    db = Database(st, database_config(cfg))
+    pipe = Pipeline(cfg)
+    pipe._fusion_network.load_state_dict({k[len('state_'):]: torch.from_numpy(g_small[k]) for k in g_small.files if k.startswith('state_')})
+    pipe = pipe.to(cuda).eval()
+    s = st.scene
+    vols = fresh_volumes(grid, False)
+    for i in range(2):
+        fi = frame_inputs(st, i)
+        oracle.integrate(fi['fd'], fi['Ki'], fi['E'], st.origin, st.resolution, fi['est'], vols['tsdf'], vols['wgt'])
+    assert sha(vols['tsdf']) == str(g['pre_tsdf_sha256']) and sha(vols['wgt']) == str(g['pre_wgt_sha256'])
+    db.scenes_est[s].volume.copy_(_t(vols['tsdf'], cuda))
+    db.fusion_weights[s].copy_(_t(vols['wgt'], cuda))
+    b = {k: (v.to(cuda) if torch.is_tensor(v) else v) for k, v in st.batch(2).items()}
+    out = pipe.fuse_training(b, db, cuda)
+    assert out['tsdf_fused'].requires_grad
+    assert out['tsdf_fused'].shape == (1, int(g['n_valid']), 9) and out['tsdf_est'].shape == (1, h * w, 9)
+    assert sha(out['tsdf_target'].detach()[0]) == str(g['tsdf_target_sha256'])
+    for k in ('tsdf_est', 'tsdf_fused'):
+        a = out[k].detach()[0].cpu().numpy()
+        d_rows = float(np.abs(a[::7] - g[k + '_rows7']).max())
+        d_sum = float(np.abs(a.astype(np.float64).sum(0) - g[k + '_colsum']).max())
+        print('fuse_training B %s %s: max |d| on every 7th row %.2e, column sums differ by %.2e (of %.1f)'
+              % (engine, k, d_rows, d_sum, float(np.abs(g[k + '_colsum']).max())))
+        assert d_rows <= 2e-5, (k, d_rows)
+        assert d_sum <= 2e-5 * a.shape[0] * 0.05, (k, d_sum)  # rounding differences do not add up coherently
+    diff = out['tsdf_fused'] - out['tsdf_target']
+    loss = diff.abs().mean() + 10 * (diff ** 2).mean()
+    assert abs(float(loss) - float(g['loss'])) <= 1e-6
+    loss.backward()
+    grads = {n: p.grad for n, p in pipe._fusion_network.named_parameters()}
+    gmax = max(float(np.abs(g['grad_' + n]).max()) for n in grads if g['grad_' + n].size)
+    worst = (0.0, None)
+    for n, got in grads.items():
+        want = g['grad_' + n]
+        assert (got is None) == (want.size == 0), n
+        if got is None:
+            continue
+        scale = max(float(np.abs(want).max()), 1e-3 * gmax)
+        e = float(np.abs(got.cpu().numpy() - want).max()) / scale
+        worst = max(worst, (e, n))
+        assert e <= 2e-3, (n, e, scale)
+    print('fuse_training B %s: worst parameter-gradient deviation %.2e of its scale (%s), largest gradient %.3e' % (engine, worst[0], worst[1], gmax))
+    wgt = db.fusion_weights[s]
+    assert int((wgt > 0).sum()) == int(g['post_touched'])
+    assert sha(wgt) == str(g['post_wgt_sha256'])
+    got = db.scenes_est[s].volume.cpu().numpy()[wgt.cpu().numpy() > 0]
+    want = g['post_tsdf_touched']
+    assert (np.isnan(got) == np.isnan(want)).all()
+    ad = np.nan_to_num(np.abs(got.astype(np.float32) - want.astype(np.float32)))
+    print('   post-frame TSDF: max |d| %.2e, %.4f %% of %d touched voxels differ' % (float(ad.max()), 100 * float((ad > 0).mean()), got.size))
+    assert ad.max() <= F16_ULP_BAND and float((ad > 0).mean()) <= 0.004
+
+
+# ---- configs[2] with PREDICTED labels at its own size against the reference's Pipeline.fuse + AdapNet -------------
+@pytest.mark.parametrize('engine', ['hip', 'torch'])
+def test_fuse_predict_strategy_at_B_matches_reference_golden(cuda, engine):
+    """modules/pipeline.py:42-60,181-185 composed with the fusion path at 320x240 -> 256^3, 30 classes, two frames
+    (tests/golden/make_golden_adapnet.py::predict_pipeline_full_size: the reference's own AdapNet around the stand-in
+    ResNet-50, seeded weights, dropout flags off).  Per frame: softmax scores within 1e-6, arg-max ids equal wherever
+    the reference's top-1 / top-2 margin exceeds 1e-4, the weight volume bit for bit (PARITY); after the last frame id /
+    score / TSDF volumes at the touched voxels (a flipped near-tie pixel may change the <= 56 entries it writes and,
+    through the semantic input channel of the two-head net, TSDF values)."""
+    from adapnet_golden_util import randomise_net
+    g = golden('pipeline_predict_240x320_g256.npz')
+    small = golden('pipeline_v3_sem_24x32_g32.npz')
+    h, w, grid, n_classes = 240, 320, 256, 30
+    cfg = default_config(h, w, semantics=True, use_semantics=True, n_classes=n_classes, integrate_mode='parity')
+    cfg.SETTINGS.device = str(cuda)
+    cfg.DATA.semantic_strategy = 'predict'
+    cfg.SEMANTIC_2D_MODEL.engine = engine
+    st = make_stream(h, w, grid, n_classes=n_classes)
+    db = Database(st, database_config(cfg))
+    pipe = Pipeline(cfg)
+    pipe._fusion_network.load_state_dict({k[len('state_'):]: torch.from_numpy(small[k]) for k in small.files if k.startswith('state_')})
+    randomise_net(pipe._semantic_2d_network, 31)
+    pipe = pipe.to(cuda).eval()
+    pipe.device = torch.device(cuda)
+    s = st.scene
+    flips_total = 0
+    with torch.no_grad():
+        for i in range(2):
+            b = {k: (v.to(cuda) if torch.is_tensor(v) else v) for k, v in st.batch(i).items()}
+            ids, scores = pipe._frame_semantics(b)
+            scores, ids = scores.reshape(h, w).cpu().numpy(), ids.reshape(h, w).cpu().numpy()
+            clear = g['f%d_seg_margin' % i].astype(np.float32) > 1e-4
+            flips = int((ids != g['f%d_seg_ids' % i]).sum())
+            flips_total += flips
+            ds = float(np.abs(scores - g['f%d_seg_scores' % i]).max())
+            print('predict B %s frame %d: max |d score| %.2e, %d arg-max flips (%d pixels with margin < 1e-4)'
+                  % (engine, i, ds, flips, int((~clear).sum())))
+            assert ds <= 1e-6
+            assert (ids[clear] == g['f%d_seg_ids' % i][clear]).all() and flips <= (~clear).sum()
+            pipe.fuse(b, db, cuda)
+            wgt = db.fusion_weights[s]
+            assert int((wgt > 0).sum()) == int(g['f%d_touched' % i])
+            assert sha(wgt) == str(g['f%d_wgt_sha256' % i]), i
+    pipe.check()
+    touched = db.fusion_weights[s].cpu().numpy() > 0
+    got_ids = db.ids_est[s].volume.cpu().numpy()[touched]
+    got_sc = db.scores[s].volume.cpu().numpy()[touched]
+    got_t = db.scenes_est[s].volume.cpu().numpy()[touched]
+    id_bad = int((got_ids != g['last_ids_touched']).sum())
+    sc_ulp = f16_ulp_distance(got_sc, g['last_scores_touched'])
+    assert (np.isnan(got_t) == np.isnan(g['last_tsdf_touched'])).all()
+    td = np.nan_to_num(np.abs(got_t.astype(np.float32) - g['last_tsdf_touched'].astype(np.float32)))
+    print('   volumes: %d of %d touched voxels with another id, score ulps max %d (%d voxels > 0), max |dTSDF| %.2e, %.4f %% differ'
+          % (id_bad, int(touched.sum()), int(sc_ulp.max()), int((sc_ulp > 0).sum()), float(td.max()), 100 * float((td > 0).mean())))
+    assert id_bad <= 56 * flips_total
+    assert sc_ulp.max() <= 1 or (sc_ulp > 1).sum() <= 56 * flips_total
+    assert td.max() <= (F16_ULP_BAND if flips_total == 0 else 2e-3)
+    assert float((td > 0).mean()) <= (0.004 if flips_total == 0 else 0.02)

@@ -212,3 +212,20 @@ def test_f_score_known_answers():
     near = metrics.reconstruction_f_score(sdf + 0.05, sdf, np.ones_like(sdf), origin, res)  # 5 cm < 1.5 voxels
     assert near['fscore'] == 1.0
     assert metrics.f_score(np.zeros((0, 3)), pts, 0.1)['fscore'] == 0.0
+
+
+def test_bench_gpus_n_without_launcher_does_not_die_in_argument_handling():
+    """``python bench.py --gpus 8`` (no torch.distributed.run around it) used to exit with
+    "launch with torch.distributed.run"; it now becomes the launcher itself.  Without a HIP device the only acceptable
+    failure is the loud "needs an MI355X" one."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    if torch.cuda.is_available():
+        pytest.skip('argument handling without a device is what this test covers')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '20', '--warmup', '5'],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert 'needs an MI355X' in r.stderr and 'torch.distributed.run' not in r.stderr
