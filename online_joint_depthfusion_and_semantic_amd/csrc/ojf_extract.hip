@@ -87,13 +87,16 @@ __device__ __forceinline__ void extract_item(const ExtractArgs &a, int n, int k,
             o[3] = i1[0]; o[4] = i1[1]; o[5] = i1[2];
         }
     }
-    // fp64 products, summed in corner order, rounded once to fp32 (extractor.py:673-681)
-    double sv = 0.0, sw = 0.0;
+    // fp64 products; the 8-term sums of torch.sum(.., dim=1) (extractor.py:673-674) in ATen's row_sum order - four
+    // interleaved partial sums s_k = p_k + p_{k+4}, then ((s_0 + s_1) + s_2) + s_3 - rounded once to fp32
+    double pv[8], pt[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        sv += (double)val[q] * wq[q];
-        sw += (double)wt[q] * wq[q];
+        pv[q] = (double)val[q] * wq[q];
+        pt[q] = (double)wt[q] * wq[q];
     }
+    const double sv = (((pv[0] + pv[4]) + (pv[1] + pv[5])) + (pv[2] + pv[6])) + (pv[3] + pv[7]);
+    const double sw = (((pt[0] + pt[4]) + (pt[1] + pt[5])) + (pt[2] + pt[6])) + (pt[3] + pt[7]);
     if (a.out_layout == 2) {
         net_tile[0] = (float)sv;            // caller-provided LDS slots of (pixel, k) and (pixel, P + k)
         net_tile[a.n_points] = (float)sw;

@@ -175,9 +175,13 @@ int ojf_oracle_extract(const float *depth, const float *Ki, const float *E, cons
                 ray_sample(cv, dir, k, half, p);
                 corners(p, idx, wq);
                 /* :660-681: out-of-bounds corners read pad_value (-0.1, hard-coded in the
-                 * reference) and weight 0; products and the 8-term sums are fp64, in corner
-                 * order, rounded once to fp32 */
-                double sv = 0.0, sw = 0.0;
+                 * reference) and weight 0; products are fp64; the 8-term fp64 sums of
+                 * torch.sum(.., dim=1) (:673-674) run in ATen's row_sum order - four interleaved
+                 * partial sums  s_k = p_k + p_{k+4},  then ((s_0 + s_1) + s_2) + s_3 - and are rounded
+                 * once to fp32.  (A corner-order sum differs from it by one fp32 ulp on ~3 of 1e6
+                 * samples of a volume with sign changes: found by the 320x240 -> 256^3 fuse_training
+                 * fixture, whose target is interpolated from the ground-truth grid.) */
+                double pv[8], pwt[8];
                 for (int q = 0; q < 8; ++q) {
                     float val = pad_value, wt = 0.0f;
                     if (in_bounds(idx[q], X, Y, Z)) {
@@ -185,9 +189,11 @@ int ojf_oracle_extract(const float *depth, const float *Ki, const float *E, cons
                         val = h2f(tsdf[lin]);
                         wt = h2f(wgt[lin]);
                     }
-                    sv += (double)val * wq[q];
-                    sw += (double)wt * wq[q];
+                    pv[q] = (double)val * wq[q];
+                    pwt[q] = (double)wt * wq[q];
                 }
+                const double sv = (((pv[0] + pv[4]) + (pv[1] + pv[5])) + (pv[2] + pv[6])) + (pv[3] + pv[7]);
+                const double sw = (((pwt[0] + pwt[4]) + (pwt[1] + pwt[5])) + (pwt[2] + pwt[6])) + (pwt[3] + pwt[7]);
                 const size_t s = n * n_points + k;
                 out_values[s] = (float)sv;
                 out_weights[s] = (float)sw;
