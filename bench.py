@@ -421,7 +421,8 @@ class TrainCase:
             at += steps
         loss_ok = bool(torch.isfinite(self.grads.flat).all()) and mean_loss == mean_loss
         ar = [a.elapsed_time(b) * 1e3 for a, b in self.reduce_events]
-        return {'times': times, 'allreduce_us': float(np.mean(ar)) if ar else None,  # (world 1: an empty bracket, ~5 us of event overhead) 'allreduce_calls': len(ar),
+        # (world 1: the bracket is empty, ~5 us of event overhead - reported as None)
+        return {'times': times, 'allreduce_us': float(np.mean(ar)) if ar else None, 'allreduce_calls': len(ar),
                 'gradient_bytes': self.grads.nbytes, 'finite': loss_ok, 'mean_loss': mean_loss}
 
 

@@ -250,6 +250,42 @@ int ojf_train_wgrad(const float *x_dev, int x_g0, int c_in_phys, const float *dy
                     int ksize, int dilation, int group, int slot, int h, int w, float *partial_dev, float *dw_dev, int accumulate,
                     ojf_stream_t stream);
 
+/* ---- whole-net TRAINING executor (csrc/ojf_train_net.h) ---------------------------------------------------------
+ * The net of modules/pipeline.py:322 inside fuse_training and the loss.backward() of train_fusion.py:171 as two calls:
+ * forward and backward pass of FusionNet_v3 / _v2 (modules/model.py:164-283) in train() or eval() mode on the layer-unit
+ * kernels above, with every activation / gradient buffer owned by the trainer and the four branches of a VortexPooling
+ * run as grouped launches.  Parameters, BatchNorm running statistics and gradient tensors stay the caller's: every call
+ * receives a table of n_layers = ojf_trainer_layer_count() entries in the layer order of ojf_net_create
+ * (v3: block0 (2 per Block) | vortex0 = {global-average conv, 4 x {1x1, 3x3, 3x3, 1x1}, final} | [block2 | vortex2] |
+ * vortex3 | pred; v2: block | vortex | vortex_final | pred).
+ *   weight [oc][ic][k][k], bias [oc] (or NULL); gamma / beta NULL = no BatchNorm after this convolution;
+ *   bn_training: batch statistics + running-statistics update (nn.BatchNorm2d.training of THAT module);
+ *   drop_scale: [oc] per-channel Dropout2d factors (0 or 1 / (1 - p)) of this pass, NULL = no dropout;
+ *   grad_*: where ojf_trainer_backward writes (accumulate == 0) or adds (accumulate != 0) the parameter gradients.
+ * ojf_trainer_forward: values / weights [n_points][h][w], frame [h][w] (+ semantic_frame [h][w] when the net has a
+ *   semantic channel) -> est [n_points][h][w] = net(x) * output_scale, all device fp32 NCHW.  weights_epoch: any number
+ *   that changes whenever a weight or bias changed (the packed copies are refreshed then).
+ * ojf_trainer_backward: d_est [n_points][h][w] -> parameter gradients; exactly one backward per forward (the forward's
+ *   activations live in the trainer).  No gradient w.r.t. the inputs is produced (fuse_training's come from the volumes). */
+typedef struct ojf_trainer ojf_trainer;
+typedef struct ojf_train_layer {
+    const float *weight, *bias, *gamma, *beta;
+    float *running_mean, *running_var;
+    float *grad_weight, *grad_bias, *grad_gamma, *grad_beta;
+    const float *drop_scale;
+    int out_channels, in_channels, ksize, dilation;
+    int bn_training, accumulate;
+    float momentum, eps;
+} ojf_train_layer;
+int ojf_trainer_create(ojf_trainer **out, int version, int n_points, int growth, int use_semantics, float output_scale, int h, int w);
+void ojf_trainer_destroy(ojf_trainer *t);
+int ojf_trainer_layer_count(const ojf_trainer *t);
+int ojf_trainer_launch_count(const ojf_trainer *t);
+int ojf_trainer_forward(ojf_trainer *t, const ojf_train_layer *layers, int n_layers, unsigned long long weights_epoch,
+                        const float *values_dev, const float *weights_dev, const float *frame_dev, const float *semantic_frame_dev,
+                        float *est_dev, ojf_stream_t stream);
+int ojf_trainer_backward(ojf_trainer *t, const ojf_train_layer *layers, int n_layers, const float *d_est_dev, ojf_stream_t stream);
+
 /* ojf_extract writing straight into the fusion net's input planes (values | weights | depth of
  * modules/pipeline.py:74-102), bit-identical to ojf_extract + ojf_net_prepare_input, for nets without a semantic
  * channel and with one head (others: error - use the two calls): no sample planes, no prepare launch. */

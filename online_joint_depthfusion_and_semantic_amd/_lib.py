@@ -28,6 +28,14 @@ class ConvLayer(ctypes.Structure):
                 ('bias_host', ctypes.c_void_p)]
 
 
+class TrainLayer(ctypes.Structure):
+    """include/ojf.h ojf_train_layer: one conv (+ BatchNorm) unit of the whole-net training executor."""
+    _fields_ = ([(n, ctypes.c_void_p) for n in ('weight', 'bias', 'gamma', 'beta', 'running_mean', 'running_var', 'grad_weight',
+                                                 'grad_bias', 'grad_gamma', 'grad_beta', 'drop_scale')]
+                + [(n, ctypes.c_int) for n in ('out_channels', 'in_channels', 'ksize', 'dilation', 'bn_training', 'accumulate')]
+                + [('momentum', ctypes.c_float), ('eps', ctypes.c_float)])
+
+
 _c = ctypes
 _vp, _i, _f, _d, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_double, _c.c_size_t
 
@@ -83,6 +91,12 @@ SIGNATURES = {
                                   _vp, _vp, _vp, _i, _vp]),
     'ojf_train_wgrad_partial_floats': (_sz, [_i, _i, _i, _i, _i]),
     'ojf_train_wgrad': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    'ojf_trainer_create': (_i, [_c.POINTER(_vp), _i, _i, _i, _i, _f, _i, _i]),
+    'ojf_trainer_destroy': (None, [_vp]),
+    'ojf_trainer_layer_count': (_i, [_vp]),
+    'ojf_trainer_launch_count': (_i, [_vp]),
+    'ojf_trainer_forward': (_i, [_vp, _c.POINTER(TrainLayer), _i, _c.c_ulonglong, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'ojf_trainer_backward': (_i, [_vp, _c.POINTER(TrainLayer), _i, _vp, _vp]),
     'ojf_seg_pack_input': (_i, [_vp, _i, _f, _i, _i, _vp, _i, _vp]),
     'ojf_seg_maxpool': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
     'ojf_seg_mean': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),

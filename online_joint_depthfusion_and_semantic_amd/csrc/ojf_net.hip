@@ -117,6 +117,7 @@ struct ConvArgs {
     int act, act_n;  // activation applied to output channels < act_n
     float scale;
     int *ovf;        // split-fp16 only: set to 1 when an activation leaves the fp16 range (host-mapped flag)
+    int accum;       // fp32 planar stores only: out += result (fan-out gradients of the training path); 0 = plain store
     unsigned w_magic, c4_magic;  // ceil(2^32 / w), ceil(2^32 / c4): x / d == umulhi(x, magic) while x * d < 2^32 (0: divide)
 };
 
@@ -183,7 +184,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x4 (&a
                 for (int j = 0; j < 4; ++j)
                     if (og * 4 + j < a.rows_n) a.out_rows[(size_t)p * a.rows_stride + og * 4 + j] = v[j];
             } else if (og < a.og_store) {
-                a.out[(size_t)(a.out_g0 + og) * a.npix + p] = v;
+                f32x4 *dst = a.out + (size_t)(a.out_g0 + og) * a.npix + p;
+                if constexpr (!GUARD)
+                    if (a.accum) v += *dst;
+                *dst = v;
                 if constexpr (GUARD) gmax = guard_max(gmax, lin4);  // pre-activation magnitude
             }
         }
@@ -1739,6 +1743,7 @@ static void fill_conv_args(ConvArgs &a, const PackedConv &pc, const float *in, i
                            const float *bias, int act, int act_n, float scale, int h, int w)
 {
     a.ovf = pc.arith == OJF_ARITH_F16X3 ? overflow_flag() : nullptr;
+    a.accum = 0;
     a.in = planes(in); a.out = planes(out); a.out_rows = nullptr;
     a.wp = planes(pc.wp); a.bias = bias ? bias : pc.bias; a.rinv = pc.rinv;
     a.in_g0 = in_g0; a.out_g0 = out_g0; a.rows_stride = 0; a.rows_n = 0;
@@ -2708,3 +2713,4 @@ OJF_API int ojf_conv2d(const float *in, int in_stride, int in_off, float *out, i
 }
 
 #include "ojf_net_train.h"
+#include "ojf_train_net.h"

@@ -34,6 +34,9 @@ struct PackArgs {
     float *wp;          // [n_ot][nsteps + kPadSteps][64][4]
     float *bp;          // [n_ot * 16] (forward form only; NULL otherwise)
     int OC, IC, taps, group, slot, c4, nsteps, n_ot, transposed;
+    // stacked layers (the four branch-entry 1x1 of a VortexPooling as ONE convolution): this weight tensor owns output
+    // channels [oc_base, oc_base + OC) of the stack; with `partial` only its elements are written (the buffer starts zeroed)
+    int oc_base, partial;
 };
 
 __device__ __forceinline__ int train_unslot(int x, int group, int slot, int n_logical)
@@ -48,26 +51,32 @@ __global__ __launch_bounds__(256) void train_pack_kernel(const PackArgs a)
     const int nsp = a.nsteps + kPadSteps;
     const long total = (long)a.n_ot * nsp * 256;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (long)a.n_ot * 16 && a.bp) a.bp[i] = (a.bias && i < a.OC) ? a.bias[i] : 0.0f;
+    if (i < (long)a.n_ot * 16 && a.bp) {
+        const long ob = i - a.oc_base;
+        const bool mine = ob >= 0 && ob < a.OC;
+        if (mine || !a.partial) a.bp[i] = (a.bias && mine) ? a.bias[ob] : 0.0f;
+    }
     if (i >= total) return;
     const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
     const long rest = i >> 8;
     const int S = (int)(rest % nsp), ot = (int)(rest / nsp);
     const int r = ot * 16 + (lane & 15), G = 4 * S + (lane >> 4);
     float v = 0.0f;
+    bool mine = false;
     if (S < a.nsteps && G < a.taps * a.c4) {
         const int tap = G / a.c4, ch = 4 * (G - tap * a.c4) + j;
         int oc, ic, t;
-        if (!a.transposed) { oc = r; ic = train_unslot(ch, a.group, a.slot, a.IC); t = tap; }
-        else { ic = train_unslot(r, a.group, a.slot, a.IC); oc = ch; t = a.taps - 1 - tap; }
-        if (oc < a.OC && ic >= 0) v = a.w[((size_t)oc * a.IC + ic) * a.taps + t];
+        if (!a.transposed) { oc = r - a.oc_base; ic = train_unslot(ch, a.group, a.slot, a.IC); t = tap; }
+        else { ic = train_unslot(r, a.group, a.slot, a.IC); oc = ch - a.oc_base; t = a.taps - 1 - tap; }
+        mine = oc >= 0 && oc < a.OC;
+        if (mine && ic >= 0) v = a.w[((size_t)oc * a.IC + ic) * a.taps + t];
     }
-    a.wp[i] = v;
+    if (mine || !a.partial) a.wp[i] = v;
 }
 
 // ---- BatchNorm statistics ------------------------------------------------------------------------------------------
 // block (slab, channel group): fp64 sums of y and y^2 over the slab's pixels of the group's four channels
-__global__ __launch_bounds__(256) void train_stats_partial_kernel(const f32x4 *y, int g0, int npix, double *partial /* [slabs][c4][8] */)
+__device__ __forceinline__ void train_stats_partial_body(const f32x4 *y, int g0, int npix, double *partial /* [slabs][c4][8] */)
 {
     __shared__ double red[4][8];
     const int cg = blockIdx.y, c4 = gridDim.y;
@@ -90,6 +99,11 @@ __global__ __launch_bounds__(256) void train_stats_partial_kernel(const f32x4 *y
     if (threadIdx.x < 8)
         partial[((size_t)blockIdx.x * c4 + cg) * 8 + threadIdx.x] =
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void train_stats_partial_kernel(const f32x4 *y, int g0, int npix, double *partial)
+{
+    train_stats_partial_body(y, g0, npix, partial);
 }
 
 // Totals of the kTrainSlabs partial rows of channel group cg (8 doubles each: what the partial kernels wrote), formed
@@ -159,8 +173,19 @@ __device__ __forceinline__ void train_channel_consts(const BnActArgs &a, int cg,
     }
 }
 
-__global__ __launch_bounds__(256) void train_bn_act_fwd_kernel(const BnActArgs a)
+// Up to four units of identical shape run as one launch (blockIdx.z): the four branches of a VortexPooling
+struct BnGroup { BnActArgs g[4]; };
+
+__global__ __launch_bounds__(256) void train_stats_group_kernel(const BnGroup grp)
 {
+    const BnActArgs &a = grp.g[blockIdx.z];
+    if (!(a.has_bn && a.training)) return;
+    train_stats_partial_body(a.y, a.y_g0, a.npix, a.partial);
+}
+
+__global__ __launch_bounds__(256) void train_bn_act_fwd_kernel(const BnGroup grp)
+{
+    const BnActArgs &a = grp.g[blockIdx.z];
     const int cg = blockIdx.y;
     __shared__ float stat[8];  // mean[4], invstd[4] of this group
     if (a.has_bn) {
@@ -214,8 +239,9 @@ __global__ __launch_bounds__(256) void train_bn_act_fwd_kernel(const BnActArgs a
 }
 
 // dz = dout * scale * drop * act'(z); partial sums of dz and dz * xhat per channel (fp64, fixed order)
-__global__ __launch_bounds__(256) void train_bn_bwd_reduce_kernel(const BnActArgs a)
+__global__ __launch_bounds__(256) void train_bn_bwd_reduce_kernel(const BnGroup grp)
 {
+    const BnActArgs &a = grp.g[blockIdx.z];
     __shared__ double red[4][8];
     const int cg = blockIdx.y;
     f32x4 mu, is, ga, be, dr;
@@ -248,8 +274,9 @@ __global__ __launch_bounds__(256) void train_bn_bwd_reduce_kernel(const BnActArg
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-__global__ __launch_bounds__(256) void train_bn_bwd_apply_kernel(const BnActArgs a)
+__global__ __launch_bounds__(256) void train_bn_bwd_apply_kernel(const BnGroup grp)
 {
+    const BnActArgs &a = grp.g[blockIdx.z];
     const int cg = blockIdx.y;
     f32x4 mu, is, ga, be, dr;
     train_channel_consts(a, cg, mu, is, ga, be, dr);
@@ -320,12 +347,16 @@ struct WgradArgs {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kWgChunk = 64, kWgPitch = 36;
 
-__global__ __launch_bounds__(64) void train_wgrad_mfma_kernel(const WgradArgs a, unsigned w_magic)
+struct WgradGroup { WgradArgs g[4]; int tiles; };  // blockIdx.y = unit * tiles + (oc, ic) tile
+
+__global__ __launch_bounds__(64) void train_wgrad_mfma_kernel(const WgradGroup grp, unsigned w_magic)
 {
     __shared__ __attribute__((aligned(16))) float tile[2][kWgChunk * kWgPitch];
+    const int unit = blockIdx.y / grp.tiles, tile_i = blockIdx.y - unit * grp.tiles;
+    const WgradArgs &a = grp.g[unit];
     const int lane = threadIdx.x, r = lane & 31, k = lane >> 5;
     const int n_it = a.icp / 32;
-    const int ot = blockIdx.y / n_it, it = blockIdx.y - ot * n_it;
+    const int ot = tile_i / n_it, it = tile_i - ot * n_it;
     const int tap = blockIdx.z;
     int dyo = 0, dxo = 0;
     if (a.taps == 9) { dyo = (tap / 3 - 1) * a.dil; dxo = (tap % 3 - 1) * a.dil; }
@@ -390,11 +421,14 @@ struct WgradReduceArgs {
     float *dw;  // [OC][IC][taps]
     int slabs, taps, ocp, icp, OC, IC, group, slot, c_in_phys;
     int accumulate;  // dw += (gradient accumulation over frames happens here instead of in a torch add per parameter)
+    int oc_base;     // first row of `partial` that belongs to this weight tensor (stacked layers; else 0)
 };
+struct WgradReduceGroup { WgradReduceArgs g[4]; };  // blockIdx.y = unit
 
 // eight lanes per weight: lane `sub` adds slabs sub, sub + 8, ... in order, then a fixed xor tree joins the eight sums
-__global__ __launch_bounds__(256) void train_wgrad_reduce_kernel(const WgradReduceArgs a)
+__global__ __launch_bounds__(256) void train_wgrad_reduce_kernel(const WgradReduceGroup grp)
 {
+    const WgradReduceArgs &a = grp.g[blockIdx.y];
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long i = t >> 3;
     const int sub = (int)(t & 7);
@@ -406,7 +440,7 @@ __global__ __launch_bounds__(256) void train_wgrad_reduce_kernel(const WgradRedu
     const int oc = (int)(r % a.OC), tap = (int)(r / a.OC);
     float s = 0.0f;
     if (live)
-        for (int b = sub; b < a.slabs; b += 8) s += a.partial[(((size_t)b * a.taps + tap) * a.ocp + oc) * a.icp + icp_i];
+        for (int b = sub; b < a.slabs; b += 8) s += a.partial[(((size_t)b * a.taps + tap) * a.ocp + a.oc_base + oc) * a.icp + icp_i];
     s += __shfl_xor(s, 4, 64);
     s += __shfl_xor(s, 2, 64);
     s += __shfl_xor(s, 1, 64);
@@ -463,6 +497,7 @@ OJF_API int ojf_train_pack(const float *w, const float *bias, int OC, int IC, in
     a.w = w; a.bias = transposed ? nullptr : bias; a.wp = packed; a.bp = transposed ? nullptr : bias_packed;
     a.OC = OC; a.IC = IC; a.taps = ksize * ksize; a.group = group; a.slot = slot;
     a.c4 = kch / 4; a.nsteps = (a.taps * a.c4 + 3) / 4; a.n_ot = round_up(round_up(rows, 16) / 16, kNT); a.transposed = transposed ? 1 : 0;
+    a.oc_base = 0; a.partial = 0;
     const long total = (long)a.n_ot * (a.nsteps + kPadSteps) * 256;
     hipLaunchKernelGGL(train_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), a);
     return check_hip(hipGetLastError(), "train_pack_kernel launch");
@@ -484,7 +519,7 @@ OJF_API int ojf_train_conv(const float *in, int in_g0, int c_in_phys, float *out
     for (int ot0 = 0; ot0 < n_ot; ot0 += 8) {  // a launch covers up to 8 output tiles per wave
         const int nt = n_ot - ot0 < 8 ? n_ot - ot0 : 8;
         ConvArgs a;
-        a.ovf = nullptr;
+        a.ovf = nullptr; a.accum = 0;
         a.in = planes(in); a.out = planes(out); a.out_rows = nullptr;
         a.wp = planes(packed) + (size_t)ot0 * (nsteps + kPadSteps) * 64;
         a.bias = (bias_packed ? bias_packed : g_train_zero_bias) + (size_t)ot0 * 16; a.rinv = nullptr;
@@ -549,7 +584,7 @@ OJF_API int ojf_train_bn_act(const float *y, int y_g0, float *out, int out_g0, i
     a.out = planes(out); a.out_g0 = out_g0; a.partial = partial;
     a.mean_out = mean; a.invstd_out = invstd; a.running_mean = running_mean; a.running_var = running_var; a.momentum = momentum; a.eps = eps;
     const int bx = (h * w + 255) / 256 < 128 ? (h * w + 255) / 256 : 128;
-    hipLaunchKernelGGL(train_bn_act_fwd_kernel, dim3(bx, c_phys / 4), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(train_bn_act_fwd_kernel, dim3(bx, c_phys / 4), dim3(256), 0, st, BnGroup{{a, a, a, a}});
     return check_hip(hipGetLastError(), "train_bn_act kernels launch");
 }
 
@@ -565,9 +600,10 @@ OJF_API int ojf_train_bn_act_bwd(const float *y, int y_g0, const float *dout, in
     BnActArgs a = train_bn_args(y, y_g0, c_phys, C, h, w, mean, invstd, gamma, beta, drop, act, scale, has_bn, training);
     a.dout = planes(dout); a.dout_g0 = dout_g0; a.dy = planes(dy); a.dy_g0 = dy_g0; a.partial = partial;
     a.dgamma = dgamma; a.dbeta = dbeta; a.dbias = dbias; a.accumulate = accumulate ? 1 : 0;
-    hipLaunchKernelGGL(train_bn_bwd_reduce_kernel, dim3(kTrainSlabs, c_phys / 4), dim3(256), 0, st, a);
+    const BnGroup grp{{a, a, a, a}};
+    hipLaunchKernelGGL(train_bn_bwd_reduce_kernel, dim3(kTrainSlabs, c_phys / 4), dim3(256), 0, st, grp);
     const int bx = (h * w + 255) / 256 < 128 ? (h * w + 255) / 256 : 128;
-    hipLaunchKernelGGL(train_bn_bwd_apply_kernel, dim3(bx, c_phys / 4), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(train_bn_bwd_apply_kernel, dim3(bx, c_phys / 4), dim3(256), 0, st, grp);
     return check_hip(hipGetLastError(), "train_bn_bwd kernels launch");
 }
 
@@ -607,12 +643,12 @@ OJF_API int ojf_train_wgrad(const float *x, int x_g0, int c_in_phys, const float
     WgradArgs a;
     a.x = planes(x); a.dy = planes(dy); a.partial = partial; a.x_g0 = x_g0; a.c4_in = c_in_phys / 4; a.dy_g0 = dy_g0; a.c4_out = c_out_phys / 4;
     a.h = h; a.w = w; a.npix = h * w; a.taps = taps; a.dil = dil; a.slabs = p.slabs; a.ocp = p.ocp; a.icp = p.icp;
-    hipLaunchKernelGGL(train_wgrad_mfma_kernel, dim3(p.slabs, (p.ocp / 32) * (p.icp / 32), taps), dim3(64), 0, st, a,
-                       div_magic(w, (uint64_t)h * w + 2 * kWgChunk));
+    hipLaunchKernelGGL(train_wgrad_mfma_kernel, dim3(p.slabs, (p.ocp / 32) * (p.icp / 32), taps), dim3(64), 0, st,
+                       WgradGroup{{a, a, a, a}, (p.ocp / 32) * (p.icp / 32)}, div_magic(w, (uint64_t)h * w + 2 * kWgChunk));
     WgradReduceArgs r;
     r.partial = partial; r.dw = dw; r.slabs = p.slabs; r.taps = taps; r.ocp = p.ocp; r.icp = p.icp; r.OC = OC; r.IC = IC;
-    r.group = group; r.slot = slot; r.c_in_phys = c_in_phys; r.accumulate = accumulate ? 1 : 0;
+    r.group = group; r.slot = slot; r.c_in_phys = c_in_phys; r.accumulate = accumulate ? 1 : 0; r.oc_base = 0;
     const long total = (long)taps * OC * c_in_phys * 8;
-    hipLaunchKernelGGL(train_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r);
+    hipLaunchKernelGGL(train_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, WgradReduceGroup{{r, r, r, r}});
     return check_hip(hipGetLastError(), "train_wgrad kernels launch");
 }

@@ -1,0 +1,850 @@
+// Whole-net TRAINING executor (ojf_trainer_*): forward and backward pass of FusionNet_v3 / _v2 in train() or eval()
+// mode as two C calls - modules/pipeline.py:322 (`self._fusion(...)` inside fuse_training) and the `loss.backward()` of
+// train_fusion.py:171 - instead of one Python autograd node per layer (included by ojf_net.hip only).
+//
+// Why: round 2's training frame step issued 712 launches from ~60 Python autograd nodes (10 ms of host time, 9.6 ms of
+// kernels per 320x240 frame).  Here the layer walk is C++, every activation / gradient buffer is owned by the trainer and
+// allocated once, and the four branches of a VortexPooling run as GROUPED launches (one launch = the same unit of all
+// four branches, blockIdx.y / z picks the branch) - convolution, statistics, normalise + activate, both BatchNorm-
+// backward kernels, weight gradient and backward-data alike.  The branch-entry 1x1 convolutions see pooled inputs
+// (modules/model.py:143-161: branch i reads pool^i(x)); a 3x3 average pool (zero padding, count_include_pad) is linear and
+// acts on pixels while a 1x1 convolution acts on channels, so W_i (P^i x) + b_i = P^i (W_i x) + b_i: the four entries are
+// ONE stacked 114 -> 4 x 19 convolution of the unpooled input followed by the pools on 19 instead of 114 channels (the
+// same identity the inference path uses); backward pools the 19-channel gradients and runs ONE weight-gradient launch.
+//
+// Layer units, arithmetic and reductions are those of ojf_net_train.h (fp32-MFMA convolutions, fp64 fixed-order slab
+// sums); parameters, BatchNorm buffers and gradient tensors stay the caller's (torch's) - the trainer only reads / writes
+// them through the pointer table handed over with every call.
+#pragma once
+
+#include <map>
+
+namespace ojf {
+
+// ---- small kernels of the executor ---------------------------------------------------------------------------------
+struct PackInArgs {
+    const float *src[4];  // NCHW sources [n_i][npix]
+    int nch[4];
+    int n_src, c4, npix;
+    f32x4 *dst;           // planes [c4][npix]
+};
+
+__global__ __launch_bounds__(256) void train_pack_input_kernel(const PackInArgs a)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.npix) return;
+    const int cg = blockIdx.y;
+    f32x4 v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int l = 4 * cg + j;
+        for (int s = 0; s < a.n_src; ++s) {
+            if (l < a.nch[s]) { v[j] = a.src[s][(size_t)l * a.npix + p]; break; }
+            l -= a.nch[s];
+        }
+    }
+    a.dst[(size_t)cg * a.npix + p] = v;
+}
+
+// planes [c4][npix] <-> NCHW [C][npix] (est out / d est in); channels >= C are dropped / zero
+__global__ __launch_bounds__(256) void train_planes_to_nchw_kernel(const f32x4 *pl, int c4, int C, int npix, float *dst)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const f32x4 v = pl[(size_t)blockIdx.y * npix + p];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (4 * (int)blockIdx.y + j < C) dst[(size_t)(4 * blockIdx.y + j) * npix + p] = v[j];
+}
+
+__global__ __launch_bounds__(256) void train_nchw_to_planes_kernel(const float *src, int C, int npix, f32x4 *pl)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    f32x4 v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (4 * (int)blockIdx.y + j < C) v[j] = src[(size_t)(4 * blockIdx.y + j) * npix + p];
+    pl[(size_t)blockIdx.y * npix + p] = v;
+}
+
+// out[group g] = P^lv(in[group g]) (+ bias of the branch), lv = g / sl4: branch i of a VortexPooling sees i successive
+// nn.AvgPool2d(3, 1, 1) (count_include_pad: zeros outside the image, divide by 9 - every level zero-pads anew).  One block =
+// one 32 x 8 pixel tile of one channel group, the intermediate levels live in LDS with a shrinking halo.  The operator is
+// symmetric, so the backward pass is the same kernel on the gradient (without bias).
+struct TrainPyramidArgs {
+    const f32x4 *in;
+    f32x4 *out;
+    const float *bias[4];  // per branch: [OC] logical, or NULL
+    int h, w, sl4, OC;
+};
+constexpr int kTpW = 32, kTpH = 8, kTpStride = kTpW + 6;
+
+__global__ __launch_bounds__(256) void train_pyramid_kernel(const TrainPyramidArgs a)
+{
+    __shared__ f32x4 buf[2][kTpStride * (kTpH + 6)];
+    const int g = blockIdx.y, lv = g / a.sl4, cg = g - lv * a.sl4;
+    const int tiles_x = (a.w + kTpW - 1) / kTpW;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int x0 = tx * kTpW, y0 = ty * kTpH, npix = a.h * a.w;
+    const f32x4 *plane = a.in + (size_t)g * npix;
+    const f32x4 zero{0.f, 0.f, 0.f, 0.f};
+    f32x4 b = zero;
+    if (a.bias[lv])
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * cg + j < a.OC) b[j] = a.bias[lv][4 * cg + j];
+    if (lv == 0) {
+        const int ly = threadIdx.x / kTpW, lx = threadIdx.x - ly * kTpW;
+        const int gy = y0 + ly, gx = x0 + lx;
+        if (gy < a.h && gx < a.w) a.out[(size_t)g * npix + gy * a.w + gx] = plane[gy * a.w + gx] + b;
+        return;
+    }
+    {
+        const int W0 = kTpW + 2 * lv, H0 = kTpH + 2 * lv;
+        for (int i = threadIdx.x; i < W0 * H0; i += 256) {
+            const int ly = i / W0, lx = i - ly * W0;
+            const int gy = y0 - lv + ly, gx = x0 - lv + lx;
+            const bool in = (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
+            buf[0][ly * kTpStride + lx] = in ? plane[gy * a.w + gx] : zero;
+        }
+    }
+    __syncthreads();
+    for (int l = 1; l <= lv; ++l) {
+        const int halo = lv - l;
+        const int Wl = kTpW + 2 * halo, Hl = kTpH + 2 * halo;
+        const f32x4 *src = buf[(l - 1) & 1];
+        for (int i = threadIdx.x; i < Wl * Hl; i += 256) {
+            const int ly = i / Wl, lx = i - ly * Wl;
+            const int gy = y0 - halo + ly, gx = x0 - halo + lx;
+            const bool in = (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
+            f32x4 s = zero;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) s += src[(ly + dy) * kTpStride + lx + dx];
+            s = s / 9.0f;
+            if (l < lv) buf[l & 1][ly * kTpStride + lx] = in ? s : zero;
+            else if (in) a.out[(size_t)g * npix + gy * a.w + gx] = s + b;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- global-average branch of a VortexPooling (modules/model.py:103-109,146): AdaptiveAvgPool2d(1) -> 1x1 conv ->
+// up-sampling of the 1x1 map (a broadcast) -> BatchNorm2d.  The BatchNorm sees a constant map: with batch statistics its
+// output is beta (variance 0), nothing upstream receives a gradient, running_mean moves towards the map's value and
+// running_var towards 0; with running statistics it is an affine map of g = W mean(x) + b and gradients flow to W, b,
+// gamma, beta and (as a per-channel constant over all pixels) to x.  One block does the vector work.
+struct GaveTrainArgs {
+    const double *partial;   // [slabs][c4_in][8]: channel sums of x (forward) / of d cat[gave slot] (backward)
+    int c4_in, c4_out, IC, OC, group, slot, npix, training, accumulate;
+    float momentum, eps;
+    const float *W, *b, *gamma, *beta;
+    float *running_mean, *running_var;
+    float *pooled, *xhat, *gis;  // saved for backward: [4 c4_in] mean of x per physical channel, [OC] x-hat, [OC] gamma * invstd
+    float *vec;                  // forward: [4 c4_out] value of the branch's constant map (padding channels 0)
+    float *dW, *db, *dgamma, *dbeta;
+    float *dpooled;              // backward (eval): [4 c4_in] per-channel constant added to d x
+};
+
+__device__ __forceinline__ double gave_slab_sum(const double *partial, int c4, int ch)
+{
+    double s = 0.0;
+    for (int b = 0; b < kTrainSlabs; ++b) s += partial[((size_t)b * c4 + (ch >> 2)) * 8 + (ch & 3)];
+    return s;
+}
+
+__global__ __launch_bounds__(256) void train_gave_fwd_kernel(const GaveTrainArgs a)
+{
+    for (int ch = threadIdx.x; ch < 4 * a.c4_in; ch += 256) a.pooled[ch] = (float)(gave_slab_sum(a.partial, a.c4_in, ch) / (double)a.npix);
+    __syncthreads();  // (one block: its own global writes are visible to it after the barrier)
+    for (int o = threadIdx.x; o < 4 * a.c4_out; o += 256) {
+        float vec = 0.0f;
+        if (o < a.OC) {
+            float g = a.b ? a.b[o] : 0.0f;
+            for (int l = 0; l < a.IC; ++l) g = fmaf(a.W[(size_t)o * a.IC + l], a.pooled[(l / a.group) * a.slot + l % a.group], g);
+            const float ga = a.gamma ? a.gamma[o] : 1.0f, be = a.beta ? a.beta[o] : 0.0f;
+            if (a.training) {
+                a.running_mean[o] = (1.0f - a.momentum) * a.running_mean[o] + a.momentum * g;
+                a.running_var[o] = (1.0f - a.momentum) * a.running_var[o];
+                a.xhat[o] = 0.0f;
+                a.gis[o] = 0.0f;
+                vec = be;
+            } else {
+                const float is = 1.0f / sqrtf(a.running_var[o] + a.eps);
+                const float xh = (g - a.running_mean[o]) * is;
+                a.xhat[o] = xh;
+                a.gis[o] = ga * is;
+                vec = xh * ga + be;
+            }
+        }
+        a.vec[o] = vec;
+    }
+}
+
+__global__ __launch_bounds__(256) void train_gave_bwd_kernel(const GaveTrainArgs a)
+{
+    __shared__ float dg[1024];
+    for (int o = threadIdx.x; o < a.OC; o += 256) {
+        const float dv = (float)gave_slab_sum(a.partial, a.c4_out, o);
+        if (a.dbeta) a.dbeta[o] = (a.accumulate ? a.dbeta[o] : 0.0f) + dv;
+        if (a.dgamma) a.dgamma[o] = (a.accumulate ? a.dgamma[o] : 0.0f) + dv * a.xhat[o];
+        const float d = dv * a.gis[o];  // 0 under batch statistics
+        dg[o] = d;
+        if (a.db) a.db[o] = (a.accumulate ? a.db[o] : 0.0f) + d;
+    }
+    __syncthreads();
+    if (a.dW)
+        for (int i = threadIdx.x; i < a.OC * a.IC; i += 256) {
+            const int o = i / a.IC, l = i - o * a.IC;
+            a.dW[i] = (a.accumulate ? a.dW[i] : 0.0f) + dg[o] * a.pooled[(l / a.group) * a.slot + l % a.group];
+        }
+    for (int ch = threadIdx.x; ch < 4 * a.c4_in; ch += 256) {
+        const int s = ch / a.slot, in = ch - s * a.slot, l = s * a.group + in;
+        float d = 0.0f;
+        if (in < a.group && l < a.IC)
+            for (int o = 0; o < a.OC; ++o) d = fmaf(a.W[(size_t)o * a.IC + l], dg[o], d);
+        a.dpooled[ch] = d / (float)a.npix;
+    }
+}
+
+// planes[g][p] = vec[4g .. 4g+3] (add != 0: +=)
+__global__ __launch_bounds__(256) void train_bcast_planes_kernel(const float *vec, f32x4 *pl, int npix, int add)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(vec + 4 * blockIdx.y);
+    f32x4 *d = pl + (size_t)blockIdx.y * npix + p;
+    *d = add ? *d + v : v;
+}
+
+// ---- plan ----------------------------------------------------------------------------------------------------------
+struct TUnit {           // conv -> [BatchNorm2d] -> activation -> [Dropout2d], one entry of the caller's layer table
+    int li, OC, IC, k, dil, group, slot, act, has_bn;
+    float scale;
+    int c4_in, c4_out;
+    float *in; int in_g0;    // input planes (window of a buffer)
+    float *din;              // gradient buffer of the input buffer (same window), NULL: not needed
+    float *y, *dy;           // convolution output / its gradient, [c4_out] groups (y_g0 inside a shared buffer for the stacked entry)
+    int y_g0;
+    float *out; int out_g0;  // unit output (window of a buffer)
+    float *dout;             // gradient buffer of the output buffer (same window)
+    float *wp, *bp, *wpT;    // packed weights: forward, bias, transposed + flipped (backward-data)
+    int n_ot, nsteps, n_otT, nstepsT;
+    float *mean, *invstd;
+    double *partial;
+    float *wpart;
+    WgradPlan wplan;
+};
+
+struct TVortex {
+    int li0;                  // layer index of the global-average conv; branches follow (4 each), then the final conv
+    float *x; int c4x, IC, group, slot; float *dx;  // input buffer (whole), its gradient
+    int o4, out_c, sl4, mid;
+    float *u, *du;            // stacked entry convolution output [4 sl4] (before the pools) / its gradient
+    float *ycat, *dycat;      // pooled + bias: the four entries' y as slices of one buffer
+    float *cat, *dcat;        // [5 o4]: gave | branch 0..3
+    int entry[4], c1[4], c2[4], close[4], final_u;  // unit indices
+    float *wp_stack, *wpT_stack, *wpart_stack;      // stacked entry weights [4 sl4 * 4 rows][K = 4 c4x]
+    int n_ot_s, nsteps_s, n_otT_s, nstepsT_s;
+    WgradPlan wplan_s;
+    double *gpartial;         // channel sums (forward: of x; backward: of d cat[gave])
+    float *pooled, *xhat, *gis, *vec, *dpooled;
+};
+
+}  // namespace ojf
+
+struct ojf_trainer {
+    int version, P, gf, sem, h, w, npix, c, sl4, out_c, o4, n_layers;
+    float scale;
+    std::vector<void *> allocs;
+    std::vector<ojf::TUnit> units;
+    std::vector<ojf::TVortex> vortex;
+    std::vector<std::vector<int>> dense;  // per head: unit indices a0, b0, a1, b1, ...
+    std::vector<float *> dbuf, ddbuf;     // per head: dense concatenation buffer / its gradient
+    std::vector<int> pred;                // unit indices
+    float *zero_bias = nullptr;
+    float *est_planes = nullptr, *dest_planes = nullptr;
+    std::map<const float *, std::vector<char>> written;  // gradient buffers: which channel groups this backward pass has stored
+    std::map<const float *, int> groups_of;
+    unsigned long long epoch = ~0ull;
+    bool have_forward = false;
+    int launches = 0;
+};
+
+namespace ojf {
+
+static int t_alloc(ojf_trainer *t, void **p, size_t bytes, bool zero = false)
+{
+    OJF_HIP(hipMalloc(p, bytes ? bytes : 16));
+    t->allocs.push_back(*p);
+    if (zero) OJF_HIP(hipMemset(*p, 0, bytes ? bytes : 16));
+    return 0;
+}
+
+static int t_planes(ojf_trainer *t, float **p, int groups, bool grad = false)
+{
+    if (t_alloc(t, reinterpret_cast<void **>(p), (size_t)groups * t->npix * 16, true)) return -2;
+    if (grad) t->groups_of[*p] = groups;
+    return 0;
+}
+
+// physical channels of `n` logical channels laid out as `group`-wide tensors in `slot`-wide slots
+static int slotted_phys(int n, int group, int slot) { return (n + group - 1) / group * slot; }
+
+static int t_add_unit(ojf_trainer *t, int li, int OC, int IC, int k, int dil, int group, int slot, int act, int has_bn, float scale,
+                      float *in, int in_g0, int c4_in, float *din, float *out, int out_g0, float *dout, bool own_y = true)
+{
+    TUnit u{};
+    u.li = li; u.OC = OC; u.IC = IC; u.k = k; u.dil = dil; u.group = group; u.slot = slot; u.act = act; u.has_bn = has_bn; u.scale = scale;
+    u.c4_in = c4_in; u.c4_out = (OC + 3) / 4;
+    u.in = in; u.in_g0 = in_g0; u.din = din; u.out = out; u.out_g0 = out_g0; u.dout = dout; u.y_g0 = 0;
+    const int cop = u.c4_out * 4, cip = c4_in * 4, taps = k * k;
+    if (ojf_train_packed_floats(cop, cip, k) == 0 || ojf_train_packed_floats(cip, cop, k) == 0) return fail("ojf_trainer: unsupported layer shape");
+    u.n_ot = round_up(round_up(cop, 16) / 16, kNT); u.nsteps = (taps * c4_in + 3) / 4;
+    u.n_otT = round_up(round_up(cip, 16) / 16, kNT); u.nstepsT = (taps * u.c4_out + 3) / 4;
+    if (u.n_ot > 8) return fail("ojf_trainer: more than 128 output channels in one unit");
+    if (own_y) {
+        if (t_planes(t, &u.y, u.c4_out) || t_planes(t, &u.dy, u.c4_out)) return -2;
+        if (t_alloc(t, reinterpret_cast<void **>(&u.wp), ojf_train_packed_floats(cop, cip, k) * 4, true)) return -2;
+        if (t_alloc(t, reinterpret_cast<void **>(&u.wpT), ojf_train_packed_floats(cip, cop, k) * 4, true)) return -2;
+        u.wplan = wgrad_plan(cop, cip, taps, t->npix);
+        if (t_alloc(t, reinterpret_cast<void **>(&u.wpart), (size_t)u.wplan.slabs * taps * u.wplan.ocp * u.wplan.icp * 4)) return -2;
+    }
+    if (t_alloc(t, reinterpret_cast<void **>(&u.bp), (size_t)u.n_ot * 16 * 4, true)) return -2;
+    if (t_alloc(t, reinterpret_cast<void **>(&u.mean), (size_t)cop * 4, true) || t_alloc(t, reinterpret_cast<void **>(&u.invstd), (size_t)cop * 4, true)) return -2;
+    if (t_alloc(t, reinterpret_cast<void **>(&u.partial), ojf_train_partial_doubles(cop) * 8, true)) return -2;
+    t->units.push_back(u);
+    return (int)t->units.size() - 1;
+}
+
+// dense head: the concatenation buffer D holds gf + 1 slots; block i reads slots [0, i], writes slot i + 1
+static int t_build_dense(ojf_trainer *t, int li0)
+{
+    const int sl4 = t->sl4, c = t->c, slot = 4 * sl4;
+    float *D, *dD;
+    if (t_planes(t, &D, (t->gf + 1) * sl4) || t_planes(t, &dD, (t->gf + 1) * sl4, true)) return -2;
+    t->dbuf.push_back(D); t->ddbuf.push_back(dD);
+    std::vector<int> ids;
+    for (int i = 0; i < t->gf; ++i) {
+        float *T, *dT;
+        if (t_planes(t, &T, sl4) || t_planes(t, &dT, sl4, true)) return -2;
+        // the first block's input is the net input: no gradient needed there
+        const int a = t_add_unit(t, li0 + 2 * i, c, (i + 1) * c, 3, 1, c, slot, OJF_ACT_LEAKY, 1, 1.0f, D, 0, (i + 1) * sl4, i ? dD : nullptr, T, 0, dT);
+        if (a < 0) return -2;
+        const int b = t_add_unit(t, li0 + 2 * i + 1, c, c, 3, 1, c, slot, OJF_ACT_LEAKY, 1, 1.0f, T, 0, sl4, dT, D, (i + 1) * sl4, dD);
+        if (b < 0) return -2;
+        ids.push_back(a); ids.push_back(b);
+    }
+    t->dense.push_back(ids);
+    return 0;
+}
+
+static const int kRates[4] = {1, 3, 9, 27};
+
+static int t_build_vortex(ojf_trainer *t, int li0, float *x, int c4x, int IC, int group, int slot, float *dx, float *out, int out_g0, float *dout)
+{
+    TVortex v{};
+    v.li0 = li0; v.x = x; v.c4x = c4x; v.IC = IC; v.group = group; v.slot = slot; v.dx = dx;
+    v.out_c = t->out_c; v.o4 = t->o4; v.sl4 = t->sl4; v.mid = t->c;
+    const int sl4 = v.sl4, mid = v.mid, o4 = v.o4;
+    if (t_planes(t, &v.u, 4 * sl4) || t_planes(t, &v.du, 4 * sl4) || t_planes(t, &v.ycat, 4 * sl4) || t_planes(t, &v.dycat, 4 * sl4)) return -2;
+    if (t_planes(t, &v.cat, 5 * o4) || t_planes(t, &v.dcat, 5 * o4, true)) return -2;
+    float *E, *dE, *F, *dF, *G, *dG;
+    if (t_planes(t, &E, 4 * sl4) || t_planes(t, &dE, 4 * sl4, true) || t_planes(t, &F, 4 * sl4) || t_planes(t, &dF, 4 * sl4, true) ||
+        t_planes(t, &G, 4 * sl4) || t_planes(t, &dG, 4 * sl4, true))
+        return -2;
+    for (int r = 0; r < 4; ++r) {
+        const int l = li0 + 1 + 4 * r;
+        // entry: y lives in the shared pooled buffer (slice r), no packed weights / wgrad scratch of its own (stacked)
+        v.entry[r] = t_add_unit(t, l, mid, IC, 1, 1, group, slot, OJF_ACT_RELU, 1, 1.0f, x, 0, c4x, dx, E, r * sl4, dE, false);
+        if (v.entry[r] < 0) return -2;
+        TUnit &e = t->units[v.entry[r]];
+        e.y = v.ycat; e.dy = v.dycat; e.y_g0 = r * sl4;
+        v.c1[r] = t_add_unit(t, l + 1, mid, mid, 3, kRates[r], mid, 4 * sl4, OJF_ACT_RELU, 1, 1.0f, E, r * sl4, sl4, dE, F, r * sl4, dF);
+        v.c2[r] = t_add_unit(t, l + 2, mid, mid, 3, kRates[r], mid, 4 * sl4, OJF_ACT_RELU, 1, 1.0f, F, r * sl4, sl4, dF, G, r * sl4, dG);
+        v.close[r] = t_add_unit(t, l + 3, v.out_c, mid, 1, 1, mid, 4 * sl4, OJF_ACT_RELU, 1, 1.0f, G, r * sl4, sl4, dG, v.cat, (1 + r) * o4, v.dcat);
+        if (v.c1[r] < 0 || v.c2[r] < 0 || v.close[r] < 0) return -2;
+    }
+    v.final_u = t_add_unit(t, li0 + 17, v.out_c, 5 * v.out_c, 1, 1, v.out_c, 4 * o4, OJF_ACT_NONE, 1, 1.0f, v.cat, 0, 5 * o4, v.dcat, out, out_g0, dout);
+    if (v.final_u < 0) return -2;
+    // stacked entry: rows = 4 slots of 4 sl4 channels, K = the input's physical channels
+    const int rows = 16 * sl4, kch = 4 * c4x;
+    if (ojf_train_packed_floats(rows, kch, 1) == 0 || ojf_train_packed_floats(kch, rows, 1) == 0) return fail("ojf_trainer: unsupported VortexPooling width");
+    v.n_ot_s = round_up(round_up(rows, 16) / 16, kNT); v.nsteps_s = (c4x + 3) / 4;
+    v.n_otT_s = round_up(round_up(kch, 16) / 16, kNT); v.nstepsT_s = (4 * sl4 + 3) / 4;
+    if (v.n_ot_s > 8) return fail("ojf_trainer: stacked entry wider than 128 channels");
+    if (t_alloc(t, reinterpret_cast<void **>(&v.wp_stack), ojf_train_packed_floats(rows, kch, 1) * 4, true) ||
+        t_alloc(t, reinterpret_cast<void **>(&v.wpT_stack), ojf_train_packed_floats(kch, rows, 1) * 4, true))
+        return -2;
+    v.wplan_s = wgrad_plan(rows, kch, 1, t->npix);
+    if (t_alloc(t, reinterpret_cast<void **>(&v.wpart_stack), (size_t)v.wplan_s.slabs * v.wplan_s.ocp * v.wplan_s.icp * 4)) return -2;
+    const int cmax = c4x > o4 ? c4x : o4;
+    if (t_alloc(t, reinterpret_cast<void **>(&v.gpartial), ojf_train_partial_doubles(4 * cmax) * 8, true)) return -2;
+    if (t_alloc(t, reinterpret_cast<void **>(&v.pooled), (size_t)c4x * 16, true) || t_alloc(t, reinterpret_cast<void **>(&v.dpooled), (size_t)c4x * 16, true) ||
+        t_alloc(t, reinterpret_cast<void **>(&v.xhat), (size_t)o4 * 16, true) || t_alloc(t, reinterpret_cast<void **>(&v.gis), (size_t)o4 * 16, true) ||
+        t_alloc(t, reinterpret_cast<void **>(&v.vec), (size_t)o4 * 16, true))
+        return -2;
+    t->vortex.push_back(v);
+    return 0;
+}
+
+// ---- launches --------------------------------------------------------------------------------------------------------
+struct TCtx {
+    ojf_trainer *t;
+    const ojf_train_layer *L;
+    hipStream_t st;
+};
+
+static inline dim3 px_grid(int npix, int gy) { return dim3((unsigned)((npix + 255) / 256), (unsigned)gy); }
+
+static int t_check_unit(const TUnit &u, const ojf_train_layer &l)
+{
+    if (!l.weight || l.out_channels != u.OC || l.in_channels != u.IC || l.ksize != u.k || l.dilation != u.dil)
+        return fail("ojf_trainer: layer table does not match the net topology (layer " + std::to_string(u.li) + ")");
+    if (u.has_bn && (!l.running_mean || !l.running_var)) return fail("ojf_trainer: BatchNorm layer without running statistics");
+    return 0;
+}
+
+static int t_pack_weights(TCtx &c)
+{
+    ojf_trainer *t = c.t;
+    for (TUnit &u : t->units) {
+        const ojf_train_layer &l = c.L[u.li];
+        if (t_check_unit(u, l)) return -2;
+        if (!u.wp) continue;  // stacked entry units: packed with their VortexPooling below
+        if (ojf_train_pack(l.weight, l.bias, u.OC, u.IC, u.k, u.group, u.slot, 4 * u.c4_in, 4 * u.c4_out, 0, u.wp, u.bp, c.st)) return -2;
+        if (u.din && ojf_train_pack(l.weight, nullptr, u.OC, u.IC, u.k, u.group, u.slot, 4 * u.c4_in, 4 * u.c4_out, 1, u.wpT, nullptr, c.st)) return -2;
+        t->launches += u.din ? 2 : 1;
+    }
+    for (TVortex &v : t->vortex)
+        for (int r = 0; r < 4; ++r) {
+            const TUnit &u = t->units[v.entry[r]];
+            const ojf_train_layer &l = c.L[u.li];
+            for (int tr = 0; tr < 2; ++tr) {
+                PackArgs a;
+                const int rows = tr ? 4 * v.c4x : 16 * v.sl4, kch = tr ? 16 * v.sl4 : 4 * v.c4x;
+                a.w = l.weight; a.bias = nullptr; a.wp = tr ? v.wpT_stack : v.wp_stack; a.bp = nullptr;
+                a.OC = u.OC; a.IC = u.IC; a.taps = 1; a.group = u.group; a.slot = u.slot;
+                a.c4 = kch / 4; a.nsteps = (a.c4 + 3) / 4; a.n_ot = round_up(round_up(rows, 16) / 16, kNT); a.transposed = tr;
+                a.oc_base = r * 4 * v.sl4; a.partial = 1;
+                const long total = (long)a.n_ot * (a.nsteps + kPadSteps) * 256;
+                hipLaunchKernelGGL(train_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.st, a);
+                ++t->launches;
+            }
+        }
+    return check_hip(hipGetLastError(), "ojf_trainer weight packing");
+}
+
+// convolution launches of up to four units (forward), chunked over output tiles when there are more than eight
+static int t_conv(TCtx &c, const ConvArgs *args, int n, int n_ot)
+{
+    for (int ot0 = 0; ot0 < n_ot; ot0 += 8) {
+        const int nt = n_ot - ot0 < 8 ? n_ot - ot0 : 8;
+        ConvArgs a[4];
+        for (int i = 0; i < n; ++i) {
+            a[i] = args[i];
+            a[i].wp = args[i].wp + (size_t)ot0 * (args[i].nsteps + kPadSteps) * 64;
+            a[i].bias = args[i].bias + (size_t)ot0 * 16;
+            a[i].out_g0 = args[i].out_g0 + ot0 * 4;
+            const int left = args[i].og_store - ot0 * 4;
+            a[i].og_store = left < nt * 4 ? left : nt * 4;
+        }
+        if (launch_conv_args(a, n, nt, c.st, OJF_ARITH_F32)) return -2;
+        ++c.t->launches;
+    }
+    return 0;
+}
+
+static ConvArgs t_conv_args(const ojf_trainer *t, const float *in, int in_g0, int c4_in, float *out, int out_g0, int c4_out, const float *wp,
+                            const float *bias, int nsteps, int k, int dil, int accum)
+{
+    ConvArgs a;
+    a.ovf = nullptr; a.accum = accum;
+    a.in = planes(in); a.out = planes(out); a.out_rows = nullptr;
+    a.wp = planes(wp); a.bias = bias; a.rinv = nullptr;
+    a.in_g0 = in_g0; a.out_g0 = out_g0; a.rows_stride = 0; a.rows_n = 0;
+    a.h = t->h; a.w = t->w; a.npix = t->npix; a.taps = k * k; a.dil = dil; a.c4 = c4_in; a.nsteps = nsteps;
+    a.w_magic = 0; a.c4_magic = 0;
+    a.og_store = c4_out;
+    a.act = OJF_ACT_NONE; a.act_n = 0; a.scale = 1.0f;
+    return a;
+}
+
+// store / accumulate decision of a gradient write into groups [g0, g0 + n) of buffer `buf`
+static int t_grad_mode(ojf_trainer *t, const float *buf, int g0, int n, int *accum)
+{
+    auto it = t->written.find(buf);
+    if (it == t->written.end()) return fail("ojf_trainer: untracked gradient buffer");
+    std::vector<char> &w = it->second;
+    int set = 0;
+    for (int g = g0; g < g0 + n; ++g) set += w[g];
+    if (set != 0 && set != n) return fail("ojf_trainer: mixed store / accumulate gradient window");
+    *accum = set ? 1 : 0;
+    for (int g = g0; g < g0 + n; ++g) w[g] = 1;
+    return 0;
+}
+
+static BnActArgs t_bn_args(const ojf_trainer *t, const TUnit &u, const ojf_train_layer &l)
+{
+    BnActArgs a = train_bn_args(u.y, u.y_g0, 4 * u.c4_out, u.OC, t->h, t->w, u.mean, u.invstd, u.has_bn ? l.gamma : nullptr, u.has_bn ? l.beta : nullptr,
+                                l.drop_scale, u.act, u.scale, u.has_bn, (u.has_bn && l.bn_training) ? 1 : 0);
+    a.partial = u.partial;
+    return a;
+}
+
+// forward of up to four units of identical shape: convolution (unless the caller already produced y), statistics, normalise + activate
+static int t_units_forward(TCtx &c, const int *ids, int n, bool conv = true)
+{
+    ojf_trainer *t = c.t;
+    if (conv) {
+        ConvArgs ca[4];
+        for (int i = 0; i < n; ++i) {
+            const TUnit &u = t->units[ids[i]];
+            ca[i] = t_conv_args(t, u.in, u.in_g0, u.c4_in, u.y, u.y_g0, u.c4_out, u.wp, u.bp, u.nsteps, u.k, u.dil, 0);
+        }
+        if (t_conv(c, ca, n, t->units[ids[0]].n_ot)) return -2;
+    }
+    BnGroup grp;
+    bool any_stats = false;
+    for (int i = 0; i < 4; ++i) {
+        const TUnit &u = t->units[ids[i < n ? i : 0]];
+        const ojf_train_layer &l = c.L[u.li];
+        BnActArgs a = t_bn_args(t, u, l);
+        a.mean = nullptr; a.invstd = nullptr;
+        a.out = planes(u.out); a.out_g0 = u.out_g0;
+        a.mean_out = u.mean; a.invstd_out = u.invstd; a.running_mean = l.running_mean; a.running_var = l.running_var;
+        a.momentum = l.momentum; a.eps = l.eps;
+        any_stats |= a.has_bn && a.training;
+        grp.g[i] = a;
+    }
+    const int c4 = t->units[ids[0]].c4_out;
+    if (any_stats) {
+        hipLaunchKernelGGL(train_stats_group_kernel, dim3(kTrainSlabs, c4, n), dim3(256), 0, c.st, grp);
+        ++t->launches;
+    }
+    const int bx = (t->npix + 255) / 256 < 128 ? (t->npix + 255) / 256 : 128;
+    hipLaunchKernelGGL(train_bn_act_fwd_kernel, dim3(bx, c4, n), dim3(256), 0, c.st, grp);
+    ++t->launches;
+    return check_hip(hipGetLastError(), "ojf_trainer unit forward");
+}
+
+// backward of up to four units: BatchNorm / activation backward (dy, d gamma, d beta, d bias); then - unless `tail` is
+// false (stacked entry: the caller pools dy first) - the weight gradient and backward-data
+static int t_units_backward(TCtx &c, const int *ids, int n, bool tail = true)
+{
+    ojf_trainer *t = c.t;
+    BnGroup grp;
+    for (int i = 0; i < 4; ++i) {
+        const TUnit &u = t->units[ids[i < n ? i : 0]];
+        const ojf_train_layer &l = c.L[u.li];
+        BnActArgs a = t_bn_args(t, u, l);
+        a.dout = planes(u.dout); a.dout_g0 = u.out_g0; a.dy = planes(u.dy); a.dy_g0 = u.y_g0;
+        a.dgamma = u.has_bn ? l.grad_gamma : nullptr; a.dbeta = u.has_bn ? l.grad_beta : nullptr; a.dbias = l.bias ? l.grad_bias : nullptr;
+        a.accumulate = l.accumulate ? 1 : 0;
+        grp.g[i] = a;
+    }
+    const int c4 = t->units[ids[0]].c4_out;
+    hipLaunchKernelGGL(train_bn_bwd_reduce_kernel, dim3(kTrainSlabs, c4, n), dim3(256), 0, c.st, grp);
+    const int bx = (t->npix + 255) / 256 < 128 ? (t->npix + 255) / 256 : 128;
+    hipLaunchKernelGGL(train_bn_bwd_apply_kernel, dim3(bx, c4, n), dim3(256), 0, c.st, grp);
+    t->launches += 2;
+    OJF_HIP(hipGetLastError());
+    if (!tail) return 0;
+    // weight gradients
+    {
+        const TUnit &u0 = t->units[ids[0]];
+        const int taps = u0.k * u0.k, tiles = (u0.wplan.ocp / 32) * (u0.wplan.icp / 32);
+        WgradGroup wg;
+        WgradReduceGroup rg;
+        long total = 0;
+        for (int i = 0; i < 4; ++i) {
+            const TUnit &u = t->units[ids[i < n ? i : 0]];
+            const ojf_train_layer &l = c.L[u.li];
+            WgradArgs a;
+            a.x = planes(u.in); a.dy = planes(u.dy); a.partial = u.wpart; a.x_g0 = u.in_g0; a.c4_in = u.c4_in; a.dy_g0 = u.y_g0; a.c4_out = u.c4_out;
+            a.h = t->h; a.w = t->w; a.npix = t->npix; a.taps = taps; a.dil = u.dil; a.slabs = u.wplan.slabs; a.ocp = u.wplan.ocp; a.icp = u.wplan.icp;
+            wg.g[i] = a;
+            WgradReduceArgs r;
+            r.partial = u.wpart; r.dw = l.grad_weight; r.slabs = u.wplan.slabs; r.taps = taps; r.ocp = u.wplan.ocp; r.icp = u.wplan.icp;
+            r.OC = u.OC; r.IC = u.IC; r.group = u.group; r.slot = u.slot; r.c_in_phys = 4 * u.c4_in; r.accumulate = l.accumulate ? 1 : 0; r.oc_base = 0;
+            rg.g[i] = r;
+            total = (long)taps * u.OC * 4 * u.c4_in * 8;
+            if (!l.grad_weight) return fail("ojf_trainer_backward: layer without a weight-gradient tensor");
+        }
+        wg.tiles = tiles;
+        hipLaunchKernelGGL(train_wgrad_mfma_kernel, dim3(u0.wplan.slabs, tiles * n, taps), dim3(64), 0, c.st, wg,
+                           div_magic(t->w, (uint64_t)t->npix + 2 * kWgChunk));
+        hipLaunchKernelGGL(train_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256), n), dim3(256), 0, c.st, rg);
+        t->launches += 2;
+        OJF_HIP(hipGetLastError());
+    }
+    // backward-data: d in (+)= conv(dy, transposed + flipped weights)
+    if (t->units[ids[0]].din) {
+        ConvArgs ca[4];
+        for (int i = 0; i < n; ++i) {
+            const TUnit &u = t->units[ids[i]];
+            int accum = 0;
+            if (t_grad_mode(t, u.din, u.in_g0, u.c4_in, &accum)) return -2;
+            ca[i] = t_conv_args(t, u.dy, u.y_g0, u.c4_out, u.din, u.in_g0, u.c4_in, u.wpT, t->zero_bias, u.nstepsT, u.k, u.dil, accum);
+        }
+        if (t_conv(c, ca, n, t->units[ids[0]].n_otT)) return -2;
+    }
+    return 0;
+}
+
+static int t_vortex_forward(TCtx &c, TVortex &v)
+{
+    ojf_trainer *t = c.t;
+    const ojf_train_layer &lg = c.L[v.li0];
+    if (!lg.weight || lg.out_channels != v.out_c || lg.in_channels != v.IC || lg.ksize != 1 || !lg.running_mean || !lg.running_var)
+        return fail("ojf_trainer: global-average layer does not match the topology");
+    // global-average branch -> slot 0 of the concatenation
+    hipLaunchKernelGGL(train_stats_partial_kernel, dim3(kTrainSlabs, v.c4x), dim3(256), 0, c.st, planes(v.x), 0, t->npix, v.gpartial);
+    GaveTrainArgs g{};
+    g.partial = v.gpartial; g.c4_in = v.c4x; g.c4_out = v.o4; g.IC = v.IC; g.OC = v.out_c; g.group = v.group; g.slot = v.slot; g.npix = t->npix;
+    g.training = lg.bn_training ? 1 : 0; g.accumulate = 0; g.momentum = lg.momentum; g.eps = lg.eps;
+    g.W = lg.weight; g.b = lg.bias; g.gamma = lg.gamma; g.beta = lg.beta; g.running_mean = lg.running_mean; g.running_var = lg.running_var;
+    g.pooled = v.pooled; g.xhat = v.xhat; g.gis = v.gis; g.vec = v.vec;
+    if (v.out_c > 1024) return fail("ojf_trainer: VortexPooling wider than 1024 channels");
+    hipLaunchKernelGGL(train_gave_fwd_kernel, dim3(1), dim3(256), 0, c.st, g);
+    hipLaunchKernelGGL(train_bcast_planes_kernel, px_grid(t->npix, v.o4), dim3(256), 0, c.st, v.vec, planes(v.cat), t->npix, 0);
+    t->launches += 3;
+    // the four branch entries: ONE stacked 1x1 convolution of the unpooled input, then the pools (+ bias) on the narrow result
+    ConvArgs ca = t_conv_args(t, v.x, 0, v.c4x, v.u, 0, 4 * v.sl4, v.wp_stack, t->zero_bias, v.nsteps_s, 1, 1, 0);
+    if (t_conv(c, &ca, 1, v.n_ot_s)) return -2;
+    TrainPyramidArgs pa;
+    pa.in = planes(v.u); pa.out = planes(v.ycat); pa.h = t->h; pa.w = t->w; pa.sl4 = v.sl4; pa.OC = v.mid;
+    for (int r = 0; r < 4; ++r) pa.bias[r] = c.L[t->units[v.entry[r]].li].bias;
+    const int tiles = ((t->w + kTpW - 1) / kTpW) * ((t->h + kTpH - 1) / kTpH);
+    hipLaunchKernelGGL(train_pyramid_kernel, dim3(tiles, 4 * v.sl4), dim3(256), 0, c.st, pa);
+    ++t->launches;
+    OJF_HIP(hipGetLastError());
+    if (t_units_forward(c, v.entry, 4, false)) return -2;
+    if (t_units_forward(c, v.c1, 4) || t_units_forward(c, v.c2, 4) || t_units_forward(c, v.close, 4)) return -2;
+    return t_units_forward(c, &v.final_u, 1);
+}
+
+static int t_vortex_backward(TCtx &c, TVortex &v)
+{
+    ojf_trainer *t = c.t;
+    if (t_units_backward(c, &v.final_u, 1)) return -2;
+    if (t_units_backward(c, v.close, 4) || t_units_backward(c, v.c2, 4) || t_units_backward(c, v.c1, 4)) return -2;
+    // entries: BatchNorm backward per branch, pool the gradients, one stacked weight gradient + one backward-data
+    if (t_units_backward(c, v.entry, 4, false)) return -2;
+    TrainPyramidArgs pa;
+    pa.in = planes(v.dycat); pa.out = planes(v.du); pa.h = t->h; pa.w = t->w; pa.sl4 = v.sl4; pa.OC = v.mid;
+    for (int r = 0; r < 4; ++r) pa.bias[r] = nullptr;
+    const int tiles = ((t->w + kTpW - 1) / kTpW) * ((t->h + kTpH - 1) / kTpH);
+    hipLaunchKernelGGL(train_pyramid_kernel, dim3(tiles, 4 * v.sl4), dim3(256), 0, c.st, pa);
+    {
+        WgradArgs a;
+        a.x = planes(v.x); a.dy = planes(v.du); a.partial = v.wpart_stack; a.x_g0 = 0; a.c4_in = v.c4x; a.dy_g0 = 0; a.c4_out = 4 * v.sl4;
+        a.h = t->h; a.w = t->w; a.npix = t->npix; a.taps = 1; a.dil = 1; a.slabs = v.wplan_s.slabs; a.ocp = v.wplan_s.ocp; a.icp = v.wplan_s.icp;
+        const int wt = (a.ocp / 32) * (a.icp / 32);
+        hipLaunchKernelGGL(train_wgrad_mfma_kernel, dim3(a.slabs, wt, 1), dim3(64), 0, c.st, WgradGroup{{a, a, a, a}, wt},
+                           div_magic(t->w, (uint64_t)t->npix + 2 * kWgChunk));
+        WgradReduceGroup rg;
+        long total = 0;
+        for (int r = 0; r < 4; ++r) {
+            const TUnit &u = t->units[v.entry[r]];
+            const ojf_train_layer &l = c.L[u.li];
+            if (!l.grad_weight) return fail("ojf_trainer_backward: layer without a weight-gradient tensor");
+            WgradReduceArgs ra;
+            ra.partial = v.wpart_stack; ra.dw = l.grad_weight; ra.slabs = a.slabs; ra.taps = 1; ra.ocp = a.ocp; ra.icp = a.icp;
+            ra.OC = u.OC; ra.IC = u.IC; ra.group = u.group; ra.slot = u.slot; ra.c_in_phys = 4 * v.c4x; ra.accumulate = l.accumulate ? 1 : 0;
+            ra.oc_base = r * 4 * v.sl4;
+            rg.g[r] = ra;
+            total = (long)u.OC * 4 * v.c4x * 8;
+        }
+        hipLaunchKernelGGL(train_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256), 4), dim3(256), 0, c.st, rg);
+    }
+    t->launches += 3;
+    OJF_HIP(hipGetLastError());
+    if (v.dx) {
+        int accum = 0;
+        if (t_grad_mode(t, v.dx, 0, v.c4x, &accum)) return -2;
+        ConvArgs ca = t_conv_args(t, v.du, 0, 4 * v.sl4, v.dx, 0, v.c4x, v.wpT_stack, t->zero_bias, v.nstepsT_s, 1, 1, accum);
+        if (t_conv(c, &ca, 1, v.n_otT_s)) return -2;
+    }
+    // global-average branch
+    const ojf_train_layer &lg = c.L[v.li0];
+    hipLaunchKernelGGL(train_stats_partial_kernel, dim3(kTrainSlabs, v.o4), dim3(256), 0, c.st, planes(v.dcat), 0, t->npix, v.gpartial);
+    GaveTrainArgs g{};
+    g.partial = v.gpartial; g.c4_in = v.c4x; g.c4_out = v.o4; g.IC = v.IC; g.OC = v.out_c; g.group = v.group; g.slot = v.slot; g.npix = t->npix;
+    g.training = lg.bn_training ? 1 : 0; g.accumulate = lg.accumulate ? 1 : 0;
+    g.W = lg.weight; g.b = lg.bias; g.gamma = lg.gamma; g.beta = lg.beta;
+    g.pooled = v.pooled; g.xhat = v.xhat; g.gis = v.gis;
+    g.dW = lg.grad_weight; g.db = lg.bias ? lg.grad_bias : nullptr; g.dgamma = lg.grad_gamma; g.dbeta = lg.grad_beta; g.dpooled = v.dpooled;
+    hipLaunchKernelGGL(train_gave_bwd_kernel, dim3(1), dim3(256), 0, c.st, g);
+    t->launches += 2;
+    if (!lg.bn_training && v.dx) {  // running statistics: the branch is an affine map of mean(x) - a per-channel constant flows back to every pixel
+        hipLaunchKernelGGL(train_bcast_planes_kernel, px_grid(t->npix, v.c4x), dim3(256), 0, c.st, v.dpooled, planes(v.dx), t->npix, 1);
+        ++t->launches;
+    }
+    return check_hip(hipGetLastError(), "ojf_trainer VortexPooling backward");
+}
+
+}  // namespace ojf
+
+// ---- C ABI ----------------------------------------------------------------------------------------------------------
+OJF_API void ojf_trainer_destroy(ojf_trainer *t)
+{
+    if (!t) return;
+    for (void *p : t->allocs) (void)hipFree(p);
+    delete t;
+}
+
+OJF_API int ojf_trainer_create(ojf_trainer **out, int version, int n_points, int growth, int use_semantics, float output_scale, int h, int w)
+{
+    using namespace ojf;
+    if (!out) return fail("ojf_trainer_create: null output pointer");
+    *out = nullptr;
+    if ((version != 2 && version != 3) || n_points < 1 || growth < 1 || h < 1 || w < 1) return fail("ojf_trainer_create: bad argument");
+    int dev_count = 0;
+    if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count <= 0) return fail("ojf_trainer_create: no HIP device");
+    ojf_trainer *t = new ojf_trainer();
+    t->version = version; t->P = n_points; t->gf = growth; t->sem = use_semantics ? 1 : 0; t->h = h; t->w = w; t->npix = h * w; t->scale = output_scale;
+    t->c = 2 * n_points + 1 + ((version == 2 && t->sem) ? 1 : 0);
+    t->sl4 = (t->c + 3) / 4;
+    t->out_c = t->c * (growth + 1);
+    t->o4 = (t->out_c + 3) / 4;
+    t->n_layers = layer_count(version, growth, t->sem);
+    int rc = 0;
+    auto build = [&]() -> int {
+        if (t_alloc(t, reinterpret_cast<void **>(&t->zero_bias), 4096 * 4, true)) return -2;
+        const int slot = 4 * t->sl4, oslot = 4 * t->o4;
+        int li = 0;
+        float *vin = nullptr, *dvin = nullptr;  // input of the last VortexPooling
+        int vin_c4 = 0, vin_ic = 0;
+        if (version == 3) {
+            const int heads = t->sem ? 2 : 1;
+            if (t_planes(t, &vin, heads * t->o4) || t_planes(t, &dvin, heads * t->o4, true)) return -2;
+            for (int hd = 0; hd < heads; ++hd) {
+                if (t_build_dense(t, li)) return -2;
+                li += 2 * growth;
+                if (t_build_vortex(t, li, t->dbuf[hd], (growth + 1) * t->sl4, t->out_c, t->c, slot, t->ddbuf[hd], vin, hd * t->o4, dvin)) return -2;
+                li += 18;
+            }
+            vin_c4 = heads * t->o4; vin_ic = heads * t->out_c;
+        } else {
+            if (t_build_dense(t, li)) return -2;
+            li += 2 * growth;
+            if (t_planes(t, &vin, t->o4) || t_planes(t, &dvin, t->o4, true)) return -2;
+            if (t_build_vortex(t, li, t->dbuf[0], (growth + 1) * t->sl4, t->out_c, t->c, slot, t->ddbuf[0], vin, 0, dvin)) return -2;
+            li += 18;
+            vin_c4 = t->o4; vin_ic = t->out_c;
+        }
+        float *pin, *dpin;
+        if (t_planes(t, &pin, t->o4) || t_planes(t, &dpin, t->o4, true)) return -2;
+        if (t_build_vortex(t, li, vin, vin_c4, vin_ic, t->out_c, oslot, dvin, pin, 0, dpin)) return -2;
+        li += 18;
+        // prediction head (modules/model.py:24-52): gf stacks; the last one ends conv -> leaky, conv -> tanh
+        float *cur = pin, *dcur = dpin;
+        int cin = t->out_c;
+        for (int i = 0; i < growth; ++i) {
+            const int cout = (growth - i) * t->c;
+            const bool last = i == growth - 1;
+            const int widths[3] = {cout, cout, n_points};
+            for (int k = 0; k < (last ? 3 : 2); ++k) {
+                const int oc = widths[k];
+                float *o, *dobuf;
+                if (t_planes(t, &o, (oc + 3) / 4) || t_planes(t, &dobuf, (oc + 3) / 4, true)) return -2;
+                const bool tanh_layer = last && k == 2;
+                const int has_bn = (last && k >= 1) ? 0 : 1;
+                const int u = t_add_unit(t, li++, oc, cin, 1, 1, cin, round_up(cin, 4), tanh_layer ? OJF_ACT_TANH : OJF_ACT_LEAKY, has_bn,
+                                         tanh_layer ? output_scale : 1.0f, cur, 0, (cin + 3) / 4, dcur, o, 0, dobuf);
+                if (u < 0) return -2;
+                t->pred.push_back(u);
+                cur = o; dcur = dobuf; cin = oc;
+            }
+        }
+        t->est_planes = cur; t->dest_planes = dcur;
+        if (li != t->n_layers) return fail("ojf_trainer_create: internal layer count mismatch");
+        return 0;
+    };
+    rc = build();
+    if (rc) { ojf_trainer_destroy(t); return rc; }
+    *out = t;
+    return 0;
+}
+
+OJF_API int ojf_trainer_layer_count(const ojf_trainer *t) { return t ? t->n_layers : -1; }
+OJF_API int ojf_trainer_launch_count(const ojf_trainer *t) { return t ? t->launches : -1; }
+
+OJF_API int ojf_trainer_forward(ojf_trainer *t, const ojf_train_layer *layers, int n_layers, unsigned long long weights_epoch,
+                                const float *values, const float *weights, const float *frame, const float *semantic_frame,
+                                float *est, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (!t || !layers || !values || !weights || !frame || !est) return fail("ojf_trainer_forward: null pointer argument");
+    if (n_layers != t->n_layers) return fail("ojf_trainer_forward: wrong number of layers");
+    if (t->sem && !semantic_frame) return fail("ojf_trainer_forward: the net has a semantic channel but semantic_frame is NULL");
+    TCtx c{t, layers, as_stream(stream)};
+    t->launches = 0;
+    if (t->epoch != weights_epoch) {
+        if (t_pack_weights(c)) return -2;
+        t->epoch = weights_epoch;
+    }
+    // net input -> slot 0 of every dense head (modules/model.py:266-270 / :203-207)
+    for (size_t hd = 0; hd < t->dbuf.size(); ++hd) {
+        PackInArgs a{};
+        a.src[0] = values; a.nch[0] = t->P; a.src[1] = weights; a.nch[1] = t->P;
+        a.n_src = 3;
+        if (t->version == 3) { a.src[2] = hd == 0 ? frame : semantic_frame; a.nch[2] = 1; }
+        else {
+            a.src[2] = frame; a.nch[2] = 1;
+            if (t->sem) { a.src[3] = semantic_frame; a.nch[3] = 1; a.n_src = 4; }
+        }
+        a.c4 = t->sl4; a.npix = t->npix; a.dst = planes(t->dbuf[hd]);
+        hipLaunchKernelGGL(train_pack_input_kernel, px_grid(t->npix, t->sl4), dim3(256), 0, c.st, a);
+        ++t->launches;
+    }
+    OJF_HIP(hipGetLastError());
+    const size_t heads = t->dbuf.size();
+    for (size_t hd = 0; hd < heads; ++hd) {
+        for (int id : t->dense[hd])
+            if (t_units_forward(c, &id, 1)) return -2;
+        if (t_vortex_forward(c, t->vortex[hd])) return -2;
+    }
+    for (size_t vi = heads; vi < t->vortex.size(); ++vi)
+        if (t_vortex_forward(c, t->vortex[vi])) return -2;
+    for (int id : t->pred)
+        if (t_units_forward(c, &id, 1)) return -2;
+    hipLaunchKernelGGL(train_planes_to_nchw_kernel, px_grid(t->npix, (t->P + 3) / 4), dim3(256), 0, c.st, planes(t->est_planes), (t->P + 3) / 4, t->P,
+                       t->npix, est);
+    ++t->launches;
+    t->have_forward = true;
+    return check_hip(hipGetLastError(), "ojf_trainer_forward");
+}
+
+OJF_API int ojf_trainer_backward(ojf_trainer *t, const ojf_train_layer *layers, int n_layers, const float *d_est, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (!t || !layers || !d_est) return fail("ojf_trainer_backward: null pointer argument");
+    if (n_layers != t->n_layers) return fail("ojf_trainer_backward: wrong number of layers");
+    if (!t->have_forward) return fail("ojf_trainer_backward: no forward pass to differentiate (one backward per forward)");
+    TCtx c{t, layers, as_stream(stream)};
+    t->launches = 0;
+    for (auto &kv : t->groups_of) t->written[kv.first].assign(kv.second, 0);
+    hipLaunchKernelGGL(train_nchw_to_planes_kernel, px_grid(t->npix, (t->P + 3) / 4), dim3(256), 0, c.st, d_est, t->P, t->npix, planes(t->dest_planes));
+    ++t->launches;
+    OJF_HIP(hipGetLastError());
+    for (auto it = t->pred.rbegin(); it != t->pred.rend(); ++it) {
+        const int id = *it;
+        if (t_units_backward(c, &id, 1)) return -2;
+    }
+    const size_t heads = t->dbuf.size();
+    for (size_t vi = t->vortex.size(); vi-- > heads;)
+        if (t_vortex_backward(c, t->vortex[vi])) return -2;
+    for (size_t hd = heads; hd-- > 0;) {
+        if (t_vortex_backward(c, t->vortex[hd])) return -2;
+        for (auto it = t->dense[hd].rbegin(); it != t->dense[hd].rend(); ++it) {
+            const int id = *it;
+            if (t_units_backward(c, &id, 1)) return -2;
+        }
+    }
+    t->have_forward = false;
+    return check_hip(hipGetLastError(), "ojf_trainer_backward");
+}
