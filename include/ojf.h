@@ -286,6 +286,25 @@ int ojf_trainer_forward(ojf_trainer *t, const ojf_train_layer *layers, int n_lay
                         float *est_dev, ojf_stream_t stream);
 int ojf_trainer_backward(ojf_trainer *t, const ojf_train_layer *layers, int n_layers, const float *d_est_dev, ojf_stream_t stream);
 
+/* The frame step's glue around the net, one launch each instead of ~70 tensor operations:
+ * ojf_train_fuse_output(_bwd): modules/pipeline.py:104-127 - fused = (max(w, 0) v + clamp(est, +-init)) / (max(w, 0) + 1) on
+ *   the sample planes [n_points][n] (est: net output, v / w: ojf_extract with out_layout 1), gathered at the n_valid pixel
+ *   indices valid[] into rows [n_valid][n_points]; backward: d est planes (zero at masked pixels and outside the clamp).
+ * ojf_train_fusion_loss(_bwd): utils/loss.py:65-103 FusionLoss on rows [n_valid][n_points] -> *loss_out (device scalar),
+ *   including the reference's reshape quirk of the sign-cosine term; fp64 partial sums in fixed order (partial:
+ *   ojf_train_loss_partial_doubles(n_valid) doubles of scratch).  Backward: d est rows = *grad_out * d loss / d est. */
+int ojf_train_fuse_output(const float *est_planes_dev, const float *values_planes_dev, const float *weights_planes_dev,
+                          const long long *valid_dev, int n, int n_points, long long n_valid, float init_value, float *fused_rows_dev,
+                          ojf_stream_t stream);
+int ojf_train_fuse_output_bwd(const float *d_fused_rows_dev, const float *est_planes_dev, const float *weights_planes_dev,
+                              const long long *valid_dev, int n, int n_points, long long n_valid, float init_value,
+                              float *d_est_planes_dev, ojf_stream_t stream);
+size_t ojf_train_loss_partial_doubles(long long n_valid);
+int ojf_train_fusion_loss(const float *est_rows_dev, const float *target_rows_dev, long long n_valid, int n_points, float w_l1, float w_l2,
+                          float w_cos, double *partial_dev, float *loss_out_dev, ojf_stream_t stream);
+int ojf_train_fusion_loss_bwd(const float *est_rows_dev, const float *target_rows_dev, long long n_valid, int n_points, float w_l1,
+                              float w_l2, const float *grad_out_dev, float *d_est_rows_dev, ojf_stream_t stream);
+
 /* ojf_extract writing straight into the fusion net's input planes (values | weights | depth of
  * modules/pipeline.py:74-102), bit-identical to ojf_extract + ojf_net_prepare_input, for nets without a semantic
  * channel and with one head (others: error - use the two calls): no sample planes, no prepare launch. */

@@ -97,6 +97,11 @@ SIGNATURES = {
     'ojf_trainer_launch_count': (_i, [_vp]),
     'ojf_trainer_forward': (_i, [_vp, _c.POINTER(TrainLayer), _i, _c.c_ulonglong, _vp, _vp, _vp, _vp, _vp, _vp]),
     'ojf_trainer_backward': (_i, [_vp, _c.POINTER(TrainLayer), _i, _vp, _vp]),
+    'ojf_train_fuse_output': (_i, [_vp, _vp, _vp, _vp, _i, _i, _c.c_longlong, _f, _vp, _vp]),
+    'ojf_train_fuse_output_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _c.c_longlong, _f, _vp, _vp]),
+    'ojf_train_loss_partial_doubles': (_sz, [_c.c_longlong]),
+    'ojf_train_fusion_loss': (_i, [_vp, _vp, _c.c_longlong, _i, _f, _f, _f, _vp, _vp, _vp]),
+    'ojf_train_fusion_loss_bwd': (_i, [_vp, _vp, _c.c_longlong, _i, _f, _f, _vp, _vp, _vp]),
     'ojf_seg_pack_input': (_i, [_vp, _i, _f, _i, _i, _vp, _i, _vp]),
     'ojf_seg_maxpool': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
     'ojf_seg_mean': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),

@@ -148,22 +148,30 @@ struct GaveTrainArgs {
     float *dpooled;              // backward (eval): [4 c4_in] per-channel constant added to d x
 };
 
+// sum of the kTrainSlabs partial rows of physical channel ch, by one wave (lane b takes row b; fixed xor tree)
 __device__ __forceinline__ double gave_slab_sum(const double *partial, int c4, int ch)
 {
-    double s = 0.0;
-    for (int b = 0; b < kTrainSlabs; ++b) s += partial[((size_t)b * c4 + (ch >> 2)) * 8 + (ch & 3)];
-    return s;
+    double v = partial[((size_t)(threadIdx.x & 63) * c4 + (ch >> 2)) * 8 + (ch & 3)];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
 }
 
-__global__ __launch_bounds__(256) void train_gave_fwd_kernel(const GaveTrainArgs a)
+constexpr int kGaveThreads = 1024, kGaveMaxC = 1024;
+
+__global__ __launch_bounds__(kGaveThreads) void train_gave_fwd_kernel(const GaveTrainArgs a)
 {
-    for (int ch = threadIdx.x; ch < 4 * a.c4_in; ch += 256) a.pooled[ch] = (float)(gave_slab_sum(a.partial, a.c4_in, ch) / (double)a.npix);
-    __syncthreads();  // (one block: its own global writes are visible to it after the barrier)
-    for (int o = threadIdx.x; o < 4 * a.c4_out; o += 256) {
+    __shared__ float pooled[kGaveMaxC];
+    const int wave = threadIdx.x >> 6, nw = kGaveThreads / 64;
+    for (int ch = wave; ch < 4 * a.c4_in; ch += nw) {
+        const float m = (float)(gave_slab_sum(a.partial, a.c4_in, ch) / (double)a.npix);
+        if ((threadIdx.x & 63) == 0) { pooled[ch] = m; a.pooled[ch] = m; }
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 4 * a.c4_out; o += kGaveThreads) {
         float vec = 0.0f;
         if (o < a.OC) {
             float g = a.b ? a.b[o] : 0.0f;
-            for (int l = 0; l < a.IC; ++l) g = fmaf(a.W[(size_t)o * a.IC + l], a.pooled[(l / a.group) * a.slot + l % a.group], g);
+            for (int l = 0; l < a.IC; ++l) g = fmaf(a.W[(size_t)o * a.IC + l], pooled[(l / a.group) * a.slot + l % a.group], g);
             const float ga = a.gamma ? a.gamma[o] : 1.0f, be = a.beta ? a.beta[o] : 0.0f;
             if (a.training) {
                 a.running_mean[o] = (1.0f - a.momentum) * a.running_mean[o] + a.momentum * g;
@@ -183,24 +191,28 @@ __global__ __launch_bounds__(256) void train_gave_fwd_kernel(const GaveTrainArgs
     }
 }
 
-__global__ __launch_bounds__(256) void train_gave_bwd_kernel(const GaveTrainArgs a)
+__global__ __launch_bounds__(kGaveThreads) void train_gave_bwd_kernel(const GaveTrainArgs a)
 {
-    __shared__ float dg[1024];
-    for (int o = threadIdx.x; o < a.OC; o += 256) {
+    __shared__ float dg[kGaveMaxC];
+    const int wave = threadIdx.x >> 6, nw = kGaveThreads / 64;
+    for (int o = wave; o < a.OC; o += nw) {
         const float dv = (float)gave_slab_sum(a.partial, a.c4_out, o);
-        if (a.dbeta) a.dbeta[o] = (a.accumulate ? a.dbeta[o] : 0.0f) + dv;
-        if (a.dgamma) a.dgamma[o] = (a.accumulate ? a.dgamma[o] : 0.0f) + dv * a.xhat[o];
-        const float d = dv * a.gis[o];  // 0 under batch statistics
-        dg[o] = d;
-        if (a.db) a.db[o] = (a.accumulate ? a.db[o] : 0.0f) + d;
+        if ((threadIdx.x & 63) == 0) {
+            if (a.dbeta) a.dbeta[o] = (a.accumulate ? a.dbeta[o] : 0.0f) + dv;
+            if (a.dgamma) a.dgamma[o] = (a.accumulate ? a.dgamma[o] : 0.0f) + dv * a.xhat[o];
+            const float d = dv * a.gis[o];  // 0 under batch statistics
+            dg[o] = d;
+            if (a.db) a.db[o] = (a.accumulate ? a.db[o] : 0.0f) + d;
+        }
     }
     __syncthreads();
     if (a.dW)
-        for (int i = threadIdx.x; i < a.OC * a.IC; i += 256) {
+        for (int i = threadIdx.x; i < a.OC * a.IC; i += kGaveThreads) {
             const int o = i / a.IC, l = i - o * a.IC;
             a.dW[i] = (a.accumulate ? a.dW[i] : 0.0f) + dg[o] * a.pooled[(l / a.group) * a.slot + l % a.group];
         }
-    for (int ch = threadIdx.x; ch < 4 * a.c4_in; ch += 256) {
+    if (a.training) return;  // nothing flows back to x under batch statistics (dg == 0)
+    for (int ch = threadIdx.x; ch < 4 * a.c4_in; ch += kGaveThreads) {
         const int s = ch / a.slot, in = ch - s * a.slot, l = s * a.group + in;
         float d = 0.0f;
         if (in < a.group && l < a.IC)
@@ -217,6 +229,119 @@ __global__ __launch_bounds__(256) void train_bcast_planes_kernel(const float *ve
     const f32x4 v = *reinterpret_cast<const f32x4 *>(vec + 4 * blockIdx.y);
     f32x4 *d = pl + (size_t)blockIdx.y * npix + p;
     *d = add ? *d + v : v;
+}
+
+// ---- the frame step's glue around the net (modules/pipeline.py:104-135, utils/loss.py:65-103) -------------------------
+// fused[r][k] = (max(w, 0) v + clamp(est, +-init)) / (max(w, 0) + 1) at pixel valid[r], sample k: the "weighted update"
+// of pipeline.py:107-116 followed by the masking of :121-127, from the plane layout [P][n] into the API's rows [Nv][P].
+struct FuseOutArgs {
+    const float *est, *fv, *fw;  // [P][n]
+    const long long *valid;      // [Nv] pixel indices
+    float *rows;                 // forward: fused [Nv][P]; backward: d fused [Nv][P] (read)
+    float *d_est;                // backward: [P][n], zeroed by the caller
+    int n, P;
+    long long n_valid;
+    float init;
+};
+
+__global__ __launch_bounds__(256) void train_fuse_output_kernel(const FuseOutArgs a)
+{
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_valid) return;
+    const long long p = a.valid[r];
+    for (int k = 0; k < a.P; ++k) {
+        const size_t i = (size_t)k * a.n + p;
+        float w = a.fw[i];
+        w = w < 0.0f ? 0.0f : w;                                        // pipeline.py:113-114
+        float e = a.est[i];
+        e = e < -a.init ? -a.init : (e > a.init ? a.init : e);           // :109-111 (NaN passes through like torch.clamp)
+        a.rows[(size_t)r * a.P + k] = (w * a.fv[i] + e) / (w + 1.0f);   // :116
+    }
+}
+
+__global__ __launch_bounds__(256) void train_fuse_output_bwd_kernel(const FuseOutArgs a)
+{
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_valid) return;
+    const long long p = a.valid[r];
+    for (int k = 0; k < a.P; ++k) {
+        const size_t i = (size_t)k * a.n + p;
+        float w = a.fw[i];
+        w = w < 0.0f ? 0.0f : w;
+        const float e = a.est[i];
+        const bool pass = !(e < -a.init) && !(e > a.init);  // torch.clamp: the gradient passes inside the closed interval
+        a.d_est[i] = pass ? a.rows[(size_t)r * a.P + k] / (w + 1.0f) : 0.0f;
+    }
+}
+
+// FusionLoss (utils/loss.py:65-103): w1 mean|e - t| + w2 mean (e - t)^2 + w3 mean_j (1 - cos_j), where the cosine runs
+// over the reference's RESHAPED sign tensors: column j of the [P, Nv] reinterpretation of the flat [Nv, P] array, i.e. the
+// flat elements i Nv + j, i < P.  Thread j owns exactly those elements, so it also carries their share of the first two
+// sums; per-block fp64 partial sums in a fixed tree, added in block order by the finishing block: bit-reproducible.
+constexpr int kLossThreads = 256;
+struct LossArgs {
+    const float *est, *tgt;   // flat [Nv * P]
+    long long nv;
+    int P;
+    float w1, w2, w3;
+    double *partial;          // [blocks][4]
+    float *loss;
+    const float *grad_out;    // backward: d loss (device scalar)
+    float *d_est;             // backward: [Nv * P]
+    int blocks;
+};
+
+__device__ __forceinline__ float loss_sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+
+__global__ __launch_bounds__(kLossThreads) void train_loss_partial_kernel(const LossArgs a)
+{
+    __shared__ double red[kLossThreads / 64][3];
+    const long long j = (long long)blockIdx.x * kLossThreads + threadIdx.x;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (j < a.nv) {
+        float dot = 0.0f, n1 = 0.0f, n2 = 0.0f;
+        for (int i = 0; i < a.P; ++i) {
+            const size_t f = (size_t)i * a.nv + j;
+            const float e = a.est[f], t = a.tgt[f], d = e - t;
+            s1 += (double)fabsf(d);
+            s2 += (double)(d * d);
+            const float se = loss_sign(e), st = loss_sign(t);
+            dot += se * st; n1 += se * se; n2 += st * st;
+        }
+        s3 = (double)(1.0f - dot / sqrtf((n1 + 1e-12f) * (n2 + 1e-12f)));
+    }
+    double v[3] = {s1, s2, s3};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        double x = v[q];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) a.partial[(size_t)blockIdx.x * 4 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(64) void train_loss_finish_kernel(const LossArgs a)
+{
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < a.blocks; b += 64)  // lane l adds blocks l, l + 64, ... in order
+        for (int q = 0; q < 3; ++q) s[q] += a.partial[(size_t)b * 4 + q];
+    for (int q = 0; q < 3; ++q)
+        for (int off = 32; off > 0; off >>= 1) s[q] += __shfl_xor(s[q], off, 64);
+    if (threadIdx.x == 0) {
+        const double n = (double)a.nv * (double)a.P;
+        *a.loss = (float)((double)a.w1 * s[0] / n + (double)a.w2 * s[1] / n + (double)a.w3 * s[2] / (double)a.nv);
+    }
+}
+
+__global__ __launch_bounds__(256) void train_loss_bwd_kernel(const LossArgs a)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = a.nv * a.P;
+    if (i >= total) return;
+    const float g = *a.grad_out / (float)total;
+    const float d = a.est[i] - a.tgt[i];
+    a.d_est[i] = g * (a.w1 * loss_sign(d) + 2.0f * a.w2 * d);  // the sign-cosine term is piecewise constant
 }
 
 // ---- plan ----------------------------------------------------------------------------------------------------------
@@ -271,6 +396,12 @@ struct ojf_trainer {
     unsigned long long epoch = ~0ull;
     bool have_forward = false;
     int launches = 0;
+    // weight gradients run on a second stream beside the dy -> dx chain (nothing of the pass depends on them)
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> fork_ev;
+    hipEvent_t join_ev = nullptr;
+    size_t next_fork = 0;
+    bool use_side = true;
 };
 
 namespace ojf {
@@ -396,6 +527,20 @@ struct TCtx {
     const ojf_train_layer *L;
     hipStream_t st;
 };
+
+// stream of the weight-gradient launches of one unit group: the side stream (after a fork from the main stream, whose
+// dy is what they read) or the main stream itself
+static int t_wgrad_stream(TCtx &c, hipStream_t *ws)
+{
+    ojf_trainer *t = c.t;
+    *ws = c.st;
+    if (!t->use_side || !t->side) return 0;
+    hipEvent_t e = t->fork_ev[t->next_fork++ % t->fork_ev.size()];
+    OJF_HIP(hipEventRecord(e, c.st));
+    OJF_HIP(hipStreamWaitEvent(t->side, e, 0));
+    *ws = t->side;
+    return 0;
+}
 
 static inline dim3 px_grid(int npix, int gy) { return dim3((unsigned)((npix + 255) / 256), (unsigned)gy); }
 
@@ -574,9 +719,11 @@ static int t_units_backward(TCtx &c, const int *ids, int n, bool tail = true)
             if (!l.grad_weight) return fail("ojf_trainer_backward: layer without a weight-gradient tensor");
         }
         wg.tiles = tiles;
-        hipLaunchKernelGGL(train_wgrad_mfma_kernel, dim3(u0.wplan.slabs, tiles * n, taps), dim3(64), 0, c.st, wg,
+        hipStream_t ws;
+        if (t_wgrad_stream(c, &ws)) return -2;
+        hipLaunchKernelGGL(train_wgrad_mfma_kernel, dim3(u0.wplan.slabs, tiles * n, taps), dim3(64), 0, ws, wg,
                            div_magic(t->w, (uint64_t)t->npix + 2 * kWgChunk));
-        hipLaunchKernelGGL(train_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256), n), dim3(256), 0, c.st, rg);
+        hipLaunchKernelGGL(train_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256), n), dim3(256), 0, ws, rg);
         t->launches += 2;
         OJF_HIP(hipGetLastError());
     }
@@ -607,8 +754,8 @@ static int t_vortex_forward(TCtx &c, TVortex &v)
     g.training = lg.bn_training ? 1 : 0; g.accumulate = 0; g.momentum = lg.momentum; g.eps = lg.eps;
     g.W = lg.weight; g.b = lg.bias; g.gamma = lg.gamma; g.beta = lg.beta; g.running_mean = lg.running_mean; g.running_var = lg.running_var;
     g.pooled = v.pooled; g.xhat = v.xhat; g.gis = v.gis; g.vec = v.vec;
-    if (v.out_c > 1024) return fail("ojf_trainer: VortexPooling wider than 1024 channels");
-    hipLaunchKernelGGL(train_gave_fwd_kernel, dim3(1), dim3(256), 0, c.st, g);
+    if (v.out_c > kGaveMaxC || 4 * v.c4x > kGaveMaxC) return fail("ojf_trainer: VortexPooling wider than 1024 channels");
+    hipLaunchKernelGGL(train_gave_fwd_kernel, dim3(1), dim3(kGaveThreads), 0, c.st, g);
     hipLaunchKernelGGL(train_bcast_planes_kernel, px_grid(t->npix, v.o4), dim3(256), 0, c.st, v.vec, planes(v.cat), t->npix, 0);
     t->launches += 3;
     // the four branch entries: ONE stacked 1x1 convolution of the unpooled input, then the pools (+ bias) on the narrow result
@@ -637,13 +784,15 @@ static int t_vortex_backward(TCtx &c, TVortex &v)
     pa.in = planes(v.dycat); pa.out = planes(v.du); pa.h = t->h; pa.w = t->w; pa.sl4 = v.sl4; pa.OC = v.mid;
     for (int r = 0; r < 4; ++r) pa.bias[r] = nullptr;
     const int tiles = ((t->w + kTpW - 1) / kTpW) * ((t->h + kTpH - 1) / kTpH);
-    hipLaunchKernelGGL(train_pyramid_kernel, dim3(tiles, 4 * v.sl4), dim3(256), 0, c.st, pa);
     {
         WgradArgs a;
         a.x = planes(v.x); a.dy = planes(v.du); a.partial = v.wpart_stack; a.x_g0 = 0; a.c4_in = v.c4x; a.dy_g0 = 0; a.c4_out = 4 * v.sl4;
         a.h = t->h; a.w = t->w; a.npix = t->npix; a.taps = 1; a.dil = 1; a.slabs = v.wplan_s.slabs; a.ocp = v.wplan_s.ocp; a.icp = v.wplan_s.icp;
         const int wt = (a.ocp / 32) * (a.icp / 32);
-        hipLaunchKernelGGL(train_wgrad_mfma_kernel, dim3(a.slabs, wt, 1), dim3(64), 0, c.st, WgradGroup{{a, a, a, a}, wt},
+        hipStream_t ws;
+        hipLaunchKernelGGL(train_pyramid_kernel, dim3(tiles, 4 * v.sl4), dim3(256), 0, c.st, pa);
+        if (t_wgrad_stream(c, &ws)) return -2;
+        hipLaunchKernelGGL(train_wgrad_mfma_kernel, dim3(a.slabs, wt, 1), dim3(64), 0, ws, WgradGroup{{a, a, a, a}, wt},
                            div_magic(t->w, (uint64_t)t->npix + 2 * kWgChunk));
         WgradReduceGroup rg;
         long total = 0;
@@ -658,7 +807,7 @@ static int t_vortex_backward(TCtx &c, TVortex &v)
             rg.g[r] = ra;
             total = (long)u.OC * 4 * v.c4x * 8;
         }
-        hipLaunchKernelGGL(train_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256), 4), dim3(256), 0, c.st, rg);
+        hipLaunchKernelGGL(train_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256), 4), dim3(256), 0, ws, rg);
     }
     t->launches += 3;
     OJF_HIP(hipGetLastError());
@@ -677,7 +826,7 @@ static int t_vortex_backward(TCtx &c, TVortex &v)
     g.W = lg.weight; g.b = lg.bias; g.gamma = lg.gamma; g.beta = lg.beta;
     g.pooled = v.pooled; g.xhat = v.xhat; g.gis = v.gis;
     g.dW = lg.grad_weight; g.db = lg.bias ? lg.grad_bias : nullptr; g.dgamma = lg.grad_gamma; g.dbeta = lg.grad_beta; g.dpooled = v.dpooled;
-    hipLaunchKernelGGL(train_gave_bwd_kernel, dim3(1), dim3(256), 0, c.st, g);
+    hipLaunchKernelGGL(train_gave_bwd_kernel, dim3(1), dim3(kGaveThreads), 0, c.st, g);
     t->launches += 2;
     if (!lg.bn_training && v.dx) {  // running statistics: the branch is an affine map of mean(x) - a per-channel constant flows back to every pixel
         hipLaunchKernelGGL(train_bcast_planes_kernel, px_grid(t->npix, v.c4x), dim3(256), 0, c.st, v.dpooled, planes(v.dx), t->npix, 1);
@@ -693,6 +842,9 @@ OJF_API void ojf_trainer_destroy(ojf_trainer *t)
 {
     if (!t) return;
     for (void *p : t->allocs) (void)hipFree(p);
+    for (hipEvent_t e : t->fork_ev) (void)hipEventDestroy(e);
+    if (t->join_ev) (void)hipEventDestroy(t->join_ev);
+    if (t->side) (void)hipStreamDestroy(t->side);
     delete t;
 }
 
@@ -765,6 +917,19 @@ OJF_API int ojf_trainer_create(ojf_trainer **out, int version, int n_points, int
         return 0;
     };
     rc = build();
+    if (!rc) {
+        static const bool no_side = getenv("OJF_TRAIN_SIDE") && atoi(getenv("OJF_TRAIN_SIDE")) == 0;  // A/B switch
+        t->use_side = !no_side;
+        if (t->use_side) {
+            rc = check_hip(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking), "trainer side stream");
+            for (int i = 0; i < 48 && !rc; ++i) {
+                hipEvent_t e = nullptr;
+                rc = check_hip(hipEventCreateWithFlags(&e, event_flags()), "trainer fork event");
+                if (!rc) t->fork_ev.push_back(e);
+            }
+            if (!rc) rc = check_hip(hipEventCreateWithFlags(&t->join_ev, event_flags()), "trainer join event");
+        }
+    }
     if (rc) { ojf_trainer_destroy(t); return rc; }
     *out = t;
     return 0;
@@ -846,5 +1011,63 @@ OJF_API int ojf_trainer_backward(ojf_trainer *t, const ojf_train_layer *layers, 
         }
     }
     t->have_forward = false;
+    if (t->use_side && t->side) {  // the gradient tensors are complete for whatever the caller enqueues next
+        OJF_HIP(hipEventRecord(t->join_ev, t->side));
+        OJF_HIP(hipStreamWaitEvent(c.st, t->join_ev, 0));
+    }
     return check_hip(hipGetLastError(), "ojf_trainer_backward");
+}
+
+OJF_API int ojf_train_fuse_output(const float *est_pn, const float *fv_pn, const float *fw_pn, const long long *valid, int n, int n_points,
+                                  long long n_valid, float init_value, float *fused_rows, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (!est_pn || !fv_pn || !fw_pn || !fused_rows || (n_valid > 0 && !valid)) return fail("ojf_train_fuse_output: null pointer argument");
+    if (n < 1 || n_points < 1 || n_valid < 0 || n_valid > n) return fail("ojf_train_fuse_output: bad sizes");
+    if (n_valid == 0) return 0;
+    FuseOutArgs a{est_pn, fv_pn, fw_pn, valid, fused_rows, nullptr, n, n_points, n_valid, init_value};
+    hipLaunchKernelGGL(train_fuse_output_kernel, dim3((unsigned)((n_valid + 255) / 256)), dim3(256), 0, as_stream(stream), a);
+    return check_hip(hipGetLastError(), "train_fuse_output_kernel launch");
+}
+
+OJF_API int ojf_train_fuse_output_bwd(const float *d_fused_rows, const float *est_pn, const float *fw_pn, const long long *valid, int n,
+                                      int n_points, long long n_valid, float init_value, float *d_est_pn, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (!d_fused_rows || !est_pn || !fw_pn || !d_est_pn || (n_valid > 0 && !valid)) return fail("ojf_train_fuse_output_bwd: null pointer argument");
+    if (n < 1 || n_points < 1 || n_valid < 0 || n_valid > n) return fail("ojf_train_fuse_output_bwd: bad sizes");
+    OJF_HIP(hipMemsetAsync(d_est_pn, 0, (size_t)n * n_points * sizeof(float), as_stream(stream)));
+    if (n_valid == 0) return 0;
+    FuseOutArgs a{est_pn, nullptr, fw_pn, valid, const_cast<float *>(d_fused_rows), d_est_pn, n, n_points, n_valid, init_value};
+    hipLaunchKernelGGL(train_fuse_output_bwd_kernel, dim3((unsigned)((n_valid + 255) / 256)), dim3(256), 0, as_stream(stream), a);
+    return check_hip(hipGetLastError(), "train_fuse_output_bwd_kernel launch");
+}
+
+OJF_API size_t ojf_train_loss_partial_doubles(long long n_valid) { return n_valid > 0 ? (size_t)((n_valid + ojf::kLossThreads - 1) / ojf::kLossThreads) * 4 : 4; }
+
+OJF_API int ojf_train_fusion_loss(const float *est_rows, const float *target_rows, long long n_valid, int n_points, float w_l1, float w_l2,
+                                  float w_cos, double *partial, float *loss_out, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (!est_rows || !target_rows || !partial || !loss_out) return fail("ojf_train_fusion_loss: null pointer argument");
+    if (n_valid < 1 || n_points < 1) return fail("ojf_train_fusion_loss: empty batch (utils/loss.py:81-82 returns the constant 1: handle it on the host)");
+    LossArgs a{};
+    a.est = est_rows; a.tgt = target_rows; a.nv = n_valid; a.P = n_points; a.w1 = w_l1; a.w2 = w_l2; a.w3 = w_cos; a.partial = partial; a.loss = loss_out;
+    a.blocks = (int)((n_valid + kLossThreads - 1) / kLossThreads);
+    hipLaunchKernelGGL(train_loss_partial_kernel, dim3(a.blocks), dim3(kLossThreads), 0, as_stream(stream), a);
+    hipLaunchKernelGGL(train_loss_finish_kernel, dim3(1), dim3(64), 0, as_stream(stream), a);
+    return check_hip(hipGetLastError(), "train_loss kernels launch");
+}
+
+OJF_API int ojf_train_fusion_loss_bwd(const float *est_rows, const float *target_rows, long long n_valid, int n_points, float w_l1, float w_l2,
+                                      const float *grad_out, float *d_est_rows, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (!est_rows || !target_rows || !grad_out || !d_est_rows) return fail("ojf_train_fusion_loss_bwd: null pointer argument");
+    if (n_valid < 1 || n_points < 1) return fail("ojf_train_fusion_loss_bwd: empty batch");
+    LossArgs a{};
+    a.est = est_rows; a.tgt = target_rows; a.nv = n_valid; a.P = n_points; a.w1 = w_l1; a.w2 = w_l2; a.grad_out = grad_out; a.d_est = d_est_rows;
+    const long long total = n_valid * n_points;
+    hipLaunchKernelGGL(train_loss_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), a);
+    return check_hip(hipGetLastError(), "train_loss_bwd_kernel launch");
 }

@@ -323,6 +323,32 @@ class Pipeline(torch.nn.Module):
             return tn(inputs)
         return self._fusion_network.forward(inputs)
 
+    def _async_count(self, mask_flat):
+        """Number of set elements of a device bool vector, on its way to the host: (pinned int32 buffer, event)."""
+        if not mask_flat.is_cuda:
+            return int(mask_flat.sum())
+        slots = self.__dict__.setdefault('_count_slots', [])
+        at = self.__dict__.get('_count_at', 0)
+        if len(slots) < 4:  # a small ring: a slot is reused three frames later, long after its value was read
+            slots.append((torch.empty(1, dtype=torch.int32).pin_memory(), torch.cuda.Event()))
+        buf, ev = slots[at % len(slots)]
+        self.__dict__['_count_at'] = at + 1
+        buf.copy_(mask_flat.sum(dtype=torch.int32).reshape(1), non_blocking=True)
+        ev.record(torch.cuda.current_stream(mask_flat.device))
+        return buf, ev
+
+    def _valid_index(self, mask_flat, count):
+        """``mask.nonzero()[:, 0]`` without draining the stream: the size comes from _async_count."""
+        if isinstance(count, int):
+            return mask_flat.nonzero()[:, 0]
+        buf, ev = count
+        ev.synchronize()
+        nv = int(buf[0])
+        try:
+            return torch.nonzero_static(mask_flat, size=nv)[:, 0]
+        except (RuntimeError, NotImplementedError):  # builds without the device kernel: the blocking form
+            return mask_flat.nonzero()[:, 0]
+
     # ---- training frame step (pipeline.py:251-363) -----------------------------------------------
     def fuse_training(self, batch, database, device):
         self.device = torch.device(device)
@@ -337,28 +363,34 @@ class Pipeline(torch.nn.Module):
         tsdf, weights = volume['current'], volume['weights']
         Ki, E = ops.camera_arrays(batch['intrinsics'][0], batch['extrinsics'][0])
 
-        cur = ops.extract(frame, Ki, E, volume['origin'], volume['resolution'], tsdf, weights, n_points=P)
-        gt = ops.extract(frame, Ki, E, volume['origin'], volume['resolution'], volume['gt'], weights, n_points=P)
+        # The shapes [1, Nv, P] of the masked outputs (pipeline.py:125-131) need the number of valid rays on the host: the one
+        # device -> host read of the frame step.  The count is REQUESTED here (one reduction + an asynchronous copy into
+        # pinned memory, behind an event) and awaited only after extract and the net's forward pass have been enqueued: by
+        # then the copy is long done, the host never drains the queue, and it runs ahead of the device through loss and
+        # backward.  (Read with a blocking ``nonzero`` after the net forward - the reference's order - the queue drained in
+        # the middle of every frame and the device idled while Python enqueued the loss: 2.7 of 10.4 ms per 320x240 frame.)
+        valid_mask = filtered.reshape(n) != 0
+        count = self._async_count(valid_mask)
 
-        def nchw(t):
-            return t.view(1, h, w, -1).permute(0, 3, 1, 2).contiguous()
-        inputs = {'tsdf_values': nchw(cur['fusion_values']), 'tsdf_weights': nchw(cur['fusion_weights']),
-                  'tsdf_frame': frame.view(1, 1, h, w)}
+        # sample planes [P, n] are NCHW [1, P, h, w] as they stand: no permute / contiguous copies in front of the net
+        cur = ops.extract(frame, Ki, E, volume['origin'], volume['resolution'], tsdf, weights, n_points=P, planes=True)
+        gt = ops.extract(frame, Ki, E, volume['origin'], volume['resolution'], volume['gt'], weights, n_points=P)
+        fv, fw = cur['fusion_values'], cur['fusion_weights']
+        inputs = {'tsdf_values': fv.view(1, P, h, w), 'tsdf_weights': fw.view(1, P, h, w), 'tsdf_frame': frame.view(1, 1, h, w)}
         if self.config.FUSION_MODEL.use_semantics:
             inputs['semantic_frame'] = ((1 + sem_ids.float()) / self.n_classes).view(1, 1, h, w)
-        tsdf_est = self._training_forward(inputs)  # differentiable; BN / dropout follow the module's train() / eval() mode
-        tsdf_est = tsdf_est.permute(0, 2, 3, 1)[..., :P].reshape(1, n, P)
+        est_pn = self._training_forward(inputs)[:, :P].reshape(1, P, n)  # differentiable; BN / dropout follow the modules' modes
+        valid = self._valid_index(valid_mask, count)
 
-        # pipeline.py:104-135
+        # pipeline.py:104-135 in the plane layout, one launch each way; the [1, n, P] tensor of the API is a transposed view
         init = self.config.DATA.init_value
-        fw = torch.clamp_min(cur['fusion_weights'].view(1, n, P), 0)
-        tsdf_fused = (fw * cur['fusion_values'].view(1, n, P) + torch.clamp(tsdf_est, -init, init)) / (fw + 1)
-        valid = (filtered.reshape(n) != 0).nonzero()[:, 0]
-        output = {'tsdf_est': tsdf_est, 'tsdf_fused': tsdf_fused[:, valid, :],
+        from .train import FuseOutput
+        tsdf_fused = FuseOutput.apply(est_pn, fv.view(1, P, n), fw.view(1, P, n), valid, init)
+        output = {'tsdf_est': est_pn.transpose(1, 2), 'tsdf_fused': tsdf_fused,
                   'tsdf_target': gt['fusion_values'].view(1, n, P)[:, valid, :]}
 
         ws = self._get_workspace(tsdf.shape, h, w, self.device)
-        est_rows = tsdf_est.detach().reshape(n, P).contiguous()
+        est_rows = est_pn.detach()[0].t().contiguous()
         ops.integrate(filtered, Ki, E, volume['origin'], volume['resolution'], est_rows, tsdf, weights, ws,
                       n_points=P, n_tail=self.config.FUSION_MODEL.n_tail_points, trunc=init,
                       mode=self._integrate_mode)  # test=False: no semantic update (pipeline.py:357)

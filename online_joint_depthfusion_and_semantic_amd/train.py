@@ -242,10 +242,17 @@ class HipTrainNet:
     """Runs ``net`` (model.FusionNet_v3 / FusionNet_v2) through ``LayerUnit`` nodes.  ``net.training`` selects batch
     statistics + dropout (train) or running statistics, no dropout (eval), exactly like the module's own forward."""
 
-    def __init__(self, net, graph=False, inplace_grads=False):
+    def __init__(self, net, graph=False, inplace_grads=False, executor=True):
         _lib.require_gpu()
         self.net = net
         self.inplace_grads = bool(inplace_grads)  # see _grad_target
+        # executor: the whole forward / backward pass as two libojf calls (ojf_trainer_*, csrc/ojf_train_net.h: C++ layer
+        # walk, grouped VortexPooling branches) behind ONE autograd node; False = one autograd node per layer unit (the
+        # round-2 path, kept for A/B runs and for graph=True)
+        self.executor = bool(executor)
+        self._trainers = {}
+        self._table = None
+        self._gen = 0
         self._cache = {}      # packed weights by (address, layout) -> (version, tensors)
         self._counters = []   # num_batches_tracked of the BatchNorms that saw batch statistics in this forward
         self._rand = None     # one uniform draw per forward for all Dropout2d masks
@@ -364,7 +371,122 @@ class HipTrainNet:
             out = self._graphed(x)
             if out is not None:
                 return out
+        if self.executor and not self.graph:
+            return self._forward_executor(x)
         return self._forward_impl(x)
+
+    # ---- whole-net executor ---------------------------------------------------------------------------------------------
+    def _layer_modules(self):
+        """(conv, bn | None, dropout | None) per layer in ojf_net_create's order (model.fold_layers)."""
+        from .model import FusionNet_v3
+
+        def seq(mods):
+            mods = list(mods)
+            out = []
+            for i, m in enumerate(mods):
+                if isinstance(m, nn.Conv2d):
+                    bn = drop = None
+                    for nxt in mods[i + 1:]:
+                        if isinstance(nxt, nn.Conv2d):
+                            break
+                        if isinstance(nxt, nn.BatchNorm2d):
+                            bn = nxt
+                        if isinstance(nxt, nn.Dropout2d):
+                            drop = nxt
+                    out.append((m, bn, drop))
+            return out
+
+        def vortex(v):
+            out = [(v.gave_pool[1], v.gave_pool[3], None)]
+            for br in v.branches:
+                out += seq(br)
+            return out + seq(v.final)
+        net = self.net
+        layers = []
+        if isinstance(net, FusionNet_v3):
+            for blk in net.block0:
+                layers += seq(blk.block)
+            layers += vortex(net.vortex0)
+            if net.config.use_semantics:
+                for blk in net.block2:
+                    layers += seq(blk.block)
+                layers += vortex(net.vortex2)
+            layers += vortex(net.vortex3)
+        else:
+            for blk in net.block:
+                layers += seq(blk.block)
+            layers += vortex(net.vortex) + vortex(net.vortex_final)
+        for p in net.pred:
+            layers += seq(p.pred)
+        return layers
+
+    def _trainer(self, h, w, dev):
+        from .model import FusionNet_v3
+        key = (h, w, str(dev))
+        tr = self._trainers.get(key)
+        if tr is None:
+            lib = _lib.load()
+            net = self.net
+            handle = _lib._vp()
+            with torch.cuda.device(dev):
+                _lib.check(lib.ojf_trainer_create(_lib._c.byref(handle), 3 if isinstance(net, FusionNet_v3) else 2, net.n_points, net.gf,
+                                                  int(bool(net.config.use_semantics)), float(net.scale), h, w), 'ojf_trainer_create')
+            tr = self._trainers[key] = _TrainerHandle(handle)
+        return tr
+
+    def _forward_executor(self, x):
+        net = self.net
+        lib = _lib.load()
+        v = x['tsdf_values']
+        dev = v.device
+        _, P, h, w = v.shape
+        tr = self._trainer(h, w, dev)
+        mods = self.__dict__.get('_mods')
+        if mods is None:
+            mods = self._mods = self._layer_modules()
+            self._params = [p for p in net.parameters()]
+            self._pindex = {id(p): i for i, p in enumerate(self._params)}
+            assert lib.ojf_trainer_layer_count(tr.handle) == len(mods)
+        table = (_lib.TrainLayer * len(mods))()
+        counters = []
+        # Dropout2d: one uniform draw for every active layer of this pass, per-channel factors 0 or 1 / keep
+        drops = [(i, d) for i, (c, b, d) in enumerate(mods) if d is not None and d.training and d.p > 0]
+        scales = {}
+        if drops:
+            keep = self.__dict__.get('_keep')
+            sig = tuple((i, d.p, mods[i][0].out_channels) for i, d in drops)
+            if keep is None or keep[0] != sig or keep[1].device != dev:
+                keep = self._keep = (sig, torch.cat([torch.full((mods[i][0].out_channels,), 1.0 - d.p) for i, d in drops]).to(dev))
+            factors = (torch.rand(keep[1].shape, device=dev) < keep[1]).float() / keep[1]
+            off = 0
+            for i, d in drops:
+                n = mods[i][0].out_channels
+                scales[i] = factors[off:off + n]
+                off += n
+        epoch = 0
+        for i, (conv, bn, drop) in enumerate(mods):
+            e = table[i]
+            e.weight, e.bias = conv.weight.data_ptr(), _p(conv.bias)
+            epoch += conv.weight._version + conv.weight.data_ptr() + (conv.bias._version + conv.bias.data_ptr() if conv.bias is not None else 0)
+            e.out_channels, e.in_channels, e.ksize, e.dilation = conv.out_channels, conv.in_channels, conv.kernel_size[0], conv.dilation[0]
+            if bn is not None:
+                if bn.momentum is None:
+                    raise _lib.OjfError('HipTrainNet: BatchNorm2d(momentum=None) is not supported (use train_engine: torch)')
+                e.gamma, e.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
+                e.running_mean, e.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                e.bn_training, e.momentum, e.eps = int(bn.training), float(bn.momentum), float(bn.eps)
+                if bn.training:
+                    counters.append(bn.num_batches_tracked)
+            if i in scales:
+                e.drop_scale = scales[i].data_ptr()
+        ins = [x['tsdf_values'], x['tsdf_weights'], x['tsdf_frame']] + ([x['semantic_frame']] if net.config.use_semantics else [])
+        ins = [t.contiguous().float() for t in ins]
+        self._gen += 1
+        state = dict(table=table, tr=tr, gen=self._gen, keep_alive=(scales, ins), epoch=epoch & 0xffffffffffffffff, dev=dev, shape=(1, P, h, w))
+        est = _NetFn.apply(self, state, *(ins + self._params))
+        if counters:
+            torch._foreach_add_(counters, 1)  # nn.BatchNorm2d.num_batches_tracked, all at once
+        return est
 
     def _graphed(self, x):
         net = self.net
@@ -410,6 +532,108 @@ class HipTrainNet:
         return from_c4(y, net.n_points)
 
     __call__ = forward
+
+
+class FuseOutput(torch.autograd.Function):
+    """modules/pipeline.py:104-127 as one launch each way (ojf_train_fuse_output): the weighted update
+    (max(w, 0) v + clamp(est, +-init)) / (max(w, 0) + 1) on sample planes [1, P, n], gathered at the valid pixels into the
+    API's rows [1, Nv, P].  Gradient flows to ``est`` only (values / weights come out of the volumes)."""
+
+    @staticmethod
+    def forward(ctx, est_pn, fv_pn, fw_pn, valid, init):
+        lib = _lib.load()
+        est_pn, fv_pn, fw_pn, valid = est_pn.contiguous(), fv_pn.contiguous(), fw_pn.contiguous(), valid.contiguous()
+        _, P, n = est_pn.shape
+        nv = valid.numel()
+        rows = torch.empty((1, nv, P), dtype=torch.float32, device=est_pn.device)
+        _lib.check(lib.ojf_train_fuse_output(est_pn.data_ptr(), fv_pn.data_ptr(), fw_pn.data_ptr(), valid.data_ptr(), n, P, nv, float(init),
+                                             rows.data_ptr(), _lib.stream_ptr(est_pn.device)), 'ojf_train_fuse_output')
+        ctx.save_for_backward(est_pn, fw_pn, valid)
+        ctx.init = float(init)
+        return rows
+
+    @staticmethod
+    def backward(ctx, d_rows):
+        lib = _lib.load()
+        est_pn, fw_pn, valid = ctx.saved_tensors
+        _, P, n = est_pn.shape
+        d_rows = d_rows.contiguous()
+        d_est = torch.empty_like(est_pn)
+        _lib.check(lib.ojf_train_fuse_output_bwd(d_rows.data_ptr(), est_pn.data_ptr(), fw_pn.data_ptr(), valid.data_ptr(), n, P, valid.numel(),
+                                                 ctx.init, d_est.data_ptr(), _lib.stream_ptr(est_pn.device)), 'ojf_train_fuse_output_bwd')
+        return d_est, None, None, None, None
+
+
+class _TrainerHandle:
+    def __init__(self, handle):
+        self.handle = handle
+        self.gen = 0  # generation of the forward pass whose activations the trainer holds
+
+    def __del__(self):
+        try:
+            _lib.load().ojf_trainer_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class _NetFn(torch.autograd.Function):
+    """The whole net as ONE autograd node on ojf_trainer_forward / ojf_trainer_backward.  The trainer keeps the
+    activations of the LAST forward pass only: backward of an older pass raises instead of differentiating the wrong one."""
+
+    @staticmethod
+    def forward(ctx, tn, state, *tensors):
+        lib = _lib.load()
+        n_in = 4 if tn.net.config.use_semantics else 3
+        ins = tensors[:n_in]
+        est = torch.empty(state['shape'], dtype=torch.float32, device=state['dev'])
+        tr = state['tr']
+        _lib.check(lib.ojf_trainer_forward(tr.handle, state['table'], len(state['table']), state['epoch'], ins[0].data_ptr(), ins[1].data_ptr(),
+                                           ins[2].data_ptr(), ins[3].data_ptr() if n_in == 4 else None, est.data_ptr(),
+                                           _lib.stream_ptr(state['dev'])), 'ojf_trainer_forward')
+        tr.gen = state['gen']
+        ctx.tn, ctx.state, ctx.n_in = tn, state, n_in
+        return est
+
+    @staticmethod
+    def backward(ctx, dest):
+        lib = _lib.load()
+        tn, state = ctx.tn, ctx.state
+        tr, table = state['tr'], state['table']
+        if tr.gen != state['gen']:
+            raise _lib.OjfError('HipTrainNet: backward of a forward pass whose activations were overwritten by a later forward '
+                                '(the executor keeps one pass; call backward before the next forward, or use executor=False)')
+        needs = ctx.needs_input_grad[2 + ctx.n_in:]
+        inplace = tn.inplace_grads and not torch.cuda.is_current_stream_capturing()
+        out = [None] * len(tn._params)
+        for i, (conv, bn, drop) in enumerate(tn._mods):
+            e = table[i]
+            ps = [(conv.weight, 'grad_weight'), (conv.bias, 'grad_bias')] + ([(bn.weight, 'grad_gamma'), (bn.bias, 'grad_beta')] if bn is not None else [])
+            ps = [(p, f) for p, f in ps if p is not None]
+            if inplace and all(p.is_leaf and p.requires_grad for p, _ in ps):
+                fresh = [p.grad is None for p, _ in ps]
+                ok = all(p.grad is None or (p.grad.is_contiguous() and p.grad.dtype == torch.float32 and p.grad.device == p.device
+                                            and p.grad.shape == p.shape) for p, _ in ps)
+                if ok:
+                    for (p, f), new in zip(ps, fresh):
+                        if new:  # one accumulate flag per layer: in a mixed state the fresh tensors start from zero
+                            p.grad = torch.empty_like(p, memory_format=torch.contiguous_format) if all(fresh) else \
+                                torch.zeros_like(p, memory_format=torch.contiguous_format)
+                        setattr(e, f, p.grad.data_ptr())
+                    e.accumulate = 0 if all(fresh) else 1
+                    continue
+            e.accumulate = 0
+            for p, f in ps:  # the ordinary route: gradients are returned to autograd
+                g = torch.empty_like(p, memory_format=torch.contiguous_format)
+                setattr(e, f, g.data_ptr())
+                k = tn._pindex[id(p)]
+                if needs[k]:
+                    out[k] = g
+                else:
+                    state.setdefault('scratch', []).append(g)
+            state.setdefault('scratch', []).extend(o for o in out if o is not None)
+        _lib.check(lib.ojf_trainer_backward(tr.handle, table, len(table), dest.contiguous().data_ptr(), _lib.stream_ptr(state['dev'])),
+                   'ojf_trainer_backward')
+        return (None, None) + (None,) * ctx.n_in + tuple(out)
 
 
 class _GraphedPass:

@@ -115,7 +115,8 @@ def _net(version, sem, h, w, seed=3):
     return net
 
 
-def _whole_net_gradient_case(cuda, version, sem, training, graph, h, w):
+def _whole_net_gradient_case(cuda, version, sem, training, path, h, w):
+    graph = path == 'graph'
     net = _net(version, sem, h, w)
     ref, ref32 = copy.deepcopy(net).double(), copy.deepcopy(net)
     net = net.to(cuda)
@@ -132,7 +133,7 @@ def _whole_net_gradient_case(cuda, version, sem, training, graph, h, w):
     loss(est_ref, target.double()).backward()
     est32 = ref32(x)
     loss(est32, target).backward()
-    tn = HipTrainNet(net, graph=graph, inplace_grads=not graph)
+    tn = HipTrainNet(net, graph=graph, inplace_grads=not graph, executor=path == 'executor')
     est = tn({k: v.to(cuda) for k, v in x.items()})
     if graph:
         sig = next(iter(tn._graphs.values()))
@@ -162,21 +163,22 @@ def _whole_net_gradient_case(cuda, version, sem, training, graph, h, w):
             bar(b, c32, c, float(c.abs().max()), name)
         else:
             assert int(b) == int(c), name
-    print('whole net %s sem=%s training=%s graph=%s %dx%d: worst deviation = %.2f x torch fp32\'s own' % (version, sem, training, graph, h, w, worst))
+    print('whole net %s sem=%s training=%s path=%s %dx%d: worst deviation = %.2f x torch fp32\'s own' % (version, sem, training, path, h, w, worst))
 
 
-@pytest.mark.parametrize('graph', [True, False])
+@pytest.mark.parametrize('path', ['executor', 'units', 'graph'])
 @pytest.mark.parametrize('training', [True, False])
-@pytest.mark.parametrize('version,sem', [('v3', False), ('v3', True), ('v2', True)])
-def test_whole_net_gradients_against_torch_autograd(cuda, version, sem, training, graph):
+@pytest.mark.parametrize('version,sem', [('v3', False), ('v3', True), ('v2', True), ('v2', False)])
+def test_whole_net_gradients_against_torch_autograd(cuda, version, sem, training, path):
     """est, every parameter gradient and every BatchNorm buffer after one loss.backward() through the whole net.  Truth =
     the module's own forward in float64.  A 46-layer net with batch statistics amplifies rounding: torch's OWN fp32
     autograd (the module on the CPU) deviates from float64 by 1e-2 of a gradient's scale in train() mode and 2e-4 in
     eval() mode (the L1 term's sign flips), so the bar per tensor is: within 1e-4 of its scale, or no further from the
     float64 truth than 2.5x torch's fp32 deviation on that tensor, or than twice torch fp32's worst relative deviation over
     all gradients (the rounding-noise level of the net; GPU torch fp32 sits at 1x - 1.5x of it, tools/dbg_train.py).
-    ``graph=True`` runs the captured forward / backward device graphs (HipTrainNet(graph=True))."""
-    _whole_net_gradient_case(cuda, version, sem, training, graph, 40, 56)
+    Paths: 'executor' = the whole pass as two libojf calls (ojf_trainer_*, the default), 'units' = one autograd node per
+    layer unit, 'graph' = the unit path captured into device graphs (HipTrainNet(graph=True))."""
+    _whole_net_gradient_case(cuda, version, sem, training, path, 40, 56)
 
 
 @pytest.mark.parametrize('version,sem,training', [('v3', False, True), ('v3', True, False)])
@@ -184,7 +186,7 @@ def test_whole_net_gradients_at_baseline_frame_size(cuda, version, sem, training
     """The same comparison at BASELINE configs[3]'s frame size, 240x320 = 76 800 pixels: the weight-gradient kernel's
     pixel-slab split, the fp64 slab reductions of the BatchNorm statistics and the dilation-27 borders all depend on
     h * w.  Truth = float64 torch on the host cores (about 40 s per case)."""
-    _whole_net_gradient_case(cuda, version, sem, training, False, 240, 320)
+    _whole_net_gradient_case(cuda, version, sem, training, 'executor', 240, 320)
 
 
 def test_graph_warm_up_leaves_parameter_gradients_alone(cuda):
@@ -196,7 +198,7 @@ def test_graph_warm_up_leaves_parameter_gradients_alone(cuda):
     g = torch.Generator().manual_seed(5)
     frames = [dict(tsdf_values=((torch.rand(1, 9, h, w, generator=g) - 0.5) * 0.2).to(cuda), tsdf_weights=(torch.rand(1, 9, h, w, generator=g) * 4).to(cuda),
                    tsdf_frame=(torch.rand(1, 1, h, w, generator=g) * 4).to(cuda)) for _ in range(2)]
-    eager = HipTrainNet(net)
+    eager = HipTrainNet(net, executor=False)  # the same unit kernels, launched one by one
     for x in frames:
         eager(x).pow(2).mean().backward()
     want = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
@@ -261,11 +263,12 @@ def test_dropout_channels_in_train_mode(cuda):
         if isinstance(m, torch.nn.Dropout2d):
             m.p = 0.2
     x = dict(tsdf_values=torch.rand(1, 9, h, w, device=cuda) * 0.1, tsdf_weights=torch.rand(1, 9, h, w, device=cuda), tsdf_frame=torch.rand(1, 1, h, w, device=cuda))
-    tn = HipTrainNet(net.train())
     torch.manual_seed(1)
-    a = tn(x)
-    b = tn(x)
-    assert not torch.equal(a, b)  # fresh masks per call
+    for executor in (True, False):
+        tn = HipTrainNet(net.train(), executor=executor)
+        a = tn(x)
+        b = tn(x)
+        assert not torch.equal(a, b)  # fresh masks per call
     blk = net.block0[0].block
     zeros = 0
     for _ in range(50):
@@ -318,3 +321,42 @@ def test_frozen_batchnorm_keeps_running_statistics(cuda):
             m.momentum = 0.0  # keep the running statistics of the comparison net out of the picture
     # (a frozen layer on batch statistics would move est by ~0.1; fp32 train-mode nets differ among themselves by ~1e-4)
     assert torch.allclose(got, ref(x), atol=2e-3)
+
+
+def test_fuse_output_and_fusion_loss_kernels_match_the_tensor_formulas(cuda):
+    """ojf_train_fuse_output / ojf_train_fusion_loss (one launch each way) against the tensor-op statements of
+    modules/pipeline.py:104-127 and utils/loss.py:65-103 (the package's FusionLoss on CPU tensors runs those), values
+    and gradients: fused rows bit for bit (the same three roundings), loss within 1e-6 relative (fp64 partial sums vs
+    torch's fp32 reductions), gradients within 1e-6 of their scale."""
+    from online_joint_depthfusion_and_semantic_amd.loss import FusionLoss
+    from online_joint_depthfusion_and_semantic_amd.train import FuseOutput
+    g = torch.Generator().manual_seed(3)
+    P, n, init = 9, 56 * 40, 0.1
+    est = ((torch.rand(1, P, n, generator=g) - 0.5) * 0.4).requires_grad_(True)   # beyond +-init on both sides
+    fv = (torch.rand(1, P, n, generator=g) - 0.5) * 0.2
+    fw = torch.rand(1, P, n, generator=g) * 3 - 0.3                                # some negative weights
+    valid = torch.nonzero(torch.rand(n, generator=g) > 0.2)[:, 0]
+    target = (torch.rand(1, valid.numel(), P, generator=g) - 0.5) * 0.2
+    target[0, :5] = 0.0  # sign(0) rows
+    crit = FusionLoss(w_l1=1.0, w_l2=10.0, w_cos=0.1)
+    # tensor-op reference on the CPU
+    fwc = torch.clamp_min(fw, 0)
+    fused_ref = ((fwc * fv + torch.clamp(est, -init, init)) / (fwc + 1)).transpose(1, 2)[:, valid, :]
+    loss_ref = crit(fused_ref, target)
+    loss_ref.backward()
+    grad_ref = est.grad.clone()
+    # kernels
+    est_d = est.detach().to(cuda).requires_grad_(True)
+    fused = FuseOutput.apply(est_d, fv.to(cuda), fw.to(cuda), valid.to(cuda), init)
+    assert torch.equal(fused.cpu(), fused_ref.detach())
+    loss = crit(fused, target.to(cuda))
+    assert loss.shape == () and abs(float(loss) - float(loss_ref)) <= 1e-6 * abs(float(loss_ref))
+    loss.backward()
+    scale = float(grad_ref.abs().max())
+    assert float((est_d.grad.cpu() - grad_ref).abs().max()) <= 1e-6 * scale
+    assert float(est_d.grad[:, :, ~torch.isin(torch.arange(n), valid).to(cuda)].abs().max()) == 0.0  # masked pixels receive nothing
+    # an upstream factor reaches the gradient (loss * 3)
+    est_d.grad = None
+    fused = FuseOutput.apply(est_d, fv.to(cuda), fw.to(cuda), valid.to(cuda), init)
+    (crit(fused, target.to(cuda)) * 3.0).backward()
+    assert float((est_d.grad.cpu() - 3.0 * grad_ref).abs().max()) <= 3e-6 * scale

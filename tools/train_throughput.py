@@ -34,3 +34,7 @@ for i in range(8, n): step(i)
 t1 = time.perf_counter()
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print('training frame step: %.1f frames/s (%.2f ms/frame; host enqueue alone %.2f ms/frame)' % ((n - 8) / dt, dt / (n - 8) * 1e3, (t1 - t0) / (n - 8) * 1e3))
+tn = pipe.__dict__.get('_hip_train')
+if tn is not None and tn._trainers:
+    from online_joint_depthfusion_and_semantic_amd import _lib
+    print('executor launches in the last backward pass: %d' % _lib.load().ojf_trainer_launch_count(next(iter(tn._trainers.values())).handle))
