@@ -362,6 +362,74 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGroup grp)
     conv_epilogue<MT, NT>(a, acc, strip, i16, g, bvec, rvec);
 }
 
+// Wide fp32 launches (NT >= 6 output tiles: the training path's 1x1 layers on 114 .. 580 channels and their
+// backward-data forms): the weight fragments of a superstep are 1 KB per output tile and every wave of the plain kernel
+// fetches all of them for its 16 pixels - 4800 waves x 64 KB through the L1s per launch of the transposed final
+// convolution, which ran at 16 % of the fp32-MFMA peak for it.  Here the four waves of a block share one copy of a
+// three-superstep chunk in LDS (the split-fp16 kernel's scheme): same arithmetic, same order, same bits.
+template <int NT>
+__global__ __launch_bounds__(256) void conv_mfma_lds_kernel(const ConvGroup grp)
+{
+    constexpr int CS = 3;
+    const ConvArgs &a = grp.g[blockIdx.y];
+    __shared__ int2 tab[(kMaxSteps + kPadSteps) * 4];
+    __shared__ f32x4 wl[CS * NT * 64];
+    build_tap_table(tab, a, (a.nsteps + kPadSteps) * 4);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int strip = (blockIdx.x * 4 + wave) * 16;  // waves past the image still take part in the barriers
+    const int p = strip + i16;
+    const int py = p < a.npix ? p / a.w : -0x40000000;
+    const int px = p - (p / a.w) * a.w;
+    f32x4 acc[1][NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[0][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<f32x4 *>(a.in), 0, (a.in_g0 + a.c4) * a.npix * 16, 0x00020000);
+    auto fetch = [&](f32x4 &xv, int S) {
+        const int2 e = tab[S * 4 + g];
+        const int dy = e.y >> 16, dx = (int)(short)(e.y & 0xffff);
+        const bool ok = (unsigned)(py + dy) < (unsigned)a.h && (unsigned)(px + dx) < (unsigned)a.w;
+        xv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (unsigned)(e.x + p) * 16u : 0xffffffffu, 0, 0));
+    };
+    auto mac = [&](const f32x4 &xv, int sl) {
+        f32x4 wv[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) wv[n] = wl[(sl * NT + n) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[n][j], xv[j], acc[0][n], 0, 0, 0);
+    };
+    f32x4 x0, x1, x2;
+    fetch(x0, 0);
+    fetch(x1, 1);
+    const int nsp = a.nsteps + kPadSteps;
+    for (int S = 0; S < a.nsteps; S += 3) {
+        if (S) __syncthreads();
+        for (int i = threadIdx.x; i < CS * NT * 64; i += 256) {  // chunk [S, S + 3) of every tile ([tile][superstep][lane] in memory)
+            const int n = i / (CS * 64), r = i - n * (CS * 64);
+            wl[((r >> 6) * NT + n) * 64 + (r & 63)] = a.wp[((size_t)n * nsp + S) * 64 + r];
+        }
+        __syncthreads();
+        fetch(x2, S + 2);
+        mac(x0, 0);
+        fetch(x0, S + 3);
+        mac(x1, 1);
+        fetch(x1, S + 4);
+        mac(x2, 2);
+    }
+    f32x4 bvec[NT], rvec[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        bvec[n] = *reinterpret_cast<const f32x4 *>(a.bias + (size_t)n * 16 + 4 * g);
+        rvec[n] = f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+    if (strip >= a.npix) return;
+    conv_epilogue<1, NT>(a, acc, strip, i16, g, bvec, rvec);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Split-fp16 variant of the generic convolution (OJF_ARITH_F16X3).  Same C4-planar fp32 activations in
 // and out; a superstep is one 32-wide K block = 8 (tap, 4-channel group) entries, lane group g owns
@@ -1718,11 +1786,18 @@ static int launch_conv_args(const ConvArgs *args, int n, int nt, hipStream_t st,
             default: return fail("conv: unsupported number of output tiles");
         }
     } else {
+        static const bool no_lds32 = getenv("OJF_CONV32_LDS") && atoi(getenv("OJF_CONV32_LDS")) == 0;  // A/B switch
         switch (nt) {
             case 2: OJF_LAUNCH32(2); break;
             case 4: OJF_LAUNCH32(4); break;
-            case 6: OJF_LAUNCH32(6); break;
-            case 8: OJF_LAUNCH32(8); break;
+            case 6:
+                if (no_lds32) OJF_LAUNCH32(6);
+                else hipLaunchKernelGGL((conv_mfma_lds_kernel<6>), grid, block, 0, st, grp);
+                break;
+            case 8:
+                if (no_lds32) OJF_LAUNCH32(8);
+                else hipLaunchKernelGGL((conv_mfma_lds_kernel<8>), grid, block, 0, st, grp);
+                break;
             default: return fail("conv: unsupported number of output tiles");
         }
     }

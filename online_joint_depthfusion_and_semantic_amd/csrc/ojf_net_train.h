@@ -37,6 +37,8 @@ struct PackArgs {
     // stacked layers (the four branch-entry 1x1 of a VortexPooling as ONE convolution): this weight tensor owns output
     // channels [oc_base, oc_base + OC) of the stack; with `partial` only its elements are written (the buffer starts zeroed)
     int oc_base, partial;
+    // a convolution that reads only input channels [ic_base, ic_base + IC) of a weight tensor with ic_total input channels
+    int ic_base, ic_total;
 };
 
 __device__ __forceinline__ int train_unslot(int x, int group, int slot, int n_logical)
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256) void train_pack_kernel(const PackArgs a)
         if (!a.transposed) { oc = r - a.oc_base; ic = train_unslot(ch, a.group, a.slot, a.IC); t = tap; }
         else { ic = train_unslot(r, a.group, a.slot, a.IC); oc = ch - a.oc_base; t = a.taps - 1 - tap; }
         mine = oc >= 0 && oc < a.OC;
-        if (mine && ic >= 0) v = a.w[((size_t)oc * a.IC + ic) * a.taps + t];
+        if (mine && ic >= 0) v = a.w[((size_t)oc * a.ic_total + a.ic_base + ic) * a.taps + t];
     }
     if (mine || !a.partial) a.wp[i] = v;
 }
@@ -140,6 +142,7 @@ struct BnActArgs {
     float momentum, eps;
     // backward: block column 0 publishes the parameter gradients (added to what is there when `accumulate`)
     float *dgamma, *dbeta, *dbias;
+    float *sum_dy;                    // backward, optional: [C] per-channel sums of dy (0 under batch statistics), plain store
     int accumulate;
 };
 
@@ -293,6 +296,7 @@ __global__ __launch_bounds__(256) void train_bn_bwd_apply_kernel(const BnGroup g
             if (blockIdx.x == 0 && c < a.C) {
                 if (a.dgamma) a.dgamma[c] = (a.accumulate ? a.dgamma[c] : 0.0f) + (float)tot[4 + j];
                 if (a.dbeta) a.dbeta[c] = (a.accumulate ? a.dbeta[c] : 0.0f) + (float)tot[j];
+                if (a.sum_dy) a.sum_dy[c] = batch ? 0.0f : (float)(tot[j] * (double)(a.has_bn ? (a.gamma ? a.gamma[c] : 1.0f) * a.invstd[c] : 1.0f));
                 if (a.dbias) {
                     // sum_p dy: zero under batch statistics (the normalisation removes the mean), gamma * invstd * sum(dz) otherwise
                     const float gi = a.has_bn ? (a.gamma ? a.gamma[c] : 1.0f) * a.invstd[c] : 1.0f;
@@ -422,6 +426,7 @@ struct WgradReduceArgs {
     int slabs, taps, ocp, icp, OC, IC, group, slot, c_in_phys;
     int accumulate;  // dw += (gradient accumulation over frames happens here instead of in a torch add per parameter)
     int oc_base;     // first row of `partial` that belongs to this weight tensor (stacked layers; else 0)
+    int ic_base, ic_total;  // the gradient covers input channels [ic_base, ic_base + IC) of a tensor with ic_total of them
 };
 struct WgradReduceGroup { WgradReduceArgs g[4]; };  // blockIdx.y = unit
 
@@ -447,7 +452,7 @@ __global__ __launch_bounds__(256) void train_wgrad_reduce_kernel(const WgradRedu
     if (!live || sub) return;
     const int ic = train_unslot(icp_i, a.group, a.slot, a.IC);
     if (ic >= 0) {
-        float *d = a.dw + ((size_t)oc * a.IC + ic) * a.taps + tap;
+        float *d = a.dw + ((size_t)oc * a.ic_total + a.ic_base + ic) * a.taps + tap;
         *d = a.accumulate ? *d + s : s;
     }
 }
@@ -497,7 +502,7 @@ OJF_API int ojf_train_pack(const float *w, const float *bias, int OC, int IC, in
     a.w = w; a.bias = transposed ? nullptr : bias; a.wp = packed; a.bp = transposed ? nullptr : bias_packed;
     a.OC = OC; a.IC = IC; a.taps = ksize * ksize; a.group = group; a.slot = slot;
     a.c4 = kch / 4; a.nsteps = (a.taps * a.c4 + 3) / 4; a.n_ot = round_up(round_up(rows, 16) / 16, kNT); a.transposed = transposed ? 1 : 0;
-    a.oc_base = 0; a.partial = 0;
+    a.oc_base = 0; a.partial = 0; a.ic_base = 0; a.ic_total = IC;
     const long total = (long)a.n_ot * (a.nsteps + kPadSteps) * 256;
     hipLaunchKernelGGL(train_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), a);
     return check_hip(hipGetLastError(), "train_pack_kernel launch");
@@ -564,7 +569,7 @@ static ojf::BnActArgs train_bn_args(const float *y, int y_g0, int c_phys, int C,
     a.y_g0 = y_g0; a.out_g0 = 0; a.dout_g0 = 0; a.dy_g0 = 0; a.c4 = c_phys / 4; a.C = C; a.npix = h * w; a.act = act;
     a.has_bn = has_bn; a.training = training; a.scale = scale;
     a.mean_out = a.invstd_out = a.running_mean = a.running_var = nullptr; a.momentum = 0.0f; a.eps = 0.0f;
-    a.dgamma = a.dbeta = a.dbias = nullptr; a.accumulate = 0;
+    a.dgamma = a.dbeta = a.dbias = nullptr; a.sum_dy = nullptr; a.accumulate = 0;
     return a;
 }
 
@@ -609,13 +614,13 @@ OJF_API int ojf_train_bn_act_bwd(const float *y, int y_g0, const float *dout, in
 
 namespace ojf {
 struct WgradPlan { int ocp, icp, slabs; };
-static WgradPlan wgrad_plan(int c_out_phys, int c_in_phys, int taps, int npix)
+static WgradPlan wgrad_plan(int c_out_phys, int c_in_phys, int taps, int npix, int units = 1)
 {
     WgradPlan p;
     p.ocp = round_up(c_out_phys, 32);
     p.icp = round_up(c_in_phys, 32);
     // two waves per SIMD (2048 one-wave blocks) hide the load latency; at most 256 slabs for the reduction
-    const int waves = taps * (p.ocp / 32) * (p.icp / 32);
+    const int waves = units * taps * (p.ocp / 32) * (p.icp / 32);  // (units: layers of identical shape sharing one grouped launch)
     int slabs = (2048 + waves - 1) / waves;
     slabs = slabs > 256 ? 256 : slabs;
     const int max_slabs = (npix + 63) / 64;
@@ -647,7 +652,7 @@ OJF_API int ojf_train_wgrad(const float *x, int x_g0, int c_in_phys, const float
                        WgradGroup{{a, a, a, a}, (p.ocp / 32) * (p.icp / 32)}, div_magic(w, (uint64_t)h * w + 2 * kWgChunk));
     WgradReduceArgs r;
     r.partial = partial; r.dw = dw; r.slabs = p.slabs; r.taps = taps; r.ocp = p.ocp; r.icp = p.icp; r.OC = OC; r.IC = IC;
-    r.group = group; r.slot = slot; r.c_in_phys = c_in_phys; r.accumulate = accumulate ? 1 : 0; r.oc_base = 0;
+    r.group = group; r.slot = slot; r.c_in_phys = c_in_phys; r.accumulate = accumulate ? 1 : 0; r.oc_base = 0; r.ic_base = 0; r.ic_total = IC;
     const long total = (long)taps * OC * c_in_phys * 8;
     hipLaunchKernelGGL(train_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, WgradReduceGroup{{r, r, r, r}});
     return check_hip(hipGetLastError(), "train_wgrad kernels launch");

@@ -146,6 +146,15 @@ struct GaveTrainArgs {
     float *vec;                  // forward: [4 c4_out] value of the branch's constant map (padding channels 0)
     float *dW, *db, *dgamma, *dbeta;
     float *dpooled;              // backward (eval): [4 c4_in] per-channel constant added to d x
+    // The branch's constant map is input channels [0, OC) of the VortexPooling's final 1x1 convolution (weights Wf
+    // [OCf][ICf_total], bias bf): over a constant map that convolution is a per-frame BIAS, Wf[:, :OC] vec - so the map is
+    // never materialised, the final convolution reads the four branch slots only, and backward needs just the channel
+    // sums of the final convolution's dy: d vec = Wf[:, :OC]^T sum_dy,  d Wf[:, :OC] = sum_dy (x) vec.
+    const float *Wf, *bf;
+    int OCf, ICf_total, accumulate_f;
+    float *bias_eff;             // forward: [OCf] bf + Wf[:, :OC] vec -> the final unit's packed bias
+    const float *sum_dy;         // backward: [OCf]
+    float *dWf;                  // backward: the final convolution's weight gradient (columns [0, OC) written here)
 };
 
 // sum of the kTrainSlabs partial rows of physical channel ch, by one wave (lane b takes row b; fixed xor tree)
@@ -160,7 +169,7 @@ constexpr int kGaveThreads = 1024, kGaveMaxC = 1024;
 
 __global__ __launch_bounds__(kGaveThreads) void train_gave_fwd_kernel(const GaveTrainArgs a)
 {
-    __shared__ float pooled[kGaveMaxC];
+    __shared__ float pooled[kGaveMaxC], vecs[kGaveMaxC];
     const int wave = threadIdx.x >> 6, nw = kGaveThreads / 64;
     for (int ch = wave; ch < 4 * a.c4_in; ch += nw) {
         const float m = (float)(gave_slab_sum(a.partial, a.c4_in, ch) / (double)a.npix);
@@ -188,28 +197,41 @@ __global__ __launch_bounds__(kGaveThreads) void train_gave_fwd_kernel(const Gave
             }
         }
         a.vec[o] = vec;
+        vecs[o] = vec;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < a.OCf; o += kGaveThreads) {  // the constant map's share of the final convolution = a bias
+        float b = a.bf ? a.bf[o] : 0.0f;
+        for (int c = 0; c < a.OC; ++c) b = fmaf(a.Wf[(size_t)o * a.ICf_total + c], vecs[c], b);
+        a.bias_eff[o] = b;
     }
 }
 
 __global__ __launch_bounds__(kGaveThreads) void train_gave_bwd_kernel(const GaveTrainArgs a)
 {
-    __shared__ float dg[kGaveMaxC];
-    const int wave = threadIdx.x >> 6, nw = kGaveThreads / 64;
-    for (int o = wave; o < a.OC; o += nw) {
-        const float dv = (float)gave_slab_sum(a.partial, a.c4_out, o);
-        if ((threadIdx.x & 63) == 0) {
-            if (a.dbeta) a.dbeta[o] = (a.accumulate ? a.dbeta[o] : 0.0f) + dv;
-            if (a.dgamma) a.dgamma[o] = (a.accumulate ? a.dgamma[o] : 0.0f) + dv * a.xhat[o];
-            const float d = dv * a.gis[o];  // 0 under batch statistics
-            dg[o] = d;
-            if (a.db) a.db[o] = (a.accumulate ? a.db[o] : 0.0f) + d;
-        }
+    __shared__ float dg[kGaveMaxC], sdy[kGaveMaxC];
+    for (int o = threadIdx.x; o < a.OCf; o += kGaveThreads) sdy[o] = a.sum_dy[o];
+    __syncthreads();
+    for (int c = threadIdx.x; c < a.OC; c += kGaveThreads) {
+        float dv = 0.0f;  // d vec = Wf[:, :OC]^T sum_dy
+        for (int o = 0; o < a.OCf; ++o) dv = fmaf(a.Wf[(size_t)o * a.ICf_total + c], sdy[o], dv);
+        if (a.dbeta) a.dbeta[c] = (a.accumulate ? a.dbeta[c] : 0.0f) + dv;
+        if (a.dgamma) a.dgamma[c] = (a.accumulate ? a.dgamma[c] : 0.0f) + dv * a.xhat[c];
+        const float d = dv * a.gis[c];  // 0 under batch statistics
+        dg[c] = d;
+        if (a.db) a.db[c] = (a.accumulate ? a.db[c] : 0.0f) + d;
     }
     __syncthreads();
     if (a.dW)
         for (int i = threadIdx.x; i < a.OC * a.IC; i += kGaveThreads) {
             const int o = i / a.IC, l = i - o * a.IC;
             a.dW[i] = (a.accumulate ? a.dW[i] : 0.0f) + dg[o] * a.pooled[(l / a.group) * a.slot + l % a.group];
+        }
+    if (a.dWf)
+        for (int i = threadIdx.x; i < a.OCf * a.OC; i += kGaveThreads) {
+            const int o = i / a.OC, c = i - o * a.OC;
+            float *d = a.dWf + (size_t)o * a.ICf_total + c;
+            *d = (a.accumulate_f ? *d : 0.0f) + sdy[o] * a.vec[c];
         }
     if (a.training) return;  // nothing flows back to x under batch statistics (dg == 0)
     for (int ch = threadIdx.x; ch < 4 * a.c4_in; ch += kGaveThreads) {
@@ -347,6 +369,8 @@ __global__ __launch_bounds__(256) void train_loss_bwd_kernel(const LossArgs a)
 // ---- plan ----------------------------------------------------------------------------------------------------------
 struct TUnit {           // conv -> [BatchNorm2d] -> activation -> [Dropout2d], one entry of the caller's layer table
     int li, OC, IC, k, dil, group, slot, act, has_bn;
+    int ic_base, IC_total;   // the unit reads input channels [ic_base, ic_base + IC) of a weight tensor with IC_total of them
+    float *sum_dy;           // backward, optional: per-channel sums of dy
     float scale;
     int c4_in, c4_out;
     float *in; int in_g0;    // input planes (window of a buffer)
@@ -375,7 +399,7 @@ struct TVortex {
     int n_ot_s, nsteps_s, n_otT_s, nstepsT_s;
     WgradPlan wplan_s;
     double *gpartial;         // channel sums (forward: of x; backward: of d cat[gave])
-    float *pooled, *xhat, *gis, *vec, *dpooled;
+    float *pooled, *xhat, *gis, *vec, *dpooled, *sum_dy;
 };
 
 }  // namespace ojf
@@ -428,6 +452,7 @@ static int t_add_unit(ojf_trainer *t, int li, int OC, int IC, int k, int dil, in
                       float *in, int in_g0, int c4_in, float *din, float *out, int out_g0, float *dout, bool own_y = true)
 {
     TUnit u{};
+    u.ic_base = 0; u.IC_total = IC; u.sum_dy = nullptr;
     u.li = li; u.OC = OC; u.IC = IC; u.k = k; u.dil = dil; u.group = group; u.slot = slot; u.act = act; u.has_bn = has_bn; u.scale = scale;
     u.c4_in = c4_in; u.c4_out = (OC + 3) / 4;
     u.in = in; u.in_g0 = in_g0; u.din = din; u.out = out; u.out_g0 = out_g0; u.dout = dout; u.y_g0 = 0;
@@ -497,9 +522,20 @@ static int t_build_vortex(ojf_trainer *t, int li0, float *x, int c4x, int IC, in
         v.c2[r] = t_add_unit(t, l + 2, mid, mid, 3, kRates[r], mid, 4 * sl4, OJF_ACT_RELU, 1, 1.0f, F, r * sl4, sl4, dF, G, r * sl4, dG);
         v.close[r] = t_add_unit(t, l + 3, v.out_c, mid, 1, 1, mid, 4 * sl4, OJF_ACT_RELU, 1, 1.0f, G, r * sl4, sl4, dG, v.cat, (1 + r) * o4, v.dcat);
         if (v.c1[r] < 0 || v.c2[r] < 0 || v.close[r] < 0) return -2;
+        for (int id : {v.c1[r], v.c2[r], v.close[r]}) {  // launched four at a time: a quarter of the pixel slabs fills the chip
+            TUnit &u = t->units[id];
+            u.wplan = wgrad_plan(4 * u.c4_out, 4 * u.c4_in, u.k * u.k, t->npix, 4);
+        }
     }
-    v.final_u = t_add_unit(t, li0 + 17, v.out_c, 5 * v.out_c, 1, 1, v.out_c, 4 * o4, OJF_ACT_NONE, 1, 1.0f, v.cat, 0, 5 * o4, v.dcat, out, out_g0, dout);
+    // final 1x1 over the concatenation [global-average map | branch 0..3]: the constant map's share is a per-frame bias
+    // (train_gave_fwd_kernel), the convolution proper reads the four branch slots
+    v.final_u = t_add_unit(t, li0 + 17, v.out_c, 4 * v.out_c, 1, 1, v.out_c, 4 * o4, OJF_ACT_NONE, 1, 1.0f, v.cat, o4, 4 * o4, v.dcat, out, out_g0, dout);
     if (v.final_u < 0) return -2;
+    if (t_alloc(t, reinterpret_cast<void **>(&v.sum_dy), (size_t)o4 * 16, true)) return -2;
+    {
+        TUnit &f = t->units[v.final_u];
+        f.ic_base = v.out_c; f.IC_total = 5 * v.out_c; f.sum_dy = v.sum_dy;
+    }
     // stacked entry: rows = 4 slots of 4 sl4 channels, K = the input's physical channels
     const int rows = 16 * sl4, kch = 4 * c4x;
     if (ojf_train_packed_floats(rows, kch, 1) == 0 || ojf_train_packed_floats(kch, rows, 1) == 0) return fail("ojf_trainer: unsupported VortexPooling width");
@@ -546,7 +582,7 @@ static inline dim3 px_grid(int npix, int gy) { return dim3((unsigned)((npix + 25
 
 static int t_check_unit(const TUnit &u, const ojf_train_layer &l)
 {
-    if (!l.weight || l.out_channels != u.OC || l.in_channels != u.IC || l.ksize != u.k || l.dilation != u.dil)
+    if (!l.weight || l.out_channels != u.OC || l.in_channels != u.IC_total || l.ksize != u.k || l.dilation != u.dil)
         return fail("ojf_trainer: layer table does not match the net topology (layer " + std::to_string(u.li) + ")");
     if (u.has_bn && (!l.running_mean || !l.running_var)) return fail("ojf_trainer: BatchNorm layer without running statistics");
     return 0;
@@ -559,9 +595,17 @@ static int t_pack_weights(TCtx &c)
         const ojf_train_layer &l = c.L[u.li];
         if (t_check_unit(u, l)) return -2;
         if (!u.wp) continue;  // stacked entry units: packed with their VortexPooling below
-        if (ojf_train_pack(l.weight, l.bias, u.OC, u.IC, u.k, u.group, u.slot, 4 * u.c4_in, 4 * u.c4_out, 0, u.wp, u.bp, c.st)) return -2;
-        if (u.din && ojf_train_pack(l.weight, nullptr, u.OC, u.IC, u.k, u.group, u.slot, 4 * u.c4_in, 4 * u.c4_out, 1, u.wpT, nullptr, c.st)) return -2;
-        t->launches += u.din ? 2 : 1;
+        for (int tr = 0; tr < (u.din ? 2 : 1); ++tr) {
+            PackArgs a;
+            const int rows = tr ? 4 * u.c4_in : 4 * u.c4_out, kch = tr ? 4 * u.c4_out : 4 * u.c4_in;
+            a.w = l.weight; a.bias = tr ? nullptr : l.bias; a.wp = tr ? u.wpT : u.wp; a.bp = tr ? nullptr : u.bp;
+            a.OC = u.OC; a.IC = u.IC; a.taps = u.k * u.k; a.group = u.group; a.slot = u.slot;
+            a.c4 = kch / 4; a.nsteps = (a.taps * a.c4 + 3) / 4; a.n_ot = round_up(round_up(rows, 16) / 16, kNT); a.transposed = tr;
+            a.oc_base = 0; a.partial = 0; a.ic_base = u.ic_base; a.ic_total = u.IC_total;
+            const long total = (long)a.n_ot * (a.nsteps + kPadSteps) * 256;
+            hipLaunchKernelGGL(train_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.st, a);
+            ++t->launches;
+        }
     }
     for (TVortex &v : t->vortex)
         for (int r = 0; r < 4; ++r) {
@@ -573,7 +617,7 @@ static int t_pack_weights(TCtx &c)
                 a.w = l.weight; a.bias = nullptr; a.wp = tr ? v.wpT_stack : v.wp_stack; a.bp = nullptr;
                 a.OC = u.OC; a.IC = u.IC; a.taps = 1; a.group = u.group; a.slot = u.slot;
                 a.c4 = kch / 4; a.nsteps = (a.c4 + 3) / 4; a.n_ot = round_up(round_up(rows, 16) / 16, kNT); a.transposed = tr;
-                a.oc_base = r * 4 * v.sl4; a.partial = 1;
+                a.oc_base = r * 4 * v.sl4; a.partial = 1; a.ic_base = 0; a.ic_total = u.IC;
                 const long total = (long)a.n_ot * (a.nsteps + kPadSteps) * 256;
                 hipLaunchKernelGGL(train_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.st, a);
                 ++t->launches;
@@ -688,6 +732,7 @@ static int t_units_backward(TCtx &c, const int *ids, int n, bool tail = true)
         a.dout = planes(u.dout); a.dout_g0 = u.out_g0; a.dy = planes(u.dy); a.dy_g0 = u.y_g0;
         a.dgamma = u.has_bn ? l.grad_gamma : nullptr; a.dbeta = u.has_bn ? l.grad_beta : nullptr; a.dbias = l.bias ? l.grad_bias : nullptr;
         a.accumulate = l.accumulate ? 1 : 0;
+        a.sum_dy = u.sum_dy;
         grp.g[i] = a;
     }
     const int c4 = t->units[ids[0]].c4_out;
@@ -714,6 +759,7 @@ static int t_units_backward(TCtx &c, const int *ids, int n, bool tail = true)
             WgradReduceArgs r;
             r.partial = u.wpart; r.dw = l.grad_weight; r.slabs = u.wplan.slabs; r.taps = taps; r.ocp = u.wplan.ocp; r.icp = u.wplan.icp;
             r.OC = u.OC; r.IC = u.IC; r.group = u.group; r.slot = u.slot; r.c_in_phys = 4 * u.c4_in; r.accumulate = l.accumulate ? 1 : 0; r.oc_base = 0;
+            r.ic_base = u.ic_base; r.ic_total = u.IC_total;
             rg.g[i] = r;
             total = (long)taps * u.OC * 4 * u.c4_in * 8;
             if (!l.grad_weight) return fail("ojf_trainer_backward: layer without a weight-gradient tensor");
@@ -754,10 +800,14 @@ static int t_vortex_forward(TCtx &c, TVortex &v)
     g.training = lg.bn_training ? 1 : 0; g.accumulate = 0; g.momentum = lg.momentum; g.eps = lg.eps;
     g.W = lg.weight; g.b = lg.bias; g.gamma = lg.gamma; g.beta = lg.beta; g.running_mean = lg.running_mean; g.running_var = lg.running_var;
     g.pooled = v.pooled; g.xhat = v.xhat; g.gis = v.gis; g.vec = v.vec;
+    {
+        const TUnit &f = t->units[v.final_u];
+        const ojf_train_layer &lf = c.L[f.li];
+        g.Wf = lf.weight; g.bf = lf.bias; g.OCf = f.OC; g.ICf_total = f.IC_total; g.bias_eff = f.bp;
+    }
     if (v.out_c > kGaveMaxC || 4 * v.c4x > kGaveMaxC) return fail("ojf_trainer: VortexPooling wider than 1024 channels");
     hipLaunchKernelGGL(train_gave_fwd_kernel, dim3(1), dim3(kGaveThreads), 0, c.st, g);
-    hipLaunchKernelGGL(train_bcast_planes_kernel, px_grid(t->npix, v.o4), dim3(256), 0, c.st, v.vec, planes(v.cat), t->npix, 0);
-    t->launches += 3;
+    t->launches += 2;
     // the four branch entries: ONE stacked 1x1 convolution of the unpooled input, then the pools (+ bias) on the narrow result
     ConvArgs ca = t_conv_args(t, v.x, 0, v.c4x, v.u, 0, 4 * v.sl4, v.wp_stack, t->zero_bias, v.nsteps_s, 1, 1, 0);
     if (t_conv(c, &ca, 1, v.n_ot_s)) return -2;
@@ -803,7 +853,7 @@ static int t_vortex_backward(TCtx &c, TVortex &v)
             WgradReduceArgs ra;
             ra.partial = v.wpart_stack; ra.dw = l.grad_weight; ra.slabs = a.slabs; ra.taps = 1; ra.ocp = a.ocp; ra.icp = a.icp;
             ra.OC = u.OC; ra.IC = u.IC; ra.group = u.group; ra.slot = u.slot; ra.c_in_phys = 4 * v.c4x; ra.accumulate = l.accumulate ? 1 : 0;
-            ra.oc_base = r * 4 * v.sl4;
+            ra.oc_base = r * 4 * v.sl4; ra.ic_base = 0; ra.ic_total = u.IC;
             rg.g[r] = ra;
             total = (long)u.OC * 4 * v.c4x * 8;
         }
@@ -819,15 +869,20 @@ static int t_vortex_backward(TCtx &c, TVortex &v)
     }
     // global-average branch
     const ojf_train_layer &lg = c.L[v.li0];
-    hipLaunchKernelGGL(train_stats_partial_kernel, dim3(kTrainSlabs, v.o4), dim3(256), 0, c.st, planes(v.dcat), 0, t->npix, v.gpartial);
     GaveTrainArgs g{};
     g.partial = v.gpartial; g.c4_in = v.c4x; g.c4_out = v.o4; g.IC = v.IC; g.OC = v.out_c; g.group = v.group; g.slot = v.slot; g.npix = t->npix;
     g.training = lg.bn_training ? 1 : 0; g.accumulate = lg.accumulate ? 1 : 0;
     g.W = lg.weight; g.b = lg.bias; g.gamma = lg.gamma; g.beta = lg.beta;
     g.pooled = v.pooled; g.xhat = v.xhat; g.gis = v.gis;
     g.dW = lg.grad_weight; g.db = lg.bias ? lg.grad_bias : nullptr; g.dgamma = lg.grad_gamma; g.dbeta = lg.grad_beta; g.dpooled = v.dpooled;
+    {
+        const TUnit &f = t->units[v.final_u];
+        const ojf_train_layer &lf = c.L[f.li];
+        g.Wf = lf.weight; g.OCf = f.OC; g.ICf_total = f.IC_total; g.sum_dy = v.sum_dy; g.vec = v.vec; g.dWf = lf.grad_weight;
+        g.accumulate_f = lf.accumulate ? 1 : 0;
+    }
     hipLaunchKernelGGL(train_gave_bwd_kernel, dim3(1), dim3(kGaveThreads), 0, c.st, g);
-    t->launches += 2;
+    ++t->launches;
     if (!lg.bn_training && v.dx) {  // running statistics: the branch is an affine map of mean(x) - a per-channel constant flows back to every pixel
         hipLaunchKernelGGL(train_bcast_planes_kernel, px_grid(t->npix, v.c4x), dim3(256), 0, c.st, v.dpooled, planes(v.dx), t->npix, 1);
         ++t->launches;
