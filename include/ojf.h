@@ -279,6 +279,10 @@ typedef struct ojf_train_layer {
 } ojf_train_layer;
 int ojf_trainer_create(ojf_trainer **out, int version, int n_points, int growth, int use_semantics, float output_scale, int h, int w);
 void ojf_trainer_destroy(ojf_trainer *t);
+/* arithmetic of the FORWARD convolutions: OJF_ARITH_F16X3 (default; activations must stay inside the fp16 range like in
+ * ojf_net_forward - a violation makes the next ojf_trainer_forward fail until ojf_net_check clears it) or OJF_ARITH_F32.
+ * Backward (tiny gradients of unbounded range) is always fp32-input MFMA. */
+int ojf_trainer_set_arithmetic(ojf_trainer *t, int arithmetic);
 int ojf_trainer_layer_count(const ojf_trainer *t);
 int ojf_trainer_launch_count(const ojf_trainer *t);
 int ojf_trainer_forward(ojf_trainer *t, const ojf_train_layer *layers, int n_layers, unsigned long long weights_epoch,

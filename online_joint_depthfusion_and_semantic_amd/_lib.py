@@ -93,6 +93,7 @@ SIGNATURES = {
     'ojf_train_wgrad': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     'ojf_trainer_create': (_i, [_c.POINTER(_vp), _i, _i, _i, _i, _f, _i, _i]),
     'ojf_trainer_destroy': (None, [_vp]),
+    'ojf_trainer_set_arithmetic': (_i, [_vp, _i]),
     'ojf_trainer_layer_count': (_i, [_vp]),
     'ojf_trainer_launch_count': (_i, [_vp]),
     'ojf_trainer_forward': (_i, [_vp, _c.POINTER(TrainLayer), _i, _c.c_ulonglong, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -366,6 +366,69 @@ __global__ __launch_bounds__(256) void train_loss_bwd_kernel(const LossArgs a)
     a.d_est[i] = g * (a.w1 * loss_sign(d) + 2.0f * a.w2 * d);  // the sign-cosine term is piecewise constant
 }
 
+// ---- split-fp16 weights for the FORWARD convolutions, packed on the device -------------------------------------------
+// The forward pass's convolutions see BatchNorm-scaled activations of order one: the inference path's split-fp16 arithmetic
+// (three fp16 MFMAs per product block, fp32 accumulate, row-equilibrated weights: DESIGN.md 3.2) applies unchanged and runs
+// the MFMA part 5.3x faster than the fp32-input instruction.  Gradients (tiny, of unbounded range) stay on fp32 MFMAs.
+// Layout = finish()'s: [superstep][oc tile][hi | lo][lane] x 8 halfs, K entry G = 8 S + 2 (lane / 16) + j / 4.
+struct Pack16Args {
+    const float *w;        // [OC][ic_total][taps]
+    float *rs;             // [n_ot * 16] power-of-two row scales (written by the row-max pass)
+    float *rinv;           // [n_ot * 16] their inverses
+    _Float16 *wp;          // packed halves
+    int OC, IC, taps, group, slot, c4, nsteps, n_ot, oc_base, ic_base, ic_total;
+};
+
+__global__ __launch_bounds__(256) void train_pack16_rowscale_kernel(const Pack16Args a)
+{
+    __shared__ float red[4];
+    const int oc = blockIdx.x;  // row of THIS weight tensor
+    float mx = 0.0f;
+    const int n = a.IC * a.taps;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int ic = i / a.taps, t = i - ic * a.taps;
+        mx = fmaxf(mx, fabsf(a.w[((size_t)oc * a.ic_total + a.ic_base + ic) * a.taps + t]));
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float rs = 1.0f;
+        if (mx > 0.0f && mx < 3.0e38f) {  // row_scale(): the largest magnitude of the row lands in [2^13, 2^14)
+            int e = 0;
+            (void)frexpf(mx, &e);
+            int k = 14 - e;
+            k = k > 100 ? 100 : (k < -100 ? -100 : k);
+            rs = ldexpf(1.0f, k);
+        }
+        a.rs[a.oc_base + oc] = rs;
+        a.rinv[a.oc_base + oc] = 1.0f / rs;
+    }
+}
+
+__global__ __launch_bounds__(256) void train_pack16_kernel(const Pack16Args a)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)a.nsteps * a.n_ot * 512;  // (S, ot, lane, j)
+    if (i >= total) return;
+    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    const long rest = i >> 9;
+    const int ot = (int)(rest % a.n_ot), S = (int)(rest / a.n_ot);
+    const int row = ot * 16 + (lane & 15), G = 8 * S + 2 * (lane >> 4) + (j >> 2);
+    const int oc = row - a.oc_base;
+    if (oc < 0 || oc >= a.OC || G >= a.taps * a.c4) return;  // (the buffer starts zeroed; other tensors of a stack own the other rows)
+    const int t = G / a.c4, ch = 4 * (G - t * a.c4) + (j & 3);
+    const int ic = train_unslot(ch, a.group, a.slot, a.IC);
+    float v = 0.0f;
+    if (ic >= 0) v = a.rs[row] * a.w[((size_t)oc * a.ic_total + a.ic_base + ic) * a.taps + t];
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    const size_t base = ((size_t)S * a.n_ot + ot) * 2 * 64 * 8;
+    a.wp[base + (size_t)lane * 8 + j] = hi;
+    a.wp[base + 64 * 8 + (size_t)lane * 8 + j] = lo;
+}
+
 // ---- plan ----------------------------------------------------------------------------------------------------------
 struct TUnit {           // conv -> [BatchNorm2d] -> activation -> [Dropout2d], one entry of the caller's layer table
     int li, OC, IC, k, dil, group, slot, act, has_bn;
@@ -380,6 +443,8 @@ struct TUnit {           // conv -> [BatchNorm2d] -> activation -> [Dropout2d], 
     float *out; int out_g0;  // unit output (window of a buffer)
     float *dout;             // gradient buffer of the output buffer (same window)
     float *wp, *bp, *wpT;    // packed weights: forward, bias, transposed + flipped (backward-data)
+    float *wp16, *rs16, *rinv16;  // forward weights in the split-fp16 layout, row scales and their inverses
+    int nsteps16;
     int n_ot, nsteps, n_otT, nstepsT;
     float *mean, *invstd;
     double *partial;
@@ -396,6 +461,8 @@ struct TVortex {
     float *cat, *dcat;        // [5 o4]: gave | branch 0..3
     int entry[4], c1[4], c2[4], close[4], final_u;  // unit indices
     float *wp_stack, *wpT_stack, *wpart_stack;      // stacked entry weights [4 sl4 * 4 rows][K = 4 c4x]
+    float *wp16_stack, *rs16_stack, *rinv16_stack;
+    int nsteps16_s;
     int n_ot_s, nsteps_s, n_otT_s, nstepsT_s;
     WgradPlan wplan_s;
     double *gpartial;         // channel sums (forward: of x; backward: of d cat[gave])
@@ -426,6 +493,7 @@ struct ojf_trainer {
     hipEvent_t join_ev = nullptr;
     size_t next_fork = 0;
     bool use_side = true;
+    int fwd_arith = OJF_ARITH_F16X3;  // arithmetic of the forward convolutions (ojf_trainer_set_arithmetic)
 };
 
 namespace ojf {
@@ -466,6 +534,11 @@ static int t_add_unit(ojf_trainer *t, int li, int OC, int IC, int k, int dil, in
         if (t_alloc(t, reinterpret_cast<void **>(&u.wp), ojf_train_packed_floats(cop, cip, k) * 4, true)) return -2;
         if (t_alloc(t, reinterpret_cast<void **>(&u.wpT), ojf_train_packed_floats(cip, cop, k) * 4, true)) return -2;
         u.wplan = wgrad_plan(cop, cip, taps, t->npix);
+        u.nsteps16 = (taps * c4_in + 7) / 8;
+        if (u.nsteps16 <= kMaxSteps) {
+            if (t_alloc(t, reinterpret_cast<void **>(&u.wp16), (size_t)(u.nsteps16 + kPad16) * u.n_ot * 128 * 16, true)) return -2;
+            if (t_alloc(t, reinterpret_cast<void **>(&u.rs16), (size_t)u.n_ot * 16 * 4, true) || t_alloc(t, reinterpret_cast<void **>(&u.rinv16), (size_t)u.n_ot * 16 * 4, true)) return -2;
+        }
         if (t_alloc(t, reinterpret_cast<void **>(&u.wpart), (size_t)u.wplan.slabs * taps * u.wplan.ocp * u.wplan.icp * 4)) return -2;
     }
     if (t_alloc(t, reinterpret_cast<void **>(&u.bp), (size_t)u.n_ot * 16 * 4, true)) return -2;
@@ -546,6 +619,11 @@ static int t_build_vortex(ojf_trainer *t, int li0, float *x, int c4x, int IC, in
         t_alloc(t, reinterpret_cast<void **>(&v.wpT_stack), ojf_train_packed_floats(kch, rows, 1) * 4, true))
         return -2;
     v.wplan_s = wgrad_plan(rows, kch, 1, t->npix);
+    v.nsteps16_s = (c4x + 7) / 8;
+    if (t_alloc(t, reinterpret_cast<void **>(&v.wp16_stack), (size_t)(v.nsteps16_s + kPad16) * v.n_ot_s * 128 * 16, true) ||
+        t_alloc(t, reinterpret_cast<void **>(&v.rs16_stack), (size_t)v.n_ot_s * 16 * 4, true) ||
+        t_alloc(t, reinterpret_cast<void **>(&v.rinv16_stack), (size_t)v.n_ot_s * 16 * 4, true))
+        return -2;
     if (t_alloc(t, reinterpret_cast<void **>(&v.wpart_stack), (size_t)v.wplan_s.slabs * v.wplan_s.ocp * v.wplan_s.icp * 4)) return -2;
     const int cmax = c4x > o4 ? c4x : o4;
     if (t_alloc(t, reinterpret_cast<void **>(&v.gpartial), ojf_train_partial_doubles(4 * cmax) * 8, true)) return -2;
@@ -606,6 +684,16 @@ static int t_pack_weights(TCtx &c)
             hipLaunchKernelGGL(train_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.st, a);
             ++t->launches;
         }
+        if (t->fwd_arith == OJF_ARITH_F16X3 && u.wp16) {
+            Pack16Args q;
+            q.w = l.weight; q.rs = u.rs16; q.rinv = u.rinv16; q.wp = reinterpret_cast<_Float16 *>(u.wp16);
+            q.OC = u.OC; q.IC = u.IC; q.taps = u.k * u.k; q.group = u.group; q.slot = u.slot; q.c4 = u.c4_in; q.nsteps = u.nsteps16; q.n_ot = u.n_ot;
+            q.oc_base = 0; q.ic_base = u.ic_base; q.ic_total = u.IC_total;
+            hipLaunchKernelGGL(train_pack16_rowscale_kernel, dim3(u.OC), dim3(256), 0, c.st, q);
+            const long tot16 = (long)q.nsteps * q.n_ot * 512;
+            hipLaunchKernelGGL(train_pack16_kernel, dim3((unsigned)((tot16 + 255) / 256)), dim3(256), 0, c.st, q);
+            t->launches += 2;
+        }
     }
     for (TVortex &v : t->vortex)
         for (int r = 0; r < 4; ++r) {
@@ -621,6 +709,16 @@ static int t_pack_weights(TCtx &c)
                 const long total = (long)a.n_ot * (a.nsteps + kPadSteps) * 256;
                 hipLaunchKernelGGL(train_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.st, a);
                 ++t->launches;
+            }
+            if (t->fwd_arith == OJF_ARITH_F16X3) {
+                Pack16Args q;
+                q.w = l.weight; q.rs = v.rs16_stack; q.rinv = v.rinv16_stack; q.wp = reinterpret_cast<_Float16 *>(v.wp16_stack);
+                q.OC = u.OC; q.IC = u.IC; q.taps = 1; q.group = u.group; q.slot = u.slot; q.c4 = v.c4x; q.nsteps = v.nsteps16_s; q.n_ot = v.n_ot_s;
+                q.oc_base = r * 4 * v.sl4; q.ic_base = 0; q.ic_total = u.IC;
+                hipLaunchKernelGGL(train_pack16_rowscale_kernel, dim3(u.OC), dim3(256), 0, c.st, q);
+                const long tot16 = (long)q.nsteps * q.n_ot * 512;
+                hipLaunchKernelGGL(train_pack16_kernel, dim3((unsigned)((tot16 + 255) / 256)), dim3(256), 0, c.st, q);
+                t->launches += 2;
             }
         }
     return check_hip(hipGetLastError(), "ojf_trainer weight packing");
@@ -661,6 +759,18 @@ static ConvArgs t_conv_args(const ojf_trainer *t, const float *in, int in_g0, in
     return a;
 }
 
+// the same launch in the split-fp16 arithmetic (forward convolutions): packed halves, inverse row scales, range guard
+static ConvArgs t_conv_args16(const ojf_trainer *t, const float *in, int in_g0, int c4_in, float *out, int out_g0, int c4_out, const float *wp16,
+                              const float *rinv, const float *bias, int nsteps16, int k, int dil)
+{
+    ConvArgs a = t_conv_args(t, in, in_g0, c4_in, out, out_g0, c4_out, wp16, bias, nsteps16, k, dil, 0);
+    a.rinv = rinv;
+    a.ovf = overflow_flag();
+    a.w_magic = div_magic(t->w, (uint64_t)t->npix);
+    a.c4_magic = div_magic(c4_in, (uint64_t)(nsteps16 + kPad16) * 8);
+    return a;
+}
+
 // store / accumulate decision of a gradient write into groups [g0, g0 + n) of buffer `buf`
 static int t_grad_mode(ojf_trainer *t, const float *buf, int g0, int n, int *accum)
 {
@@ -689,11 +799,16 @@ static int t_units_forward(TCtx &c, const int *ids, int n, bool conv = true)
     ojf_trainer *t = c.t;
     if (conv) {
         ConvArgs ca[4];
+        const bool f16 = t->fwd_arith == OJF_ARITH_F16X3 && t->units[ids[0]].wp16;
         for (int i = 0; i < n; ++i) {
             const TUnit &u = t->units[ids[i]];
-            ca[i] = t_conv_args(t, u.in, u.in_g0, u.c4_in, u.y, u.y_g0, u.c4_out, u.wp, u.bp, u.nsteps, u.k, u.dil, 0);
+            ca[i] = f16 ? t_conv_args16(t, u.in, u.in_g0, u.c4_in, u.y, u.y_g0, u.c4_out, u.wp16, u.rinv16, u.bp, u.nsteps16, u.k, u.dil)
+                        : t_conv_args(t, u.in, u.in_g0, u.c4_in, u.y, u.y_g0, u.c4_out, u.wp, u.bp, u.nsteps, u.k, u.dil, 0);
         }
-        if (t_conv(c, ca, n, t->units[ids[0]].n_ot)) return -2;
+        if (f16) {
+            if (launch_conv_args(ca, n, t->units[ids[0]].n_ot, c.st, OJF_ARITH_F16X3)) return -2;
+            ++t->launches;
+        } else if (t_conv(c, ca, n, t->units[ids[0]].n_ot)) return -2;
     }
     BnGroup grp;
     bool any_stats = false;
@@ -809,8 +924,14 @@ static int t_vortex_forward(TCtx &c, TVortex &v)
     hipLaunchKernelGGL(train_gave_fwd_kernel, dim3(1), dim3(kGaveThreads), 0, c.st, g);
     t->launches += 2;
     // the four branch entries: ONE stacked 1x1 convolution of the unpooled input, then the pools (+ bias) on the narrow result
-    ConvArgs ca = t_conv_args(t, v.x, 0, v.c4x, v.u, 0, 4 * v.sl4, v.wp_stack, t->zero_bias, v.nsteps_s, 1, 1, 0);
-    if (t_conv(c, &ca, 1, v.n_ot_s)) return -2;
+    if (t->fwd_arith == OJF_ARITH_F16X3) {
+        ConvArgs ca = t_conv_args16(t, v.x, 0, v.c4x, v.u, 0, 4 * v.sl4, v.wp16_stack, v.rinv16_stack, t->zero_bias, v.nsteps16_s, 1, 1);
+        if (launch_conv_args(&ca, 1, v.n_ot_s, c.st, OJF_ARITH_F16X3)) return -2;
+        ++t->launches;
+    } else {
+        ConvArgs ca = t_conv_args(t, v.x, 0, v.c4x, v.u, 0, 4 * v.sl4, v.wp_stack, t->zero_bias, v.nsteps_s, 1, 1, 0);
+        if (t_conv(c, &ca, 1, v.n_ot_s)) return -2;
+    }
     TrainPyramidArgs pa;
     pa.in = planes(v.u); pa.out = planes(v.ycat); pa.h = t->h; pa.w = t->w; pa.sl4 = v.sl4; pa.OC = v.mid;
     for (int r = 0; r < 4; ++r) pa.bias[r] = c.L[t->units[v.entry[r]].li].bias;
@@ -990,6 +1111,15 @@ OJF_API int ojf_trainer_create(ojf_trainer **out, int version, int n_points, int
     return 0;
 }
 
+OJF_API int ojf_trainer_set_arithmetic(ojf_trainer *t, int arithmetic)
+{
+    using namespace ojf;
+    if (!t || (arithmetic != OJF_ARITH_F32 && arithmetic != OJF_ARITH_F16X3)) return fail("ojf_trainer_set_arithmetic: bad argument");
+    if (t->fwd_arith != arithmetic) t->epoch = ~0ull;  // the packed copies of the other arithmetic are stale
+    t->fwd_arith = arithmetic;
+    return 0;
+}
+
 OJF_API int ojf_trainer_layer_count(const ojf_trainer *t) { return t ? t->n_layers : -1; }
 OJF_API int ojf_trainer_launch_count(const ojf_trainer *t) { return t ? t->launches : -1; }
 
@@ -1001,6 +1131,7 @@ OJF_API int ojf_trainer_forward(ojf_trainer *t, const ojf_train_layer *layers, i
     if (!t || !layers || !values || !weights || !frame || !est) return fail("ojf_trainer_forward: null pointer argument");
     if (n_layers != t->n_layers) return fail("ojf_trainer_forward: wrong number of layers");
     if (t->sem && !semantic_frame) return fail("ojf_trainer_forward: the net has a semantic channel but semantic_frame is NULL");
+    if (t->fwd_arith == OJF_ARITH_F16X3 && g_ovf_host && *g_ovf_host) return fail(kOverflowMsg);
     TCtx c{t, layers, as_stream(stream)};
     t->launches = 0;
     if (t->epoch != weights_epoch) {

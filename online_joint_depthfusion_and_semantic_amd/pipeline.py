@@ -319,7 +319,7 @@ class Pipeline(torch.nn.Module):
             if tn is None or tn.net is not self._fusion_network:
                 from .train import HipTrainNet
                 tn = self.__dict__['_hip_train'] = HipTrainNet(self._fusion_network, graph=self.config.FUSION_MODEL.get('train_graph', False),
-                                                               inplace_grads=True)
+                                                               inplace_grads=True, arithmetic=self.config.FUSION_MODEL.get('train_arithmetic', 'f16x3'))
             return tn(inputs)
         return self._fusion_network.forward(inputs)
 

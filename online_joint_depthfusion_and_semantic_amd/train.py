@@ -242,7 +242,7 @@ class HipTrainNet:
     """Runs ``net`` (model.FusionNet_v3 / FusionNet_v2) through ``LayerUnit`` nodes.  ``net.training`` selects batch
     statistics + dropout (train) or running statistics, no dropout (eval), exactly like the module's own forward."""
 
-    def __init__(self, net, graph=False, inplace_grads=False, executor=True):
+    def __init__(self, net, graph=False, inplace_grads=False, executor=True, arithmetic='f16x3'):
         _lib.require_gpu()
         self.net = net
         self.inplace_grads = bool(inplace_grads)  # see _grad_target
@@ -250,6 +250,8 @@ class HipTrainNet:
         # walk, grouped VortexPooling branches) behind ONE autograd node; False = one autograd node per layer unit (the
         # round-2 path, kept for A/B runs and for graph=True)
         self.executor = bool(executor)
+        # forward convolutions of the executor: 'f16x3' (split-fp16, the inference arithmetic) | 'f32'; backward is always fp32-MFMA
+        self.arithmetic = arithmetic
         self._trainers = {}
         self._table = None
         self._gen = 0
@@ -432,6 +434,7 @@ class HipTrainNet:
                 _lib.check(lib.ojf_trainer_create(_lib._c.byref(handle), 3 if isinstance(net, FusionNet_v3) else 2, net.n_points, net.gf,
                                                   int(bool(net.config.use_semantics)), float(net.scale), h, w), 'ojf_trainer_create')
             tr = self._trainers[key] = _TrainerHandle(handle)
+            _lib.check(lib.ojf_trainer_set_arithmetic(handle, _lib.ARITHMETIC[self.arithmetic]), 'ojf_trainer_set_arithmetic')
         return tr
 
     def _forward_executor(self, x):

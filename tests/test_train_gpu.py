@@ -133,7 +133,7 @@ def _whole_net_gradient_case(cuda, version, sem, training, path, h, w):
     loss(est_ref, target.double()).backward()
     est32 = ref32(x)
     loss(est32, target).backward()
-    tn = HipTrainNet(net, graph=graph, inplace_grads=not graph, executor=path == 'executor')
+    tn = HipTrainNet(net, graph=graph, inplace_grads=not graph, executor=path.startswith('executor'), arithmetic='f32' if path == 'executor_f32' else 'f16x3')
     est = tn({k: v.to(cuda) for k, v in x.items()})
     if graph:
         sig = next(iter(tn._graphs.values()))
@@ -166,7 +166,7 @@ def _whole_net_gradient_case(cuda, version, sem, training, path, h, w):
     print('whole net %s sem=%s training=%s path=%s %dx%d: worst deviation = %.2f x torch fp32\'s own' % (version, sem, training, path, h, w, worst))
 
 
-@pytest.mark.parametrize('path', ['executor', 'units', 'graph'])
+@pytest.mark.parametrize('path', ['executor', 'executor_f32', 'units', 'graph'])
 @pytest.mark.parametrize('training', [True, False])
 @pytest.mark.parametrize('version,sem', [('v3', False), ('v3', True), ('v2', True), ('v2', False)])
 def test_whole_net_gradients_against_torch_autograd(cuda, version, sem, training, path):
