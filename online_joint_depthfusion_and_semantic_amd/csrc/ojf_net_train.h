@@ -86,7 +86,17 @@ __device__ __forceinline__ void train_stats_partial_body(const f32x4 *y, int g0,
     const int p0 = blockIdx.x * per, p1 = min(npix, p0 + per);
     const f32x4 *plane = y + (size_t)(g0 + cg) * npix;
     double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+    // four loads in flight per lane (the kernels of this file are latency-, not bandwidth-bound); the sums run in the
+    // same order as a plain loop
+    int p = p0 + threadIdx.x;
+    for (; p + 768 < p1; p += 1024) {
+        const f32x4 v4[4] = {plane[p], plane[p + 256], plane[p + 512], plane[p + 768]};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s[j] += (double)v4[u][j]; s[4 + j] += (double)v4[u][j] * (double)v4[u][j]; }
+    }
+    for (; p < p1; p += 256) {
         const f32x4 v = plane[p];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { s[j] += (double)v[j]; s[4 + j] += (double)v[j] * (double)v[j]; }
@@ -228,8 +238,8 @@ __global__ __launch_bounds__(256) void train_bn_act_fwd_kernel(const BnGroup grp
     }
     const f32x4 *yp = a.y + (size_t)(a.y_g0 + cg) * a.npix;
     f32x4 *op = a.out + (size_t)(a.out_g0 + cg) * a.npix;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < a.npix; p += gridDim.x * blockDim.x) {
-        const f32x4 y = yp[p];
+    const int stride = gridDim.x * blockDim.x;
+    auto one = [&](const f32x4 &y) {
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -237,8 +247,14 @@ __global__ __launch_bounds__(256) void train_bn_act_fwd_kernel(const BnGroup grp
             const float z = xh * ga[j] + be[j];
             o[j] = 4 * cg + j < a.C ? train_act(z, a.act) * a.scale * dr[j] : 0.0f;
         }
-        op[p] = o;
+        return o;
+    };
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    for (; p + 2 * stride < a.npix; p += 3 * stride) {  // three loads in flight per lane
+        const f32x4 y0 = yp[p], y1 = yp[p + stride], y2 = yp[p + 2 * stride];
+        op[p] = one(y0); op[p + stride] = one(y1); op[p + 2 * stride] = one(y2);
     }
+    for (; p < a.npix; p += stride) op[p] = one(yp[p]);
 }
 
 // dz = dout * scale * drop * act'(z); partial sums of dz and dz * xhat per channel (fp64, fixed order)
@@ -254,8 +270,7 @@ __global__ __launch_bounds__(256) void train_bn_bwd_reduce_kernel(const BnGroup 
     const f32x4 *yp = a.y + (size_t)(a.y_g0 + cg) * a.npix;
     const f32x4 *gp = a.dout + (size_t)(a.dout_g0 + cg) * a.npix;
     double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int p = p0 + threadIdx.x; p < p1; p += 256) {
-        const f32x4 y = yp[p], g = gp[p];
+    auto add = [&](const f32x4 &y, const f32x4 &g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float xh = (y[j] - mu[j]) * is[j];
@@ -264,7 +279,15 @@ __global__ __launch_bounds__(256) void train_bn_bwd_reduce_kernel(const BnGroup 
             s[j] += (double)dz;
             s[4 + j] += (double)dz * (double)xh;
         }
+    };
+    int p = p0 + threadIdx.x;
+    for (; p + 768 < p1; p += 1024) {  // eight loads in flight per lane, sums in the order of a plain loop
+        const f32x4 y4[4] = {yp[p], yp[p + 256], yp[p + 512], yp[p + 768]};
+        const f32x4 g4[4] = {gp[p], gp[p + 256], gp[p + 512], gp[p + 768]};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) add(y4[u], g4[u]);
     }
+    for (; p < p1; p += 256) add(yp[p], gp[p]);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         double v = s[j];
@@ -312,8 +335,8 @@ __global__ __launch_bounds__(256) void train_bn_bwd_apply_kernel(const BnGroup g
     const f32x4 *yp = a.y + (size_t)(a.y_g0 + cg) * a.npix;
     const f32x4 *gp = a.dout + (size_t)(a.dout_g0 + cg) * a.npix;
     f32x4 *dp = a.dy + (size_t)(a.dy_g0 + cg) * a.npix;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < a.npix; p += gridDim.x * blockDim.x) {
-        const f32x4 y = yp[p], g = gp[p];
+    const int stride = gridDim.x * blockDim.x;
+    auto one = [&](const f32x4 &y, const f32x4 &g) {
         f32x4 d;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -322,8 +345,15 @@ __global__ __launch_bounds__(256) void train_bn_bwd_apply_kernel(const BnGroup g
             const float dz = g[j] * a.scale * dr[j] * train_act_grad(z, a.act);
             d[j] = ga[j] * is[j] * (dz - m1[j] - xh * m2[j]);  // m1 = m2 = 0 without batch statistics
         }
-        dp[p] = d;
+        return d;
+    };
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    for (; p + 2 * stride < a.npix; p += 3 * stride) {  // six loads in flight per lane
+        const f32x4 y0 = yp[p], y1 = yp[p + stride], y2 = yp[p + 2 * stride];
+        const f32x4 g0 = gp[p], g1 = gp[p + stride], g2 = gp[p + 2 * stride];
+        dp[p] = one(y0, g0); dp[p + stride] = one(y1, g1); dp[p + 2 * stride] = one(y2, g2);
     }
+    for (; p < a.npix; p += stride) dp[p] = one(yp[p], gp[p]);
 }
 
 // ---- weight gradient -----------------------------------------------------------------------------------------------
