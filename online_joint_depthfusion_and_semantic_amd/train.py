@@ -450,7 +450,10 @@ class HipTrainNet:
             self._params = [p for p in net.parameters()]
             self._pindex = {id(p): i for i, p in enumerate(self._params)}
             assert lib.ojf_trainer_layer_count(tr.handle) == len(mods)
-        table = (_lib.TrainLayer * len(mods))()
+        table = self.__dict__.get('_table_obj')
+        if table is None:  # one table for the trainer's life: backward finds last frame's gradient pointers still in place
+            table = self._table_obj = (_lib.TrainLayer * len(mods))()
+            self._grad_sig = None
         counters = []
         # Dropout2d: one uniform draw for every active layer of this pass, per-channel factors 0 or 1 / keep
         drops = [(i, d) for i, (c, b, d) in enumerate(mods) if d is not None and d.training and d.p > 0]
@@ -480,8 +483,7 @@ class HipTrainNet:
                 e.bn_training, e.momentum, e.eps = int(bn.training), float(bn.momentum), float(bn.eps)
                 if bn.training:
                     counters.append(bn.num_batches_tracked)
-            if i in scales:
-                e.drop_scale = scales[i].data_ptr()
+            e.drop_scale = scales[i].data_ptr() if i in scales else None
         ins = [x['tsdf_values'], x['tsdf_weights'], x['tsdf_frame']] + ([x['semantic_frame']] if net.config.use_semantics else [])
         ins = [t.contiguous().float() for t in ins]
         self._gen += 1
@@ -608,6 +610,13 @@ class _NetFn(torch.autograd.Function):
         needs = ctx.needs_input_grad[2 + ctx.n_in:]
         inplace = tn.inplace_grads and not torch.cuda.is_current_stream_capturing()
         out = [None] * len(tn._params)
+        sig = tn.__dict__.get('_grad_sig')
+        steady = inplace and sig is not None and all(p.grad is g for p, g in zip(tn._params, sig))
+        if steady:  # every parameter still accumulates into the tensor whose address the table already holds
+            _lib.check(lib.ojf_trainer_backward(tr.handle, table, len(table), dest.contiguous().data_ptr(), _lib.stream_ptr(state['dev'])),
+                       'ojf_trainer_backward')
+            return (None, None) + (None,) * ctx.n_in + tuple(out)
+        all_accumulating = inplace
         for i, (conv, bn, drop) in enumerate(tn._mods):
             e = table[i]
             ps = [(conv.weight, 'grad_weight'), (conv.bias, 'grad_bias')] + ([(bn.weight, 'grad_gamma'), (bn.bias, 'grad_beta')] if bn is not None else [])
@@ -623,8 +632,10 @@ class _NetFn(torch.autograd.Function):
                                 torch.zeros_like(p, memory_format=torch.contiguous_format)
                         setattr(e, f, p.grad.data_ptr())
                     e.accumulate = 0 if all(fresh) else 1
+                    all_accumulating = all_accumulating and not any(fresh)
                     continue
             e.accumulate = 0
+            all_accumulating = False
             for p, f in ps:  # the ordinary route: gradients are returned to autograd
                 g = torch.empty_like(p, memory_format=torch.contiguous_format)
                 setattr(e, f, g.data_ptr())
@@ -636,6 +647,13 @@ class _NetFn(torch.autograd.Function):
             state.setdefault('scratch', []).extend(o for o in out if o is not None)
         _lib.check(lib.ojf_trainer_backward(tr.handle, table, len(table), dest.contiguous().data_ptr(), _lib.stream_ptr(state['dev'])),
                    'ojf_trainer_backward')
+        # steady state from the next pass on: the gradient tensors exist and the table says "accumulate" for every layer
+        tn._grad_sig = [p.grad for p in tn._params] if inplace else None
+        if tn._grad_sig is not None and not all_accumulating:
+            for e in table:
+                e.accumulate = 1
+            if any(g is None for g in tn._grad_sig):
+                tn._grad_sig = None
         return (None, None) + (None,) * ctx.n_in + tuple(out)
 
 
