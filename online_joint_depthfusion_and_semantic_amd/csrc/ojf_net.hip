@@ -117,7 +117,8 @@ struct ConvArgs {
     int act, act_n;  // activation applied to output channels < act_n
     float scale;
     int *ovf;        // split-fp16 only: set to 1 when an activation leaves the fp16 range (host-mapped flag)
-    int accum;       // fp32 planar stores only: out += result (fan-out gradients of the training path); 0 = plain store
+    int accum;       // planar stores only: out += result (fan-out gradients of the training path); 0 = plain store
+    const float *dscale;  // training backward-data: the input carries a power-of-two factor *dscale - the result is divided by it; NULL = off
     unsigned w_magic, c4_magic;  // ceil(2^32 / w), ceil(2^32 / c4): x / d == umulhi(x, magic) while x * d < 2^32 (0: divide)
 };
 
@@ -160,6 +161,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x4 (&a
 {
     const float slope = act_slope(a.act);
     const bool use_tanh = a.act == OJF_ACT_TANH;
+    const float oscale = a.dscale ? a.scale / *a.dscale : a.scale;
     float gmax = 0.0f;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -176,7 +178,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x4 (&a
                 const float lin = v[j];
                 float r = lin > 0.0f ? lin : lin * slope;
                 if (use_tanh) r = tanhf(lin);
-                v[j] = (og * 4 + j < a.act_n ? r : lin) * a.scale;
+                v[j] = (og * 4 + j < a.act_n ? r : lin) * oscale;
             }
             if (p >= a.npix) continue;
             if (a.out_rows) {
@@ -185,8 +187,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x4 (&a
                     if (og * 4 + j < a.rows_n) a.out_rows[(size_t)p * a.rows_stride + og * 4 + j] = v[j];
             } else if (og < a.og_store) {
                 f32x4 *dst = a.out + (size_t)(a.out_g0 + og) * a.npix + p;
-                if constexpr (!GUARD)
-                    if (a.accum) v += *dst;
+                if (a.accum) v += *dst;
                 *dst = v;
                 if constexpr (GUARD) gmax = guard_max(gmax, lin4);  // pre-activation magnitude
             }
@@ -1818,7 +1819,7 @@ static void fill_conv_args(ConvArgs &a, const PackedConv &pc, const float *in, i
                            const float *bias, int act, int act_n, float scale, int h, int w)
 {
     a.ovf = pc.arith == OJF_ARITH_F16X3 ? overflow_flag() : nullptr;
-    a.accum = 0;
+    a.accum = 0; a.dscale = nullptr;
     a.in = planes(in); a.out = planes(out); a.out_rows = nullptr;
     a.wp = planes(pc.wp); a.bias = bias ? bias : pc.bias; a.rinv = pc.rinv;
     a.in_g0 = in_g0; a.out_g0 = out_g0; a.rows_stride = 0; a.rows_n = 0;

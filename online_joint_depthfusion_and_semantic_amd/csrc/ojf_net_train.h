@@ -153,6 +153,12 @@ struct BnActArgs {
     // backward: block column 0 publishes the parameter gradients (added to what is there when `accumulate`)
     float *dgamma, *dbeta, *dbias;
     float *sum_dy;                    // backward, optional: [C] per-channel sums of dy (0 under batch statistics), plain store
+    // backward, optional: dy is STORED multiplied by the power of two *dy_scale (so that the split-fp16 backward-data
+    // convolution sees operands of order one; its consumers divide again), and the largest |dy| of the pass is collected
+    // in dy_max[block] (one plain store per block: same-address atomics from ~60 k waves took 3 ms per frame) for the
+    // next pass's scale
+    const float *dy_scale;
+    float *dy_max;
     int accumulate;
 };
 
@@ -336,6 +342,8 @@ __global__ __launch_bounds__(256) void train_bn_bwd_apply_kernel(const BnGroup g
     const f32x4 *gp = a.dout + (size_t)(a.dout_g0 + cg) * a.npix;
     f32x4 *dp = a.dy + (size_t)(a.dy_g0 + cg) * a.npix;
     const int stride = gridDim.x * blockDim.x;
+    const float dys = a.dy_scale ? *a.dy_scale : 1.0f;
+    float dmax = 0.0f;
     auto one = [&](const f32x4 &y, const f32x4 &g) {
         f32x4 d;
 #pragma unroll
@@ -343,7 +351,9 @@ __global__ __launch_bounds__(256) void train_bn_bwd_apply_kernel(const BnGroup g
             const float xh = (y[j] - mu[j]) * is[j];
             const float z = xh * ga[j] + be[j];
             const float dz = g[j] * a.scale * dr[j] * train_act_grad(z, a.act);
-            d[j] = ga[j] * is[j] * (dz - m1[j] - xh * m2[j]);  // m1 = m2 = 0 without batch statistics
+            const float v = ga[j] * is[j] * (dz - m1[j] - xh * m2[j]);  // m1 = m2 = 0 without batch statistics
+            dmax = fmaxf(dmax, fabsf(v));
+            d[j] = v * dys;
         }
         return d;
     };
@@ -354,6 +364,13 @@ __global__ __launch_bounds__(256) void train_bn_bwd_apply_kernel(const BnGroup g
         dp[p] = one(y0, g0); dp[p + stride] = one(y1, g1); dp[p + 2 * stride] = one(y2, g2);
     }
     for (; p < a.npix; p += stride) dp[p] = one(yp[p], gp[p]);
+    if (a.dy_max) {
+        __shared__ float wmax[4];
+        for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = dmax;
+        __syncthreads();
+        if (threadIdx.x == 0) a.dy_max[blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    }
 }
 
 // ---- weight gradient -----------------------------------------------------------------------------------------------
@@ -457,6 +474,7 @@ struct WgradReduceArgs {
     int accumulate;  // dw += (gradient accumulation over frames happens here instead of in a torch add per parameter)
     int oc_base;     // first row of `partial` that belongs to this weight tensor (stacked layers; else 0)
     int ic_base, ic_total;  // the gradient covers input channels [ic_base, ic_base + IC) of a tensor with ic_total of them
+    const float *dy_scale;  // dy carried this power-of-two factor (NULL: none): the sums are divided by it
 };
 struct WgradReduceGroup { WgradReduceArgs g[4]; };  // blockIdx.y = unit
 
@@ -480,6 +498,7 @@ __global__ __launch_bounds__(256) void train_wgrad_reduce_kernel(const WgradRedu
     s += __shfl_xor(s, 2, 64);
     s += __shfl_xor(s, 1, 64);
     if (!live || sub) return;
+    if (a.dy_scale) s /= *a.dy_scale;  // exact: a power of two
     const int ic = train_unslot(icp_i, a.group, a.slot, a.IC);
     if (ic >= 0) {
         float *d = a.dw + ((size_t)oc * a.ic_total + a.ic_base + ic) * a.taps + tap;
@@ -554,7 +573,7 @@ OJF_API int ojf_train_conv(const float *in, int in_g0, int c_in_phys, float *out
     for (int ot0 = 0; ot0 < n_ot; ot0 += 8) {  // a launch covers up to 8 output tiles per wave
         const int nt = n_ot - ot0 < 8 ? n_ot - ot0 : 8;
         ConvArgs a;
-        a.ovf = nullptr; a.accum = 0;
+        a.ovf = nullptr; a.accum = 0; a.dscale = nullptr;
         a.in = planes(in); a.out = planes(out); a.out_rows = nullptr;
         a.wp = planes(packed) + (size_t)ot0 * (nsteps + kPadSteps) * 64;
         a.bias = (bias_packed ? bias_packed : g_train_zero_bias) + (size_t)ot0 * 16; a.rinv = nullptr;
@@ -599,7 +618,7 @@ static ojf::BnActArgs train_bn_args(const float *y, int y_g0, int c_phys, int C,
     a.y_g0 = y_g0; a.out_g0 = 0; a.dout_g0 = 0; a.dy_g0 = 0; a.c4 = c_phys / 4; a.C = C; a.npix = h * w; a.act = act;
     a.has_bn = has_bn; a.training = training; a.scale = scale;
     a.mean_out = a.invstd_out = a.running_mean = a.running_var = nullptr; a.momentum = 0.0f; a.eps = 0.0f;
-    a.dgamma = a.dbeta = a.dbias = nullptr; a.sum_dy = nullptr; a.accumulate = 0;
+    a.dgamma = a.dbeta = a.dbias = nullptr; a.sum_dy = nullptr; a.accumulate = 0; a.dy_scale = nullptr; a.dy_max = nullptr;
     return a;
 }
 
@@ -682,7 +701,7 @@ OJF_API int ojf_train_wgrad(const float *x, int x_g0, int c_in_phys, const float
                        WgradGroup{{a, a, a, a}, (p.ocp / 32) * (p.icp / 32)}, div_magic(w, (uint64_t)h * w + 2 * kWgChunk));
     WgradReduceArgs r;
     r.partial = partial; r.dw = dw; r.slabs = p.slabs; r.taps = taps; r.ocp = p.ocp; r.icp = p.icp; r.OC = OC; r.IC = IC;
-    r.group = group; r.slot = slot; r.c_in_phys = c_in_phys; r.accumulate = accumulate ? 1 : 0; r.oc_base = 0; r.ic_base = 0; r.ic_total = IC;
+    r.group = group; r.slot = slot; r.c_in_phys = c_in_phys; r.accumulate = accumulate ? 1 : 0; r.oc_base = 0; r.ic_base = 0; r.ic_total = IC; r.dy_scale = nullptr;
     const long total = (long)taps * OC * c_in_phys * 8;
     hipLaunchKernelGGL(train_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, WgradReduceGroup{{r, r, r, r}});
     return check_hip(hipGetLastError(), "train_wgrad kernels launch");

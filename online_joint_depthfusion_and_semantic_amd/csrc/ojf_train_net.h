@@ -429,6 +429,105 @@ __global__ __launch_bounds__(256) void train_pack16_kernel(const Pack16Args a)
     a.wp[base + 64 * 8 + (size_t)lane * 8 + j] = lo;
 }
 
+// Backward-data form of the same: rows = the convolution's INPUT channels (physical, chunk of <= 128 rows starting at
+// row0), K entry (tap, 4 output channels) <- w[oc][ic][taps - 1 - tap]; a stack of up to four weight tensors shares the K
+// axis (kper output channels each: the four branch entries of a VortexPooling).
+struct Pack16TArgs {
+    const float *w[4];     // [OC][ic_total][taps] each
+    int n_src, kper;       // K channels [b * kper, b * kper + OC) belong to tensor b
+    float *rs, *rinv;      // [rows of the whole layer, padded]
+    _Float16 *wp;          // this chunk's packed halves
+    int OC, IC, taps, group, slot, c4k, nsteps, n_ot, row0, rows, ic_base, ic_total;
+};
+
+__global__ __launch_bounds__(256) void train_pack16t_rowscale_kernel(const Pack16TArgs a)
+{
+    __shared__ float red[4];
+    const int r = blockIdx.x;  // physical input channel
+    const int ic = train_unslot(r, a.group, a.slot, a.IC);
+    float mx = 0.0f;
+    if (ic >= 0)
+        for (int b = 0; b < a.n_src; ++b)
+            for (int i = threadIdx.x; i < a.OC * a.taps; i += 256) {
+                const int oc = i / a.taps, t = i - oc * a.taps;
+                mx = fmaxf(mx, fabsf(a.w[b][((size_t)oc * a.ic_total + a.ic_base + ic) * a.taps + t]));
+            }
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float rs = 1.0f;
+        if (mx > 0.0f && mx < 3.0e38f) {
+            int e = 0;
+            (void)frexpf(mx, &e);
+            int k = 14 - e;
+            k = k > 100 ? 100 : (k < -100 ? -100 : k);
+            rs = ldexpf(1.0f, k);
+        }
+        a.rs[r] = rs;
+        a.rinv[r] = 1.0f / rs;
+    }
+}
+
+__global__ __launch_bounds__(256) void train_pack16t_kernel(const Pack16TArgs a)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)a.nsteps * a.n_ot * 512;
+    if (i >= total) return;
+    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    const long rest = i >> 9;
+    const int ot = (int)(rest % a.n_ot), S = (int)(rest / a.n_ot);
+    const int row = a.row0 + ot * 16 + (lane & 15), G = 8 * S + 2 * (lane >> 4) + (j >> 2);
+    float v = 0.0f;
+    if (row < a.rows && G < a.taps * a.c4k) {
+        const int tap = G / a.c4k, ch = 4 * (G - tap * a.c4k) + (j & 3);
+        const int b = ch / a.kper, oc = ch - b * a.kper;
+        const int ic = train_unslot(row, a.group, a.slot, a.IC);
+        if (b < a.n_src && oc < a.OC && ic >= 0)
+            v = a.rs[row] * a.w[b][((size_t)oc * a.ic_total + a.ic_base + ic) * a.taps + (a.taps - 1 - tap)];
+    }
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    const size_t base = ((size_t)S * a.n_ot + ot) * 2 * 64 * 8;
+    a.wp[base + (size_t)lane * 8 + j] = hi;
+    a.wp[base + 64 * 8 + (size_t)lane * 8 + j] = lo;
+}
+
+// block maxima of a unit's bn-backward launch -> the scale group's maximum (one atomic per unit)
+struct DyMaxArgs { const float *blocks; int n; unsigned *dst; };
+__global__ __launch_bounds__(256) void train_dy_max_reduce_kernel(const DyMaxArgs *units)
+{
+    __shared__ float wmax[4];
+    const DyMaxArgs a = units[blockIdx.x];
+    float m = 0.0f;
+    for (int i = threadIdx.x; i < a.n; i += 256) m = fmaxf(m, a.blocks[i]);
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        if (m > 0.0f) atomicMax(a.dst, __float_as_uint(m));  // (non-negative floats order like their bits)
+    }
+}
+
+// after a backward pass: next pass's dy scale per scale group from this pass's largest |dy| (it lands near 2^4: 12 binades
+// of headroom to the fp16 maximum, and elements down to 2^-30 of the largest keep all their bits), maxima reset
+__global__ void train_dy_scale_update_kernel(float *scales, unsigned *maxes, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float m = __uint_as_float(maxes[i]);
+    if (m > 0.0f && m < 3.0e38f) {
+        int e = 0;
+        (void)frexpf(m, &e);
+        int k = 4 - e;
+        k = k > 100 ? 100 : (k < -100 ? -100 : k);
+        scales[i] = ldexpf(1.0f, k);
+    }
+    maxes[i] = 0u;
+}
+
 // ---- plan ----------------------------------------------------------------------------------------------------------
 struct TUnit {           // conv -> [BatchNorm2d] -> activation -> [Dropout2d], one entry of the caller's layer table
     int li, OC, IC, k, dil, group, slot, act, has_bn;
@@ -445,6 +544,10 @@ struct TUnit {           // conv -> [BatchNorm2d] -> activation -> [Dropout2d], 
     float *wp, *bp, *wpT;    // packed weights: forward, bias, transposed + flipped (backward-data)
     float *wp16, *rs16, *rinv16;  // forward weights in the split-fp16 layout, row scales and their inverses
     int nsteps16;
+    float *wpT16, *rsT16, *rinvT16;  // backward-data weights in the split-fp16 layout: chunks of <= 8 row tiles, one after the other
+    int nsteps16T;
+    int sg;                  // scale group of this unit's dy (index into the trainer's scales / maxima)
+    float *dymax_blocks;     // [kBnBlocksX * c4_out] per-block maxima of |dy| of the last backward pass
     int n_ot, nsteps, n_otT, nstepsT;
     float *mean, *invstd;
     double *partial;
@@ -463,6 +566,8 @@ struct TVortex {
     float *wp_stack, *wpT_stack, *wpart_stack;      // stacked entry weights [4 sl4 * 4 rows][K = 4 c4x]
     float *wp16_stack, *rs16_stack, *rinv16_stack;
     int nsteps16_s;
+    float *wpT16_stack, *rsT16_stack, *rinvT16_stack;
+    int nsteps16T_s;
     int n_ot_s, nsteps_s, n_otT_s, nstepsT_s;
     WgradPlan wplan_s;
     double *gpartial;         // channel sums (forward: of x; backward: of d cat[gave])
@@ -493,7 +598,13 @@ struct ojf_trainer {
     hipEvent_t join_ev = nullptr;
     size_t next_fork = 0;
     bool use_side = true;
-    int fwd_arith = OJF_ARITH_F16X3;  // arithmetic of the forward convolutions (ojf_trainer_set_arithmetic)
+    int fwd_arith = OJF_ARITH_F16X3;  // arithmetic of the forward AND backward-data convolutions (ojf_trainer_set_arithmetic)
+    // power-of-two factors the dy tensors are stored with (one per unit; the four entries of a VortexPooling share one)
+    float *scales = nullptr;
+    unsigned *maxes = nullptr;
+    int n_sg = 0;
+    long bwd_passes = 0;     // passes since the scales were reset: the first one measures, the later ones use split-fp16
+    ojf::DyMaxArgs *dymax_units = nullptr;  // device table for train_dy_max_reduce_kernel
 };
 
 namespace ojf {
@@ -534,6 +645,11 @@ static int t_add_unit(ojf_trainer *t, int li, int OC, int IC, int k, int dil, in
         if (t_alloc(t, reinterpret_cast<void **>(&u.wp), ojf_train_packed_floats(cop, cip, k) * 4, true)) return -2;
         if (t_alloc(t, reinterpret_cast<void **>(&u.wpT), ojf_train_packed_floats(cip, cop, k) * 4, true)) return -2;
         u.wplan = wgrad_plan(cop, cip, taps, t->npix);
+        u.nsteps16T = (taps * u.c4_out + 7) / 8;
+        if (din && u.nsteps16T <= kMaxSteps) {
+            if (t_alloc(t, reinterpret_cast<void **>(&u.wpT16), (size_t)(u.nsteps16T + kPad16) * u.n_otT * 128 * 16, true)) return -2;
+            if (t_alloc(t, reinterpret_cast<void **>(&u.rsT16), (size_t)u.n_otT * 16 * 4, true) || t_alloc(t, reinterpret_cast<void **>(&u.rinvT16), (size_t)u.n_otT * 16 * 4, true)) return -2;
+        }
         u.nsteps16 = (taps * c4_in + 7) / 8;
         if (u.nsteps16 <= kMaxSteps) {
             if (t_alloc(t, reinterpret_cast<void **>(&u.wp16), (size_t)(u.nsteps16 + kPad16) * u.n_ot * 128 * 16, true)) return -2;
@@ -544,6 +660,8 @@ static int t_add_unit(ojf_trainer *t, int li, int OC, int IC, int k, int dil, in
     if (t_alloc(t, reinterpret_cast<void **>(&u.bp), (size_t)u.n_ot * 16 * 4, true)) return -2;
     if (t_alloc(t, reinterpret_cast<void **>(&u.mean), (size_t)cop * 4, true) || t_alloc(t, reinterpret_cast<void **>(&u.invstd), (size_t)cop * 4, true)) return -2;
     if (t_alloc(t, reinterpret_cast<void **>(&u.partial), ojf_train_partial_doubles(cop) * 8, true)) return -2;
+    u.sg = t->n_sg++;
+    if (t_alloc(t, reinterpret_cast<void **>(&u.dymax_blocks), (size_t)128 * u.c4_out * 4, true)) return -2;
     t->units.push_back(u);
     return (int)t->units.size() - 1;
 }
@@ -591,6 +709,7 @@ static int t_build_vortex(ojf_trainer *t, int li0, float *x, int c4x, int IC, in
         if (v.entry[r] < 0) return -2;
         TUnit &e = t->units[v.entry[r]];
         e.y = v.ycat; e.dy = v.dycat; e.y_g0 = r * sl4;
+        e.sg = t->units[v.entry[0]].sg;  // one factor for the four slices: the pooled gradients feed ONE stacked convolution
         v.c1[r] = t_add_unit(t, l + 1, mid, mid, 3, kRates[r], mid, 4 * sl4, OJF_ACT_RELU, 1, 1.0f, E, r * sl4, sl4, dE, F, r * sl4, dF);
         v.c2[r] = t_add_unit(t, l + 2, mid, mid, 3, kRates[r], mid, 4 * sl4, OJF_ACT_RELU, 1, 1.0f, F, r * sl4, sl4, dF, G, r * sl4, dG);
         v.close[r] = t_add_unit(t, l + 3, v.out_c, mid, 1, 1, mid, 4 * sl4, OJF_ACT_RELU, 1, 1.0f, G, r * sl4, sl4, dG, v.cat, (1 + r) * o4, v.dcat);
@@ -619,6 +738,11 @@ static int t_build_vortex(ojf_trainer *t, int li0, float *x, int c4x, int IC, in
         t_alloc(t, reinterpret_cast<void **>(&v.wpT_stack), ojf_train_packed_floats(kch, rows, 1) * 4, true))
         return -2;
     v.wplan_s = wgrad_plan(rows, kch, 1, t->npix);
+    v.nsteps16T_s = (4 * sl4 + 7) / 8;
+    if (t_alloc(t, reinterpret_cast<void **>(&v.wpT16_stack), (size_t)(v.nsteps16T_s + kPad16) * v.n_otT_s * 128 * 16, true) ||
+        t_alloc(t, reinterpret_cast<void **>(&v.rsT16_stack), (size_t)v.n_otT_s * 16 * 4, true) ||
+        t_alloc(t, reinterpret_cast<void **>(&v.rinvT16_stack), (size_t)v.n_otT_s * 16 * 4, true))
+        return -2;
     v.nsteps16_s = (c4x + 7) / 8;
     if (t_alloc(t, reinterpret_cast<void **>(&v.wp16_stack), (size_t)(v.nsteps16_s + kPad16) * v.n_ot_s * 128 * 16, true) ||
         t_alloc(t, reinterpret_cast<void **>(&v.rs16_stack), (size_t)v.n_ot_s * 16 * 4, true) ||
@@ -694,6 +818,22 @@ static int t_pack_weights(TCtx &c)
             hipLaunchKernelGGL(train_pack16_kernel, dim3((unsigned)((tot16 + 255) / 256)), dim3(256), 0, c.st, q);
             t->launches += 2;
         }
+        if (t->fwd_arith == OJF_ARITH_F16X3 && u.wpT16) {
+            Pack16TArgs q{};
+            q.w[0] = l.weight; q.n_src = 1; q.kper = 4 * u.c4_out; q.rs = u.rsT16; q.rinv = u.rinvT16;
+            q.OC = u.OC; q.IC = u.IC; q.taps = u.k * u.k; q.group = u.group; q.slot = u.slot; q.c4k = u.c4_out; q.nsteps = u.nsteps16T;
+            q.rows = 4 * u.c4_in; q.ic_base = u.ic_base; q.ic_total = u.IC_total;
+            hipLaunchKernelGGL(train_pack16t_rowscale_kernel, dim3(4 * u.c4_in), dim3(256), 0, c.st, q);
+            ++t->launches;
+            for (int ot0 = 0; ot0 < u.n_otT; ot0 += 8) {
+                q.n_ot = u.n_otT - ot0 < 8 ? u.n_otT - ot0 : 8;
+                q.row0 = ot0 * 16;
+                q.wp = reinterpret_cast<_Float16 *>(u.wpT16) + (size_t)(u.nsteps16T + kPad16) * ot0 * 128 * 8;
+                const long tot16 = (long)q.nsteps * q.n_ot * 512;
+                hipLaunchKernelGGL(train_pack16t_kernel, dim3((unsigned)((tot16 + 255) / 256)), dim3(256), 0, c.st, q);
+                ++t->launches;
+            }
+        }
     }
     for (TVortex &v : t->vortex)
         for (int r = 0; r < 4; ++r) {
@@ -719,6 +859,25 @@ static int t_pack_weights(TCtx &c)
                 const long tot16 = (long)q.nsteps * q.n_ot * 512;
                 hipLaunchKernelGGL(train_pack16_kernel, dim3((unsigned)((tot16 + 255) / 256)), dim3(256), 0, c.st, q);
                 t->launches += 2;
+            }
+        }
+    if (t->fwd_arith == OJF_ARITH_F16X3)
+        for (TVortex &v : t->vortex) {
+            const TUnit &u0 = t->units[v.entry[0]];
+            Pack16TArgs q{};
+            for (int r = 0; r < 4; ++r) q.w[r] = c.L[t->units[v.entry[r]].li].weight;
+            q.n_src = 4; q.kper = 4 * v.sl4; q.rs = v.rsT16_stack; q.rinv = v.rinvT16_stack;
+            q.OC = u0.OC; q.IC = u0.IC; q.taps = 1; q.group = u0.group; q.slot = u0.slot; q.c4k = 4 * v.sl4; q.nsteps = v.nsteps16T_s;
+            q.rows = 4 * v.c4x; q.ic_base = 0; q.ic_total = u0.IC;
+            hipLaunchKernelGGL(train_pack16t_rowscale_kernel, dim3(4 * v.c4x), dim3(256), 0, c.st, q);
+            ++t->launches;
+            for (int ot0 = 0; ot0 < v.n_otT_s; ot0 += 8) {
+                q.n_ot = v.n_otT_s - ot0 < 8 ? v.n_otT_s - ot0 : 8;
+                q.row0 = ot0 * 16;
+                q.wp = reinterpret_cast<_Float16 *>(v.wpT16_stack) + (size_t)(v.nsteps16T_s + kPad16) * ot0 * 128 * 8;
+                const long tot16 = (long)q.nsteps * q.n_ot * 512;
+                hipLaunchKernelGGL(train_pack16t_kernel, dim3((unsigned)((tot16 + 255) / 256)), dim3(256), 0, c.st, q);
+                ++t->launches;
             }
         }
     return check_hip(hipGetLastError(), "ojf_trainer weight packing");
@@ -748,7 +907,7 @@ static ConvArgs t_conv_args(const ojf_trainer *t, const float *in, int in_g0, in
                             const float *bias, int nsteps, int k, int dil, int accum)
 {
     ConvArgs a;
-    a.ovf = nullptr; a.accum = accum;
+    a.ovf = nullptr; a.accum = accum; a.dscale = nullptr;
     a.in = planes(in); a.out = planes(out); a.out_rows = nullptr;
     a.wp = planes(wp); a.bias = bias; a.rinv = nullptr;
     a.in_g0 = in_g0; a.out_g0 = out_g0; a.rows_stride = 0; a.rows_n = 0;
@@ -782,6 +941,51 @@ static int t_grad_mode(ojf_trainer *t, const float *buf, int g0, int n, int *acc
     if (set != 0 && set != n) return fail("ojf_trainer: mixed store / accumulate gradient window");
     *accum = set ? 1 : 0;
     for (int g = g0; g < g0 + n; ++g) w[g] = 1;
+    return 0;
+}
+
+// backward-data of up to four units (or of ONE wide one, in chunks of eight row tiles): d in (+)= conv(dy, W^T flipped) / s,
+// where s is the power of two dy was stored with.  From the second pass on (the first one measures the gradients' magnitude)
+// in the split-fp16 arithmetic, else on the fp32-input MFMA.
+struct TBwdData {
+    const float *dy; int dy_g0, c4k;       // input: gradient planes of the unit's convolution output
+    float *din; int in_g0, c4_in;          // output window
+    const float *wpT; int nstepsT;         // fp32 form
+    const float *wpT16, *rinvT16; int nsteps16T;
+    int n_otT, k, dil, sg;
+};
+
+static int t_backward_data(TCtx &c, const TBwdData *b, int n)
+{
+    ojf_trainer *t = c.t;
+    const bool f16 = t->fwd_arith == OJF_ARITH_F16X3 && t->bwd_passes > 0 && b[0].wpT16;
+    int accum[4];
+    for (int i = 0; i < n; ++i)
+        if (t_grad_mode(t, b[i].din, b[i].in_g0, b[i].c4_in, &accum[i])) return -2;
+    if (!f16) {
+        ConvArgs ca[4];
+        for (int i = 0; i < n; ++i) {
+            ca[i] = t_conv_args(t, b[i].dy, b[i].dy_g0, b[i].c4k, b[i].din, b[i].in_g0, b[i].c4_in, b[i].wpT, t->zero_bias, b[i].nstepsT, b[i].k, b[i].dil, accum[i]);
+            ca[i].dscale = t->scales + b[i].sg;
+        }
+        return t_conv(c, ca, n, b[0].n_otT);
+    }
+    if (b[0].n_otT > 8 && n != 1) return fail("ojf_trainer: grouped backward-data wider than 128 channels");
+    for (int ot0 = 0; ot0 < b[0].n_otT; ot0 += 8) {
+        const int nt = b[0].n_otT - ot0 < 8 ? b[0].n_otT - ot0 : 8;
+        ConvArgs ca[4];
+        for (int i = 0; i < n; ++i) {
+            const float *wp = b[i].wpT16 + (size_t)(b[i].nsteps16T + kPad16) * ot0 * 128 * 4;
+            ca[i] = t_conv_args16(t, b[i].dy, b[i].dy_g0, b[i].c4k, b[i].din, b[i].in_g0 + ot0 * 4, 0, wp, b[i].rinvT16 + (size_t)ot0 * 16,
+                                  t->zero_bias, b[i].nsteps16T, b[i].k, b[i].dil);
+            const int left = b[i].c4_in - ot0 * 4;
+            ca[i].og_store = left < nt * 4 ? left : nt * 4;
+            ca[i].accum = accum[i];
+            ca[i].dscale = t->scales + b[i].sg;
+        }
+        if (launch_conv_args(ca, n, nt, c.st, OJF_ARITH_F16X3)) return -2;
+        ++t->launches;
+    }
     return 0;
 }
 
@@ -848,6 +1052,7 @@ static int t_units_backward(TCtx &c, const int *ids, int n, bool tail = true)
         a.dgamma = u.has_bn ? l.grad_gamma : nullptr; a.dbeta = u.has_bn ? l.grad_beta : nullptr; a.dbias = l.bias ? l.grad_bias : nullptr;
         a.accumulate = l.accumulate ? 1 : 0;
         a.sum_dy = u.sum_dy;
+        a.dy_scale = t->scales + u.sg; a.dy_max = u.dymax_blocks;  // (grid.x <= 128 blocks per channel group)
         grp.g[i] = a;
     }
     const int c4 = t->units[ids[0]].c4_out;
@@ -874,7 +1079,7 @@ static int t_units_backward(TCtx &c, const int *ids, int n, bool tail = true)
             WgradReduceArgs r;
             r.partial = u.wpart; r.dw = l.grad_weight; r.slabs = u.wplan.slabs; r.taps = taps; r.ocp = u.wplan.ocp; r.icp = u.wplan.icp;
             r.OC = u.OC; r.IC = u.IC; r.group = u.group; r.slot = u.slot; r.c_in_phys = 4 * u.c4_in; r.accumulate = l.accumulate ? 1 : 0; r.oc_base = 0;
-            r.ic_base = u.ic_base; r.ic_total = u.IC_total;
+            r.ic_base = u.ic_base; r.ic_total = u.IC_total; r.dy_scale = t->scales + u.sg;
             rg.g[i] = r;
             total = (long)taps * u.OC * 4 * u.c4_in * 8;
             if (!l.grad_weight) return fail("ojf_trainer_backward: layer without a weight-gradient tensor");
@@ -890,14 +1095,12 @@ static int t_units_backward(TCtx &c, const int *ids, int n, bool tail = true)
     }
     // backward-data: d in (+)= conv(dy, transposed + flipped weights)
     if (t->units[ids[0]].din) {
-        ConvArgs ca[4];
+        TBwdData bd[4];
         for (int i = 0; i < n; ++i) {
             const TUnit &u = t->units[ids[i]];
-            int accum = 0;
-            if (t_grad_mode(t, u.din, u.in_g0, u.c4_in, &accum)) return -2;
-            ca[i] = t_conv_args(t, u.dy, u.y_g0, u.c4_out, u.din, u.in_g0, u.c4_in, u.wpT, t->zero_bias, u.nstepsT, u.k, u.dil, accum);
+            bd[i] = TBwdData{u.dy, u.y_g0, u.c4_out, u.din, u.in_g0, u.c4_in, u.wpT, u.nstepsT, u.wpT16, u.rinvT16, u.nsteps16T, u.n_otT, u.k, u.dil, u.sg};
         }
-        if (t_conv(c, ca, n, t->units[ids[0]].n_otT)) return -2;
+        if (t_backward_data(c, bd, n)) return -2;
     }
     return 0;
 }
@@ -908,7 +1111,7 @@ static int t_vortex_forward(TCtx &c, TVortex &v)
     const ojf_train_layer &lg = c.L[v.li0];
     if (!lg.weight || lg.out_channels != v.out_c || lg.in_channels != v.IC || lg.ksize != 1 || !lg.running_mean || !lg.running_var)
         return fail("ojf_trainer: global-average layer does not match the topology");
-    // global-average branch -> slot 0 of the concatenation
+    // global-average branch -> a bias of the final convolution (on the side stream it gained nothing: 191 vs 192 frames/s)
     hipLaunchKernelGGL(train_stats_partial_kernel, dim3(kTrainSlabs, v.c4x), dim3(256), 0, c.st, planes(v.x), 0, t->npix, v.gpartial);
     GaveTrainArgs g{};
     g.partial = v.gpartial; g.c4_in = v.c4x; g.c4_out = v.o4; g.IC = v.IC; g.OC = v.out_c; g.group = v.group; g.slot = v.slot; g.npix = t->npix;
@@ -974,7 +1177,7 @@ static int t_vortex_backward(TCtx &c, TVortex &v)
             WgradReduceArgs ra;
             ra.partial = v.wpart_stack; ra.dw = l.grad_weight; ra.slabs = a.slabs; ra.taps = 1; ra.ocp = a.ocp; ra.icp = a.icp;
             ra.OC = u.OC; ra.IC = u.IC; ra.group = u.group; ra.slot = u.slot; ra.c_in_phys = 4 * v.c4x; ra.accumulate = l.accumulate ? 1 : 0;
-            ra.oc_base = r * 4 * v.sl4; ra.ic_base = 0; ra.ic_total = u.IC;
+            ra.oc_base = r * 4 * v.sl4; ra.ic_base = 0; ra.ic_total = u.IC; ra.dy_scale = t->scales + u.sg;
             rg.g[r] = ra;
             total = (long)u.OC * 4 * v.c4x * 8;
         }
@@ -983,10 +1186,9 @@ static int t_vortex_backward(TCtx &c, TVortex &v)
     t->launches += 3;
     OJF_HIP(hipGetLastError());
     if (v.dx) {
-        int accum = 0;
-        if (t_grad_mode(t, v.dx, 0, v.c4x, &accum)) return -2;
-        ConvArgs ca = t_conv_args(t, v.du, 0, 4 * v.sl4, v.dx, 0, v.c4x, v.wpT_stack, t->zero_bias, v.nstepsT_s, 1, 1, accum);
-        if (t_conv(c, &ca, 1, v.n_otT_s)) return -2;
+        const TBwdData bd{v.du, 0, 4 * v.sl4, v.dx, 0, v.c4x, v.wpT_stack, v.nstepsT_s, v.wpT16_stack, v.rinvT16_stack, v.nsteps16T_s, v.n_otT_s, 1, 1,
+                          t->units[v.entry[0]].sg};
+        if (t_backward_data(c, &bd, 1)) return -2;
     }
     // global-average branch
     const ojf_train_layer &lg = c.L[v.li0];
@@ -1090,6 +1292,14 @@ OJF_API int ojf_trainer_create(ojf_trainer **out, int version, int n_points, int
         }
         t->est_planes = cur; t->dest_planes = dcur;
         if (li != t->n_layers) return fail("ojf_trainer_create: internal layer count mismatch");
+        if (t_alloc(t, reinterpret_cast<void **>(&t->scales), (size_t)t->n_sg * 4) || t_alloc(t, reinterpret_cast<void **>(&t->maxes), (size_t)t->n_sg * 4, true)) return -2;
+        std::vector<float> ones((size_t)t->n_sg, 1.0f);
+        OJF_HIP(hipMemcpy(t->scales, ones.data(), ones.size() * 4, hipMemcpyHostToDevice));
+        const int bx = (t->npix + 255) / 256 < 128 ? (t->npix + 255) / 256 : 128;
+        std::vector<DyMaxArgs> tab;
+        for (const TUnit &u : t->units) tab.push_back(DyMaxArgs{u.dymax_blocks, bx * u.c4_out, t->maxes + u.sg});
+        if (t_alloc(t, reinterpret_cast<void **>(&t->dymax_units), tab.size() * sizeof(DyMaxArgs))) return -2;
+        OJF_HIP(hipMemcpy(t->dymax_units, tab.data(), tab.size() * sizeof(DyMaxArgs), hipMemcpyHostToDevice));
         return 0;
     };
     rc = build();
@@ -1115,7 +1325,13 @@ OJF_API int ojf_trainer_set_arithmetic(ojf_trainer *t, int arithmetic)
 {
     using namespace ojf;
     if (!t || (arithmetic != OJF_ARITH_F32 && arithmetic != OJF_ARITH_F16X3)) return fail("ojf_trainer_set_arithmetic: bad argument");
-    if (t->fwd_arith != arithmetic) t->epoch = ~0ull;  // the packed copies of the other arithmetic are stale
+    if (t->fwd_arith != arithmetic) {
+        t->epoch = ~0ull;  // the packed copies of the other arithmetic are stale
+        t->bwd_passes = 0;
+        std::vector<float> ones((size_t)t->n_sg, 1.0f);
+        OJF_HIP(hipMemcpy(t->scales, ones.data(), ones.size() * 4, hipMemcpyHostToDevice));
+        OJF_HIP(hipMemset(t->maxes, 0, (size_t)t->n_sg * 4));
+    }
     t->fwd_arith = arithmetic;
     return 0;
 }
@@ -1200,6 +1416,12 @@ OJF_API int ojf_trainer_backward(ojf_trainer *t, const ojf_train_layer *layers, 
     if (t->use_side && t->side) {  // the gradient tensors are complete for whatever the caller enqueues next
         OJF_HIP(hipEventRecord(t->join_ev, t->side));
         OJF_HIP(hipStreamWaitEvent(c.st, t->join_ev, 0));
+    }
+    if (t->fwd_arith == OJF_ARITH_F16X3) {  // (every reader of this pass's factors has been enqueued)
+        hipLaunchKernelGGL(train_dy_max_reduce_kernel, dim3((unsigned)t->units.size()), dim3(256), 0, c.st, t->dymax_units);
+        hipLaunchKernelGGL(train_dy_scale_update_kernel, dim3((t->n_sg + 63) / 64), dim3(64), 0, c.st, t->scales, t->maxes, t->n_sg);
+        t->launches += 2;
+        ++t->bwd_passes;
     }
     return check_hip(hipGetLastError(), "ojf_trainer_backward");
 }

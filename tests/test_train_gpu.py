@@ -237,7 +237,7 @@ def test_gradients_accumulate_in_place_like_autograd(cuda):
     x = dict(tsdf_values=((torch.rand(1, 9, h, w, generator=g) - 0.5) * 0.2).to(cuda), tsdf_weights=(torch.rand(1, 9, h, w, generator=g) * 4).to(cuda),
              tsdf_frame=(torch.rand(1, 1, h, w, generator=g) * 4).to(cuda),
              semantic_frame=(torch.randint(1, 31, (1, 1, h, w), generator=g).float() / 30).to(cuda))
-    eng = HipTrainNet(net, inplace_grads=True)
+    eng = HipTrainNet(net, inplace_grads=True, arithmetic='f32')  # (bit-equality of pass 1 and 2: one arithmetic for both)
     eng(x).pow(2).mean().backward()
     once = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
     holders = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
@@ -360,3 +360,37 @@ def test_fuse_output_and_fusion_loss_kernels_match_the_tensor_formulas(cuda):
     fused = FuseOutput.apply(est_d, fv.to(cuda), fw.to(cuda), valid.to(cuda), init)
     (crit(fused, target.to(cuda)) * 3.0).backward()
     assert float((est_d.grad.cpu() - 3.0 * grad_ref).abs().max()) <= 3e-6 * scale
+
+
+@pytest.mark.parametrize('training', [False, True])
+@pytest.mark.parametrize('version,sem', [('v3', True), ('v2', False)])
+def test_executor_backward_data_in_split_fp16_from_the_second_pass(cuda, version, sem, training):
+    """The executor's first backward pass runs backward-data on fp32-input MFMAs and measures the magnitude of every dy
+    tensor; from the second pass on dy is stored with a power-of-two factor and backward-data runs in the split-fp16
+    arithmetic (ojf_trainer_backward).  Same frame, same weights (eval() mode, or train() mode without dropout: batch
+    statistics do not depend on the running buffers): passes 2 and 3 must reproduce pass 1's gradients to fp32-class
+    accuracy - per tensor within 2e-5 of max(its scale, 1e-3 of the largest gradient) in eval() mode; 2e-4 in train() mode,
+    where the batch-statistics chain amplifies any rounding difference (torch's own fp32 runs differ by 1e-2 there)."""
+    h, w = 40, 56
+    net = _net(version, sem, h, w).to(cuda).train(training)
+    g = torch.Generator().manual_seed(17)
+    x = dict(tsdf_values=((torch.rand(1, 9, h, w, generator=g) - 0.5) * 0.2).to(cuda), tsdf_weights=(torch.rand(1, 9, h, w, generator=g) * 4).to(cuda),
+             tsdf_frame=(torch.rand(1, 1, h, w, generator=g) * 4).to(cuda), semantic_frame=(torch.randint(1, 31, (1, 1, h, w), generator=g).float() / 30).to(cuda))
+    target = ((torch.rand(1, 9, h, w, generator=g) - 0.5) * 0.2).to(cuda)
+    params = [p for p in net.parameters()]
+    tn = HipTrainNet(net)
+    passes = []
+    for _ in range(3):
+        e = tn(x)
+        loss = (e - target).abs().mean() + 10 * ((e - target) ** 2).mean()
+        passes.append(torch.autograd.grad(loss, params, allow_unused=True))
+    gmax = max(float(a.abs().max()) for a in passes[0] if a is not None)
+    worst = 0.0
+    for k in (1, 2):
+        for p0, pk in zip(passes[0], passes[k]):
+            if p0 is None:
+                continue
+            scale = max(float(p0.abs().max()), 1e-3 * gmax)
+            worst = max(worst, float((p0 - pk).abs().max()) / scale)
+    print('split-fp16 backward-data %s sem=%s training=%s: worst deviation from the fp32 pass %.2e of a tensor\'s scale' % (version, sem, training, worst))
+    assert worst <= (2e-4 if training else 2e-5)
