@@ -314,11 +314,14 @@ def train_fusion(config, dataset, device, rank=0, world=1, max_steps=None, log=p
                 loss = frame_step(pipeline, criterion, batch, database, device)
                 if loss.grad_fn is not None:
                     loss.backward()
-                    losses.append(float(loss.item()))
-                    window += losses[-1]
+                    # train_fusion.py:172 reads loss.item() on every frame; the values are kept on the device and read at the
+                    # logging / evaluation boundaries instead (a host read per frame drains the queue: the frame step runs
+                    # asynchronously otherwise, pipeline.py::fuse_training)
+                    losses.append(loss.detach())
+                    window = window + losses[-1]
             if log_freq and (i + 1) % log_freq == 0:
                 if chief:
-                    workspace.writer.add_scalar('Train/loss', window / log_freq, global_step=i + 1 + epoch * n_steps)
+                    workspace.writer.add_scalar('Train/loss', float(window) / log_freq, global_step=i + 1 + epoch * n_steps)
                 window = 0.
             if opt.clipping:
                 torch.nn.utils.clip_grad_norm_(net.parameters(), max_norm=1., norm_type=2)
@@ -367,6 +370,7 @@ def train_fusion(config, dataset, device, rank=0, world=1, max_steps=None, log=p
                 break
         if done:
             break
+    losses = [float(v) for v in torch.stack(losses).cpu()] if losses else []  # one transfer for the whole run
     log('rank {} mean loss {:.6f} over {} frames'.format(rank, float(np.mean(losses)) if losses else float('nan'), len(losses)))
     return pipeline, database, losses
 
