@@ -12,13 +12,23 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- $B > $O/b
 python tools/kernel_trace_summary.py $(find $O/kt -name '*kernel_trace.csv' | head -1) 0 60 > $O/kernel_trace_summary.txt 2>&1
 cp $(find $O/kt -name '*kernel_stats.csv' | head -1) $O/bench_kernel_stats.csv
 bash tools/pmc_profile.sh $O
+# counter calibration on known byte counts (FETCH_SIZE / WRITE_SIZE units and the scattered-record pattern)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/cf -o cf -- python tools/pmc_calibrate.py > /dev/null 2> $O/cf.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/cw -o cw -- python tools/pmc_calibrate.py > /dev/null 2> $O/cw.err
+python tools/pmc_calibrate_summary.py $(find $O/cf -name '*counter_collection.csv' | head -1) $(find $O/cw -name '*counter_collection.csv' | head -1) > $O/pmc_calibration.txt 2>&1
+# SQ counters of the predict path (AdapNet++ engine + two-head net): MFMA-pipe utilisation per kernel
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $O/sqp -o sqp -- python bench.py --semantics --semantic-strategy predict --steps 20 --warmup 2 --lean > /dev/null 2> $O/sqp.err
+python tools/pmc_sq_summary.py $(find $O/sqp -name '*counter_collection.csv' | head -1) $O/sq_counters_predict.json > $O/sq_counters_predict.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kp -o kp -- python bench.py --semantics --semantic-strategy predict --steps 50 --warmup 10 --cpu-frames 0 --secondary 0 > $O/bench_predict.json 2> $O/kp.err
 cp $(find $O/kp -name '*kernel_stats.csv' | head -1) $O/predict_kernel_stats.csv
 python tools/train_throughput.py > $O/train_throughput.txt 2>&1
+python tools/train_throughput.py >> $O/train_throughput.txt 2>&1
+python bench.py --train --steps 64 --warmup 16 --repeats 5 > $O/bench_train.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktr -o ktr -- python tools/train_throughput.py > /dev/null 2> $O/ktr.err
 cp $(find $O/ktr -name '*kernel_stats.csv' | head -1) $O/train_kernel_stats.csv
+python tools/train_timeline.py $(find $O/ktr -name '*kernel_trace.csv' | head -1) > $O/train_timeline.txt 2>&1
 python tools/adapnet_engine_probe.py 2>&1 | grep -v MIOpen > $O/adapnet_engine_probe.txt
 python bench.py --mode parity --steps 100 --cpu-frames 0 --secondary 0 > $O/bench_parity.json 2>/dev/null
 python bench.py --height 120 --width 160 --grid 64 --cpu-frames 0 --secondary 0 > $O/bench_A.json 2>/dev/null
-rm -rf $O/kt $O/pf $O/pw $O/sq $O/kp $O/ktr
+rm -rf $O/kt $O/pf $O/pw $O/sq $O/kp $O/ktr $O/cf $O/cw $O/sqp
 ls -la $O
