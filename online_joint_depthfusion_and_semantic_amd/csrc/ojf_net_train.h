@@ -467,6 +467,10 @@ __global__ __launch_bounds__(64) void train_wgrad_mfma_kernel(const WgradGroup g
     for (int v = 0; v < 16; ++v) dst[(size_t)(8 * (v / 4) + 4 * k + (v % 4)) * a.icp] = acc[v];
 }
 
+// (Round 3 tried a row-merged form for the 3x3 layers - one wave = the three taps of a kernel row, dy staged once per three
+// taps, x once per 64 + 2 d pixel band with per-pixel tap masks at read time, a third of the traffic through L2: correct,
+// but 174 against 191 frames/s for the training step - a third of the waves with three accumulators each hide the LDS
+// transposes worse than they save fetches.)
 struct WgradReduceArgs {
     const float *partial;
     float *dw;  // [OC][IC][taps]
