@@ -266,7 +266,9 @@ int ojf_train_wgrad(const float *x_dev, int x_g0, int c_in_phys, const float *dy
  *   semantic channel) -> est [n_points][h][w] = net(x) * output_scale, all device fp32 NCHW.  weights_epoch: any number
  *   that changes whenever a weight or bias changed (the packed copies are refreshed then).
  * ojf_trainer_backward: d_est [n_points][h][w] -> parameter gradients; exactly one backward per forward (the forward's
- *   activations live in the trainer).  No gradient w.r.t. the inputs is produced (fuse_training's come from the volumes). */
+ *   activations live in the trainer).  No gradient w.r.t. the inputs is produced (fuse_training's come from the volumes).
+ * A trainer serves one stream at a time (its buffers, its side stream and its dy factors are per-trainer state); create one
+ * per concurrent training stream.  Frame sizes are arbitrary (no multiple-of-16 requirement). */
 typedef struct ojf_trainer ojf_trainer;
 typedef struct ojf_train_layer {
     const float *weight, *bias, *gamma, *beta;

@@ -15,7 +15,7 @@
 // first-touch lists live in per-tile slices of the workspace (tile t owns [t*2048, (t+1)*2048) of both), so
 // the hot path has NO same-address global atomics: three per-tile counter atomics on one cache line cost
 // 14 us per frame.  Only the rare hash-full entries and the entry-list path allocate from counters, behind
-// the slices.  The finalize pass walks the touched voxels, sums their 2-3 records, applies the running-mean
+// the slices.  The finalize pass walks the touched voxels, sums their ~2 records, applies the running-mean
 // update and zeroes the head entries, so every call leaves the workspace clean.
 //
 // PARITY mode (ojf_integrate_parity.hip) reproduces the reference's sequential fp32 sums bit for bit.
@@ -28,12 +28,17 @@ namespace ojf {
 
 constexpr int kSlots = 2048;
 constexpr unsigned int kEmpty = 0xffffffffu;
+// Pixel tile of one accumulate block: 16 x 8.  Round 3 (was 8 x 8): a tile's rays hit 1150-1390 distinct voxels at most
+// (host count over the bench streams at 320x240 -> 256^3 and 640x480 -> 512^3; 8 x 8: 730-810), still inside the 2048-slot
+// hash; a voxel now receives 2.1 instead of 2.6-2.9 records per frame, and 600 blocks at 320x240 are ONE round over the
+// 768 block slots of the chip where 1200 were 1.56 (= two) rounds of a latency-bound kernel.
+constexpr int kTileW = 16, kTileH = 8, kTilePix = kTileW * kTileH;
 
-static size_t tile_count(int h, int w) { return (size_t)((h + 7) / 8) * ((w + 7) / 8); }
+static size_t tile_count(int h, int w) { return (size_t)((h + kTileH - 1) / kTileH) * ((w + kTileW - 1) / kTileW); }
 // records / first touches: a 2048-element slice per tile, then room for every entry that found its tile's hash full
 static size_t list_capacity(int h, int w, int n_tail)
 {
-    const size_t per_tile = (size_t)64 * n_tail * 8;
+    const size_t per_tile = (size_t)kTilePix * n_tail * 8;
     return tile_count(h, w) * (kSlots + per_tile);
 }
 
@@ -56,14 +61,14 @@ __device__ __forceinline__ bool link_record(const IntegrateArgs &a, unsigned int
     return prev == 0;
 }
 
-// LDS-aggregated accumulate: one block owns an 8x8 pixel tile and all n_tail samples of its rays.
-// A wave is the 64 pixels of the tile at one ray offset, so its lanes hit a few dozen distinct voxels;
+// LDS-aggregated accumulate: one block owns a 16x8 pixel tile and all n_tail samples of its rays.
+// A wave is 64 pixels of the tile at one ray offset, so its lanes hit a few dozen distinct voxels;
 // colliding writes are first combined in a 2048-slot LDS hash (integer adds / maxima), and only one
-// record per (tile, voxel) goes to HBM (~16 entries/voxel -> ~2.6 tiles/voxel).  Entries that find the
+// record per (tile, voxel) goes to HBM (~22 entries/voxel -> 2.1 tiles/voxel).  Entries that find the
 // hash full become single-entry records.
-// SEM = false (geometry only) drops the two entry-id tables: 51 KB instead of 67 KB of LDS per block, i.e. three
+// SEM = false (geometry only) drops the two entry-id tables: 46 KB instead of 62 KB of LDS per block, i.e. three
 // blocks per CU instead of two for a kernel that is bound by the latency of its atomics.
-// threads of an accumulate block (one 8x8 tile): eight waves - the tile's 448 items in one pass, four slots per thread
+// threads of an accumulate block (one 16x8 tile): eight waves - the tile's 896 items in two passes, four slots per thread
 // to publish; LDS allows three blocks per CU either way (measured: 256 threads 62 us, 512 56 us, 1024 68 us per frame)
 constexpr int kAccThreads = 512;
 template <bool SEM>
@@ -74,20 +79,23 @@ __global__ __launch_bounds__(kAccThreads) void integrate_accumulate_tiled_kernel
     __shared__ unsigned long long accu[kSlots];
     __shared__ unsigned int elast[SEM ? kSlots : 1];
     __shared__ unsigned int ediff[SEM ? kSlots : 1];
-    __shared__ unsigned int newlist[kSlots];  // voxels this tile touched first
     __shared__ unsigned int n_entries, n_new, n_rec, base_rec;
-    __shared__ double frame[6][64];  // ray frame (voxel-space point, unit direction) of the tile's 64 pixels
+    __shared__ double frame[6][kTilePix];  // ray frame (voxel-space point, unit direction) of the tile's pixels
+    // slots of the voxels this tile touched first: 4 KB on top of the ray frames, which are dead once the items are done
+    // (46 KB per geometry-only block: three blocks per CU)
+    unsigned short *newlist = reinterpret_cast<unsigned short *>(&frame[0][0]);
+    static_assert(sizeof(frame) >= kSlots * sizeof(unsigned short), "newlist aliases the ray frames");
     for (int s = threadIdx.x; s < kSlots; s += kAccThreads) {
         keys[s] = kEmpty; accw[s] = 0; accu[s] = 0;
         if constexpr (SEM) { elast[s] = 0; ediff[s] = 0; }
     }
     if (threadIdx.x == 0) { n_entries = 0; n_new = 0; n_rec = 0; }
-    const int tiles_x = (a.w + 7) >> 3;
+    const int tiles_x = (a.w + kTileW - 1) / kTileW;
     const int tile = banded_block_x();  // one band of the image per XCD: neighbouring tiles hit the same voxels
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    if (threadIdx.x < 64) {  // once per pixel instead of once per (pixel, sample): three fp64 divisions and a sqrt each
+    if (threadIdx.x < kTilePix) {  // once per pixel instead of once per (pixel, sample): three fp64 divisions and a sqrt each
         const int p = threadIdx.x;
-        const int r = ty * 8 + (p >> 3), c = tx * 8 + (p & 7);
+        const int r = ty * kTileH + p / kTileW, c = tx * kTileW + p % kTileW;
         if (r < a.h && c < a.w) {
             float pw[3];
             double cv[3], dir[3];
@@ -105,9 +113,9 @@ __global__ __launch_bounds__(kAccThreads) void integrate_accumulate_tiled_kernel
     constexpr bool sem = SEM;
     const int half = (a.n_points - 1) / 2;
     unsigned int n_in = 0;
-    for (int item = threadIdx.x; item < 64 * a.n_tail; item += kAccThreads) {
-        const int k = item >> 6, p = item & 63;
-        const int r = ty * 8 + (p >> 3), c = tx * 8 + (p & 7);
+    for (int item = threadIdx.x; item < kTilePix * a.n_tail; item += kAccThreads) {
+        const int k = item / kTilePix, p = item % kTilePix;
+        const int r = ty * kTileH + p / kTileW, c = tx * kTileW + p % kTileW;
         if (r >= a.h || c >= a.w) continue;
         const int n = r * a.w + c;
         const float z = frame_depth(a, n);
@@ -187,11 +195,11 @@ __global__ __launch_bounds__(kAccThreads) void integrate_accumulate_tiled_kernel
         r.lin = keys[s]; r.next = prev[j]; r.w = accw[s]; r.u = accu[s];
         r.e_last = SEM ? elast[s] : 0u; r.e_diff = SEM ? ediff[s] : 0u;
         a.recs[base_rec + mine[j]] = r;
-        if (prev[j] == 0) newlist[atomicAdd(&n_new, 1u)] = r.lin;
+        if (prev[j] == 0) newlist[atomicAdd(&n_new, 1u)] = (unsigned short)s;
     }
     __syncthreads();
     if (threadIdx.x == 0) a.tile_new[tile] = n_new;
-    for (unsigned int i = threadIdx.x; i < n_new; i += kAccThreads) a.touched[tile * kSlots + i] = newlist[i];
+    for (unsigned int i = threadIdx.x; i < n_new; i += kAccThreads) a.touched[tile * kSlots + i] = keys[newlist[i]];
 }
 
 // Entry-list variant for the reference's own Integrator.forward signature (modules/integrator.py:15-126):

@@ -115,7 +115,7 @@ def _net(version, sem, h, w, seed=3):
     return net
 
 
-def _whole_net_gradient_case(cuda, version, sem, training, path, h, w):
+def _whole_net_gradient_case(cuda, version, sem, training, path, h, w, noise_factor=2.0):
     graph = path == 'graph'
     net = _net(version, sem, h, w)
     ref, ref32 = copy.deepcopy(net).double(), copy.deepcopy(net)
@@ -148,7 +148,7 @@ def _whole_net_gradient_case(cuda, version, sem, training, path, h, w):
     def bar(got, fp32, truth, floor, what):
         got, fp32, truth = got.detach().cpu().double(), fp32.detach().double(), truth.detach()
         e, e32 = float((got - truth).abs().max()), float((fp32 - truth).abs().max())
-        assert e <= max(REL * floor, 2.5 * e32, 2.0 * noise * floor), (what, e, e32, floor, noise)
+        assert e <= max(REL * floor, 2.5 * e32, noise_factor * noise * floor), (what, e, e32, floor, noise)
         return e / max(e32, REL * floor)
     worst = bar(est, est32, est_ref, float(est_ref.abs().max()), 'est')
     for (name, p), (_, q32), (_, q) in zip(net.named_parameters(), ref32.named_parameters(), ref.named_parameters()):
@@ -179,6 +179,17 @@ def test_whole_net_gradients_against_torch_autograd(cuda, version, sem, training
     Paths: 'executor' = the whole pass as two libojf calls (ojf_trainer_*, the default), 'units' = one autograd node per
     layer unit, 'graph' = the unit path captured into device graphs (HipTrainNet(graph=True))."""
     _whole_net_gradient_case(cuda, version, sem, training, path, 40, 56)
+
+
+@pytest.mark.parametrize('h,w', [(13, 15), (23, 37)])
+@pytest.mark.parametrize('training', [True, False])
+def test_whole_net_gradients_on_ragged_frames(cuda, training, h, w):
+    """Frames whose pixel count is no multiple of the 16-pixel MFMA tiles, the 64-pixel weight-gradient chunks, the 32 x 8
+    pooling tiles or the 64 reduction slabs (and, at 13 x 15, smaller than the dilation-27 reach): the executor's padding
+    lanes and partial slabs against float64 torch."""
+    # (batch statistics over 195 / 851 pixels amplify rounding more than over 2 240: three instead of two noise levels -
+    # the eval() cases, which see the same padding lanes and partial slabs, sit at 0.01-0.02 of torch fp32's own deviation)
+    _whole_net_gradient_case(cuda, 'v3', True, training, 'executor', h, w, noise_factor=3.0)
 
 
 @pytest.mark.parametrize('version,sem,training', [('v3', False, True), ('v3', True, False)])
