@@ -197,6 +197,42 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x4 (&a
         if (gmax > 65504.0f && a.ovf) *a.ovf = 1;
 }
 
+// The common case of the split-fp16 launches - planar output, ReLU / LeakyReLU / no activation on every stored channel,
+// unit scale, plain store - without the generic epilogue's per-value branches (row output, tanh, partial activation,
+// scale pointers): the same operations on the same values in the same order, i.e. the same bits, in ~1/3 of the
+// instructions (the grouped 19 -> 19 convolutions issue 9 VALU per MFMA and half of a wave's instructions were its
+// prologue and epilogue: r03_final_inst_counters.txt).  The host picks it per launch (conv_lean_ok).
+template <int MT, int NT>
+__device__ __forceinline__ void conv_epilogue_lean(const ConvArgs &a, const f32x4 (&acc)[MT][NT], int strip, int i16, int g,
+                                                   const f32x4 (&bvec)[NT], const f32x4 (&rvec)[NT])
+{
+    const float slope = act_slope(a.act);
+    float gmax = 0.0f;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int og = n * 4 + g;
+        if (og >= a.og_store) continue;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int p = strip + m * 16 + i16;
+            const f32x4 lin4 = fma4(acc[m][n], rvec[n], bvec[n]);
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = lin4[j] > 0.0f ? lin4[j] : lin4[j] * slope;
+            if (p < a.npix) {
+                a.out[(size_t)(a.out_g0 + og) * a.npix + p] = v;
+                gmax = guard_max(gmax, lin4);
+            }
+        }
+    }
+    if (gmax > 65504.0f && a.ovf) *a.ovf = 1;
+}
+
+static inline bool conv_lean_ok(const ConvArgs &a)
+{
+    return !a.out_rows && a.act != OJF_ACT_TANH && (a.act == OJF_ACT_NONE || a.act_n >= 4 * a.og_store) && a.scale == 1.0f && !a.dscale && !a.accum;
+}
+
 // Per-(superstep, slot) source table: float4 index of the tap's plane origin relative to a.in (-1 = the zero
 // float4 every activation buffer keeps in front of its planes) and the tap's (dy, dx) packed in one int.
 __device__ __forceinline__ void build_tap_table(int2 *tab, const ConvArgs &a, int entries)
@@ -445,7 +481,7 @@ constexpr int conv16_chunk(int nt) { return nt <= 2 ? 6 : 3; }  // supersteps pe
 
 // ABL: profiling-only ablation mask (tests/microbench): 1 = no activation loads, 2 = no LDS weight reads,
 // 4 = no MFMA, 8 = no fp16 split.  Product launches always use ABL = 0.
-template <int MT, int NT, bool SKIP = true, int ABL = 0>
+template <int MT, int NT, bool SKIP = true, int ABL = 0, bool LEAN = false>
 __global__ __launch_bounds__(256) void conv_f16x3_kernel(const ConvGroup grp)
 {
     constexpr int CS = conv16_chunk(NT);
@@ -584,7 +620,8 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const ConvGroup grp)
             rvec[n] = *reinterpret_cast<const f32x4 *>(a.rinv + (size_t)n * 16 + 4 * g);
         }
     }
-    conv_epilogue<MT, NT, true>(a, acc, strip, i16, g, bvec, rvec);
+    if constexpr (LEAN) conv_epilogue_lean<MT, NT>(a, acc, strip, i16, g, bvec, rvec);
+    else conv_epilogue<MT, NT, true>(a, acc, strip, i16, g, bvec, rvec);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1769,7 +1806,14 @@ static int launch_conv_args(const ConvArgs *args, int n, int nt, hipStream_t st,
         grp.nblocks = (int)grid.x;
         grid16.x = round_up((int)grid.x, 8);
     }
-#define OJF_LAUNCH16(MT_, NT_) hipLaunchKernelGGL((conv_f16x3_kernel<MT_, NT_>), grid16, block, tab_bytes, st, grp)
+    static const bool no_lean = getenv("OJF_CONV_LEAN") && atoi(getenv("OJF_CONV_LEAN")) == 0;  // A/B switch
+    bool lean = arith == OJF_ARITH_F16X3 && !no_lean;
+    for (int i = 0; i < n && lean; ++i) lean = conv_lean_ok(args[i]);
+#define OJF_LAUNCH16(MT_, NT_)                                                                                      \
+    do {                                                                                                             \
+        if (lean) hipLaunchKernelGGL((conv_f16x3_kernel<MT_, NT_, true, 0, true>), grid16, block, tab_bytes, st, grp); \
+        else hipLaunchKernelGGL((conv_f16x3_kernel<MT_, NT_>), grid16, block, tab_bytes, st, grp);                   \
+    } while (0)
     if (arith == OJF_ARITH_F16X3 && mt == 2) {
         switch (nt) {
             case 2: OJF_LAUNCH16(2, 2); break;
