@@ -150,6 +150,27 @@ __device__ __forceinline__ float act_slope(int act)
 {
     return act == OJF_ACT_RELU ? 0.0f : (act == OJF_ACT_LEAKY ? 0.01f : 1.0f);
 }
+// x > 0 ? x : slope * x for 0 <= slope <= 1 as max(x, slope * x): one multiply (packed with its neighbour) + one max
+// instead of compare + select + multiply - a third of the VALU instructions of the fused tails were activations.  The
+// same bits for every finite x, +-0 and NaN (max(NaN, NaN) = NaN); -inf under ReLU gives -inf where the select form gave
+// NaN (-inf * 0) - both are outside the range the split-fp16 guard admits.
+// (v_max_f32 by hand: fmaxf() makes the compiler canonicalise both operands with an extra max each and unpack the
+// neighbouring packed multiplies)
+__device__ __forceinline__ float leaky_max(float x, float slope)
+{
+    const float sx = slope * x;
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(sx));
+    return r;
+}
+__device__ __forceinline__ f32x4 leaky_max4(const f32x4 &x, float slope)
+{
+    const f32x4 sx = x * slope;  // two v_pk_mul_f32
+    f32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm("v_max_f32 %0, %1, %2" : "=v"(r[j]) : "v"(x[j]), "v"(sx[j]));
+    return r;
+}
 
 constexpr int kMaxSteps = 128;  // supersteps per conv (K <= 2048)
 constexpr int kPadSteps = 4;    // dead supersteps appended for the three-stage prefetch (fetches reach S+4)
@@ -216,9 +237,7 @@ __device__ __forceinline__ void conv_epilogue_lean(const ConvArgs &a, const f32x
         for (int m = 0; m < MT; ++m) {
             const int p = strip + m * 16 + i16;
             const f32x4 lin4 = fma4(acc[m][n], rvec[n], bvec[n]);
-            f32x4 v;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = lin4[j] > 0.0f ? lin4[j] : lin4[j] * slope;
+            const f32x4 v = leaky_max4(lin4, slope);
             if (p < a.npix) {
                 a.out[(size_t)(a.out_g0 + og) * a.npix + p] = v;
                 gmax = guard_max(gmax, lin4);
@@ -882,8 +901,7 @@ __device__ __forceinline__ void chain_layer(const f32x4 (&in)[MT][NA], f32x4 (&o
                     }
                 } else {
                     constexpr float slope = MODE == kChainRelu ? 0.0f : 0.01f;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.0f ? v[j] : slope * v[j];
+                    v = leaky_max4(v, slope);
                     if constexpr (ARITH == OJF_ARITH_F16X3) gmax = guard_max(gmax, lin4);  // pre-activation magnitude
                     out[m][n2] = v;
                 }

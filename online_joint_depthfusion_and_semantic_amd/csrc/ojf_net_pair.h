@@ -254,7 +254,7 @@ __global__ __launch_bounds__(1024) void dense_pair_kernel(const PairArgs a)
                 if (ok) gmax = guard_max(gmax, lin);
                 f32x4 v;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = ok ? (lin[j] > 0.0f ? lin[j] : 0.01f * lin[j]) : 0.0f;
+                for (int j = 0; j < 4; ++j) v[j] = ok ? leaky_max(lin[j], 0.01f) : 0.0f;
                 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
                 const f16x4 h4 = __builtin_convertvector(v, f16x4);
                 const uint2 hp = __builtin_bit_cast(uint2, h4);
@@ -305,9 +305,7 @@ __global__ __launch_bounds__(1024) void dense_pair_kernel(const PairArgs a)
                 if (og >= a.og_store) continue;
                 const f32x4 lin = fma4(accb[m][n], rv[n], bv[n]);
                 gmax = guard_max(gmax, lin);
-                f32x4 v;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = lin[j] > 0.0f ? lin[j] : 0.01f * lin[j];
+                const f32x4 v = leaky_max4(lin, 0.01f);
                 a.out[(size_t)(a.out_g0 + og) * a.npix + p] = v;
             }
         }
