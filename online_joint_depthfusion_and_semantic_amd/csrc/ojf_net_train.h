@@ -383,6 +383,7 @@ struct WgradArgs {
     const f32x4 *dy;  // gradient planes of its output (window at dy_g0, c4_out groups)
     float *partial;   // [slabs][taps][ocp][icp], ocp / icp = channel counts rounded up to 32
     int x_g0, c4_in, dy_g0, c4_out, h, w, npix, taps, dil, slabs, ocp, icp;
+    int *ovf;  // split-fp16 form: range-guard flag for dy where no backward-data convolution checks it (else NULL)
 };
 
 // One wave (= one block) = one 32 x 32 (oc, ic) tile of ONE tap over one
@@ -400,6 +401,13 @@ constexpr int kWgChunk = 64, kWgPitch = 36;
 
 struct WgradGroup { WgradArgs g[4]; int tiles; };  // blockIdx.y = unit * tiles + (oc, ic) tile
 
+// F16: split-fp16 form (v_mfma_f32_32x32x16_f16, three per 16 pixels: dy_hi x_hi + dy_hi x_lo + dy_lo x_hi, fp32 accumulate)
+// for passes whose dy carries its power-of-two factor (the trainer's second backward pass on) - the matrix pipe's share of a
+// 64-pixel chunk drops from 32 x 64 to 12 x 32 cycles.  Same staging; the transposed LDS reads fetch EIGHT consecutive
+// pixels of the lane's channel (K = 8 k .. 8 k + 7 of a 16-pixel step, the same pixels for A and for B) and are split in
+// registers.  x is an activation the forward convolution already split (inside the fp16 range by its guard); dy is
+// guarded by the backward-data convolution that reads the same planes, or here (a.ovf) where there is none.
+template <bool F16>
 __global__ __launch_bounds__(64) void train_wgrad_mfma_kernel(const WgradGroup grp, unsigned w_magic)
 {
     __shared__ __attribute__((aligned(16))) float tile[2][kWgChunk * kWgPitch];
@@ -419,6 +427,7 @@ __global__ __launch_bounds__(64) void train_wgrad_mfma_kernel(const WgradGroup g
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
     f32x4 dv[8], xv[8];
+    float gmax = 0.0f;
     auto fetch = [&](int pc) {  // this lane's pixel of the chunk at pc: its eight channel groups of dy and of x
         const int p = pc + lane;
         const int py = fast_div(p, a.w, w_magic), px = p - py * a.w;
@@ -438,29 +447,60 @@ __global__ __launch_bounds__(64) void train_wgrad_mfma_kernel(const WgradGroup g
         for (int g = 0; g < 8; ++g) {
             *reinterpret_cast<f32x4 *>(&tile[0][lane * kWgPitch + 4 * g]) = dv[g];
             *reinterpret_cast<f32x4 *>(&tile[1][lane * kWgPitch + 4 * g]) = xv[g];
+            if constexpr (F16)
+                if (a.ovf) gmax = guard_max(gmax, dv[g]);
         }
         __syncthreads();
         fetch(pc + kWgChunk);  // the next chunk travels while this one is multiplied (past the slab: all zeros, no traffic)
-        // operands of eight K steps per register block; the next block's LDS reads are issued before this block's
-        // MFMAs (read -> wait -> 2 MFMAs, as the compiler schedules the plain loop, exposes the LDS latency 16 times)
-        float av[2][8], bv[2][8];
-        auto read_block = [&](int blk, float (&ar)[8], float (&br)[8]) {
+        if constexpr (F16) {
+            // a register block = one 16-pixel K step: 8 + 8 transposed reads, two splits, three MFMAs
+            float av[2][8], bv[2][8];
+            auto read_step = [&](int s, float (&ar)[8], float (&br)[8]) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                ar[u] = tile[0][(2 * (8 * blk + u) + k) * kWgPitch + r];
-                br[u] = tile[1][(2 * (8 * blk + u) + k) * kWgPitch + r];
+                for (int u = 0; u < 8; ++u) {
+                    ar[u] = tile[0][(16 * s + 8 * k + u) * kWgPitch + r];
+                    br[u] = tile[1][(16 * s + 8 * k + u) * kWgPitch + r];
+                }
+            };
+            read_step(0, av[0], bv[0]);
+#pragma unroll
+            for (int s = 0; s < kWgChunk / 16; ++s) {
+                if (s + 1 < kWgChunk / 16) read_step(s + 1, av[(s + 1) & 1], bv[(s + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const float(&ar)[8] = av[s & 1];
+                const float(&br)[8] = bv[s & 1];
+                f16x8 dh, dl, xh, xl;
+                split_f16(f32x4{ar[0], ar[1], ar[2], ar[3]}, f32x4{ar[4], ar[5], ar[6], ar[7]}, dh, dl);
+                split_f16(f32x4{br[0], br[1], br[2], br[3]}, f32x4{br[4], br[5], br[6], br[7]}, xh, xl);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(dl, xh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh, xl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh, xh, acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-        };
-        read_block(0, av[0], bv[0]);
+        } else {
+            // operands of eight K steps per register block; the next block's LDS reads are issued before this block's
+            // MFMAs (read -> wait -> 2 MFMAs, as the compiler schedules the plain loop, exposes the LDS latency 16 times)
+            float av[2][8], bv[2][8];
+            auto read_block = [&](int blk, float (&ar)[8], float (&br)[8]) {
 #pragma unroll
-        for (int blk = 0; blk < kWgChunk / 16; ++blk) {
-            if (blk + 1 < kWgChunk / 16) read_block(blk + 1, av[(blk + 1) & 1], bv[(blk + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks every read next to its MFMA again)
+                for (int u = 0; u < 8; ++u) {
+                    ar[u] = tile[0][(2 * (8 * blk + u) + k) * kWgPitch + r];
+                    br[u] = tile[1][(2 * (8 * blk + u) + k) * kWgPitch + r];
+                }
+            };
+            read_block(0, av[0], bv[0]);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[blk & 1][u], bv[blk & 1][u], acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int blk = 0; blk < kWgChunk / 16; ++blk) {
+                if (blk + 1 < kWgChunk / 16) read_block(blk + 1, av[(blk + 1) & 1], bv[(blk + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks every read next to its MFMA again)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[blk & 1][u], bv[blk & 1][u], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
+    if constexpr (F16)
+        if (a.ovf && gmax > 65504.0f) *a.ovf = 1;
     // D layout: acc[v] = D[i][j], j = lane % 32 (ic), i = 8 * (v / 4) + 4 * (lane / 32) + v % 4 (oc)
     float *dst = a.partial + (((size_t)blockIdx.x * a.taps + tap) * a.ocp + (size_t)ot * 32) * a.icp + (size_t)it * 32 + r;
 #pragma unroll
@@ -701,7 +741,8 @@ OJF_API int ojf_train_wgrad(const float *x, int x_g0, int c_in_phys, const float
     WgradArgs a;
     a.x = planes(x); a.dy = planes(dy); a.partial = partial; a.x_g0 = x_g0; a.c4_in = c_in_phys / 4; a.dy_g0 = dy_g0; a.c4_out = c_out_phys / 4;
     a.h = h; a.w = w; a.npix = h * w; a.taps = taps; a.dil = dil; a.slabs = p.slabs; a.ocp = p.ocp; a.icp = p.icp;
-    hipLaunchKernelGGL(train_wgrad_mfma_kernel, dim3(p.slabs, (p.ocp / 32) * (p.icp / 32), taps), dim3(64), 0, st,
+    a.ovf = nullptr;
+    hipLaunchKernelGGL(train_wgrad_mfma_kernel<false>, dim3(p.slabs, (p.ocp / 32) * (p.icp / 32), taps), dim3(64), 0, st,
                        WgradGroup{{a, a, a, a}, (p.ocp / 32) * (p.icp / 32)}, div_magic(w, (uint64_t)h * w + 2 * kWgChunk));
     WgradReduceArgs r;
     r.partial = partial; r.dw = dw; r.slabs = p.slabs; r.taps = taps; r.ocp = p.ocp; r.icp = p.icp; r.OC = OC; r.IC = IC;

@@ -1040,6 +1040,13 @@ static int t_units_forward(TCtx &c, const int *ids, int n, bool conv = true)
 
 // backward of up to four units: BatchNorm / activation backward (dy, d gamma, d beta, d bias); then - unless `tail` is
 // false (stacked entry: the caller pools dy first) - the weight gradient and backward-data
+// weight gradients in split-fp16: with the forward arithmetic, from the pass on whose dy carries measured factors
+static inline bool t_wgrad_f16(const ojf_trainer *t)
+{
+    static const bool off = getenv("OJF_TRAIN_WGRAD16") && atoi(getenv("OJF_TRAIN_WGRAD16")) == 0;  // A/B switch
+    return !off && t->fwd_arith == OJF_ARITH_F16X3 && t->bwd_passes > 0;
+}
+
 static int t_units_backward(TCtx &c, const int *ids, int n, bool tail = true)
 {
     ojf_trainer *t = c.t;
@@ -1075,6 +1082,7 @@ static int t_units_backward(TCtx &c, const int *ids, int n, bool tail = true)
             WgradArgs a;
             a.x = planes(u.in); a.dy = planes(u.dy); a.partial = u.wpart; a.x_g0 = u.in_g0; a.c4_in = u.c4_in; a.dy_g0 = u.y_g0; a.c4_out = u.c4_out;
             a.h = t->h; a.w = t->w; a.npix = t->npix; a.taps = taps; a.dil = u.dil; a.slabs = u.wplan.slabs; a.ocp = u.wplan.ocp; a.icp = u.wplan.icp;
+            a.ovf = u.din ? nullptr : overflow_flag();  // (dy of a unit with a backward-data convolution is range-checked there)
             wg.g[i] = a;
             WgradReduceArgs r;
             r.partial = u.wpart; r.dw = l.grad_weight; r.slabs = u.wplan.slabs; r.taps = taps; r.ocp = u.wplan.ocp; r.icp = u.wplan.icp;
@@ -1087,8 +1095,12 @@ static int t_units_backward(TCtx &c, const int *ids, int n, bool tail = true)
         wg.tiles = tiles;
         hipStream_t ws;
         if (t_wgrad_stream(c, &ws)) return -2;
-        hipLaunchKernelGGL(train_wgrad_mfma_kernel, dim3(u0.wplan.slabs, tiles * n, taps), dim3(64), 0, ws, wg,
-                           div_magic(t->w, (uint64_t)t->npix + 2 * kWgChunk));
+        if (t_wgrad_f16(t))
+            hipLaunchKernelGGL(train_wgrad_mfma_kernel<true>, dim3(u0.wplan.slabs, tiles * n, taps), dim3(64), 0, ws, wg,
+                               div_magic(t->w, (uint64_t)t->npix + 2 * kWgChunk));
+        else
+            hipLaunchKernelGGL(train_wgrad_mfma_kernel<false>, dim3(u0.wplan.slabs, tiles * n, taps), dim3(64), 0, ws, wg,
+                               div_magic(t->w, (uint64_t)t->npix + 2 * kWgChunk));
         hipLaunchKernelGGL(train_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256), n), dim3(256), 0, ws, rg);
         t->launches += 2;
         OJF_HIP(hipGetLastError());
@@ -1162,12 +1174,17 @@ static int t_vortex_backward(TCtx &c, TVortex &v)
         WgradArgs a;
         a.x = planes(v.x); a.dy = planes(v.du); a.partial = v.wpart_stack; a.x_g0 = 0; a.c4_in = v.c4x; a.dy_g0 = 0; a.c4_out = 4 * v.sl4;
         a.h = t->h; a.w = t->w; a.npix = t->npix; a.taps = 1; a.dil = 1; a.slabs = v.wplan_s.slabs; a.ocp = v.wplan_s.ocp; a.icp = v.wplan_s.icp;
+        a.ovf = nullptr;
         const int wt = (a.ocp / 32) * (a.icp / 32);
         hipStream_t ws;
         hipLaunchKernelGGL(train_pyramid_kernel, dim3(tiles, 4 * v.sl4), dim3(256), 0, c.st, pa);
         if (t_wgrad_stream(c, &ws)) return -2;
-        hipLaunchKernelGGL(train_wgrad_mfma_kernel, dim3(a.slabs, wt, 1), dim3(64), 0, ws, WgradGroup{{a, a, a, a}, wt},
-                           div_magic(t->w, (uint64_t)t->npix + 2 * kWgChunk));
+        if (t_wgrad_f16(t))
+            hipLaunchKernelGGL(train_wgrad_mfma_kernel<true>, dim3(a.slabs, wt, 1), dim3(64), 0, ws, WgradGroup{{a, a, a, a}, wt},
+                               div_magic(t->w, (uint64_t)t->npix + 2 * kWgChunk));
+        else
+            hipLaunchKernelGGL(train_wgrad_mfma_kernel<false>, dim3(a.slabs, wt, 1), dim3(64), 0, ws, WgradGroup{{a, a, a, a}, wt},
+                               div_magic(t->w, (uint64_t)t->npix + 2 * kWgChunk));
         WgradReduceGroup rg;
         long total = 0;
         for (int r = 0; r < 4; ++r) {
