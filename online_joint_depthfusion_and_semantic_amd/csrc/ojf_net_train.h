@@ -422,22 +422,31 @@ __global__ __launch_bounds__(64) void train_wgrad_mfma_kernel(const WgradGroup g
     const int per = ((a.npix + a.slabs - 1) / a.slabs + 1) & ~1;  // even: a K step never straddles two slabs
     const int p0 = blockIdx.x * per, p1 = min(a.npix, p0 + per);
     const int shift = dyo * a.w + dxo;
-    const f32x4 zero{0.f, 0.f, 0.f, 0.f};
     f32x16 acc;
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
     f32x4 dv[8], xv[8];
     float gmax = 0.0f;
+    // buffer loads: a lane outside the slab / a tap outside the image gets an offset beyond the descriptor's range and
+    // reads zeros, and so does a channel group outside the tensor - no per-load branches (as plain predicated loads the
+    // sixteen fetches of a chunk were sixteen exec-mask regions, ~130 VALU + ~240 scalar instructions)
+    const int n_og = min(8, a.c4_out - ot * 8), n_ig = min(8, a.c4_in - it * 8);
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<f32x4 *>(a.dy + (size_t)(a.dy_g0 + ot * 8) * a.npix), 0, n_og * a.npix * 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<f32x4 *>(a.x + (size_t)(a.x_g0 + it * 8) * a.npix), 0, n_ig * a.npix * 16, 0x00020000);
+    const int plane = a.npix * 16;
     auto fetch = [&](int pc) {  // this lane's pixel of the chunk at pc: its eight channel groups of dy and of x
         const int p = pc + lane;
         const int py = fast_div(p, a.w, w_magic), px = p - py * a.w;
         const bool in = p < p1;
         const bool tap_ok = in && (unsigned)(py + dyo) < (unsigned)a.h && (unsigned)(px + dxo) < (unsigned)a.w;
+        const unsigned od = in ? (unsigned)p * 16u : 0x80000000u, ox = tap_ok ? (unsigned)(p + shift) * 16u : 0x80000000u;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            const int og = ot * 8 + g, ig = it * 8 + g;
-            dv[g] = (in && og < a.c4_out) ? a.dy[(size_t)(a.dy_g0 + og) * a.npix + p] : zero;
-            xv[g] = (tap_ok && ig < a.c4_in) ? a.x[(size_t)(a.x_g0 + ig) * a.npix + p + shift] : zero;
+            // (the plane offset rides in the per-lane offset, which the range check sees: groups past the tensor read zeros too)
+            dv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, od + (unsigned)(g * plane), 0, 0));
+            xv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, ox + (unsigned)(g * plane), 0, 0));
         }
     };
     fetch(p0);
@@ -447,9 +456,12 @@ __global__ __launch_bounds__(64) void train_wgrad_mfma_kernel(const WgradGroup g
         for (int g = 0; g < 8; ++g) {
             *reinterpret_cast<f32x4 *>(&tile[0][lane * kWgPitch + 4 * g]) = dv[g];
             *reinterpret_cast<f32x4 *>(&tile[1][lane * kWgPitch + 4 * g]) = xv[g];
-            if constexpr (F16)
-                if (a.ovf) gmax = guard_max(gmax, dv[g]);
         }
+        if constexpr (F16)
+            if (a.ovf) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) gmax = guard_max(gmax, dv[g]);
+            }
         __syncthreads();
         fetch(pc + kWgChunk);  // the next chunk travels while this one is multiplied (past the slab: all zeros, no traffic)
         if constexpr (F16) {
