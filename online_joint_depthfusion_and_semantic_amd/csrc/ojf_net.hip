@@ -1810,7 +1810,10 @@ static int launch_conv_args(const ConvArgs *args, int n, int nt, hipStream_t st,
     // split-fp16: two pixel tiles per wave share the LDS weight reads and the per-wave prologue; measured in one run
     // (net stage): MT = 2 everywhere 0.501 ms, MT = 2 only for grouped / wide launches 0.508 ms, MT = 1 0.514 ms.
     static const int mt_env = getenv("OJF_CONV_MT") ? atoi(getenv("OJF_CONV_MT")) : 0;  // tuning switch only
-    const int mt = arith == OJF_ARITH_F16X3 ? (mt_env ? mt_env : 2) : 1;
+    // The wide launches of the training executor (NT >= 6: 96 / 128 output channels) need 204-212 + 64 registers at MT = 2 -
+    // one wave per SIMD, nothing to run while a block waits for its weight chunk; MT = 1 (140 + 32) keeps two: training
+    // frame step 216 -> 220 and 204 -> 217 frames/s on two boxes (NT <= 4: no difference).
+    const int mt = arith == OJF_ARITH_F16X3 ? (mt_env ? mt_env : (nt >= 6 ? 1 : 2)) : 1;
     const int strips = (args[0].npix + mt * 16 - 1) / (mt * 16);
     const dim3 grid((strips + 3) / 4, n), block(256);
 #define OJF_LAUNCH32(NT_) hipLaunchKernelGGL((conv_mfma_kernel<1, NT_>), grid, block, 0, st, grp)
