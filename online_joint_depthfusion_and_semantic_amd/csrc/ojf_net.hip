@@ -87,6 +87,33 @@ __device__ __forceinline__ void split_f16(const f32x4 &a, const f32x4 &b, f16x8 
     lo = __builtin_bit_cast(f16x8, l);
 }
 
+// One float4 -> its split-fp16 form in the same 16 bytes: halfs {h0 h1 h2 h3 | l0 l1 l2 l3}, the very halves split_f16
+// makes of these values (same pairs, same instructions).  A producer that stores its planes this way ("split planes")
+// spares every consumer tap the split: the grouped 3x3 convolutions re-split each input value nine times, 12 of the
+// ~19 VALU instructions a 16-pixel tile costs per superstep.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 split_pack4(const f32x4 &x)
+{
+    const f16x4 hi = __builtin_convertvector(x, f16x4);  // 2 x v_cvt_pk_f16_f32
+    const u32x2 h = __builtin_bit_cast(u32x2, hi);
+    const u32x4 r{h[0], h[1], split_lo_pair(h[0], x[0], x[1]), split_lo_pair(h[1], x[2], x[3])};
+    return __builtin_bit_cast(f32x4, r);
+}
+// two split-plane float4 (channel groups A, B) -> the MFMA operand halves of their eight channels
+__device__ __forceinline__ void unpack_split(const f32x4 &a, const f32x4 &b, f16x8 &hi, f16x8 &lo)
+{
+    // (A0 A1 A2 A3)(B0 B1 B2 B3) -> (A0 A1 B0 B1)(A2 A3 B2 B3) in place: two register swaps (as plain vector shuffles the
+    // compiler spends six moves per pair)
+    u32x4 A = __builtin_bit_cast(u32x4, a), B = __builtin_bit_cast(u32x4, b);
+    unsigned a2 = A[2], a3 = A[3], b0 = B[0], b1 = B[1];
+    asm("v_swap_b32 %0, %1" : "+v"(a2), "+v"(b0));
+    asm("v_swap_b32 %0, %1" : "+v"(a3), "+v"(b1));
+    A[2] = a2; A[3] = a3; B[0] = b0; B[1] = b1;
+    hi = __builtin_bit_cast(f16x8, A);
+    lo = __builtin_bit_cast(f16x8, B);
+}
+
 // acc += W * X for one 16x16 tile over a 32-wide K block, W and X given as split halves
 __device__ __forceinline__ f32x4 mfma_f16x3(const f32x4 &wh, const f32x4 &wl, const f16x8 &xh, const f16x8 &xl, f32x4 acc)
 {
@@ -120,6 +147,7 @@ struct ConvArgs {
     int accum;       // planar stores only: out += result (fan-out gradients of the training path); 0 = plain store
     const float *dscale;  // training backward-data: the input carries a power-of-two factor *dscale - the result is divided by it; NULL = off
     unsigned w_magic, c4_magic;  // ceil(2^32 / w), ceil(2^32 / c4): x / d == umulhi(x, magic) while x * d < 2^32 (0: divide)
+    int in_split = 0, out_split = 0;  // split-fp16 launches: the input / output planes are split planes (split_pack4)
 };
 
 __device__ __forceinline__ int fast_div(int x, int d, unsigned magic) { return magic ? (int)__umulhi((unsigned)x, magic) : x / d; }
@@ -209,7 +237,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x4 (&a
             } else if (og < a.og_store) {
                 f32x4 *dst = a.out + (size_t)(a.out_g0 + og) * a.npix + p;
                 if (a.accum) v += *dst;
-                *dst = v;
+                *dst = a.out_split ? split_pack4(v) : v;
                 if constexpr (GUARD) gmax = guard_max(gmax, lin4);  // pre-activation magnitude
             }
         }
@@ -239,7 +267,7 @@ __device__ __forceinline__ void conv_epilogue_lean(const ConvArgs &a, const f32x
             const f32x4 lin4 = fma4(acc[m][n], rvec[n], bvec[n]);
             const f32x4 v = leaky_max4(lin4, slope);
             if (p < a.npix) {
-                a.out[(size_t)(a.out_g0 + og) * a.npix + p] = v;
+                a.out[(size_t)(a.out_g0 + og) * a.npix + p] = a.out_split ? split_pack4(v) : v;
                 gmax = guard_max(gmax, lin4);
             }
         }
@@ -500,7 +528,8 @@ constexpr int conv16_chunk(int nt) { return nt <= 2 ? 6 : 3; }  // supersteps pe
 
 // ABL: profiling-only ablation mask (tests/microbench): 1 = no activation loads, 2 = no LDS weight reads,
 // 4 = no MFMA, 8 = no fp16 split.  Product launches always use ABL = 0.
-template <int MT, int NT, bool SKIP = true, int ABL = 0, bool LEAN = false>
+// INS: the input planes are split planes (every convolution of the launch: the host checks)
+template <int MT, int NT, bool SKIP = true, int ABL = 0, bool LEAN = false, bool INS = false>
 __global__ __launch_bounds__(256) void conv_f16x3_kernel(const ConvGroup grp)
 {
     constexpr int CS = conv16_chunk(NT);
@@ -536,7 +565,16 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const ConvGroup grp)
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < NT; ++n) {
+            acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // MT = 1: the zeros are made opaque, so that every MFMA accumulates in place.  Left to itself clang folds them into
+            // the first MFMA of the peeled first superstep (SrcC = 0) and, at NT >= 6, sends tile 0 through a scratch tuple
+            // (a[0:3] = W_lo X_hi; a[0:3] += W_hi X_lo; a[8:11] = W_hi X_hi + a[0:3], next tile's first MFMA into a[0:3]
+            // right behind): on MI355X that tile came out without its low-half products (2e-4 instead of 2e-6) or as NaN
+            // (tests/test_net_gpu.py::test_conv2d_layer at 114 -> 95 and 19 -> 114 caught it when the wide launches moved to
+            // MT = 1); the same back-to-back shapes occur in kernels that are right, so this is pinned by test, not by rule.
+            if constexpr (MT == 1) asm volatile("" : "+v"(acc[m][n]));
+        }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<f32x4 *>(a.in), 0, (a.in_g0 + a.c4) * a.npix * 16, 0x00020000);
     // bias and inverse row scale of the epilogue: for the narrow layers they are fetched here, so that their latency
@@ -591,6 +629,8 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const ConvGroup grp)
             if constexpr (ABL & 8) {
                 xh = __builtin_bit_cast(f16x8, xa[m]);
                 xl = __builtin_bit_cast(f16x8, xb[m]);
+            } else if constexpr (INS) {
+                unpack_split(xa[m], xb[m], xh, xl);
             } else {
                 split_f16(xa[m], xb[m], xh, xl);
             }
@@ -668,6 +708,7 @@ struct ChainArgs {
     f32x4 *out_planes;
     int out_g0, og_store, act_n;  // ReLU on channels < act_n (branch 0), the pooled branches stay linear
     struct ColSums *colsum;       // channel sums of the entry layer's INPUT (global-average branch), see block_colsum
+    int split_groups = 0;         // kChainEntry: channel groups < split_groups (branch 0, read by its 3x3 convolution only) are stored as split planes
 };
 
 // Weight fragments of one (output tile, K block) pair.  fp32: K block = one 16-channel input tile, 64 float4
@@ -896,7 +937,7 @@ __device__ __forceinline__ void chain_layer(const f32x4 (&in)[MT][NA], f32x4 (&o
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = (og * 4 + j < a.act_n && !(v[j] > 0.0f)) ? (v[j] != v[j] ? v[j] : 0.0f) : v[j];
                     if (p[m] < a.npix && og < a.og_store) {
-                        a.out_planes[(size_t)(a.out_g0 + og) * a.npix + p[m]] = v;
+                        a.out_planes[(size_t)(a.out_g0 + og) * a.npix + p[m]] = og < a.split_groups ? split_pack4(v) : v;
                         if constexpr (ARITH == OJF_ARITH_F16X3) gmax = guard_max(gmax, lin4);
                     }
                 } else {
@@ -1113,6 +1154,7 @@ struct TailArgs {
     f32x4 *entry_out;
     int entry_og, entry_act_n;
     struct ColSums *colsum;
+    int entry_split;  // ChainArgs::split_groups of the fused entry layer
 };
 
 constexpr int kTailEntry = 1;
@@ -1226,7 +1268,7 @@ __global__ __launch_bounds__(kChainThreads, OJF_CHAIN_BLOCKS) void vortex_tail_k
         if (gmax > 65504.0f && a.ovf) *a.ovf = 1;
     if constexpr (CHAIN == kTailEntry) {
         block_colsum<MT, NO>(y, p, a.npix, red, a.colsum, lane, wave);
-        ca.out_planes = a.entry_out; ca.out_g0 = 0; ca.og_store = a.entry_og; ca.act_n = a.entry_act_n;
+        ca.out_planes = a.entry_out; ca.out_g0 = 0; ca.og_store = a.entry_og; ca.act_n = a.entry_act_n; ca.split_groups = a.entry_split;
         chain_layer<ARITH, MT, 8, 5, kChainEntry, 0>(y, t, wlds, a.entry_w, ca, p, lane, pre, buf, vs);
     } else if constexpr (CHAIN) {
         ca.out_rows = a.out_rows; ca.rows_stride = a.rows_stride; ca.rows_n = a.rows_n; ca.scale = a.scale;
@@ -1257,6 +1299,7 @@ struct PyramidArgs {
     int h, w, c4;
     int tiles;      // pixel tiles; with fold_gave, block column `tiles` folds the global-average branch instead
     int fold_gave;
+    int split_out;  // q[] are split planes (split_pack4): their only reader is the branch's first 3x3 convolution
     GaveArgs gave;
 };
 
@@ -1310,7 +1353,7 @@ __device__ __forceinline__ void pool_pyramid_body(const PyramidArgs &a, f32x4 (&
                 s += *reinterpret_cast<const f32x4 *>(a.bias[LV - 1] + 4 * cg);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) s[j] = s[j] < 0.0f ? 0.0f : s[j];  // keeps NaN, like torch.relu
-                a.q[LV - 1][(size_t)cg * npix + gy * a.w + gx] = s;
+                a.q[LV - 1][(size_t)cg * npix + gy * a.w + gx] = a.split_out ? split_pack4(s) : s;
             }
         }
         if (l < LV) __syncthreads();
@@ -1830,6 +1873,10 @@ static int launch_conv_args(const ConvArgs *args, int n, int nt, hipStream_t st,
     static const bool no_lean = getenv("OJF_CONV_LEAN") && atoi(getenv("OJF_CONV_LEAN")) == 0;  // A/B switch
     bool lean = arith == OJF_ARITH_F16X3 && !no_lean;
     for (int i = 0; i < n && lean; ++i) lean = conv_lean_ok(args[i]);
+    int n_ins = 0, n_outs = 0;
+    for (int i = 0; i < n; ++i) { n_ins += args[i].in_split ? 1 : 0; n_outs += args[i].out_split ? 1 : 0; }
+    if ((n_ins || n_outs) && (arith != OJF_ARITH_F16X3 || (n_ins && (n_ins != n || mt != 2 || nt != 2))))
+        return fail("conv: split planes are a format of the split-fp16 grouped 3x3 launches only");
 #define OJF_LAUNCH16(MT_, NT_)                                                                                      \
     do {                                                                                                             \
         if (lean) hipLaunchKernelGGL((conv_f16x3_kernel<MT_, NT_, true, 0, true>), grid16, block, tab_bytes, st, grp); \
@@ -1837,7 +1884,11 @@ static int launch_conv_args(const ConvArgs *args, int n, int nt, hipStream_t st,
     } while (0)
     if (arith == OJF_ARITH_F16X3 && mt == 2) {
         switch (nt) {
-            case 2: OJF_LAUNCH16(2, 2); break;
+            case 2:
+                if (n_ins && lean) hipLaunchKernelGGL((conv_f16x3_kernel<2, 2, true, 0, true, true>), grid16, block, tab_bytes, st, grp);
+                else if (n_ins) hipLaunchKernelGGL((conv_f16x3_kernel<2, 2, true, 0, false, true>), grid16, block, tab_bytes, st, grp);
+                else OJF_LAUNCH16(2, 2);
+                break;
             case 4: OJF_LAUNCH16(2, 4); break;
             case 6: OJF_LAUNCH16(2, 6); break;
             case 8: OJF_LAUNCH16(2, 8); break;
@@ -2183,6 +2234,10 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
     // Chain flow (no side stream, no events): entry GEMM + column sums in one chain-layer launch (or inside the previous
     // tail), the global-average fold as one extra block of the pyramid launch, all four branches in the grouped launches.
     const bool chain_flow = v.entry_w && v.tail_w && !legacy_env;
+    // split planes between the branch-entry producers (entry GEMM: branch 0; pool pyramid: branches 1-3), the branches' first
+    // 3x3 and their second 3x3 (whose result the tail reads as plain fp32 planes)
+    static const bool no_split = getenv("OJF_CONV_SPLIT") && atoi(getenv("OJF_CONV_SPLIT")) == 0;  // A/B switch
+    const bool split = h16 && chain_flow && !no_split;
     if (!chain_flow) {
         if (entry_done) return fail("run_vortex: internal error (entry planes without the chain flow)");
         // global-average branch -> bias of the final conv, on the side stream (fork here, join before the tail)
@@ -2204,6 +2259,7 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
         ea.in_g0 = in_g0; ea.c4_in = v.c_in_phys / 4; ea.npix = net->npix; ea.rows_stride = 0; ea.rows_n = 0; ea.scale = 1.0f;
         ea.ovf = h16 ? overflow_flag() : nullptr;
         ea.out_planes = planes(sc.Z); ea.out_g0 = 0; ea.og_store = 4 * c4; ea.act_n = net->cs; ea.colsum = sc.colsum;
+        ea.split_groups = split ? c4 : 0;
         const dim3 grid(chain_blocks(net)), block(ojf::kChainThreads);
         if (h16) hipLaunchKernelGGL((entry1x1_kernel<OJF_ARITH_F16X3, 1, 8, 5>), grid, block, 0, st, ea);
         else hipLaunchKernelGGL((entry1x1_kernel<OJF_ARITH_F32, 1, 8, 5>), grid, block, 0, st, ea);
@@ -2219,6 +2275,7 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
         pa.tiles = ((w + kPoolTW - 1) / kPoolTW) * ((h + kPoolTH - 1) / kPoolTH);
         pa.gave = gave_args(net, v, nullptr, 0, 0, sc.colsum);
         pa.fold_gave = chain_flow ? 1 : 0;
+        pa.split_out = split ? 1 : 0;
         // grid.x: the tiles (+ the global-average block of the chain flow) rounded up to a multiple of 8 (XCD bands)
         hipLaunchKernelGGL(pool_pyramid_kernel, dim3(round_up(pa.tiles + (chain_flow ? 1 : 0), 8), 3 * c4), dim3(256), 0, st, pa);
         mark_launch("pool_pyramid_kernel", st);
@@ -2232,6 +2289,7 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
         for (int br = 0; br < 4; ++br) {
             fill_conv_args(ga[br], v.b3a[br], bin[br], 0, sc.U, br * c4, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w);
             fill_conv_args(gb[br], v.b3b[br], sc.U, br * c4, sc.V, br * c4, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w);
+            ga[br].in_split = ga[br].out_split = gb[br].in_split = split ? 1 : 0;
         }
         // Legacy flow: branch 0 needs no pooling, its 3x3 pair follows the global-average kernels on the side stream
         static const bool b0_main = getenv("OJF_BRANCH0_MAIN") != nullptr;  // ablation switch only
@@ -2263,7 +2321,7 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
     ta.out = planes(out); ta.c4 = c4; ta.out_g0 = out_g0; ta.og_store = o4; ta.npix = net->npix;
     ta.ovf = h16 ? overflow_flag() : nullptr;
     ta.chain_w = nullptr; ta.chain_b = nullptr; ta.out_rows = nullptr; ta.rows_stride = 0; ta.rows_n = 0; ta.scale = 1.0f;
-    ta.entry_w = nullptr; ta.entry_b = nullptr; ta.entry_out = nullptr; ta.entry_og = 0; ta.entry_act_n = 0; ta.colsum = nullptr;
+    ta.entry_w = nullptr; ta.entry_b = nullptr; ta.entry_out = nullptr; ta.entry_og = 0; ta.entry_act_n = 0; ta.colsum = nullptr; ta.entry_split = 0;
     // MT = 1: two pixel tiles per wave (324 VGPRs, one wave per SIMD) measured slower (0.624 vs 0.609 ms net)
     const dim3 grid(chain_blocks(net)), block(ojf::kChainThreads);
     static const bool no_head_fusion = getenv("OJF_NO_HEAD_FUSION") != nullptr;  // ablation switch only
@@ -2281,6 +2339,7 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
         // this VortexPooling feeds the next one: its entry GEMM and column sums ride along, `out` is never written
         ta.entry_w = planes(next->entry_w); ta.entry_b = next->entry_b; ta.entry_out = planes(sc.Z);
         ta.entry_og = 4 * c4; ta.entry_act_n = net->cs; ta.colsum = sc.colsum;
+        ta.entry_split = (h16 && !no_split) ? c4 : 0;  // (the next VortexPooling runs the chain flow: same rule as its `split`)
         if (h16) hipLaunchKernelGGL((vortex_tail_kernel<OJF_ARITH_F16X3, 1, 2, 8, kTailEntry>), grid, block, 0, st, ta);
         else hipLaunchKernelGGL((vortex_tail_kernel<OJF_ARITH_F32, 1, 2, 8, kTailEntry>), grid, block, 0, st, ta);
         mark_launch("vortex_tail_kernel (+ next entry GEMM)", st);
