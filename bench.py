@@ -431,7 +431,7 @@ def train_report(case, res, steps, warmup, world, h, w, grid):
     med = times[len(times) // 2] if len(times) % 2 else 0.5 * (times[len(times) // 2 - 1] + times[len(times) // 2])
     return {'workload': 'BASELINE configs[3]: training frame step (fuse_training + FusionLoss + backward per frame; flat-gradient '
                         'all-reduce + RMSprop step every %d frames), %dx%d depth into a %d^3 grid, FusionNet_v3 train() mode '
-                        '(batch statistics, dropout), split-fp16 forward / backward-data convolutions + fp32-MFMA weight gradients, one scene per GPU' % (case.accum, w, h, grid),
+                        '(batch statistics, dropout), split-fp16 forward / backward-data convolutions and weight gradients, one scene per GPU' % (case.accum, w, h, grid),
             'value': world * steps / med, 'unit': 'frames/sec', 'ms_per_step': 1e3 * med / steps, 'steps': steps, 'warmup': warmup,
             'repeats': len(times), 'value_min': world * steps / times[-1], 'value_max': world * steps / times[0],
             'allreduce_us': res['allreduce_us'] if world > 1 else None, 'allreduce_calls_in_timed_region': res['allreduce_calls'],

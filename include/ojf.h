@@ -281,9 +281,11 @@ typedef struct ojf_train_layer {
 } ojf_train_layer;
 int ojf_trainer_create(ojf_trainer **out, int version, int n_points, int growth, int use_semantics, float output_scale, int h, int w);
 void ojf_trainer_destroy(ojf_trainer *t);
-/* arithmetic of the FORWARD convolutions: OJF_ARITH_F16X3 (default; activations must stay inside the fp16 range like in
+/* arithmetic of the convolutions: OJF_ARITH_F16X3 (default; activations must stay inside the fp16 range like in
  * ojf_net_forward - a violation makes the next ojf_trainer_forward fail until ojf_net_check clears it) or OJF_ARITH_F32.
- * Backward (tiny gradients of unbounded range) is always fp32-input MFMA. */
+ * Under OJF_ARITH_F16X3 the first backward pass after creation (or after a switch) runs on fp32-input MFMAs and measures the
+ * gradients' ranges; from the second pass on dy is stored under a per-unit power-of-two factor and backward-data AND the
+ * weight gradients run in split-fp16 as well (the factor is divided out exactly). */
 int ojf_trainer_set_arithmetic(ojf_trainer *t, int arithmetic);
 int ojf_trainer_layer_count(const ojf_trainer *t);
 int ojf_trainer_launch_count(const ojf_trainer *t);
