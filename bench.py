@@ -292,6 +292,51 @@ def kernel_table(kernels, c, N, peak_tf, total_macs):
     return rows
 
 
+def adapnet_gflop(net, h, w):
+    """Useful GFLOP of one AdapNet++ forward (convolutions and transposed convolutions that feed output[0]: the auxiliary
+    heads the engine skips are left out), counted by running a meta-device copy of the module tree with hooks."""
+    import copy
+    m = copy.deepcopy(net).to('meta')
+    macs = [0]
+
+    def hook(mod, inp, out):
+        k = mod.kernel_size[0] * mod.kernel_size[1]
+        hw = inp[0].shape[2] * inp[0].shape[3] if isinstance(mod, torch.nn.ConvTranspose2d) else out.shape[2] * out.shape[3]
+        macs[0] += hw * mod.in_channels * mod.out_channels * k // mod.groups
+    for name, mm in m.named_modules():
+        if isinstance(mm, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)) and 'aux' not in name:
+            mm.register_forward_hook(hook)
+    x = torch.zeros(1, 3, h, w, device='meta')
+    with torch.no_grad():
+        m(x, x) if getattr(net, 'fusion', False) else m(x)
+    return 2e-9 * macs[0]
+
+
+def segmentation_report(case, seg_ms, c):
+    """The AdapNet++ share of a predict-strategy frame: its time (HIP events around Pipeline._frame_semantics on the sampled
+    frames: graph replay + the host work up to the extract launch), useful TFLOP/s against the split-fp16 MFMA peak, and the
+    MFMA-pipe-busy time of its convolution kernels per frame replayed from the round's SQ-counter pass."""
+    out = {'ms_per_frame': seg_ms, 'engine': c['seg_engine']}
+    try:
+        gf = adapnet_gflop(case.pipe._semantic_2d_network, c['h'], c['w'])
+        out.update(gflop=gf, tflops=gf / seg_ms, frac_of_mfma_peak=gf / seg_ms / ARITH['f16x3'][2],
+                   note='useful flops of the convolutions feeding output[0] / segmentation stage time; peak = split-fp16 (838.9 TFLOP/s)')
+    except Exception as e:  # a reporting extra must not fail the leg
+        out['gflop_error'] = repr(e)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_final_sq_counters_predict.json')
+    if os.path.exists(path) and (c['h'], c['w']) == (240, 320) and c['seg_engine'] == 'hip':
+        try:
+            sq = json.load(open(path))
+            rows = {k: v for k, v in sq.items() if k.startswith('segconv')}
+            frames = 22.0  # frames of that counter pass (bench.py --steps 20 --warmup 2 --lean)
+            out['mfma_pipe_busy_us_per_frame'] = sum(v['mfma_busy_us_per_simd_per_dispatch'] * v['dispatches'] for v in rows.values()) / frames
+            out['segconv_dispatches_per_frame'] = sum(v['dispatches'] for v in rows.values()) / frames
+            out['mfma_source'] = 'replayed from profiles/r03_final_sq_counters_predict.json (segconv* kernels, per SIMD)'
+        except Exception as e:
+            out['mfma_error'] = repr(e)
+    return out
+
+
 def report(case, res, steps, warmup, world, args_cpu_frames=0, full=True):
     c, cfg, st = case.c, case.cfg, case.st
     h, w, grid = c['h'], c['w'], c['grid']
@@ -306,6 +351,8 @@ def report(case, res, steps, warmup, world, args_cpu_frames=0, full=True):
            'value_max': world * steps / times[0], 'stages_ms': stages, 'stage_samples_in_timed_region': res['stage_samples'],
            'stages_ms_all_frames': res['stages_all'], 'stages_all_frames_pass': '%d untimed frames, events on every frame' % res['stages_all_frames'],
            'net_launches_per_frame': res['launches']}
+    if c['semantics'] and c['strategy'] == 'predict' and 'segmentation' in stages:
+        out['segmentation'] = segmentation_report(case, stages['segmentation'], c)
     if not full:
         return out
     P, T = cfg.FUSION_MODEL.n_points, cfg.FUSION_MODEL.n_tail_points
@@ -586,7 +633,7 @@ def main():
                       % (args.repeats, args.steps),
         }
         for k in ('repeats', 'value_min', 'value_max', 'stages_ms', 'stage_samples_in_timed_region', 'stages_ms_all_frames',
-                  'stages_all_frames_pass', 'net_launches_per_frame', 'kernels', 'roofline', 'roofline_net', 'roofline_hbm'):
+                  'stages_all_frames_pass', 'net_launches_per_frame', 'kernels', 'segmentation', 'roofline', 'roofline_net', 'roofline_hbm'):
             if k in r:
                 out[k] = r[k]
         del case

@@ -77,8 +77,19 @@ class Pipeline(torch.nn.Module):
             e.record(torch.cuda.current_stream(self.device).cuda_stream)
             self._marks.append(e)
 
+    def _mark_segmentation(self):
+        """Event in front of the 2-D segmentation of a frame the stage sampling will pick (predict strategy only)."""
+        if not self.profile or not self.config.DATA.semantics or self.config.DATA.semantic_strategy != 'predict':
+            return None
+        if self.profile is not True and (self._frames_fused + 1) % int(self.profile) != 0:
+            return None
+        e = _lib.TimingEvent()
+        e.record(torch.cuda.current_stream(self.device).cuda_stream)
+        return e
+
     def reset_profile(self):
         self._marks = []
+        self._seg_marks = []
 
     def stage_times_ms(self):
         """Mean milliseconds per frame of extract / net / integrate over the frames fused since
@@ -92,7 +103,11 @@ class Pipeline(torch.nn.Module):
         for f in range(n):
             for j in range(3):
                 acc[j] += ev[4 * f + j].elapsed_time(ev[4 * f + j + 1])
-        return {'extract': acc[0] / n, 'net': acc[1] / n, 'integrate': acc[2] / n}
+        out = {'extract': acc[0] / n, 'net': acc[1] / n, 'integrate': acc[2] / n}
+        seg = self.__dict__.get('_seg_marks') or []
+        if seg:  # AdapNet++ prediction of the frame's labels (+ the host work between it and the extract launch)
+            out['segmentation'] = sum(a.elapsed_time(b) for a, b in seg) / len(seg)
+        return out
 
     def check(self):
         """Synchronise and raise OjfError if the split-fp16 range guard fired since the last check (the frames
@@ -270,6 +285,7 @@ class Pipeline(torch.nn.Module):
     def fuse(self, batch, database, device):
         self.device = torch.device(device)
         self._shape = batch['image'].shape
+        seg0 = self._mark_segmentation()
         sem_ids, scores = self._frame_semantics(batch)
         frame, mask = self._frames(batch, filtered=False)
         h, w = frame.shape
@@ -282,6 +298,8 @@ class Pipeline(torch.nn.Module):
         eng = self._get_engine(h, w, self.device)
         P = self.n_points
         self._mark(first=True)
+        if seg0 is not None and self._marks:
+            self.__dict__.setdefault('_seg_marks', []).append((seg0, self._marks[-1]))
         use_sem = self.config.FUSION_MODEL.use_semantics
         if eng.fused_input:
             # geometry-only net: the extractor writes the net's input planes itself (one launch less, no sample planes)
