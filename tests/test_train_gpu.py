@@ -373,16 +373,7 @@ def test_fuse_output_and_fusion_loss_kernels_match_the_tensor_formulas(cuda):
     assert float((est_d.grad.cpu() - 3.0 * grad_ref).abs().max()) <= 3e-6 * scale
 
 
-@pytest.mark.parametrize('training', [False, True])
-@pytest.mark.parametrize('version,sem', [('v3', True), ('v2', False)])
-def test_executor_backward_data_in_split_fp16_from_the_second_pass(cuda, version, sem, training):
-    """The executor's first backward pass runs backward-data on fp32-input MFMAs and measures the magnitude of every dy
-    tensor; from the second pass on dy is stored with a power-of-two factor and backward-data runs in the split-fp16
-    arithmetic (ojf_trainer_backward).  Same frame, same weights (eval() mode, or train() mode without dropout: batch
-    statistics do not depend on the running buffers): passes 2 and 3 must reproduce pass 1's gradients to fp32-class
-    accuracy - per tensor within 2e-5 of max(its scale, 1e-3 of the largest gradient) in eval() mode; 2e-4 in train() mode,
-    where the batch-statistics chain amplifies any rounding difference (torch's own fp32 runs differ by 1e-2 there)."""
-    h, w = 40, 56
+def _second_pass_case(cuda, version, sem, training, h, w):
     net = _net(version, sem, h, w).to(cuda).train(training)
     g = torch.Generator().manual_seed(17)
     x = dict(tsdf_values=((torch.rand(1, 9, h, w, generator=g) - 0.5) * 0.2).to(cuda), tsdf_weights=(torch.rand(1, 9, h, w, generator=g) * 4).to(cuda),
@@ -403,5 +394,26 @@ def test_executor_backward_data_in_split_fp16_from_the_second_pass(cuda, version
                 continue
             scale = max(float(p0.abs().max()), 1e-3 * gmax)
             worst = max(worst, float((p0 - pk).abs().max()) / scale)
-    print('split-fp16 backward-data %s sem=%s training=%s: worst deviation from the fp32 pass %.2e of a tensor\'s scale' % (version, sem, training, worst))
+    print('split-fp16 backward %s sem=%s training=%s %dx%d: worst deviation from the fp32 pass %.2e of a tensor\'s scale' % (version, sem, training, h, w, worst))
+    return worst
+
+
+@pytest.mark.parametrize('training', [False, True])
+@pytest.mark.parametrize('version,sem', [('v3', True), ('v2', False)])
+def test_executor_backward_data_in_split_fp16_from_the_second_pass(cuda, version, sem, training):
+    """The executor's first backward pass runs backward-data and the weight gradients on fp32-input MFMAs and measures the
+    magnitude of every dy tensor; from the second pass on dy is stored with a power-of-two factor and both run in the
+    split-fp16 arithmetic (ojf_trainer_backward: conv_f16x3_kernel on the transposed weights, train_wgrad_mfma_kernel<true>).
+    Same frame, same weights (eval() mode, or train() mode without dropout: batch statistics do not depend on the running
+    buffers): passes 2 and 3 must reproduce pass 1's gradients to fp32-class accuracy - per tensor within 2e-5 of max(its
+    scale, 1e-3 of the largest gradient) in eval() mode; 2e-4 in train() mode, where the batch-statistics chain amplifies any
+    rounding difference (torch's own fp32 runs differ by 1e-2 there)."""
+    worst = _second_pass_case(cuda, version, sem, training, 40, 56)
     assert worst <= (2e-4 if training else 2e-5)
+
+
+def test_split_fp16_backward_at_baseline_frame_size(cuda):
+    """The same comparison at BASELINE configs[3]'s frame size: 76 800 pixels is where the weight gradient's pixel slabs, its
+    64-pixel chunks (K of the split-fp16 MFMAs) and the fp64 slab reductions take the shape they have in a training run."""
+    worst = _second_pass_case(cuda, 'v3', False, False, 240, 320)
+    assert worst <= 2e-5
