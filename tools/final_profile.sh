@@ -27,8 +27,10 @@ python bench.py --train --steps 64 --warmup 16 --repeats 5 > $O/bench_train.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktr -o ktr -- python tools/train_throughput.py > /dev/null 2> $O/ktr.err
 cp $(find $O/ktr -name '*kernel_stats.csv' | head -1) $O/train_kernel_stats.csv
 python tools/train_timeline.py $(find $O/ktr -name '*kernel_trace.csv' | head -1) > $O/train_timeline.txt 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $O/sqt -o sqt -- python tools/train_throughput.py > /dev/null 2> $O/sqt.err
+python tools/pmc_sq_summary.py $(find $O/sqt -name '*counter_collection.csv' | head -1) $O/train_sq_counters.json > $O/train_sq_counters.txt 2>&1
 python tools/adapnet_engine_probe.py 2>&1 | grep -v MIOpen > $O/adapnet_engine_probe.txt
 python bench.py --mode parity --steps 100 --cpu-frames 0 --secondary 0 > $O/bench_parity.json 2>/dev/null
 python bench.py --height 120 --width 160 --grid 64 --cpu-frames 0 --secondary 0 > $O/bench_A.json 2>/dev/null
-rm -rf $O/kt $O/pf $O/pw $O/sq $O/kp $O/ktr $O/cf $O/cw $O/sqp
+rm -rf $O/kt $O/pf $O/pw $O/sq $O/kp $O/ktr $O/cf $O/cw $O/sqp $O/sqt
 ls -la $O
