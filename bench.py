@@ -323,15 +323,18 @@ def segmentation_report(case, seg_ms, c):
                    note='useful flops of the convolutions feeding output[0] / segmentation stage time; peak = split-fp16 (838.9 TFLOP/s)')
     except Exception as e:  # a reporting extra must not fail the leg
         out['gflop_error'] = repr(e)
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_final_sq_counters_predict.json')
-    if os.path.exists(path) and (c['h'], c['w']) == (240, 320) and c['seg_engine'] == 'hip':
+    import glob
+    found = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r[0-9][0-9]_*sq_counters_predict.json')))
+    if found and (c['h'], c['w']) == (240, 320) and c['seg_engine'] == 'hip':
         try:
+            path = found[-1]  # the latest round's counter pass
             sq = json.load(open(path))
-            rows = {k: v for k, v in sq.items() if k.startswith('segconv')}
-            frames = 22.0  # frames of that counter pass (bench.py --steps 20 --warmup 2 --lean)
-            out['mfma_pipe_busy_us_per_frame'] = sum(v['mfma_busy_us_per_simd_per_dispatch'] * v['dispatches'] for v in rows.values()) / frames
-            out['segconv_dispatches_per_frame'] = sum(v['dispatches'] for v in rows.values()) / frames
-            out['mfma_source'] = 'replayed from profiles/r03_final_sq_counters_predict.json (segconv* kernels, per SIMD)'
+            rows = {k: v for k, v in sq.items() if k.startswith('segconv') and isinstance(v, dict)}
+            frames = float(sq.get('_frames', 22.0))  # frames of that counter pass (bench.py --steps 20 --warmup 2 --lean unless the file says otherwise)
+            out['replayed_not_measured_in_this_run'] = {
+                'mfma_pipe_busy_us_per_frame': sum(v['mfma_busy_us_per_simd_per_dispatch'] * v['dispatches'] for v in rows.values()) / frames,
+                'segconv_dispatches_per_frame': sum(v['dispatches'] for v in rows.values()) / frames,
+                'source': 'profiles/%s (segconv* kernels, per SIMD; a rocprofv3 --pmc pass of an earlier run of this workload)' % os.path.basename(path)}
         except Exception as e:
             out['mfma_error'] = repr(e)
     return out
@@ -442,6 +445,8 @@ class TrainCase:
             # train_fusion.py:172 adds loss.item() to a window that is read every log_freq frames; summed on the device
             # and read once per timed loop here (the same numbers, without a host round trip per frame)
             self.loss_sum = loss.detach() if self.loss_sum is None else self.loss_sum + loss.detach()
+        if self.cfg.TRAINING.optimization.clipping:  # train_fusion.py:182-183: on the accumulated gradients, every frame
+            torch.nn.utils.clip_grad_norm_(self.pipe._fusion_network.parameters(), max_norm=1., norm_type=2)
         if (i + 1) % self.accum == 0:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
@@ -477,12 +482,13 @@ def train_report(case, res, steps, warmup, world, h, w, grid):
     times = sorted(res['times'])
     med = times[len(times) // 2] if len(times) % 2 else 0.5 * (times[len(times) // 2 - 1] + times[len(times) // 2])
     return {'workload': 'BASELINE configs[3]: training frame step (fuse_training + FusionLoss + backward per frame; flat-gradient '
-                        'all-reduce + RMSprop step every %d frames), %dx%d depth into a %d^3 grid, FusionNet_v3 train() mode '
+                        'all-reduce + RMSprop step every %d frames, clip_grad_norm_ every frame), %dx%d depth into a %d^3 grid, FusionNet_v3 train() mode '
                         '(batch statistics, dropout), split-fp16 forward / backward-data convolutions and weight gradients, one scene per GPU' % (case.accum, w, h, grid),
             'value': world * steps / med, 'unit': 'frames/sec', 'ms_per_step': 1e3 * med / steps, 'steps': steps, 'warmup': warmup,
             'repeats': len(times), 'value_min': world * steps / times[-1], 'value_max': world * steps / times[0],
             'allreduce_us': res['allreduce_us'] if world > 1 else None, 'allreduce_calls_in_timed_region': res['allreduce_calls'],
-            'allreduce_backend': ('rccl' if world > 1 else 'none (one rank)'), 'gradient_bytes': res['gradient_bytes'],
+            'allreduce_backend': (('rccl' if torch.distributed.get_backend() == 'nccl' else 'gloo (dry run: gradient buffer staged through the host)')
+                                  if world > 1 else 'none (one rank)'), 'gradient_bytes': res['gradient_bytes'],
             'gradients_finite': res['finite'], 'mean_loss_last_repeat': res['mean_loss']}
 
 
@@ -586,9 +592,8 @@ def main():
     metric = 'frames/sec fused (%dx%d, %d^3 grid)' % (args.width, args.height, args.grid)
     total = args.warmup + args.steps * args.repeats
     if args.train:
-        if world > 1 and args.dist_backend != 'nccl':
-            # gloo validates the launch / barrier / schedule on one device; its all-reduce needs host tensors
-            raise SystemExit('bench.py --train with N > 1 needs --dist-backend nccl (the gradient buffer lives in HBM)')
+        # (--dist-backend gloo: a dry run of the training schedule on one device - launch, barrier, accumulation boundary,
+        # max over ranks; FlatGradientAllReduce stages the gradient buffer through the host for gloo, 'allreduce_backend' says so)
         tc = TrainCase(args.height, args.width, args.grid, dev, rank, total)
         res = tc.run(args.steps, args.warmup, sync, args.repeats)
         res['times'] = max_over_ranks(res['times'])

@@ -282,11 +282,16 @@ typedef struct ojf_train_layer {
 int ojf_trainer_create(ojf_trainer **out, int version, int n_points, int growth, int use_semantics, float output_scale, int h, int w);
 void ojf_trainer_destroy(ojf_trainer *t);
 /* arithmetic of the convolutions: OJF_ARITH_F16X3 (default; activations must stay inside the fp16 range like in
- * ojf_net_forward - a violation makes the next ojf_trainer_forward fail until ojf_net_check clears it) or OJF_ARITH_F32.
- * Under OJF_ARITH_F16X3 the first backward pass after creation (or after a switch) runs on fp32-input MFMAs and measures the
- * gradients' ranges; from the second pass on dy is stored under a per-unit power-of-two factor and backward-data AND the
- * weight gradients run in split-fp16 as well (the factor is divided out exactly). */
+ * ojf_net_forward - a violation makes the next ojf_trainer_forward fail, which also clears the flag) or OJF_ARITH_F32.
+ * Under OJF_ARITH_F16X3 backward-data AND the weight gradients run in split-fp16 as well: every dy tensor is stored under a
+ * per-unit power-of-two factor that the SAME pass derives from a guaranteed bound on |dy| (max|dz| and max|xhat| collected by
+ * the BatchNorm-backward reduction), so gradients of any magnitude stay inside the fp16 range; the factor is divided out
+ * exactly by the consumers. */
 int ojf_trainer_set_arithmetic(ojf_trainer *t, int arithmetic);
+/* arithmetic of the BACKWARD convolutions (backward-data and weight gradients) under a split-fp16 forward:
+ * OJF_ARITH_F16X3 (default: as described above) or OJF_ARITH_F32 (every backward pass on the fp32-input MFMA path).
+ * Replaces nothing in the reference (loss.backward() of train_fusion.py:171 is fp32 throughout). */
+int ojf_trainer_set_backward_arithmetic(ojf_trainer *t, int arithmetic);
 int ojf_trainer_layer_count(const ojf_trainer *t);
 int ojf_trainer_launch_count(const ojf_trainer *t);
 int ojf_trainer_forward(ojf_trainer *t, const ojf_train_layer *layers, int n_layers, unsigned long long weights_epoch,

@@ -94,6 +94,7 @@ SIGNATURES = {
     'ojf_trainer_create': (_i, [_c.POINTER(_vp), _i, _i, _i, _i, _f, _i, _i]),
     'ojf_trainer_destroy': (None, [_vp]),
     'ojf_trainer_set_arithmetic': (_i, [_vp, _i]),
+    'ojf_trainer_set_backward_arithmetic': (_i, [_vp, _i]),
     'ojf_trainer_layer_count': (_i, [_vp]),
     'ojf_trainer_launch_count': (_i, [_vp]),
     'ojf_trainer_forward': (_i, [_vp, _c.POINTER(TrainLayer), _i, _c.c_ulonglong, _vp, _vp, _vp, _vp, _vp, _vp]),

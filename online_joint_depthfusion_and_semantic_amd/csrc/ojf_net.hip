@@ -1734,7 +1734,19 @@ static long long *g_pair_dbg = nullptr;
 struct PackedPair {
     float *wa = nullptr, *wb = nullptr, *vec = nullptr;  // vec: bias_a | rinv_a | bias_b | rinv_b (32 floats each)
     int c4_in = 0, n_chunks = 0, np_last = 0, np_b = 0, og_store = 0;
+    int cfg = 0;  // PairCfg the weights were packed for (chunk size)
 };
+
+// Launch shapes of dense_pair_kernel (PairGeom): picked per frame size, the chunk size is part of the weight packing
+enum PairCfg { PAIR_20x16_W16 = 0, PAIR_12x8_W16 = 1, PAIR_20x8_W8 = 2, PAIR_16x8_W8 = 3, PAIR_20x8_W8_CP4 = 4 };
+static inline int pair_cfg_chunk_pairs(int cfg) { return cfg == PAIR_20x8_W8 || cfg == PAIR_16x8_W8 ? 3 : 4; }
+static int pair_cfg_for(int h, int w)
+{
+    static const int forced = getenv("OJF_PAIR_CFG") ? atoi(getenv("OJF_PAIR_CFG")) : -1;  // tuning switch
+    if (forced >= 0 && forced <= 4) return forced;
+    // one block per tile, 16 waves: the large tile when it still gives every CU a block (320x240: 240 blocks)
+    return ((w + 19) / 20) * ((h + 15) / 16) >= 200 ? PAIR_20x16_W16 : PAIR_12x8_W16;
+}
 
 static void release(PackedPair &pp)
 {
@@ -1745,11 +1757,11 @@ static void release(PackedPair &pp)
 }
 
 // K blocks of `np_chunk`-pair chunks: unit u = 4S + g -> (tap = u / np, pair = u % np), K slot j = channel 8*pair + j
-static void pack_pair_conv(const ConvBuilder &b, const std::vector<float> &rs, std::vector<float> &dst)
+static void pack_pair_conv(const ConvBuilder &b, const std::vector<float> &rs, std::vector<float> &dst, int cp)
 {
-    const int npairs = (b.c_in_phys + 7) / 8, n_chunks = (npairs + 3) / 4;
+    const int npairs = (b.c_in_phys + 7) / 8, n_chunks = (npairs + cp - 1) / cp;
     for (int c = 0; c < n_chunks; ++c) {
-        const int np = c == n_chunks - 1 ? npairs - 4 * c : 4, nkb = (9 * np + 3) / 4;
+        const int np = c == n_chunks - 1 ? npairs - cp * c : cp, nkb = (9 * np + 3) / 4;
         const size_t base = dst.size();
         dst.resize(base + (size_t)nkb * 256 * 4, 0.0f);
         _Float16 *hp = reinterpret_cast<_Float16 *>(dst.data() + base);
@@ -1759,7 +1771,7 @@ static void pack_pair_conv(const ConvBuilder &b, const std::vector<float> &rs, s
                     for (int j = 0; j < 8; ++j) {
                         const int oc = nt * 16 + (lane & 15), u = 4 * S + (lane >> 4);
                         if (oc >= b.c_out_phys || u >= 9 * np) continue;
-                        const int tap = u / np, ch = 8 * (4 * c + u % np) + j;
+                        const int tap = u / np, ch = 8 * (cp * c + u % np) + j;
                         if (ch >= b.c_in_phys) continue;
                         const float v = rs[oc] * b.W[((size_t)oc * b.taps + tap) * b.c_in_phys + ch];
                         const size_t ub = ((size_t)S * 2 + nt) * 2 * 64 * 8;
@@ -1768,8 +1780,10 @@ static void pack_pair_conv(const ConvBuilder &b, const std::vector<float> &rs, s
     }
 }
 
-static int finish_pair(const ConvBuilder &ba, const ConvBuilder &bb, PackedPair &pp)
+static int finish_pair(const ConvBuilder &ba, const ConvBuilder &bb, PackedPair &pp, int cfg = PAIR_20x16_W16)
 {
+    const int cp = pair_cfg_chunk_pairs(cfg);
+    pp.cfg = cfg;
     if (ba.taps != 9 || bb.taps != 9 || ba.dil != 1 || bb.dil != 1 || ba.c_out_phys > 24 || bb.c_in_phys != ba.c_out_phys ||
         bb.c_out_phys > 32 || ba.c_in_phys % 4)
         return fail("pair packing: unsupported layer shapes");
@@ -1787,31 +1801,31 @@ static int finish_pair(const ConvBuilder &ba, const ConvBuilder &bb, PackedPair 
         return rs;
     };
     const std::vector<float> ra = scales(ba, 0), rb = scales(bb, 64);
-    pack_pair_conv(ba, ra, wa);
-    pack_pair_conv(bb, rb, wb);
+    pack_pair_conv(ba, ra, wa, cp);
+    pack_pair_conv(bb, rb, wb, 4);  // (3 pairs: one chunk whatever the chunk size)
     pp.np_b = (bb.c_in_phys + 7) / 8;
     const int npairs = (ba.c_in_phys + 7) / 8;
     pp.c4_in = ba.c_in_phys / 4;
-    pp.n_chunks = (npairs + 3) / 4;
-    pp.np_last = npairs - 4 * (pp.n_chunks - 1);
+    pp.n_chunks = (npairs + cp - 1) / cp;
+    pp.np_last = npairs - cp * (pp.n_chunks - 1);
     pp.og_store = round_up(bb.c_out_phys, 4) / 4;
     if (upload(wa, &pp.wa) || upload(wb, &pp.wb) || upload(vec, &pp.vec)) return -2;
     return 0;
 }
 
-template <int TW, int TH>
+template <int TW, int TH, int WAVES = 16, int CP = 4, bool ALIAS = false>
 static int launch_pair_t(PairArgs &a, hipStream_t st)
 {
-    using G = PairGeom<TW, TH>;
+    using G = PairGeom<TW, TH, WAVES, CP, ALIAS>;
     static bool configured = false;
     if (!configured) {
-        OJF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_pair_kernel<TW, TH>),
+        OJF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_pair_kernel<TW, TH, WAVES, CP, ALIAS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
         configured = true;
     }
     a.tiles_x = (a.w + TW - 1) / TW;
     const int tiles = a.tiles_x * ((a.h + TH - 1) / TH);
-    hipLaunchKernelGGL((dense_pair_kernel<TW, TH>), dim3(tiles), dim3(G::THREADS), G::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((dense_pair_kernel<TW, TH, WAVES, CP, ALIAS>), dim3(tiles), dim3(G::THREADS), G::LDS_BYTES, st, a);
     mark_launch("dense_pair_kernel", st);
     return check_hip(hipGetLastError(), "dense_pair_kernel launch");
 }
@@ -1832,9 +1846,14 @@ static int launch_pair(const PackedPair &pp, const float *in, int in_g0, float *
 #ifdef OJF_PAIR_TIMING
     a.dbg = g_pair_dbg;
 #endif
-    // one block per tile, 16 waves: the large tile when it still gives every CU a block (320x240: 240 blocks)
-    if (((w + 19) / 20) * ((h + 15) / 16) >= 200) return launch_pair_t<20, 16>(a, st);
-    return launch_pair_t<12, 8>(a, st);
+    switch (pp.cfg) {
+    case PAIR_20x16_W16: return launch_pair_t<20, 16>(a, st);
+    case PAIR_12x8_W16: return launch_pair_t<12, 8>(a, st);
+    case PAIR_20x8_W8: return launch_pair_t<20, 8, 8, 3, true>(a, st);
+    case PAIR_16x8_W8: return launch_pair_t<16, 8, 8, 3, true>(a, st);
+    case PAIR_20x8_W8_CP4: return launch_pair_t<20, 8, 8, 4, true>(a, st);
+    }
+    return fail("dense pair: unknown launch shape");
 }
 
 // Launches n (<= 4) independent convolutions with the same number of output tiles as ONE grid
@@ -2474,7 +2493,7 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
             net->dense[head].push_back(pb);
             if (net->arith == OJF_ARITH_F16X3 && cs <= 24) {
                 PackedPair pp;
-                if (finish_pair(ba, bb, pp)) return -2;
+                if (finish_pair(ba, bb, pp, pair_cfg_for(net->h, net->w))) return -2;
                 net->pairs[head].push_back(pp);
             }
         }

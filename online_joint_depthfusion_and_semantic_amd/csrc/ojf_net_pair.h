@@ -31,11 +31,18 @@ namespace ojf {
 constexpr int pair_round16(int x) { return (x + 15) / 16 * 16; }
 constexpr int pair_max(int a, int b) { return a > b ? a : b; }
 
-template <int TW, int TH>
+// Two shapes of the same kernel:
+//   <TW, TH, 16, 4, false>  one 16-wave block per CU (143 KB of LDS at 20 x 16): four waves per SIMD take turns through the
+//                           load / split / epilogue phases of the ONE block a CU holds (8 waves 101 us, 12 waves 95 us, 16
+//                           waves 90 us per frame) - but all blocks of a launch fetch, compute and store in the same phases
+//   <TW, TH, 8, CP, true>   round 4: 8-wave blocks small enough for TWO per CU (<= 80 KB: chunks of CP = 3 channel pairs,
+//                           the T planes alias the window planes - the window is dead once conv a has finished), so that one
+//                           block's fetch / split / barrier phases run beside the other's MFMA phase
+template <int TW, int TH, int WAVES_ = 16, int CP_ = 4, bool ALIAS_ = false>
 struct PairGeom {
-    // 16 waves (the largest block): four per SIMD take turns through the load / split / epilogue phases of the ONE block a
-    // CU holds (measured per frame: 8 waves 101 us, 12 waves 95 us, 16 waves 90 us)
-    static constexpr int WAVES = 16, THREADS = 64 * WAVES;
+    static constexpr int WAVES = WAVES_, THREADS = 64 * WAVES, CP = CP_;
+    static constexpr bool ALIAS = ALIAS_;
+    static constexpr int NKB = (9 * CP + 3) / 4;           // K blocks of a full chunk
     static constexpr int PW = TW + 4;                      // slot pitch = window width
     static constexpr int XS = (TH + 4) * PW;               // window slots
     static constexpr int TS = (TH + 2) * PW;               // slots of the intermediate
@@ -45,11 +52,14 @@ struct PairGeom {
     // plane lengths in slots: reads of junk columns / junk tiles must stay inside the plane
     static constexpr int XP = pair_round16(pair_max(XS, TILES_A * 16 + 2 * PW + 2));
     static constexpr int TP = pair_round16(pair_max(TILES_A * 16, TILES_B * 16 + 2 * PW + 2));
-    static constexpr int X_F4 = 4 * 2 * XP, T_F4 = 3 * 2 * TP, W_F4 = 9 * 256;  // float4 counts of the three LDS areas
-    static constexpr int NXI = (4 * XS + THREADS - 1) / THREADS;   // window items (pair, slot) per thread and chunk
+    // float4 counts of the three LDS areas (conv b always has 3 pairs = 7 K blocks of weights)
+    static constexpr int X_F4 = CP * 2 * XP, T_F4 = 3 * 2 * TP, W_F4 = pair_max(NKB, 7) * 256;
+    static constexpr int XT_F4 = ALIAS ? pair_max(X_F4, T_F4) : X_F4 + T_F4;
+    static constexpr int NXI = (CP * XS + THREADS - 1) / THREADS;  // window items (pair, slot) per thread and chunk
     static constexpr int NWI = (W_F4 + THREADS - 1) / THREADS;     // weight float4 per thread and chunk
     static constexpr int NPRE = NXI > NWI ? NXI : NWI;
-    static constexpr size_t LDS_BYTES = (size_t)(X_F4 + T_F4 + W_F4) * 16 + 128 * sizeof(int) + 128 * sizeof(float);
+    static constexpr size_t LDS_BYTES = (size_t)(XT_F4 + W_F4) * 16 + 128 * sizeof(int) + 128 * sizeof(float);
+    static constexpr int BLOCKS_PER_CU = LDS_BYTES <= 80 * 1024 && WAVES <= 8 ? 2 : 1;
 };
 
 struct PairArgs {
@@ -60,7 +70,7 @@ struct PairArgs {
     const float *bias_a, *rinv_a, *bias_b, *rinv_b;  // 32 floats each
     int in_g0, c4_in, out_g0, og_store;
     int h, w, npix, tiles_x;
-    int n_chunks, np_last;  // chunks of 4 channel pairs; pairs in the last chunk (1..4)
+    int n_chunks, np_last;  // chunks of CP channel pairs; pairs in the last chunk (1..CP)
     int np_b;               // channel pairs of the intermediate (1..3)
     int xcd_bands;          // 1: tile = xcd_band_block(blockIdx.x) (tuning switch)
     int *ovf;               // split-fp16 range guard flag
@@ -106,15 +116,17 @@ __device__ __forceinline__ void pair_mac(f32x4 (&acc)[MT][2], const f32x4 *act, 
     }
 }
 
-template <int TW, int TH>
-__global__ __launch_bounds__(1024) void dense_pair_kernel(const PairArgs a)
+template <int TW, int TH, int WAVES, int CP, bool ALIAS>
+__global__ __launch_bounds__(64 * WAVES, (WAVES / 4) * (WAVES <= 8 ? 2 : 1))  // (8-wave blocks: two per CU, <= 128 VGPRs)
+void dense_pair_kernel(const PairArgs a)
 {
-    using G = PairGeom<TW, TH>;
+    using G = PairGeom<TW, TH, WAVES, CP, ALIAS>;
+    static_assert(WAVES > 8 || G::BLOCKS_PER_CU == 2, "8-wave shapes must fit two blocks into a CU's LDS");
     constexpr int PW = G::PW, XP = G::XP, TP = G::TP;
     extern __shared__ f32x4 pair_lds[];
-    f32x4 *xl = pair_lds;               // [4 pairs][hi | lo][XP]
-    f32x4 *tl = xl + G::X_F4;           // [3 pairs][hi | lo][TP]
-    f32x4 *wl = tl + G::T_F4;           // one chunk of weights
+    f32x4 *xl = pair_lds;                          // [CP pairs][hi | lo][XP]
+    f32x4 *tl = ALIAS ? xl : xl + G::X_F4;         // [3 pairs][hi | lo][TP] (ALIAS: over the window, once conv a is done)
+    f32x4 *wl = pair_lds + G::XT_F4;               // one chunk of weights
     int *uo = reinterpret_cast<int *>(wl + G::W_F4);  // unit tables: [0] full chunk, [1] last chunk, [2] conv b
     float *vl = reinterpret_cast<float *>(uo + 128);  // bias_a | rinv_a | bias_b | rinv_b (their global latency hides behind conv a)
 
@@ -135,7 +147,7 @@ __global__ __launch_bounds__(1024) void dense_pair_kernel(const PairArgs a)
 
     if (tid < 3 * 36) {  // unit -> slot offset (float4 units) of its (tap, pair) inside the window / T planes
         const int type = tid / 36, u = tid - type * 36;
-        const int np = type == 0 ? 4 : (type == 1 ? a.np_last : a.np_b);
+        const int np = type == 0 ? CP : (type == 1 ? a.np_last : a.np_b);
         int off = 0;
         if (u < 9 * np) {
             const int tap = u / np, pr = u - tap * np;
@@ -146,10 +158,17 @@ __global__ __launch_bounds__(1024) void dense_pair_kernel(const PairArgs a)
     if (tid >= 128 && tid < 160)  // the four epilogue vectors are contiguous (PackedPair::vec)
         reinterpret_cast<f32x4 *>(vl)[tid - 128] = reinterpret_cast<const f32x4 *>(a.bias_a)[tid - 128];
     // the T planes' tails (slots a junk output column may read; conv a writes every slot below) must hold finite values
-    if (tid >= 192 && tid < 192 + 6 * (TP - G::TILES_A * 16)) {
-        const int i = tid - 192, pl = i / (TP - G::TILES_A * 16), sl = i - pl * (TP - G::TILES_A * 16);
-        tl[pl * TP + G::TILES_A * 16 + sl] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    auto zero_t_tails = [&]() {
+        constexpr int TAIL = TP - G::TILES_A * 16;
+        if constexpr (TAIL > 0) {
+            if (tid >= 192 && tid < 192 + 6 * TAIL) {
+                const int i = tid - 192, pl = i / TAIL, sl = i - pl * TAIL;
+                tl[pl * TP + G::TILES_A * 16 + sl] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    static_assert(192 + 6 * (TP - G::TILES_A * 16) <= G::THREADS, "T tail fill needs more threads");
+    if constexpr (!ALIAS) zero_t_tails();
 
     // ---- window items of this thread: (pair, slot) -> byte offset of the pixel (or out of range) -----------------
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -162,11 +181,11 @@ __global__ __launch_bounds__(1024) void dense_pair_kernel(const PairArgs a)
         const int pr = item / G::XS, s = item - pr * G::XS;
         const int sy = s / PW, sx = s - sy * PW;
         const int gy = y0 - 2 + sy, gx = x0 - 2 + sx;
-        const bool ok = item < 4 * G::XS && (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
+        const bool ok = item < CP * G::XS && (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
         poff[k] = ok ? (unsigned)(((a.in_g0 + 2 * pr) * a.npix + gy * a.w + gx) * 16) : 0xffffffffu;
-        xdst[k] = item < 4 * G::XS ? pr * 2 * XP + s : -1;
+        xdst[k] = item < CP * G::XS ? pr * 2 * XP + s : -1;
     }
-    const unsigned chunk_bytes = (unsigned)(8 * a.npix * 16), group_bytes = (unsigned)(a.npix * 16);
+    const unsigned chunk_bytes = (unsigned)(2 * CP * a.npix * 16), group_bytes = (unsigned)(a.npix * 16);
     f32x4 xpa[G::NXI], xpb[G::NXI], wpre[G::NWI];
     // piece k of the next chunk: window item k (two float4) and weight float4 k of this thread
     auto prefetch_piece = [&](int k, int c, bool with_x, const f32x4 *wsrc_, int n_f4) {
@@ -183,7 +202,7 @@ __global__ __launch_bounds__(1024) void dense_pair_kernel(const PairArgs a)
             if (kk < G::NWI && kk * G::THREADS + tid < n_f4) wpre[kk] = wsrc_[kk * G::THREADS + tid];
         }
     };
-    auto nkb_of = [&](int c) { return c == last ? (9 * a.np_last + 3) >> 2 : 9; };
+    auto nkb_of = [&](int c) { return c == last ? (9 * a.np_last + 3) >> 2 : G::NKB; };
 
     // ---- conv a ----------------------------------------------------------------------------------------------
     const int mt_a = (G::TILES_A - wave + G::WAVES - 1) / G::WAVES;  // tiles wave, wave + WAVES, ... < TILES_A
@@ -230,6 +249,13 @@ __global__ __launch_bounds__(1024) void dense_pair_kernel(const PairArgs a)
     }
 
     OJF_STAMP();  // conv a done
+    if constexpr (ALIAS) {  // the window is dead: T takes its place, conv b's weights take conv a's
+        __syncthreads();
+        zero_t_tails();
+#pragma unroll
+        for (int k = 0; k < G::NWI; ++k)
+            if (k * G::THREADS + tid < nkb_b * 256) wl[k * G::THREADS + tid] = wpre[k];
+    }
     // epilogue a: bias, LeakyReLU, zero outside the image / the needed region, split, into the T planes
     float gmax = 0.0f;
     {
@@ -268,10 +294,12 @@ __global__ __launch_bounds__(1024) void dense_pair_kernel(const PairArgs a)
     }
     OJF_STAMP();  // epilogue a done
     __syncthreads();  // T complete, conv a's weights no longer read
+    if constexpr (!ALIAS) {
 #pragma unroll
-    for (int k = 0; k < G::NWI; ++k)
-        if (k * G::THREADS + tid < nkb_b * 256) wl[k * G::THREADS + tid] = wpre[k];
-    __syncthreads();
+        for (int k = 0; k < G::NWI; ++k)
+            if (k * G::THREADS + tid < nkb_b * 256) wl[k * G::THREADS + tid] = wpre[k];
+        __syncthreads();
+    }
 
     OJF_STAMP();  // conv b weights in place
     // ---- conv b ----------------------------------------------------------------------------------------------

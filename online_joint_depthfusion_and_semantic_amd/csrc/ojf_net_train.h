@@ -153,12 +153,19 @@ struct BnActArgs {
     // backward: block column 0 publishes the parameter gradients (added to what is there when `accumulate`)
     float *dgamma, *dbeta, *dbias;
     float *sum_dy;                    // backward, optional: [C] per-channel sums of dy (0 under batch statistics), plain store
-    // backward, optional: dy is STORED multiplied by the power of two *dy_scale (so that the split-fp16 backward-data
-    // convolution sees operands of order one; its consumers divide again), and the largest |dy| of the pass is collected
-    // in dy_max[block] (one plain store per block: same-address atomics from ~60 k waves took 3 ms per frame) for the
-    // next pass's scale
-    const float *dy_scale;
-    float *dy_max;
+    // backward, optional (the whole-net executor): dy is STORED multiplied by a power of two, so that the split-fp16
+    // backward-data convolution and weight gradient see operands inside the fp16 range with all their bits; the consumers
+    // divide again (exact).  The factor is derived IN THIS PASS from a guaranteed bound on |dy|, not from the previous pass:
+    //   dy = gamma invstd (dz - mean(dz) - xhat mean(dz xhat))  =>  |dy| <= |gamma invstd| max|dz| (2 + max|xhat|^2)
+    // (without batch statistics: |gamma invstd| max|dz|).  train_bn_bwd_reduce_kernel, which reads every dz and xhat anyway,
+    // leaves  A_c = |gamma_c invstd_c| max|dz_c|  and  X_c = max|xhat_c|  in bnd[c] / bnd[bnd_stride + c] (atomicMax on the
+    // bits of non-negative floats: kTrainSlabs arrivals per word); train_bn_bwd_apply_kernel turns them into the power of
+    // two that puts the bound into [2^13, 2^14) and publishes it in *dy_scale_out.  No lag, no headroom to outgrow, nothing
+    // to guard: a gradient of any magnitude is in range by construction (round 3 used the previous pass's maximum with 12
+    // binades of headroom - a larger jump turned dy into +-inf halves and NaN sums that no guard could see).
+    unsigned *bnd;
+    int bnd_stride;
+    float *dy_scale_out;
     int accumulate;
 };
 
@@ -193,7 +200,8 @@ __device__ __forceinline__ void train_channel_consts(const BnActArgs &a, int cg,
 }
 
 // Up to four units of identical shape run as one launch (blockIdx.z): the four branches of a VortexPooling
-struct BnGroup { BnActArgs g[4]; };
+// share_scale: the units' dy tensors are consumed as ONE stacked tensor (the branch entries) - one common factor
+struct BnGroup { BnActArgs g[4]; int share_scale; };
 
 __global__ __launch_bounds__(256) void train_stats_group_kernel(const BnGroup grp)
 {
@@ -276,6 +284,7 @@ __global__ __launch_bounds__(256) void train_bn_bwd_reduce_kernel(const BnGroup 
     const f32x4 *yp = a.y + (size_t)(a.y_g0 + cg) * a.npix;
     const f32x4 *gp = a.dout + (size_t)(a.dout_g0 + cg) * a.npix;
     double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float mx[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // max |dz|, max |xhat| per channel (the bound behind dy's factor)
     auto add = [&](const f32x4 &y, const f32x4 &g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -284,6 +293,8 @@ __global__ __launch_bounds__(256) void train_bn_bwd_reduce_kernel(const BnGroup 
             const float dz = g[j] * a.scale * dr[j] * train_act_grad(z, a.act);
             s[j] += (double)dz;
             s[4 + j] += (double)dz * (double)xh;
+            mx[j] = fmaxf(mx[j], fabsf(dz));
+            mx[4 + j] = fmaxf(mx[4 + j], fabsf(xh));
         }
     };
     int p = p0 + threadIdx.x;
@@ -304,6 +315,35 @@ __global__ __launch_bounds__(256) void train_bn_bwd_reduce_kernel(const BnGroup 
     if (threadIdx.x < 8)
         a.partial[((size_t)blockIdx.x * a.c4 + cg) * 8 + threadIdx.x] =
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (a.bnd) {
+        __shared__ float redm[4][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = mx[j];
+            for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+            if ((threadIdx.x & 63) == 0) redm[threadIdx.x >> 6][j] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            const int j = threadIdx.x & 3, c = 4 * cg + j;
+            float v = fmaxf(fmaxf(redm[0][threadIdx.x], redm[1][threadIdx.x]), fmaxf(redm[2][threadIdx.x], redm[3][threadIdx.x]));
+            if (threadIdx.x < 4) v *= fabsf(ga[j] * is[j]);  // (the per-lane constants are the same in every lane)
+            // (an infinite maximum orders above every finite one; a NaN never wins an fmaxf: NaN gradients are the
+            // reference's NaN gradients, not a range event)
+            if (c < a.C && v > 0.0f) atomicMax(a.bnd + (threadIdx.x < 4 ? 0 : a.bnd_stride) + c, __float_as_uint(v));
+        }
+    }
+}
+
+// the power of two that brings `bound` into [2^13, 2^14) (1 for a zero or non-finite bound)
+__device__ __forceinline__ float train_dy_factor(float bound)
+{
+    if (!(bound > 0.0f) || !(bound < 3.0e38f)) return 1.0f;
+    int e = 0;
+    (void)frexpf(bound, &e);  // bound = f 2^e, f in [0.5, 1)
+    int k = 14 - e;
+    k = k > 100 ? 100 : (k < -100 ? -100 : k);
+    return ldexpf(1.0f, k);
 }
 
 __global__ __launch_bounds__(256) void train_bn_bwd_apply_kernel(const BnGroup grp)
@@ -342,8 +382,26 @@ __global__ __launch_bounds__(256) void train_bn_bwd_apply_kernel(const BnGroup g
     const f32x4 *gp = a.dout + (size_t)(a.dout_g0 + cg) * a.npix;
     f32x4 *dp = a.dy + (size_t)(a.dy_g0 + cg) * a.npix;
     const int stride = gridDim.x * blockDim.x;
-    const float dys = a.dy_scale ? *a.dy_scale : 1.0f;
-    float dmax = 0.0f;
+    float dys = 1.0f;
+    if (a.bnd) {  // this pass's factor from the bound the reduce launch left (the same value in every block of the scale group)
+        __shared__ float bw[4];
+        const int n_units = grp.share_scale ? (int)gridDim.z : 1, per = 4 * a.c4;
+        float b = 0.0f;
+        if ((int)threadIdx.x < n_units * per) {
+            const int u = threadIdx.x / per, c = threadIdx.x - u * per;
+            const BnActArgs &o = grp.g[grp.share_scale ? u : (int)blockIdx.z];
+            if (c < o.C) {
+                const float A = __uint_as_float(o.bnd[c]), X = __uint_as_float(o.bnd[o.bnd_stride + c]);
+                b = (o.has_bn && o.training) ? A * (2.0f + X * X) : A;
+                if (b != b) b = 3.4e38f;  // (inf * 0)
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) b = fmaxf(b, __shfl_xor(b, off, 64));
+        if ((threadIdx.x & 63) == 0) bw[threadIdx.x >> 6] = b;
+        __syncthreads();
+        dys = train_dy_factor(fmaxf(fmaxf(bw[0], bw[1]), fmaxf(bw[2], bw[3])));
+        if (a.dy_scale_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.dy_scale_out = dys;
+    }
     auto one = [&](const f32x4 &y, const f32x4 &g) {
         f32x4 d;
 #pragma unroll
@@ -352,7 +410,6 @@ __global__ __launch_bounds__(256) void train_bn_bwd_apply_kernel(const BnGroup g
             const float z = xh * ga[j] + be[j];
             const float dz = g[j] * a.scale * dr[j] * train_act_grad(z, a.act);
             const float v = ga[j] * is[j] * (dz - m1[j] - xh * m2[j]);  // m1 = m2 = 0 without batch statistics
-            dmax = fmaxf(dmax, fabsf(v));
             d[j] = v * dys;
         }
         return d;
@@ -364,13 +421,6 @@ __global__ __launch_bounds__(256) void train_bn_bwd_apply_kernel(const BnGroup g
         dp[p] = one(y0, g0); dp[p + stride] = one(y1, g1); dp[p + 2 * stride] = one(y2, g2);
     }
     for (; p < a.npix; p += stride) dp[p] = one(yp[p], gp[p]);
-    if (a.dy_max) {
-        __shared__ float wmax[4];
-        for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
-        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = dmax;
-        __syncthreads();
-        if (threadIdx.x == 0) a.dy_max[blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-    }
 }
 
 // ---- weight gradient -----------------------------------------------------------------------------------------------
@@ -674,7 +724,7 @@ static ojf::BnActArgs train_bn_args(const float *y, int y_g0, int c_phys, int C,
     a.y_g0 = y_g0; a.out_g0 = 0; a.dout_g0 = 0; a.dy_g0 = 0; a.c4 = c_phys / 4; a.C = C; a.npix = h * w; a.act = act;
     a.has_bn = has_bn; a.training = training; a.scale = scale;
     a.mean_out = a.invstd_out = a.running_mean = a.running_var = nullptr; a.momentum = 0.0f; a.eps = 0.0f;
-    a.dgamma = a.dbeta = a.dbias = nullptr; a.sum_dy = nullptr; a.accumulate = 0; a.dy_scale = nullptr; a.dy_max = nullptr;
+    a.dgamma = a.dbeta = a.dbias = nullptr; a.sum_dy = nullptr; a.accumulate = 0; a.bnd = nullptr; a.bnd_stride = 0; a.dy_scale_out = nullptr;
     return a;
 }
 

@@ -494,40 +494,6 @@ __global__ __launch_bounds__(256) void train_pack16t_kernel(const Pack16TArgs a)
     a.wp[base + 64 * 8 + (size_t)lane * 8 + j] = lo;
 }
 
-// block maxima of a unit's bn-backward launch -> the scale group's maximum (one atomic per unit)
-struct DyMaxArgs { const float *blocks; int n; unsigned *dst; };
-__global__ __launch_bounds__(256) void train_dy_max_reduce_kernel(const DyMaxArgs *units)
-{
-    __shared__ float wmax[4];
-    const DyMaxArgs a = units[blockIdx.x];
-    float m = 0.0f;
-    for (int i = threadIdx.x; i < a.n; i += 256) m = fmaxf(m, a.blocks[i]);
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-        if (m > 0.0f) atomicMax(a.dst, __float_as_uint(m));  // (non-negative floats order like their bits)
-    }
-}
-
-// after a backward pass: next pass's dy scale per scale group from this pass's largest |dy| (it lands near 2^4: 12 binades
-// of headroom to the fp16 maximum, and elements down to 2^-30 of the largest keep all their bits), maxima reset
-__global__ void train_dy_scale_update_kernel(float *scales, unsigned *maxes, int n)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float m = __uint_as_float(maxes[i]);
-    if (m > 0.0f && m < 3.0e38f) {
-        int e = 0;
-        (void)frexpf(m, &e);
-        int k = 4 - e;
-        k = k > 100 ? 100 : (k < -100 ? -100 : k);
-        scales[i] = ldexpf(1.0f, k);
-    }
-    maxes[i] = 0u;
-}
-
 // ---- plan ----------------------------------------------------------------------------------------------------------
 struct TUnit {           // conv -> [BatchNorm2d] -> activation -> [Dropout2d], one entry of the caller's layer table
     int li, OC, IC, k, dil, group, slot, act, has_bn;
@@ -546,8 +512,8 @@ struct TUnit {           // conv -> [BatchNorm2d] -> activation -> [Dropout2d], 
     int nsteps16;
     float *wpT16, *rsT16, *rinvT16;  // backward-data weights in the split-fp16 layout: chunks of <= 8 row tiles, one after the other
     int nsteps16T;
-    int sg;                  // scale group of this unit's dy (index into the trainer's scales / maxima)
-    float *dymax_blocks;     // [kBnBlocksX * c4_out] per-block maxima of |dy| of the last backward pass
+    int sg;                  // scale group of this unit's dy (index into the trainer's factors)
+    unsigned *bnd;           // [2][4 c4_out]: this pass's bounds behind dy's factor (BnActArgs::bnd), zeroed behind every pass
     int n_ot, nsteps, n_otT, nstepsT;
     float *mean, *invstd;
     double *partial;
@@ -599,12 +565,13 @@ struct ojf_trainer {
     size_t next_fork = 0;
     bool use_side = true;
     int fwd_arith = OJF_ARITH_F16X3;  // arithmetic of the forward AND backward-data convolutions (ojf_trainer_set_arithmetic)
-    // power-of-two factors the dy tensors are stored with (one per unit; the four entries of a VortexPooling share one)
+    // power-of-two factors the dy tensors are stored with (one per unit; the four entries of a VortexPooling share one),
+    // written by every backward pass's own BatchNorm-backward launches before their consumers read them
     float *scales = nullptr;
-    unsigned *maxes = nullptr;
     int n_sg = 0;
-    long bwd_passes = 0;     // passes since the scales were reset: the first one measures, the later ones use split-fp16
-    ojf::DyMaxArgs *dymax_units = nullptr;  // device table for train_dy_max_reduce_kernel
+    unsigned *bnd_pool = nullptr;  // all units' bound words in one allocation (one memset behind a pass)
+    size_t bnd_words = 0;
+    int bwd_arith = OJF_ARITH_F16X3;  // OJF_ARITH_F32: backward-data and weight gradients stay on the fp32-input MFMA path
 };
 
 namespace ojf {
@@ -661,7 +628,6 @@ static int t_add_unit(ojf_trainer *t, int li, int OC, int IC, int k, int dil, in
     if (t_alloc(t, reinterpret_cast<void **>(&u.mean), (size_t)cop * 4, true) || t_alloc(t, reinterpret_cast<void **>(&u.invstd), (size_t)cop * 4, true)) return -2;
     if (t_alloc(t, reinterpret_cast<void **>(&u.partial), ojf_train_partial_doubles(cop) * 8, true)) return -2;
     u.sg = t->n_sg++;
-    if (t_alloc(t, reinterpret_cast<void **>(&u.dymax_blocks), (size_t)128 * u.c4_out * 4, true)) return -2;
     t->units.push_back(u);
     return (int)t->units.size() - 1;
 }
@@ -947,6 +913,10 @@ static int t_grad_mode(ojf_trainer *t, const float *buf, int g0, int n, int *acc
 // backward-data of up to four units (or of ONE wide one, in chunks of eight row tiles): d in (+)= conv(dy, W^T flipped) / s,
 // where s is the power of two dy was stored with.  From the second pass on (the first one measures the gradients' magnitude)
 // in the split-fp16 arithmetic, else on the fp32-input MFMA.
+// split-fp16 backward (backward-data AND weight gradients): with the forward arithmetic, unless the caller asked for fp32
+// gradients (ojf_trainer_set_backward_arithmetic)
+static inline bool t_bwd_f16(const ojf_trainer *t) { return t->fwd_arith == OJF_ARITH_F16X3 && t->bwd_arith == OJF_ARITH_F16X3; }
+
 struct TBwdData {
     const float *dy; int dy_g0, c4k;       // input: gradient planes of the unit's convolution output
     float *din; int in_g0, c4_in;          // output window
@@ -958,7 +928,7 @@ struct TBwdData {
 static int t_backward_data(TCtx &c, const TBwdData *b, int n)
 {
     ojf_trainer *t = c.t;
-    const bool f16 = t->fwd_arith == OJF_ARITH_F16X3 && t->bwd_passes > 0 && b[0].wpT16;
+    const bool f16 = t_bwd_f16(t) && b[0].wpT16;
     int accum[4];
     for (int i = 0; i < n; ++i)
         if (t_grad_mode(t, b[i].din, b[i].in_g0, b[i].c4_in, &accum[i])) return -2;
@@ -1015,6 +985,7 @@ static int t_units_forward(TCtx &c, const int *ids, int n, bool conv = true)
         } else if (t_conv(c, ca, n, t->units[ids[0]].n_ot)) return -2;
     }
     BnGroup grp;
+    grp.share_scale = 0;
     bool any_stats = false;
     for (int i = 0; i < 4; ++i) {
         const TUnit &u = t->units[ids[i < n ? i : 0]];
@@ -1044,7 +1015,7 @@ static int t_units_forward(TCtx &c, const int *ids, int n, bool conv = true)
 static inline bool t_wgrad_f16(const ojf_trainer *t)
 {
     static const bool off = getenv("OJF_TRAIN_WGRAD16") && atoi(getenv("OJF_TRAIN_WGRAD16")) == 0;  // A/B switch
-    return !off && t->fwd_arith == OJF_ARITH_F16X3 && t->bwd_passes > 0;
+    return !off && t_bwd_f16(t);
 }
 
 static int t_units_backward(TCtx &c, const int *ids, int n, bool tail = true)
@@ -1059,9 +1030,10 @@ static int t_units_backward(TCtx &c, const int *ids, int n, bool tail = true)
         a.dgamma = u.has_bn ? l.grad_gamma : nullptr; a.dbeta = u.has_bn ? l.grad_beta : nullptr; a.dbias = l.bias ? l.grad_bias : nullptr;
         a.accumulate = l.accumulate ? 1 : 0;
         a.sum_dy = u.sum_dy;
-        a.dy_scale = t->scales + u.sg; a.dy_max = u.dymax_blocks;  // (grid.x <= 128 blocks per channel group)
+        a.bnd = u.bnd; a.bnd_stride = 4 * u.c4_out; a.dy_scale_out = t->scales + u.sg;
         grp.g[i] = a;
     }
+    grp.share_scale = tail ? 0 : 1;  // the stacked branch entries: one factor for the four dy tensors
     const int c4 = t->units[ids[0]].c4_out;
     hipLaunchKernelGGL(train_bn_bwd_reduce_kernel, dim3(kTrainSlabs, c4, n), dim3(256), 0, c.st, grp);
     const int bx = (t->npix + 255) / 256 < 128 ? (t->npix + 255) / 256 : 128;
@@ -1082,7 +1054,7 @@ static int t_units_backward(TCtx &c, const int *ids, int n, bool tail = true)
             WgradArgs a;
             a.x = planes(u.in); a.dy = planes(u.dy); a.partial = u.wpart; a.x_g0 = u.in_g0; a.c4_in = u.c4_in; a.dy_g0 = u.y_g0; a.c4_out = u.c4_out;
             a.h = t->h; a.w = t->w; a.npix = t->npix; a.taps = taps; a.dil = u.dil; a.slabs = u.wplan.slabs; a.ocp = u.wplan.ocp; a.icp = u.wplan.icp;
-            a.ovf = u.din ? nullptr : overflow_flag();  // (dy of a unit with a backward-data convolution is range-checked there)
+            a.ovf = nullptr;  // (dy is inside the fp16 range by construction: BnActArgs::bnd; x was guarded by the forward pass)
             wg.g[i] = a;
             WgradReduceArgs r;
             r.partial = u.wpart; r.dw = l.grad_weight; r.slabs = u.wplan.slabs; r.taps = taps; r.ocp = u.wplan.ocp; r.icp = u.wplan.icp;
@@ -1309,14 +1281,14 @@ OJF_API int ojf_trainer_create(ojf_trainer **out, int version, int n_points, int
         }
         t->est_planes = cur; t->dest_planes = dcur;
         if (li != t->n_layers) return fail("ojf_trainer_create: internal layer count mismatch");
-        if (t_alloc(t, reinterpret_cast<void **>(&t->scales), (size_t)t->n_sg * 4) || t_alloc(t, reinterpret_cast<void **>(&t->maxes), (size_t)t->n_sg * 4, true)) return -2;
+        if (t_alloc(t, reinterpret_cast<void **>(&t->scales), (size_t)t->n_sg * 4)) return -2;
         std::vector<float> ones((size_t)t->n_sg, 1.0f);
         OJF_HIP(hipMemcpy(t->scales, ones.data(), ones.size() * 4, hipMemcpyHostToDevice));
-        const int bx = (t->npix + 255) / 256 < 128 ? (t->npix + 255) / 256 : 128;
-        std::vector<DyMaxArgs> tab;
-        for (const TUnit &u : t->units) tab.push_back(DyMaxArgs{u.dymax_blocks, bx * u.c4_out, t->maxes + u.sg});
-        if (t_alloc(t, reinterpret_cast<void **>(&t->dymax_units), tab.size() * sizeof(DyMaxArgs))) return -2;
-        OJF_HIP(hipMemcpy(t->dymax_units, tab.data(), tab.size() * sizeof(DyMaxArgs), hipMemcpyHostToDevice));
+        t->bnd_words = 0;
+        for (const TUnit &u : t->units) t->bnd_words += (size_t)8 * u.c4_out;
+        if (t_alloc(t, reinterpret_cast<void **>(&t->bnd_pool), t->bnd_words * 4, true)) return -2;
+        size_t at = 0;
+        for (TUnit &u : t->units) { u.bnd = t->bnd_pool + at; at += (size_t)8 * u.c4_out; }
         return 0;
     };
     rc = build();
@@ -1342,14 +1314,16 @@ OJF_API int ojf_trainer_set_arithmetic(ojf_trainer *t, int arithmetic)
 {
     using namespace ojf;
     if (!t || (arithmetic != OJF_ARITH_F32 && arithmetic != OJF_ARITH_F16X3)) return fail("ojf_trainer_set_arithmetic: bad argument");
-    if (t->fwd_arith != arithmetic) {
-        t->epoch = ~0ull;  // the packed copies of the other arithmetic are stale
-        t->bwd_passes = 0;
-        std::vector<float> ones((size_t)t->n_sg, 1.0f);
-        OJF_HIP(hipMemcpy(t->scales, ones.data(), ones.size() * 4, hipMemcpyHostToDevice));
-        OJF_HIP(hipMemset(t->maxes, 0, (size_t)t->n_sg * 4));
-    }
+    if (t->fwd_arith != arithmetic) t->epoch = ~0ull;  // the packed copies of the other arithmetic are stale
     t->fwd_arith = arithmetic;
+    return 0;
+}
+
+OJF_API int ojf_trainer_set_backward_arithmetic(ojf_trainer *t, int arithmetic)
+{
+    using namespace ojf;
+    if (!t || (arithmetic != OJF_ARITH_F32 && arithmetic != OJF_ARITH_F16X3)) return fail("ojf_trainer_set_backward_arithmetic: bad argument");
+    t->bwd_arith = arithmetic;
     return 0;
 }
 
@@ -1364,7 +1338,10 @@ OJF_API int ojf_trainer_forward(ojf_trainer *t, const ojf_train_layer *layers, i
     if (!t || !layers || !values || !weights || !frame || !est) return fail("ojf_trainer_forward: null pointer argument");
     if (n_layers != t->n_layers) return fail("ojf_trainer_forward: wrong number of layers");
     if (t->sem && !semantic_frame) return fail("ojf_trainer_forward: the net has a semantic channel but semantic_frame is NULL");
-    if (t->fwd_arith == OJF_ARITH_F16X3 && g_ovf_host && *g_ovf_host) return fail(kOverflowMsg);
+    if (t->fwd_arith == OJF_ARITH_F16X3 && g_ovf_host && *g_ovf_host) {
+        *g_ovf_host = 0;  // reported once: the caller may switch the arithmetic and go on
+        return fail(kOverflowMsg);
+    }
     TCtx c{t, layers, as_stream(stream)};
     t->launches = 0;
     if (t->epoch != weights_epoch) {
@@ -1434,12 +1411,8 @@ OJF_API int ojf_trainer_backward(ojf_trainer *t, const ojf_train_layer *layers, 
         OJF_HIP(hipEventRecord(t->join_ev, t->side));
         OJF_HIP(hipStreamWaitEvent(c.st, t->join_ev, 0));
     }
-    if (t->fwd_arith == OJF_ARITH_F16X3) {  // (every reader of this pass's factors has been enqueued)
-        hipLaunchKernelGGL(train_dy_max_reduce_kernel, dim3((unsigned)t->units.size()), dim3(256), 0, c.st, t->dymax_units);
-        hipLaunchKernelGGL(train_dy_scale_update_kernel, dim3((t->n_sg + 63) / 64), dim3(64), 0, c.st, t->scales, t->maxes, t->n_sg);
-        t->launches += 2;
-        ++t->bwd_passes;
-    }
+    OJF_HIP(hipMemsetAsync(t->bnd_pool, 0, t->bnd_words * 4, c.st));  // (behind every launch that read this pass's bounds)
+    ++t->launches;
     return check_hip(hipGetLastError(), "ojf_trainer_backward");
 }
 

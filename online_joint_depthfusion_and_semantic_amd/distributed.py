@@ -80,7 +80,13 @@ class FlatGradientAllReduce:
 
     def reduce(self):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            if self.flat.is_cuda and dist.get_backend(self.group) == 'gloo':
+                # dry runs of the schedule on one device (bench.py --dist-backend gloo, tests): gloo reduces host tensors
+                host = self.flat.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                self.flat.copy_(host)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             if self.average:
                 self.flat.div_(dist.get_world_size(self.group))
         return self.flat

@@ -52,7 +52,8 @@ class FusionLoss(torch.nn.Module):
     def forward(self, est, target):
         if est.shape[1] == 0:
             return torch.ones_like(est).sum().clamp(min=1)
-        if est.is_cuda and est.dtype == torch.float32 and target.dtype == torch.float32 and est.dim() == 3 and not target.requires_grad:
+        if (est.is_cuda and est.dtype == torch.float32 and target.dtype == torch.float32 and est.dim() == 3 and est.shape[0] == 1
+                and target.shape == est.shape and not target.requires_grad):  # (the kernels take ONE batch row set: [1, Nv, P])
             return _FusionLossFn.apply(est, target, float(self.lambda1), float(self.lambda2), float(self.lambda3))
         s_e = torch.sign(est).reshape([est.shape[0], est.shape[2], est.shape[1]])
         s_t = torch.sign(target).reshape([target.shape[0], target.shape[2], target.shape[1]])

@@ -114,6 +114,9 @@ class Pipeline(torch.nn.Module):
         fused in between are invalid then; set FUSION_MODEL.arithmetic = 'f32').  Cheap: call per scene / epoch."""
         if self._engine is not None:
             self._engine.check()
+        elif self.__dict__.get('_hip_train') is not None:  # training only: the executor's forward pass shares the guard
+            from . import _lib
+            _lib.check(_lib.load().ojf_net_check(_lib.stream_ptr(self.device)), 'ojf_net_check')
 
     # ---- cached device objects ----------------------------------------------------------------
     def _weights_fingerprint(self):
@@ -337,7 +340,8 @@ class Pipeline(torch.nn.Module):
             if tn is None or tn.net is not self._fusion_network:
                 from .train import HipTrainNet
                 tn = self.__dict__['_hip_train'] = HipTrainNet(self._fusion_network, graph=self.config.FUSION_MODEL.get('train_graph', False),
-                                                               inplace_grads=True, arithmetic=self.config.FUSION_MODEL.get('train_arithmetic', 'f16x3'))
+                                                               inplace_grads=True, arithmetic=self.config.FUSION_MODEL.get('train_arithmetic', 'f16x3'),
+                                                               backward_arithmetic=self.config.FUSION_MODEL.get('train_arithmetic_bwd', None))
             return tn(inputs)
         return self._fusion_network.forward(inputs)
 

@@ -242,7 +242,7 @@ class HipTrainNet:
     """Runs ``net`` (model.FusionNet_v3 / FusionNet_v2) through ``LayerUnit`` nodes.  ``net.training`` selects batch
     statistics + dropout (train) or running statistics, no dropout (eval), exactly like the module's own forward."""
 
-    def __init__(self, net, graph=False, inplace_grads=False, executor=True, arithmetic='f16x3'):
+    def __init__(self, net, graph=False, inplace_grads=False, executor=True, arithmetic='f16x3', backward_arithmetic=None):
         _lib.require_gpu()
         self.net = net
         self.inplace_grads = bool(inplace_grads)  # see _grad_target
@@ -250,8 +250,16 @@ class HipTrainNet:
         # walk, grouped VortexPooling branches) behind ONE autograd node; False = one autograd node per layer unit (the
         # round-2 path, kept for A/B runs and for graph=True)
         self.executor = bool(executor)
-        # forward convolutions of the executor: 'f16x3' (split-fp16, the inference arithmetic) | 'f32'; backward is always fp32-MFMA
+        # Convolutions of the executor.  ``arithmetic``: 'f16x3' (split-fp16, the inference arithmetic) | 'f32' for the
+        # forward pass.  ``backward_arithmetic`` (FUSION_MODEL.train_arithmetic_bwd; default = ``arithmetic``): under a
+        # split-fp16 forward, backward-data and the weight gradients run in split-fp16 as well - every dy tensor is stored
+        # under a power of two derived in the SAME pass from a guaranteed bound on its magnitude (csrc/ojf_net_train.h
+        # BnActArgs::bnd), so no gradient can leave the fp16 range whatever the loss scale; 'f32' keeps the backward
+        # convolutions on the fp32-input MFMA path.
         self.arithmetic = arithmetic
+        self.backward_arithmetic = backward_arithmetic or arithmetic
+        self._weights_sig = None
+        self._weights_epoch = 0
         self._trainers = {}
         self._table = None
         self._gen = 0
@@ -435,7 +443,25 @@ class HipTrainNet:
                                                   int(bool(net.config.use_semantics)), float(net.scale), h, w), 'ojf_trainer_create')
             tr = self._trainers[key] = _TrainerHandle(handle)
             _lib.check(lib.ojf_trainer_set_arithmetic(handle, _lib.ARITHMETIC[self.arithmetic]), 'ojf_trainer_set_arithmetic')
+            _lib.check(lib.ojf_trainer_set_backward_arithmetic(handle, _lib.ARITHMETIC[self.backward_arithmetic]),
+                       'ojf_trainer_set_backward_arithmetic')
         return tr
+
+    def invalidate(self):
+        """Forces the packed weight copies to be rebuilt by the next forward pass.  In-place updates (optimizer steps,
+        ``load_state_dict``) and re-assigned storage are seen without it (per-tensor version counters and addresses);
+        writes through ``p.data`` / ``tensor.data.copy_`` / ``dist.broadcast(p.data)`` bump no counter: call this after
+        them."""
+        self._weights_sig = None
+
+    def _epoch(self, mods):
+        """A number that changes whenever a convolution weight or bias may have changed (ojf_trainer_forward's
+        ``weights_epoch``): the per-tensor (address, version) tuples are compared element-wise - no sum that could cancel."""
+        sig = tuple((c.weight.data_ptr(), c.weight._version, _p(c.bias), c.bias._version if c.bias is not None else -1) for c, _, _ in mods)
+        if sig != self._weights_sig:
+            self._weights_sig = sig
+            self._weights_epoch += 1
+        return self._weights_epoch
 
     def _forward_executor(self, x):
         net = self.net
@@ -450,10 +476,9 @@ class HipTrainNet:
             self._params = [p for p in net.parameters()]
             self._pindex = {id(p): i for i, p in enumerate(self._params)}
             assert lib.ojf_trainer_layer_count(tr.handle) == len(mods)
-        table = self.__dict__.get('_table_obj')
-        if table is None:  # one table for the trainer's life: backward finds last frame's gradient pointers still in place
-            table = self._table_obj = (_lib.TrainLayer * len(mods))()
-            self._grad_sig = None
+        table = tr.table
+        if table is None:  # one table per trainer (= per frame shape), for its life: backward finds the gradient pointers in place
+            table = tr.table = (_lib.TrainLayer * len(mods))()
         counters = []
         # Dropout2d: one uniform draw for every active layer of this pass, per-channel factors 0 or 1 / keep
         drops = [(i, d) for i, (c, b, d) in enumerate(mods) if d is not None and d.training and d.p > 0]
@@ -469,11 +494,10 @@ class HipTrainNet:
                 n = mods[i][0].out_channels
                 scales[i] = factors[off:off + n]
                 off += n
-        epoch = 0
+        epoch = self._epoch(mods)
         for i, (conv, bn, drop) in enumerate(mods):
             e = table[i]
             e.weight, e.bias = conv.weight.data_ptr(), _p(conv.bias)
-            epoch += conv.weight._version + conv.weight.data_ptr() + (conv.bias._version + conv.bias.data_ptr() if conv.bias is not None else 0)
             e.out_channels, e.in_channels, e.ksize, e.dilation = conv.out_channels, conv.in_channels, conv.kernel_size[0], conv.dilation[0]
             if bn is not None:
                 if bn.momentum is None:
@@ -487,7 +511,7 @@ class HipTrainNet:
         ins = [x['tsdf_values'], x['tsdf_weights'], x['tsdf_frame']] + ([x['semantic_frame']] if net.config.use_semantics else [])
         ins = [t.contiguous().float() for t in ins]
         self._gen += 1
-        state = dict(table=table, tr=tr, gen=self._gen, keep_alive=(scales, ins), epoch=epoch & 0xffffffffffffffff, dev=dev, shape=(1, P, h, w))
+        state = dict(table=table, tr=tr, gen=self._gen, keep_alive=(scales, ins), epoch=epoch, dev=dev, shape=(1, P, h, w))
         est = _NetFn.apply(self, state, *(ins + self._params))
         if counters:
             torch._foreach_add_(counters, 1)  # nn.BatchNorm2d.num_batches_tracked, all at once
@@ -573,6 +597,8 @@ class _TrainerHandle:
     def __init__(self, handle):
         self.handle = handle
         self.gen = 0  # generation of the forward pass whose activations the trainer holds
+        self.table = None   # this trainer's layer table (ojf_train_layer[n]): pointers / flags of ITS last forward pass
+        self.grad_sig = None  # the p.grad tensors whose addresses the table holds (steady state of in-place accumulation)
 
     def __del__(self):
         try:
@@ -610,7 +636,7 @@ class _NetFn(torch.autograd.Function):
         needs = ctx.needs_input_grad[2 + ctx.n_in:]
         inplace = tn.inplace_grads and not torch.cuda.is_current_stream_capturing()
         out = [None] * len(tn._params)
-        sig = tn.__dict__.get('_grad_sig')
+        sig = tr.grad_sig
         steady = inplace and sig is not None and all(p.grad is g for p, g in zip(tn._params, sig))
         if steady:  # every parameter still accumulates into the tensor whose address the table already holds
             _lib.check(lib.ojf_trainer_backward(tr.handle, table, len(table), dest.contiguous().data_ptr(), _lib.stream_ptr(state['dev'])),
@@ -648,12 +674,12 @@ class _NetFn(torch.autograd.Function):
         _lib.check(lib.ojf_trainer_backward(tr.handle, table, len(table), dest.contiguous().data_ptr(), _lib.stream_ptr(state['dev'])),
                    'ojf_trainer_backward')
         # steady state from the next pass on: the gradient tensors exist and the table says "accumulate" for every layer
-        tn._grad_sig = [p.grad for p in tn._params] if inplace else None
-        if tn._grad_sig is not None and not all_accumulating:
+        tr.grad_sig = [p.grad for p in tn._params] if inplace else None
+        if tr.grad_sig is not None and not all_accumulating:
             for e in table:
                 e.accumulate = 1
-            if any(g is None for g in tn._grad_sig):
-                tn._grad_sig = None
+            if any(g is None for g in tr.grad_sig):
+                tr.grad_sig = None
         return (None, None) + (None,) * ctx.n_in + tuple(out)
 
 

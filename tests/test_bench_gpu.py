@@ -56,6 +56,18 @@ def test_train_flag_times_the_configs3_frame_step(cuda):
     assert out['value'] > 0 and out['gradient_bytes'] > 1e6
 
 
+def test_train_gpus_2_over_gloo_dry_runs_the_training_schedule_on_one_device(cuda):
+    """the TRAINING schedule (self-launch, barrier, accumulation boundary on the common counter, the
+    all-reduce call, max over ranks) as a two-rank gloo dry run on one device; the gradient buffer is staged through the host
+    for gloo and the JSON line says so."""
+    out = _bench('--train', '--gpus', '2', '--dist-backend', 'gloo', '--steps', '8', '--warmup', '8', '--repeats', '2',
+                 '--height', '48', '--width', '64', '--grid', '64')
+    assert out['n_gpus'] == 2 and 'configs[3]' in out['config']['workload']
+    assert out['allreduce_calls_in_timed_region'] == 2 and out['gradients_finite'] is True
+    assert out['allreduce_backend'].startswith('gloo') and out['allreduce_us'] > 0
+    assert abs(out['value'] * out['ms_per_step'] / 1e3 - 2.0) < 1e-6
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason='two ranks on RCCL need two HIP devices')
 @pytest.mark.parametrize('train', [False, True])
 def test_gpus_2_over_rccl(cuda, train):
