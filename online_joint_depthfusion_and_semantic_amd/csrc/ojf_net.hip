@@ -1738,14 +1738,20 @@ struct PackedPair {
 };
 
 // Launch shapes of dense_pair_kernel (PairGeom): picked per frame size, the chunk size is part of the weight packing
-enum PairCfg { PAIR_20x16_W16 = 0, PAIR_12x8_W16 = 1, PAIR_20x8_W8 = 2, PAIR_16x8_W8 = 3, PAIR_20x8_W8_CP4 = 4 };
+enum PairCfg { PAIR_20x16_W16 = 0, PAIR_12x8_W16 = 1, PAIR_20x8_W8 = 2, PAIR_16x8_W8 = 3, PAIR_20x8_W8_CP4 = 4,
+               PAIR_20x16_W16_P5 = 5, PAIR_12x8_W16_P5 = 6, PAIR_CFG_COUNT = 7 };
 static inline int pair_cfg_chunk_pairs(int cfg) { return cfg == PAIR_20x8_W8 || cfg == PAIR_16x8_W8 ? 3 : 4; }
-static int pair_cfg_for(int h, int w)
+static inline bool pair_cfg_pack(int cfg) { return cfg == PAIR_20x16_W16_P5 || cfg == PAIR_12x8_W16_P5; }
+// c_out_phys: physical output channels of both convolutions (the packed-row shapes are written for 20 = 19 + padding)
+static int pair_cfg_for(int h, int w, int c_out_phys)
 {
     static const int forced = getenv("OJF_PAIR_CFG") ? atoi(getenv("OJF_PAIR_CFG")) : -1;  // tuning switch
-    if (forced >= 0 && forced <= 4) return forced;
     // one block per tile, 16 waves: the large tile when it still gives every CU a block (320x240: 240 blocks)
-    return ((w + 19) / 20) * ((h + 15) / 16) >= 200 ? PAIR_20x16_W16 : PAIR_12x8_W16;
+    const bool big = ((w + 19) / 20) * ((h + 15) / 16) >= 200;
+    // (round 4 measured the other shapes - two 8-wave blocks per CU, packed rows - against this one: DESIGN.md §5.0, no gain)
+    int cfg = big ? PAIR_20x16_W16 : PAIR_12x8_W16;
+    if (forced >= 0 && forced < PAIR_CFG_COUNT && (!pair_cfg_pack(forced) || c_out_phys == 20)) cfg = forced;
+    return cfg;
 }
 
 static void release(PackedPair &pp)
@@ -1757,6 +1763,33 @@ static void release(PackedPair &pp)
 }
 
 // K blocks of `np_chunk`-pair chunks: unit u = 4S + g -> (tap = u / np, pair = u % np), K slot j = channel 8*pair + j
+// packed-row form (PairGeom PACK): [K block][3 row tiles][lane] x 8 halfs; packed row R = hi half of output row R for
+// R < c_out_phys, lo half of output row R - c_out_phys for R < 2 c_out_phys, zero beyond
+static void pack_pair_conv5(const ConvBuilder &b, const std::vector<float> &rs, std::vector<float> &dst, int cp)
+{
+    const int npairs = (b.c_in_phys + 7) / 8, n_chunks = (npairs + cp - 1) / cp, ocp = b.c_out_phys;
+    for (int c = 0; c < n_chunks; ++c) {
+        const int np = c == n_chunks - 1 ? npairs - cp * c : cp, nkb = (9 * np + 3) / 4;
+        const size_t base = dst.size();
+        dst.resize(base + (size_t)nkb * 192 * 4, 0.0f);
+        _Float16 *hp = reinterpret_cast<_Float16 *>(dst.data() + base);
+        for (int S = 0; S < nkb; ++S)
+            for (int t = 0; t < 3; ++t)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int R = t * 16 + (lane & 15), u = 4 * S + (lane >> 4);
+                        if (R >= 2 * ocp || u >= 9 * np) continue;
+                        const int oc = R < ocp ? R : R - ocp;
+                        const int tap = u / np, ch = 8 * (cp * c + u % np) + j;
+                        if (ch >= b.c_in_phys) continue;
+                        const float v = rs[oc] * b.W[((size_t)oc * b.taps + tap) * b.c_in_phys + ch];
+                        _Float16 hi, lo;
+                        split_weight(v, hi, lo);
+                        hp[(((size_t)S * 3 + t) * 64 + lane) * 8 + j] = R < ocp ? hi : lo;
+                    }
+    }
+}
+
 static void pack_pair_conv(const ConvBuilder &b, const std::vector<float> &rs, std::vector<float> &dst, int cp)
 {
     const int npairs = (b.c_in_phys + 7) / 8, n_chunks = (npairs + cp - 1) / cp;
@@ -1801,8 +1834,14 @@ static int finish_pair(const ConvBuilder &ba, const ConvBuilder &bb, PackedPair 
         return rs;
     };
     const std::vector<float> ra = scales(ba, 0), rb = scales(bb, 64);
-    pack_pair_conv(ba, ra, wa, cp);
-    pack_pair_conv(bb, rb, wb, 4);  // (3 pairs: one chunk whatever the chunk size)
+    if (pair_cfg_pack(cfg)) {
+        if (ba.c_out_phys != 20 || bb.c_out_phys != 20) return fail("pair packing: the packed-row shapes need 20 physical output channels");
+        pack_pair_conv5(ba, ra, wa, cp);
+        pack_pair_conv5(bb, rb, wb, 4);
+    } else {
+        pack_pair_conv(ba, ra, wa, cp);
+        pack_pair_conv(bb, rb, wb, 4);  // (3 pairs: one chunk whatever the chunk size)
+    }
     pp.np_b = (bb.c_in_phys + 7) / 8;
     const int npairs = (ba.c_in_phys + 7) / 8;
     pp.c4_in = ba.c_in_phys / 4;
@@ -1813,19 +1852,19 @@ static int finish_pair(const ConvBuilder &ba, const ConvBuilder &bb, PackedPair 
     return 0;
 }
 
-template <int TW, int TH, int WAVES = 16, int CP = 4, bool ALIAS = false>
+template <int TW, int TH, int WAVES = 16, int CP = 4, bool ALIAS = false, bool PACK = false>
 static int launch_pair_t(PairArgs &a, hipStream_t st)
 {
-    using G = PairGeom<TW, TH, WAVES, CP, ALIAS>;
+    using G = PairGeom<TW, TH, WAVES, CP, ALIAS, PACK>;
     static bool configured = false;
     if (!configured) {
-        OJF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_pair_kernel<TW, TH, WAVES, CP, ALIAS>),
+        OJF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_pair_kernel<TW, TH, WAVES, CP, ALIAS, PACK>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
         configured = true;
     }
     a.tiles_x = (a.w + TW - 1) / TW;
     const int tiles = a.tiles_x * ((a.h + TH - 1) / TH);
-    hipLaunchKernelGGL((dense_pair_kernel<TW, TH, WAVES, CP, ALIAS>), dim3(tiles), dim3(G::THREADS), G::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((dense_pair_kernel<TW, TH, WAVES, CP, ALIAS, PACK>), dim3(tiles), dim3(G::THREADS), G::LDS_BYTES, st, a);
     mark_launch("dense_pair_kernel", st);
     return check_hip(hipGetLastError(), "dense_pair_kernel launch");
 }
@@ -1852,6 +1891,8 @@ static int launch_pair(const PackedPair &pp, const float *in, int in_g0, float *
     case PAIR_20x8_W8: return launch_pair_t<20, 8, 8, 3, true>(a, st);
     case PAIR_16x8_W8: return launch_pair_t<16, 8, 8, 3, true>(a, st);
     case PAIR_20x8_W8_CP4: return launch_pair_t<20, 8, 8, 4, true>(a, st);
+    case PAIR_20x16_W16_P5: return launch_pair_t<20, 16, 16, 4, false, true>(a, st);
+    case PAIR_12x8_W16_P5: return launch_pair_t<12, 8, 16, 4, false, true>(a, st);
     }
     return fail("dense pair: unknown launch shape");
 }
@@ -2493,7 +2534,7 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
             net->dense[head].push_back(pb);
             if (net->arith == OJF_ARITH_F16X3 && cs <= 24) {
                 PackedPair pp;
-                if (finish_pair(ba, bb, pp, pair_cfg_for(net->h, net->w))) return -2;
+                if (finish_pair(ba, bb, pp, pair_cfg_for(net->h, net->w, cs))) return -2;
                 net->pairs[head].push_back(pp);
             }
         }

@@ -38,10 +38,20 @@ constexpr int pair_max(int a, int b) { return a > b ? a : b; }
 //   <TW, TH, 8, CP, true>   round 4: 8-wave blocks small enough for TWO per CU (<= 80 KB: chunks of CP = 3 channel pairs,
 //                           the T planes alias the window planes - the window is dead once conv a has finished), so that one
 //                           block's fetch / split / barrier phases run beside the other's MFMA phase
-template <int TW, int TH, int WAVES_ = 16, int CP_ = 4, bool ALIAS_ = false>
+//   <..., PACK = true>      round 4: FIVE MFMAs per (K block, pixel tile) instead of six.  The 19 (20 padded) output channels
+//                           occupy 2 x 16 MFMA rows per weight half = 4 row tiles for the hi and lo halves, 41 % of them
+//                           padding.  Packed, the 20 hi rows and the 20 lo rows are 40 consecutive rows = 3 row tiles:
+//                           x_hi meets all three (w_hi x_hi and w_lo x_hi), x_lo the two that hold hi rows (w_hi x_lo;
+//                           the lo rows riding along add w_lo x_lo, the term the split otherwise drops).  The epilogue
+//                           adds the hi-row and lo-row accumulators of a channel group (they sit 5 lane groups apart).
+//                           The K loops of this kernel run at ~89 % of the matrix pipe (s_memtime stamps,
+//                           profiles/r04_pair_stamps.txt), so the sixth MFMA was the bound.
+template <int TW, int TH, int WAVES_ = 16, int CP_ = 4, bool ALIAS_ = false, bool PACK_ = false>
 struct PairGeom {
     static constexpr int WAVES = WAVES_, THREADS = 64 * WAVES, CP = CP_;
-    static constexpr bool ALIAS = ALIAS_;
+    static constexpr bool ALIAS = ALIAS_, PACK = PACK_;
+    static constexpr int WT = PACK ? 3 : 4;               // weight float4 per lane and K block: 3 packed row tiles, or 2 x (hi, lo)
+    static constexpr int NACC = PACK ? 3 : 2;             // accumulator tiles per pixel tile
     static constexpr int NKB = (9 * CP + 3) / 4;           // K blocks of a full chunk
     static constexpr int PW = TW + 4;                      // slot pitch = window width
     static constexpr int XS = (TH + 4) * PW;               // window slots
@@ -53,7 +63,7 @@ struct PairGeom {
     static constexpr int XP = pair_round16(pair_max(XS, TILES_A * 16 + 2 * PW + 2));
     static constexpr int TP = pair_round16(pair_max(TILES_A * 16, TILES_B * 16 + 2 * PW + 2));
     // float4 counts of the three LDS areas (conv b always has 3 pairs = 7 K blocks of weights)
-    static constexpr int X_F4 = CP * 2 * XP, T_F4 = 3 * 2 * TP, W_F4 = pair_max(NKB, 7) * 256;
+    static constexpr int X_F4 = CP * 2 * XP, T_F4 = 3 * 2 * TP, W_F4 = pair_max(NKB, 7) * 64 * WT;
     static constexpr int XT_F4 = ALIAS ? pair_max(X_F4, T_F4) : X_F4 + T_F4;
     static constexpr int NXI = (CP * XS + THREADS - 1) / THREADS;  // window items (pair, slot) per thread and chunk
     static constexpr int NWI = (W_F4 + THREADS - 1) / THREADS;     // weight float4 per thread and chunk
@@ -91,36 +101,74 @@ __device__ __forceinline__ void pair_split(const f32x4 &a, const f32x4 &b, f32x4
 // acc[m][n] += W[K block][n] * act[unit(K block, g)][slot[m] + tap] over `nkb` K blocks
 // `hook(S)` runs once per K block before its MFMAs: the caller trickles the next chunk's global loads through it (a
 // burst of 13 loads per lane at the top of the loop stalled the in-order waves at issue until the memory queue drained)
-template <int MT, int PLANE, class Hook>
-__device__ __forceinline__ void pair_mac(f32x4 (&acc)[MT][2], const f32x4 *act, const int *uo, int nkb, const f32x4 *wl,
+template <int MT, int PLANE, int NACC, class Hook>
+__device__ __forceinline__ void pair_mac(f32x4 (&acc)[MT][NACC], const f32x4 *act, const int *uo, int nkb, const f32x4 *wl,
                                          const int (&slot)[MT], int mt_wave, int lane, int g, Hook hook)
 {
     for (int S = 0; S < nkb; ++S) {
         hook(S);
         const int off = uo[4 * S + g];
-        f32x4 wh[2], wlo[2];
+        if constexpr (NACC == 2) {
+            f32x4 wh[2], wlo[2];
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            wh[n] = wl[(S * 2 + n) * 128 + lane];
-            wlo[n] = wl[(S * 2 + n) * 128 + 64 + lane];
-        }
+            for (int n = 0; n < 2; ++n) {
+                wh[n] = wl[(S * 2 + n) * 128 + lane];
+                wlo[n] = wl[(S * 2 + n) * 128 + 64 + lane];
+            }
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            if (m < mt_wave) {  // wave-uniform
-                const f16x8 xh = __builtin_bit_cast(f16x8, act[off + slot[m]]);
-                const f16x8 xl = __builtin_bit_cast(f16x8, act[off + PLANE + slot[m]]);
+            for (int m = 0; m < MT; ++m) {
+                if (m < mt_wave) {  // wave-uniform
+                    const f16x8 xh = __builtin_bit_cast(f16x8, act[off + slot[m]]);
+                    const f16x8 xl = __builtin_bit_cast(f16x8, act[off + PLANE + slot[m]]);
 #pragma unroll
-                for (int n = 0; n < 2; ++n) acc[m][n] = mfma_f16x3(wh[n], wlo[n], xh, xl, acc[m][n]);
+                    for (int n = 0; n < 2; ++n) acc[m][n] = mfma_f16x3(wh[n], wlo[n], xh, xl, acc[m][n]);
+                }
+            }
+        } else {  // packed rows: tile 0 = hi rows 0..15, tile 1 = hi rows 16..19 | lo rows 0..11, tile 2 = lo rows 12..19
+            f16x8 w[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) w[t] = __builtin_bit_cast(f16x8, wl[(S * 3 + t) * 64 + lane]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                if (m < mt_wave) {  // wave-uniform
+                    const f16x8 xh = __builtin_bit_cast(f16x8, act[off + slot[m]]);
+                    const f16x8 xl = __builtin_bit_cast(f16x8, act[off + PLANE + slot[m]]);
+                    // (small terms first, like mfma_f16x3)
+                    acc[m][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[2], xh, acc[m][2], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[1], xl, acc[m][1], 0, 0, 0);
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[0], xl, acc[m][0], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[1], xh, acc[m][1], 0, 0, 0);
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[0], xh, acc[m][0], 0, 0, 0);
+                }
             }
         }
     }
 }
 
-template <int TW, int TH, int WAVES, int CP, bool ALIAS>
+// Packed rows (PairGeom PACK), 20 physical output channels: channel group og's hi rows are packed group og, its lo rows packed
+// group og + 5; lane (i16, g) of accumulator tile t holds packed group 4 t + g.  Returns hi + lo of group g in `main` (every
+// lane) and of group 4 in `extra` (meaningful in lanes g == 0).
+__device__ __forceinline__ void pair_unpack5(const f32x4 (&acc)[3], int lane, int i16, int g, f32x4 &main, f32x4 &extra)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // (through float temporaries: __builtin_bit_cast applied to a vector ELEMENT lvalue reads element 0 whatever the index
+        // - hipcc 7.2 - and all four exchanges collapse into one)
+        const float f1 = acc[1][j], f2 = acc[2][j];
+        const int a1 = __float_as_int(f1), a2 = __float_as_int(f2);
+        const int up1 = __builtin_amdgcn_ds_bpermute(((lane + 16) & 63) * 4, a1);  // tile 1, lane group g + 1: lo rows of groups 0..2
+        const int lo3 = __builtin_amdgcn_ds_bpermute(i16 * 4, a2);                 // tile 2, lane group 0: lo rows of group 3
+        const int up2 = __builtin_amdgcn_ds_bpermute(((lane + 16) & 63) * 4, a2);  // tile 2, lane group 1: lo rows of group 4
+        main[j] = acc[0][j] + __int_as_float(g < 3 ? up1 : lo3);
+        extra[j] = f1 + __int_as_float(up2);
+    }
+}
+
+template <int TW, int TH, int WAVES, int CP, bool ALIAS, bool PACK>
 __global__ __launch_bounds__(64 * WAVES, (WAVES / 4) * (WAVES <= 8 ? 2 : 1))  // (8-wave blocks: two per CU, <= 128 VGPRs)
 void dense_pair_kernel(const PairArgs a)
 {
-    using G = PairGeom<TW, TH, WAVES, CP, ALIAS>;
+    using G = PairGeom<TW, TH, WAVES, CP, ALIAS, PACK>;
     static_assert(WAVES > 8 || G::BLOCKS_PER_CU == 2, "8-wave shapes must fit two blocks into a CU's LDS");
     constexpr int PW = G::PW, XP = G::XP, TP = G::TP;
     extern __shared__ f32x4 pair_lds[];
@@ -209,16 +257,18 @@ void dense_pair_kernel(const PairArgs a)
     int slot_a[G::MT_A];
 #pragma unroll
     for (int m = 0; m < G::MT_A; ++m) slot_a[m] = (wave + G::WAVES * (m < mt_a ? m : 0)) * 16 + i16;
-    f32x4 acc[G::MT_A][2];
+    f32x4 acc[G::MT_A][G::NACC];
 #pragma unroll
-    for (int m = 0; m < G::MT_A; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < G::MT_A; ++m)
+#pragma unroll
+        for (int n = 0; n < G::NACC; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     OJF_STAMP();  // 1: setup done
 #pragma unroll
-    for (int k = 0; k < G::NPRE; ++k) prefetch_piece(k, 0, true, a.wa, nkb_of(0) * 256);
+    for (int k = 0; k < G::NPRE; ++k) prefetch_piece(k, 0, true, a.wa, nkb_of(0) * 64 * G::WT);
     const f32x4 *wsrc = a.wa;
     for (int c = 0; c <= last; ++c) {
-        const int nkb = nkb_of(c);
+        const int nkb = nkb_of(c), wf4 = 64 * G::WT;  // weight float4 per K block
         if (c) __syncthreads();  // readers of the previous chunk are done
         OJF_STAMP();  // 2 + 3c: chunk c: previous compute done
 #pragma unroll
@@ -232,16 +282,16 @@ void dense_pair_kernel(const PairArgs a)
         }
 #pragma unroll
         for (int k = 0; k < G::NWI; ++k)
-            if (k * G::THREADS + tid < nkb * 256) wl[k * G::THREADS + tid] = wpre[k];
+            if (k * G::THREADS + tid < nkb * wf4) wl[k * G::THREADS + tid] = wpre[k];
         OJF_STAMP();  // 3 + 3c: operands arrived and written
         __syncthreads();
         OJF_STAMP();  // 4 + 3c: barrier passed
-        wsrc += nkb * 256;
+        wsrc += nkb * wf4;
         // the next chunk's window and weights (or conv b's weights), one piece per K block
         const bool more = c < last;
         const f32x4 *nsrc = more ? wsrc : a.wb;
-        const int n_f4 = more ? nkb_of(c + 1) * 256 : nkb_b * 256;
-        pair_mac<G::MT_A, XP>(acc, xl, uo + (c == last ? 36 : 0), nkb, wl, slot_a, mt_a, lane, g,
+        const int n_f4 = more ? nkb_of(c + 1) * wf4 : nkb_b * wf4;
+        pair_mac<G::MT_A, XP, G::NACC>(acc, xl, uo + (c == last ? 36 : 0), nkb, wl, slot_a, mt_a, lane, g,
                               [&](int S) { if (S < G::NPRE) prefetch_piece(S, c + 1, more, nsrc, n_f4); });
 #pragma unroll
         for (int k = 0; k < G::NPRE; ++k)
@@ -254,7 +304,7 @@ void dense_pair_kernel(const PairArgs a)
         zero_t_tails();
 #pragma unroll
         for (int k = 0; k < G::NWI; ++k)
-            if (k * G::THREADS + tid < nkb_b * 256) wl[k * G::THREADS + tid] = wpre[k];
+            if (k * G::THREADS + tid < nkb_b * 64 * G::WT) wl[k * G::THREADS + tid] = wpre[k];
     }
     // epilogue a: bias, LeakyReLU, zero outside the image / the needed region, split, into the T planes
     float gmax = 0.0f;
@@ -272,11 +322,9 @@ void dense_pair_kernel(const PairArgs a)
             const int ry = s / PW, rx = s - ry * PW;
             const int gy = y0 - 1 + ry, gx = x0 - 1 + rx;
             const bool ok = s < G::TS && rx < TW + 2 && (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const int pr = 2 * n + (g >> 1);
-                if (pr >= 3) continue;
-                const f32x4 lin = fma4(acc[m][n], rv[n], bv[n]);
+            // channel group og of this pixel -> the T planes (pair og / 2, half og & 1)
+            auto put_t = [&](int og, const f32x4 &raw, const f32x4 &r4, const f32x4 &b4) {
+                const f32x4 lin = fma4(raw, r4, b4);
                 if (ok) gmax = guard_max(gmax, lin);
                 f32x4 v;
 #pragma unroll
@@ -285,10 +333,27 @@ void dense_pair_kernel(const PairArgs a)
                 const f16x4 h4 = __builtin_convertvector(v, f16x4);
                 const uint2 hp = __builtin_bit_cast(uint2, h4);
                 const uint2 l4 = uint2{split_lo_pair(hp.x, v[0], v[1]), split_lo_pair(hp.y, v[2], v[3])};
-                uint2 *dh = reinterpret_cast<uint2 *>(tl + pr * 2 * TP + s) + (g & 1);
-                uint2 *dl = reinterpret_cast<uint2 *>(tl + pr * 2 * TP + TP + s) + (g & 1);
+                const int pr = og >> 1;
+                uint2 *dh = reinterpret_cast<uint2 *>(tl + pr * 2 * TP + s) + (og & 1);
+                uint2 *dl = reinterpret_cast<uint2 *>(tl + pr * 2 * TP + TP + s) + (og & 1);
                 *dh = __builtin_bit_cast(uint2, h4);
                 *dl = l4;
+            };
+            if constexpr (G::PACK) {
+                f32x4 main, extra;
+                pair_unpack5(acc[m], lane, i16, g, main, extra);
+                put_t(g, main, rv[0], bv[0]);
+                if (g == 0) put_t(4, extra, rv[1], bv[1]);
+                if (g == 1) {  // group 5 = padding channels 20..23 of the third pair: zeros
+                    reinterpret_cast<uint2 *>(tl + 2 * 2 * TP + s)[1] = uint2{0u, 0u};
+                    reinterpret_cast<uint2 *>(tl + 2 * 2 * TP + TP + s)[1] = uint2{0u, 0u};
+                }
+            } else {
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    if (2 * n + (g >> 1) >= 3) continue;
+                    put_t(4 * n + g, acc[m][n], rv[n], bv[n]);
+                }
             }
         }
     }
@@ -297,7 +362,7 @@ void dense_pair_kernel(const PairArgs a)
     if constexpr (!ALIAS) {
 #pragma unroll
         for (int k = 0; k < G::NWI; ++k)
-            if (k * G::THREADS + tid < nkb_b * 256) wl[k * G::THREADS + tid] = wpre[k];
+            if (k * G::THREADS + tid < nkb_b * 64 * G::WT) wl[k * G::THREADS + tid] = wpre[k];
         __syncthreads();
     }
 
@@ -307,10 +372,12 @@ void dense_pair_kernel(const PairArgs a)
     int slot_b[G::MT_B];
 #pragma unroll
     for (int m = 0; m < G::MT_B; ++m) slot_b[m] = (wave + G::WAVES * (m < mt_b ? m : 0)) * 16 + i16;
-    f32x4 accb[G::MT_B][2];
+    f32x4 accb[G::MT_B][G::NACC];
 #pragma unroll
-    for (int m = 0; m < G::MT_B; ++m) accb[m][0] = accb[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    pair_mac<G::MT_B, TP>(accb, tl, uo + 72, nkb_b, wl, slot_b, mt_b, lane, g, [](int) {});
+    for (int m = 0; m < G::MT_B; ++m)
+#pragma unroll
+        for (int n = 0; n < G::NACC; ++n) accb[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    pair_mac<G::MT_B, TP, G::NACC>(accb, tl, uo + 72, nkb_b, wl, slot_b, mt_b, lane, g, [](int) {});
     OJF_STAMP();  // conv b done
     {
         f32x4 bv[2], rv[2];
@@ -325,16 +392,22 @@ void dense_pair_kernel(const PairArgs a)
             const int s = slot_b[m];
             const int oy = s / PW, ox = s - oy * PW;
             const int gy = y0 + oy, gx = x0 + ox;
-            if (!(s < G::OS && ox < TW && gy < a.h && gx < a.w)) continue;
+            const bool ok = s < G::OS && ox < TW && gy < a.h && gx < a.w;
             const int p = gy * a.w + gx;
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const int og = 4 * n + g;
-                if (og >= a.og_store) continue;
-                const f32x4 lin = fma4(accb[m][n], rv[n], bv[n]);
+            auto put_o = [&](int og, const f32x4 &raw, const f32x4 &r4, const f32x4 &b4) {
+                if (!ok || og >= a.og_store) return;
+                const f32x4 lin = fma4(raw, r4, b4);
                 gmax = guard_max(gmax, lin);
-                const f32x4 v = leaky_max4(lin, 0.01f);
-                a.out[(size_t)(a.out_g0 + og) * a.npix + p] = v;
+                a.out[(size_t)(a.out_g0 + og) * a.npix + p] = leaky_max4(lin, 0.01f);
+            };
+            if constexpr (G::PACK) {
+                f32x4 main, extra;
+                pair_unpack5(accb[m], lane, i16, g, main, extra);  // (every lane takes part in the exchanges)
+                put_o(g, main, rv[0], bv[0]);
+                if (g == 0) put_o(4, extra, rv[1], bv[1]);
+            } else {
+#pragma unroll
+                for (int n = 0; n < 2; ++n) put_o(4 * n + g, accb[m][n], rv[n], bv[n]);
             }
         }
     }

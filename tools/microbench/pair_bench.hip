@@ -30,7 +30,7 @@ int main(int argc, char **argv)
         ba.add(la, 0, (i + 1) * c, slot_map((i + 1) * c, c, cs), 0, true);
         bb.add(lb, 0, c, slot_map(c, c, cs), 0, true);
         PackedPair pp;
-        if (finish_pair(ba, bb, pp, pair_cfg_for(h, w))) { printf("pack failed: %s\n", ojf_last_error()); return 1; }
+        if (finish_pair(ba, bb, pp, pair_cfg_for(h, w, cs))) { printf("pack failed: %s\n", ojf_last_error()); return 1; }
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
         for (int r = 0; r < 5; ++r) launch_pair(pp, X, 0, X, (i + 1) * (cs / 4), h, w, 0);
