@@ -1538,6 +1538,7 @@ __global__ __launch_bounds__(256) void planes_to_rows_kernel(const f32x4 *planes
 
 }  // namespace ojf
 #include "ojf_net_pair.h"
+#include "ojf_net_chain.h"
 namespace ojf {
 
 // ------------------------------------------------------------------------------------------------
@@ -1895,6 +1896,142 @@ static int launch_pair(const PackedPair &pp, const float *in, int in_g0, float *
     case PAIR_12x8_W16_P5: return launch_pair_t<12, 8, 16, 4, false, true>(a, st);
     }
     return fail("dense pair: unknown launch shape");
+}
+
+// ---- all dense Blocks of a head in one persistent launch (dense_chain_kernel, ojf_net_chain.h) ---------------------
+#ifdef OJF_CHAIN_TIMING
+static long long *g_chain_dbg = nullptr;
+#endif
+struct PackedChain {
+    float *w = nullptr, *vec = nullptr;
+    int *sync = nullptr;  // [0] epoch, [1] blocks finished, [2] error flag (a neighbour never arrived), [16...] one flag per tile
+    int layers = 0;
+};
+constexpr int kChainSyncInts = 16 + 4096;
+
+static void release(PackedChain &pc)
+{
+    if (pc.w) (void)hipFree(pc.w);
+    if (pc.vec) (void)hipFree(pc.vec);
+    if (pc.sync) (void)hipFree(pc.sync);
+    pc.w = pc.vec = nullptr; pc.sync = nullptr; pc.layers = 0;
+}
+
+// one step of dense_chain_kernel: input channels [ch0, ch0 + 20) of `b`, [K block][packed row tile][lane] x 8 halfs;
+// packed row tiles (ojf_net_chain.h): 0 = hi halves of channels 0..15, 1 = their lo halves, 2 = hi | lo halves of channels
+// 16..19 in rows 0..3 | 4..7; lane (row r16, lane group g), half j: position (R = 2 S + j / 4, g) -> (tap, channel group),
+// input channel 4 q + j % 4
+static void pack_chain_step(const ConvBuilder &b, const std::vector<float> &rs, int ch0, std::vector<float> &dst)
+{
+    const size_t base = dst.size();
+    dst.resize(base + (size_t)kChainStepF4 * 4, 0.0f);
+    _Float16 *hp = reinterpret_cast<_Float16 *>(dst.data() + base);
+    for (int S = 0; S < kChainKB; ++S)
+        for (int t = 0; t < 3; ++t)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int r16 = lane & 15, g = lane >> 4, R = 2 * S + (j >> 2);
+                    const int oc = t < 2 ? r16 : (r16 < 8 ? 16 + (r16 & 3) : -1);
+                    const bool want_lo = t == 1 || (t == 2 && r16 >= 4);
+                    const int tap = chain_hu_tap(R, g), ch = ch0 + 4 * chain_hu_q(R, g) + (j & 3);
+                    if (oc < 0 || oc >= b.c_out_phys || tap < 0 || ch >= b.c_in_phys) continue;
+                    const float v = rs[oc] * b.W[((size_t)oc * b.taps + tap) * b.c_in_phys + ch];
+                    _Float16 hi, lo;
+                    split_weight(v, hi, lo);
+                    hp[(((size_t)S * 3 + t) * 64 + lane) * 8 + j] = want_lo ? lo : hi;
+                }
+}
+
+// ba[l] / bb[l]: the two convolutions of Block l (ba[l].c_in_phys = 20 (l + 1), everything else 20 channels)
+static int finish_chain(const std::vector<ConvBuilder> &ba, const std::vector<ConvBuilder> &bb, PackedChain &pc)
+{
+    const int L = (int)ba.size();
+    if (L < 1 || L > kChainMaxLayers || (int)bb.size() != L) return fail("chain packing: unsupported Block count");
+    std::vector<float> vec((size_t)L * 128, 0.0f), w;
+    for (int l = 0; l < L; ++l) {
+        const ConvBuilder &a = ba[l], &b = bb[l];
+        if (a.taps != 9 || b.taps != 9 || a.dil != 1 || b.dil != 1 || a.c_out_phys != 4 * kChainNG || b.c_in_phys != 4 * kChainNG ||
+            b.c_out_phys != 4 * kChainNG || a.c_in_phys != 4 * kChainNG * (l + 1))
+            return fail("chain packing: unsupported layer shapes");
+        auto scales = [&](const ConvBuilder &cb, int off) {
+            std::vector<float> rs(32, 1.0f);
+            for (int oc = 0; oc < cb.c_out_phys; ++oc) {
+                float mx = 0.0f;
+                const float *row = cb.W.data() + (size_t)oc * cb.taps * cb.c_in_phys;
+                for (int i = 0; i < cb.taps * cb.c_in_phys; ++i) mx = std::fmax(mx, std::fabs(row[i]));
+                rs[oc] = row_scale(mx);
+                vec[(size_t)l * 128 + off + oc] = cb.B[oc];
+            }
+            for (int oc = 0; oc < 32; ++oc) vec[(size_t)l * 128 + off + 32 + oc] = 1.0f / rs[oc];
+            return rs;
+        };
+        const std::vector<float> ra = scales(a, 0), rb = scales(b, 64);
+        for (int c = 0; c <= l; ++c) pack_chain_step(a, ra, 4 * kChainNG * c, w);
+        pack_chain_step(b, rb, 0, w);
+    }
+    pc.layers = L;
+    if (upload(w, &pc.w) || upload(vec, &pc.vec)) return -2;
+    OJF_HIP(hipMalloc(reinterpret_cast<void **>(&pc.sync), kChainSyncInts * sizeof(int)));
+    OJF_HIP(hipMemset(pc.sync, 0, kChainSyncInts * sizeof(int)));
+    const int epoch0 = kChainEpoch;
+    OJF_HIP(hipMemcpy(pc.sync, &epoch0, sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int device_cu_count()
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    }
+    return cus;
+}
+
+template <int TW, int TH>
+static bool chain_fits(int h, int w)
+{
+    const int tiles = ((w + TW - 1) / TW) * ((h + TH - 1) / TH);
+    // one block per CU (132 KB of LDS), every block resident: the Blocks of the chain wait for their neighbours
+    return round_up(tiles, 8) <= device_cu_count() && tiles <= kChainSyncInts - 16;
+}
+
+template <int TW, int TH, int WAVES>
+static int launch_chain_t(ChainDenseArgs &a, hipStream_t st)
+{
+    using G = ChainGeom<TW, TH, WAVES>;
+    static bool configured = false;
+    if (!configured) {
+        OJF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_chain_kernel<TW, TH, WAVES>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+        configured = true;
+    }
+    a.tiles_x = (a.w_img + TW - 1) / TW;
+    a.tiles_y = (a.h + TH - 1) / TH;
+    if (!chain_fits<TW, TH>(a.h, a.w_img)) return fail("dense chain: the frame has more tiles than the device has CUs");
+    hipLaunchKernelGGL((dense_chain_kernel<TW, TH, WAVES>), dim3(round_up(a.tiles_x * a.tiles_y, 8)), dim3(G::THREADS), G::LDS_BYTES, st, a);
+    mark_launch("dense_chain_kernel", st);
+    return check_hip(hipGetLastError(), "dense_chain_kernel launch");
+}
+
+// x: the dense-growth buffer as split planes (slot 0 filled; slots 1..layers are written)
+static int launch_chain(const PackedChain &pc, float *x, int h, int w, hipStream_t st)
+{
+    ChainDenseArgs a;
+    a.x = planes(x); a.xo = planes(x);
+    a.w = planes(pc.w); a.vec = pc.vec;
+    a.sync = pc.sync; a.layers = pc.layers;
+    a.h = h; a.w_img = w; a.npix = h * w; a.tiles_x = a.tiles_y = 0;
+    static const bool no_band = getenv("OJF_NO_XCD_BAND") != nullptr;  // tuning switch only
+    a.xcd_bands = no_band ? 0 : 1;
+    a.ovf = overflow_flag();
+#ifdef OJF_CHAIN_TIMING
+    a.dbg = g_chain_dbg;
+#endif
+    static const int waves = getenv("OJF_CHAIN_WAVES") ? atoi(getenv("OJF_CHAIN_WAVES")) : 16;  // tuning switch
+    if (chain_fits<20, 16>(h, w) && ((w + 19) / 20) * ((h + 15) / 16) >= 200)
+        return waves == 16 ? launch_chain_t<20, 16, 16>(a, st) : launch_chain_t<20, 16, 8>(a, st);
+    return launch_chain_t<12, 8, 8>(a, st);
 }
 
 // Launches n (<= 4) independent convolutions with the same number of output tiles as ONE grid

@@ -8,7 +8,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float))
 n = collections.Counter()
 for r in csv.DictReader(open(sys.argv[1])):
     k = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '').replace('ojf::', '')
-    if not k.startswith(('conv', 'chain', 'vortex', 'dense_pair', 'entry1x1', 'extract', 'integrate', 'pool', 'colsum', 'gave', 'prepare', 'segconv', 'seg_', 'mesh', 'points', 'train_')):
+    if not k.startswith(('conv', 'chain', 'vortex', 'dense_pair', 'dense_chain', 'entry1x1', 'extract', 'integrate', 'pool', 'colsum', 'gave', 'prepare', 'segconv', 'seg_', 'mesh', 'points', 'train_')):
         continue
     acc[k][r['Counter_Name']] += float(r['Counter_Value'])
     if r['Counter_Name'] == 'SQ_WAVES':
