@@ -1907,7 +1907,7 @@ struct PackedChain {
     int *sync = nullptr;  // [0] epoch, [1] blocks finished, [2] error flag (a neighbour never arrived), [16...] one flag per tile
     int layers = 0;
 };
-constexpr int kChainSyncInts = 16 + 4096;
+constexpr int kChainSyncInts = 16 + 8192;
 
 static void release(PackedChain &pc)
 {
@@ -1988,14 +1988,6 @@ static int device_cu_count()
     return cus;
 }
 
-template <int TW, int TH>
-static bool chain_fits(int h, int w)
-{
-    const int tiles = ((w + TW - 1) / TW) * ((h + TH - 1) / TH);
-    // one block per CU (132 KB of LDS), every block resident: the Blocks of the chain wait for their neighbours
-    return round_up(tiles, 8) <= device_cu_count() && tiles <= kChainSyncInts - 16;
-}
-
 template <int TW, int TH, int WAVES>
 static int launch_chain_t(ChainDenseArgs &a, hipStream_t st)
 {
@@ -2008,8 +2000,11 @@ static int launch_chain_t(ChainDenseArgs &a, hipStream_t st)
     }
     a.tiles_x = (a.w_img + TW - 1) / TW;
     a.tiles_y = (a.h + TH - 1) / TH;
-    if (!chain_fits<TW, TH>(a.h, a.w_img)) return fail("dense chain: the frame has more tiles than the device has CUs");
-    hipLaunchKernelGGL((dense_chain_kernel<TW, TH, WAVES>), dim3(round_up(a.tiles_x * a.tiles_y, 8)), dim3(G::THREADS), G::LDS_BYTES, st, a);
+    const int tiles = a.tiles_x * a.tiles_y, cus = device_cu_count();
+    if (tiles > kChainSyncInts - 16) return fail("dense chain: too many tiles for the flag array");
+    // one block per CU (160 KB of LDS); the blocks draw (Block, tile) items until none is left
+    const int grid = cus > 0 && cus < tiles ? cus : tiles;
+    hipLaunchKernelGGL((dense_chain_kernel<TW, TH, WAVES>), dim3(grid), dim3(G::THREADS), G::LDS_BYTES, st, a);
     mark_launch("dense_chain_kernel", st);
     return check_hip(hipGetLastError(), "dense_chain_kernel launch");
 }
@@ -2029,8 +2024,8 @@ static int launch_chain(const PackedChain &pc, float *x, int h, int w, hipStream
     a.dbg = g_chain_dbg;
 #endif
     static const int waves = getenv("OJF_CHAIN_WAVES") ? atoi(getenv("OJF_CHAIN_WAVES")) : 16;  // tuning switch
-    if (chain_fits<20, 16>(h, w) && ((w + 19) / 20) * ((h + 15) / 16) >= 200)
-        return waves == 16 ? launch_chain_t<20, 16, 16>(a, st) : launch_chain_t<20, 16, 8>(a, st);
+    if (((w + 19) / 20) * ((h + 15) / 16) >= 200)  // (the large tile when it still gives every CU an item per Block)
+        return waves == 16 ? launch_chain_t<20, 16, 16>(a, st) : (waves == 12 ? launch_chain_t<20, 16, 12>(a, st) : launch_chain_t<20, 16, 8>(a, st));
     return launch_chain_t<12, 8, 8>(a, st);
 }
 

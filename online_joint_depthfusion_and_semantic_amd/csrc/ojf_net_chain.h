@@ -56,7 +56,7 @@ struct ChainGeom {
     static constexpr int X_F4 = NPIECE * 64;                     // float4 per window buffer
     static constexpr int NPX = (NPIECE + WAVES - 1) / WAVES;     // pieces per wave
     static constexpr int NPW = (kChainStepF4 / 64 + WAVES - 1) / WAVES;
-    static constexpr size_t LDS_BYTES = (size_t)(3 * X_F4 + 2 * kChainStepF4) * 16 + kChainMaxLayers * 128 * sizeof(float);
+    static constexpr size_t LDS_BYTES = (size_t)(3 * X_F4 + 2 * kChainStepF4) * 16 + kChainMaxLayers * 128 * sizeof(float) + 16;
 };
 
 struct ChainDenseArgs {
@@ -65,7 +65,8 @@ struct ChainDenseArgs {
     const f32x4 *w;   // steps back to back (Block 0: slot 0, conv b; Block 1: slots 0, 1, conv b; ...)
     const float *vec; // per Block: bias_a | rinv_a | bias_b | rinv_b, 32 floats each
     int *sync;        // [0] epoch (advanced by the block that finishes last: the launch is graph-replayable), [1] blocks finished,
-                      // [2] error flag (a neighbour's flag never arrived: bounded spin), [16 + tile] epoch + Blocks completed
+                      // [2] error flag (a neighbour's flag never arrived: bounded spin), [3] next ticket,
+                      // [16 + tile] epoch + Blocks completed on that tile
     int layers;
     int h, w_img, npix, tiles_x, tiles_y;
     int xcd_bands;
@@ -87,10 +88,11 @@ struct ChainDenseArgs {
 // 1: the epilogue adds two accumulators; channels 16..19 need one cross-lane-group exchange (pair of lane groups 0, 1).
 // xg: window buffer + g * XP (the lane group's plane for R < 9); x4: window buffer + 4 * XP; t9: the lane's slot offsets
 // for R = 9, 10, 11.  Straight-line code per tile count (the caller branches once per step).
-template <int MTW, int MT, int PW, class Hook>
+template <int MTW, int MT, int PW, int TSTRIDE, class Hook>
 __device__ __forceinline__ void chain_mac_t(f32x4 (&acc)[MT][3], const f32x4 *xg, const f32x4 *x4, const f32x4 *wl_lane,
-                                            const int (&slot)[MT], const int (&t9)[3], Hook hook)
+                                            const int (&t9)[3], Hook hook)
 {
+    // (xg / x4 point at the lane's slot of pixel tile 0; tile m lies TSTRIDE slots further: an immediate offset)
 #pragma unroll
     for (int S = 0; S < kChainKB; ++S) {
         f16x8 w[3];
@@ -101,10 +103,10 @@ __device__ __forceinline__ void chain_mac_t(f32x4 (&acc)[MT][3], const f32x4 *xg
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
             f32x4 A, B;
-            if (RA < 9) A = xg[slot[m] + (RA / 3) * PW + RA % 3];
-            else A = x4[slot[m] + t9[RA >= 9 ? RA - 9 : 0]];
-            if (RB < 9) B = xg[slot[m] + (RB / 3) * PW + RB % 3];
-            else B = x4[slot[m] + t9[RB >= 9 ? RB - 9 : 0]];
+            if (RA < 9) A = xg[m * TSTRIDE + (RA / 3) * PW + RA % 3];
+            else A = x4[m * TSTRIDE + t9[RA >= 9 ? RA - 9 : 0]];
+            if (RB < 9) B = xg[m * TSTRIDE + (RB / 3) * PW + RB % 3];
+            else B = x4[m * TSTRIDE + t9[RB >= 9 ? RB - 9 : 0]];
             // (plain shuffles, not unpack_split's hand-placed v_swap_b32: hipcc cannot see what inline assembly writes, and with
             // the x_lo product first in line an MFMA read the swapped registers too early - wrong tile-2 sums on MI355X)
             const f16x8 xh = __builtin_bit_cast(f16x8, __builtin_shufflevector(A, B, 0, 1, 4, 5));
@@ -116,15 +118,19 @@ __device__ __forceinline__ void chain_mac_t(f32x4 (&acc)[MT][3], const f32x4 *xg
             acc[m][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[2], xh, acc[m][2], 0, 0, 0);
             acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[0], xh, acc[m][0], 0, 0, 0);
         }
+        // (keeps hipcc from lifting later K blocks' reads above this one's MFMAs: it spends every register of the
+        // 128-VGPR budget on that and then spills the per-lane state of the item loop - each reload waits for the
+        // window pieces and write-through stores in flight)
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
-template <int MT, int PW, class Hook>
+template <int MT, int PW, int TSTRIDE, class Hook>
 __device__ __forceinline__ void chain_mac(f32x4 (&acc)[MT][3], const f32x4 *xg, const f32x4 *x4, const f32x4 *wl_lane,
-                                          const int (&slot)[MT], int mt_wave, const int (&t9)[3], Hook hook)
+                                          int mt_wave, const int (&t9)[3], Hook hook)
 {
     // (pixel tiles are dealt round robin: a wave has MT or MT - 1 of them)
-    if (MT == 1 || mt_wave == MT) chain_mac_t<MT, MT, PW>(acc, xg, x4, wl_lane, slot, t9, hook);
-    else chain_mac_t<(MT > 1 ? MT - 1 : 1), MT, PW>(acc, xg, x4, wl_lane, slot, t9, hook);
+    if (MT == 1 || mt_wave == MT) chain_mac_t<MT, MT, PW, TSTRIDE>(acc, xg, x4, wl_lane, t9, hook);
+    else chain_mac_t<(MT > 1 ? MT - 1 : 1), MT, PW, TSTRIDE>(acc, xg, x4, wl_lane, t9, hook);
 }
 // Packed accumulators of one pixel tile -> lane (pixel i16, g): `main` = channels 4 g .. 4 g + 3, `extra` = channels
 // 16..19 (meaningful in lane group 0): the lo rows of tile 2 sit one lane group up; v_permlane16_swap_b32 (gfx950) of a
@@ -151,48 +157,66 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dense_chain_kernel(cons
     f32x4 *xl = chain_lds + 2 * kChainStepF4;               // [2][X_F4]: window (5 planes of XP slots)
     f32x4 *tl = xl + 2 * G::X_F4;                           // [X_F4]: the intermediate T, same plane layout
     float *vl = reinterpret_cast<float *>(tl + G::X_F4);    // [layers][128]
+    int *tk = reinterpret_cast<int *>(vl + kChainMaxLayers * 128);  // [0..1]: the block's tickets (written by thread 0), [2]: look-ahead
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, g = lane >> 4;
     const int ntiles = a.tiles_x * a.tiles_y;
-    const int tile = (gridDim.x & 7) == 0 && a.xcd_bands ? xcd_band_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-    if (tile >= ntiles) return;  // (grid padded to a multiple of 8; nobody waits for a padding block)
-    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-    const int x0 = tx * TW, y0 = ty * TH;
-    const int L = a.layers;
+    const int L = a.layers, total = L * ntiles;
     const int epoch = *a.sync;  // (constant during the launch: only the last block to finish advances it)
     int *flags = a.sync + 16;
 #ifdef OJF_CHAIN_TIMING
     int stamp_i = 0;
-#define OJF_CSTAMP() do { if (tile == 37 && tid == 0 && stamp_i < 96) a.dbg[stamp_i] = (long long)__builtin_amdgcn_s_memtime(); ++stamp_i; } while (0)
+#define OJF_CSTAMP() do { if (blockIdx.x == 37 && tid == 0 && stamp_i < 96) a.dbg[stamp_i] = (long long)__builtin_amdgcn_s_memtime(); ++stamp_i; } while (0)
 #else
 #define OJF_CSTAMP() do {} while (0)
 #endif
     OJF_CSTAMP();
 
+    // ---- work items: (Block l, tile t) = ticket l * ntiles + t, handed out in that order --------------------------
+    // A block draws its NEXT ticket while it works on the current one.  Every item waits only for items of the previous
+    // Block, i.e. for smaller tickets, and the smallest unfinished ticket is always some running block's CURRENT item
+    // (whoever holds it as its next one is still busy with a smaller one): the launch makes progress with any number of
+    // resident blocks - two chains on two streams, two processes on one device, a grid larger than the device.
+    // The draw is one returning atomic on one word (up to ~3 us when every block of the grid asks at once): the wave with
+    // the fewest pixel tiles issues it behind the first step of an item and hands the ticket over before the item's last
+    // step, so that nobody ever waits for it - except at the very start.
+    if (tid == 0) {
+        tk[0] = __hip_atomic_fetch_add(a.sync + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tk[2] = 0;
+    }
     for (int i = tid; i < L * 32; i += G::THREADS)
         reinterpret_cast<f32x4 *>(vl)[i] = reinterpret_cast<const f32x4 *>(a.vec)[i];
+    __syncthreads();
+    int ticket = __builtin_amdgcn_readfirstlane(tk[0]);
 
-    // ---- this wave's window pieces: item = piece * 64 + lane -> (group, slot) -> pixel (float4 offset in a slot) ----
-    // fresh: the slot was written by this launch and is read for the first time (sc1: L1 bypassed, coherent with the
-    // neighbours' write-through stores); later reads of the same slot are plain loads and stay in the XCD's L2
-    int xoff[G::NPX];
-#pragma unroll
-    for (int j = 0; j < G::NPX; ++j) {
-        const int item = (wave + G::WAVES * j) * 64 + lane;
-        const int q = item / XP, sl = item - q * XP;
-        const int sy = sl / PW, sx = sl - sy * PW;
-        const int gy = y0 - 2 + sy, gx = x0 - 2 + sx;
-        const bool ok = q < kChainNG && sl < G::XS && (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w_img;
-        xoff[j] = ok ? q * a.npix + gy * a.w_img + gx : -1;
-    }
-    auto load_x = [&](int slot, int buf, bool fresh) {
+    // ---- per item: tile origin, this wave's window pieces, the neighbours' flags -------------------------------------
+    // window piece: item = piece * 64 + lane -> (group, slot) -> pixel (float4 offset inside an input slot, -1: none)
+    // An item is four scalars (the kernel runs at 128 VGPRs: whatever is per lane - the window piece of a lane, its
+    // neighbour flag - is recomputed where it is used, a few dozen VALU instructions per 5000-cycle step)
+    struct Item { int l, tile, x0, y0; };
+    auto make_item = [&](int t_, Item &it) {
+        const int t = __builtin_amdgcn_readfirstlane(t_);
+        it.l = t / ntiles;
+        it.tile = t - it.l * ntiles;
+        const int ty = it.tile / a.tiles_x, tx = it.tile - ty * a.tiles_x;
+        it.x0 = tx * TW; it.y0 = ty * TH;
+    };
+    // window piece: element = piece * 64 + lane -> (group, slot) -> pixel, or the zero float4 in front of the planes
+    // fresh: the slot is read for the first time after another CU of this launch wrote it (sc1: L1 bypassed, coherent with
+    // the write-through stores); any later read of the same slot is a plain load and stays in the XCD's L2
+    auto load_x = [&](const Item &it, int slot, int buf, bool fresh) {
         const f32x4 *base = a.x + (size_t)slot * kChainNG * a.npix;
 #pragma unroll
         for (int j = 0; j < G::NPX; ++j) {
             const int pc = wave + G::WAVES * j;
             if (pc < G::NPIECE) {
-                const f32x4 *src = xoff[j] >= 0 ? base + xoff[j] : a.x - 1;
+                const int e = pc * 64 + lane;
+                const int q = e / XP, sl = e - q * XP;
+                const int sy = sl / PW, sx = sl - sy * PW;
+                const int gy = it.y0 - 2 + sy, gx = it.x0 - 2 + sx;
+                const bool ok = q < kChainNG && sl < G::XS && (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w_img;
+                const f32x4 *src = ok ? base + (q * a.npix + gy * a.w_img + gx) : a.x - 1;
                 if (fresh)
                     __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)src,
                                                      (void __attribute__((address_space(3))) *)(xl + buf * G::X_F4 + pc * 64), 16, 0, 16);
@@ -212,36 +236,36 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dense_chain_kernel(cons
                                                  (void __attribute__((address_space(3))) *)(wl + buf * kChainStepF4 + pc * 64), 16, 0, 0);
         }
     };
-    load_x(0, 0, false);
-    issue_w(0, 0);
-
-    // ---- neighbours (lanes 0..8 of every wave poll one flag each) -------------------------------------------------
-    const int *nbflag = nullptr;
-    if (lane < 9) {
-        const int ny = ty + lane / 3 - 1, nx = tx + lane % 3 - 1;
-        if ((unsigned)ny < (unsigned)a.tiles_y && (unsigned)nx < (unsigned)a.tiles_x) nbflag = flags + ny * a.tiles_x + nx;
-    }
-    auto wait_neighbours = [&](int done) {  // until every neighbour has completed `done` Blocks
+    // Blocks completed by every neighbour of `it` >= done?  (one relaxed sc1 load per lane 0..8)
+    auto neighbours_done = [&](const Item &it, int done) {
         const int need = epoch + done;
-        for (int spins = 0;; ++spins) {
-            int v = need;
-            if (nbflag) v = __hip_atomic_load(nbflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__builtin_amdgcn_ballot_w64(v - need < 0) == 0) break;
-            if (spins > (1 << 20)) {  // (a launch that cannot make progress must end: the host reports the flag)
+        int v = need;  // lanes 0..8 look at one neighbour each (the tile itself included)
+        if (lane < 9) {
+            const int ty = it.tile / a.tiles_x, tx = it.tile - ty * a.tiles_x;
+            const int ny = ty + lane / 3 - 1, nx = tx + lane % 3 - 1;
+            if ((unsigned)ny < (unsigned)a.tiles_y && (unsigned)nx < (unsigned)a.tiles_x)
+                v = __hip_atomic_load(flags + ny * a.tiles_x + nx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return __builtin_amdgcn_ballot_w64(v - need < 0) == 0;
+    };
+    auto wait_neighbours = [&](const Item &it, int done) {
+        for (int spins = 0; !neighbours_done(it, done); ++spins) {
+            if (spins > (1 << 20)) {  // (cannot happen by construction; a launch must end all the same: the host reports the flag)
                 if (lane == 0) a.sync[2] = 1;
                 break;
             }
             __builtin_amdgcn_s_sleep(4);
         }
     };
+    auto first_step = [](int l) { return l * (l + 3) / 2; };  // Block l: steps for slots 0..l, then conv b
 
     // ---- pixel tiles of this wave ---------------------------------------------------------------------------------
     const int mt_a = (G::TILES_A - wave + G::WAVES - 1) / G::WAVES, mt_b = (G::TILES_B - wave + G::WAVES - 1) / G::WAVES;
-    int slot_a[G::MT_A], slot_b[G::MT_B];
-#pragma unroll
-    for (int m = 0; m < G::MT_A; ++m) slot_a[m] = (wave + G::WAVES * (m < mt_a ? m : 0)) * 16 + i16;
-#pragma unroll
-    for (int m = 0; m < G::MT_B; ++m) slot_b[m] = (wave + G::WAVES * (m < mt_b ? m : 0)) * 16 + i16;
+    // pixel tile m of the wave = tile wave + WAVES m: slot = ls + TSTRIDE m (a wave has MT or MT - 1 tiles: chain_mac; the
+    // epilogues skip the rest).  `ls` is refreshed through an opaque no-op at the top of every step: left alone, hipcc
+    // hoists every (buffer, plane, tile) address combination out of the item loop - some thirty VGPRs - and spills.
+    constexpr int TSTRIDE = G::WAVES * 16;
+    int ls = wave * 16 + i16;
     int t9[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -254,9 +278,22 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dense_chain_kernel(cons
     float gmax = 0.0f;
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(a.xo, 0, (L + 1) * kChainNG * a.npix * 16, 0x00020000);
 
-    int xb = 0, wb = 0, step = 0;
+    Item cur;
+    int xb = 0, wb = 0;              // window / weight buffer of the coming step
+    int pub_tile = -1, pub_val = 0;  // the finished item whose flag is published behind the next barrier
+    if (ticket < total) {
+        make_item(ticket, cur);
+        load_x(cur, 0, 0, false);
+        issue_w(first_step(cur.l), 0);
+    }
     OJF_CSTAMP();
-    for (int l = 0; l < L; ++l) {
+    while (ticket < total) {
+        const int l = cur.l;
+        int step = first_step(l);
+        int nxt_l = 0;
+        int known = 0;  // Blocks every neighbour is known to have completed (slots 0..known may be read)
+        int next_ticket = total, drawn = total;
+        bool draw_pending = false;  // (wave WAVES - 1: the returning atomic is this wave's youngest memory operation)
         f32x4 acc[G::MT_A][3];
 #pragma unroll
         for (int m = 0; m < G::MT_A; ++m)
@@ -264,24 +301,41 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dense_chain_kernel(cons
             for (int n = 0; n < 3; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
         // ---- conv a: one step per slot, the slot Block l - 1 produced comes last --------------------------------
         for (int c = 0; c <= l; ++c) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed, its stores are drained
+            // this wave's pieces have landed, its stores are drained (the ticket may stay in flight across one barrier)
+            if (draw_pending) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            draw_pending = false;
             __syncthreads();
             OJF_CSTAMP();
-            if (c == 0 && l > 0 && tid == 0)  // every wave's stores of Block l - 1 were drained before the barrier
-                __hip_atomic_store(flags + tile, epoch + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c == 0) {
+                if (pub_tile >= 0 && tid == 0)  // every wave's stores of the previous item were drained before the barrier
+                    __hip_atomic_store(flags + pub_tile, pub_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pub_tile = -1;
+                known = __builtin_amdgcn_readfirstlane(tk[2]);  // (what the previous item's look-ahead found)
+            }
             const bool last = c == l;
             issue_w(step + 1, wb ^ 1);  // (the next slot's, or conv b's)
-            const int nslot = last ? 0 : c + 1;  // behind the last slot: the next Block's first window
-            const bool have_next = !last || l + 1 < L;
-            const bool fresh = !last && c + 1 == l;  // written by this launch: this tile and its neighbours
-            if (have_next && !fresh) load_x(nslot, xb ^ 1, false);
-            const f32x4 *xbuf = xl + xb * G::X_F4, *wl_lane = wl + wb * kChainStepF4 + lane;
-            chain_mac<G::MT_A, PW>(acc, xbuf + g * XP, xbuf + 4 * XP, wl_lane, slot_a, mt_a, t9, [&]() {
+            // the window of the coming step: this item's next slot, or - behind its last slot - the next item's first one
+            const bool fresh = !last && c + 1 == l;  // the slot Block l - 1 wrote: wanted last, asked for in mid-step
+            if (!last && !fresh) {
+                if (known < c + 1) {  // (only when the neighbours lag by more than a Block: this tile's earlier Blocks ran elsewhere)
+                    wait_neighbours(cur, l - 1);
+                    known = l - 1;
+                }
+                load_x(cur, c + 1, xb ^ 1, false);
+            }
+            asm volatile("" : "+v"(ls));
+            const f32x4 *xbuf = xl + xb * G::X_F4 + ls, *wl_lane = wl + wb * kChainStepF4 + lane;
+            chain_mac<G::MT_A, PW, TSTRIDE>(acc, xbuf + g * XP, xbuf + 4 * XP, wl_lane, mt_a, t9, [&]() {
                 if (fresh) {
-                    wait_neighbours(l);
-                    load_x(nslot, xb ^ 1, true);
+                    wait_neighbours(cur, l);
+                    load_x(cur, c + 1, xb ^ 1, true);
                 }
             });
+            if (c == 0 && wave == G::WAVES - 1) {  // (behind everything else this step asked for)
+                if (lane == 0) drawn = __hip_atomic_fetch_add(a.sync + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                draw_pending = !last;
+            }
             ++step;
             wb ^= 1;
             if (!last) xb ^= 1;
@@ -295,9 +349,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dense_chain_kernel(cons
 #pragma unroll
             for (int m = 0; m < G::MT_A; ++m) {
                 if (m >= mt_a) continue;
-                const int s = slot_a[m];
+                const int s = ls + TSTRIDE * m;
                 const int ry = s / PW, rx = s - ry * PW;
-                const int gy = y0 - 1 + ry, gx = x0 - 1 + rx;
+                const int gy = cur.y0 - 1 + ry, gx = cur.x0 - 1 + rx;
                 const bool ok = s < G::TS && rx < TW + 2 && (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w_img;
                 f32x4 main, extra;
                 chain_unpack(acc[m], main, extra);
@@ -314,13 +368,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dense_chain_kernel(cons
             }
         }
         OJF_CSTAMP();
+        if (wave == G::WAVES - 1 && lane == 0) tk[0] = drawn;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // conv b's weights
         __syncthreads();
-        if (l + 1 < L) issue_w(step + 1, wb ^ 1);
-#ifdef OJF_CHAIN_TIMING
-        if (l == 0 && tile == 37)  // debugging aid: what conv b of Block 0 finds in its weight buffer
-            for (int i = tid; i < kChainStepF4; i += G::THREADS) reinterpret_cast<f32x4 *>(a.dbg + 128)[i] = wl[wb * kChainStepF4 + i];
-#endif
+        next_ticket = __builtin_amdgcn_readfirstlane(tk[0]);
+        if (next_ticket < total) {  // the next item's first window and weights travel while this item's second convolution runs
+            Item nxt;
+            make_item(next_ticket, nxt);
+            load_x(nxt, 0, xb ^ 1, false);
+            nxt_l = nxt.l;
+            issue_w(first_step(nxt_l), wb ^ 1);
+        }
         // ---- conv b -------------------------------------------------------------------------------------------
         f32x4 accb[G::MT_B][3];
 #pragma unroll
@@ -328,8 +386,22 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dense_chain_kernel(cons
 #pragma unroll
             for (int n = 0; n < 3; ++n) accb[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
         {
-            const f32x4 *wl_lane = wl + wb * kChainStepF4 + lane;
-            chain_mac<G::MT_B, PW>(accb, tl + g * XP, tl + 4 * XP, wl_lane, slot_b, mt_b, t9, []() {});
+            asm volatile("" : "+v"(ls));
+            const f32x4 *wl_lane = wl + wb * kChainStepF4 + lane, *tbuf = tl + ls;
+            chain_mac<G::MT_B, PW, TSTRIDE>(accb, tbuf + g * XP, tbuf + 4 * XP, wl_lane, mt_b, t9, [&]() {
+                // A look at the next item's neighbours by the wave with the fewest pixel tiles, while the matrix pipe is busy:
+                // in step with the rest of the grid they have completed the Blocks before the one this block is finishing,
+                // which covers every slot the next item reads before its own mid-step poll
+                if (wave == G::WAVES - 1) {
+                    bool ok = false;
+                    if (next_ticket < total && nxt_l >= 2) {
+                        Item nxt;
+                        make_item(next_ticket, nxt);
+                        ok = neighbours_done(nxt, nxt_l - 1);
+                    }
+                    if (lane == 0) tk[2] = ok ? nxt_l - 1 : 0;
+                }
+            });
         }
         OJF_CSTAMP();
         {
@@ -339,9 +411,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dense_chain_kernel(cons
 #pragma unroll
             for (int m = 0; m < G::MT_B; ++m) {
                 if (m >= mt_b) continue;
-                const int s = slot_b[m];
+                const int s = ls + TSTRIDE * m;
                 const int oy = s / PW, ox = s - oy * PW;
-                const int gy = y0 + oy, gx = x0 + ox;
+                const int gy = cur.y0 + oy, gx = cur.x0 + ox;
                 const bool ok = s < G::OS && ox < TW && gy < a.h && gx < a.w_img;
                 const int p = gy * a.w_img + gx;
                 f32x4 main, extra;
@@ -359,15 +431,23 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dense_chain_kernel(cons
             }
         }
         OJF_CSTAMP();
-        ++step;
+        pub_tile = cur.tile;
+        pub_val = epoch + l + 1;
         wb ^= 1;
-        xb ^= 1;  // the next Block's first window went there
+        xb ^= 1;  // the next item's first window went there
+        ticket = next_ticket;
+        if (ticket < total) make_item(ticket, cur);
     }
+    // the last item's flag: somebody may be waiting for it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (pub_tile >= 0 && tid == 0) __hip_atomic_store(flags + pub_tile, pub_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (gmax > 65504.0f && a.ovf) *a.ovf = 1;
-    if (tid == 0) {  // the block that finishes last re-arms the flags for the next launch
+    if (tid == 0) {  // the block that finishes last re-arms tickets and flags for the next launch (every block has drawn its last ticket)
         const int done = __hip_atomic_fetch_add(a.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (done == ntiles - 1) {
+        if (done == (int)gridDim.x - 1) {
             a.sync[1] = 0;
+            a.sync[3] = 0;
             a.sync[0] = epoch + kChainEpoch;
         }
     }
