@@ -54,6 +54,20 @@ __device__ __forceinline__ unsigned split_lo_pair(unsigned hpair, float x0, floa
     return r;
 }
 
+// One float4 -> its split-fp16 form in the same 16 bytes: halfs {h0 h1 h2 h3 | l0 l1 l2 l3} ("split planes", the form the
+// fusion net's dense-growth buffer holds for dense_chain_kernel; bit for bit ojf_net.hip's split_pack4)
+__device__ __forceinline__ float4 split_planes4(const float4 &v)
+{
+    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+    const f4_t x{v.x, v.y, v.z, v.w};
+    const h4_t hi = __builtin_convertvector(x, h4_t);  // 2 x v_cvt_pk_f16_f32
+    const u2_t h = __builtin_bit_cast(u2_t, hi);
+    return float4{__uint_as_float(h[0]), __uint_as_float(h[1]), __uint_as_float(split_lo_pair(h[0], v.x, v.y)),
+                  __uint_as_float(split_lo_pair(h[1], v.z, v.w))};
+}
+
 __device__ __forceinline__ float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 __device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
 
@@ -148,8 +162,9 @@ __device__ __forceinline__ bool in_volume(const int64_t idx[3], int X, int Y, in
 
 // (ojf_net.hip) where a single-head geometry net keeps the first slot of its dense block, for ojf_extract_to_net:
 // plane buffer ([cs4][h*w] float4), its group count, n_points, frame size and the split-fp16 range flag (or NULL).
-// Returns nonzero when the net needs ojf_net_prepare_input (semantic channel, two heads).
-struct NetInputSlot { float *x0; int cs4, P, h, w; int *ovf; };
+// split: the buffer holds split planes (split_planes4).  Returns nonzero when the net needs ojf_net_prepare_input (semantic
+// channel, two heads).
+struct NetInputSlot { float *x0; int cs4, P, h, w; int *ovf; int split; };
 int net_input_slot(::ojf_net *net, NetInputSlot *slot);
 
 }  // namespace ojf

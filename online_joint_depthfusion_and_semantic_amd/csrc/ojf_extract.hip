@@ -29,6 +29,7 @@ struct ExtractArgs {
     float4 *net_x0;
     int net_cs4;
     int *ovf;  // split-fp16 range flag of the net (or NULL)
+    int net_split;  // the net keeps this slot as split planes (split_planes4)
 };
 
 constexpr int kNetPitch = 36;  // floats per pixel of the LDS transpose tile (<= 8 channel groups + padding against bank conflicts)
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(64 * kMaxTilePoints) void extract_tile_kernel(Extra
         const int cg = t >> 6, px = t & 63;
         if (n0 + px >= N) continue;
         const float4 v = *reinterpret_cast<const float4 *>(tile + px * kNetPitch + 4 * cg);
-        a.net_x0[(size_t)cg * N + n0 + px] = v;
+        a.net_x0[(size_t)cg * N + n0 + px] = a.net_split ? split_planes4(v) : v;
         bad = bad || fabsf(v.x) > 65504.0f || fabsf(v.y) > 65504.0f || fabsf(v.z) > 65504.0f || fabsf(v.w) > 65504.0f;
     }
     if (bad && a.ovf) *a.ovf = 1;  // split-fp16 range guard of the net input (NaN passes, like everywhere else)
@@ -213,7 +214,7 @@ OJF_API int ojf_extract(const float *depth, const float *Ki, const float *E, con
     if ((int64_t)h * w * n_points > 0x7fffffffLL) return fail("ojf_extract: frame too large");
     if (!(res > 0.0)) return fail("ojf_extract: resolution must be > 0");
     ExtractArgs a{depth, tsdf, wgt, out_values, out_weights, dbg_idx, dbg_w, dbg_pts, dbg_pcl,
-                  X, Y, Z, h, w, n_points, out_stride, out_layout, pad_value, nullptr, 0, nullptr};
+                  X, Y, Z, h, w, n_points, out_stride, out_layout, pad_value, nullptr, 0, nullptr, 0};
     const Camera cam = make_camera(Ki, E, origin, res);
     if (n_points <= kMaxTilePoints) {
         hipLaunchKernelGGL(extract_tile_kernel, dim3((h * w + 63) / 64), dim3(64 * n_points), 0, as_stream(stream), a, cam);
@@ -239,7 +240,7 @@ OJF_API int ojf_extract_to_net(const float *depth, const float *Ki, const float 
     if (n_points < 1 || (n_points & 1) == 0 || n_points > kMaxTilePoints || 4 * slot.cs4 > kNetPitch || 2 * n_points + 1 > 4 * slot.cs4)
         return fail("ojf_extract_to_net: unsupported n_points / slot width");
     ExtractArgs a{depth, tsdf, wgt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                  X, Y, Z, h, w, n_points, h * w, 2, pad_value, reinterpret_cast<float4 *>(slot.x0), slot.cs4, slot.ovf};
+                  X, Y, Z, h, w, n_points, h * w, 2, pad_value, reinterpret_cast<float4 *>(slot.x0), slot.cs4, slot.ovf, slot.split};
     const Camera cam = make_camera(Ki, E, origin, res);
     hipLaunchKernelGGL(extract_tile_kernel, dim3((h * w + 63) / 64), dim3(64 * n_points), 0, as_stream(stream), a, cam);
     return check_hip(hipGetLastError(), "ojf_extract_to_net launch");

@@ -100,6 +100,13 @@ __device__ __forceinline__ f32x4 split_pack4(const f32x4 &x)
     const u32x4 r{h[0], h[1], split_lo_pair(h[0], x[0], x[1]), split_lo_pair(h[1], x[2], x[3])};
     return __builtin_bit_cast(f32x4, r);
 }
+// split planes -> fp32: hi + lo (exact: the halves have 11 + 11 significant bits)
+__device__ __forceinline__ f32x4 unsplit4(const f32x4 &s)
+{
+    typedef _Float16 f16x8_ __attribute__((ext_vector_type(8)));
+    const f16x8_ h = __builtin_bit_cast(f16x8_, s);
+    return f32x4{(float)h[0] + (float)h[4], (float)h[1] + (float)h[5], (float)h[2] + (float)h[6], (float)h[3] + (float)h[7]};
+}
 // two split-plane float4 (channel groups A, B) -> the MFMA operand halves of their eight channels
 __device__ __forceinline__ void unpack_split(const f32x4 &a, const f32x4 &b, f16x8 &hi, f16x8 &lo)
 {
@@ -708,6 +715,7 @@ struct ChainArgs {
     f32x4 *out_planes;
     int out_g0, og_store, act_n;  // ReLU on channels < act_n (branch 0), the pooled branches stay linear
     struct ColSums *colsum;       // channel sums of the entry layer's INPUT (global-average branch), see block_colsum
+    int in_split = 0;             // entry1x1_kernel: the input planes are split planes (the dense-growth buffer of dense_chain_kernel)
     int split_groups = 0;         // kChainEntry: channel groups < split_groups (branch 0, read by its 3x3 convolution only) are stored as split planes
 };
 
@@ -1118,6 +1126,7 @@ __global__ __launch_bounds__(kChainThreads, OJF_CHAIN_BLOCKS) void entry1x1_kern
             const int G = 4 * S + g;
             const bool ok = p[m] < a.npix && G < a.c4_in;
             x[m][S] = a.in[ok ? (a.in_g0 + G) * a.npix + p[m] : -1];
+            if (a.in_split) x[m][S] = unsplit4(x[m][S]);  // hi + lo: exact in fp32, the value every consumer of the halves means
         }
     }
     if (a.colsum) block_colsum<MT, NTIN>(x, p, a.npix, red, a.colsum, lane, wave);
@@ -1476,6 +1485,7 @@ struct PrepArgs {
     f32x4 *x1;
     int rows_stride, in_layout, npix, P, cs4, n_classes, v2_sem;
     int *ovf;  // split-fp16 range guard flag (NULL for fp32 arithmetic)
+    int split; // the slots are kept as split planes (dense_chain_kernel)
 };
 
 // modules/pipeline.py:74-102 _prepare_fusion_input: channels [values(P) | weights(P) | depth | (sem)]
@@ -1505,8 +1515,8 @@ __global__ __launch_bounds__(256) void prepare_input_kernel(const PrepArgs a)
             if (c == 2 * a.P) { r0[j] = d; r1[j] = sf; }
             if (c == 2 * a.P + 1 && a.v2_sem) r0[j] = sf;
         }
-        a.x0[(size_t)cg * a.npix + p] = r0;
-        if (a.x1) a.x1[(size_t)cg * a.npix + p] = r1;
+        a.x0[(size_t)cg * a.npix + p] = a.split ? split_pack4(r0) : r0;
+        if (a.x1) a.x1[(size_t)cg * a.npix + p] = a.split ? split_pack4(r1) : r1;
         bad = bad || beyond_f16(r0) || beyond_f16(r1);
     }
     if (bad && a.ovf) *a.ovf = 1;
@@ -1601,6 +1611,8 @@ static unsigned event_flags()
     return fence ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
 }
 
+static const char *kChainStuckMsg =
+    "fusion net: dense_chain_kernel gave up waiting for a neighbouring tile (internal error: the results of this forward pass are invalid)";
 static const char *kOverflowMsg =
     "split-fp16 arithmetic: an activation or input left the fp16 range (|x| > 65504 or NaN); results since the last "
     "ojf_net_check are invalid - use ojf_net_set_arithmetic(OJF_ARITH_F32) for this network";
@@ -2233,6 +2245,8 @@ struct ojf_net {
     int last_launches = 0;  // kernel launches of the most recent ojf_net_forward (all streams)
     std::vector<ojf::PackedConv> dense[2];  // block0 / block2 (or v2's block): 2*gf convs each
     std::vector<ojf::PackedPair> pairs[2];  // split-fp16: the same layers packed for dense_pair_kernel (one launch per Block)
+    ojf::PackedChain chains[2];             // ... and for dense_chain_kernel (all Blocks of a head in one launch)
+    bool chain_dense = false;               // X[] hold split planes, run_dense = one dense_chain_kernel launch per head
     ojf::Vortex vortex[3];                  // v3: vortex0, vortex2, vortex3 ; v2: vortex, -, vortex_final
     std::vector<ojf::PackedConv> pred;
     float *chain_w = nullptr, *chain_b = nullptr;  // fused prediction head (when the topology is supported)
@@ -2418,7 +2432,7 @@ static int chain_blocks(const ojf_net *net) { return ((net->npix + 15) / 16 + oj
 //       instead of writing `out`; *next_done reports it.
 static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float *out, int out_g0, hipStream_t st,
                       ojf_net::Scratch &sc, const ChainArgs *head = nullptr, bool *head_done = nullptr,
-                      bool entry_done = false, const Vortex *next = nullptr, bool *next_done = nullptr)
+                      bool entry_done = false, const Vortex *next = nullptr, bool *next_done = nullptr, bool in_split = false)
 {
     const int h = net->h, w = net->w, c4 = net->cs / 4, o4 = net->os / 4;
     const bool h16 = net->arith == OJF_ARITH_F16X3;
@@ -2430,6 +2444,7 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
     // 3x3 and their second 3x3 (whose result the tail reads as plain fp32 planes)
     static const bool no_split = getenv("OJF_CONV_SPLIT") && atoi(getenv("OJF_CONV_SPLIT")) == 0;  // A/B switch
     const bool split = h16 && chain_flow && !no_split;
+    if (in_split && (!chain_flow || entry_done)) return fail("run_vortex: internal error (split-plane input without the entry kernel)");
     if (!chain_flow) {
         if (entry_done) return fail("run_vortex: internal error (entry planes without the chain flow)");
         // global-average branch -> bias of the final conv, on the side stream (fork here, join before the tail)
@@ -2452,6 +2467,7 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
         ea.ovf = h16 ? overflow_flag() : nullptr;
         ea.out_planes = planes(sc.Z); ea.out_g0 = 0; ea.og_store = 4 * c4; ea.act_n = net->cs; ea.colsum = sc.colsum;
         ea.split_groups = split ? c4 : 0;
+        ea.in_split = in_split ? 1 : 0;
         const dim3 grid(chain_blocks(net)), block(ojf::kChainThreads);
         if (h16) hipLaunchKernelGGL((entry1x1_kernel<OJF_ARITH_F16X3, 1, 8, 5>), grid, block, 0, st, ea);
         else hipLaunchKernelGGL((entry1x1_kernel<OJF_ARITH_F32, 1, 8, 5>), grid, block, 0, st, ea);
@@ -2551,6 +2567,7 @@ static int run_dense(ojf_net *net, int head, hipStream_t st)
     const int c4 = net->cs / 4;
     float *T = net->sc[head].T;
     static const bool no_pair = getenv("OJF_NO_PAIR") != nullptr;  // ablation switch only
+    if (net->chain_dense) return launch_chain(net->chains[head], net->X[head], net->h, net->w, st);  // one launch (ojf_net_chain.h)
     if (!no_pair && (int)net->pairs[head].size() == net->gf) {  // one fused launch per Block (ojf_net_pair.h)
         for (int i = 0; i < net->gf; ++i)
             if (launch_pair(net->pairs[head][i], net->X[head], 0, net->X[head], (i + 1) * c4, net->h, net->w, st)) return -2;
@@ -2590,6 +2607,7 @@ OJF_API void ojf_net_destroy(ojf_net *net)
     for (int hd = 0; hd < 2; ++hd) {
         for (auto &pc : net->dense[hd]) release(pc);
         for (auto &pp : net->pairs[hd]) release(pp);
+        release(net->chains[hd]);
     }
     for (auto &pc : net->pred) release(pc);
     for (auto &v : net->vortex) free_vortex(v);
@@ -2653,6 +2671,7 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
     int rc = 0;
     int li = 0;
     auto build_dense = [&](int head) -> int {
+        std::vector<ConvBuilder> bas, bbs;
         for (int i = 0; i < gf; ++i) {
             const ojf_conv_layer &la = L[li++], &lb = L[li++];
             if (la.ksize != 3 || lb.ksize != 3 || la.c_in != (i + 1) * c || la.c_out != c || lb.c_in != c || lb.c_out != c)
@@ -2668,8 +2687,11 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
                 PackedPair pp;
                 if (finish_pair(ba, bb, pp, pair_cfg_for(net->h, net->w, cs))) return -2;
                 net->pairs[head].push_back(pp);
+                bas.push_back(ba);
+                bbs.push_back(bb);
             }
         }
+        if ((int)bas.size() == gf && cs == 4 * kChainNG && gf <= kChainMaxLayers && finish_chain(bas, bbs, net->chains[head])) return -2;
         return 0;
     };
     const std::vector<int> dense_map = slot_map(net->pool_in, c, cs);
@@ -2730,6 +2752,16 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
         if (version == 3 && sem) { skip_dense(); sub_gave(); }
         sub_gave();
     }
+    if (!rc) {
+        // One dense_chain_kernel launch per head instead of gf dense_pair_kernel launches: the dense-growth buffers then hold
+        // split planes, which only the chain-flow entry kernel reads (OJF_NO_DENSE_CHAIN=1 / the legacy flow: pair kernels)
+        static const bool no_chain = getenv("OJF_NO_DENSE_CHAIN") != nullptr || getenv("OJF_LEGACY_VORTEX") != nullptr ||
+                                     getenv("OJF_NO_PAIR") != nullptr;
+        bool ok = net->arith == OJF_ARITH_F16X3 && !no_chain;
+        for (int hd = 0; hd < net->heads && ok; ++hd)
+            ok = net->chains[hd].layers == gf && net->vortex[hd].entry_w && net->vortex[hd].tail_w;
+        net->chain_dense = ok;
+    }
     const size_t np = (size_t)net->npix;
     if (!rc) rc = alloc_planes(&net->X[0], np, (gf + 1) * cs);
     if (!rc && net->heads == 2) rc = alloc_planes(&net->X[1], np, (gf + 1) * cs);
@@ -2778,6 +2810,7 @@ int net_input_slot(::ojf_net *net, NetInputSlot *slot)
     if (!net || !slot || net->sem || net->heads != 1) return 1;
     slot->x0 = net->X[0]; slot->cs4 = net->cs / 4; slot->P = net->P; slot->h = net->h; slot->w = net->w;
     slot->ovf = net->arith == OJF_ARITH_F16X3 ? overflow_flag() : nullptr;
+    slot->split = net->chain_dense ? 1 : 0;
     return 0;
 }
 }  // namespace ojf
@@ -2801,6 +2834,7 @@ OJF_API int ojf_net_prepare_input(ojf_net *net, const float *values, const float
     a.n_classes = n_classes;
     a.v2_sem = (net->version == 2 && net->sem) ? 1 : 0;
     a.ovf = net->arith == OJF_ARITH_F16X3 ? overflow_flag() : nullptr;
+    a.split = net->chain_dense ? 1 : 0;
     hipLaunchKernelGGL(prepare_input_kernel, dim3((a.npix + 255) / 256), dim3(256), 0, as_stream(stream), a);
     return check_hip(hipGetLastError(), "prepare_input_kernel launch");
 }
@@ -2893,12 +2927,13 @@ static int forward_launches(ojf_net *net, float *est, int est_stride, hipStream_
         }
         if (two) {
             if (run_dense(net, 1, s1)) return -2;
-            if (run_vortex(net, net->vortex[1], net->X[1], 0, net->YY, o4, s1, net->sc[1])) return -2;
+            if (run_vortex(net, net->vortex[1], net->X[1], 0, net->YY, o4, s1, net->sc[1], nullptr, nullptr, false, nullptr, nullptr,
+                           net->chain_dense)) return -2;
         }
         if (run_dense(net, 0, st)) return -2;
         bool entry_done = false;  // single head: vortex0's tail runs vortex3's entry GEMM (its own output is never written)
         if (run_vortex(net, net->vortex[0], net->X[0], 0, net->YY, 0, st, net->sc[0], nullptr, nullptr, false,
-                       two ? nullptr : &net->vortex[2], &entry_done)) return -2;
+                       two ? nullptr : &net->vortex[2], &entry_done, net->chain_dense)) return -2;
         if (two && s1 != st) {
             OJF_HIP(hipEventRecord(net->ev_head_join, s1));
             OJF_HIP(hipStreamWaitEvent(st, net->ev_head_join, 0));
@@ -2908,7 +2943,7 @@ static int forward_launches(ojf_net *net, float *est, int est_stride, hipStream_
         if (run_dense(net, 0, st)) return -2;
         bool entry_done = false;
         if (run_vortex(net, net->vortex[0], net->X[0], 0, net->YY, 0, st, net->sc[0], nullptr, nullptr, false, &net->vortex[2],
-                       &entry_done)) return -2;
+                       &entry_done, net->chain_dense)) return -2;
         if (run_vortex(net, net->vortex[2], net->YY, 0, net->Y3, 0, st, net->sc[0], head, &head_done, entry_done)) return -2;
     }
     if (head_done) return 0;
@@ -3060,8 +3095,9 @@ OJF_API int ojf_net_check(ojf_stream_t stream)
     using namespace ojf;
     OJF_HIP(hipStreamSynchronize(as_stream(stream)));
     if (g_ovf_host && *g_ovf_host) {
+        const int what = *g_ovf_host;
         *g_ovf_host = 0;
-        return fail(kOverflowMsg);
+        return fail(what == 2 ? kChainStuckMsg : kOverflowMsg);
     }
     return 0;
 }

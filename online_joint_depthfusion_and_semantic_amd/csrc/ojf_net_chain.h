@@ -251,7 +251,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dense_chain_kernel(cons
     auto wait_neighbours = [&](const Item &it, int done) {
         for (int spins = 0; !neighbours_done(it, done); ++spins) {
             if (spins > (1 << 20)) {  // (cannot happen by construction; a launch must end all the same: the host reports the flag)
-                if (lane == 0) a.sync[2] = 1;
+                if (lane == 0) {
+                    a.sync[2] = 1;
+                    if (a.ovf) *a.ovf = 2;  // (reported by ojf_net_forward / ojf_net_check)
+                }
                 break;
             }
             __builtin_amdgcn_s_sleep(4);
