@@ -1916,10 +1916,10 @@ static long long *g_chain_dbg = nullptr;
 #endif
 struct PackedChain {
     float *w = nullptr, *vec = nullptr;
-    int *sync = nullptr;  // [0] epoch, [1] blocks finished, [2] error flag (a neighbour never arrived), [16...] one flag per tile
+    int *sync = nullptr;  // ChainDenseArgs::sync
     int layers = 0;
 };
-constexpr int kChainSyncInts = 16 + 8192;
+constexpr int kChainSyncInts = kChainFlags0 + 8192;
 
 static void release(PackedChain &pc)
 {
@@ -2013,7 +2013,7 @@ static int launch_chain_t(ChainDenseArgs &a, hipStream_t st)
     a.tiles_x = (a.w_img + TW - 1) / TW;
     a.tiles_y = (a.h + TH - 1) / TH;
     const int tiles = a.tiles_x * a.tiles_y, cus = device_cu_count();
-    if (tiles > kChainSyncInts - 16) return fail("dense chain: too many tiles for the flag array");
+    if (tiles > kChainSyncInts - kChainFlags0) return fail("dense chain: too many tiles for the flag array");
     // one block per CU (160 KB of LDS); the blocks draw (Block, tile) items until none is left
     const int grid = cus > 0 && cus < tiles ? cus : tiles;
     hipLaunchKernelGGL((dense_chain_kernel<TW, TH, WAVES>), dim3(grid), dim3(G::THREADS), G::LDS_BYTES, st, a);

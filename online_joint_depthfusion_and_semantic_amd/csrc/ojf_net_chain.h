@@ -33,6 +33,9 @@ constexpr int kChainKB = 6;            // K blocks per step
 constexpr int kChainStepF4 = kChainKB * 3 * 64;  // weight float4 per step: [K block][packed row tile][lane]
 constexpr int kChainMaxLayers = 7;
 constexpr int kChainEpoch = 8;         // flag = epoch + Blocks completed (epoch advances by this per launch)
+// ints of the synchronisation array: the eight band counters sit 128 bytes apart (returning atomics on one line serialise
+// whatever word they address: ~12 ns each, 3 us for 240 blocks), the per-tile flags behind them
+constexpr int kChainBand0 = 32, kChainBandStride = 32, kChainFlags0 = kChainBand0 + 8 * kChainBandStride;
 
 __host__ __device__ constexpr int chain_hu_q(int R, int g) { return R < 9 ? g : 4; }
 __host__ __device__ constexpr int chain_hu_tap(int R, int g)  // -1: empty position (zero weights)
@@ -65,8 +68,9 @@ struct ChainDenseArgs {
     const f32x4 *w;   // steps back to back (Block 0: slot 0, conv b; Block 1: slots 0, 1, conv b; ...)
     const float *vec; // per Block: bias_a | rinv_a | bias_b | rinv_b, 32 floats each
     int *sync;        // [0] epoch (advanced by the block that finishes last: the launch is graph-replayable), [1] blocks finished,
-                      // [2] error flag (a neighbour's flag never arrived: bounded spin), [3] next ticket,
-                      // [16 + tile] epoch + Blocks completed on that tile
+                      // [2] error flag (a neighbour's flag never arrived: bounded spin), [3] tickets of Blocks 1.. handed out,
+                      // [kChainBand0 + kChainBandStride q] items of Block 0 handed out in band q,
+                      // [kChainFlags0 + tile] epoch + Blocks completed on that tile
     int layers;
     int h, w_img, npix, tiles_x, tiles_y;
     int xcd_bands;
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dense_chain_kernel(cons
     const int ntiles = a.tiles_x * a.tiles_y;
     const int L = a.layers, total = L * ntiles;
     const int epoch = *a.sync;  // (constant during the launch: only the last block to finish advances it)
-    int *flags = a.sync + 16;
+    int *flags = a.sync + kChainFlags0;
 #ifdef OJF_CHAIN_TIMING
     int stamp_i = 0;
 #define OJF_CSTAMP() do { if (blockIdx.x == 37 && tid == 0 && stamp_i < 96) a.dbg[stamp_i] = (long long)__builtin_amdgcn_s_memtime(); ++stamp_i; } while (0)
@@ -178,12 +182,47 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dense_chain_kernel(cons
     // Block, i.e. for smaller tickets, and the smallest unfinished ticket is always some running block's CURRENT item
     // (whoever holds it as its next one is still busy with a smaller one): the launch makes progress with any number of
     // resident blocks - two chains on two streams, two processes on one device, a grid larger than the device.
-    // The draw is one returning atomic on one word (up to ~3 us when every block of the grid asks at once): the wave with
-    // the fewest pixel tiles issues it behind the first step of an item and hands the ticket over before the item's last
-    // step, so that nobody ever waits for it - except at the very start.
-    if (tid == 0) {
-        tk[0] = __hip_atomic_fetch_add(a.sync + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        tk[2] = 0;
+    // Drawing (one wave, lane 0 keeps the result).  Block 0's items have no predecessors, so their order is free: they come
+    // from eight counters, one per band of tiles - block b starts with band b % 8 (blocks are observed to land on XCD
+    // b % 8: a band's tiles share their halos in one L2; and 30 blocks per word instead of 240 at the start of a launch,
+    // ~0.3 instead of ~3 us).  Everything else comes from ONE counter, and only a wave that has SEEN all eight bands
+    // exhausted may use it: a ticket of a later Block exists => every item of Block 0 is in the hands of a running block.
+    // Later draws are issued by the wave with the fewest pixel tiles behind the first step of an item and handed over
+    // before the item's second convolution: nobody waits for them.
+    bool bands_open = true;
+    auto band_first = [&](int q) { return q * ntiles / 8; };
+    auto draw = [&]() -> int {  // (call with the whole wave)
+        if (bands_open) {
+            for (int tries = 0; tries < 64; ++tries) {
+                int left = 0;
+                if (lane < 8) left = band_first(lane + 1) - band_first(lane) - __hip_atomic_load(a.sync + kChainBand0 + kChainBandStride * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long open = __builtin_amdgcn_ballot_w64(left > 0);
+                if (!open) break;
+                const int home = blockIdx.x & 7;
+                const unsigned rot = (unsigned)((open >> home) | (open << (8 - home))) & 0xffu;  // bands home, home + 1, ... as bits 0, 1, ...
+                const int q = (home + __builtin_ctz(rot)) & 7;
+                int k = 0;
+                if (lane == 0) k = __hip_atomic_fetch_add(a.sync + kChainBand0 + kChainBandStride * q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                k = __builtin_amdgcn_readfirstlane(k);
+                if (k < band_first(q + 1) - band_first(q)) return band_first(q) + k;
+            }
+            bands_open = false;
+        }
+        int t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(a.sync + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return ntiles + t;  // (lane 0)
+    };
+    if (wave == 0) {
+        // (the first draw skips the look at the counters: the block's own band has items left unless the grid is tiny)
+        const int home = blockIdx.x & 7;
+        int k = 0;
+        if (lane == 0) k = __hip_atomic_fetch_add(a.sync + kChainBand0 + kChainBandStride * home, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        k = __builtin_amdgcn_readfirstlane(k);
+        int t = k < band_first(home + 1) - band_first(home) ? band_first(home) + k : draw();
+        if (lane == 0) {
+            tk[0] = t;
+            tk[2] = 0;
+        }
     }
     for (int i = tid; i < L * 32; i += G::THREADS)
         reinterpret_cast<f32x4 *>(vl)[i] = reinterpret_cast<const f32x4 *>(a.vec)[i];
@@ -336,7 +375,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dense_chain_kernel(cons
                 }
             });
             if (c == 0 && wave == G::WAVES - 1) {  // (behind everything else this step asked for)
-                if (lane == 0) drawn = __hip_atomic_fetch_add(a.sync + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                drawn = draw();
                 draw_pending = !last;
             }
             ++step;
@@ -451,6 +490,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dense_chain_kernel(cons
         if (done == (int)gridDim.x - 1) {
             a.sync[1] = 0;
             a.sync[3] = 0;
+            for (int q = 0; q < 8; ++q) a.sync[kChainBand0 + kChainBandStride * q] = 0;
             a.sync[0] = epoch + kChainEpoch;
         }
     }
