@@ -205,6 +205,14 @@ void ojf_segconv_destroy(ojf_segconv *conv);
 int ojf_segconv_forward(const ojf_segconv *conv, const float *in_dev, int in_stride, float *out_dev, int out_stride,
                         const float *res_dev, int res_stride, const float *mul_dev, int mul_stride, int act, int h,
                         int w, ojf_stream_t stream);
+/* n (1..8) convolutions of one shape - channels, kernel size, stride, frame; dilation / padding may differ as long as the
+ * output size agrees - as ONE launch: the two modality encoders of modules/adapnet.py:364-380 in lock-step, the two
+ * dilations of a multi-scale unit (:56-73), the three cascades of an eASPP (:175-202).  Arrays of n device pointers
+ * (ress / muls: NULL, or per-member pointers); the row strides are common to the members.  Same arithmetic and the same
+ * bits per member as n ojf_segconv_forward calls. */
+int ojf_segconv_forward_group(int n, const ojf_segconv *const *convs, const float *const *ins_dev, int in_stride,
+                              float *const *outs_dev, int out_stride, const float *const *ress_dev, int res_stride,
+                              const float *const *muls_dev, int mul_stride, int act, int h, int w, ojf_stream_t stream);
 
 /* ---- FUSION NET, TRAINING (modules/pipeline.py:301-363 with the net in train() mode; csrc/ojf_net_train.h) -------
  * One layer unit of the reference's Sequentials (modules/model.py:4-52,115-141) - conv -> BatchNorm2d (batch

@@ -76,6 +76,7 @@ SIGNATURES = {
     'ojf_segdeconv_create': (_i, [_c.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i]),
     'ojf_segconv_destroy': (None, [_vp]),
     'ojf_segconv_forward': (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    'ojf_segconv_forward_group': (_i, [_i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'ojf_train_packed_floats': (_sz, [_i, _i, _i]),
     'ojf_train_pack': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'ojf_train_conv': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -14,6 +14,8 @@ heads (adapnet.py:299-305) do not feed the result and are skipped.  ~772 launche
 The engine snapshots the weights: build it after ``load_state_dict`` (``Pipeline`` rebuilds it when the
 parameters change).  No fallback path: it needs libojf and a GPU.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -47,6 +49,61 @@ class _Unit:
             return F.dropout(y, p=0.5, training=True) if self.module.dropout else y
         y = self.c2(y, act='relu')
         return self.c3(y, residual=idn, act='relu')
+
+
+def _units(units, xs):
+    """The same unit of several encoders in lock-step (``[u(x) for u, x in zip(units, xs)]``): every layer is ONE grouped
+    launch over the encoders, the two dilations of a multi-scale unit ride in the same launch."""
+    u0 = units[0]
+    idns = xs if u0.down is None else segconv.group([u.down for u in units], xs)
+    ys = segconv.group([u.c1 for u in units], xs, act='relu')
+    if u0.multi:
+        half = u0.c2a.c_out
+        cats = [nhwc(2 * half, y.shape[2], y.shape[3], y.device, zero=False) for y in ys]
+        segconv.group([u.c2a for u in units] + [u.c2b for u in units], ys + ys,
+                      outs=[c[:, :half] for c in cats] + [c[:, half:] for c in cats], act='relu')
+        ys = segconv.group([u.c3 for u in units], cats, residuals=idns, act='relu')
+        return [F.dropout(y, p=0.5, training=True) if u.module.dropout else y for u, y in zip(units, ys)]
+    ys = segconv.group([u.c2 for u in units], ys, act='relu')
+    return segconv.group([u.c3 for u in units], ys, residuals=idns, act='relu')
+
+
+def _encoders(encs, images, skip2_outs, skip1_outs):
+    """``[e(image, s2, s1) for ...]`` for encoders of one architecture (the two modalities of the fusion net), layer by
+    layer in grouped launches: half the graph nodes, no side stream."""
+    xs = [im if im.shape[1] == 8 else segconv.pack_input(im.contiguous()) for im in images]
+    xs = segconv.group([e.stem for e in encs], [x[:, :3] for x in xs], act='relu')
+    xs = [segconv.maxpool(x) for x in xs]
+    for units in zip(*[e.layers[0] for e in encs]):
+        xs = _units(units, xs)
+    segconv.group([e.skip2 for e in encs], xs, outs=skip2_outs)
+    for units in zip(*[e.layers[1] for e in encs]):
+        xs = _units(units, xs)
+    segconv.group([e.skip1 for e in encs], xs, outs=skip1_outs)
+    for li in (2, 3):
+        for units in zip(*[e.layers[li] for e in encs]):
+            xs = _units(units, xs)
+    return xs
+
+
+def _easpps(aspps, xs, outs):
+    """``[a(x, out) for ...]`` in grouped launches: branch 1, step i of the three cascades and the closing convolution of
+    every eASPP are one launch each."""
+    a0 = aspps[0]
+    h, w = xs[0].shape[2:]
+    n = a0.b1.c_out
+    cats = [nhwc(5 * n, h, w, x.device, zero=False) for x in xs]
+    segconv.group([a.b1 for a in aspps], xs, outs=[c[:, :n] for c in cats], act='relu')
+    depth = len(a0.cascades[0])
+    ys = [x for x in xs for _ in a0.cascades]  # (eASPP, cascade) pairs, eASPP-major
+    for i in range(depth):
+        convs = [casc[i] for a in aspps for casc in a.cascades]
+        last = i == depth - 1
+        outs_i = [c[:, (k + 1) * n:(k + 2) * n] for c in cats for k in range(len(a0.cascades))] if last else None
+        ys = segconv.group(convs, ys, outs=outs_i, act='relu')
+    for a, x, c in zip(aspps, xs, cats):
+        segconv.broadcast(a.b5(segconv.mean(x), act='relu'), c[:, 4 * n:])  # bilinear upsampling of a 1x1 map = broadcast
+    return segconv.group([a.fin for a in aspps], cats, outs=outs, act='relu')
 
 
 class _Encoder:
@@ -147,7 +204,16 @@ class SegEngine:
         top = nhwc(256 * k, h16, w16, dev, zero=False)
         cat2 = nhwc(280, h8, w8, dev, zero=False)    # decoder stage 2 input: (deconv1 output, skip1)
         cat3 = nhwc(280, h4, w4, dev, zero=False)    # decoder stage 3 input: (stage 2 output, skip2)
-        if self.fusion:
+        grouped = self.fusion and not os.environ.get('OJF_SEG_TWO_STREAMS')  # (A/B switch: the round-3 flow on two streams)
+        if grouped:
+            # The two modality encoders have one architecture: they run in lock-step, every layer ONE grouped launch
+            # (blockIdx.z = modality; the dilations of a multi-scale unit and the cascades of the eASPPs ride along): 208 ->
+            # ~110 graph nodes per frame and no cross-stream fork / join, on maps (15x20, 30x40) where one encoder alone
+            # leaves most CUs idle.
+            x, x2 = _encoders([self.enc1, self.enc2], [mod1, mod2], [s2[:, :24], s2[:, 24:]], [s1[:, :24], s1[:, 24:]])
+            _easpps([self.aspp1, self.aspp2], [x, x2], [top[:, :256], top[:, 256:]])
+            del x2
+        elif self.fusion:
             # the two modality encoders are independent and their 15x20 / 30x40 layers leave most CUs idle: the second
             # one runs on a side stream (also inside a graph capture, where the fork / join become graph edges): 2.06 ->
             # 1.60 ms.  Finer forks (the halves of a multi-scale unit, shortcuts, eASPP branches) were measured too: every
@@ -165,10 +231,12 @@ class SegEngine:
                 x2 = self.enc2(mod2, s2[:, 24:], s1[:, 24:])
                 self.aspp2(x2, top[:, 256:])
                 del x2
-        x = self.enc1(mod1, s2[:, :24], s1[:, :24])
-        self.aspp1(x, top[:, :256])
+        if not grouped:
+            x = self.enc1(mod1, s2[:, :24], s1[:, :24])
+            self.aspp1(x, top[:, :256])
         if self.fusion:
-            main.wait_stream(side)
+            if not grouped:
+                main.wait_stream(side)
             skip2 = self.ssma_s2(s2)
             skip1 = self.ssma_s1(s1)
             x = self.ssma_res(top)

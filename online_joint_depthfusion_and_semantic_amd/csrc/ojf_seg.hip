@@ -78,6 +78,11 @@ struct SegArgs {
     int *ovf;
     int up, up_c, up_cp;   // transposed convolution: upscale factor (1: none), real / padded channels per phase
 };
+// Up to kSegGroup convolutions of the same shape (channels, kernel size, stride, frame: the launch geometry) run as ONE
+// launch, blockIdx.z = member: the two modality encoders of AdapNet++ in lock-step, the two dilations of a multi-scale
+// unit, the three cascades of an eASPP - half the graph nodes of the front end and no cross-stream fork / join.
+constexpr int kSegGroup = 8;
+struct SegGroupArgs { SegArgs a[kSegGroup]; };
 
 
 // KS = 1: the 4 waves of a block take different (channel group, pixel tiles) pairs: WM along the channels.
@@ -169,8 +174,9 @@ __device__ __forceinline__ void seg_epilogue(const SegArgs &a, const f32x4 (&acc
 
 // kDepth = K blocks in flight per wave (a cold weight fetch costs ~1 us, the MFMAs of a block ~0.1 us).
 template <int MW, int NW, int WM, int KS, int kDepth>
-__global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void segconv_kernel(SegArgs a)
+__global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void segconv_kernel(const SegGroupArgs grp)
 {
+    const SegArgs &a = grp.a[blockIdx.z];
     constexpr bool SPLITK = KS > 1;  // KS waves of a block split K
     constexpr int WN = SPLITK ? 1 : 4 / WM;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -297,8 +303,9 @@ __global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void segconv_kernel(SegArgs
 // stages): one global fetch per block instead of one per wave.  With per-wave fetches these layers were bound by
 // L1 (12 KB per wave per K block against 24 MFMAs); B operands stay per-wave buffer loads.
 template <int NW>
-__global__ __launch_bounds__(256) void segconv_wide_kernel(SegArgs a)
+__global__ __launch_bounds__(256) void segconv_wide_kernel(const SegGroupArgs grp)
 {
+    const SegArgs &a = grp.a[blockIdx.z];
     constexpr int MW = 4, D = 3;
     __shared__ f32x4 wtile[D][MW * 2 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -512,10 +519,13 @@ OJF_API void ojf_segconv_destroy(ojf_segconv *c)
     delete c;
 }
 
-OJF_API int ojf_segconv_forward(const ojf_segconv *c, const float *in, int in_stride, float *out, int out_stride, const float *res,
-                                int res_stride, const float *mul, int mul_stride, int act, int h, int w, ojf_stream_t stream)
+namespace ojf {
+namespace {
+
+// argument checks + kernel arguments of one convolution; the launch geometry comes back in Ho / Wo of `a`
+int seg_fill(const ojf_segconv *c, const float *in, int in_stride, float *out, int out_stride, const float *res, int res_stride,
+             const float *mul, int mul_stride, int act, int h, int w, SegArgs &a)
 {
-    using namespace ojf;
     if (!c || !in || !out) return fail("ojf_segconv_forward: null pointer argument");
     if (h < 1 || w < 1 || act < 0 || act > 2) return fail("ojf_segconv_forward: bad size or activation");
     if (in_stride < c->c8 * 8 || in_stride % 4 || (reinterpret_cast<uintptr_t>(in) & 15))
@@ -527,7 +537,6 @@ OJF_API int ojf_segconv_forward(const ojf_segconv *c, const float *in, int in_st
     if (Ho < 1 || Wo < 1) return fail("ojf_segconv_forward: empty output");
     const size_t in_bytes = ((size_t)h * w - 1) * in_stride * 4 + (size_t)c->c8 * 32;
     if (in_bytes >= 0xfffffff0ull) return fail("ojf_segconv_forward: input larger than 4 GB");
-    SegArgs a;
     a.in = in; a.out = out; a.res = res; a.mul = mul; a.wp = c->wp; a.rinv = c->rinv; a.bias = c->bias;
     a.in_stride = in_stride; a.out_stride = out_stride; a.res_stride = res_stride; a.mul_stride = mul_stride;
     a.H = h; a.W = w; a.Ho = Ho; a.Wo = Wo; a.stride = c->stride; a.pad = c->pad; a.dil = c->dil; a.ksize = c->ksize;
@@ -536,30 +545,67 @@ OJF_API int ojf_segconv_forward(const ojf_segconv *c, const float *in, int in_st
     a.in_bytes = (unsigned)in_bytes;
     a.ovf = range_flag_device();
     a.up = c->up; a.up_c = c->up_c; a.up_cp = c->up_cp;
-    hipStream_t st = as_stream(stream);
-    const int n_pt = (Ho * Wo + 15) / 16, groups = c->n_ct / kMW;  // pixel tiles, 64-channel groups
+    return 0;
+}
+
+// n members of one shape (the first one's n_kb / n_ct / output size decide the launch)
+int seg_launch(const SegGroupArgs &g, int n, hipStream_t st)
+{
+    const SegArgs &a = g.a[0];
+    const int n_pt = (a.Ho * a.Wo + 15) / 16, groups = a.n_ct / kMW;  // pixel tiles, 64-channel groups
+    const unsigned z = (unsigned)n;
     // Enough independent waves (>= 4 per CU) to hide the operand latency: waves own their (channels, pixels) pair.
     // Otherwise the four waves of a block split K (when K is long enough to be worth the LDS reduction).
-    const long waves2 = (long)groups * ((n_pt + 1) / 2);
+    const long waves2 = (long)groups * ((n_pt + 1) / 2) * n;
     static const int force_mw = getenv("OJF_SEG_MW") ? atoi(getenv("OJF_SEG_MW")) : 0;  // tuning only
     static const int no_wide = getenv("OJF_SEG_NO_WIDE") ? atoi(getenv("OJF_SEG_NO_WIDE")) : 0;  // tuning only
     static const int wide_min = getenv("OJF_SEG_WIDE_MIN") ? atoi(getenv("OJF_SEG_WIDE_MIN")) : 256;  // tuning only
-    if (!no_wide && c->n_kb >= 6 && (long)groups * ((n_pt + 7) / 8) >= wide_min) {
-        hipLaunchKernelGGL((segconv_wide_kernel<2>), dim3((n_pt + 7) / 8, groups), dim3(256), 0, st, a);
-    } else if (waves2 >= 1024 || c->n_kb < 8) {
-        if (groups == 1) hipLaunchKernelGGL((segconv_kernel<4, 2, 1, 1, 3>), dim3((n_pt + 7) / 8, 1), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((segconv_kernel<4, 2, 2, 1, 3>), dim3((n_pt + 3) / 4, (groups + 1) / 2), dim3(256), 0, st, a);
+    if (!no_wide && a.n_kb >= 6 && (long)groups * ((n_pt + 7) / 8) * n >= wide_min) {
+        hipLaunchKernelGGL((segconv_wide_kernel<2>), dim3((n_pt + 7) / 8, groups, z), dim3(256), 0, st, g);
+    } else if (waves2 >= 1024 || a.n_kb < 8) {
+        if (groups == 1) hipLaunchKernelGGL((segconv_kernel<4, 2, 1, 1, 3>), dim3((n_pt + 7) / 8, 1, z), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((segconv_kernel<4, 2, 2, 1, 3>), dim3((n_pt + 3) / 4, (groups + 1) / 2, z), dim3(256), 0, st, g);
     } else {
         // few pixels: the 4 waves of a block split K.  Channel tiles per block: as many as leave >= 150 blocks (measured
         // per layer shape on the 15x20 / 30x40 maps: one CU cannot pull a block's operands faster than ~150 GB/s, so
         // small layers want many small blocks; cross-block K splitting is not an option - the device-scope fence it
         // needs writes back the whole L2 and doubled the frame time)
         int mw = 4;
-        while (mw > 1 && (long)n_pt * (c->n_ct / mw) < 150) mw /= 2;
+        while (mw > 1 && (long)n_pt * (a.n_ct / mw) * n < 150) mw /= 2;
         if (force_mw) mw = force_mw;
-        if (mw == 1) hipLaunchKernelGGL((segconv_kernel<1, 1, 1, 4, 3>), dim3(n_pt, c->n_ct), dim3(256), 0, st, a);
-        else if (mw == 2) hipLaunchKernelGGL((segconv_kernel<2, 1, 1, 4, 3>), dim3(n_pt, c->n_ct / 2), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((segconv_kernel<4, 1, 1, 4, 3>), dim3(n_pt, groups), dim3(256), 0, st, a);
+        if (mw == 1) hipLaunchKernelGGL((segconv_kernel<1, 1, 1, 4, 3>), dim3(n_pt, a.n_ct, z), dim3(256), 0, st, g);
+        else if (mw == 2) hipLaunchKernelGGL((segconv_kernel<2, 1, 1, 4, 3>), dim3(n_pt, a.n_ct / 2, z), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((segconv_kernel<4, 1, 1, 4, 3>), dim3(n_pt, groups, z), dim3(256), 0, st, g);
     }
     return check_hip(hipGetLastError(), "segconv_kernel launch");
+}
+
+}  // namespace
+}  // namespace ojf
+
+OJF_API int ojf_segconv_forward(const ojf_segconv *c, const float *in, int in_stride, float *out, int out_stride, const float *res,
+                                int res_stride, const float *mul, int mul_stride, int act, int h, int w, ojf_stream_t stream)
+{
+    using namespace ojf;
+    SegGroupArgs g;
+    if (int rc = seg_fill(c, in, in_stride, out, out_stride, res, res_stride, mul, mul_stride, act, h, w, g.a[0])) return rc;
+    return seg_launch(g, 1, as_stream(stream));
+}
+
+OJF_API int ojf_segconv_forward_group(int n, const ojf_segconv *const *convs, const float *const *ins, int in_stride, float *const *outs,
+                                      int out_stride, const float *const *ress, int res_stride, const float *const *muls,
+                                      int mul_stride, int act, int h, int w, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (n < 1 || n > kSegGroup || !convs || !ins || !outs) return fail("ojf_segconv_forward_group: 1..8 members, non-null arrays");
+    SegGroupArgs g;
+    for (int i = 0; i < n; ++i) {
+        if (int rc = seg_fill(convs[i], ins[i], in_stride, outs[i], out_stride, ress ? ress[i] : nullptr, res_stride,
+                              muls ? muls[i] : nullptr, mul_stride, act, h, w, g.a[i])) return rc;
+        const SegArgs &a = g.a[i], &b = g.a[0];
+        if (a.n_kb != b.n_kb || a.n_ct != b.n_ct || a.c8 != b.c8 || a.c_out != b.c_out || a.ksize != b.ksize || a.stride != b.stride ||
+            a.Ho != b.Ho || a.Wo != b.Wo || a.up != b.up)
+            return fail("ojf_segconv_forward_group: the members must share channels, kernel size, stride and output size");
+    }
+    return seg_launch(g, n, as_stream(stream));
 }

@@ -85,6 +85,38 @@ class SegConv:
         return out
 
 
+def group(convs, xs, outs=None, act=None, residuals=None, muls=None):
+    """``[c(x, out=o, act=act, residual=r, mul=m) for ...]`` as ONE launch (``ojf_segconv_forward_group``): up to 8
+    ``SegConv`` of one shape (channels, kernel size, stride; dilation / padding may differ) on same-sized inputs - the two
+    modality encoders in lock-step, the dilations of a multi-scale unit, the cascades of an eASPP.  Same bits as the
+    single calls.  Returns the list of outputs."""
+    n = len(convs)
+    assert 1 <= n <= 8 and len(xs) == n
+    c0 = convs[0]
+    H, W = xs[0].shape[2:]
+    Ho, Wo = c0.out_size(H, W)
+    if outs is None:
+        outs = [nhwc((c0.c_out + 7) // 8 * 8, Ho, Wo, xs[0].device, zero=c0.c_out % 8 != 0)[:, :c0.c_out] for _ in range(n)]
+    assert len(outs) == n and all(o.shape[1] == c0.c_out and tuple(o.shape[2:]) == (Ho, Wo) for o in outs)
+    assert all(tuple(x.shape[2:]) == (H, W) for x in xs)
+
+    def rows(ts):
+        if ts is None:
+            return None, 0
+        pr = [_rows(t) for t in ts]
+        assert len(pr) == n and all(r[1] == pr[0][1] for r in pr), 'segconv.group: the members share their row strides'
+        return (ctypes.c_void_p * n)(*[r[0] for r in pr]), pr[0][1]
+
+    xp, xs_ = rows(xs)
+    op, os_ = rows(outs)
+    rp, rs = rows(residuals)
+    mp, ms = rows(muls)
+    handles = (ctypes.c_void_p * n)(*[c._h.value for c in convs])
+    rc = c0._lib.ojf_segconv_forward_group(n, handles, xp, xs_, op, os_, rp, rs, mp, ms, ACT[act], H, W, _lib.stream_ptr(xs[0].device))
+    _lib.check(rc, 'ojf_segconv_forward_group')
+    return list(outs)
+
+
 class SegDeconv:
     """``nn.ConvTranspose2d(c_in, c_out, 2*s, stride=s, padding=s//2)`` [+ eval ``bn``] on the SEGCONV kernel
     (``ojf_segdeconv_create``: 3x3 convolution to s*s phase copies + pixel-shuffle store).  Deterministic."""
