@@ -107,11 +107,21 @@ __device__ __forceinline__ f32x4 unsplit4(const f32x4 &s)
     const f16x8_ h = __builtin_bit_cast(f16x8_, s);
     return f32x4{(float)h[0] + (float)h[4], (float)h[1] + (float)h[5], (float)h[2] + (float)h[6], (float)h[3] + (float)h[7]};
 }
-// two split-plane float4 (channel groups A, B) -> the MFMA operand halves of their eight channels
+// two split-plane float4 (channel groups A, B) -> the MFMA operand halves of their eight channels:
+// (A0 A1 A2 A3)(B0 B1 B2 B3) -> (A0 A1 B0 B1)(A2 A3 B2 B3).
+// Round 3 did this in place with two hand-placed v_swap_b32 (inline assembly: as plain vector shuffles the compiler spends
+// moves).  Round 4 found that form UNSAFE next to MFMAs: hipcc's hazard recogniser does not look inside inline assembly, so
+// nothing keeps a swap from rewriting a register an MFMA in flight still reads (or an MFMA from reading a register the
+// swap has not finished writing) - dense_chain_kernel's packed-row loop computed wrong sums for exactly the operand dwords
+// the swaps touch, on some waves, run after run, and a padding s_nop 7 did not cure all of it.  The convolution kernels
+// never failed a test with it, but "never failed" is not a proof: plain shuffles (OJF_UNSAFE_SWAP=1 restores the old form
+// for measurements: 2539 / 2542 frames/s with the shuffles against 2533 / 2538 with the swaps on one box, no difference).
+#ifndef OJF_UNSAFE_SWAP
+#define OJF_UNSAFE_SWAP 0
+#endif
 __device__ __forceinline__ void unpack_split(const f32x4 &a, const f32x4 &b, f16x8 &hi, f16x8 &lo)
 {
-    // (A0 A1 A2 A3)(B0 B1 B2 B3) -> (A0 A1 B0 B1)(A2 A3 B2 B3) in place: two register swaps (as plain vector shuffles the
-    // compiler spends six moves per pair)
+#if OJF_UNSAFE_SWAP
     u32x4 A = __builtin_bit_cast(u32x4, a), B = __builtin_bit_cast(u32x4, b);
     unsigned a2 = A[2], a3 = A[3], b0 = B[0], b1 = B[1];
     asm("v_swap_b32 %0, %1" : "+v"(a2), "+v"(b0));
@@ -119,6 +129,10 @@ __device__ __forceinline__ void unpack_split(const f32x4 &a, const f32x4 &b, f16
     A[2] = a2; A[3] = a3; B[0] = b0; B[1] = b1;
     hi = __builtin_bit_cast(f16x8, A);
     lo = __builtin_bit_cast(f16x8, B);
+#else
+    hi = __builtin_bit_cast(f16x8, __builtin_shufflevector(a, b, 0, 1, 4, 5));
+    lo = __builtin_bit_cast(f16x8, __builtin_shufflevector(a, b, 2, 3, 6, 7));
+#endif
 }
 
 // acc += W * X for one 16x16 tile over a 32-wide K block, W and X given as split halves
