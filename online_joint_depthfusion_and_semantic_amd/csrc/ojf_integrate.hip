@@ -19,6 +19,7 @@
 // update and zeroes the head entries, so every call leaves the workspace clean.
 //
 // PARITY mode (ojf_integrate_parity.hip) reproduces the reference's sequential fp32 sums bit for bit.
+#include <cstdlib>
 #include <mutex>
 #include <unordered_map>
 
@@ -71,7 +72,10 @@ __device__ __forceinline__ bool link_record(const IntegrateArgs &a, unsigned int
 // threads of an accumulate block (one 16x8 tile): eight waves - the tile's 896 items in two passes, four slots per thread
 // to publish; LDS allows three blocks per CU either way (measured: 256 threads 62 us, 512 56 us, 1024 68 us per frame)
 constexpr int kAccThreads = 512;
-template <bool SEM>
+// WCOMB (round 4, OJF_INTEGRATE_WAVE_COMBINE=1; off by default): colliding writes INSIDE a wave are combined in registers
+// before they reach the LDS hash - measured 60.2 against 56.8 us per frame for the integrate stage at 320x240 -> 256^3 (the
+// exchanges cost more VALU time than the same-address LDS atomics they spare; results identical bit for bit)
+template <bool SEM, bool WCOMB>
 __global__ __launch_bounds__(kAccThreads) void integrate_accumulate_tiled_kernel(IntegrateArgs a, Camera cam)
 {
     __shared__ unsigned int keys[kSlots];
@@ -113,53 +117,138 @@ __global__ __launch_bounds__(kAccThreads) void integrate_accumulate_tiled_kernel
     constexpr bool sem = SEM;
     const int half = (a.n_points - 1) / 2;
     unsigned int n_in = 0;
-    for (int item = threadIdx.x; item < kTilePix * a.n_tail; item += kAccThreads) {
-        const int k = item / kTilePix, p = item % kTilePix;
-        const int r = ty * kTileH + p / kTileW, c = tx * kTileW + p % kTileW;
-        if (r >= a.h || c >= a.w) continue;
-        const int n = r * a.w + c;
-        const float z = frame_depth(a, n);
-        if (!(z != 0.0f)) continue;  // modules/pipeline.py:145-146
-        const double cv[3] = {frame[0][p], frame[1][p], frame[2][p]};
-        const double dir[3] = {frame[3][p], frame[4][p], frame[5][p]};
-        RaySample s;
-        ray_sample(cv, dir, k, half, s);
-        float v = a.est[(size_t)n * a.est_stride + k];  // pipeline.py:153-156
-        v = v < -a.trunc ? -a.trunc : (v > a.trunc ? a.trunc : v);
-        const uint8_t id_e = sem ? a.sem_ids[n] : 0;
-        const unsigned int e0 = ((unsigned int)n * a.n_tail + k) * 8u + 1u;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            int64_t idx[3];
-            double wq;
-            corner(s, q, idx, wq);
-            if (!in_volume(idx, a.X, a.Y, a.Z)) continue;  // integrator.py:48-53
-            const unsigned int lin = (unsigned int)(((size_t)idx[0] * a.Y + (size_t)idx[1]) * a.Z + (size_t)idx[2]);
-            const float we = (float)wq;  // integrator.py:45
-            const float ue = we * v;     // integrator.py:55
-            const unsigned long long xw = (unsigned long long)__double2ll_rn((double)we * kFixScale);
-            const unsigned long long xu = (unsigned long long)__double2ll_rn((double)ue * kFixScale);
-            const unsigned int e = e0 + q;
-            const unsigned int ed = (sem && a.id_vol[lin] != id_e) ? e : 0u;  // integrator.py:105
-            ++n_in;
-            const unsigned int h0 = (lin * 2654435761u) >> 21;
-            int slot = -1;
-            for (int probe = 0; probe < 16; ++probe) {
-                const unsigned int sidx = (h0 + probe) & (kSlots - 1);
-                const unsigned int prev = atomicCAS(&keys[sidx], kEmpty, lin);
-                if (prev == kEmpty || prev == lin) { slot = (int)sidx; break; }
-            }
-            if (slot >= 0) {
-                atomicAdd(&accw[slot], xw);
-                atomicAdd(&accu[slot], xu);
-                if constexpr (SEM) {
-                    atomicMax(&elast[slot], e);
-                    if (ed) atomicMax(&ediff[slot], ed);
+    if constexpr (!WCOMB) {
+        for (int item = threadIdx.x; item < kTilePix * a.n_tail; item += kAccThreads) {
+            const int k = item / kTilePix, p = item % kTilePix;
+            const int r = ty * kTileH + p / kTileW, c = tx * kTileW + p % kTileW;
+            if (r >= a.h || c >= a.w) continue;
+            const int n = r * a.w + c;
+            const float z = frame_depth(a, n);
+            if (!(z != 0.0f)) continue;  // modules/pipeline.py:145-146
+            const double cv[3] = {frame[0][p], frame[1][p], frame[2][p]};
+            const double dir[3] = {frame[3][p], frame[4][p], frame[5][p]};
+            RaySample s;
+            ray_sample(cv, dir, k, half, s);
+            float v = a.est[(size_t)n * a.est_stride + k];  // pipeline.py:153-156
+            v = v < -a.trunc ? -a.trunc : (v > a.trunc ? a.trunc : v);
+            const uint8_t id_e = sem ? a.sem_ids[n] : 0;
+            const unsigned int e0 = ((unsigned int)n * a.n_tail + k) * 8u + 1u;
+    #pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                int64_t idx[3];
+                double wq;
+                corner(s, q, idx, wq);
+                if (!in_volume(idx, a.X, a.Y, a.Z)) continue;  // integrator.py:48-53
+                const unsigned int lin = (unsigned int)(((size_t)idx[0] * a.Y + (size_t)idx[1]) * a.Z + (size_t)idx[2]);
+                const float we = (float)wq;  // integrator.py:45
+                const float ue = we * v;     // integrator.py:55
+                const unsigned long long xw = (unsigned long long)__double2ll_rn((double)we * kFixScale);
+                const unsigned long long xu = (unsigned long long)__double2ll_rn((double)ue * kFixScale);
+                const unsigned int e = e0 + q;
+                const unsigned int ed = (sem && a.id_vol[lin] != id_e) ? e : 0u;  // integrator.py:105
+                ++n_in;
+                const unsigned int h0 = (lin * 2654435761u) >> 21;
+                int slot = -1;
+                for (int probe = 0; probe < 16; ++probe) {
+                    const unsigned int sidx = (h0 + probe) & (kSlots - 1);
+                    const unsigned int prev = atomicCAS(&keys[sidx], kEmpty, lin);
+                    if (prev == kEmpty || prev == lin) { slot = (int)sidx; break; }
                 }
-            } else {  // hash full: a record of its own behind the tile slices (rare)
-                const unsigned int ridx = a.list_base + atomicAdd(&a.counters[2], 1u);
-                if (link_record(a, ridx, lin, xw, xu, e, ed)) a.touched[a.list_base + atomicAdd(&a.counters[0], 1u)] = lin;
-                if (a.stats) atomicAdd(&a.stats[2], 1u);
+                if (slot >= 0) {
+                    atomicAdd(&accw[slot], xw);
+                    atomicAdd(&accu[slot], xu);
+                    if constexpr (SEM) {
+                        atomicMax(&elast[slot], e);
+                        if (ed) atomicMax(&ediff[slot], ed);
+                    }
+                } else {  // hash full: a record of its own behind the tile slices (rare)
+                    const unsigned int ridx = a.list_base + atomicAdd(&a.counters[2], 1u);
+                    if (link_record(a, ridx, lin, xw, xu, e, ed)) a.touched[a.list_base + atomicAdd(&a.counters[0], 1u)] = lin;
+                    if (a.stats) atomicAdd(&a.stats[2], 1u);
+                }
+            }
+        }
+    } else {
+        const int lane = threadIdx.x & 63;
+        // (wave-uniform trip count: the lanes of a wave are 64 consecutive pixels of the tile at ONE ray offset k, and every
+        // lane of a running wave walks the eight corners - dead ones with `ok` false - because the lanes talk to each other)
+        for (int item0 = threadIdx.x - lane; item0 < kTilePix * a.n_tail; item0 += kAccThreads) {
+            const int item = item0 + lane;
+            const int k = item / kTilePix, p = item % kTilePix;
+            const int r = ty * kTileH + p / kTileW, c = tx * kTileW + p % kTileW;
+            bool live = item < kTilePix * a.n_tail && r < a.h && c < a.w;
+            const int n = live ? r * a.w + c : 0;
+            const float z = live ? frame_depth(a, n) : 0.0f;
+            live = live && z != 0.0f;  // modules/pipeline.py:145-146
+            const double cv[3] = {frame[0][p], frame[1][p], frame[2][p]};
+            const double dir[3] = {frame[3][p], frame[4][p], frame[5][p]};
+            RaySample s;
+            ray_sample(cv, dir, k, half, s);
+            float v = live ? a.est[(size_t)n * a.est_stride + k] : 0.0f;  // pipeline.py:153-156
+            v = v < -a.trunc ? -a.trunc : (v > a.trunc ? a.trunc : v);
+            const uint8_t id_e = (sem && live) ? a.sem_ids[n] : 0;
+            const unsigned int e0 = ((unsigned int)n * a.n_tail + k) * 8u + 1u;
+    #pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                int64_t idx[3];
+                double wq;
+                corner(s, q, idx, wq);
+                bool ok = live && in_volume(idx, a.X, a.Y, a.Z);  // integrator.py:48-53
+                unsigned int lin = ok ? (unsigned int)(((size_t)idx[0] * a.Y + (size_t)idx[1]) * a.Z + (size_t)idx[2]) : kEmpty;
+                const float we = (float)wq;  // integrator.py:45
+                const float ue = we * v;     // integrator.py:55
+                unsigned long long xw = (unsigned long long)__double2ll_rn((double)we * kFixScale);
+                unsigned long long xu = (unsigned long long)__double2ll_rn((double)ue * kFixScale);
+                unsigned int e = e0 + q;
+                unsigned int ed = (sem && ok && a.id_vol[lin] != id_e) ? e : 0u;  // integrator.py:105
+                if (ok) ++n_in;
+                // Colliding writes INSIDE the wave are combined before they reach the LDS hash: neighbouring pixels' rays fall
+                // into the same voxel more often than not (a voxel is ~3 pixels wide on the bench stream), and same-address LDS
+                // atomics serialise (round 3's counters: half of the kernel's LDS-active cycles were such conflicts).  Two
+                // butterfly steps over the lane's quad - lane ^ 1, then lane ^ 2, DPP quad permutes, no LDS traffic - : where
+                // the partner holds the same voxel the lower lane takes both contributions (integer sums and entry-id maxima:
+                // any combining order gives the same bits) and the upper lane drops out.
+    #pragma unroll
+                for (int stp = 0; stp < 2; ++stp) {
+                    const int ctrl = stp == 0 ? 0xB1 : 0x4E;  // quad_perm [1,0,3,2] / [2,3,0,1]
+                    auto dpp = [&](unsigned int x) {
+                        return stp == 0 ? (unsigned int)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xf, 0xf, true)
+                                        : (unsigned int)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xf, 0xf, true);
+                    };
+                    (void)ctrl;
+                    const unsigned int plin = dpp(ok ? lin : kEmpty);
+                    const unsigned long long pxw = ((unsigned long long)dpp((unsigned int)(xw >> 32)) << 32) | dpp((unsigned int)xw);
+                    const unsigned long long pxu = ((unsigned long long)dpp((unsigned int)(xu >> 32)) << 32) | dpp((unsigned int)xu);
+                    unsigned int pe = 0, ped = 0;
+                    if constexpr (SEM) { pe = dpp(e); ped = dpp(ed); }
+                    const bool same = ok && plin == lin;  // (a dead partner sends kEmpty)
+                    const bool upper = (lane >> stp) & 1;
+                    if (same && !upper) {
+                        xw += pxw; xu += pxu;
+                        if constexpr (SEM) { e = pe > e ? pe : e; ed = ped > ed ? ped : ed; }
+                    }
+                    if (same && upper) ok = false;
+                }
+                if (!ok) continue;
+                const unsigned int h0 = (lin * 2654435761u) >> 21;
+                int slot = -1;
+                for (int probe = 0; probe < 16; ++probe) {
+                    const unsigned int sidx = (h0 + probe) & (kSlots - 1);
+                    const unsigned int prev = atomicCAS(&keys[sidx], kEmpty, lin);
+                    if (prev == kEmpty || prev == lin) { slot = (int)sidx; break; }
+                }
+                if (slot >= 0) {
+                    atomicAdd(&accw[slot], xw);
+                    atomicAdd(&accu[slot], xu);
+                    if constexpr (SEM) {
+                        atomicMax(&elast[slot], e);
+                        if (ed) atomicMax(&ediff[slot], ed);
+                    }
+                } else {  // hash full: a record of its own behind the tile slices (rare)
+                    const unsigned int ridx = a.list_base + atomicAdd(&a.counters[2], 1u);
+                    if (link_record(a, ridx, lin, xw, xu, e, ed)) a.touched[a.list_base + atomicAdd(&a.counters[0], 1u)] = lin;
+                    if (a.stats) atomicAdd(&a.stats[2], 1u);
+                }
             }
         }
     }
@@ -438,8 +527,11 @@ OJF_API int ojf_integrate_masked(const float *depth_filtered, const uint8_t *mas
         a.list_base = (unsigned int)tiles * kSlots;
     }
     if (stats) OJF_HIP(hipMemsetAsync(stats, 0, 4 * sizeof(uint32_t), st));
-    if (id_vol) hipLaunchKernelGGL(integrate_accumulate_tiled_kernel<true>, dim3(tiles), dim3(kAccThreads), 0, st, a, cam);
-    else hipLaunchKernelGGL(integrate_accumulate_tiled_kernel<false>, dim3(tiles), dim3(kAccThreads), 0, st, a, cam);
+    static const bool wcomb = getenv("OJF_INTEGRATE_WAVE_COMBINE") != nullptr;  // measured slower: see the kernel
+    if (id_vol && wcomb) hipLaunchKernelGGL((integrate_accumulate_tiled_kernel<true, true>), dim3(tiles), dim3(kAccThreads), 0, st, a, cam);
+    else if (id_vol) hipLaunchKernelGGL((integrate_accumulate_tiled_kernel<true, false>), dim3(tiles), dim3(kAccThreads), 0, st, a, cam);
+    else if (wcomb) hipLaunchKernelGGL((integrate_accumulate_tiled_kernel<false, true>), dim3(tiles), dim3(kAccThreads), 0, st, a, cam);
+    else hipLaunchKernelGGL((integrate_accumulate_tiled_kernel<false, false>), dim3(tiles), dim3(kAccThreads), 0, st, a, cam);
     OJF_HIP(hipGetLastError());
     hipLaunchKernelGGL(integrate_finalize_kernel, dim3(tiles < 1024 ? 1024 : tiles), dim3(256), 0, st, a);
     return check_hip(hipGetLastError(), "ojf_integrate launch");

@@ -137,6 +137,45 @@ def test_integrate_fast_is_deterministic(cuda):
         assert n_mismatch(outs[0][key], outs[1][key]) == 0 and n_mismatch(outs[0][key], outs[2][key]) == 0, key
 
 
+_DIGEST_SCRIPT = r"""
+import hashlib, sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + '/tests')
+from online_joint_depthfusion_and_semantic_amd import ops
+from helpers import fresh_volumes, frame_inputs, to_cuda, make_stream
+import numpy as np
+dev = torch.device('cuda:0')
+h, w, grid = 120, 160, 64
+st = make_stream(h, w, grid)
+ws = ops.IntegrateWorkspace((grid,) * 3, h, w, 7, ops.MODE_FAST, dev)
+g = to_cuda(fresh_volumes(grid, True), dev)
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+for i in range(3):
+    fi = frame_inputs(st, i)
+    ops.integrate(t(fi['fd']), fi['Ki'], fi['E'], st.origin, st.resolution, t(fi['est']), g['tsdf'], g['wgt'], ws, mode=ops.MODE_FAST,
+                  sem_ids=t(fi['sem_ids'].reshape(-1)), sem_scores=t(fi['sem_scores'].reshape(-1)), id_vol=g['ids'], score_vol=g['scores'])
+torch.cuda.synchronize()
+print('DIGEST', ' '.join(hashlib.sha256(g[k].cpu().numpy().tobytes()).hexdigest() for k in sorted(g)))
+"""
+
+
+def test_wave_combined_accumulate_gives_the_same_bits(cuda):
+    # OJF_INTEGRATE_WAVE_COMBINE=1 (colliding writes combined inside the wave before the LDS hash: measured slower, off by
+    # default) is read once per process: two child processes, same frames, same volume digests
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for on in (False, True):
+        env = dict(os.environ)
+        env.pop('OJF_INTEGRATE_WAVE_COMBINE', None)
+        if on:
+            env['OJF_INTEGRATE_WAVE_COMBINE'] = '1'
+        out = subprocess.run([sys.executable, '-c', _DIGEST_SCRIPT, root], env=env, capture_output=True, text=True, timeout=600)
+        line = [l for l in out.stdout.splitlines() if l.startswith('DIGEST')]
+        assert out.returncode == 0 and line, out.stderr[-2000:]
+        digests.append(line[0])
+    assert digests[0] == digests[1]
+
+
 def test_known_answer_constant_update_on_empty_volume(cuda):
     # SURVEY.md §8c: constant est == v on an empty volume (w_old = 0) gives TSDF = fp16(v) and
     # weight = fp16(sum of corner weights) at every touched voxel; untouched voxels keep the init value
