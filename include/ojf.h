@@ -82,9 +82,9 @@ int ojf_extract(const float *depth_dev, const float *Kinv_host, const float *E_h
  *   scenes of one grid size on one stream.
  * stats_dev (optional, NULL to skip - the counters cost ~14 us per frame of same-line atomics): dev u32[4]
  *   receiving {touched voxels, scatter entries, records (FAST), 0}.
- * Threading / streams: calls that share a workspace must be issued from one host thread onto one stream (OJF_MODE_FAST
- *   alternates two counter sets per host call); distinct workspaces are independent.  OJF_MODE_FAST refuses to run
- *   inside a HIP stream capture (the alternation is host state a replayed graph would not follow).
+ * Threading / streams: calls that share a workspace must be ordered on one stream (OJF_MODE_FAST alternates two counter
+ *   sets per call; which one is next is kept IN the workspace header since round 4, so the call can be captured into a HIP
+ *   graph and replayed); distinct workspaces are independent.
  * Range: per frame and voxel the summed corner weight must stay below 2^19 in the 2^-44 fixed point; beyond that the
  *   sums are redone in fp64 and the weight saturates to fp16 infinity like the reference's. */
 size_t ojf_integrate_workspace_bytes(int X, int Y, int Z, int h, int w, int n_tail, int mode);

@@ -22,7 +22,8 @@ static_assert(sizeof(VoxelRec) == 32, "VoxelRec layout");
 // 19 integer bits remain: per-frame weight sums below 5e5 per voxel.
 constexpr double kFixScale = 17592186044416.0;        // 2^44
 constexpr double kFixInv = 1.0 / 17592186044416.0;
-constexpr size_t kHeaderBytes = 256;                  // two sets of 32 counters: [0] counter-allocated touched voxels, [2] counter-allocated records
+constexpr size_t kHeaderBytes = 512;                  // two sets of 32 counters ([0] counter-allocated touched voxels, [2] counter-allocated records), then the two phase words (kPhaseAcc, kPhaseFin)
+constexpr int kPhaseAcc = 64, kPhaseFin = 65;         // uint index in the header: counter set the next accumulate / the coming finalize uses
 
 struct IntegrateArgs {
     const float *depth;  // filtered frame, or the raw frame when `mask` is set
@@ -35,7 +36,8 @@ struct IntegrateArgs {
     uint8_t *id_vol;
     uint16_t *score_vol;
     unsigned int *counters;
-    unsigned int *counters_next;  // FAST frame path: the other counter set, zeroed by finalize for the next call (or NULL)
+    unsigned int *counters_next;  // unused (kept for layout)
+    int phased;                   // FAST frame path: `counters` is the header; the two counter sets alternate by the phase words IN the header
     unsigned int *head;   // dense [X*Y*Z]: first record of the voxel (index + 1), 0 = untouched; left zeroed
     VoxelRec *recs;
     unsigned int *touched;

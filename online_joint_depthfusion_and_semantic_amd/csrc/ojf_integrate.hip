@@ -94,6 +94,10 @@ __global__ __launch_bounds__(kAccThreads) void integrate_accumulate_tiled_kernel
         if constexpr (SEM) { elast[s] = 0; ediff[s] = 0; }
     }
     if (threadIdx.x == 0) { n_entries = 0; n_new = 0; n_rec = 0; }
+    // the counter set of this call (header word kPhaseAcc: flipped by the previous call's finalize kernel, nobody writes it now)
+    const unsigned int phase = a.phased ? a.counters[kPhaseAcc] & 1u : 0u;
+    unsigned int *const counters = a.counters + 32 * phase;
+    if (a.phased && blockIdx.x == 0 && threadIdx.x == 0) a.counters[kPhaseFin] = phase;  // (read by this call's finalize kernel only)
     const int tiles_x = (a.w + kTileW - 1) / kTileW;
     const int tile = banded_block_x();  // one band of the image per XCD: neighbouring tiles hit the same voxels
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
@@ -162,8 +166,8 @@ __global__ __launch_bounds__(kAccThreads) void integrate_accumulate_tiled_kernel
                         if (ed) atomicMax(&ediff[slot], ed);
                     }
                 } else {  // hash full: a record of its own behind the tile slices (rare)
-                    const unsigned int ridx = a.list_base + atomicAdd(&a.counters[2], 1u);
-                    if (link_record(a, ridx, lin, xw, xu, e, ed)) a.touched[a.list_base + atomicAdd(&a.counters[0], 1u)] = lin;
+                    const unsigned int ridx = a.list_base + atomicAdd(&counters[2], 1u);
+                    if (link_record(a, ridx, lin, xw, xu, e, ed)) a.touched[a.list_base + atomicAdd(&counters[0], 1u)] = lin;
                     if (a.stats) atomicAdd(&a.stats[2], 1u);
                 }
             }
@@ -245,8 +249,8 @@ __global__ __launch_bounds__(kAccThreads) void integrate_accumulate_tiled_kernel
                         if (ed) atomicMax(&ediff[slot], ed);
                     }
                 } else {  // hash full: a record of its own behind the tile slices (rare)
-                    const unsigned int ridx = a.list_base + atomicAdd(&a.counters[2], 1u);
-                    if (link_record(a, ridx, lin, xw, xu, e, ed)) a.touched[a.list_base + atomicAdd(&a.counters[0], 1u)] = lin;
+                    const unsigned int ridx = a.list_base + atomicAdd(&counters[2], 1u);
+                    if (link_record(a, ridx, lin, xw, xu, e, ed)) a.touched[a.list_base + atomicAdd(&counters[0], 1u)] = lin;
                     if (a.stats) atomicAdd(&a.stats[2], 1u);
                 }
             }
@@ -399,35 +403,27 @@ __global__ __launch_bounds__(256) void integrate_finalize_kernel(IntegrateArgs a
         for (unsigned int i = threadIdx.x; i < n; i += blockDim.x) finalize_voxel(a, a.touched[(size_t)tile * kSlots + i], per_pixel, sem);
         if (a.stats && threadIdx.x == 0 && n) atomicAdd(&a.stats[0], n);
     }
-    const unsigned int count = a.counters[0];
+    // (header word kPhaseFin: written by this call's accumulate kernel, stable while finalize runs)
+    const unsigned int phase = a.phased ? a.counters[kPhaseFin] & 1u : 0u;
+    const unsigned int count = a.counters[32 * phase];
     for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x)
         finalize_voxel(a, a.touched[a.list_base + t], per_pixel, sem);
     if (a.stats && blockIdx.x == 0 && threadIdx.x == 0 && count) atomicAdd(&a.stats[0], count);
     // the counter set the NEXT call will use (nobody touches it during this one): clean it here instead of a memset
     // launch in front of every frame's accumulate kernel
-    if (a.counters_next && blockIdx.x == 0 && threadIdx.x < 32) a.counters_next[threadIdx.x] = 0;
+    if (a.phased && blockIdx.x == 0 && threadIdx.x < 32) a.counters[32 * (1 - phase) + threadIdx.x] = 0;
+    if (a.phased && blockIdx.x == 0 && threadIdx.x == 0) a.counters[kPhaseAcc] = phase ^ 1u;  // (the next call's accumulate kernel reads it)
 }
 
 }  // namespace ojf
 
 namespace ojf {
-// FAST frame path: the header holds two counter sets used alternately; a call counts in one and its finalize kernel
-// zeroes the other, so no memset launch sits between the net and the accumulate kernel (~8 us per frame).  Which
-// set comes next is host state per workspace address.  Any phase is valid on a zeroed header (fresh workspace,
-// ojf_integrate_workspace_init), and after a call exactly the other set is clean - the invariant survives address
-// reuse by the caller's allocator.
-static std::mutex g_phase_mutex;
-static std::unordered_map<const void *, unsigned> g_phase;
-static unsigned next_phase(const void *ws)
-{
-    std::lock_guard<std::mutex> lock(g_phase_mutex);
-    return g_phase[ws]++ & 1u;
-}
-static void reset_phase(const void *ws)
-{
-    std::lock_guard<std::mutex> lock(g_phase_mutex);
-    g_phase.erase(ws);
-}
+// FAST frame path: the header holds two counter sets used alternately - a call counts in one and its finalize kernel
+// zeroes the other, so no memset launch sits between the net and the accumulate kernel (~8 us per frame).  Which set
+// comes next is DEVICE state since round 4 (two phase words in the header, each written by one kernel and read by the
+// other: rounds 1-3 kept the phase on the host per workspace address, which is why the call refused stream capture): the
+// call sequence is the same every time and can be captured into a HIP graph.  Any phase is valid on a zeroed header
+// (fresh workspace, ojf_integrate_workspace_init, the entry-list and PARITY paths, which zero the header themselves).
 }  // namespace ojf
 
 OJF_API size_t ojf_integrate_workspace_bytes(int X, int Y, int Z, int h, int w, int n_tail, int mode)
@@ -450,7 +446,6 @@ OJF_API int ojf_integrate_workspace_init(void *ws, size_t ws_bytes, int X, int Y
     // FAST: header + dense head table must start zeroed (every call restores that invariant)
     const size_t zero_bytes = mode == OJF_MODE_FAST ? kHeaderBytes + (size_t)X * Y * Z * sizeof(unsigned int)
                                                     : kHeaderBytes;
-    reset_phase(ws);
     return check_hip(hipMemsetAsync(ws, 0, zero_bytes, as_stream(stream)), "workspace memset");
 }
 
@@ -493,7 +488,7 @@ OJF_API int ojf_integrate_masked(const float *depth_filtered, const uint8_t *mas
     a.depth = depth_filtered; a.mask = mask; a.est = est; a.tsdf = tsdf; a.wgt = wgt;
     a.sem_ids = sem_ids; a.sem_scores = sem_scores; a.id_vol = id_vol; a.score_vol = score_vol;
     a.counters = reinterpret_cast<unsigned int *>(base);
-    a.counters_next = nullptr;
+    a.counters_next = nullptr; a.phased = 0;
     a.head = nullptr; a.recs = nullptr; a.touched = nullptr; a.tile_new = nullptr; a.list_base = 0; a.n_tiles = 0; a.stats = stats;
     a.X = X; a.Y = Y; a.Z = Z; a.h = h; a.w = w; a.n_points = n_points; a.n_tail = n_tail;
     a.est_stride = est_stride; a.trunc = trunc;
@@ -503,17 +498,7 @@ OJF_API int ojf_integrate_masked(const float *depth_filtered, const uint8_t *mas
         OJF_HIP(hipMemsetAsync(a.counters, 0, kHeaderBytes, st));
         return integrate_parity(a, cam, base + kHeaderBytes, ws_bytes - kHeaderBytes, st);
     }
-    {
-        // The counter-set alternation is host-call-order state: a stream capture would freeze one phase into the graph and
-        // every replay would reuse it (stale `touched` entries after a hash-full frame).  Refuse instead of corrupting.
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
-            return fail("ojf_integrate (FAST): not capturable into a HIP graph (the two counter sets alternate per host call); "
-                        "use OJF_MODE_PARITY inside a capture or launch the frame step directly");
-        const unsigned phase = next_phase(ws);
-        a.counters = reinterpret_cast<unsigned int *>(base) + 32 * phase;
-        a.counters_next = reinterpret_cast<unsigned int *>(base) + 32 * (1 - phase);
-    }
+    a.phased = 1;  // (a.counters = the header)
 
     const int tiles = (int)tile_count(h, w);
     {
@@ -564,15 +549,11 @@ OJF_API int ojf_integrate_entries(const float *values, const int64_t *indices, c
     a.head = reinterpret_cast<unsigned int *>(base + kHeaderBytes);
     a.recs = reinterpret_cast<VoxelRec *>(base + kHeaderBytes + nvox * sizeof(unsigned int));
     a.touched = reinterpret_cast<unsigned int *>(base + kHeaderBytes + nvox * sizeof(unsigned int) + entries * sizeof(VoxelRec));
-    a.stats = stats; a.tile_new = nullptr; a.list_base = 0; a.n_tiles = 0; a.counters_next = nullptr;
+    a.stats = stats; a.tile_new = nullptr; a.list_base = 0; a.n_tiles = 0; a.counters_next = nullptr; a.phased = 0;
     a.X = X; a.Y = Y; a.Z = Z; a.h = 1; a.w = 1; a.n_points = 1; a.est_stride = 0; a.trunc = 0.0f;
     a.n_tail = 1;  // finalize maps entry id -> row as (id - 1) / (n_tail * 8)
     OJF_HIP(hipMemsetAsync(base, 0, kHeaderBytes, st));
-    {   // same alternation as the frame path (the two may share a workspace): count in one set, leave the other clean
-        const unsigned phase = next_phase(ws);
-        a.counters = reinterpret_cast<unsigned int *>(base) + 32 * phase;
-        a.counters_next = reinterpret_cast<unsigned int *>(base) + 32 * (1 - phase);
-    }
+    // (the header was zeroed above: both counter sets clean, phase 0 - the frame path may share this workspace)
     if (stats) OJF_HIP(hipMemsetAsync(stats, 0, 4 * sizeof(uint32_t), st));
     if (n_rows > 0) {
         EntryArgs e{values, indices, weights, row_ids, (int)n_rows};

@@ -157,7 +157,7 @@ class EntryWorkspace:
         X, Y, Z = shape
         nvox = X * Y * Z
         self.shape, self.max_rows = tuple(shape), int(max_rows)
-        self.bytes = 256 + nvox * 4 + self.max_rows * 8 * 32 + min(self.max_rows * 8, nvox) * 4
+        self.bytes = 512 + nvox * 4 + self.max_rows * 8 * 32 + min(self.max_rows * 8, nvox) * 4  # (header: csrc/ojf_integrate.h kHeaderBytes)
         self.buf = torch.zeros(self.bytes, dtype=torch.uint8, device=device)  # the head table starts clean
         self.stats = torch.zeros(4, dtype=torch.int32, device=device)
 

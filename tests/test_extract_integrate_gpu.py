@@ -452,19 +452,27 @@ def test_fast_mode_weight_overflow_saturates_like_the_reference(cuda):
     assert np.abs(got_t[touched].astype(np.float32) - ref['tsdf'][touched].astype(np.float32)).max() <= 2e-3
 
 
-def test_fast_integrate_refuses_stream_capture(cuda):
-    """include/ojf.h: OJF_MODE_FAST alternates two counter sets per HOST call - inside a graph capture it fails loudly
-    instead of freezing one phase into the graph."""
-    from online_joint_depthfusion_and_semantic_amd._lib import OjfError
+def test_fast_integrate_inside_a_graph(cuda):
+    """include/ojf.h: OJF_MODE_FAST alternates two counter sets per call; the phase lives in the workspace header (device
+    state, round 4), so a captured call replays correctly - here with hash-full frames (a tiny grid: every tile overflows
+    its LDS hash into the counter-allocated lists, the part the alternation exists for) against direct calls."""
     h, w, grid = 24, 32, 16
     st = make_stream(h, w, grid)
     fi = frame_inputs(st, 0)
-    g = to_cuda(fresh_volumes(grid, False), cuda)
-    ws = ops.IntegrateWorkspace((grid,) * 3, h, w, 7, ops.MODE_FAST, cuda)
     fd, est = _t(fi['fd'], cuda), _t(fi['est'], cuda)
-    ops.integrate(fd, fi['Ki'], fi['E'], st.origin, st.resolution, est, g['tsdf'], g['wgt'], ws, mode=ops.MODE_FAST)
+    vols = [to_cuda(fresh_volumes(grid, False), cuda) for _ in range(2)]
+    wss = [ops.IntegrateWorkspace((grid,) * 3, h, w, 7, ops.MODE_FAST, cuda) for _ in range(2)]
+    run = lambda k: ops.integrate(fd, fi['Ki'], fi['E'], st.origin, st.resolution, est, vols[k]['tsdf'], vols[k]['wgt'], wss[k], mode=ops.MODE_FAST)
+    for k in range(2):
+        run(k)  # (warm-up outside the capture; both sides have integrated the frame once)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with pytest.raises(OjfError, match='not capturable'):
-        with torch.cuda.graph(graph):
-            ops.integrate(fd, fi['Ki'], fi['E'], st.origin, st.resolution, est, g['tsdf'], g['wgt'], ws, mode=ops.MODE_FAST)
+    with torch.cuda.graph(graph):
+        run(0)
+    for _ in range(3):  # an odd number of replays: both counter phases are exercised
+        graph.replay()
+        run(1)
+    torch.cuda.synchronize()
+    # (the capture itself does not execute: side 0 ran 1 + 3 times, side 1 ran 1 + 3 times)
+    for key in ('tsdf', 'wgt'):
+        assert n_mismatch(vols[0][key].cpu().numpy(), vols[1][key].cpu().numpy()) == 0, key
