@@ -305,3 +305,79 @@ def test_extract_to_net_equals_extract_plus_prepare(cuda, version, h, w, grid):
     assert not sem_eng.fused_input
     with pytest.raises(_lib.OjfError):
         ops.extract_to_net(depth, Ki, E, origin, res, tsdf, wgt, sem_eng)
+
+
+def test_dense_chain_kernel_under_concurrent_chains(cuda):
+    """dense_chain_kernel (csrc/ojf_net_chain.h) hands its (Block, tile) items out by ticket so that it makes progress with
+    any number of resident blocks: three nets of the headline frame size on three streams, launched back to back without
+    synchronising, leave every CU contested by three persistent kernels that wait for their neighbours' tiles.  Every
+    forward pass must return the bits a lone forward pass returns (the kernel's arithmetic is order-free), and the range /
+    stuck flag must stay clear."""
+    h, w = 240, 320
+    x = _inputs(h, w)
+    engines, streams, lone = [], [], []
+    for k in range(3):
+        eng = FusionNetEngine(seeded_net('v3', False, h, w, seed=k), h, w, cuda)
+        engines.append(eng)
+        streams.append(torch.cuda.Stream(device=cuda))
+        lone.append(_run(eng, x, h, w, cuda).clone())
+        eng.check()
+    torch.cuda.synchronize()
+    outs = [[torch.empty((h * w, 9), device=cuda) for _ in range(6)] for _ in engines]
+    fv = x['tsdf_values'][0].permute(1, 2, 0).reshape(h * w, 9).contiguous().to(cuda)
+    fw = x['tsdf_weights'][0].permute(1, 2, 0).reshape(h * w, 9).contiguous().to(cuda)
+    fr = x['tsdf_frame'].reshape(h, w).contiguous().to(cuda)
+    torch.cuda.synchronize()
+    for rep in range(6):
+        for k, eng in enumerate(engines):
+            with torch.cuda.stream(streams[k]):
+                eng.prepare_input(fv, fw, fr, None, 0)
+                eng.forward(outs[k][rep])
+    torch.cuda.synchronize()
+    for k, eng in enumerate(engines):
+        eng.check()
+        for rep in range(6):
+            assert torch.equal(outs[k][rep], lone[k]), (k, rep, float((outs[k][rep] - lone[k]).abs().max()))
+        eng.close()
+
+
+_CHAIN_AB_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + '/tests')
+import test_net_gpu as t
+dev = torch.device('cuda:0')
+h, w = int(sys.argv[2]), int(sys.argv[3])
+sem = sys.argv[4] == '1'
+net = t.seeded_net('v3', sem, h, w)
+x = t._inputs(h, w)
+eng = t.FusionNetEngine(net, h, w, dev)
+fv = x['tsdf_values'][0].permute(1, 2, 0).reshape(h * w, 9).contiguous().to(dev)
+fw = x['tsdf_weights'][0].permute(1, 2, 0).reshape(h * w, 9).contiguous().to(dev)
+eng.prepare_input(fv, fw, x['tsdf_frame'].reshape(h, w).contiguous().to(dev), x['sem_ids'].contiguous().to(dev) if sem else None, 30)
+est = torch.empty((h * w, 9), device=dev)
+eng.forward(est); eng.check()
+torch.save(est.cpu(), sys.argv[5])
+"""
+
+
+@pytest.mark.parametrize('h,w,sem', [(240, 320, False), (60, 80, True), (45, 77, False)])
+def test_dense_chain_kernel_against_the_pair_kernels(cuda, tmp_path, h, w, sem):
+    """One dense_chain_kernel launch per head (default) against one dense_pair_kernel launch per Block
+    (OJF_NO_DENSE_CHAIN=1, read once per process: two child processes): same split-fp16 products, another summation
+    order - the outputs agree far inside the 1e-5 bar both hold against the fp32 CPU net."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for off in (False, True):
+        env = dict(os.environ)
+        env.pop('OJF_NO_DENSE_CHAIN', None)
+        if off:
+            env['OJF_NO_DENSE_CHAIN'] = '1'
+        path = str(tmp_path / ('est%d.pt' % off))
+        out = subprocess.run([sys.executable, '-c', _CHAIN_AB_SCRIPT, root, str(h), str(w), '1' if sem else '0', path], env=env,
+                             capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res.append(torch.load(path))
+    err = float((res[0] - res[1]).abs().max())
+    print('dense chain vs pair kernels %dx%d sem=%s: max difference %.2e' % (w, h, sem, err))
+    assert err <= 2e-6, err
