@@ -446,7 +446,7 @@ class TrainCase:
             # and read once per timed loop here (the same numbers, without a host round trip per frame)
             self.loss_sum = loss.detach() if self.loss_sum is None else self.loss_sum + loss.detach()
         if self.cfg.TRAINING.optimization.clipping:  # train_fusion.py:182-183: on the accumulated gradients, every frame
-            torch.nn.utils.clip_grad_norm_(self.pipe._fusion_network.parameters(), max_norm=1., norm_type=2)
+            self.grads.clip_(1.0)  # (= clip_grad_norm_(parameters, 1., 2): the gradients are views into the flat buffer)
         if (i + 1) % self.accum == 0:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()

@@ -3038,7 +3038,7 @@ OJF_API int ojf_net_forward(ojf_net *net, float *est, int est_stride, ojf_stream
     if (!net || !est) return fail("ojf_net_forward: null pointer argument");
     if (est_stride < net->P) return fail("ojf_net_forward: est_stride < n_points");
     hipStream_t st = as_stream(stream);
-    if (net->arith == OJF_ARITH_F16X3 && g_ovf_host && *g_ovf_host) return fail(kOverflowMsg);
+    if (net->arith == OJF_ARITH_F16X3 && g_ovf_host && *g_ovf_host) return fail(*g_ovf_host == 2 ? kChainStuckMsg : kOverflowMsg);
     if (net->use_graph) {
         if (!net->gexec || net->g_est != est || net->g_stride != est_stride) capture_graph(net, est, est_stride);
         if (net->gexec) return check_hip(hipGraphLaunch(net->gexec, st), "hipGraphLaunch (net forward)");

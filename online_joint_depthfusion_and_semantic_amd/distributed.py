@@ -78,6 +78,16 @@ class FlatGradientAllReduce:
     def zero(self):
         self.flat.zero_()
 
+    def clip_(self, max_norm=1.0, eps=1e-6):
+        """``torch.nn.utils.clip_grad_norm_(module.parameters(), max_norm, 2)`` (train_fusion.py:182-183) on the flat
+        buffer: the 2-norm of all gradients is the 2-norm of the buffer, so the clip is three small launches and no
+        Python walk over 230 tensors (the per-frame clip cost the training step ~0.3 ms of host time).  Same formula
+        (coef = max_norm / (norm + 1e-6), clamped to 1); the norm is summed in one pass instead of per tensor, i.e. it
+        differs from torch's in the last bits only.  Returns the norm (a 0-d tensor: no host read)."""
+        norm = torch.linalg.vector_norm(self.flat, 2)
+        self.flat.mul_(torch.clamp(max_norm / (norm + eps), max=1.0))
+        return norm
+
     def reduce(self):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             if self.flat.is_cuda and dist.get_backend(self.group) == 'gloo':

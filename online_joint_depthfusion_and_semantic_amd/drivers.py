@@ -324,7 +324,7 @@ def train_fusion(config, dataset, device, rank=0, world=1, max_steps=None, log=p
                     workspace.writer.add_scalar('Train/loss', float(window) / log_freq, global_step=i + 1 + epoch * n_steps)
                 window = 0.
             if opt.clipping:
-                torch.nn.utils.clip_grad_norm_(net.parameters(), max_norm=1., norm_type=2)
+                grads.clip_(1.0)  # clip_grad_norm_(net.parameters(), 1., 2) on the flat buffer the gradients live in
             if boundary:
                 grads.reduce()  # the single exchange step of the whole training path: every rank, every boundary
                 optimizer.step()

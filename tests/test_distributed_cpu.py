@@ -154,3 +154,23 @@ def test_train_driver_collective_schedule_with_unequal_shards(tmp_path):
     assert all(r[k]['same_weights'] and r[k]['same_buffers'] and r[k]['finite'] for k in r)
     ck = torch.load(os.path.join(str(tmp_path), 'last.pth.tar'), map_location='cpu')
     assert set(ck) == {'epoch', 'model_state', 'optimizer_state', 'scheduler_state'} and ck['epoch'] == 2
+
+
+def test_flat_clip_equals_clip_grad_norm():
+    """FlatGradientAllReduce.clip_ = torch.nn.utils.clip_grad_norm_(parameters, 1., 2) (train_fusion.py:182-183)."""
+    import copy
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8), torch.nn.Conv2d(8, 4, 1))
+    ref = copy.deepcopy(net)
+    red = FlatGradientAllReduce(net)
+    for scale in (5.0, 1e-3):  # a clipped and an unclipped case
+        g = torch.Generator().manual_seed(11)
+        for p, q in zip(net.parameters(), ref.parameters()):
+            v = torch.randn(p.shape, generator=g) * scale
+            p.grad.copy_(v)
+            q.grad = v.clone()
+        n0 = red.clip_(1.0)
+        n1 = torch.nn.utils.clip_grad_norm_(ref.parameters(), max_norm=1., norm_type=2)
+        assert abs(float(n0) - float(n1)) <= 1e-6 * float(n1)
+        for p, q in zip(net.parameters(), ref.parameters()):
+            assert torch.allclose(p.grad, q.grad, rtol=1e-6, atol=1e-9)
