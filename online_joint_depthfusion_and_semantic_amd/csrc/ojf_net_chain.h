@@ -466,7 +466,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dense_chain_kernel(cons
                     gmax = guard_max(gmax, lin);
                     const f32x4 val = split_pack4(leaky_max4(lin, 0.01f));
                     const unsigned off = (unsigned)((((l + 1) * kChainNG + og) * a.npix + p) * 16);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), ors, off, 0, 16 /* sc1: write-through */);
+                    // sc1: write-through, for the neighbours that read this slot inside the launch; the last Block's slot is
+                    // read by the next kernel only: plain stores leave it in the XCD's L2 (an sc1 store drops the line)
+                    if (l + 1 < L) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), ors, off, 0, 16);
+                    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), ors, off, 0, 0);
                 };
                 put_o(g, main, rm, bm);
                 if (g == 0) put_o(4, extra, re, be);
