@@ -166,3 +166,30 @@ def test_front_end_operators_match_torch(cuda):
         ws, wi = torch.softmax(logits.cpu(), dim=1).max(dim=1)
         assert i.dtype == torch.uint8 and torch.equal(i.cpu().long().view(19, 23), wi[0])
         assert torch.allclose(s.cpu().view(19, 23), ws[0], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,dils,h,w', [
+    (256, 64, 1, 1, (1, 1), 60, 80),          # two encoders, one layer (wave-per-tile kernel)
+    (128, 32, 3, 1, (1, 2, 1, 2), 30, 40),    # both dilations of a multi-scale unit of both encoders
+    (64, 64, 3, 1, (3, 6, 12, 3, 6, 12), 15, 20),  # the three cascades of two eASPPs (split-K kernel)
+    (1024, 256, 1, 1, (1, 1), 15, 20), (64, 64, 3, 1, (1, 1), 240, 320)])  # ... and the LDS-shared-weights kernel
+def test_grouped_launch_gives_the_bits_of_single_launches(cin, cout, k, stride, dils, h, w):
+    """ojf_segconv_forward_group (blockIdx.z = member) against one ojf_segconv_forward per member: same kernels, same
+    arithmetic, same order - identical bits, with residuals and ReLU, on members of different dilation."""
+    from online_joint_depthfusion_and_semantic_amd import segconv
+    dev = torch.device('cuda:0')
+    torch.manual_seed(cin + cout + len(dils))
+    convs, xs, ress = [], [], []
+    for d in dils:
+        conv = nn.Conv2d(cin, cout, k, stride=stride, dilation=d, padding=d * (k // 2)).to(dev)
+        bn = nn.BatchNorm2d(cout).to(dev).eval()
+        bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5)
+        convs.append(segconv.SegConv(conv, bn))
+        xs.append(to_nhwc(torch.randn(1, cin, h, w, device=dev)))
+        ho, wo = convs[-1].out_size(h, w)
+        ress.append(to_nhwc(torch.randn(1, cout, ho, wo, device=dev)))
+    single = [c(x, act='relu', residual=r).clone() for c, x, r in zip(convs, xs, ress)]
+    grouped = segconv.group(convs, xs, act='relu', residuals=ress)
+    torch.cuda.synchronize()
+    for a, b in zip(single, grouped):
+        assert torch.equal(a, b)
