@@ -2055,6 +2055,131 @@ static int launch_chain(const PackedChain &pc, float *x, int h, int w, hipStream
     return launch_chain_t<12, 8, 8>(a, st);
 }
 
+// ---- the four branches of a VortexPooling in one persistent launch (vortex_branch_kernel, ojf_net_branch.h) -----------
+}  // namespace ojf
+#include "ojf_net_branch.h"
+namespace ojf {
+
+struct PackedBranches {
+    float *w = nullptr, *vec = nullptr;
+    int4 *items = nullptr;
+    int n_items = 0;
+    int dil[4] = {0, 0, 0, 0};
+};
+
+static void release(PackedBranches &pb)
+{
+    if (pb.w) (void)hipFree(pb.w);
+    if (pb.vec) (void)hipFree(pb.vec);
+    if (pb.items) (void)hipFree(pb.items);
+    pb = PackedBranches();
+}
+
+// The item table of vortex_branch_kernel for an h x w frame (ojf_net_branch.h): per branch the kind with the fewest MFMA
+// pixel tiles, the table sorted by kind; inside a branch the phases of a tile 8 items apart (same XCD: measured 82 against
+// 95 us per frame for the kernel with the sub-images of a tile dealt to neighbouring blocks, i.e. to eight L2s).
+static std::vector<int4> branch_items(const int (&dil)[4], int h, int w)
+{
+    struct Plan { int br, kind, ntx, nty, cost; };
+    std::vector<Plan> plans;
+    for (int br = 0; br < 4; ++br) {
+        const int d = dil[br], smw = (w + d - 1) / d, smh = (h + d - 1) / d;
+        Plan p{br, 0, 0, 0, 0};
+        if (smw <= BranchK2::TW && smh <= BranchK2::TH) {
+            p.kind = 2; p.ntx = p.nty = 1;
+        } else {
+            const int ntx = (smw + 19) / 20, n0 = (smh + BranchK0::TH - 1) / BranchK0::TH, n1 = (smh + BranchK1::TH - 1) / BranchK1::TH;
+            const int c0 = n0 * (BranchK0::TILES_A + BranchK0::TILES_B), c1 = n1 * (BranchK1::TILES_A + BranchK1::TILES_B);
+            p.kind = c1 < c0 ? 1 : 0; p.ntx = ntx; p.nty = c1 < c0 ? n1 : n0;
+        }
+        plans.push_back(p);
+    }
+    std::vector<int4> items;
+    for (int kind = 0; kind < 3; ++kind)
+        for (const Plan &p : plans) {
+            if (p.kind != kind) continue;
+            const int d = dil[p.br];
+            std::vector<int> phases;  // px | py << 16 of the non-empty sub-images
+            for (int py = 0; py < d && py < h; ++py)
+                for (int px = 0; px < d && px < w; ++px) phases.push_back(px | (py << 16));
+            const int head = p.br | (kind << 4);
+            if (kind == 2) {
+                for (size_t i = 0; i < phases.size(); i += 2)
+                    items.push_back(int4{head, phases[i], i + 1 < phases.size() ? phases[i + 1] : -1, 0});
+                continue;
+            }
+            const int tw = 20, th = kind == 1 ? BranchK1::TH : BranchK0::TH, nt = p.ntx * p.nty;
+            for (int t0 = 0; t0 < nt; t0 += 8) {
+                const int n = nt - t0 < 8 ? nt - t0 : 8;
+                for (int ph : phases)
+                    for (int c = 0; c < n; ++c) {
+                        // full groups: position c of an eight holds the tile whose number is congruent to the item's index mod 8
+                        const int t = n == 8 ? t0 + (int)(items.size() & 7u) : t0 + c;
+                        items.push_back(int4{head, ph, -1, ((t % p.ntx) * tw) | (((t / p.ntx) * th) << 16)});
+                    }
+            }
+        }
+    return items;
+}
+
+// ba[br] / bb[br]: the two dilated 3x3 of branch br (20 -> 20 channels)
+static int finish_branches(const std::vector<ConvBuilder> &ba, const std::vector<ConvBuilder> &bb, int h, int w, PackedBranches &pb)
+{
+    if (ba.size() != 4 || bb.size() != 4) return fail("branch packing: four branches expected");
+    std::vector<float> vec(4 * 128, 0.0f), wts;
+    for (int br = 0; br < 4; ++br) {
+        const ConvBuilder &a = ba[br], &b = bb[br];
+        if (a.taps != 9 || b.taps != 9 || a.dil != b.dil || a.dil < 1 || a.c_in_phys != 4 * kChainNG || a.c_out_phys != 4 * kChainNG ||
+            b.c_in_phys != 4 * kChainNG || b.c_out_phys != 4 * kChainNG)
+            return fail("branch packing: unsupported layer shapes");
+        pb.dil[br] = a.dil;
+        auto scales = [&](const ConvBuilder &cb, int off) {
+            std::vector<float> rs(32, 1.0f);
+            for (int oc = 0; oc < cb.c_out_phys; ++oc) {
+                float mx = 0.0f;
+                const float *row = cb.W.data() + (size_t)oc * cb.taps * cb.c_in_phys;
+                for (int i = 0; i < cb.taps * cb.c_in_phys; ++i) mx = std::fmax(mx, std::fabs(row[i]));
+                rs[oc] = row_scale(mx);
+                vec[(size_t)br * 128 + off + oc] = cb.B[oc];
+            }
+            for (int oc = 0; oc < 32; ++oc) vec[(size_t)br * 128 + off + 32 + oc] = 1.0f / rs[oc];
+            return rs;
+        };
+        const std::vector<float> ra = scales(a, 0), rb = scales(b, 64);
+        pack_chain_step(a, ra, 0, wts);
+        pack_chain_step(b, rb, 0, wts);
+    }
+    const std::vector<int4> items = branch_items(pb.dil, h, w);
+    if (items.empty() || items.size() > (1u << 20)) return fail("branch packing: bad item count");
+    pb.n_items = (int)items.size();
+    if (upload(wts, &pb.w) || upload(vec, &pb.vec)) return -2;
+    OJF_HIP(hipMalloc(reinterpret_cast<void **>(&pb.items), items.size() * sizeof(int4)));
+    OJF_HIP(hipMemcpy(pb.items, items.data(), items.size() * sizeof(int4), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// in[br]: split planes of the branch inputs; out: fp32 planes, branch br at groups [5 br, 5 br + 5)
+static int launch_branches(const PackedBranches &pb, const float *const *in, float *out, int h, int w, hipStream_t st)
+{
+    static bool configured = false;
+    if (!configured) {
+        OJF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&vortex_branch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)kBranchLdsBytes));
+        configured = true;
+    }
+    BranchArgs a;
+    for (int br = 0; br < 4; ++br) { a.in[br] = planes(in[br]); a.dil[br] = pb.dil[br]; }
+    a.out = planes(out);
+    a.w = planes(pb.w); a.vec = pb.vec; a.items = pb.items; a.n_items = pb.n_items;
+    a.h = h; a.w_img = w; a.npix = h * w;
+    a.ovf = overflow_flag();
+    const int cus = device_cu_count();
+    const int grid = cus > 0 && cus < pb.n_items ? cus : pb.n_items;
+    hipLaunchKernelGGL(vortex_branch_kernel, dim3(grid), dim3(64 * kBranchWaves), kBranchLdsBytes, st, a);
+    mark_launch("vortex_branch_kernel", st);
+    return check_hip(hipGetLastError(), "vortex_branch_kernel launch");
+}
+
 // Launches n (<= 4) independent convolutions with the same number of output tiles as ONE grid
 // (blockIdx.y = problem): the four branches of a VortexPooling run together instead of as four
 // under-filled launches with their own ramp-up and tail.
@@ -2246,6 +2371,7 @@ struct Vortex {
     float *Wg = nullptr, *bg = nullptr, *Wfg = nullptr, *bf = nullptr, *bias_final = nullptr;
     float *tail_w = nullptr, *tail_b1 = nullptr, *tail_rinv = nullptr;  // fused tail (closing 1x1s + final conv), when supported
     float *entry_w = nullptr, *entry_b = nullptr;  // the stacked entry GEMM as one chain layer (8 input tiles -> 5), when supported
+    PackedBranches branches;  // both 3x3 of the four branches for vortex_branch_kernel (split-fp16, 20-channel slots)
 };
 
 }  // namespace ojf
@@ -2361,6 +2487,7 @@ static int build_vortex(ojf_net *net, Vortex &v, const ojf_conv_layer *L, int c_
         }
     }
     const std::vector<int> id_c = slot_map(c, c, cs);
+    std::vector<ConvBuilder> bas, bbs;
     for (int br = 0; br < 4; ++br) {
         const ojf_conv_layer &la = L[2 + 4 * br], &lb = L[3 + 4 * br], &l1 = L[4 + 4 * br];
         if (la.c_in != c || la.c_out != c || lb.c_in != c || lb.c_out != c || l1.c_in != c || l1.c_out != out)
@@ -2370,7 +2497,12 @@ static int build_vortex(ojf_net *net, Vortex &v, const ojf_conv_layer *L, int c_
         bb.add(lb, 0, c, id_c, 0, true);
         b1.add(l1, 0, c, id_c, 0, true);
         if (finish(ba, v.b3a[br], net->arith) || finish(bb, v.b3b[br], net->arith) || finish(b1, v.b1[br], net->arith)) return -2;
+        bas.push_back(ba);
+        bbs.push_back(bb);
     }
+    if (net->arith == OJF_ARITH_F16X3 && cs == 4 * kChainNG && v.entry_w && bas[0].dil == bbs[0].dil && bas[1].dil == bbs[1].dil &&
+        bas[2].dil == bbs[2].dil && bas[3].dil == bbs[3].dil && finish_branches(bas, bbs, net->h, net->w, v.branches))
+        return -2;
     {   // final 1x1 over [gave | b0 | b1 | b2 | b3]; the gave columns become a per-frame bias
         const ojf_conv_layer &lf = L[17];
         ConvBuilder b(4 * os, os, 1, 1);
@@ -2423,6 +2555,7 @@ static void free_vortex(Vortex &v)
         release(v.b1[b]);
         if (v.pool_bias[b]) (void)hipFree(v.pool_bias[b]);
     }
+    release(v.branches);
     float *ptrs[] = {v.Wg, v.bg, v.Wfg, v.bf, v.bias_final, v.tail_w, v.tail_b1, v.tail_rinv, v.entry_w, v.entry_b};
     for (float *p : ptrs)
         if (p) (void)hipFree(p);
@@ -2506,7 +2639,12 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
     const float *bin[4] = {sc.Z, sc.Q1, sc.Q2, sc.Q3};
     static const bool unfused = getenv("OJF_NO_TAIL") != nullptr;  // ablation switch only
     const bool fused = v.tail_w && !unfused;
-    {   // the four branches' dilated 3x3 pairs: two grouped launches (all first convs, then all second convs)
+    // (measured equal to the two grouped launches, not faster - 82 against 79-80 us per frame, profiles/r04_pair_experiments.txt -
+    // so it is opt-in: OJF_BRANCH_KERNEL=1)
+    static const bool branch_kernel = getenv("OJF_BRANCH_KERNEL") != nullptr && atoi(getenv("OJF_BRANCH_KERNEL")) != 0;
+    if (split && v.branches.n_items && branch_kernel) {  // both 3x3 of all four branches: one launch (ojf_net_branch.h)
+        if (launch_branches(v.branches, bin, sc.V, h, w, st)) return -2;
+    } else {   // the four branches' dilated 3x3 pairs: two grouped launches (all first convs, then all second convs)
         ConvArgs ga[4], gb[4];
         for (int br = 0; br < 4; ++br) {
             fill_conv_args(ga[br], v.b3a[br], bin[br], 0, sc.U, br * c4, nullptr, OJF_ACT_RELU, net->cs, 1.0f, h, w);
