@@ -57,7 +57,7 @@ def test_argument_validation_without_device():
     assert lib.ojf_integrate_workspace_bytes(0, 8, 8, 4, 4, 7, 0) == 0
     # header + 4 B/voxel head table + one 32-B record per entry + touched list
     # FAST: header + head table + (32-B records + 4-B first touches) x tiles x (2048 + 128 * n_tail * 8) + tile counts (16 x 8 pixel tiles)
-    assert lib.ojf_integrate_workspace_bytes(8, 8, 8, 4, 4, 7, 0) == 256 + 512 * 4 + 1 * (2048 + 7168) * 36 + 1 * 4
+    assert lib.ojf_integrate_workspace_bytes(8, 8, 8, 4, 4, 7, 0) == 512 + 512 * 4 + 1 * (2048 + 7168) * 36 + 1 * 4
 
 
 def test_segconv_and_mesh_argument_validation_without_device():
