@@ -276,7 +276,7 @@ def kernel_table(kernels, c, N, peak_tf, total_macs):
     flops = {}
     if not c['semantics']:
         m = net_kernel_macs()
-        flops = {'dense_pair_kernel': m['dense'], 'dense_chain_kernel': m['dense'], 'conv_f16x3_kernel (grouped)': 2 * m['branches'], 'conv_mfma_kernel': None,
+        flops = {'dense_pair_kernel': m['dense'], 'dense_chain_kernel': m['dense'], 'conv_f16x3_kernel (grouped)': 2 * m['branches'], 'vortex_branch_kernel': 2 * m['branches'], 'conv_mfma_kernel': None,
                  'entry1x1_kernel': m['entry'], 'vortex_tail_kernel (+ next entry GEMM)': m['tail'] + m['entry'],
                  'vortex_tail_kernel (+ prediction head)': m['tail'] + m['head']}
         assert m['dense'] + 2 * m['branches'] + 2 * m['entry'] + 2 * m['tail'] + m['head'] == total_macs, (m, total_macs)
@@ -367,7 +367,7 @@ def report(case, res, steps, warmup, world, args_cpu_frames=0, full=True):
     tr, tr_src = pmc_traffic(c)
     net_traffic = hbm_traffic = None
     if tr:
-        net_k = [k for k in tr if k.startswith(('conv_mfma', 'conv_f16x3', 'chain1x1', 'vortex_tail', 'dense_pair', 'dense_chain', 'entry1x1'))]
+        net_k = [k for k in tr if k.startswith(('conv_mfma', 'conv_f16x3', 'chain1x1', 'vortex_tail', 'vortex_branch', 'dense_pair', 'dense_chain', 'entry1x1'))]
         net_traffic = sum(tr[k]['fetch_bytes_per_frame_x2'] + tr[k]['write_bytes_per_frame'] for k in net_k)
         hbm_traffic = sum(tr[k]['fetch_bytes_per_frame_x2'] + tr[k]['write_bytes_per_frame'] for k in tr if 'extract' in k or 'integrate' in k)
     if dom:
