@@ -2064,6 +2064,8 @@ struct PackedBranches {
     float *w = nullptr, *vec = nullptr;
     int4 *items = nullptr;
     int n_items = 0;
+    int4 *sub_items = nullptr;  // subconv_kernel's table
+    int n_sub = 0;
     int dil[4] = {0, 0, 0, 0};
 };
 
@@ -2072,6 +2074,7 @@ static void release(PackedBranches &pb)
     if (pb.w) (void)hipFree(pb.w);
     if (pb.vec) (void)hipFree(pb.vec);
     if (pb.items) (void)hipFree(pb.items);
+    if (pb.sub_items) (void)hipFree(pb.sub_items);
     pb = PackedBranches();
 }
 
@@ -2122,6 +2125,39 @@ static std::vector<int4> branch_items(const int (&dil)[4], int h, int w)
     return items;
 }
 
+// The item table of subconv_kernel (one block per item): per branch the kind with the fewest MFMA pixel tiles; inside a branch
+// the phases of a tile 8 items apart (blocks land on XCD blockIdx % 8: the r x r sub-images of one image region share an L2).
+static std::vector<int4> subconv_items(const int (&dil)[4], int h, int w)
+{
+    struct Kind { int tw, th, tiles; };
+    const Kind kinds[4] = {{SubK0::TW, SubK0::TH, SubK0::TILES}, {SubK1::TW, SubK1::TH, SubK1::TILES}, {SubK2::TW, SubK2::TH, SubK2::TILES},
+                           {SubK3::TW, SubK3::TH, SubK3::TILES}};
+    std::vector<int4> items;
+    for (int br = 0; br < 4; ++br) {
+        const int d = dil[br], smw = (w + d - 1) / d, smh = (h + d - 1) / d;
+        int best = 0;
+        long best_cost = -1;
+        for (int k = 0; k < 4; ++k) {
+            const long cost = (long)((smw + kinds[k].tw - 1) / kinds[k].tw) * ((smh + kinds[k].th - 1) / kinds[k].th) * kinds[k].tiles;
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = k; }
+        }
+        const Kind &K = kinds[best];
+        const int ntx = (smw + K.tw - 1) / K.tw, nty = (smh + K.th - 1) / K.th, nt = ntx * nty, head = br | (best << 4);
+        std::vector<int> phases;
+        for (int py = 0; py < d && py < h; ++py)
+            for (int px = 0; px < d && px < w; ++px) phases.push_back(px | (py << 16));
+        for (int t0 = 0; t0 < nt; t0 += 8) {
+            const int n = nt - t0 < 8 ? nt - t0 : 8;
+            for (int ph : phases)
+                for (int c = 0; c < n; ++c) {
+                    const int t = n == 8 ? t0 + (int)(items.size() & 7u) : t0 + c;
+                    items.push_back(int4{head, ph, -1, ((t % ntx) * K.tw) | (((t / ntx) * K.th) << 16)});
+                }
+        }
+    }
+    return items;
+}
+
 // ba[br] / bb[br]: the two dilated 3x3 of branch br (20 -> 20 channels)
 static int finish_branches(const std::vector<ConvBuilder> &ba, const std::vector<ConvBuilder> &bb, int h, int w, PackedBranches &pb)
 {
@@ -2155,7 +2191,32 @@ static int finish_branches(const std::vector<ConvBuilder> &ba, const std::vector
     if (upload(wts, &pb.w) || upload(vec, &pb.vec)) return -2;
     OJF_HIP(hipMalloc(reinterpret_cast<void **>(&pb.items), items.size() * sizeof(int4)));
     OJF_HIP(hipMemcpy(pb.items, items.data(), items.size() * sizeof(int4), hipMemcpyHostToDevice));
+    const std::vector<int4> sub = subconv_items(pb.dil, h, w);
+    if (sub.empty() || sub.size() > (1u << 22)) return fail("branch packing: bad subconv item count");
+    pb.n_sub = (int)sub.size();
+    OJF_HIP(hipMalloc(reinterpret_cast<void **>(&pb.sub_items), sub.size() * sizeof(int4)));
+    OJF_HIP(hipMemcpy(pb.sub_items, sub.data(), sub.size() * sizeof(int4), hipMemcpyHostToDevice));
     return 0;
+}
+
+// one dilated 3x3 of the four branches (second = 0 / 1): in[br] split planes, out[br] split planes or fp32 (5 groups each)
+static int launch_subconv(const PackedBranches &pb, const float *const *in, float *const *out, int second, bool out_split, int h, int w,
+                          hipStream_t st)
+{
+    static bool configured = false;
+    if (!configured) {
+        OJF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&subconv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSubLdsBytes));
+        configured = true;
+    }
+    SubArgs a;
+    for (int br = 0; br < 4; ++br) { a.in[br] = planes(in[br]); a.out[br] = planes(out[br]); a.dil[br] = pb.dil[br]; }
+    a.w = planes(pb.w); a.vec = pb.vec; a.items = pb.sub_items;
+    a.second = second; a.out_split = out_split ? 1 : 0;
+    a.h = h; a.w_img = w; a.npix = h * w;
+    a.ovf = overflow_flag();
+    hipLaunchKernelGGL(subconv_kernel, dim3(pb.n_sub), dim3(256), kSubLdsBytes, st, a);
+    mark_launch("subconv_kernel", st);
+    return check_hip(hipGetLastError(), "subconv_kernel launch");
 }
 
 // in[br]: split planes of the branch inputs; out: fp32 planes, branch br at groups [5 br, 5 br + 5)
@@ -2642,8 +2703,19 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
     // (measured equal to the two grouped launches, not faster - 82 against 79-80 us per frame, profiles/r04_pair_experiments.txt -
     // so it is opt-in: OJF_BRANCH_KERNEL=1)
     static const bool branch_kernel = getenv("OJF_BRANCH_KERNEL") != nullptr && atoi(getenv("OJF_BRANCH_KERNEL")) != 0;
+    static const bool subconv = getenv("OJF_SUBCONV") != nullptr && atoi(getenv("OJF_SUBCONV")) != 0;
     if (split && v.branches.n_items && branch_kernel) {  // both 3x3 of all four branches: one launch (ojf_net_branch.h)
         if (launch_branches(v.branches, bin, sc.V, h, w, st)) return -2;
+    } else if (split && v.branches.n_sub && subconv) {  // LDS-staged sub-image blocks: one launch per 3x3 (ojf_net_branch.h)
+        float *u[4], *vv[4];
+        const float *uc[4];
+        for (int br = 0; br < 4; ++br) {
+            u[br] = sc.U + (size_t)br * c4 * 4 * net->npix;
+            uc[br] = u[br];
+            vv[br] = sc.V + (size_t)br * c4 * 4 * net->npix;
+        }
+        if (launch_subconv(v.branches, bin, u, 0, true, h, w, st)) return -2;
+        if (launch_subconv(v.branches, uc, vv, 1, false, h, w, st)) return -2;
     } else {   // the four branches' dilated 3x3 pairs: two grouped launches (all first convs, then all second convs)
         ConvArgs ga[4], gb[4];
         for (int br = 0; br < 4; ++br) {

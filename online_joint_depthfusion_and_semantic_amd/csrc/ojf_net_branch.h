@@ -442,4 +442,143 @@ __global__ __launch_bounds__(64 * kBranchWaves, kBranchWaves / 4) void vortex_br
     if (gmax > 65504.0f && a.ovf) *a.ovf = 1;
 }
 
+
+// ---- one dilated 3x3 of the four branches as small LDS-staged blocks (subconv_kernel) ---------------------------------------
+// The same decomposition - dilation r = a plain 3x3 on each of the r x r sub-images - for ONE convolution per launch and
+// four-wave blocks, several per CU: a block stages the window of its tile (halo 1 in sub-image coordinates) and the
+// convolution's 18 KB of packed weights in LDS by LDS-DMA, then runs the K loop of ojf_net_chain.h on it.  Against
+// conv_f16x3_kernel, which fetches every operand from L1 once per tap (24 KB per 32 pixels): 15 KB of window per ~112
+// pixels, five MFMAs per product block instead of six, no tap table; what one block waits for, the other blocks of its CU
+// cover (what the one-block-per-CU kernel above could not).  MEASURED SLOWER, opt-in (OJF_SUBCONV=1): 27 against 20 us per
+// launch - the sub-images of r >= 3 are 16-byte granules 16 r bytes apart, so windows (8.9 us of a launch by ablation) and
+// stores (6 us) move at a fraction of the rate of conv_f16x3_kernel's 256-byte runs; the K loop is 2 us.  Kinds = (pitch PW, rows TH) of the output region, usable
+// columns TW = PW - 2: (32, 4) for r = 1, (16, 8) for r = 3, (40, 3) for 36-wide sub-images (r = 9 at 320 x 240),
+// (16, 9) for 12 x 9 sub-images (r = 27) - every pitch a multiple of 8 (conflict-free reads of the fifth group's taps).
+template <int KIND_, int PW_, int TH_>
+struct SubGeom {
+    static constexpr int KIND = KIND_, PW = PW_, TH = TH_, TW = PW_ - 2, WAVES = 4;
+    static constexpr int XS = (TH + 2) * PW, OS = TH * PW;
+    static constexpr int TILES = (OS + 15) / 16, MT = (TILES + WAVES - 1) / WAVES;
+    static constexpr int XP = pair_round16(pair_max(XS, TILES * 16 + 2 * PW + 3));
+    static constexpr int NPIECE = (kChainNG * XP + 63) / 64, X_F4 = NPIECE * 64;
+    static constexpr int NPX = (NPIECE + WAVES - 1) / WAVES;
+};
+using SubK0 = SubGeom<0, 32, 4>;
+using SubK1 = SubGeom<1, 16, 8>;
+using SubK2 = SubGeom<2, 40, 3>;
+using SubK3 = SubGeom<3, 16, 9>;
+constexpr int kSubXF4 = pair_max(pair_max(SubK0::X_F4, SubK1::X_F4), pair_max(SubK2::X_F4, SubK3::X_F4));
+constexpr size_t kSubLdsBytes = (size_t)(kSubXF4 + kChainStepF4) * 16;
+
+struct SubArgs {
+    const f32x4 *in[4];  // split planes of the four inputs (5 channel groups each; float4 -1 is zero)
+    f32x4 *out[4];       // output planes of the four branches (5 groups each): split planes or fp32
+    const f32x4 *w;      // steps of ojf_net_chain.h: branch br = step 2 br + second
+    const float *vec;    // per branch: bias_a | rinv_a | bias_b | rinv_b, 32 floats each
+    const int4 *items;   // x = branch | kind << 4, y = px | py << 16, w = sx0 | sy0 << 16
+    int second;          // 0 / 1: the branches' first / second 3x3
+    int out_split;
+    int dil[4];
+    int h, w_img, npix;
+    int *ovf;
+};
+
+template <class G>
+__device__ __forceinline__ void subconv_body(const SubArgs &a, const int4 &it4, f32x4 *wl, f32x4 *xl)
+{
+    constexpr int PW = G::PW, XP = G::XP, TSTRIDE = G::WAVES * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, g = lane >> 4;
+    const int br = __builtin_amdgcn_readfirstlane(it4.x) & 3, d = a.dil[br];
+    const int yy = __builtin_amdgcn_readfirstlane(it4.y), ww = __builtin_amdgcn_readfirstlane(it4.w);
+    const int px = yy & 0xffff, py = yy >> 16, sx0 = ww & 0xffff, sy0 = ww >> 16;
+    // window slot (row, col) <-> sub-image (sx0 - 1 + col, sy0 - 1 + row); pixel index or -1
+    auto pixel = [&](int row, int col) {
+        const int gx = px + d * (sx0 - 1 + col), gy = py + d * (sy0 - 1 + row);
+        // (a column / row in front of the sub-image gives a negative coordinate: px < d)
+        return (unsigned)gx < (unsigned)a.w_img && (unsigned)gy < (unsigned)a.h ? gy * a.w_img + gx : -1;
+    };
+    {   // weights and window by LDS-DMA
+        const f32x4 *src = a.w + (size_t)(2 * br + a.second) * kChainStepF4;
+#pragma unroll
+        for (int j = 0; j < (kChainStepF4 / 64 + G::WAVES - 1) / G::WAVES; ++j) {
+            const int pc = wave + G::WAVES * j;
+            if (pc < kChainStepF4 / 64)
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + pc * 64 + lane),
+                                                 (void __attribute__((address_space(3))) *)(wl + pc * 64), 16, 0, 0);
+        }
+        const f32x4 *base = a.in[br];
+#pragma unroll
+        for (int j = 0; j < G::NPX; ++j) {
+            const int pc = wave + G::WAVES * j;
+            if (pc < G::NPIECE) {
+                const int e = pc * 64 + lane;
+                const int q = e / XP, sl = e - q * XP;
+                const int ry = sl / PW, rx = sl - ry * PW;
+                int p = pixel(ry, rx);
+                if (q >= kChainNG || sl >= G::XS) p = -1;
+                const f32x4 *s4 = p >= 0 ? base + (q * a.npix + p) : a.in[0] - 1;  // (in[0] is the start of a buffer: the zero float4 in front of it)
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)s4,
+                                                 (void __attribute__((address_space(3))) *)(xl + pc * 64), 16, 0, 0);
+            }
+        }
+    }
+    const int mt = (G::TILES - wave + G::WAVES - 1) / G::WAVES;
+    const int ls = wave * 16 + i16;
+    int t9[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        int tap = 0;
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg)
+            if (g == gg) tap = chain_read_tap(9 + r, gg);
+        t9[r] = (tap / 3) * PW + tap % 3;
+    }
+    // bias / 1 / row scale of this lane's channels (in L2: every block reads the same 512 bytes)
+    const float *v = a.vec + br * 128 + a.second * 64;
+    const f32x4 bm = *reinterpret_cast<const f32x4 *>(v + 4 * g), rm = *reinterpret_cast<const f32x4 *>(v + 32 + 4 * g);
+    const f32x4 be = *reinterpret_cast<const f32x4 *>(v + 16), re = *reinterpret_cast<const f32x4 *>(v + 48);
+    f32x4 acc[G::MT][3];
+#pragma unroll
+    for (int m = 0; m < G::MT; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    chain_mac<G::MT, PW, TSTRIDE>(acc, xl + ls + g * XP, xl + ls + 4 * XP, wl + lane, mt, t9, []() {});
+    float gmax = 0.0f;
+    f32x4 *out = a.out[br];
+#pragma unroll
+    for (int m = 0; m < G::MT; ++m) {
+        if (m >= mt) continue;
+        const int s = ls + TSTRIDE * m;
+        const int oy = s / PW, ox = s - oy * PW;
+        const int p = (s < G::OS && ox < G::TW) ? pixel(oy + 1, ox + 1) : -1;
+        f32x4 main, extra;
+        chain_unpack(acc[m], main, extra);
+        auto put_o = [&](int og, const f32x4 &raw, const f32x4 &r4, const f32x4 &b4) {
+            if (p < 0) return;
+            const f32x4 lin = fma4(raw, r4, b4);
+            gmax = guard_max(gmax, lin);
+            const f32x4 val = leaky_max4(lin, 0.0f);
+            out[og * a.npix + p] = a.out_split ? split_pack4(val) : val;
+        };
+        put_o(g, main, rm, bm);
+        if (g == 0) put_o(4, extra, re, be);
+    }
+    if (gmax > 65504.0f && a.ovf) *a.ovf = 1;
+}
+
+__global__ __launch_bounds__(256, 4) void subconv_kernel(const SubArgs a)
+{
+    extern __shared__ f32x4 sub_lds[];
+    f32x4 *wl = sub_lds, *xl = sub_lds + kChainStepF4;
+    const int4 it4 = a.items[blockIdx.x];
+    const int kind = __builtin_amdgcn_readfirstlane(it4.x) >> 4;
+    if (kind == 0) subconv_body<SubK0>(a, it4, wl, xl);
+    else if (kind == 1) subconv_body<SubK1>(a, it4, wl, xl);
+    else if (kind == 2) subconv_body<SubK2>(a, it4, wl, xl);
+    else subconv_body<SubK3>(a, it4, wl, xl);
+}
+
 }  // namespace ojf

@@ -383,10 +383,12 @@ def test_dense_chain_kernel_against_the_pair_kernels(cuda, tmp_path, h, w, sem):
     assert err <= 2e-6, err
 
 
+@pytest.mark.parametrize('switch', ['OJF_BRANCH_KERNEL', 'OJF_SUBCONV'])
 @pytest.mark.parametrize('h,w,sem', [(240, 320, False), (60, 80, True), (45, 77, False), (480, 640, False)])
-def test_branch_kernel_against_the_grouped_launches(cuda, tmp_path, h, w, sem):
+def test_branch_kernel_against_the_grouped_launches(cuda, tmp_path, h, w, sem, switch):
     """vortex_branch_kernel (opt-in, OJF_BRANCH_KERNEL=1, read once per process: two child processes) - both dilated 3x3 of the
-    four VortexPooling branches as one LDS-resident launch over the r x r sub-images of every dilation r - against the two
+    four VortexPooling branches as one LDS-resident launch over the r x r sub-images of every dilation r - and subconv_kernel
+    (opt-in, OJF_SUBCONV=1: the same decomposition as small LDS-staged blocks, one launch per 3x3) against the two
     grouped conv_f16x3_kernel launches of the default path: the same split-fp16 products in another summation order (and a
     w_lo x_lo term for channels 16..19), so the net's outputs agree far inside the 1e-5 bar both hold against the fp32 CPU net.
     The frame sizes cover every item kind (20x16 / 20x14 tiles, stacked whole sub-images) and ragged sub-image borders."""
@@ -396,14 +398,15 @@ def test_branch_kernel_against_the_grouped_launches(cuda, tmp_path, h, w, sem):
     for on in (False, True):
         env = dict(os.environ)
         env.pop('OJF_BRANCH_KERNEL', None)
+        env.pop('OJF_SUBCONV', None)
         if on:
-            env['OJF_BRANCH_KERNEL'] = '1'
+            env[switch] = '1'
         path = str(tmp_path / ('est%d.pt' % on))
         out = subprocess.run([sys.executable, '-c', _CHAIN_AB_SCRIPT, root, str(h), str(w), '1' if sem else '0', path], env=env,
                              capture_output=True, text=True, timeout=900)
         assert out.returncode == 0, out.stderr[-2000:]
         res.append(torch.load(path))
     err = float((res[0] - res[1]).abs().max())
-    print('branch kernel vs grouped launches %dx%d sem=%s: max difference %.2e' % (w, h, sem, err))
-    assert err > 0.0, 'OJF_BRANCH_KERNEL=1 did not change the path'
+    print('%s=1 vs grouped launches %dx%d sem=%s: max difference %.2e' % (switch, w, h, sem, err))
+    assert err > 0.0, switch + '=1 did not change the path'
     assert err <= 2e-6, err
