@@ -169,8 +169,20 @@ int ojf_net_get_arithmetic(const ojf_net *net);
  * raises a process-wide flag if that value is beyond +-65504 (it cannot be split; a trained, BN-folded FusionNet
  * stays orders of magnitude below).  NaN inputs are not violations: they propagate to NaN outputs as in fp32.
  * ojf_net_forward polls the flag without synchronising and fails once it is set; ojf_net_check synchronises `stream`, returns non-zero (and clears the flag) if it was raised
- * since the last check.  Results produced in between are invalid: switch that network to OJF_ARITH_F32. */
+ * since the last check.  Results produced in between are invalid: switch that network to OJF_ARITH_F32.
+ * The volumes are protected: while the flag is set every ojf_integrate / ojf_integrate_masked / ojf_integrate_entries
+ * call (both modes) returns 0 without touching a volume - the frame whose net tripped the guard and every frame
+ * enqueued after it stay unfused until ojf_net_check has reported (and cleared) the event, so a scene is never
+ * corrupted silently; the caller re-fuses those frames after switching the arithmetic (Pipeline does, with
+ * FUSION_MODEL.guard_policy = 'f32').  (The reference has no counterpart: its fp32 torch ops have no range limit,
+ * modules/pipeline.py:62-72.) */
 int ojf_net_check(ojf_stream_t stream);
+/* Synchronises `stream`; *flag = 0 none | 1 range violation | 2 internal (dense chain gave up waiting), *skipped = the
+ * number of integrate calls skipped since the flag was raised.  Clears nothing (ojf_net_check does).  Either pointer may
+ * be NULL. */
+int ojf_guard_status(ojf_stream_t stream, int *flag, int *skipped);
+/* The flag as the host sees it right now (no synchronisation: what ojf_net_forward tests). */
+int ojf_guard_poll(void);
 
 /* Stand-alone fused convolution on NHWC fp32 rows (the kernel the net is built from; exported so
  * the parity tests can pin it layer by layer against torch.nn.functional.conv2d).

@@ -42,6 +42,18 @@ Camera make_camera(const float *Ki, const float *E, const double *origin, double
 __device__ __forceinline__ int xcd_band_block(int b, int n8) { return (b & 7) * (n8 >> 3) + (b >> 3); }
 __device__ __forceinline__ int banded_block_x() { return (gridDim.x & 7) == 0 ? xcd_band_block(blockIdx.x, gridDim.x) : (int)blockIdx.x; }
 
+// Range guard of the split-fp16 arithmetic (ojf_net.hip: overflow_flag): a DEVICE-resident block {flag, integrate calls
+// skipped, pointer to the host-mapped mirror of the flag}.  A kernel that meets a value a later split could not
+// represent raises the flag here - the device word is what the integrate kernels test before they touch a volume (a
+// frame whose net tripped the guard must not be fused), the host-mapped mirror is what the host polls without
+// synchronising.  Runs only when the guard fires: no traffic otherwise.
+__device__ __forceinline__ void guard_raise(int *g, int v)
+{
+    g[0] = v;
+    int *host = *reinterpret_cast<int *const *>(g + 2);
+    *host = v;
+}
+
 // Low halves of the split-fp16 operands: fp16(x0 - hi.lo), fp16(x1 - hi.hi) packed like `hpair` (the two fp16 high
 // halves of x0, x1).  v_fma_mix{lo,hi}_f16 forms x - hi exactly in fp32 and rounds once to fp16: the same bits as
 // converting, subtracting and converting again, in 2 instructions instead of 5 (clang folds the source-level

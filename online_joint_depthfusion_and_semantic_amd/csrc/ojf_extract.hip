@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64 * kMaxTilePoints) void extract_tile_kernel(Extra
         a.net_x0[(size_t)cg * N + n0 + px] = a.net_split ? split_planes4(v) : v;
         bad = bad || fabsf(v.x) > 65504.0f || fabsf(v.y) > 65504.0f || fabsf(v.z) > 65504.0f || fabsf(v.w) > 65504.0f;
     }
-    if (bad && a.ovf) *a.ovf = 1;  // split-fp16 range guard of the net input (NaN passes, like everywhere else)
+    if (bad && a.ovf) guard_raise(a.ovf, 1);  // split-fp16 range guard of the net input (NaN passes, like everywhere else)
 }
 
 // any n_points: one lane per (sample k, pixel n), k-major; every item computes its own ray frame

@@ -45,6 +45,10 @@ struct IntegrateArgs {
     unsigned int list_base;   // first element of the counter-allocated parts of `touched` / `recs`
     int n_tiles;              // 0 on the entry-list path
     uint32_t *stats;
+    // range guard of the split-fp16 net (ojf_common.h guard_raise): device block {flag, skipped calls, ...} or NULL.  While
+    // the flag is set no integrate call touches a volume - the est rows of a tripped frame are invalid, and so is every
+    // frame until the host has reported the event (ojf_net_check) - and [1] counts the calls skipped.
+    int *guard;
     int X, Y, Z, h, w, n_points, n_tail, est_stride;
     float trunc;
 };
@@ -54,6 +58,9 @@ __device__ __forceinline__ float frame_depth(const IntegrateArgs &a, int n)
     const float z = a.depth[n];
     return (a.mask && !a.mask[n]) ? 0.0f : z;  // torch.where(mask == 0, 0, frame)
 }
+
+const int *range_guard_if_any();  // ojf_net.hip
+__device__ __forceinline__ bool guard_set(const IntegrateArgs &a) { return a.guard && *static_cast<volatile const int *>(a.guard) != 0; }
 
 size_t fast_workspace_bytes(int X, int Y, int Z, int h, int w, int n_tail);
 size_t parity_workspace_bytes(int X, int Y, int Z, int h, int w, int n_tail);

@@ -101,6 +101,13 @@ __global__ __launch_bounds__(kAccThreads) void integrate_accumulate_tiled_kernel
     const int tiles_x = (a.w + kTileW - 1) / kTileW;
     const int tile = banded_block_x();  // one band of the image per XCD: neighbouring tiles hit the same voxels
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    if (guard_set(a)) {  // block-uniform: the net's range guard fired - this frame must not reach the volumes
+        if (threadIdx.x == 0) {
+            a.tile_new[tile] = 0;  // nothing for the finalize kernel (which still flips the counter sets)
+            if (blockIdx.x == 0) atomicAdd(a.guard + 1, 1);
+        }
+        return;
+    }
     if (threadIdx.x < kTilePix) {  // once per pixel instead of once per (pixel, sample): three fp64 divisions and a sqrt each
         const int p = threadIdx.x;
         const int r = ty * kTileH + p / kTileW, c = tx * kTileW + p % kTileW;
@@ -316,7 +323,9 @@ __global__ __launch_bounds__(256) void integrate_entries_kernel(IntegrateArgs a,
     __syncthreads();
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned int n_in = 0;
-    if (r < e.R) {
+    const bool skip = guard_set(a);  // the net's range guard fired: nothing reaches the volumes
+    if (skip && r == 0) atomicAdd(a.guard + 1, 1);
+    if (r < e.R && !skip) {
         const float v = e.values[r];
         const bool sem = a.id_vol != nullptr;
         const uint8_t id_e = sem ? e.row_ids[r] : 0;
@@ -489,6 +498,7 @@ OJF_API int ojf_integrate_masked(const float *depth_filtered, const uint8_t *mas
     a.sem_ids = sem_ids; a.sem_scores = sem_scores; a.id_vol = id_vol; a.score_vol = score_vol;
     a.counters = reinterpret_cast<unsigned int *>(base);
     a.counters_next = nullptr; a.phased = 0;
+    a.guard = const_cast<int *>(range_guard_if_any());
     a.head = nullptr; a.recs = nullptr; a.touched = nullptr; a.tile_new = nullptr; a.list_base = 0; a.n_tiles = 0; a.stats = stats;
     a.X = X; a.Y = Y; a.Z = Z; a.h = h; a.w = w; a.n_points = n_points; a.n_tail = n_tail;
     a.est_stride = est_stride; a.trunc = trunc;
@@ -550,6 +560,7 @@ OJF_API int ojf_integrate_entries(const float *values, const int64_t *indices, c
     a.recs = reinterpret_cast<VoxelRec *>(base + kHeaderBytes + nvox * sizeof(unsigned int));
     a.touched = reinterpret_cast<unsigned int *>(base + kHeaderBytes + nvox * sizeof(unsigned int) + entries * sizeof(VoxelRec));
     a.stats = stats; a.tile_new = nullptr; a.list_base = 0; a.n_tiles = 0; a.counters_next = nullptr; a.phased = 0;
+    a.guard = const_cast<int *>(range_guard_if_any());
     a.X = X; a.Y = Y; a.Z = Z; a.h = 1; a.w = 1; a.n_points = 1; a.est_stride = 0; a.trunc = 0.0f;
     a.n_tail = 1;  // finalize maps entry id -> row as (id - 1) / (n_tail * 8)
     OJF_HIP(hipMemsetAsync(base, 0, kHeaderBytes, st));

@@ -69,7 +69,9 @@ __global__ __launch_bounds__(256) void parity_emit_kernel(IntegrateArgs a, Camer
     const int k = item - n * a.n_tail;
     const size_t slot0 = (size_t)item * 8;
     const float z = frame_depth(a, n);
-    const bool valid = (z != 0.0f);
+    const bool skip = guard_set(a);  // the net's range guard fired: every key becomes the sentinel, the walk finds nothing
+    if (skip && item == 0) atomicAdd(a.guard + 1, 1);
+    const bool valid = (z != 0.0f) && !skip;
     RaySample s;
     if (valid) {
         const int r = n / a.w, c = n - r * a.w;

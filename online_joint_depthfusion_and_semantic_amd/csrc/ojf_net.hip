@@ -264,7 +264,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x4 (&a
         }
     }
     if constexpr (GUARD)
-        if (gmax > 65504.0f && a.ovf) *a.ovf = 1;
+        if (gmax > 65504.0f && a.ovf) guard_raise(a.ovf, 1);
 }
 
 // The common case of the split-fp16 launches - planar output, ReLU / LeakyReLU / no activation on every stored channel,
@@ -293,7 +293,7 @@ __device__ __forceinline__ void conv_epilogue_lean(const ConvArgs &a, const f32x
             }
         }
     }
-    if (gmax > 65504.0f && a.ovf) *a.ovf = 1;
+    if (gmax > 65504.0f && a.ovf) guard_raise(a.ovf, 1);
 }
 
 static inline bool conv_lean_ok(const ConvArgs &a)
@@ -971,7 +971,7 @@ __device__ __forceinline__ void chain_layer(const f32x4 (&in)[MT][NA], f32x4 (&o
             }
         }
         if constexpr (ARITH == OJF_ARITH_F16X3)
-            if (gmax > 65504.0f && a.ovf) *a.ovf = 1;
+            if (gmax > 65504.0f && a.ovf) guard_raise(a.ovf, 1);
     }
 }
 
@@ -1288,7 +1288,7 @@ __global__ __launch_bounds__(kChainThreads, OJF_CHAIN_BLOCKS) void vortex_tail_k
         }
     }
     if constexpr (ARITH == OJF_ARITH_F16X3)
-        if (gmax > 65504.0f && a.ovf) *a.ovf = 1;
+        if (gmax > 65504.0f && a.ovf) guard_raise(a.ovf, 1);
     if constexpr (CHAIN == kTailEntry) {
         block_colsum<MT, NO>(y, p, a.npix, red, a.colsum, lane, wave);
         ca.out_planes = a.entry_out; ca.out_g0 = 0; ca.og_store = a.entry_og; ca.act_n = a.entry_act_n; ca.split_groups = a.entry_split;
@@ -1533,7 +1533,7 @@ __global__ __launch_bounds__(256) void prepare_input_kernel(const PrepArgs a)
         if (a.x1) a.x1[(size_t)cg * a.npix + p] = a.split ? split_pack4(r1) : r1;
         bad = bad || beyond_f16(r0) || beyond_f16(r1);
     }
-    if (bad && a.ovf) *a.ovf = 1;
+    if (bad && a.ovf) guard_raise(a.ovf, 1);
 }
 
 // rows <-> planes (ojf_conv2d test entry point only)
@@ -1578,19 +1578,26 @@ struct PackedConv {
 
 static int g_default_arith = OJF_ARITH_F16X3;
 
-// Range guard of the split-fp16 arithmetic: one host-mapped flag per process.  Kernels store 1 when a value that
-// a later layer would split leaves the fp16 range (or is NaN); the host polls it without synchronising
-// (ojf_net_forward) or after a stream synchronise (ojf_net_check).  No traffic unless it fires.
+// Range guard of the split-fp16 arithmetic: one flag per process, in two places.  Kernels raise it (guard_raise,
+// ojf_common.h) when a value that a later layer would split leaves the fp16 range (or is NaN): in a device-resident
+// block {flag, skipped integrate calls, pointer to the mirror} - what ojf_integrate* test before they touch a volume, so
+// that a frame whose net tripped the guard (and every frame after it, until the host has dealt with it) is NOT fused -
+// and in a host-mapped mirror, which the host polls without synchronising (ojf_net_forward) or after a stream
+// synchronise (ojf_net_check).  No traffic unless it fires.
 static volatile int *g_ovf_host = nullptr;
-static int *g_ovf_dev = nullptr;
+static int *g_ovf_dev = nullptr;  // device block: [0] flag, [1] integrate calls skipped, [2..3] device address of the mirror
 
 static int *overflow_flag()
 {
     if (!g_ovf_dev) {
-        void *h = nullptr, *d = nullptr;
+        void *h = nullptr, *hd = nullptr, *d = nullptr;
         if (hipHostMalloc(&h, sizeof(int), hipHostMallocMapped) != hipSuccess) return nullptr;
         *static_cast<int *>(h) = 0;
-        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) return nullptr;
+        if (hipHostGetDevicePointer(&hd, h, 0) != hipSuccess) return nullptr;
+        if (hipMalloc(&d, 16) != hipSuccess) return nullptr;
+        struct { int flag, skipped; void *mirror; } init{0, 0, hd};
+        static_assert(sizeof(init) == 16, "guard block layout");
+        if (hipMemcpy(d, &init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
         g_ovf_host = static_cast<volatile int *>(h);
         g_ovf_dev = static_cast<int *>(d);
     }
@@ -1598,6 +1605,26 @@ static int *overflow_flag()
 }
 
 int *range_flag_device() { return overflow_flag(); }  // shared with ojf_seg.hip
+const int *range_guard_if_any() { return g_ovf_dev; }  // ojf_integrate*.hip: NULL while no split-fp16 kernel ever got the flag
+
+// Host side of a fired guard, after the stream was synchronised: the value (0 none, 1 range, 2 dense chain stuck), how many
+// integrate calls were skipped because of it; `clear` re-arms both copies.
+static int guard_take(int *skipped, bool clear)
+{
+    if (!g_ovf_host || !*g_ovf_host) {
+        if (skipped) *skipped = 0;
+        return 0;
+    }
+    const int what = *g_ovf_host;
+    int blk[2] = {what, 0};
+    (void)hipMemcpy(blk, g_ovf_dev, sizeof(blk), hipMemcpyDeviceToHost);
+    if (skipped) *skipped = blk[1];
+    if (clear) {
+        (void)hipMemset(g_ovf_dev, 0, 2 * sizeof(int));
+        *g_ovf_host = 0;
+    }
+    return what;
+}
 
 // Launch log of a forward pass: every launch site calls mark_launch(name, stream) right after its launch.  It counts the
 // launches (ojf_net_launch_count) and, in profile mode (ojf_net_profile), records a fence-free timing event behind the
@@ -3318,11 +3345,18 @@ OJF_API int ojf_net_check(ojf_stream_t stream)
 {
     using namespace ojf;
     OJF_HIP(hipStreamSynchronize(as_stream(stream)));
-    if (g_ovf_host && *g_ovf_host) {
-        const int what = *g_ovf_host;
-        *g_ovf_host = 0;
-        return fail(what == 2 ? kChainStuckMsg : kOverflowMsg);
-    }
+    if (const int what = guard_take(nullptr, true)) return fail(what == 2 ? kChainStuckMsg : kOverflowMsg);
+    return 0;
+}
+
+OJF_API int ojf_guard_poll(void) { return ojf::g_ovf_host ? *ojf::g_ovf_host : 0; }
+
+OJF_API int ojf_guard_status(ojf_stream_t stream, int *flag, int *skipped)
+{
+    using namespace ojf;
+    OJF_HIP(hipStreamSynchronize(as_stream(stream)));
+    const int what = guard_take(skipped, false);
+    if (flag) *flag = what;
     return 0;
 }
 
@@ -3353,10 +3387,7 @@ OJF_API int ojf_conv2d(const float *in, int in_stride, int in_off, float *out, i
         hipLaunchKernelGGL(planes_to_rows_kernel, dim3((npix * (cout_phys / 4) + 255) / 256), dim3(256), 0, st,
                            planes(pout), cout_phys / 4, npix, out, out_stride, out_off);
         rc = check_hip(hipStreamSynchronize(st), "ojf_conv2d sync");  // test-only API: packs per call
-        if (!rc && g_ovf_host && *g_ovf_host) {
-            *g_ovf_host = 0;
-            rc = fail(kOverflowMsg);
-        }
+        if (!rc && guard_take(nullptr, true)) rc = fail(kOverflowMsg);
     }
     free_planes(pin);
     free_planes(pout);

@@ -439,7 +439,7 @@ __global__ __launch_bounds__(64 * kBranchWaves, kBranchWaves / 4) void vortex_br
     i = branch_run<BranchK0>(a, i, iend, cur4, nxt4, wbr, wl, xl, tl, vl, xb, gmax, ors);
     i = branch_run<BranchK1>(a, i, iend, cur4, nxt4, wbr, wl, xl, tl, vl, xb, gmax, ors);
     i = branch_run<BranchK2>(a, i, iend, cur4, nxt4, wbr, wl, xl, tl, vl, xb, gmax, ors);
-    if (gmax > 65504.0f && a.ovf) *a.ovf = 1;
+    if (gmax > 65504.0f && a.ovf) guard_raise(a.ovf, 1);
 }
 
 
@@ -566,7 +566,7 @@ __device__ __forceinline__ void subconv_body(const SubArgs &a, const int4 &it4, 
         put_o(g, main, rm, bm);
         if (g == 0) put_o(4, extra, re, be);
     }
-    if (gmax > 65504.0f && a.ovf) *a.ovf = 1;
+    if (gmax > 65504.0f && a.ovf) guard_raise(a.ovf, 1);
 }
 
 __global__ __launch_bounds__(256, 4) void subconv_kernel(const SubArgs a)

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dense_chain_kernel(cons
             if (spins > (1 << 20)) {  // (cannot happen by construction; a launch must end all the same: the host reports the flag)
                 if (lane == 0) {
                     a.sync[2] = 1;
-                    if (a.ovf) *a.ovf = 2;  // (reported by ojf_net_forward / ojf_net_check)
+                    if (a.ovf) guard_raise(a.ovf, 2);  // (reported by ojf_net_forward / ojf_net_check)
                 }
                 break;
             }
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void dense_chain_kernel(cons
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (pub_tile >= 0 && tid == 0) __hip_atomic_store(flags + pub_tile, pub_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (gmax > 65504.0f && a.ovf) *a.ovf = 1;
+    if (gmax > 65504.0f && a.ovf) guard_raise(a.ovf, 1);
     if (tid == 0) {  // the block that finishes last re-arms tickets and flags for the next launch (every block has drawn its last ticket)
         const int done = __hip_atomic_fetch_add(a.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (done == (int)gridDim.x - 1) {

@@ -411,7 +411,7 @@ void dense_pair_kernel(const PairArgs a)
             }
         }
     }
-    if (gmax > 65504.0f && a.ovf) *a.ovf = 1;
+    if (gmax > 65504.0f && a.ovf) guard_raise(a.ovf, 1);
     OJF_STAMP();  // stores issued
 #undef OJF_STAMP
 }

@@ -387,13 +387,15 @@ __global__ __launch_bounds__(256) void train_bn_bwd_apply_kernel(const BnGroup g
         __shared__ float bw[4];
         const int n_units = grp.share_scale ? (int)gridDim.z : 1, per = 4 * a.c4;
         float b = 0.0f;
-        if ((int)threadIdx.x < n_units * per) {
-            const int u = threadIdx.x / per, c = threadIdx.x - u * per;
+        // (strided: a wide net - ojf_trainer_create takes widths up to 1024 - has more bound words than the block has threads)
+        for (int i = threadIdx.x; i < n_units * per; i += blockDim.x) {
+            const int u = i / per, c = i - u * per;
             const BnActArgs &o = grp.g[grp.share_scale ? u : (int)blockIdx.z];
             if (c < o.C) {
                 const float A = __uint_as_float(o.bnd[c]), X = __uint_as_float(o.bnd[o.bnd_stride + c]);
-                b = (o.has_bn && o.training) ? A * (2.0f + X * X) : A;
-                if (b != b) b = 3.4e38f;  // (inf * 0)
+                float bi = (o.has_bn && o.training) ? A * (2.0f + X * X) : A;
+                if (bi != bi) bi = 3.4e38f;  // (inf * 0)
+                b = fmaxf(b, bi);
             }
         }
         for (int off = 32; off > 0; off >>= 1) b = fmaxf(b, __shfl_xor(b, off, 64));
@@ -562,7 +564,7 @@ __global__ __launch_bounds__(64) void train_wgrad_mfma_kernel(const WgradGroup g
         }
     }
     if constexpr (F16)
-        if (a.ovf && gmax > 65504.0f) *a.ovf = 1;
+        if (a.ovf && gmax > 65504.0f) guard_raise(a.ovf, 1);
     // D layout: acc[v] = D[i][j], j = lane % 32 (ic), i = 8 * (v / 4) + 4 * (lane / 32) + v % 4 (oc)
     float *dst = a.partial + (((size_t)blockIdx.x * a.taps + tap) * a.ocp + (size_t)ot * 32) * a.icp + (size_t)it * 32 + r;
 #pragma unroll

@@ -20,6 +20,7 @@
 // (concatenations) are addressed by pointer + row stride.  Transposed convolutions: see ojf_segdeconv_create.
 // Tuning-only environment switches: OJF_SEG_MW, OJF_SEG_NO_WIDE, OJF_SEG_WIDE_MIN.
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -82,7 +83,37 @@ struct SegArgs {
 // launch, blockIdx.z = member: the two modality encoders of AdapNet++ in lock-step, the two dilations of a multi-scale
 // unit, the three cascades of an eASPP - half the graph nodes of the front end and no cross-stream fork / join.
 constexpr int kSegGroup = 8;
-struct SegGroupArgs { SegArgs a[kSegGroup]; };
+// Block -> (pixel block x, channel block y, member z) of a launch with the logical grid X x Y x Z, launched as a 1-D grid.
+// Block b runs on XCD b % 8 (ojf_common.h) and every XCD has its own L2: with the plain (x, y, z) numbering the 19 pixel
+// blocks of a channel block on a 15x20 map land on all eight XCDs and every XCD pulls every weight through the fabric -
+// measured (round 5, rocprofv3 FETCH_SIZE per launch): 190 MB fetched by a layer4 shortcut whose weights are 17 MB, and
+// its 37 us are those bytes at ~5 TB/s.  Here a (channel block, member) pair - the unit that shares weights - lives on
+// ONE XCD: pair q = y + Y z goes to XCD q % 8 with all its pixel blocks.  Few pairs (Q = Y Z not a multiple of 8): the
+// pixel blocks of a pair are cut into S contiguous chunks ("virtual pairs" v = q S + s, V = Q S a multiple of 8 where S
+// <= 8 allows) so that all XCDs work.  Padding blocks (v >= V or x >= X) exit.  Speed only: any placement computes the same.
+struct SegMap { int X, Y, Z, S, chunk, V; };
+struct SegGroupArgs { SegArgs a[kSegGroup]; SegMap map; };
+
+__device__ __forceinline__ bool seg_block(const SegMap &m, int &bx, int &by, int &bz)
+{
+    if (m.S == 0) {  // plain numbering (OJF_SEG_XCD=0: A/B switch)
+        const int b = (int)blockIdx.x;
+        bx = b % m.X;
+        const int q = b / m.X;
+        by = q % m.Y;
+        bz = q / m.Y;
+        return true;
+    }
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    const int vl = slot / m.chunk, xl = slot - vl * m.chunk;
+    const int v = vl * 8 + xcd;
+    if (v >= m.V) return false;
+    const int q = v / m.S, sp = v - q * m.S;
+    bx = sp * m.chunk + xl;
+    by = q % m.Y;
+    bz = q / m.Y;
+    return bx < m.X;
+}
 
 
 // KS = 1: the 4 waves of a block take different (channel group, pixel tiles) pairs: WM along the channels.
@@ -169,19 +200,21 @@ __device__ __forceinline__ void seg_epilogue(const SegArgs &a, const f32x4 (&acc
             }
         }
     }
-    if (a.ovf && gmax > 65504.0f) *a.ovf = 1;  // a later layer would split this value: outside the fp16 range
+    if (a.ovf && gmax > 65504.0f) guard_raise(a.ovf, 1);  // a later layer would split this value: outside the fp16 range
 }
 
 // kDepth = K blocks in flight per wave (a cold weight fetch costs ~1 us, the MFMAs of a block ~0.1 us).
 template <int MW, int NW, int WM, int KS, int kDepth>
 __global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void segconv_kernel(const SegGroupArgs grp)
 {
-    const SegArgs &a = grp.a[blockIdx.z];
+    int bx, by, bz;
+    if (!seg_block(grp.map, bx, by, bz)) return;  // block-uniform
+    const SegArgs &a = grp.a[bz];
     constexpr bool SPLITK = KS > 1;  // KS waves of a block split K
     constexpr int WN = SPLITK ? 1 : 4 / WM;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ct0 = SPLITK ? (int)blockIdx.y * MW : ((int)blockIdx.y * WM + wave % WM) * MW;
-    const int pt0 = SPLITK ? (int)blockIdx.x * NW : ((int)blockIdx.x * WN + wave / WM) * NW;
+    const int ct0 = SPLITK ? by * MW : (by * WM + wave % WM) * MW;
+    const int pt0 = SPLITK ? bx * NW : (bx * WN + wave / WM) * NW;
     const int n_pix = a.Ho * a.Wo;
     if (!SPLITK && (ct0 >= a.n_ct || pt0 * 16 >= n_pix)) return;  // wave-uniform (n_ct is a multiple of 4 >= MW)
     const int col = lane & 15, kg = lane >> 4;
@@ -305,12 +338,14 @@ __global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void segconv_kernel(const S
 template <int NW>
 __global__ __launch_bounds__(256) void segconv_wide_kernel(const SegGroupArgs grp)
 {
-    const SegArgs &a = grp.a[blockIdx.z];
+    int bx, by, bz;
+    if (!seg_block(grp.map, bx, by, bz)) return;  // block-uniform
+    const SegArgs &a = grp.a[bz];
     constexpr int MW = 4, D = 3;
     __shared__ f32x4 wtile[D][MW * 2 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ct0 = (int)blockIdx.y * MW;
-    const int pt0 = ((int)blockIdx.x * 4 + wave) * NW;
+    const int ct0 = by * MW;
+    const int pt0 = (bx * 4 + wave) * NW;
     const int n_pix = a.Ho * a.Wo;
     const int col = lane & 15, kg = lane >> 4;
     const int n_kb = a.n_kb;
@@ -548,23 +583,46 @@ int seg_fill(const ojf_segconv *c, const float *in, int in_stride, float *out, i
     return 0;
 }
 
+// 1-D launch geometry of the logical grid X x Y x Z (see SegMap)
+unsigned seg_map(SegMap &m, int X, int Y, int Z)
+{
+    static const int xcd = getenv("OJF_SEG_XCD") ? atoi(getenv("OJF_SEG_XCD")) : 1;  // A/B switch (0: plain numbering)
+    m.X = X; m.Y = Y; m.Z = Z;
+    if (!xcd) {
+        m.S = 0; m.chunk = X; m.V = Y * Z;
+        return (unsigned)(X * Y * Z);
+    }
+    const int Q = Y * Z;
+    int S = 1;
+    while (S < 8 && (Q * S) % 8 != 0 && (X + 2 * S - 1) / (2 * S) >= 2) S *= 2;  // chunks of >= 2 pixel blocks
+    m.S = S; m.chunk = (X + S - 1) / S; m.V = Q * S;
+    return (unsigned)((m.V + 7) / 8 * 8 * m.chunk);
+}
+
 // n members of one shape (the first one's n_kb / n_ct / output size decide the launch)
-int seg_launch(const SegGroupArgs &g, int n, hipStream_t st)
+int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
 {
     const SegArgs &a = g.a[0];
     const int n_pt = (a.Ho * a.Wo + 15) / 16, groups = a.n_ct / kMW;  // pixel tiles, 64-channel groups
-    const unsigned z = (unsigned)n;
     // Enough independent waves (>= 4 per CU) to hide the operand latency: waves own their (channels, pixels) pair.
     // Otherwise the four waves of a block split K (when K is long enough to be worth the LDS reduction).
     const long waves2 = (long)groups * ((n_pt + 1) / 2) * n;
     static const int force_mw = getenv("OJF_SEG_MW") ? atoi(getenv("OJF_SEG_MW")) : 0;  // tuning only
     static const int no_wide = getenv("OJF_SEG_NO_WIDE") ? atoi(getenv("OJF_SEG_NO_WIDE")) : 0;  // tuning only
     static const int wide_min = getenv("OJF_SEG_WIDE_MIN") ? atoi(getenv("OJF_SEG_WIDE_MIN")) : 256;  // tuning only
+    static const int trace = getenv("OJF_SEG_TRACE") ? atoi(getenv("OJF_SEG_TRACE")) : 0;  // tuning only: one line per launch
+    const char *variant;
     if (!no_wide && a.n_kb >= 6 && (long)groups * ((n_pt + 7) / 8) * n >= wide_min) {
-        hipLaunchKernelGGL((segconv_wide_kernel<2>), dim3((n_pt + 7) / 8, groups, z), dim3(256), 0, st, g);
+        variant = "wide<2>";
+        hipLaunchKernelGGL((segconv_wide_kernel<2>), dim3(seg_map(g.map, (n_pt + 7) / 8, groups, n)), dim3(256), 0, st, g);
     } else if (waves2 >= 1024 || a.n_kb < 8) {
-        if (groups == 1) hipLaunchKernelGGL((segconv_kernel<4, 2, 1, 1, 3>), dim3((n_pt + 7) / 8, 1, z), dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((segconv_kernel<4, 2, 2, 1, 3>), dim3((n_pt + 3) / 4, (groups + 1) / 2, z), dim3(256), 0, st, g);
+        if (groups == 1) {
+            variant = "<4,2,1,1>";
+            hipLaunchKernelGGL((segconv_kernel<4, 2, 1, 1, 3>), dim3(seg_map(g.map, (n_pt + 7) / 8, 1, n)), dim3(256), 0, st, g);
+        } else {
+            variant = "<4,2,2,1>";
+            hipLaunchKernelGGL((segconv_kernel<4, 2, 2, 1, 3>), dim3(seg_map(g.map, (n_pt + 3) / 4, (groups + 1) / 2, n)), dim3(256), 0, st, g);
+        }
     } else {
         // few pixels: the 4 waves of a block split K.  Channel tiles per block: as many as leave >= 150 blocks (measured
         // per layer shape on the 15x20 / 30x40 maps: one CU cannot pull a block's operands faster than ~150 GB/s, so
@@ -573,10 +631,21 @@ int seg_launch(const SegGroupArgs &g, int n, hipStream_t st)
         int mw = 4;
         while (mw > 1 && (long)n_pt * (a.n_ct / mw) * n < 150) mw /= 2;
         if (force_mw) mw = force_mw;
-        if (mw == 1) hipLaunchKernelGGL((segconv_kernel<1, 1, 1, 4, 3>), dim3(n_pt, a.n_ct, z), dim3(256), 0, st, g);
-        else if (mw == 2) hipLaunchKernelGGL((segconv_kernel<2, 1, 1, 4, 3>), dim3(n_pt, a.n_ct / 2, z), dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((segconv_kernel<4, 1, 1, 4, 3>), dim3(n_pt, groups, z), dim3(256), 0, st, g);
+        if (mw == 1) {
+            variant = "<1,1,1,4>";
+            hipLaunchKernelGGL((segconv_kernel<1, 1, 1, 4, 3>), dim3(seg_map(g.map, n_pt, a.n_ct, n)), dim3(256), 0, st, g);
+        } else if (mw == 2) {
+            variant = "<2,1,1,4>";
+            hipLaunchKernelGGL((segconv_kernel<2, 1, 1, 4, 3>), dim3(seg_map(g.map, n_pt, a.n_ct / 2, n)), dim3(256), 0, st, g);
+        } else {
+            variant = "<4,1,1,4>";
+            hipLaunchKernelGGL((segconv_kernel<4, 1, 1, 4, 3>), dim3(seg_map(g.map, n_pt, groups, n)), dim3(256), 0, st, g);
+        }
     }
+    if (trace)
+        fprintf(stderr, "segconv %-10s n %d  c_in %4d c_out %4d k %d s %d d %2d  in %3dx%3d out %3dx%3d  n_kb %4d  grid %dx%dx%d S %d%s%s%s\n", variant, n,
+                a.c8 * 8, a.c_out, a.ksize, a.stride, a.dil, a.H, a.W, a.Ho, a.Wo, a.n_kb, g.map.X, g.map.Y, g.map.Z, g.map.S,
+                a.res ? " +res" : "", a.mul ? " *mul" : "", a.up > 1 ? " deconv" : "");
     return check_hip(hipGetLastError(), "segconv_kernel launch");
 }
 

@@ -1338,10 +1338,10 @@ OJF_API int ojf_trainer_forward(ojf_trainer *t, const ojf_train_layer *layers, i
     if (!t || !layers || !values || !weights || !frame || !est) return fail("ojf_trainer_forward: null pointer argument");
     if (n_layers != t->n_layers) return fail("ojf_trainer_forward: wrong number of layers");
     if (t->sem && !semantic_frame) return fail("ojf_trainer_forward: the net has a semantic channel but semantic_frame is NULL");
-    if (t->fwd_arith == OJF_ARITH_F16X3 && g_ovf_host && *g_ovf_host) {
-        *g_ovf_host = 0;  // reported once: the caller may switch the arithmetic and go on
-        return fail(kOverflowMsg);
-    }
+    // (polled without synchronising and NOT cleared here: the flag is shared with the inference nets and the 2-D engine,
+    // whose frames since the event must stay unfused until ojf_net_check has reported it - the caller clears it there
+    // and may then switch the arithmetic and go on)
+    if (t->fwd_arith == OJF_ARITH_F16X3 && g_ovf_host && *g_ovf_host) return fail(*g_ovf_host == 2 ? kChainStuckMsg : kOverflowMsg);
     TCtx c{t, layers, as_stream(stream)};
     t->launches = 0;
     if (t->epoch != weights_epoch) {

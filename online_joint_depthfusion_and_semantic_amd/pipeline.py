@@ -113,6 +113,8 @@ class Pipeline(torch.nn.Module):
         """Synchronise and raise OjfError if the split-fp16 range guard fired since the last check (the frames
         fused in between are invalid then; set FUSION_MODEL.arithmetic = 'f32').  Cheap: call per scene / epoch."""
         if self._engine is not None:
+            if self._guard_policy() == 'f32':
+                self._guard_recover()  # (a tripped frame at the end of a scene: nothing after it polled the flag)
             self._engine.check()
         elif self.__dict__.get('_hip_train') is not None:  # training only: the executor's forward pass shares the guard
             from . import _lib
@@ -284,9 +286,82 @@ class Pipeline(torch.nn.Module):
         filtered = torch.where(mask, frame, zero)  # pipeline.py:196; one launch (a python scalar costs a fill kernel)
         return frame[0], filtered[0]
 
-    # ---- inference frame step (pipeline.py:173-248) ---------------------------------------------
+    # ---- range guard of the split-fp16 net: no frame of a tripped net reaches a volume --------------
+    # (include/ojf.h ojf_net_check: while the flag is set the integrate calls skip, so nothing is corrupted; what is left
+    # to decide is what happens to the skipped frames.)  FUSION_MODEL.guard_policy:
+    #   'raise' (default)  the next fuse() / check() raises OjfError; the volumes hold every frame in front of the event
+    #                      and nothing after it;
+    #   'f32'              the pipeline switches this network to the fp32-input MFMA arithmetic for good (a warning says
+    #                      so) and fuses the skipped frames again, in order: the stream comes out as if the net had run in
+    #                      fp32 from the event on.  The batches of the last <= 48 frames stay alive for that (an event
+    #                      every 16 frames bounds how far the host may run ahead of the device).
+    _GUARD_EVERY, _GUARD_KEEP = 16, 48
+
+    def _guard_policy(self):
+        if self.config.FUSION_MODEL.get('arithmetic', 'f16x3') != 'f16x3':
+            return 'raise'
+        return self.config.FUSION_MODEL.get('guard_policy', 'raise')
+
+    def _guard_remember(self, batch, database):
+        ring = self.__dict__.setdefault('_guard_ring', [])
+        marks = self.__dict__.setdefault('_guard_marks', [])
+        ring.append((batch, database))
+        if len(ring) % self._GUARD_EVERY == 0:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            marks.append([len(ring), ev])
+        if len(ring) > self._GUARD_KEEP:
+            upto, ev = marks.pop(0)
+            ev.synchronize()  # (long done unless the host is > 32 frames ahead of the device)
+            if not _lib.load().ojf_guard_poll():  # the frames in front of that event were fused with the guard silent
+                del ring[:upto]
+                for m in marks:
+                    m[0] -= upto
+
+    def _guard_recover(self, err=None):
+        """guard_policy 'f32': if the guard fired - report + clear the event, switch the arithmetic, fuse the skipped frames
+        again.  Synchronises.  Returns True when it did."""
+        import ctypes
+        import warnings
+        lib = _lib.load()
+        flag, skipped = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(lib.ojf_guard_status(_lib.stream_ptr(self.device), ctypes.byref(flag), ctypes.byref(skipped)), 'ojf_guard_status')
+        if flag.value != 1:  # nothing pending, or an internal error: not this policy's to absorb
+            if err is not None:
+                raise err
+            return False
+        lib.ojf_net_check(_lib.stream_ptr(self.device))  # (reports what `flag` said and clears it)
+        ring = self.__dict__.get('_guard_ring', [])
+        n = skipped.value
+        if n > len(ring):
+            raise _lib.OjfError('range guard: %d frames were skipped but only %d are remembered' % (n, len(ring)))
+        redo = ring[len(ring) - n:] if n else []
+        self.__dict__['_guard_ring'], self.__dict__['_guard_marks'] = [], []
+        self.config.FUSION_MODEL.arithmetic = 'f32'
+        self.guard_events = self.__dict__.get('guard_events', 0) + 1
+        warnings.warn('split-fp16 range guard fired: FUSION_MODEL.arithmetic switched to f32 for this network, '
+                      '%d skipped frame(s) fused again' % n, RuntimeWarning)
+        for b, db in redo:
+            self._fuse_frame(b, db)
+        return True
+
     def fuse(self, batch, database, device):
         self.device = torch.device(device)
+        if self._guard_policy() != 'f32':
+            return self._fuse_frame(batch, database)
+        try:
+            self._fuse_frame(batch, database)
+        except _lib.OjfError as err:
+            if 'fp16 range' not in str(err):
+                raise
+            # raised by the forward call's poll BEFORE this frame's net / integrate were enqueued: the frame is not among the
+            # skipped ones, it follows them
+            self._guard_recover(err)
+            self._fuse_frame(batch, database)
+            return
+        self._guard_remember(batch, database)
+
+    def _fuse_frame(self, batch, database):
         self._shape = batch['image'].shape
         seg0 = self._mark_segmentation()
         sem_ids, scores = self._frame_semantics(batch)

@@ -282,3 +282,82 @@ def test_engine_follows_replaced_parameters(cuda):
             p.data = p.data.clone() * 1.0001
         pipe.fuse(_batch(st, 2, cuda), db, cuda)
         assert pipe._engine is not second
+
+
+# ---- the range guard protects the scene -------------------------------------------------------------
+def _tripping_pipeline(cuda, h, w, grid, policy, sem=False):
+    """A pipeline whose net leaves the fp16 range: first convolution scaled by 1e9 (eval-mode BN with fresh running
+    statistics does not normalise it away)."""
+    cfg, st, db, pipe = _setup(h, w, grid, sem, False, 'fast', cuda)
+    cfg.FUSION_MODEL.guard_policy = policy
+    torch.manual_seed(5)
+    for m in pipe._fusion_network.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            torch.nn.init.xavier_normal_(m.weight)
+    with torch.no_grad():
+        pipe._fusion_network.block0[0].block[0].weight.mul_(1e9)
+    return cfg, st, db, pipe
+
+
+def _volumes(db, s):
+    return [db.scenes_est[s].volume.clone(), db.fusion_weights[s].clone()]
+
+
+@pytest.mark.parametrize('mode', ['fast', 'parity'])
+def test_range_guard_leaves_the_volumes_untouched(cuda, mode):
+    """A frame whose net trips the split-fp16 range guard must not be fused - nor any frame after it until the host has
+    reported the event: volumes bit-identical to the pre-frame state, Pipeline.check() raises, and after the check the
+    same scene fuses normally again with arithmetic f32."""
+    from online_joint_depthfusion_and_semantic_amd import _lib
+    h, w, grid = 48, 64, 64
+    cfg, st, db, pipe = _tripping_pipeline(cuda, h, w, grid, 'raise')
+    pipe._integrate_mode = _lib.MODE_PARITY if mode == 'parity' else _lib.MODE_FAST
+    s = st.scene
+    good = Pipeline(default_config(h, w, semantics=False, use_semantics=False, integrate_mode=mode)).to(cuda).eval()
+    with torch.no_grad():
+        good.fuse(_batch(st, 0, cuda), db, cuda)  # a healthy frame first: the pre-frame state is not the empty volume
+        good.check()
+        before = _volumes(db, s)
+        assert float((before[1].float() > 0).sum()) > 1000
+        fused = 0
+        for i in range(1, 4):
+            try:
+                pipe.fuse(_batch(st, i, cuda), db, cuda)
+                fused += 1
+            except _lib.OjfError:  # (a later frame's forward may already see the flag: equally fine)
+                break
+        torch.cuda.synchronize()
+        for a, b in zip(before, _volumes(db, s)):
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+        with pytest.raises(_lib.OjfError, match='fp16 range'):
+            pipe.check()
+        pipe.check()  # cleared
+        # the scene is alive: the same (un-normalised) net fuses on the fp32-input path
+        cfg.FUSION_MODEL.arithmetic = 'f32'
+        pipe.fuse(_batch(st, 1, cuda), db, cuda)
+        pipe.check()
+        after = _volumes(db, s)
+        assert not torch.equal(before[1].view(torch.int16), after[1].view(torch.int16))
+
+
+def test_range_guard_policy_f32_refuses_nothing_and_loses_nothing(cuda):
+    """FUSION_MODEL.guard_policy = 'f32': the tripped frames are fused again on the fp32-input path, in order - the volumes
+    equal those of a pipeline that ran arithmetic f32 from the first frame, bit for bit."""
+    h, w, grid = 48, 64, 64
+    n_frames = 6
+    cfg, st, db, pipe = _tripping_pipeline(cuda, h, w, grid, 'f32')
+    cfg2, st2, db2, ref = _tripping_pipeline(cuda, h, w, grid, 'raise')
+    cfg2.FUSION_MODEL.arithmetic = 'f32'
+    ref._fusion_network.load_state_dict(pipe._fusion_network.state_dict())
+    with torch.no_grad(), pytest.warns(RuntimeWarning, match='switched to f32'):
+        for i in range(n_frames):
+            pipe.fuse(_batch(st, i, cuda), db, cuda)
+        pipe.check()
+    with torch.no_grad():
+        for i in range(n_frames):
+            ref.fuse(_batch(st2, i, cuda), db2, cuda)
+        ref.check()
+    assert pipe.guard_events == 1 and cfg.FUSION_MODEL.arithmetic == 'f32'
+    for a, b in zip(_volumes(db, st.scene), _volumes(db2, st2.scene)):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    assert float((db.fusion_weights[st.scene].float() > 0).sum()) > 1000

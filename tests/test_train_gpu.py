@@ -100,8 +100,8 @@ def test_layer_unit_against_torch(cuda, IC, OC, k, dil, group, slot, act, bn, tr
         assert int(bnm.num_batches_tracked) == (1 if training else 0)
 
 
-def _net(version, sem, h, w, seed=3):
-    cfg = type('C', (), dict(n_points=9, growth_factor=6, use_semantics=sem, output_scale=0.9, resx=w, resy=h))()
+def _net(version, sem, h, w, seed=3, n_points=9):
+    cfg = type('C', (), dict(n_points=n_points, growth_factor=6, use_semantics=sem, output_scale=0.9, resx=w, resy=h))()
     torch.manual_seed(seed)
     net = getattr(model, 'FusionNet_' + version)(cfg)
     for m in net.modules():
@@ -526,3 +526,37 @@ def test_weights_edited_through_data_need_invalidate(cuda):
         tn.invalidate()                              # ... without this
         e2 = tn(x).clone()
     assert float((e2 - e0).abs().max()) <= 1e-6
+
+
+def test_wide_net_dy_factor_sees_every_channel(cuda):
+    """the BatchNorm-backward apply kernel derives the same-pass dy factor from the bound words of ALL
+    channels of its scale group.  It used to look at the first 256 only; n_points = 23 gives 47-channel slots and a 282-channel
+    VortexPooling output, and the channels past 256 carry the largest gradients here (their BatchNorm gamma is 1e4 times the
+    others'): with the factor taken from the first 256 channels their dy left the fp16 range in the split-fp16 passes (inf
+    halves, NaN gradients).  Passes 2 and 3 (split-fp16 backward) must reproduce pass 1 (fp32 backward)."""
+    h, w, P = 24, 40, 23
+    net = _net('v3', False, h, w, n_points=P).to(cuda).train(True)
+    with torch.no_grad():
+        for vp in (net.vortex0, net.vortex3):
+            vp.final[1].weight[256:] *= 1e4
+    g = torch.Generator().manual_seed(29)
+    x = dict(tsdf_values=((torch.rand(1, P, h, w, generator=g) - 0.5) * 0.2).to(cuda), tsdf_weights=(torch.rand(1, P, h, w, generator=g) * 4).to(cuda),
+             tsdf_frame=(torch.rand(1, 1, h, w, generator=g) * 4).to(cuda))
+    target = ((torch.rand(1, P, h, w, generator=g) - 0.5) * 0.2).to(cuda)
+    params = [p for p in net.parameters()]
+    bufs = [b.clone() for b in net.buffers()]
+    tn = HipTrainNet(net)
+    passes = []
+    for _ in range(3):
+        for b, saved in zip(net.buffers(), bufs):
+            b.copy_(saved)
+        e = tn(x)
+        loss = (e - target).abs().mean() + 10 * ((e - target) ** 2).mean()
+        passes.append(torch.autograd.grad(loss, params, allow_unused=True))
+    gmax = max(float(a.abs().max()) for a in passes[0] if a is not None)
+    for k in (1, 2):
+        for (name, _), p0, pk in zip(net.named_parameters(), passes[0], passes[k]):
+            if p0 is None:
+                continue
+            assert torch.isfinite(pk).all(), (k, name)
+            assert float((p0 - pk).abs().max()) <= 2e-3 * max(float(p0.abs().max()), 1e-3 * gmax), (k, name)
