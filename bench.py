@@ -101,6 +101,9 @@ def workload_name(c):
         base, c['w'], c['h'], c['grid'], sem if sem else ', geometry-only', c['mode'], c['arith'])
 
 
+CPU_WARMUP = 2  # untimed frames in front of the CPU baseline's sample (>= 10 frames after 2 warm-up)
+
+
 def cpu_baseline(args, h, w, grid, semantics):
     """Times oracle/torch_port.fuse (the reference's op sequence on torch-CPU) on a bounded sample, on a stated number
     of threads: min(16, cores) - with all 128 host threads the oneDNN / ATen calls of this size oversubscribe and run
@@ -122,17 +125,17 @@ def cpu_baseline(args, h, w, grid, semantics):
         origin = torch.from_numpy(st.origin)
         times = []
         with torch.no_grad():
-            for i in range(args.cpu_frames + 1):
+            for i in range(args.cpu_frames + CPU_WARMUP):
                 b = st.batch(i)
                 t0 = time.perf_counter()
                 torch_port.fuse(b, vols, net, origin, st.resolution, semantics=semantics)
                 times.append(time.perf_counter() - t0)
     finally:
         torch.set_num_threads(before)
-    t = float(np.mean(times[1:]))
+    t = float(np.mean(times[CPU_WARMUP:]))
     return {'value': 1.0 / t, 'unit': 'frames/sec', 'cores': threads, 'host_cores': nproc, 'torch_threads_default': before,
             'kind': 'port',
-            'sample': '%d frames of the %dx%d -> %d^3 workload after 1 warm-up frame, torch-CPU op-for-op port of the reference '
+            'sample': '%d frames of the %dx%d -> %d^3 workload after 2 warm-up frames (SURVEY.md 8d), torch-CPU op-for-op port of the reference '
                       '(oracle/torch_port.py) on %d threads (torch.set_num_threads; %d host cores), %.2f s/frame'
                       % (args.cpu_frames, w, h, grid, threads, nproc, t)}
 
@@ -144,11 +147,11 @@ def pmc_traffic(c):
     import glob
     found = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_*traffic_pmc.json')))
     if not found:
-        return None, None
+        return None, 'no profiles/rNN_*traffic_pmc.json in this tree (tools/pmc_profile.sh writes one)'
     path = found[-1]  # the latest round's passes
     name = os.path.basename(path)
     if (c['h'], c['w'], c['grid'], c['semantics'], c['arith']) != (240, 320, 256, False, 'f16x3'):
-        return None, None
+        return None, 'the committed counter passes (profiles/%s) were taken on BASELINE configs[1] with the f16x3 arithmetic, not on this workload' % name
     with open(path) as f:
         return json.load(f), 'profiles/' + name
 
@@ -319,7 +322,7 @@ def segmentation_report(case, seg_ms, c):
     out = {'ms_per_frame': seg_ms, 'engine': c['seg_engine']}
     try:
         gf = adapnet_gflop(case.pipe._semantic_2d_network, c['h'], c['w'])
-        out.update(gflop=gf, tflops=gf / seg_ms, frac_of_mfma_peak=gf / seg_ms / ARITH['f16x3'][2],
+        out.update(gflop=gf, tflops=gf / seg_ms, frac_of_mfma_peak=gf / seg_ms / ARITH['f16x3'][2], frac_of_raw_fp16_peak=gf / seg_ms / F16_MFMA_PEAK_TF,
                    note='useful flops of the convolutions feeding output[0] / segmentation stage time; peak = split-fp16 (838.9 TFLOP/s)')
     except Exception as e:  # a reporting extra must not fail the leg
         out['gflop_error'] = repr(e)
@@ -380,15 +383,17 @@ def report(case, res, steps, warmup, world, args_cpu_frames=0, full=True):
         out['roofline'] = {'bound': 'mfma', 'kernel': dom['kernel'], 'launches_per_frame': dom['launches_per_frame'],
                            'avg_launch_us': per_launch_us, 'flops_per_launch': dom['gflop'] * 1e9 / dom['launches_per_frame'],
                            'achieved': dom['tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': dom['tflops'] / peak,
-                           'traffic': dom_traffic, 'traffic_source': ('replayed from ' + tr_src) if dom_traffic is not None else None,
+                           'frac_of_raw_fp16_peak': dom['tflops'] / F16_MFMA_PEAK_TF,
+                           'traffic': dom_traffic, 'traffic_source': ('replayed from ' + tr_src) if dom_traffic is not None else ('none: ' + str(tr_src)),
                            'note': 'the net kernel with the largest share of the frame (kernels[] lists all): algorithmic '
                                    '(fp32-equivalent, padding excluded) flops per launch / its launch duration from HIP events behind '
                                    'every launch on the launch stream (ojf_net_profile); peak = dense MFMA peak of the arithmetic '
                                    '(f16x3: 2516.6/3 TFLOP/s because every product block costs three fp16 MFMAs; f32: 157.3)'}
     out['roofline_net'] = {'bound': 'mfma', 'kernel': 'all MFMA launches of the frame', 'achieved': flops / net_s / 1e12, 'peak': peak,
                            'unit': 'TFLOP/s', 'frac': flops / net_s / 1e12 / peak, 'flops_per_frame': flops,
-                           'frac_of_f32_mfma_peak': flops / net_s / 1e12 / F32_MFMA_PEAK_TF, 'traffic': net_traffic,
-                           'traffic_source': ('replayed from ' + tr_src) if net_traffic is not None else None,
+                           'frac_of_f32_mfma_peak': flops / net_s / 1e12 / F32_MFMA_PEAK_TF,
+                           'frac_of_raw_fp16_peak': flops / net_s / 1e12 / F16_MFMA_PEAK_TF, 'traffic': net_traffic,
+                           'traffic_source': ('replayed from ' + tr_src) if net_traffic is not None else ('none: ' + str(tr_src)),
                            'note': 'useful flops of the whole net / HIP-event time of the net stage inside the timed region'}
     n_b = len(case.batches)
     sample = [(warmup + k * max(1, steps // 4)) % n_b for k in range(4)]
@@ -397,7 +402,7 @@ def report(case, res, steps, warmup, world, args_cpu_frames=0, full=True):
     out['roofline_hbm'] = {'bound': 'hbm', 'kernel': 'extract_tile_kernel + integrate_*_kernel',
                            'achieved': bytes_frame / ei_s / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                            'frac': bytes_frame / ei_s / 1e9 / HBM_PEAK_GBS, 'traffic': hbm_traffic,
-                           'traffic_source': ('replayed from ' + tr_src) if hbm_traffic is not None else None,
+                           'traffic_source': ('replayed from ' + tr_src) if hbm_traffic is not None else ('none: ' + str(tr_src)),
                            'bytes_per_frame': bytes_frame, 'unique_gather_voxels': ug, 'unique_scatter_voxels': us}
     return out
 
@@ -536,7 +541,7 @@ def main():
                     help="AdapNet++ convolutions: 'hip' = SEGCONV MFMA kernels (default), 'torch' = module forward on MIOpen")
     ap.add_argument('--mode', default='fast', choices=['fast', 'parity'])
     ap.add_argument('--arith', default='f16x3', choices=['f16x3', 'f32'], help='net MFMA arithmetic (include/ojf.h OJF_ARITH_*)')
-    ap.add_argument('--cpu-frames', type=int, default=4, help='timed frames of the CPU baseline (0 = skip)')
+    ap.add_argument('--cpu-frames', type=int, default=10, help='timed frames of the CPU baseline (0 = skip)')
     ap.add_argument('--secondary', type=int, default=None,
                     help='steps of each secondary workload (default: 60 when the headline runs with default flags on 1 GPU, else 0)')
     ap.add_argument('--lean', action='store_true',

@@ -202,7 +202,11 @@ int ojf_conv2d(const float *in_dev, int in_stride, int in_off, float *out_dev, i
  * round_up(c_in, 8) readable, finite channels (the extra ones meet zero weights) and be 16-byte aligned.
  * Output size: floor((h + 2*padding - dilation*(ksize-1) - 1) / stride) + 1 per axis, like torch.
  * Arithmetic: split-fp16 MFMA with fp32 accumulation (see ojf_net_set_arithmetic); the range guard of
- * ojf_net_check covers these launches too.  weight_host is [c_out][c_in][ksize][ksize] (torch layout). */
+ * ojf_net_check covers these launches too.  weight_host is [c_out][c_in][ksize][ksize] (torch layout).
+ * act may carry OJF_SEG_ACT_ZERO_PAD: the launch also writes zeros into channels c_out .. round_up(c_out, 8) - 1 of every
+ * output row (rows the caller owns with that many floats), which the next layer reads as part of its last group of 8 -
+ * instead of a fill launch in front of every such layer. */
+#define OJF_SEG_ACT_ZERO_PAD 0x100
 typedef struct ojf_segconv ojf_segconv;
 int ojf_segconv_create(ojf_segconv **out, const float *weight_host, const float *scale_host, const float *bias_host,
                        int c_in, int c_out, int ksize, int stride, int dilation, int padding);
@@ -214,6 +218,15 @@ int ojf_segconv_create(ojf_segconv **out, const float *weight_host, const float 
 int ojf_segdeconv_create(ojf_segconv **out, const float *weight_host, const float *scale_host, const float *bias_host,
                          int c_in, int c_out, int stride);
 void ojf_segconv_destroy(ojf_segconv *conv);
+/* The reference's multi-scale units end in `nn.Dropout(p=0.5)(out)` on a module constructed inside forward(), i.e.
+ * ALWAYS in training mode (modules/adapnet.py:80-82): activations are dropped at inference too.  With a state set, the
+ * launches of this layer apply that dropout in their epilogue (after residual + ReLU): element e of the layer is kept
+ * (and doubled) iff bit 0 of Philox-4x32-10(counter = {e / 4, stream_id, frame}, key = seed) word e % 4 is set, with
+ * rng_state_dev = {seed, frame} (two u64 in device memory, owned by the caller).  The masks are a pure function of
+ * (seed, frame, stream_id, e): deterministic, graph-replayable, a fresh draw per frame.  advance != 0 instead marks
+ * the layer whose launch increments `frame` (the LAST convolution of a forward pass; no dropout there).
+ * rng_state_dev == NULL switches both off.  (torch's own generator is not consumed: seed it from torch.initial_seed().) */
+int ojf_segconv_set_dropout(ojf_segconv *conv, const unsigned long long *rng_state_dev, unsigned stream_id, int advance);
 int ojf_segconv_forward(const ojf_segconv *conv, const float *in_dev, int in_stride, float *out_dev, int out_stride,
                         const float *res_dev, int res_stride, const float *mul_dev, int mul_stride, int act, int h,
                         int w, ojf_stream_t stream);
@@ -353,7 +366,12 @@ int ojf_extract_to_net(const float *depth_dev, const float *Kinv_host, const flo
  * ojf_seg_maxpool: nn.MaxPool2d(3, 2, 1) of the ResNet stem (modules/adapnet.py:101, torchvision layout).
  * ojf_seg_mean: mean over the pixels per channel (eASPP branch 5 :204-208, Decoder._skip :292-296) -> out[c].
  * ojf_seg_broadcast: out[p][c] = vec[c] (* mul[p][c]): the bilinear upsampling of a 1x1 map / the gated skip.
- * ojf_seg_softmax_max: pipeline.py:57,183 softmax over the classes then max: scores f32[npix], ids u8[npix]. */
+ * ojf_seg_softmax_max: pipeline.py:57,183 softmax over the classes then max: scores f32[npix], ids u8[npix].
+ * ojf_seg_pool_fc: the squeeze chains of eASPP branch 5 (adapnet.py:204-210) and Decoder._skip (:292-296) as two launches
+ *   for n (1..8) members: out_m[p][c] = act(bias[c] + sum_k W[c][k] * mean_p' in_m[p'][k]) (* mul_m[p][c]) for every pixel p
+ *   of the OUTPUT map - global average (two fixed-order stages), a 1x1 convolution on the 1x1 map in fp32 (W_dev [c_out][c_in],
+ *   bias_dev [c_out] or NULL, per member), ReLU (act 1) or none (0), and the broadcast that bilinear upsampling of a 1x1
+ *   map is.  partial_dev: n * 128 * c_in floats of scratch. */
 int ojf_seg_pack_input(const float *src_dev, int chan_stride, float divisor, int h, int w, float *out_dev, int out_stride,
                        ojf_stream_t stream);
 int ojf_seg_maxpool(const float *in_dev, int in_stride, int c, int h, int w, float *out_dev, int out_stride, ojf_stream_t stream);
@@ -361,6 +379,9 @@ int ojf_seg_mean(const float *in_dev, int in_stride, int c, int npix, float *par
                  float *out_dev, ojf_stream_t stream);
 int ojf_seg_broadcast(const float *vec_dev, const float *mul_dev, int mul_stride, int c, int npix, float *out_dev, int out_stride,
                       ojf_stream_t stream);
+int ojf_seg_pool_fc(int n, const float *const *ins_dev, int in_stride, int c_in, int npix_in, const float *const *weights_dev,
+                    const float *const *biases_dev, int c_out, int act, const float *const *muls_dev, int mul_stride,
+                    float *const *outs_dev, int out_stride, int npix_out, float *partial_dev, ojf_stream_t stream);
 int ojf_seg_softmax_max(const float *logits_dev, int stride, int n_classes, int npix, float *scores_dev, uint8_t *ids_dev,
                         ojf_stream_t stream);
 

@@ -10,6 +10,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libojf.so')
+if os.environ.get('OJF_LIB_PATH'):  # A/B runs of two builds on one box (tools/): never set in production
+    LIB_PATH = os.environ['OJF_LIB_PATH']
 
 MODE_FAST = 0
 MODE_PARITY = 1
@@ -112,6 +114,8 @@ SIGNATURES = {
     'ojf_seg_mean': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     'ojf_seg_broadcast': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     'ojf_seg_softmax_max': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    'ojf_seg_pool_fc': (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp]),
+    'ojf_segconv_set_dropout': (_i, [_vp, _vp, _c.c_uint, _i]),
     'ojf_points_within': (_i, [_vp, _sz, _vp, _vp, _vp, _d, _i, _i, _i, _d, _vp, _vp, _vp]),
     'ojf_mesh_workspace_bytes': (_sz, [_i, _i, _i]),
     'ojf_mesh_extract': (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _d, _vp, _sz, _vp, _vp, _vp, _c.c_uint32, _vp, _vp]),

@@ -6,9 +6,12 @@ forward pass of ``AdapNet.forward`` (adapnet.py:390-415) for inference: activati
 fp32, every convolution + BN + residual + ReLU / sigmoid(+gate) is ONE HIP launch, concatenations are written in
 place through channel slices, the three transposed convolutions of the decoder run on the same kernel (phase
 expansion + pixel-shuffle store: deterministic, unlike MIOpen's atomics).  Input packing (image / 255, depth x 3),
-the stem's max-pool, the global average pools with their broadcasts / gates and the final softmax + max are libojf
-launches too (csrc/ojf_seg_ops.hip); the only torch op left is the reference's always-on dropout quirk of the
-multi-scale units (adapnet.py:80-82: its random stream IS torch's), off under ``no_resn50_dropout``.  The auxiliary
+the stem's max-pool, the squeeze chains (global average -> 1x1 convolution -> broadcast / gate: two launches) and the
+final softmax + max are libojf launches too (csrc/ojf_seg_ops.hip); the reference's always-on dropout quirk of the
+multi-scale units (adapnet.py:80-82) rides in the epilogue of each unit's last convolution (round 5: masks from
+Philox-4x32-10 keyed by (torch.initial_seed() at construction, frame, unit) - the same distribution, not torch's
+stream, which the lock-step order of the two encoders had left behind anyway; ten dropout / generator-bookkeeping
+launches per frame gone), off per unit under ``no_resn50_dropout``.  The auxiliary
 heads (adapnet.py:299-305) do not feed the result and are skipped.  ~772 launches of the torch forward become ~165.
 
 The engine snapshots the weights: build it after ``load_state_dict`` (``Pipeline`` rebuilds it when the
@@ -17,7 +20,6 @@ parameters change).  No fallback path: it needs libojf and a GPU.
 import os
 
 import torch
-import torch.nn.functional as F
 
 from . import segconv
 from .segconv import SegConv, SegDeconv, nhwc
@@ -45,8 +47,8 @@ class _Unit:
             cat = nhwc(2 * half, y.shape[2], y.shape[3], x.device, zero=False)
             self.c2a(y, out=cat[:, :half], act='relu')
             self.c2b(y, out=cat[:, half:], act='relu')
-            y = self.c3(cat, residual=idn, act='relu')
-            return F.dropout(y, p=0.5, training=True) if self.module.dropout else y
+            self.c3.set_dropout(self.rng if self.module.dropout else None, self.drop_id)  # (read at call time, like the module)
+            return self.c3(cat, residual=idn, act='relu')
         y = self.c2(y, act='relu')
         return self.c3(y, residual=idn, act='relu')
 
@@ -62,8 +64,9 @@ def _units(units, xs):
         cats = [nhwc(2 * half, y.shape[2], y.shape[3], y.device, zero=False) for y in ys]
         segconv.group([u.c2a for u in units] + [u.c2b for u in units], ys + ys,
                       outs=[c[:, :half] for c in cats] + [c[:, half:] for c in cats], act='relu')
-        ys = segconv.group([u.c3 for u in units], cats, residuals=idns, act='relu')
-        return [F.dropout(y, p=0.5, training=True) if u.module.dropout else y for u, y in zip(units, ys)]
+        for u in units:
+            u.c3.set_dropout(u.rng if u.module.dropout else None, u.drop_id)  # (read at call time, like the module)
+        return segconv.group([u.c3 for u in units], cats, residuals=idns, act='relu')
     ys = segconv.group([u.c2 for u in units], ys, act='relu')
     return segconv.group([u.c3 for u in units], ys, residuals=idns, act='relu')
 
@@ -101,8 +104,8 @@ def _easpps(aspps, xs, outs):
         last = i == depth - 1
         outs_i = [c[:, (k + 1) * n:(k + 2) * n] for c in cats for k in range(len(a0.cascades))] if last else None
         ys = segconv.group(convs, ys, outs=outs_i, act='relu')
-    for a, x, c in zip(aspps, xs, cats):
-        segconv.broadcast(a.b5(segconv.mean(x), act='relu'), c[:, 4 * n:])  # bilinear upsampling of a 1x1 map = broadcast
+    # branch 5: pool -> 1x1 conv -> ReLU -> bilinear upsampling of a 1x1 map (= broadcast), both eASPPs in two launches
+    segconv.pool_fc([a.b5 for a in aspps], xs, [c[:, 4 * n:] for c in cats], act='relu')
     return segconv.group([a.fin for a in aspps], cats, outs=outs, act='relu')
 
 
@@ -136,7 +139,7 @@ class _EASPP:
     def __init__(self, m):
         self.b1 = SegConv(m.branch1_conv, m.branch1_bn)
         self.cascades = [[SegConv(seq[i], seq[i + 1]) for i in (0, 3, 6, 9)] for seq in m.branch234]
-        self.b5 = SegConv(m.branch5_conv)  # its BatchNorm is unused by the reference (adapnet.py:209-210)
+        self.b5 = segconv.PoolFC(m.branch5_conv)  # its BatchNorm is unused by the reference (adapnet.py:209-210)
         self.fin = SegConv(m.eASPP_fin_conv, m.eASPP_fin_bn)
 
     def __call__(self, x, out):
@@ -149,7 +152,7 @@ class _EASPP:
             for c in convs[:-1]:
                 y = c(y, act='relu')
             convs[-1](y, out=cat[:, (i + 1) * n:(i + 2) * n], act='relu')
-        segconv.broadcast(self.b5(segconv.mean(x), act='relu'), cat[:, 4 * n:])  # bilinear upsampling of a 1x1 map = broadcast
+        segconv.pool_fc([self.b5], [x], [cat[:, 4 * n:]], act='relu')  # bilinear upsampling of a 1x1 map = broadcast
         return self.fin(cat, out=out, act='relu')
 
 
@@ -183,14 +186,24 @@ class SegEngine:
         self.deconv2 = SegDeconv(d.stage2[6], d.stage2[7])
         self.stage3 = [SegConv(d.stage3[0], d.stage3[1]), SegConv(d.stage3[3], d.stage3[4]), SegConv(d.stage3[6], d.stage3[7])]
         self.deconv3 = SegDeconv(d.stage3[8], d.stage3[9])
-        self.fuse1, self.fuse2 = SegConv(d.fuse_conv1), SegConv(d.fuse_conv2)
+        self.fuse1, self.fuse2 = segconv.PoolFC(d.fuse_conv1), segconv.PoolFC(d.fuse_conv2)
+        # the always-on dropout of the multi-scale units (adapnet.py:80-82) rides in their last convolution's epilogue: masks
+        # from a counter-based generator keyed by (seed, frame, unit) - seeded from torch's seed at construction, one stream
+        # id per unit, the frame counter advanced by the last launch of a forward pass (deconv3)
+        self.rng = torch.tensor([torch.initial_seed() & 0x7fffffffffffffff, 0], dtype=torch.int64, device=next(net.parameters()).device)
+        encs = [self.enc1] + ([self.enc2] if self.fusion else [])
+        for e, enc in enumerate(encs):
+            for li, layer in enumerate(enc.layers):
+                for ui, u in enumerate(layer):
+                    u.rng, u.drop_id = self.rng, 1 + ui + 16 * (li + 4 * e)
+        self.deconv3.set_dropout(self.rng, advance=True)
 
     def _skip(self, x, skip, conv, out):
         """Decoder._skip (adapnet.py:292-296): with two modalities the skip is gated by the pooled decoder state."""
         if not self.fusion:
             out.copy_(skip)
             return
-        segconv.broadcast(conv(segconv.mean(x), act='relu'), out, mul=skip)
+        segconv.pool_fc([conv], [x], [out], act='relu', muls=[skip])
 
     def forward(self, mod1, mod2=None):
         """Logits [1, n_classes, H, W] (channels_last memory) = AdapNet.forward(...)[0]."""
@@ -249,7 +262,7 @@ class SegEngine:
         self._skip(cat3[:, :256], skip2, self.fuse2, cat3[:, 256:])
         y = self.stage3[1](self.stage3[0](cat3, act='relu'), act='relu')
         y = self.stage3[2](y)
-        return self.deconv3(y)
+        return self.deconv3(y, zero_pad=False)  # (the classes' pad channels are read by nobody)
 
     __call__ = forward
 

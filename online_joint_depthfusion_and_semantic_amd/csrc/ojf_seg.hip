@@ -78,7 +78,26 @@ struct SegArgs {
     unsigned in_bytes;
     int *ovf;
     int up, up_c, up_cp;   // transposed convolution: upscale factor (1: none), real / padded channels per phase
+    int pad_to;            // channels c_out .. pad_to - 1 of every output row are written as zeros (OJF_SEG_ACT_ZERO_PAD), else = c_out
+    const unsigned long long *rng;  // always-on dropout of a multi-scale unit (adapnet.py:80-82): {seed, frame counter}, or NULL
+    unsigned long long *rng_bump;   // this launch advances the frame counter (the last convolution of a forward pass), or NULL
+    unsigned drop_id;               // stream id of this layer inside a frame
 };
+
+// Philox-4x32-10 (Salmon et al., the generator torch's own dropout draws from): counter-based, so the mask of element e of
+// layer `id` in frame f is a pure function of (seed, f, id, e) - no state to carry between launches, replayable in a graph.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = uint4{hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0};
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
 // Up to kSegGroup convolutions of the same shape (channels, kernel size, stride, frame: the launch geometry) run as ONE
 // launch, blockIdx.z = member: the two modality encoders of AdapNet++ in lock-step, the two dilations of a multi-scale
 // unit, the three cascades of an eASPP - half the graph nodes of the front end and no cross-stream fork / join.
@@ -135,16 +154,18 @@ __device__ __forceinline__ void seg_vectors(const SegArgs &a, int ct0, int kg, f
     }
 }
 
-template <int MW, int NW>
+template <int MW, int NW, bool DROP = false>
 __device__ __forceinline__ void seg_epilogue(const SegArgs &a, const f32x4 (&acc)[MW][NW], int ct0, int pt0, int n_pix, int col, int kg,
                                              const f32x4 (&rvs)[MW], const f32x4 (&bvs)[MW])
 {
     // epilogue: lane holds output channels c .. c+3 of pixel (pt0+n)*16 + col
     float gmax = 0.0f;
+    unsigned long long seed = 0, frame = 0;
+    if constexpr (DROP) { seed = a.rng[0]; frame = a.rng[1]; }
 #pragma unroll
     for (int m = 0; m < MW; ++m) {
         const int c = (ct0 + m) * 16 + kg * 4;
-        if (c >= a.c_out) continue;
+        if (c >= a.pad_to) continue;
         const f32x4 rv = rvs[m], bv = bvs[m];
         // transposed convolution: GEMM row c = (phase, channel); phase (ay, ax) of input pixel (y, x) is output pixel
         // (y*up + ay, x*up + ax).  up_cp is a multiple of 4, so a lane's four rows share the phase.
@@ -185,26 +206,43 @@ __device__ __forceinline__ void seg_epilogue(const SegArgs &a, const f32x4 (&acc
                 for (int i = 0; i < 4; ++i)
                     if (full || co + i < n_co) v[i] *= g[i];
             }
+            if constexpr (DROP) {  // nn.Dropout(p = 0.5) in training mode, always (adapnet.py:80-82): keep with probability 1/2, scale by 2
+                const unsigned e = (unsigned)p * (unsigned)(a.c_out >> 2) + (unsigned)(c >> 2);
+                const uint4 r = philox4x32_10(uint4{e, a.drop_id, (unsigned)frame, (unsigned)(frame >> 32)},
+                                              uint2{(unsigned)seed, (unsigned)(seed >> 32)});
+                v[0] = (r.x & 1u) ? v[0] + v[0] : 0.0f;
+                v[1] = (r.y & 1u) ? v[1] + v[1] : 0.0f;
+                v[2] = (r.z & 1u) ? v[2] + v[2] : 0.0f;
+                v[3] = (r.w & 1u) ? v[3] + v[3] : 0.0f;
+            }
+            if (a.pad_to > a.c_out) {  // pad channels of an engine-owned row: zeros (the next layer reads groups of 8)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (co + i >= n_co) v[i] = 0.0f;
+            }
             size_t row = (size_t)p;
             if (a.up > 1) {
                 const int oy = p / a.Wo, ox = p - oy * a.Wo;
                 row = ((size_t)oy * a.up + ay) * ((size_t)a.Wo * a.up) + (size_t)ox * a.up + ax;
             }
             float *o = a.out + row * a.out_stride + co;
-            if (full && a.vec_store) {
+            if ((full || co + 3 < a.pad_to) && a.vec_store) {
                 *reinterpret_cast<f32x4 *>(o) = v;
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (co + i < n_co) o[i] = v[i];
+                    if (co + i < n_co || co + i < a.pad_to) o[i] = v[i];
             }
         }
     }
     if (a.ovf && gmax > 65504.0f) guard_raise(a.ovf, 1);  // a later layer would split this value: outside the fp16 range
+    // (at the END of the kernel: tested first thing, the scalar load of this field sat in front of every other argument load
+    // of every launch - 0.4 us each)
+    if (a.rng_bump && blockIdx.x == 0 && threadIdx.x == 0) a.rng_bump[1] += 1;  // next frame: new dropout masks
 }
 
 // kDepth = K blocks in flight per wave (a cold weight fetch costs ~1 us, the MFMAs of a block ~0.1 us).
-template <int MW, int NW, int WM, int KS, int kDepth>
+template <int MW, int NW, int WM, int KS, int kDepth, bool DROP = false>
 __global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void segconv_kernel(const SegGroupArgs grp)
 {
     int bx, by, bz;
@@ -328,20 +366,20 @@ __global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void segconv_kernel(const S
                 }
     }
 
-    seg_epilogue<MW, NW>(a, acc, ct0, pt0, n_pix, col, kg, rvs, bvs);
+    seg_epilogue<MW, NW, DROP>(a, acc, ct0, pt0, n_pix, col, kg, rvs, bvs);
 }
 
 // Many-pixel layers (decoder 3x3 stacks, layer1): the four waves of a block work on the SAME 64 output channels and
 // 32 pixels each, and the weight fragments of a K block reach them through LDS (LDS-DMA, 8 KB per K block, three
 // stages): one global fetch per block instead of one per wave.  With per-wave fetches these layers were bound by
 // L1 (12 KB per wave per K block against 24 MFMAs); B operands stay per-wave buffer loads.
-template <int NW>
+template <int NW, int D>
 __global__ __launch_bounds__(256) void segconv_wide_kernel(const SegGroupArgs grp)
 {
     int bx, by, bz;
     if (!seg_block(grp.map, bx, by, bz)) return;  // block-uniform
     const SegArgs &a = grp.a[bz];
-    constexpr int MW = 4, D = 3;
+    constexpr int MW = 4;  // D = stages of the weight ring / K blocks of pixel operands in flight per wave
     __shared__ f32x4 wtile[D][MW * 2 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ct0 = by * MW;
@@ -429,8 +467,7 @@ __global__ __launch_bounds__(256) void segconv_wide_kernel(const SegGroupArgs gr
 #pragma unroll
         for (int s = 0; s < D; ++s) {
             const int kb = r * D + s;
-            if constexpr (NW == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // all but the newest K block's operations
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * (2 + 2 * NW)) : "memory");  // all but the D - 2 newest K blocks' operations
             __syncthreads();
             stream_weights(kb + D - 1, (s + D - 1) % D);
             fetch_pixels(kb + D - 1, xa[(s + D - 1) % D], xb[(s + D - 1) % D]);
@@ -462,6 +499,9 @@ struct ojf_segconv {
     ojf::f32x4 *wp;
     float *rinv, *bias;
     int up, up_c, up_cp;  // ojf_segdeconv_create: upscale factor, channels per phase (real / padded to 4)
+    const unsigned long long *rng = nullptr;  // ojf_segconv_set_dropout
+    unsigned long long *rng_bump = nullptr;
+    unsigned drop_id = 0;
 };
 
 OJF_API int ojf_segconv_create(ojf_segconv **out, const float *weight, const float *scale, const float *bias, int c_in, int c_out,
@@ -547,6 +587,16 @@ OJF_API int ojf_segdeconv_create(ojf_segconv **out, const float *weight, const f
     return 0;
 }
 
+OJF_API int ojf_segconv_set_dropout(ojf_segconv *c, const unsigned long long *rng_state_dev, unsigned stream_id, int advance)
+{
+    if (!c) return ojf::fail("ojf_segconv_set_dropout: null layer");
+    if (advance && !rng_state_dev) return ojf::fail("ojf_segconv_set_dropout: advance needs the state");
+    c->rng = advance ? nullptr : rng_state_dev;
+    c->rng_bump = advance ? const_cast<unsigned long long *>(rng_state_dev) : nullptr;
+    c->drop_id = stream_id;
+    return 0;
+}
+
 OJF_API void ojf_segconv_destroy(ojf_segconv *c)
 {
     if (!c) return;
@@ -562,6 +612,8 @@ int seg_fill(const ojf_segconv *c, const float *in, int in_stride, float *out, i
              const float *mul, int mul_stride, int act, int h, int w, SegArgs &a)
 {
     if (!c || !in || !out) return fail("ojf_segconv_forward: null pointer argument");
+    const bool zero_pad = (act & OJF_SEG_ACT_ZERO_PAD) != 0;
+    act &= ~OJF_SEG_ACT_ZERO_PAD;
     if (h < 1 || w < 1 || act < 0 || act > 2) return fail("ojf_segconv_forward: bad size or activation");
     if (in_stride < c->c8 * 8 || in_stride % 4 || (reinterpret_cast<uintptr_t>(in) & 15))
         return fail("ojf_segconv_forward: input rows must hold round_up(c_in, 8) channels, 16-byte aligned");
@@ -580,6 +632,14 @@ int seg_fill(const ojf_segconv *c, const float *in, int in_stride, float *out, i
     a.in_bytes = (unsigned)in_bytes;
     a.ovf = range_flag_device();
     a.up = c->up; a.up_c = c->up_c; a.up_cp = c->up_cp;
+    a.pad_to = a.c_out;
+    if (zero_pad) {
+        if (c->up > 1) return fail("ojf_segconv_forward: OJF_SEG_ACT_ZERO_PAD is not defined for transposed convolutions");
+        a.pad_to = round_up(c->c_out, 8);
+        if (out_stride < a.pad_to) return fail("ojf_segconv_forward: OJF_SEG_ACT_ZERO_PAD needs rows of round_up(c_out, 8) floats");
+    }
+    a.rng = c->rng; a.rng_bump = c->rng_bump; a.drop_id = c->drop_id;
+    if (a.rng && c->up > 1) return fail("ojf_segconv_forward: dropout on a transposed convolution");
     return 0;
 }
 
@@ -611,10 +671,32 @@ int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
     static const int no_wide = getenv("OJF_SEG_NO_WIDE") ? atoi(getenv("OJF_SEG_NO_WIDE")) : 0;  // tuning only
     static const int wide_min = getenv("OJF_SEG_WIDE_MIN") ? atoi(getenv("OJF_SEG_WIDE_MIN")) : 256;  // tuning only
     static const int trace = getenv("OJF_SEG_TRACE") ? atoi(getenv("OJF_SEG_TRACE")) : 0;  // tuning only: one line per launch
+    static const int wide1_min = getenv("OJF_SEG_WIDE1_MIN") ? atoi(getenv("OJF_SEG_WIDE1_MIN")) : (1 << 30);  // tuning only
+    static const int wide_depth = getenv("OJF_SEG_WIDE_DEPTH") ? atoi(getenv("OJF_SEG_WIDE_DEPTH")) : 3;  // tuning only: 3 | 6 | 8
     const char *variant;
-    if (!no_wide && a.n_kb >= 6 && (long)groups * ((n_pt + 7) / 8) * n >= wide_min) {
+    // a layer with the always-on dropout in its epilogue (the last convolution of a multi-scale unit): the DROP instantiation of
+    // the same kernel - the plain ones do not carry the generator's code (it cost every launch ~0.6 us)
+    bool drop = false;
+    for (int i = 0; i < n; ++i) drop = drop || g.a[i].rng != nullptr;
+    if (drop) {
+        for (int i = 0; i < n; ++i)
+            if (!g.a[i].rng) return fail("ojf_segconv_forward_group: dropout on some members only");
+        int mw = 4;
+        while (mw > 1 && (long)n_pt * (a.n_ct / mw) * n < 150) mw /= 2;
+        if (mw == 1) hipLaunchKernelGGL((segconv_kernel<1, 1, 1, 4, 3, true>), dim3(seg_map(g.map, n_pt, a.n_ct, n)), dim3(256), 0, st, g);
+        else if (mw == 2) hipLaunchKernelGGL((segconv_kernel<2, 1, 1, 4, 3, true>), dim3(seg_map(g.map, n_pt, a.n_ct / 2, n)), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((segconv_kernel<4, 1, 1, 4, 3, true>), dim3(seg_map(g.map, n_pt, groups, n)), dim3(256), 0, st, g);
+        variant = "<*,1,1,4> drop";
+    } else if (!no_wide && a.n_kb >= 6 && (long)groups * ((n_pt + 7) / 8) * n >= wide_min) {
         variant = "wide<2>";
-        hipLaunchKernelGGL((segconv_wide_kernel<2>), dim3(seg_map(g.map, (n_pt + 7) / 8, groups, n)), dim3(256), 0, st, g);
+        if (wide_depth == 3) hipLaunchKernelGGL((segconv_wide_kernel<2, 3>), dim3(seg_map(g.map, (n_pt + 7) / 8, groups, n)), dim3(256), 0, st, g);
+        else if (wide_depth == 8) hipLaunchKernelGGL((segconv_wide_kernel<2, 8>), dim3(seg_map(g.map, (n_pt + 7) / 8, groups, n)), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((segconv_wide_kernel<2, 6>), dim3(seg_map(g.map, (n_pt + 7) / 8, groups, n)), dim3(256), 0, st, g);
+    } else if (!no_wide && a.n_kb >= 6 && (long)groups * ((n_pt + 3) / 4) * n >= wide1_min) {
+        variant = "wide<1>";
+        if (wide_depth == 3) hipLaunchKernelGGL((segconv_wide_kernel<1, 3>), dim3(seg_map(g.map, (n_pt + 3) / 4, groups, n)), dim3(256), 0, st, g);
+        else if (wide_depth == 8) hipLaunchKernelGGL((segconv_wide_kernel<1, 8>), dim3(seg_map(g.map, (n_pt + 3) / 4, groups, n)), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((segconv_wide_kernel<1, 6>), dim3(seg_map(g.map, (n_pt + 3) / 4, groups, n)), dim3(256), 0, st, g);
     } else if (waves2 >= 1024 || a.n_kb < 8) {
         if (groups == 1) {
             variant = "<4,2,1,1>";
@@ -673,7 +755,7 @@ OJF_API int ojf_segconv_forward_group(int n, const ojf_segconv *const *convs, co
                               muls ? muls[i] : nullptr, mul_stride, act, h, w, g.a[i])) return rc;
         const SegArgs &a = g.a[i], &b = g.a[0];
         if (a.n_kb != b.n_kb || a.n_ct != b.n_ct || a.c8 != b.c8 || a.c_out != b.c_out || a.ksize != b.ksize || a.stride != b.stride ||
-            a.Ho != b.Ho || a.Wo != b.Wo || a.up != b.up)
+            a.Ho != b.Ho || a.Wo != b.Wo || a.up != b.up || (i > 0 && a.rng_bump))
             return fail("ojf_segconv_forward_group: the members must share channels, kernel size, stride and output size");
     }
     return seg_launch(g, n, as_stream(stream));

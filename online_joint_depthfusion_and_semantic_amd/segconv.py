@@ -10,6 +10,7 @@ import torch
 from . import _lib
 
 ACT = {None: 0, 'none': 0, 'relu': 1, 'sigmoid': 2}
+ZERO_PAD = 0x100  # include/ojf.h OJF_SEG_ACT_ZERO_PAD: the launch zeroes the pad channels of rows this module allocated
 
 
 def nhwc(channels, h, w, device, zero=True):
@@ -64,6 +65,16 @@ class SegConv:
             self._lib.ojf_segconv_destroy(self._h)
             self._h = None
 
+    def set_dropout(self, state, stream_id=0, advance=False):
+        """The always-on ``nn.Dropout(0.5)`` of a multi-scale unit (adapnet.py:80-82) in this layer's epilogue
+        (``ojf_segconv_set_dropout``): ``state`` = int64 device tensor {seed, frame} or None (off); ``advance``: this layer's
+        launch increments ``frame`` instead."""
+        key = (None if state is None else state.data_ptr(), int(stream_id), bool(advance))
+        if getattr(self, '_drop_key', (None, 0, False)) == key:
+            return
+        _lib.check(self._lib.ojf_segconv_set_dropout(self._h, key[0], key[1], int(key[2])), 'ojf_segconv_set_dropout')
+        self._drop_key = key
+
     def out_size(self, h, w):
         span = self.dil * (self.k - 1) + 1
         return (h + 2 * self.pad - span) // self.stride + 1, (w + 2 * self.pad - span) // self.stride + 1
@@ -73,14 +84,16 @@ class SegConv:
         write (default: a fresh tensor with c_out channels, padded to a multiple of 8 with zeros)."""
         H, W = x.shape[2:]
         Ho, Wo = self.out_size(H, W)
-        if out is None:
-            out = nhwc((self.c_out + 7) // 8 * 8, Ho, Wo, x.device, zero=self.c_out % 8 != 0)[:, :self.c_out]
+        flags = 0
+        if out is None:  # own rows, padded to a multiple of 8 channels: the launch itself zeroes the pad (no fill kernel)
+            out = nhwc((self.c_out + 7) // 8 * 8, Ho, Wo, x.device, zero=False)[:, :self.c_out]
+            flags = ZERO_PAD if self.c_out % 8 else 0
         assert out.shape[1] == self.c_out and tuple(out.shape[2:]) == (Ho, Wo)
         xp, xs = _rows(x)
         op, os_ = _rows(out)
         rp, rs = _rows(residual) if residual is not None else (None, 0)
         mp, ms = _rows(mul) if mul is not None else (None, 0)
-        rc = self._lib.ojf_segconv_forward(self._h, xp, xs, op, os_, rp, rs, mp, ms, ACT[act], H, W, _lib.stream_ptr(x.device))
+        rc = self._lib.ojf_segconv_forward(self._h, xp, xs, op, os_, rp, rs, mp, ms, ACT[act] | flags, H, W, _lib.stream_ptr(x.device))
         _lib.check(rc, 'ojf_segconv_forward')
         return out
 
@@ -95,8 +108,10 @@ def group(convs, xs, outs=None, act=None, residuals=None, muls=None):
     c0 = convs[0]
     H, W = xs[0].shape[2:]
     Ho, Wo = c0.out_size(H, W)
+    flags = 0
     if outs is None:
-        outs = [nhwc((c0.c_out + 7) // 8 * 8, Ho, Wo, xs[0].device, zero=c0.c_out % 8 != 0)[:, :c0.c_out] for _ in range(n)]
+        outs = [nhwc((c0.c_out + 7) // 8 * 8, Ho, Wo, xs[0].device, zero=False)[:, :c0.c_out] for _ in range(n)]
+        flags = ZERO_PAD if c0.c_out % 8 else 0
     assert len(outs) == n and all(o.shape[1] == c0.c_out and tuple(o.shape[2:]) == (Ho, Wo) for o in outs)
     assert all(tuple(x.shape[2:]) == (H, W) for x in xs)
 
@@ -112,7 +127,7 @@ def group(convs, xs, outs=None, act=None, residuals=None, muls=None):
     rp, rs = rows(residuals)
     mp, ms = rows(muls)
     handles = (ctypes.c_void_p * n)(*[c._h.value for c in convs])
-    rc = c0._lib.ojf_segconv_forward_group(n, handles, xp, xs_, op, os_, rp, rs, mp, ms, ACT[act], H, W, _lib.stream_ptr(xs[0].device))
+    rc = c0._lib.ojf_segconv_forward_group(n, handles, xp, xs_, op, os_, rp, rs, mp, ms, ACT[act] | flags, H, W, _lib.stream_ptr(xs[0].device))
     _lib.check(rc, 'ojf_segconv_forward_group')
     return list(outs)
 
@@ -142,10 +157,14 @@ class SegDeconv:
             self._lib.ojf_segconv_destroy(self._h)
             self._h = None
 
-    def __call__(self, x, out=None, act=None):
+    set_dropout = SegConv.set_dropout
+
+    def __call__(self, x, out=None, act=None, zero_pad=True):
+        """zero_pad=False: the pad channels of a fresh output (c_out not a multiple of 8) stay uninitialised - for outputs no
+        convolution reads (the logits)."""
         H, W = x.shape[2:]
         if out is None:
-            out = nhwc((self.c_out + 7) // 8 * 8, H * self.up, W * self.up, x.device, zero=self.c_out % 8 != 0)[:, :self.c_out]
+            out = nhwc((self.c_out + 7) // 8 * 8, H * self.up, W * self.up, x.device, zero=zero_pad and self.c_out % 8 != 0)[:, :self.c_out]
         assert out.shape[1] == self.c_out and tuple(out.shape[2:]) == (H * self.up, W * self.up)
         xp, xs = _rows(x)
         op, os_ = _rows(out)
@@ -204,6 +223,42 @@ def broadcast(vec, out, mul=None):
     mp, ms = _rows(mul) if mul is not None else (None, 0)
     _lib.check(lib.ojf_seg_broadcast(vec.data_ptr(), mp, ms, C, H * W, op, os_, _lib.stream_ptr(out.device)), 'ojf_seg_broadcast')
     return out
+
+
+class PoolFC:
+    """Global average -> 1x1 ``conv`` (+ bias, no BatchNorm) on the 1x1 map -> ReLU -> broadcast to an output map (x gate): the
+    squeeze chains of eASPP branch 5 (adapnet.py:204-210) and ``Decoder._skip`` (:292-296), two launches for up to 8
+    members (``ojf_seg_pool_fc``; the 1x1 convolution runs in fp32)."""
+
+    def __init__(self, conv):
+        assert isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.groups == 1
+        dev = conv.weight.device
+        self.c_out, self.c_in = int(conv.weight.shape[0]), int(conv.weight.shape[1])
+        self.w = conv.weight.detach().float().reshape(self.c_out, self.c_in).contiguous().clone()
+        self.b = conv.bias.detach().float().contiguous().clone() if conv.bias is not None else None
+        assert self.w.is_cuda, dev
+
+
+def pool_fc(fcs, xs, outs, act='relu', muls=None):
+    """``outs[i][:, c, y, x] = act(fc_i(mean(xs[i])))[c] (* muls[i][:, c, y, x])`` for n <= 8 members of one shape."""
+    lib = _lib.load()
+    n = len(fcs)
+    f0 = fcs[0]
+    C, H, W = xs[0].shape[1:]
+    Co, Ho, Wo = outs[0].shape[1:]
+    assert C == f0.c_in and Co == f0.c_out and all(f.c_in == C and f.c_out == Co for f in fcs)
+    xr = [_rows(x) for x in xs]
+    orr = [_rows(o) for o in outs]
+    mr = [_rows(m) for m in muls] if muls is not None else None
+    assert all(r[1] == xr[0][1] for r in xr) and all(r[1] == orr[0][1] for r in orr) and (mr is None or all(r[1] == mr[0][1] for r in mr))
+    arr = lambda ptrs: (ctypes.c_void_p * n)(*ptrs)
+    partial = torch.empty(n * 128 * C, dtype=torch.float32, device=xs[0].device)
+    biases = arr([f.b.data_ptr() if f.b is not None else None for f in fcs]) if any(f.b is not None for f in fcs) else None
+    rc = lib.ojf_seg_pool_fc(n, arr([r[0] for r in xr]), xr[0][1], C, H * W, arr([f.w.data_ptr() for f in fcs]), biases, Co, ACT[act],
+                             arr([r[0] for r in mr]) if mr is not None else None, mr[0][1] if mr is not None else 0,
+                             arr([r[0] for r in orr]), orr[0][1], Ho * Wo, partial.data_ptr(), _lib.stream_ptr(xs[0].device))
+    _lib.check(rc, 'ojf_seg_pool_fc')
+    return outs
 
 
 def softmax_max(logits):
