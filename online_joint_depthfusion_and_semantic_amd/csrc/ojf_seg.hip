@@ -478,6 +478,133 @@ __global__ __launch_bounds__(256) void segconv_wide_kernel(const SegGroupArgs gr
     seg_epilogue<MW, NW>(a, acc, ct0, pt0, n_pix, col, kg, rvs, bvs);
 }
 
+// The same tile as segconv_wide_kernel (64 output channels x 4 waves x NW pixel tiles, weights shared through LDS), with the
+// weight fragments staged through REGISTERS instead of LDS-DMA (round 5).  A wave's `global_load_lds` instructions do not
+// overlap: the second one issues when the first has returned (tools/microbench/dma_issue_bench.hip, round 4), so the wide
+// kernel paid two memory latencies per K block whatever its ring depth - 1 us per K block on a 60x80 decoder layer, 71 us
+// for 72 K blocks where the MFMAs need 12.  Plain loads do not block: every wave keeps P K blocks of its two weight chunks
+// and of its pixel operands in flight in registers, writes the chunks of block i + 1 into the other half of a two-slot LDS
+// tile while block i is multiplied, one barrier per K block.
+template <int NW, int U>
+__global__ __launch_bounds__(256) void segconv_tile_kernel(const SegGroupArgs grp)
+{
+    int bx, by, bz;
+    if (!seg_block(grp.map, bx, by, bz)) return;  // block-uniform
+    const SegArgs &a = grp.a[bz];
+    // U K blocks per step (= per barrier): with one wave per SIMD - what these launches have - the phases of a step (wait,
+    // LDS write, split, loads, LDS reads, MFMAs, barrier) run one after the other, ~1300 cycles per K block at U = 1 for 192
+    // cycles of MFMAs (SQ counters, round 5); a longer step amortises the waits and lets the LDS reads of one K block sit
+    // under the MFMAs of the one before.  P steps in flight per wave.
+    constexpr int MW = 4, P = 2;
+    __shared__ f32x4 wtile[2][U][MW * 2 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ct0 = by * MW;
+    const int pt0 = (bx * 4 + wave) * NW;
+    const int n_pix = a.Ho * a.Wo;
+    const int col = lane & 15, kg = lane >> 4;
+    const int n_kb = a.n_kb;
+
+    int iy0[NW], ix0[NW];
+    bool live[NW];
+#pragma unroll
+    for (int n = 0; n < NW; ++n) {
+        const int p = (pt0 + n) * 16 + col;
+        live[n] = p < n_pix;
+        const int oy = p / a.Wo, ox = p - oy * a.Wo;
+        iy0[n] = oy * a.stride - a.pad;
+        ix0[n] = ox * a.stride - a.pad;
+    }
+    int tap = kg / a.c8, cg = kg - tap * a.c8;
+    int ty = tap / a.ksize, tx = tap - ty * a.ksize;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in), 0, a.in_bytes, 0x00020000);
+
+    f32x4 rvs[MW], bvs[MW];
+    seg_vectors<MW>(a, ct0, kg, rvs, bvs);
+    f32x4 acc[MW][NW];
+#pragma unroll
+    for (int m = 0; m < MW; ++m)
+#pragma unroll
+        for (int n = 0; n < NW; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // wave w stages chunks w and w + 4 of the 8 one-KB chunks (channel tile m, half h) of a K block
+    const f32x4 *wsrc[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int c = wave + 4 * r, m = c >> 1, h = c & 1;
+        wsrc[r] = a.wp + (size_t)(ct0 + m) * n_kb * 128 + h * 64 + lane;
+    }
+    f32x4 wr[P][U][2], xa[P][U][NW], xb[P][U][NW];
+    auto issue = [&](int kb0, f32x4 (&fw)[U][2], f32x4 (&fa)[U][NW], f32x4 (&fb)[U][NW]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {  // all weight chunks of the step first: they are wanted one step earlier than the pixels
+            const int kb = kb0 + u, kbc = kb < n_kb ? kb : n_kb - 1;  // past the end: the last block again (multiplied by zeros)
+            fw[u][0] = wsrc[0][(size_t)kbc * 128];
+            fw[u][1] = wsrc[1][(size_t)kbc * 128];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kb = kb0 + u;
+            const int dy = ty * a.dil, dx = tx * a.dil;
+            const bool in_range = kb < n_kb;
+#pragma unroll
+            for (int n = 0; n < NW; ++n) {
+                const int iy = iy0[n] + dy, ix = ix0[n] + dx;
+                const bool ok = in_range && live[n] && ty < a.ksize && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                const unsigned off = ok ? (unsigned)(((iy * a.W + ix) * a.in_stride + cg * 8) * 4) : 0xfffffff0u;
+                fa[u][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+                fb[u][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off + 16u : 0xfffffff0u, 0, 0));
+            }
+            cg += 4;
+            while (cg >= a.c8) {
+                cg -= a.c8;
+                if (++tx == a.ksize) {
+                    tx = 0;
+                    ++ty;
+                }
+            }
+        }
+    };
+    auto stage = [&](int buf, const f32x4 (&fw)[U][2]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            wtile[buf][u][wave * 64 + lane] = fw[u][0];
+            wtile[buf][u][(wave + 4) * 64 + lane] = fw[u][1];
+        }
+    };
+    constexpr int kW = 2 * U, kX = 2 * NW * U;  // memory operations of one step per wave, in issue order: weight chunks, then pixels
+#pragma unroll
+    for (int s = 0; s < P; ++s) issue(s * U, wr[s], xa[s], xb[s]);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * (kW + kX) + kX) : "memory");  // the weight chunks of step 0
+    stage(0, wr[0]);
+    __syncthreads();
+    const int steps = (n_kb + U - 1) / U, rounds = (steps + P - 1) / P;
+    for (int r = 0; r < rounds; ++r) {
+#pragma unroll
+        for (int s = 0; s < P; ++s) {
+            // here: steps i .. i + P - 1 are in flight (i = r P + s); wanted: the pixels of i, the weight chunks of i + 1
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 2) * (kW + kX) + kX) : "memory");
+            stage((s + 1) & 1, wr[(s + 1) % P]);
+            f16x8 xh[U][NW], xl[U][NW];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int n = 0; n < NW; ++n) split8(xa[s][u][n], xb[s][u][n], xh[u][n], xl[u][n]);
+            issue((r * P + s + P) * U, wr[s], xa[s], xb[s]);  // (the registers of step i are free: its chunks sit in LDS, its pixels are split)
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int m = 0; m < MW; ++m) {
+                    const f32x4 wh = wtile[s & 1][u][(m * 2) * 64 + lane], wl = wtile[s & 1][u][(m * 2 + 1) * 64 + lane];
+#pragma unroll
+                    for (int n = 0; n < NW; ++n) acc[m][n] = mfma3(wh, wl, xh[u][n], xl[u][n], acc[m][n]);
+                }
+            __syncthreads();  // step i + 1's chunks are visible; nobody reads slot i & 1 any more
+        }
+    }
+    if (pt0 * 16 >= n_pix) return;
+    seg_epilogue<MW, NW>(a, acc, ct0, pt0, n_pix, col, kg, rvs, bvs);
+}
+
 inline float pow2_row_scale(float row_max)
 {
     if (!(row_max > 0.0f) || !std::isfinite(row_max)) return 1.0f;
@@ -672,6 +799,9 @@ int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
     static const int wide_min = getenv("OJF_SEG_WIDE_MIN") ? atoi(getenv("OJF_SEG_WIDE_MIN")) : 256;  // tuning only
     static const int trace = getenv("OJF_SEG_TRACE") ? atoi(getenv("OJF_SEG_TRACE")) : 0;  // tuning only: one line per launch
     static const int wide1_min = getenv("OJF_SEG_WIDE1_MIN") ? atoi(getenv("OJF_SEG_WIDE1_MIN")) : (1 << 30);  // tuning only
+    static const int splitk_nw2_min = getenv("OJF_SEG_SPLITK_NW2_MIN") ? atoi(getenv("OJF_SEG_SPLITK_NW2_MIN")) : (1 << 30);  // tuning only
+    static const int tile_u = getenv("OJF_SEG_TILE_U") ? atoi(getenv("OJF_SEG_TILE_U")) : 1;  // tuning only: K blocks per barrier of the tile kernel
+    static const int use_tile = getenv("OJF_SEG_TILE") ? atoi(getenv("OJF_SEG_TILE")) : 0;  // tuning only: register-staged tile kernel
     static const int wide_depth = getenv("OJF_SEG_WIDE_DEPTH") ? atoi(getenv("OJF_SEG_WIDE_DEPTH")) : 3;  // tuning only: 3 | 6 | 8
     const char *variant;
     // a layer with the always-on dropout in its epilogue (the last convolution of a multi-scale unit): the DROP instantiation of
@@ -688,13 +818,19 @@ int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
         else hipLaunchKernelGGL((segconv_kernel<4, 1, 1, 4, 3, true>), dim3(seg_map(g.map, n_pt, groups, n)), dim3(256), 0, st, g);
         variant = "<*,1,1,4> drop";
     } else if (!no_wide && a.n_kb >= 6 && (long)groups * ((n_pt + 7) / 8) * n >= wide_min) {
-        variant = "wide<2>";
-        if (wide_depth == 3) hipLaunchKernelGGL((segconv_wide_kernel<2, 3>), dim3(seg_map(g.map, (n_pt + 7) / 8, groups, n)), dim3(256), 0, st, g);
+        variant = use_tile ? "tile<2>" : "wide<2>";
+        if (use_tile && tile_u == 4) hipLaunchKernelGGL((segconv_tile_kernel<2, 4>), dim3(seg_map(g.map, (n_pt + 7) / 8, groups, n)), dim3(256), 0, st, g);
+        else if (use_tile && tile_u == 2) hipLaunchKernelGGL((segconv_tile_kernel<2, 2>), dim3(seg_map(g.map, (n_pt + 7) / 8, groups, n)), dim3(256), 0, st, g);
+        else if (use_tile) hipLaunchKernelGGL((segconv_tile_kernel<2, 1>), dim3(seg_map(g.map, (n_pt + 7) / 8, groups, n)), dim3(256), 0, st, g);
+        else if (wide_depth == 3) hipLaunchKernelGGL((segconv_wide_kernel<2, 3>), dim3(seg_map(g.map, (n_pt + 7) / 8, groups, n)), dim3(256), 0, st, g);
         else if (wide_depth == 8) hipLaunchKernelGGL((segconv_wide_kernel<2, 8>), dim3(seg_map(g.map, (n_pt + 7) / 8, groups, n)), dim3(256), 0, st, g);
         else hipLaunchKernelGGL((segconv_wide_kernel<2, 6>), dim3(seg_map(g.map, (n_pt + 7) / 8, groups, n)), dim3(256), 0, st, g);
     } else if (!no_wide && a.n_kb >= 6 && (long)groups * ((n_pt + 3) / 4) * n >= wide1_min) {
-        variant = "wide<1>";
-        if (wide_depth == 3) hipLaunchKernelGGL((segconv_wide_kernel<1, 3>), dim3(seg_map(g.map, (n_pt + 3) / 4, groups, n)), dim3(256), 0, st, g);
+        variant = use_tile ? "tile<1>" : "wide<1>";
+        if (use_tile && tile_u == 4) hipLaunchKernelGGL((segconv_tile_kernel<1, 4>), dim3(seg_map(g.map, (n_pt + 3) / 4, groups, n)), dim3(256), 0, st, g);
+        else if (use_tile && tile_u == 2) hipLaunchKernelGGL((segconv_tile_kernel<1, 2>), dim3(seg_map(g.map, (n_pt + 3) / 4, groups, n)), dim3(256), 0, st, g);
+        else if (use_tile) hipLaunchKernelGGL((segconv_tile_kernel<1, 1>), dim3(seg_map(g.map, (n_pt + 3) / 4, groups, n)), dim3(256), 0, st, g);
+        else if (wide_depth == 3) hipLaunchKernelGGL((segconv_wide_kernel<1, 3>), dim3(seg_map(g.map, (n_pt + 3) / 4, groups, n)), dim3(256), 0, st, g);
         else if (wide_depth == 8) hipLaunchKernelGGL((segconv_wide_kernel<1, 8>), dim3(seg_map(g.map, (n_pt + 3) / 4, groups, n)), dim3(256), 0, st, g);
         else hipLaunchKernelGGL((segconv_wide_kernel<1, 6>), dim3(seg_map(g.map, (n_pt + 3) / 4, groups, n)), dim3(256), 0, st, g);
     } else if (waves2 >= 1024 || a.n_kb < 8) {
@@ -719,6 +855,9 @@ int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
         } else if (mw == 2) {
             variant = "<2,1,1,4>";
             hipLaunchKernelGGL((segconv_kernel<2, 1, 1, 4, 3>), dim3(seg_map(g.map, n_pt, a.n_ct / 2, n)), dim3(256), 0, st, g);
+        } else if (n_pt >= splitk_nw2_min) {
+            variant = "<4,2,1,4>";
+            hipLaunchKernelGGL((segconv_kernel<4, 2, 1, 4, 3>), dim3(seg_map(g.map, (n_pt + 1) / 2, groups, n)), dim3(256), 0, st, g);
         } else {
             variant = "<4,1,1,4>";
             hipLaunchKernelGGL((segconv_kernel<4, 1, 1, 4, 3>), dim3(seg_map(g.map, n_pt, groups, n)), dim3(256), 0, st, g);
