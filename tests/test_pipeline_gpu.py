@@ -361,3 +361,68 @@ def test_range_guard_policy_f32_refuses_nothing_and_loses_nothing(cuda):
     for a, b in zip(_volumes(db, st.scene), _volumes(db2, st2.scene)):
         assert torch.equal(a.view(torch.int16), b.view(torch.int16))
     assert float((db.fusion_weights[st.scene].float() > 0).sum()) > 1000
+
+
+# ---- the reference's own net in train() mode -------------------------------------------------------
+@pytest.mark.parametrize('engine', ['hip', 'torch'])
+def test_fuse_training_train_mode_matches_reference_golden(cuda, engine):
+    """Fixture = ONE ``fuse_training`` frame + ``loss.backward()`` of the reference with /root/reference/modules/model.py's
+    FusionNet_v3 in train() mode (batch statistics, running-statistics update; only the Dropout2d modules in eval), held
+    twice from the same pre-frame state: as the reference runs (fp32) and with the same module tree in float64
+    (tests/golden/make_golden.py::run_training_train_mode).  A batch-statistics net amplifies rounding (the reference's own
+    fp32 gradients deviate by up to 6 % of a tensor's scale from its float64 ones here), so every tensor is judged against
+    the float64 values: within 1e-4 of its scale, or no further away than 2.5x the reference's own fp32 run.  Checked:
+    tsdf_target bit for bit, tsdf_est, tsdf_fused, loss, ALL parameter gradients, ALL BatchNorm buffers after the step
+    (running_mean, running_var, num_batches_tracked), the post-frame weight volume bit for bit and the TSDF volume."""
+    g = golden('train_mode_v3_nosem_48x64_g64.npz')
+    h, w, grid = 48, 64, 64
+    state = {k[len('state_'):]: torch.from_numpy(g[k]) for k in g.files if k.startswith('state_')}
+    cfg, st, db, pipe = _setup(h, w, grid, False, False, 'parity', cuda, state)
+    cfg.FUSION_MODEL.train_engine = engine
+    s = st.scene
+    db.scenes_est[s].volume.copy_(torch.from_numpy(g['pre_tsdf']))
+    db.fusion_weights[s].copy_(torch.from_numpy(g['pre_wgt']))
+    net = pipe._fusion_network
+    net.train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.eval()
+    out = pipe.fuse_training(_batch(st, 2, cuda), db, cuda)
+    diff = out['tsdf_fused'] - out['tsdf_target']
+    loss = diff.abs().mean() + 10 * (diff ** 2).mean()
+    loss.backward()
+    import hashlib
+    tgt = np.ascontiguousarray(out['tsdf_target'].detach()[0].cpu().numpy())
+    assert hashlib.sha256(tgt.tobytes()).hexdigest() == str(g['32_tsdf_target_sha256'])
+    assert out['tsdf_fused'].shape[1] == int(g['32_n_valid'])
+
+    worst = [0.0]
+
+    def bar(got, key, floor=None, what=None):
+        got = np.asarray(got, np.float64)
+        truth, fp32 = g['64_' + key].astype(np.float64), g['32_' + key].astype(np.float64)
+        scale = max(float(np.abs(truth).max()), floor or 0.0)
+        e, e32 = float(np.abs(got - truth).max()), float(np.abs(fp32 - truth).max())
+        assert e <= max(1e-4 * scale, 2.5 * e32), (what or key, e, e32, scale)
+        worst[0] = max(worst[0], e / max(e32, 1e-4 * scale))
+    bar(out['tsdf_est'].detach()[0].cpu().numpy(), 'tsdf_est')
+    bar(out['tsdf_fused'].detach()[0].cpu().numpy(), 'tsdf_fused')
+    bar(float(loss), 'loss')
+    gmax = max(float(np.abs(g[k]).max()) for k in g.files if k.startswith('64_grad_') and g[k].size)
+    for name, p in net.named_parameters():
+        want = g['64_grad_' + name]
+        assert (p.grad is None) == (want.size == 0), name
+        if want.size:
+            bar(p.grad.cpu().numpy(), 'grad_' + name, floor=1e-3 * gmax)
+    for name, b in net.named_buffers():
+        if b.dtype.is_floating_point:
+            bar(b.cpu().numpy(), 'buf_' + name)
+        else:
+            assert int(b) == int(g['64_buf_' + name]) == 1, name
+    print('train() mode vs the reference (%s engine): worst deviation = %.2f x the reference\'s own fp32 run' % (engine, worst[0]))
+    # volumes: integrate(test=False) with the clamped est
+    assert f16_ulp_distance(db.fusion_weights[s].cpu().numpy(), g['32_post_wgt']).max() == 0
+    got = db.scenes_est[s].volume.cpu().numpy().astype(np.float32)
+    td = np.nan_to_num(np.abs(got - g['32_post_tsdf'].astype(np.float32)))
+    touched = g['32_post_wgt'] > 0
+    assert td.max() <= 2 * TSDF_ABS_TOL and (td[touched] > 0).mean() <= 0.02, (float(td.max()), float((td[touched] > 0).mean()))
