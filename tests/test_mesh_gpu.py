@@ -324,3 +324,87 @@ def test_device_f_score_equals_host_definition():
     assert same == {'precision': 1.0, 'recall': 1.0, 'fscore': 1.0}
     none = metrics.reconstruction_f_score(dev(gt), dev(gt), dev(np.zeros_like(w)), origin, res)
     assert none == {'precision': 0.0, 'recall': 0.0, 'fscore': 0.0}
+
+
+# ---- analytic surfaces from a committed fixture ---------------------------------------------------
+def _analytic_sdf(case, pts):
+    """Signed distance (negative inside the solid) of the fixture's closed-form solids at points [n, 3]."""
+    kind = case['kind']
+    if kind == 'torus':
+        q = pts - np.asarray(case['centre'])
+        ring = np.sqrt(q[:, 0] ** 2 + q[:, 1] ** 2) - case['R']
+        return np.sqrt(ring ** 2 + q[:, 2] ** 2) - case['r']
+    if kind == 'spheres':
+        d = [np.linalg.norm(pts - np.asarray(c), axis=1) - r for c, r in zip(case['centres'], case['radii'])]
+        return np.minimum.reduce(d)
+    if kind == 'shell':  # solid between two concentric spheres
+        rho = np.linalg.norm(pts - np.asarray(case['centre']), axis=1)
+        return np.maximum(rho - case['R'], case['r'] - rho)
+    raise ValueError(kind)
+
+
+def _analytic_samples(case, n=6000, seed=3):
+    """Points ON the analytic surface (for the surface -> mesh half of the Hausdorff check)."""
+    rng = np.random.default_rng(seed)
+    kind = case['kind']
+    if kind == 'torus':
+        u, v = rng.uniform(0, 2 * np.pi, n), rng.uniform(0, 2 * np.pi, n)
+        R, r = case['R'], case['r']
+        p = np.stack([(R + r * np.cos(v)) * np.cos(u), (R + r * np.cos(v)) * np.sin(u), r * np.sin(v)], axis=1)
+        return p + np.asarray(case['centre'])
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    if kind == 'spheres':
+        half = n // 2
+        return np.concatenate([np.asarray(case['centres'][0]) + case['radii'][0] * d[:half],
+                               np.asarray(case['centres'][1]) + case['radii'][1] * d[half:]])
+    half = n // 2
+    return np.asarray(case['centre']) + np.concatenate([case['R'] * d[:half], case['r'] * d[half:]])
+
+
+def _components(n_vertices, faces):
+    parent = np.arange(n_vertices)
+
+    def find(i):
+        while parent[i] != i:
+            parent[i] = parent[parent[i]]
+            i = parent[i]
+        return i
+    for a, b in np.concatenate([faces[:, [0, 1]], faces[:, [1, 2]]]):
+        ra, rb = find(a), find(b)
+        if ra != rb:
+            parent[ra] = rb
+    return len({find(i) for i in range(n_vertices)})
+
+
+def test_analytic_surfaces():
+    """tests/golden/mesh_analytic_cases.json: torus (genus 1), two spheres (two components), a spherical shell (two nested
+    surfaces of opposite orientation).  Closed 2-manifold, Euler characteristic and component count exact; area and enclosed
+    volume against the closed forms; every vertex within the stated distance of the analytic surface and every analytic
+    surface sample within one voxel of a vertex (two-sided Hausdorff bound)."""
+    import json
+    import os
+    from scipy.spatial import cKDTree
+    from online_joint_depthfusion_and_semantic_amd import mesh
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'mesh_analytic_cases.json')))['cases']
+    n = 64
+    g = np.stack(np.meshgrid(*[np.arange(n)] * 3, indexing='ij'), axis=-1).reshape(-1, 3).astype(np.float64)
+    for case in cases:
+        vol = np.clip(_analytic_sdf(case, g), -4, 4).astype(np.float16).reshape(n, n, n)
+        m = mesh.extract_mesh(dev(vol), resolution=1.0)
+        v, f = m['vertices'].astype(np.float64), m['faces']
+        e = edge_table(f)
+        key = e[:, 0].astype(np.int64) * v.shape[0] + e[:, 1]
+        rkey = e[:, 1].astype(np.int64) * v.shape[0] + e[:, 0]
+        assert np.unique(key).size == key.size and np.array_equal(np.sort(key), np.sort(rkey)), case['name']  # closed, oriented
+        assert v.shape[0] - e.shape[0] // 2 + f.shape[0] == case['euler'], case['name']
+        assert _components(v.shape[0], f) == case['components'], case['name']
+        a, b, c = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+        fn = np.cross(b - a, c - a)
+        area = 0.5 * np.linalg.norm(fn, axis=1).sum()
+        volume = (a * fn).sum() / 6.0  # divergence theorem with outward (towards positive SDF) faces
+        assert abs(area / case['area'] - 1) < case['rel_tol'], (case['name'], area)
+        assert abs(volume / case['volume'] - 1) < case['rel_tol'], (case['name'], volume)
+        assert np.abs(_analytic_sdf(case, v)).max() < case['max_vertex_distance'], (case['name'], float(np.abs(_analytic_sdf(case, v)).max()))
+        gap = cKDTree(v).query(_analytic_samples(case))[0].max()
+        assert gap < case['max_surface_gap'], (case['name'], float(gap))
