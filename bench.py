@@ -273,6 +273,79 @@ class Case:
                 'stages_all_frames': profile_frames, 'kernels': kernels, 'launches': pipe._engine.launches}
 
 
+class ManyScenes:
+    """S BenchStreams as one dataset object (Database pulls .scenes / .get_grid from it, modules/database.py:48-58)."""
+
+    def __init__(self, streams):
+        self.streams = {st.scene: st for st in streams}
+        self.scenes = [st.scene for st in streams]
+
+    def get_grid(self, scene, truncation, semantic_grid=True):
+        return self.streams[scene].get_grid(scene, truncation, semantic_grid)
+
+
+class ManyCase:
+    """S scenes of one frame size on ONE GPU, one frame of each per step through Pipeline.fuse_many:
+    the aggregate frames/s of the device when the per-frame launch chains of several scenes run side by side."""
+
+    def __init__(self, c, dev, rank, n_frames, S):
+        self.c, self.S, self.dev = c, S, dev
+        h, w, grid = c['h'], c['w'], c['grid']
+        cfg = default_config(h, w, semantics=c['semantics'], integrate_mode=c['mode'], n_classes=c['n_classes'])
+        cfg.SETTINGS.device = str(dev)
+        cfg.FUSION_MODEL.arithmetic = c['arith']
+        if c['semantics']:
+            cfg.DATA.semantic_strategy = c['strategy']
+            cfg.SEMANTIC_2D_MODEL.engine = c['seg_engine']
+        self.cfg = cfg
+        n_distinct = min(n_frames, DISTINCT_FRAMES)
+        streams = [BenchStream(h, w, grid, max(n_distinct, 40), scene='room_%d_%d' % (rank, k), seed=1911 + rank + 101 * k, n_classes=c['n_classes'])
+                   for k in range(S)]
+        self.db = Database(ManyScenes(streams), database_config(cfg))
+        pipe = Pipeline(cfg)
+        seeded_weights(pipe)
+        self.pipe = pipe.to(dev).eval()
+        predict = c['semantics'] and c['strategy'] == 'predict'
+        image = torch.zeros((1, 3, h, w), device=dev)
+        self.batches = []
+        for i in range(n_distinct):
+            row = []
+            for st in streams:
+                f = st.frame(i)
+                b = {'image': torch.from_numpy(f['image']).unsqueeze(0).to(dev) if predict else image, 'frame_id': [f['frame_id']],
+                     st.depth_key: torch.from_numpy(f[st.depth_key]).unsqueeze(0).to(dev), 'mask': torch.from_numpy(f['mask']).unsqueeze(0).to(dev),
+                     'extrinsics': torch.from_numpy(f['extrinsics']).unsqueeze(0), 'intrinsics': torch.from_numpy(f['intrinsics']).unsqueeze(0)}
+                if c['semantics']:
+                    b['semantic_gt'] = torch.from_numpy(f['semantic_gt']).unsqueeze(0).to(dev)
+                row.append(b)
+            self.batches.append(row)
+
+    def run(self, steps, warmup, sync, repeats=3):
+        times = []
+        with torch.no_grad():
+            for i in range(warmup):
+                self.pipe.fuse_many(self.batches[i % len(self.batches)], self.db, self.dev)
+            at = warmup
+            host = []
+            for _ in range(repeats):
+                sync()
+                t0 = time.perf_counter()
+                for i in range(at, at + steps):
+                    self.pipe.fuse_many(self.batches[i % len(self.batches)], self.db, self.dev)
+                host.append(time.perf_counter() - t0)  # the host's share: enqueue time of the loop (the queue never blocks it here)
+                sync()
+                times.append(time.perf_counter() - t0)
+                at += steps
+            self.pipe.check()
+        self.host_ms_per_call = 1e3 * sorted(host)[len(host) // 2] / steps
+        times.sort()
+        med = times[len(times) // 2]
+        return {'workload': workload_name(self.c) + ' - %d scenes per GPU, one frame of each per Pipeline.fuse_many call' % self.S, 'scenes_per_gpu': self.S,
+                'value': self.S * steps / med, 'unit': 'frames/sec (all scenes)', 'ms_per_call': 1e3 * med / steps, 'steps': steps, 'warmup': warmup,
+                'repeats': repeats, 'value_min': self.S * steps / times[-1], 'value_max': self.S * steps / times[0],
+                'host_enqueue_ms_per_call': self.host_ms_per_call}
+
+
 def kernel_table(kernels, c, N, peak_tf, total_macs):
     """Adds algorithmic GFLOP / TFLOP/s / fraction of the arithmetic's MFMA peak to the profiled per-kernel times
     (geometry-only net; with the semantic head the table carries times only)."""
@@ -541,6 +614,7 @@ def main():
                     help="AdapNet++ convolutions: 'hip' = SEGCONV MFMA kernels (default), 'torch' = module forward on MIOpen")
     ap.add_argument('--mode', default='fast', choices=['fast', 'parity'])
     ap.add_argument('--arith', default='f16x3', choices=['f16x3', 'f32'], help='net MFMA arithmetic (include/ojf.h OJF_ARITH_*)')
+    ap.add_argument('--scenes', type=int, default=0, help='S > 1: time Pipeline.fuse_many over S scenes on this GPU instead (prints its own line)')
     ap.add_argument('--cpu-frames', type=int, default=10, help='timed frames of the CPU baseline (0 = skip)')
     ap.add_argument('--secondary', type=int, default=None,
                     help='steps of each secondary workload (default: 60 when the headline runs with default flags on 1 GPU, else 0)')
@@ -614,6 +688,14 @@ def main():
         if world > 1:
             torch.distributed.destroy_process_group()
         return
+    if args.scenes > 1:  # aggregate of S scenes on one GPU (a secondary measurement: the headline stays one scene per GPU)
+        mc = ManyCase(head, dev, rank, total, args.scenes)
+        r = mc.run(args.steps, args.warmup, sync, args.repeats)
+        if rank == 0:
+            print(json.dumps(dict(r, metric=metric + ', %d scenes per GPU (fuse_many)' % args.scenes, n_gpus=world)))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     case = Case(head, dev, rank, total)
     if args.lean:
         res = case.run(args.steps, args.warmup, sync, profile_frames=0, kernel_reps=0, repeats=1)
@@ -663,6 +745,16 @@ def main():
                     del case2
                 except Exception as e:  # a secondary workload must not take the headline line down with it
                     r2 = {'workload': workload_name(c2), 'error': repr(e)}
+                torch.cuda.empty_cache()
+                secondary.append(r2)
+            for extra, S in ((dict(), 2), (dict(), 4), (dict(semantics=True, strategy='predict'), 4)):
+                c2 = dict(head, **extra)  # several scenes per GPU (fuse_many): aggregate frames/s, next to the S = 1 legs above
+                try:
+                    mc = ManyCase(c2, dev, rank, 3 * n_sec + 10, S)
+                    r2 = mc.run(n_sec, 10, sync, 3)
+                    del mc
+                except Exception as e:
+                    r2 = {'workload': workload_name(c2) + ' - %d scenes per GPU' % S, 'error': repr(e)}
                 torch.cuda.empty_cache()
                 secondary.append(r2)
             try:  # BASELINE configs[3]: the training frame step on this GPU (no collective at N = 1)

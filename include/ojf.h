@@ -238,6 +238,18 @@ int ojf_segconv_forward(const ojf_segconv *conv, const float *in_dev, int in_str
 int ojf_segconv_forward_group(int n, const ojf_segconv *const *convs, const float *const *ins_dev, int in_stride,
                               float *const *outs_dev, int out_stride, const float *const *ress_dev, int res_stride,
                               const float *const *muls_dev, int mul_stride, int act, int h, int w, ojf_stream_t stream);
+/* The same on `batch` (1..64) images per tensor: every tensor is [batch, h, w, C] NHWC (batch-major, same row stride), the
+ * frames of several scenes through the 2-D network at once (Pipeline.fuse_many).  A pixel's result does not depend on
+ * the batch it travels in as long as the launch takes the same kernel form (the form is chosen by the number of pixel
+ * tiles, and the forms differ in the order they add the K blocks): equal to the single-image call up to that rounding
+ * (a few 1e-7 relative).  The weights of a layer are fetched once per launch whatever the batch: on the 15x20 / 30x40
+ * maps, where a single frame leaves the matrix pipe idle behind the weight stream, this is what batching buys. */
+int ojf_segconv_forward_batch(const ojf_segconv *conv, int batch, const float *in_dev, int in_stride, float *out_dev, int out_stride,
+                              const float *res_dev, int res_stride, const float *mul_dev, int mul_stride, int act, int h,
+                              int w, ojf_stream_t stream);
+int ojf_segconv_forward_group_batch(int n, int batch, const ojf_segconv *const *convs, const float *const *ins_dev, int in_stride,
+                                    float *const *outs_dev, int out_stride, const float *const *ress_dev, int res_stride,
+                                    const float *const *muls_dev, int mul_stride, int act, int h, int w, ojf_stream_t stream);
 
 /* ---- FUSION NET, TRAINING (modules/pipeline.py:301-363 with the net in train() mode; csrc/ojf_net_train.h) -------
  * One layer unit of the reference's Sequentials (modules/model.py:4-52,115-141) - conv -> BatchNorm2d (batch
@@ -375,6 +387,8 @@ int ojf_extract_to_net(const float *depth_dev, const float *Kinv_host, const flo
 int ojf_seg_pack_input(const float *src_dev, int chan_stride, float divisor, int h, int w, float *out_dev, int out_stride,
                        ojf_stream_t stream);
 int ojf_seg_maxpool(const float *in_dev, int in_stride, int c, int h, int w, float *out_dev, int out_stride, ojf_stream_t stream);
+int ojf_seg_maxpool_batch(int batch, const float *in_dev, int in_stride, int c, int h, int w, float *out_dev, int out_stride,
+                          ojf_stream_t stream);  /* [batch, h, w, C] tensors */
 int ojf_seg_mean(const float *in_dev, int in_stride, int c, int npix, float *partial_dev /* 32 * c floats of scratch */,
                  float *out_dev, ojf_stream_t stream);
 int ojf_seg_broadcast(const float *vec_dev, const float *mul_dev, int mul_stride, int c, int npix, float *out_dev, int out_stride,

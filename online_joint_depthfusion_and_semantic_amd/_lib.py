@@ -80,7 +80,9 @@ SIGNATURES = {
     'ojf_segdeconv_create': (_i, [_c.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i]),
     'ojf_segconv_destroy': (None, [_vp]),
     'ojf_segconv_forward': (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    'ojf_segconv_forward_batch': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'ojf_segconv_forward_group': (_i, [_i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    'ojf_segconv_forward_group_batch': (_i, [_i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'ojf_train_packed_floats': (_sz, [_i, _i, _i]),
     'ojf_train_pack': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'ojf_train_conv': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -111,6 +113,7 @@ SIGNATURES = {
     'ojf_train_fusion_loss_bwd': (_i, [_vp, _vp, _c.c_longlong, _i, _f, _f, _vp, _vp, _vp]),
     'ojf_seg_pack_input': (_i, [_vp, _i, _f, _i, _i, _vp, _i, _vp]),
     'ojf_seg_maxpool': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    'ojf_seg_maxpool_batch': (_i, [_i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     'ojf_seg_mean': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     'ojf_seg_broadcast': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     'ojf_seg_softmax_max': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),

@@ -44,7 +44,7 @@ class _Unit:
         y = self.c1(x, act='relu')
         if self.multi:
             half = self.c2a.c_out
-            cat = nhwc(2 * half, y.shape[2], y.shape[3], x.device, zero=False)
+            cat = nhwc(2 * half, y.shape[2], y.shape[3], x.device, zero=False, batch=y.shape[0])
             self.c2a(y, out=cat[:, :half], act='relu')
             self.c2b(y, out=cat[:, half:], act='relu')
             self.c3.set_dropout(self.rng if self.module.dropout else None, self.drop_id)  # (read at call time, like the module)
@@ -61,7 +61,7 @@ def _units(units, xs):
     ys = segconv.group([u.c1 for u in units], xs, act='relu')
     if u0.multi:
         half = u0.c2a.c_out
-        cats = [nhwc(2 * half, y.shape[2], y.shape[3], y.device, zero=False) for y in ys]
+        cats = [nhwc(2 * half, y.shape[2], y.shape[3], y.device, zero=False, batch=y.shape[0]) for y in ys]
         segconv.group([u.c2a for u in units] + [u.c2b for u in units], ys + ys,
                       outs=[c[:, :half] for c in cats] + [c[:, half:] for c in cats], act='relu')
         for u in units:
@@ -95,7 +95,7 @@ def _easpps(aspps, xs, outs):
     a0 = aspps[0]
     h, w = xs[0].shape[2:]
     n = a0.b1.c_out
-    cats = [nhwc(5 * n, h, w, x.device, zero=False) for x in xs]
+    cats = [nhwc(5 * n, h, w, x.device, zero=False, batch=x.shape[0]) for x in xs]
     segconv.group([a.b1 for a in aspps], xs, outs=[c[:, :n] for c in cats], act='relu')
     depth = len(a0.cascades[0])
     ys = [x for x in xs for _ in a0.cascades]  # (eASPP, cascade) pairs, eASPP-major
@@ -145,7 +145,7 @@ class _EASPP:
     def __call__(self, x, out):
         h, w = x.shape[2:]
         n = self.b1.c_out
-        cat = nhwc(5 * n, h, w, x.device, zero=False)
+        cat = nhwc(5 * n, h, w, x.device, zero=False, batch=x.shape[0])
         self.b1(x, out=cat[:, :n], act='relu')
         for i, convs in enumerate(self.cascades):
             y = x
@@ -206,17 +206,18 @@ class SegEngine:
         segconv.pool_fc([conv], [x], [out], act='relu', muls=[skip])
 
     def forward(self, mod1, mod2=None):
-        """Logits [1, n_classes, H, W] (channels_last memory) = AdapNet.forward(...)[0]."""
+        """Logits [B, n_classes, H, W] (channels_last memory) = AdapNet.forward(...)[0]; B images per call run as ONE
+        pass (every tensor [B, H, W, C], every layer one launch: the weights of a layer are fetched once for all images)."""
         dev = mod1.device
-        H, W = mod1.shape[2:]
-        assert mod1.shape[0] == 1 and H % 16 == 0 and W % 16 == 0, 'SegEngine: batch 1, frame sides multiples of 16'
+        B, _, H, W = mod1.shape
+        assert H % 16 == 0 and W % 16 == 0 and (mod2 is None or mod2.shape[0] == B), 'SegEngine: frame sides multiples of 16'
         h4, w4, h8, w8, h16, w16 = H // 4, W // 4, H // 8, W // 8, H // 16, W // 16
         k = 2 if self.fusion else 1
-        s2 = nhwc(24 * k, h4, w4, dev, zero=False)   # skip2 of both modalities side by side = SSMA's concatenation
-        s1 = nhwc(24 * k, h8, w8, dev, zero=False)
-        top = nhwc(256 * k, h16, w16, dev, zero=False)
-        cat2 = nhwc(280, h8, w8, dev, zero=False)    # decoder stage 2 input: (deconv1 output, skip1)
-        cat3 = nhwc(280, h4, w4, dev, zero=False)    # decoder stage 3 input: (stage 2 output, skip2)
+        s2 = nhwc(24 * k, h4, w4, dev, zero=False, batch=B)   # skip2 of both modalities side by side = SSMA's concatenation
+        s1 = nhwc(24 * k, h8, w8, dev, zero=False, batch=B)
+        top = nhwc(256 * k, h16, w16, dev, zero=False, batch=B)
+        cat2 = nhwc(280, h8, w8, dev, zero=False, batch=B)    # decoder stage 2 input: (deconv1 output, skip1)
+        cat3 = nhwc(280, h4, w4, dev, zero=False, batch=B)    # decoder stage 3 input: (stage 2 output, skip2)
         grouped = self.fusion and not os.environ.get('OJF_SEG_TWO_STREAMS')  # (A/B switch: the round-3 flow on two streams)
         if grouped:
             # The two modality encoders have one architecture: they run in lock-step, every layer ONE grouped launch
@@ -265,6 +266,28 @@ class SegEngine:
         return self.deconv3(y, zero_pad=False)  # (the classes' pad channels are read by nobody)
 
     __call__ = forward
+
+    def predict_many(self, images, depths=None):
+        """``[predict(i, d) for i, d in zip(images, depths)]`` as ONE batched pass: -> (scores f32 [B, H*W], ids u8 [B, H*W]).
+        The frames of several scenes (Pipeline.fuse_many); per-pixel results equal the single-frame pass up to the rounding
+        of a different K-block order where the batch changes a layer's kernel form (include/ojf.h)."""
+        B = len(images)
+        H, W = images[0].shape[-2:]
+        dev = images[0].device
+        first = nhwc(8, H, W, dev, zero=False, batch=B)
+        for b, im in enumerate(images):
+            segconv.pack_input(im.contiguous(), 255.0, out=first[b:b + 1])
+        second = None
+        if depths is not None and depths[0] is not None:
+            second = nhwc(8, H, W, dev, zero=False, batch=B)
+            for b, d in enumerate(depths):
+                segconv.pack_input(d.contiguous(), 1.0, out=second[b:b + 1])
+        if self.fusion:
+            logits = self.forward(first, second if second is not None else first)
+        else:
+            logits = self.forward(second if second is not None else first)
+        scores, ids = segconv.softmax_max(logits)
+        return scores.view(B, H * W), ids.view(B, H * W)
 
     def predict(self, image, depth=None):
         """Pipeline._segmentation(...).max(-1) (modules/pipeline.py:42-60,183): raw batch tensors in - ``image`` [1,3,H,W]

@@ -68,6 +68,7 @@ struct SegArgs {
     const float *bias;     // [tiles*16]
     int in_stride, out_stride, res_stride, mul_stride;  // floats per pixel row
     int H, W, Ho, Wo;
+    int B;                 // images per tensor ([B, H, W, C] rows, batch-major): a pixel index runs over B * Ho * Wo
     int stride, pad, dil, ksize;
     int c8;                // groups of 8 input channels per tap
     int n_kb;              // K blocks of 4 (tap, group) entries
@@ -222,8 +223,9 @@ __device__ __forceinline__ void seg_epilogue(const SegArgs &a, const f32x4 (&acc
             }
             size_t row = (size_t)p;
             if (a.up > 1) {
-                const int oy = p / a.Wo, ox = p - oy * a.Wo;
-                row = ((size_t)oy * a.up + ay) * ((size_t)a.Wo * a.up) + (size_t)ox * a.up + ax;
+                const int b = p / (a.Ho * a.Wo), q = p - b * (a.Ho * a.Wo);
+                const int oy = q / a.Wo, ox = q - oy * a.Wo;
+                row = (size_t)b * a.Ho * a.Wo * a.up * a.up + ((size_t)oy * a.up + ay) * ((size_t)a.Wo * a.up) + (size_t)ox * a.up + ax;
             }
             float *o = a.out + row * a.out_stride + co;
             if ((full || co + 3 < a.pad_to) && a.vec_store) {
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void segconv_kernel(const S
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ct0 = SPLITK ? by * MW : (by * WM + wave % WM) * MW;
     const int pt0 = SPLITK ? bx * NW : (bx * WN + wave / WM) * NW;
-    const int n_pix = a.Ho * a.Wo;
+    const int n_pix = a.B * a.Ho * a.Wo;
     if (!SPLITK && (ct0 >= a.n_ct || pt0 * 16 >= n_pix)) return;  // wave-uniform (n_ct is a multiple of 4 >= MW)
     const int col = lane & 15, kg = lane >> 4;
     int kb0 = 0, kb1 = a.n_kb;
@@ -264,15 +266,17 @@ __global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void segconv_kernel(const S
         kb1 = kb0 + per < a.n_kb ? kb0 + per : a.n_kb;
     }
 
-    int iy0[NW], ix0[NW];
+    int iy0[NW], ix0[NW], img0[NW];
     bool live[NW];
 #pragma unroll
     for (int n = 0; n < NW; ++n) {
         const int p = (pt0 + n) * 16 + col;
         live[n] = p < n_pix;
-        const int oy = p / a.Wo, ox = p - oy * a.Wo;
+        const int b = p / (a.Ho * a.Wo), q = p - b * (a.Ho * a.Wo);  // image, pixel inside it
+        const int oy = q / a.Wo, ox = q - oy * a.Wo;
         iy0[n] = oy * a.stride - a.pad;
         ix0[n] = ox * a.stride - a.pad;
+        img0[n] = b * a.H * a.W;
     }
     // this lane group's walk over the (tap, channel group) entries: entry kb*4 + kg of K block kb
     const int e0 = kb0 * 4 + kg;
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void segconv_kernel(const S
         for (int n = 0; n < NW; ++n) {
             const int iy = iy0[n] + dy, ix = ix0[n] + dx;
             const bool ok = in_range && live[n] && ty < a.ksize && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const unsigned off = ok ? (unsigned)(((iy * a.W + ix) * a.in_stride + cg * 8) * 4) : 0xfffffff0u;
+            const unsigned off = ok ? (unsigned)(((img0[n] + iy * a.W + ix) * a.in_stride + cg * 8) * 4) : 0xfffffff0u;
             fa[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
             fb[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off + 16u : 0xfffffff0u, 0, 0));
         }
@@ -384,19 +388,21 @@ __global__ __launch_bounds__(256) void segconv_wide_kernel(const SegGroupArgs gr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ct0 = by * MW;
     const int pt0 = (bx * 4 + wave) * NW;
-    const int n_pix = a.Ho * a.Wo;
+    const int n_pix = a.B * a.Ho * a.Wo;
     const int col = lane & 15, kg = lane >> 4;
     const int n_kb = a.n_kb;
 
-    int iy0[NW], ix0[NW];
+    int iy0[NW], ix0[NW], img0[NW];
     bool live[NW];
 #pragma unroll
     for (int n = 0; n < NW; ++n) {
         const int p = (pt0 + n) * 16 + col;
         live[n] = p < n_pix;
-        const int oy = p / a.Wo, ox = p - oy * a.Wo;
+        const int b = p / (a.Ho * a.Wo), q = p - b * (a.Ho * a.Wo);  // image, pixel inside it
+        const int oy = q / a.Wo, ox = q - oy * a.Wo;
         iy0[n] = oy * a.stride - a.pad;
         ix0[n] = ox * a.stride - a.pad;
+        img0[n] = b * a.H * a.W;
     }
     int tap = kg / a.c8, cg = kg - tap * a.c8;
     int ty = tap / a.ksize, tx = tap - ty * a.ksize;
@@ -429,7 +435,7 @@ __global__ __launch_bounds__(256) void segconv_wide_kernel(const SegGroupArgs gr
         for (int n = 0; n < NW; ++n) {
             const int iy = iy0[n] + dy, ix = ix0[n] + dx;
             const bool ok = in_range && live[n] && ty < a.ksize && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const unsigned off = ok ? (unsigned)(((iy * a.W + ix) * a.in_stride + cg * 8) * 4) : 0xfffffff0u;
+            const unsigned off = ok ? (unsigned)(((img0[n] + iy * a.W + ix) * a.in_stride + cg * 8) * 4) : 0xfffffff0u;
             fa[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
             fb[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off + 16u : 0xfffffff0u, 0, 0));
         }
@@ -500,19 +506,21 @@ __global__ __launch_bounds__(256) void segconv_tile_kernel(const SegGroupArgs gr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ct0 = by * MW;
     const int pt0 = (bx * 4 + wave) * NW;
-    const int n_pix = a.Ho * a.Wo;
+    const int n_pix = a.B * a.Ho * a.Wo;
     const int col = lane & 15, kg = lane >> 4;
     const int n_kb = a.n_kb;
 
-    int iy0[NW], ix0[NW];
+    int iy0[NW], ix0[NW], img0[NW];
     bool live[NW];
 #pragma unroll
     for (int n = 0; n < NW; ++n) {
         const int p = (pt0 + n) * 16 + col;
         live[n] = p < n_pix;
-        const int oy = p / a.Wo, ox = p - oy * a.Wo;
+        const int b = p / (a.Ho * a.Wo), q = p - b * (a.Ho * a.Wo);  // image, pixel inside it
+        const int oy = q / a.Wo, ox = q - oy * a.Wo;
         iy0[n] = oy * a.stride - a.pad;
         ix0[n] = ox * a.stride - a.pad;
+        img0[n] = b * a.H * a.W;
     }
     int tap = kg / a.c8, cg = kg - tap * a.c8;
     int ty = tap / a.ksize, tx = tap - ty * a.ksize;
@@ -550,7 +558,7 @@ __global__ __launch_bounds__(256) void segconv_tile_kernel(const SegGroupArgs gr
             for (int n = 0; n < NW; ++n) {
                 const int iy = iy0[n] + dy, ix = ix0[n] + dx;
                 const bool ok = in_range && live[n] && ty < a.ksize && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-                const unsigned off = ok ? (unsigned)(((iy * a.W + ix) * a.in_stride + cg * 8) * 4) : 0xfffffff0u;
+                const unsigned off = ok ? (unsigned)(((img0[n] + iy * a.W + ix) * a.in_stride + cg * 8) * 4) : 0xfffffff0u;
                 fa[u][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
                 fb[u][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off + 16u : 0xfffffff0u, 0, 0));
             }
@@ -735,9 +743,10 @@ namespace ojf {
 namespace {
 
 // argument checks + kernel arguments of one convolution; the launch geometry comes back in Ho / Wo of `a`
-int seg_fill(const ojf_segconv *c, const float *in, int in_stride, float *out, int out_stride, const float *res, int res_stride,
+int seg_fill(const ojf_segconv *c, int batch, const float *in, int in_stride, float *out, int out_stride, const float *res, int res_stride,
              const float *mul, int mul_stride, int act, int h, int w, SegArgs &a)
 {
+    if (batch < 1 || batch > 64) return fail("ojf_segconv_forward: batch must be 1..64");
     if (!c || !in || !out) return fail("ojf_segconv_forward: null pointer argument");
     const bool zero_pad = (act & OJF_SEG_ACT_ZERO_PAD) != 0;
     act &= ~OJF_SEG_ACT_ZERO_PAD;
@@ -749,11 +758,11 @@ int seg_fill(const ojf_segconv *c, const float *in, int in_stride, float *out, i
     const int span = c->dil * (c->ksize - 1) + 1;
     const int Ho = (h + 2 * c->pad - span) / c->stride + 1, Wo = (w + 2 * c->pad - span) / c->stride + 1;
     if (Ho < 1 || Wo < 1) return fail("ojf_segconv_forward: empty output");
-    const size_t in_bytes = ((size_t)h * w - 1) * in_stride * 4 + (size_t)c->c8 * 32;
+    const size_t in_bytes = ((size_t)batch * h * w - 1) * in_stride * 4 + (size_t)c->c8 * 32;
     if (in_bytes >= 0xfffffff0ull) return fail("ojf_segconv_forward: input larger than 4 GB");
     a.in = in; a.out = out; a.res = res; a.mul = mul; a.wp = c->wp; a.rinv = c->rinv; a.bias = c->bias;
     a.in_stride = in_stride; a.out_stride = out_stride; a.res_stride = res_stride; a.mul_stride = mul_stride;
-    a.H = h; a.W = w; a.Ho = Ho; a.Wo = Wo; a.stride = c->stride; a.pad = c->pad; a.dil = c->dil; a.ksize = c->ksize;
+    a.H = h; a.W = w; a.Ho = Ho; a.Wo = Wo; a.B = batch; a.stride = c->stride; a.pad = c->pad; a.dil = c->dil; a.ksize = c->ksize;
     a.c8 = c->c8; a.n_kb = c->n_kb; a.n_ct = c->n_ct; a.c_out = c->c_out; a.act = act;
     a.vec_store = (out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) ? 1 : 0;
     a.in_bytes = (unsigned)in_bytes;
@@ -790,7 +799,7 @@ unsigned seg_map(SegMap &m, int X, int Y, int Z)
 int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
 {
     const SegArgs &a = g.a[0];
-    const int n_pt = (a.Ho * a.Wo + 15) / 16, groups = a.n_ct / kMW;  // pixel tiles, 64-channel groups
+    const int n_pt = (a.B * a.Ho * a.Wo + 15) / 16, groups = a.n_ct / kMW;  // pixel tiles, 64-channel groups
     // Enough independent waves (>= 4 per CU) to hide the operand latency: waves own their (channels, pixels) pair.
     // Otherwise the four waves of a block split K (when K is long enough to be worth the LDS reduction).
     const long waves2 = (long)groups * ((n_pt + 1) / 2) * n;
@@ -873,24 +882,31 @@ int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
 }  // namespace
 }  // namespace ojf
 
-OJF_API int ojf_segconv_forward(const ojf_segconv *c, const float *in, int in_stride, float *out, int out_stride, const float *res,
-                                int res_stride, const float *mul, int mul_stride, int act, int h, int w, ojf_stream_t stream)
+OJF_API int ojf_segconv_forward_batch(const ojf_segconv *c, int batch, const float *in, int in_stride, float *out, int out_stride,
+                                      const float *res, int res_stride, const float *mul, int mul_stride, int act, int h, int w,
+                                      ojf_stream_t stream)
 {
     using namespace ojf;
     SegGroupArgs g;
-    if (int rc = seg_fill(c, in, in_stride, out, out_stride, res, res_stride, mul, mul_stride, act, h, w, g.a[0])) return rc;
+    if (int rc = seg_fill(c, batch, in, in_stride, out, out_stride, res, res_stride, mul, mul_stride, act, h, w, g.a[0])) return rc;
     return seg_launch(g, 1, as_stream(stream));
 }
 
-OJF_API int ojf_segconv_forward_group(int n, const ojf_segconv *const *convs, const float *const *ins, int in_stride, float *const *outs,
-                                      int out_stride, const float *const *ress, int res_stride, const float *const *muls,
-                                      int mul_stride, int act, int h, int w, ojf_stream_t stream)
+OJF_API int ojf_segconv_forward(const ojf_segconv *c, const float *in, int in_stride, float *out, int out_stride, const float *res,
+                                int res_stride, const float *mul, int mul_stride, int act, int h, int w, ojf_stream_t stream)
+{
+    return ojf_segconv_forward_batch(c, 1, in, in_stride, out, out_stride, res, res_stride, mul, mul_stride, act, h, w, stream);
+}
+
+OJF_API int ojf_segconv_forward_group_batch(int n, int batch, const ojf_segconv *const *convs, const float *const *ins, int in_stride,
+                                            float *const *outs, int out_stride, const float *const *ress, int res_stride,
+                                            const float *const *muls, int mul_stride, int act, int h, int w, ojf_stream_t stream)
 {
     using namespace ojf;
     if (n < 1 || n > kSegGroup || !convs || !ins || !outs) return fail("ojf_segconv_forward_group: 1..8 members, non-null arrays");
     SegGroupArgs g;
     for (int i = 0; i < n; ++i) {
-        if (int rc = seg_fill(convs[i], ins[i], in_stride, outs[i], out_stride, ress ? ress[i] : nullptr, res_stride,
+        if (int rc = seg_fill(convs[i], batch, ins[i], in_stride, outs[i], out_stride, ress ? ress[i] : nullptr, res_stride,
                               muls ? muls[i] : nullptr, mul_stride, act, h, w, g.a[i])) return rc;
         const SegArgs &a = g.a[i], &b = g.a[0];
         if (a.n_kb != b.n_kb || a.n_ct != b.n_ct || a.c8 != b.c8 || a.c_out != b.c_out || a.ksize != b.ksize || a.stride != b.stride ||
@@ -898,4 +914,11 @@ OJF_API int ojf_segconv_forward_group(int n, const ojf_segconv *const *convs, co
             return fail("ojf_segconv_forward_group: the members must share channels, kernel size, stride and output size");
     }
     return seg_launch(g, n, as_stream(stream));
+}
+
+OJF_API int ojf_segconv_forward_group(int n, const ojf_segconv *const *convs, const float *const *ins, int in_stride, float *const *outs,
+                                      int out_stride, const float *const *ress, int res_stride, const float *const *muls,
+                                      int mul_stride, int act, int h, int w, ojf_stream_t stream)
+{
+    return ojf_segconv_forward_group_batch(n, 1, convs, ins, in_stride, outs, out_stride, ress, res_stride, muls, mul_stride, act, h, w, stream);
 }

@@ -29,14 +29,16 @@ __global__ __launch_bounds__(256) void seg_pack_input_kernel(const float *src, i
 // one lane per (output pixel, 4-channel group); -inf padding like torch (NaN inputs propagate: v > m is false for NaN
 // m only, so a NaN in the window wins through the explicit test)
 __global__ __launch_bounds__(256) void seg_maxpool_kernel(const float *in, int in_stride, int C, int H, int W, float *out,
-                                                           int out_stride, int Ho, int Wo)
+                                                           int out_stride, int Ho, int Wo, int B)
 {
     const int c4 = (C + 3) / 4;
     const long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (item >= (long)Ho * Wo * c4) return;
+    if (item >= (long)B * Ho * Wo * c4) return;
     const int cg = (int)(item % c4);
-    const int po = (int)(item / c4);
-    const int oy = po / Wo, ox = po - oy * Wo;
+    const int po = (int)(item / c4);  // output pixel over the B images
+    const int b = po / (Ho * Wo), q = po - b * (Ho * Wo);
+    const int oy = q / Wo, ox = q - oy * Wo;
+    in += (size_t)b * H * W * in_stride;
     float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     for (int dy = 0; dy < 3; ++dy) {
         const int y = 2 * oy - 1 + dy;
@@ -270,15 +272,20 @@ OJF_API int ojf_seg_pack_input(const float *src, int chan_stride, float divisor,
     return check_hip(hipGetLastError(), "seg_pack_input_kernel launch");
 }
 
-OJF_API int ojf_seg_maxpool(const float *in, int in_stride, int c, int h, int w, float *out, int out_stride, ojf_stream_t stream)
+OJF_API int ojf_seg_maxpool_batch(int batch, const float *in, int in_stride, int c, int h, int w, float *out, int out_stride, ojf_stream_t stream)
 {
     using namespace ojf;
-    if (!in || !out || c < 1 || h < 1 || w < 1 || in_stride < c || out_stride < c) return fail("ojf_seg_maxpool: bad argument");
+    if (!in || !out || c < 1 || h < 1 || w < 1 || in_stride < c || out_stride < c || batch < 1 || batch > 64) return fail("ojf_seg_maxpool: bad argument");
     const int Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;  // floor((h + 2 - 3) / 2) + 1
-    const long items = (long)Ho * Wo * ((c + 3) / 4);
+    const long items = (long)batch * Ho * Wo * ((c + 3) / 4);
     hipLaunchKernelGGL(seg_maxpool_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, as_stream(stream), in, in_stride, c, h, w,
-                       out, out_stride, Ho, Wo);
+                       out, out_stride, Ho, Wo, batch);
     return check_hip(hipGetLastError(), "seg_maxpool_kernel launch");
+}
+
+OJF_API int ojf_seg_maxpool(const float *in, int in_stride, int c, int h, int w, float *out, int out_stride, ojf_stream_t stream)
+{
+    return ojf_seg_maxpool_batch(1, in, in_stride, c, h, w, out, out_stride, stream);
 }
 
 OJF_API int ojf_seg_mean(const float *in, int in_stride, int c, int npix, float *partial, float *out, ojf_stream_t stream)

@@ -58,10 +58,10 @@ class Pipeline(torch.nn.Module):
         self._fusion_network.register_load_state_dict_post_hook(_drop_fingerprint)
         mode = getattr(config.SETTINGS, 'integrate_mode', 'fast')
         self._integrate_mode = MODE_PARITY if mode == 'parity' else MODE_FAST
-        self._engine = None
-        self._engine_key = None
+        # per-slot device state (engine with its activation buffers, est rows, sample planes, integrate workspaces): slot 0
+        # is the frame step of fuse() / fuse_training(); fuse_many() runs scene i of a call on slot i and its own stream
+        self._slots = {}
         self._workspaces = {}
-        self._est = None
         self.profile = False  # True / N: fuse() brackets its three stages with HIP events on every (N-th) frame
         self._frames_fused = 0
         self._marks = []
@@ -115,6 +115,7 @@ class Pipeline(torch.nn.Module):
         if self._engine is not None:
             if self._guard_policy() == 'f32':
                 self._guard_recover()  # (a tripped frame at the end of a scene: nothing after it polled the flag)
+            torch.cuda.synchronize(self.device)  # (every slot's stream)
             self._engine.check()
         elif self.__dict__.get('_hip_train') is not None:  # training only: the executor's forward pass shares the guard
             from . import _lib
@@ -135,22 +136,36 @@ class Pipeline(torch.nn.Module):
         # the load_state_dict hook below at once and by the re-collection within 64 frames otherwise
         return (len(cache[1]), sum(t._version for t in cache[1]), sum(t.data_ptr() for t in cache[1]) & 0xffffffffffff)
 
-    def _get_engine(self, h, w, device):
-        arith = self.config.FUSION_MODEL.get('arithmetic', 'f16x3')
-        key = (h, w, str(device), arith, self._weights_fingerprint())
-        if self._engine is None or self._engine_key != key:
-            if self._engine is not None:
-                self._engine.close()
-            self._engine = FusionNetEngine(self._fusion_network, h, w, device,
-                                           arithmetic=arith)
-            self._engine_key = key
-            self._est = torch.empty((h * w, self.n_points), dtype=torch.float32, device=device)
-            self._fv = torch.empty((self.n_points, h * w), dtype=torch.float32, device=device)  # sample planes
-            self._fw = torch.empty((self.n_points, h * w), dtype=torch.float32, device=device)
-        return self._engine
+    class _Slot:
+        engine = key = est = fv = fw = None
 
-    def _get_workspace(self, shape, h, w, device):
-        key = (tuple(shape), h, w, self._integrate_mode)
+    # slot 0 under the names the rest of the package (and bench.py) knows
+    _engine = property(lambda self: self._slots[0].engine if 0 in self._slots else None)
+    _est = property(lambda self: self._slots[0].est if 0 in self._slots else None)
+    _fv = property(lambda self: self._slots[0].fv if 0 in self._slots else None)
+    _fw = property(lambda self: self._slots[0].fw if 0 in self._slots else None)
+
+    def _get_slot(self, h, w, device, slot=0, fingerprint=None):
+        arith = self.config.FUSION_MODEL.get('arithmetic', 'f16x3')
+        key = (h, w, str(device), arith, fingerprint if fingerprint is not None else self._weights_fingerprint())
+        sl = self._slots.get(slot)
+        if sl is None:
+            sl = self._slots[slot] = Pipeline._Slot()
+        if sl.engine is None or sl.key != key:
+            if sl.engine is not None:
+                sl.engine.close()
+            sl.engine = FusionNetEngine(self._fusion_network, h, w, device, arithmetic=arith)
+            sl.key = key
+            sl.est = torch.empty((h * w, self.n_points), dtype=torch.float32, device=device)
+            sl.fv = torch.empty((self.n_points, h * w), dtype=torch.float32, device=device)  # sample planes
+            sl.fw = torch.empty((self.n_points, h * w), dtype=torch.float32, device=device)
+        return sl
+
+    def _get_engine(self, h, w, device):
+        return self._get_slot(h, w, device).engine
+
+    def _get_workspace(self, shape, h, w, device, slot=0):
+        key = (tuple(shape), h, w, self._integrate_mode, slot)
         if key not in self._workspaces:
             self._workspaces[key] = ops.IntegrateWorkspace(shape, h, w, self.config.FUSION_MODEL.n_tail_points,
                                                            self._integrate_mode, device)
@@ -267,6 +282,55 @@ class Pipeline(torch.nn.Module):
         scores = scores.to(self.device).float().reshape(h * w).contiguous()
         return sem_ids, scores
 
+    def _frame_semantics_many(self, batches):
+        """``[_frame_semantics(b) for b in batches]``; with ``semantic_strategy: predict`` on the HIP engine the S frames go
+        through the 2-D network as ONE batched pass (SegEngine.predict_many: every layer's weights fetched once for all
+        frames), replayed from a device graph per (S, frame shape)."""
+        cfg = self.config
+        if (not cfg.DATA.semantics or cfg.DATA.semantic_strategy != 'predict' or len(batches) == 1
+                or self._semantic_2d_network.training or cfg.SEMANTIC_2D_MODEL.get('stage', 2) == 1):
+            return [self._frame_semantics(b) for b in batches]
+        with torch.no_grad():
+            engine = self._seg_engine(batches[0]['image'].shape)
+            if engine is None:
+                return [self._frame_semantics(b) for b in batches]
+            in_ = cfg.DATA.input
+            images = [b['image'].to(self.device).float() for b in batches]
+            depths = [b[in_].to(self.device).float() for b in batches] if in_ != 'image' else None
+            S = len(batches)
+            h, w = images[0].shape[-2:]
+            key = (S, tuple(images[0].shape), None if depths is None else tuple(depths[0].shape), str(self.device), id(engine))
+            st = self.__dict__.get('_seg_graph_many')
+            if st is None or st['key'] != key:
+                st = self.__dict__['_seg_graph_many'] = {'key': key, 'graph': None}
+                if cfg.SEMANTIC_2D_MODEL.get('graph', True):
+                    try:
+                        st['images'] = [torch.zeros_like(im) for im in images]
+                        st['depths'] = [torch.zeros_like(d) for d in depths] if depths is not None else None
+                        side = torch.cuda.Stream(device=self.device)
+                        side.wait_stream(torch.cuda.current_stream(self.device))
+                        with torch.cuda.stream(side):
+                            for _ in range(2):
+                                engine.predict_many(st['images'], st['depths'])
+                        torch.cuda.current_stream(self.device).wait_stream(side)
+                        graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(graph):
+                            st['scores'], st['ids'] = engine.predict_many(st['images'], st['depths'])
+                        st['graph'] = graph
+                    except Exception:  # capture is an optimisation only
+                        st['graph'] = None
+            if st['graph'] is None:
+                scores, ids = engine.predict_many(images, depths)
+            else:
+                for dst, src in zip(st['images'], images):
+                    dst.copy_(src, non_blocking=True)
+                if depths is not None:
+                    for dst, src in zip(st['depths'], depths):
+                        dst.copy_(src.reshape(dst.shape), non_blocking=True)
+                st['graph'].replay()
+                scores, ids = st['scores'], st['ids']
+            return [(ids[i].contiguous(), scores[i].contiguous()) for i in range(S)]
+
     def _frames(self, batch, filtered=True):
         """(frame, filtered frame) of pipeline.py:194-199; with ``filtered=False`` the second item is the bool mask
         instead and the integrate kernels apply it themselves (ojf_integrate_masked)."""
@@ -361,10 +425,13 @@ class Pipeline(torch.nn.Module):
             return
         self._guard_remember(batch, database)
 
-    def _fuse_frame(self, batch, database):
+    def _fuse_frame(self, batch, database, slot=0, semantics=None, fingerprint=None):
+        """One frame step on the current stream with the device state of ``slot``; ``semantics`` = (sem_ids, scores) computed
+        by the caller (fuse_many) instead of here."""
         self._shape = batch['image'].shape
-        seg0 = self._mark_segmentation()
-        sem_ids, scores = self._frame_semantics(batch)
+        profiled = slot == 0 and semantics is None
+        seg0 = self._mark_segmentation() if profiled else None
+        sem_ids, scores = self._frame_semantics(batch) if semantics is None else semantics
         frame, mask = self._frames(batch, filtered=False)
         h, w = frame.shape
 
@@ -373,39 +440,77 @@ class Pipeline(torch.nn.Module):
         tsdf, weights = volume['current'], volume['weights']
         Ki, E = ops.camera_arrays(batch['intrinsics'][0], batch['extrinsics'][0])
 
-        eng = self._get_engine(h, w, self.device)
+        sl = self._get_slot(h, w, self.device, slot, fingerprint)
+        eng = sl.engine
         P = self.n_points
-        self._mark(first=True)
+        mark = self._mark if profiled else (lambda first=False: None)
+        mark(first=True)
         if seg0 is not None and self._marks:
             self.__dict__.setdefault('_seg_marks', []).append((seg0, self._marks[-1]))
         use_sem = self.config.FUSION_MODEL.use_semantics
         if eng.fused_input:
             # geometry-only net: the extractor writes the net's input planes itself (one launch less, no sample planes)
             ops.extract_to_net(frame, Ki, E, volume['origin'], volume['resolution'], tsdf, weights, eng)
-            self._mark()
+            mark()
         else:
             ops.extract(frame, Ki, E, volume['origin'], volume['resolution'], tsdf, weights, n_points=P,
-                        out_values=self._fv, out_weights=self._fw, out_stride=h * w, planes=True)
-            self._mark()
-            eng.prepare_input(self._fv, self._fw, frame, sem_ids if use_sem else None, self.n_classes if use_sem else 0,
+                        out_values=sl.fv, out_weights=sl.fw, out_stride=h * w, planes=True)
+            mark()
+            eng.prepare_input(sl.fv, sl.fw, frame, sem_ids if use_sem else None, self.n_classes if use_sem else 0,
                               planes=True)
-        eng.forward(self._est)
-        self._mark()
+        eng.forward(sl.est)
+        mark()
 
         sem = bool(self.config.DATA.semantics)
-        ws = self._get_workspace(tsdf.shape, h, w, self.device)
-        ops.integrate(frame, Ki, E, volume['origin'], volume['resolution'], self._est, tsdf, weights, ws,
+        ws = self._get_workspace(tsdf.shape, h, w, self.device, slot)
+        ops.integrate(frame, Ki, E, volume['origin'], volume['resolution'], sl.est, tsdf, weights, ws,
                       n_points=P, n_tail=self.config.FUSION_MODEL.n_tail_points,
                       trunc=self.config.DATA.init_value,
                       sem_ids=sem_ids if sem else None, sem_scores=scores if sem else None,
                       id_vol=volume['ids_est'] if sem else None, score_vol=volume['scores'] if sem else None,
                       mode=self._integrate_mode, mask=mask)  # filtered frame of pipeline.py:196 formed in the kernels
-        self._mark()
+        mark()
 
         database.state[scene_id] = True  # volumes were updated in place (pipeline.py:239-244)
         database.scenes_est[scene_id].volume = tsdf
         database.fusion_weights[scene_id] = weights
         return
+
+    # ---- several scenes per call (SURVEY.md §7 "hard parts") ------------------------------------------
+    def fuse_many(self, batches, database, device):
+        """``for b in batches: fuse(b, database, device)`` for frames of DISTINCT scenes (one frame each, one frame size),
+        with the frame steps running side by side on the device: scene i of the call uses slot i - its own engine
+        (activation buffers), est rows and integrate workspace - on its own stream, forked from and joined to the current
+        stream.  The scenes' volumes do not overlap, every slot runs the kernels ``fuse`` runs with the same arguments, so the
+        volumes come out bit for bit as from the separate calls; what changes is the schedule - the launches of one frame are
+        latency-bound chains of 600-block kernels, and several of them fill the chip better (the two heads of a semantic net
+        already run this way).  With ``semantic_strategy: predict`` the 2-D network of the S frames runs first, on the current
+        stream (one engine).  The reference has no counterpart: its drivers fuse one frame at a time
+        (test_fusion.py:68-80)."""
+        self.device = torch.device(device)
+        ids = [b['frame_id'][0].split('/')[0] for b in batches]
+        if len(set(ids)) != len(ids):
+            raise ValueError('Pipeline.fuse_many: one frame per scene (the frames of ONE scene depend on each other)')
+        if len(batches) == 1 or self.device.type != 'cuda':
+            for b in batches:
+                self._fuse_frame(b, database)
+            return
+        main = torch.cuda.current_stream(self.device)
+        sems = self._frame_semantics_many(batches)  # (None, None) without semantics; predict: ONE batched pass, this stream
+        fp = self._weights_fingerprint()
+        streams = self.__dict__.setdefault('_slot_streams', [])
+        while len(streams) < len(batches) - 1:
+            streams.append(torch.cuda.Stream(device=self.device))
+        for i, (b, sem) in enumerate(zip(batches, sems)):
+            if i == 0:
+                self._fuse_frame(b, database, 0, sem, fp)
+                continue
+            st = streams[i - 1]
+            st.wait_stream(main)  # (the frame tensors and the labels were produced on the current stream)
+            with torch.cuda.stream(st):
+                self._fuse_frame(b, database, i, sem, fp)
+        for st in streams[:len(batches) - 1]:
+            main.wait_stream(st)
 
     def _training_forward(self, inputs):
         """The net forward of pipeline.py:322 with a graph for ``loss.backward()``: on the libojf training kernels

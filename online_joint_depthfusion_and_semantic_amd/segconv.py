@@ -13,19 +13,21 @@ ACT = {None: 0, 'none': 0, 'relu': 1, 'sigmoid': 2}
 ZERO_PAD = 0x100  # include/ojf.h OJF_SEG_ACT_ZERO_PAD: the launch zeroes the pad channels of rows this module allocated
 
 
-def nhwc(channels, h, w, device, zero=True):
-    """[1, channels, h, w] fp32 tensor in channels_last memory (channels padded by the caller where a consumer
+def nhwc(channels, h, w, device, zero=True, batch=1):
+    """[batch, channels, h, w] fp32 tensor in channels_last memory (channels padded by the caller where a consumer
     reads groups of 8)."""
     make = torch.zeros if zero else torch.empty
-    return make((1, h, w, channels), dtype=torch.float32, device=device).permute(0, 3, 1, 2)
+    return make((batch, h, w, channels), dtype=torch.float32, device=device).permute(0, 3, 1, 2)
 
 
 def _rows(t):
-    """(pointer to channel 0 of pixel 0, floats per pixel row) of an NHWC view [1, C, H, W] (channel slices allowed)."""
-    assert t.dim() == 4 and t.shape[0] == 1 and t.dtype == torch.float32 and t.is_cuda
-    C, H, W = t.shape[1:]
+    """(pointer to channel 0 of pixel 0, floats per pixel row) of an NHWC view [B, C, H, W] (channel slices allowed; the
+    images of a batch follow each other: batch stride = H * W rows)."""
+    assert t.dim() == 4 and t.dtype == torch.float32 and t.is_cuda
+    B, C, H, W = t.shape
     row = t.stride(3) if W > 1 else (t.stride(2) if H > 1 else max(C, 1))
     assert (C == 1 or t.stride(1) == 1) and (H == 1 or W == 1 or t.stride(2) == W * row), 'segconv wants NHWC (channels_last) tensors'
+    assert B == 1 or t.stride(0) == H * W * row, 'segconv wants the images of a batch back to back'
     return t.data_ptr(), row
 
 
@@ -83,17 +85,18 @@ class SegConv:
         """x: NHWC view [1, >=c_in, H, W] whose rows hold round_up(c_in, 8) finite channels.  out: NHWC view to
         write (default: a fresh tensor with c_out channels, padded to a multiple of 8 with zeros)."""
         H, W = x.shape[2:]
+        B = x.shape[0]
         Ho, Wo = self.out_size(H, W)
         flags = 0
         if out is None:  # own rows, padded to a multiple of 8 channels: the launch itself zeroes the pad (no fill kernel)
-            out = nhwc((self.c_out + 7) // 8 * 8, Ho, Wo, x.device, zero=False)[:, :self.c_out]
+            out = nhwc((self.c_out + 7) // 8 * 8, Ho, Wo, x.device, zero=False, batch=B)[:, :self.c_out]
             flags = ZERO_PAD if self.c_out % 8 else 0
-        assert out.shape[1] == self.c_out and tuple(out.shape[2:]) == (Ho, Wo)
+        assert out.shape[1] == self.c_out and tuple(out.shape[2:]) == (Ho, Wo) and out.shape[0] == B
         xp, xs = _rows(x)
         op, os_ = _rows(out)
         rp, rs = _rows(residual) if residual is not None else (None, 0)
         mp, ms = _rows(mul) if mul is not None else (None, 0)
-        rc = self._lib.ojf_segconv_forward(self._h, xp, xs, op, os_, rp, rs, mp, ms, ACT[act] | flags, H, W, _lib.stream_ptr(x.device))
+        rc = self._lib.ojf_segconv_forward_batch(self._h, B, xp, xs, op, os_, rp, rs, mp, ms, ACT[act] | flags, H, W, _lib.stream_ptr(x.device))
         _lib.check(rc, 'ojf_segconv_forward')
         return out
 
@@ -107,13 +110,14 @@ def group(convs, xs, outs=None, act=None, residuals=None, muls=None):
     assert 1 <= n <= 8 and len(xs) == n
     c0 = convs[0]
     H, W = xs[0].shape[2:]
+    B = xs[0].shape[0]
     Ho, Wo = c0.out_size(H, W)
     flags = 0
     if outs is None:
-        outs = [nhwc((c0.c_out + 7) // 8 * 8, Ho, Wo, xs[0].device, zero=False)[:, :c0.c_out] for _ in range(n)]
+        outs = [nhwc((c0.c_out + 7) // 8 * 8, Ho, Wo, xs[0].device, zero=False, batch=B)[:, :c0.c_out] for _ in range(n)]
         flags = ZERO_PAD if c0.c_out % 8 else 0
-    assert len(outs) == n and all(o.shape[1] == c0.c_out and tuple(o.shape[2:]) == (Ho, Wo) for o in outs)
-    assert all(tuple(x.shape[2:]) == (H, W) for x in xs)
+    assert len(outs) == n and all(o.shape[1] == c0.c_out and tuple(o.shape[2:]) == (Ho, Wo) and o.shape[0] == B for o in outs)
+    assert all(tuple(x.shape[2:]) == (H, W) and x.shape[0] == B for x in xs)
 
     def rows(ts):
         if ts is None:
@@ -127,7 +131,7 @@ def group(convs, xs, outs=None, act=None, residuals=None, muls=None):
     rp, rs = rows(residuals)
     mp, ms = rows(muls)
     handles = (ctypes.c_void_p * n)(*[c._h.value for c in convs])
-    rc = c0._lib.ojf_segconv_forward_group(n, handles, xp, xs_, op, os_, rp, rs, mp, ms, ACT[act] | flags, H, W, _lib.stream_ptr(xs[0].device))
+    rc = c0._lib.ojf_segconv_forward_group_batch(n, B, handles, xp, xs_, op, os_, rp, rs, mp, ms, ACT[act] | flags, H, W, _lib.stream_ptr(xs[0].device))
     _lib.check(rc, 'ojf_segconv_forward_group')
     return list(outs)
 
@@ -163,27 +167,30 @@ class SegDeconv:
         """zero_pad=False: the pad channels of a fresh output (c_out not a multiple of 8) stay uninitialised - for outputs no
         convolution reads (the logits)."""
         H, W = x.shape[2:]
+        B = x.shape[0]
         if out is None:
-            out = nhwc((self.c_out + 7) // 8 * 8, H * self.up, W * self.up, x.device, zero=zero_pad and self.c_out % 8 != 0)[:, :self.c_out]
-        assert out.shape[1] == self.c_out and tuple(out.shape[2:]) == (H * self.up, W * self.up)
+            out = nhwc((self.c_out + 7) // 8 * 8, H * self.up, W * self.up, x.device, zero=zero_pad and self.c_out % 8 != 0, batch=B)[:, :self.c_out]
+        assert out.shape[1] == self.c_out and tuple(out.shape[2:]) == (H * self.up, W * self.up) and out.shape[0] == B
         xp, xs = _rows(x)
         op, os_ = _rows(out)
-        rc = self._lib.ojf_segconv_forward(self._h, xp, xs, op, os_, None, 0, None, 0, ACT[act], H, W, _lib.stream_ptr(x.device))
+        rc = self._lib.ojf_segconv_forward_batch(self._h, B, xp, xs, op, os_, None, 0, None, 0, ACT[act], H, W, _lib.stream_ptr(x.device))
         _lib.check(rc, 'ojf_segconv_forward')
         return out
 
 
 # ---- the operators around the convolutions (csrc/ojf_seg_ops.hip) -------------------------------------------------
-def pack_input(src, divisor=1.0):
+def pack_input(src, divisor=1.0, out=None):
     """[1, 3, H, W] (contiguous NCHW) or a single [H, W] plane replicated three times (the depth modality,
-    pipeline.py:50) divided by ``divisor`` -> the stem's NHWC rows: an [1, 8, H, W] channels_last tensor, channels 3..7 zero."""
+    pipeline.py:50) divided by ``divisor`` -> the stem's NHWC rows: an [1, 8, H, W] channels_last tensor, channels 3..7 zero
+    (``out``: one image of a batch tensor to write instead)."""
     _lib.require_gpu()
     lib = _lib.load()
     src = src.float()
     H, W = src.shape[-2:]
     planes = src.reshape(-1, H, W)
     assert planes.is_cuda and planes.is_contiguous() and planes.shape[0] in (1, 3)
-    out = nhwc(8, H, W, src.device, zero=False)
+    if out is None:
+        out = nhwc(8, H, W, src.device, zero=False)
     op, os_ = _rows(out)
     rc = lib.ojf_seg_pack_input(planes.data_ptr(), H * W if planes.shape[0] == 3 else 0, float(divisor), H, W, op, os_,
                                 _lib.stream_ptr(src.device))
@@ -194,12 +201,12 @@ def pack_input(src, divisor=1.0):
 def maxpool(x):
     """nn.MaxPool2d(3, stride 2, padding 1) on an NHWC view."""
     lib = _lib.load()
-    C, H, W = x.shape[1:]
+    B, C, H, W = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    out = nhwc((C + 7) // 8 * 8, Ho, Wo, x.device, zero=C % 8 != 0)[:, :C]
+    out = nhwc((C + 7) // 8 * 8, Ho, Wo, x.device, zero=C % 8 != 0, batch=B)[:, :C]
     xp, xs = _rows(x)
     op, os_ = _rows(out)
-    _lib.check(lib.ojf_seg_maxpool(xp, xs, C, H, W, op, os_, _lib.stream_ptr(x.device)), 'ojf_seg_maxpool')
+    _lib.check(lib.ojf_seg_maxpool_batch(B, xp, xs, C, H, W, op, os_, _lib.stream_ptr(x.device)), 'ojf_seg_maxpool')
     return out
 
 
@@ -242,6 +249,14 @@ class PoolFC:
 def pool_fc(fcs, xs, outs, act='relu', muls=None):
     """``outs[i][:, c, y, x] = act(fc_i(mean(xs[i])))[c] (* muls[i][:, c, y, x])`` for n <= 8 members of one shape."""
     lib = _lib.load()
+    B = xs[0].shape[0]
+    if B > 1:  # every image of a batch has its own mean: (member, image) pairs, at most 8 per launch
+        pairs = [(f, x[b:b + 1], o[b:b + 1], None if muls is None else m[b:b + 1])
+                 for f, x, o, m in zip(fcs, xs, outs, muls if muls is not None else [None] * len(fcs)) for b in range(B)]
+        for i in range(0, len(pairs), 8):
+            part = pairs[i:i + 8]
+            pool_fc([p[0] for p in part], [p[1] for p in part], [p[2] for p in part], act, None if muls is None else [p[3] for p in part])
+        return outs
     n = len(fcs)
     f0 = fcs[0]
     C, H, W = xs[0].shape[1:]
@@ -264,10 +279,10 @@ def pool_fc(fcs, xs, outs, act='relu', muls=None):
 def softmax_max(logits):
     """torch.softmax(logits, 1).max(1) of an NHWC view [1, C, H, W] -> (scores f32 [H*W], ids u8 [H*W])."""
     lib = _lib.load()
-    C, H, W = logits.shape[1:]
-    scores = torch.empty(H * W, dtype=torch.float32, device=logits.device)
-    ids = torch.empty(H * W, dtype=torch.uint8, device=logits.device)
+    B, C, H, W = logits.shape
+    scores = torch.empty(B * H * W, dtype=torch.float32, device=logits.device)
+    ids = torch.empty(B * H * W, dtype=torch.uint8, device=logits.device)
     lp, ls = _rows(logits)
-    _lib.check(lib.ojf_seg_softmax_max(lp, ls, C, H * W, scores.data_ptr(), ids.data_ptr(), _lib.stream_ptr(logits.device)),
+    _lib.check(lib.ojf_seg_softmax_max(lp, ls, C, B * H * W, scores.data_ptr(), ids.data_ptr(), _lib.stream_ptr(logits.device)),
                'ojf_seg_softmax_max')
     return scores, ids

@@ -151,3 +151,27 @@ def test_engine_matches_reference_whole_network_golden(stage):
     err, top = float((got - want).abs().max()), float(want.abs().max())
     assert err <= 5e-4 * top, (err, top)
     assert float((got.argmax(1) == want.argmax(1)).float().mean()) > 0.995
+
+
+def test_predict_many_equals_predict_per_frame():
+    """SegEngine.predict_many: B frames as one [B, H, W, C] pass == B single-frame passes (scores to 1e-6: a layer's kernel
+    form - and with it the order its K blocks are added - may differ with the number of pixel tiles; arg-max identical apart
+    from exact near-ties)."""
+    from online_joint_depthfusion_and_semantic_amd.adapnet_engine import SegEngine
+    net = build(2, 30)
+    net.no_resn50_dropout()
+    for m in net.modules():
+        if hasattr(m, 'dropout') and isinstance(m.dropout, bool):
+            m.dropout = False
+    g = torch.Generator().manual_seed(9)
+    B, h, w = 3, 64, 96
+    images = [(torch.rand((1, 3, h, w), generator=g) * 255).cuda() for _ in range(B)]
+    depths = [(torch.rand((1, h, w), generator=g) * 3).cuda() for _ in range(B)]
+    with torch.no_grad():
+        eng = SegEngine(net)
+        scores, ids = eng.predict_many(images, depths)
+        for b in range(B):
+            s1, i1 = eng.predict(images[b], depths[b])
+            assert (scores[b] - s1).abs().max().item() <= 1e-6
+            assert (ids[b] == i1).float().mean().item() >= 0.9995
+    assert scores.shape == (B, h * w) and ids.dtype == torch.uint8

@@ -431,3 +431,100 @@ def test_fuse_training_train_mode_matches_reference_golden(cuda, engine):
     td = np.nan_to_num(np.abs(got - g['32_post_tsdf'].astype(np.float32)))
     touched = g['32_post_wgt'] > 0
     assert td.max() <= 2 * TSDF_ABS_TOL and (td[touched] > 0).mean() <= 0.02, (float(td.max()), float((td[touched] > 0).mean()))
+
+
+# ---- several scenes per call ---------------------------------------------------------------------------
+@pytest.mark.parametrize('sem', [False, True])
+def test_fuse_many_equals_separate_fuse_calls(cuda, sem):
+    """Pipeline.fuse_many runs one frame of each of S scenes side by side (slot i: own engine, est rows, workspace, stream):
+    every volume of every scene must come out bit for bit as from S separate fuse() calls per step - FAST mode is
+    deterministic and the scenes share nothing but the read-only weights."""
+    from online_joint_depthfusion_and_semantic_amd.synthetic import SyntheticDataset
+    h, w, grid, S, frames = 48, 64, 64, 3, 4
+    scenes = tuple('room_%d' % k for k in range(S))
+
+    def build():
+        cfg = default_config(h, w, semantics=sem, use_semantics=sem, integrate_mode='fast')
+        cfg.SETTINGS.device = str(cuda)
+        ds = SyntheticDataset(h, w, grid, 8, scenes=scenes)
+        db = Database(ds, database_config(cfg))
+        torch.manual_seed(3)
+        pipe = Pipeline(cfg)
+        for m in pipe._fusion_network.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                torch.nn.init.xavier_normal_(m.weight)
+        return ds, db, pipe.to(cuda).eval()
+    ds_a, db_a, many = build()
+    ds_b, db_b, one = build()
+    one._fusion_network.load_state_dict(many._fusion_network.state_dict())
+
+    def batch(ds, s, i):
+        b = ds.streams[s].batch(i)
+        return {k: (v.to(cuda) if torch.is_tensor(v) else v) for k, v in b.items()}
+    with torch.no_grad():
+        for i in range(frames):
+            many.fuse_many([batch(ds_a, s, i) for s in scenes], db_a, cuda)
+            for s in scenes:
+                one.fuse(batch(ds_b, s, i), db_b, cuda)
+        many.check()
+        one.check()
+        with pytest.raises(ValueError):
+            many.fuse_many([batch(ds_a, scenes[0], 0), batch(ds_a, scenes[0], 1)], db_a, cuda)
+    for s in scenes:
+        assert float((db_a.fusion_weights[s].float() > 0).sum()) > 1000
+        pairs = [(db_a.scenes_est[s].volume, db_b.scenes_est[s].volume), (db_a.fusion_weights[s], db_b.fusion_weights[s])]
+        if sem:
+            pairs += [(db_a.ids_est[s].volume, db_b.ids_est[s].volume), (db_a.scores[s].volume, db_b.scores[s].volume)]
+        for a, b in pairs:
+            assert torch.equal(a.view(torch.uint8) if a.dtype == torch.uint8 else a.view(torch.int16), b.view(torch.uint8) if b.dtype == torch.uint8 else b.view(torch.int16)), s
+    assert not torch.equal(db_a.fusion_weights[scenes[0]], db_a.fusion_weights[scenes[1]])  # (the scenes differ)
+
+
+def test_fuse_many_with_predicted_semantics(cuda):
+    """fuse_many with ``semantic_strategy: predict``: the S frames go through AdapNet++ as ONE batched pass
+    (SegEngine.predict_many).  Geometry (TSDF, weights: the geometry-only net never sees the labels) bit for bit as from
+    separate fuse() calls; the per-frame (score, id) images equal the single-frame pass to 1e-6 / apart from near-ties, so
+    the semantic volumes agree on >= 99.9 % of the touched voxels and the score volume to one fp16 ulp."""
+    from adapnet_golden_util import randomise_net
+    from online_joint_depthfusion_and_semantic_amd.synthetic import SyntheticDataset
+    h, w, grid, S, n_classes = 64, 96, 32, 3, 12
+    scenes = tuple('room_%d' % k for k in range(S))
+
+    def build():
+        cfg = default_config(h, w, semantics=True, use_semantics=False, n_classes=n_classes, integrate_mode='fast')
+        cfg.SETTINGS.device = str(cuda)
+        cfg.DATA.semantic_strategy = 'predict'
+        ds = SyntheticDataset(h, w, grid, 8, scenes=scenes, n_classes=n_classes)
+        db = Database(ds, database_config(cfg))
+        torch.manual_seed(3)
+        pipe = Pipeline(cfg)
+        for m in pipe._fusion_network.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                torch.nn.init.xavier_normal_(m.weight)
+        randomise_net(pipe._semantic_2d_network, 31)
+        for m in pipe._semantic_2d_network.modules():
+            if hasattr(m, 'dropout') and isinstance(m.dropout, bool):
+                m.dropout = False  # (the masks are a function of the frame counter: the two pipelines would draw differently)
+        return ds, db, pipe.to(cuda).eval()
+    ds_a, db_a, many = build()
+    ds_b, db_b, one = build()
+    one.load_state_dict(many.state_dict())
+
+    def batch(ds, s, i):
+        return {k: (v.to(cuda) if torch.is_tensor(v) else v) for k, v in ds.streams[s].batch(i).items()}
+    with torch.no_grad():
+        for i in range(3):
+            many.fuse_many([batch(ds_a, s, i) for s in scenes], db_a, cuda)
+            for s in scenes:
+                one.fuse(batch(ds_b, s, i), db_b, cuda)
+        many.check()
+        one.check()
+    assert many.__dict__['_seg_graph_many']['graph'] is not None  # the batched pass was captured and replayed
+    for s in scenes:
+        assert torch.equal(db_a.scenes_est[s].volume.view(torch.int16), db_b.scenes_est[s].volume.view(torch.int16))
+        assert torch.equal(db_a.fusion_weights[s].view(torch.int16), db_b.fusion_weights[s].view(torch.int16))
+        touched = db_b.fusion_weights[s] > 0
+        same = (db_a.ids_est[s].volume[touched] == db_b.ids_est[s].volume[touched]).float().mean().item()
+        assert same >= 0.999, (s, same)
+        ulp = f16_ulp_distance(db_a.scores[s].volume.cpu().numpy(), db_b.scores[s].volume.cpu().numpy())
+        assert ulp.max() <= 1, (s, int(ulp.max()))

@@ -193,3 +193,84 @@ def test_grouped_launch_gives_the_bits_of_single_launches(cin, cout, k, stride, 
     torch.cuda.synchronize()
     for a, b in zip(single, grouped):
         assert torch.equal(a, b)
+
+
+# ---- batches: [B, H, W, C] tensors, the frames of several scenes in one pass (round 5) ------------------------------------
+def to_nhwc_batch(x, pad_to=8):
+    from online_joint_depthfusion_and_semantic_amd.segconv import nhwc
+    b, c = x.shape[:2]
+    buf = nhwc((c + pad_to - 1) // pad_to * pad_to, x.shape[2], x.shape[3], x.device, batch=b)
+    buf[:, :c] = x
+    return buf[:, :c]
+
+
+@pytest.mark.parametrize('shape', [(64, 64, 3, 1, 1, 1, 60, 80), (256, 512, 1, 2, 1, 0, 60, 80), (512, 256, 3, 1, 8, 8, 15, 20), (1024, 256, 1, 1, 1, 0, 15, 20),
+                                   (48, 4, 3, 1, 1, 1, 30, 40), (24, 40, 3, 1, 1, 1, 7, 5), (8, 8, 5, 3, 2, 4, 33, 17), (3, 64, 7, 2, 1, 3, 48, 64)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('B', [2, 3])
+def test_batched_convolution_equals_per_image_calls(shape, B):
+    """A [B, H, W, C] tensor through one launch == the B images through B launches: a pixel's sum never crosses an image (taps
+    outside ITS image read zeros, 15x20 = 18.75 pixel tiles: tiles straddle images), residual / gate rows and the pad
+    channels follow the batch.  Equal up to the K-block order of a different kernel form (3e-6 of the layer's scale)."""
+    from online_joint_depthfusion_and_semantic_amd.segconv import SegConv, group
+    cin, cout, k, s, d, p, h, w = shape
+    g = torch.Generator().manual_seed(cin * 7 + cout + B)
+    conv = nn.Conv2d(cin, cout, k, stride=s, dilation=d, padding=p, bias=True).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / np.sqrt(cin * k * k))
+    op = SegConv(conv)
+    x = (torch.randn((B, cin, h, w), generator=g) * 2).cuda()
+    Ho, Wo = op.out_size(h, w)
+    res = torch.randn((B, cout, Ho, Wo), generator=g).cuda()
+    xb, rb = to_nhwc_batch(x), to_nhwc_batch(res)
+    got = op(xb, act='relu', residual=rb)
+    assert got.shape == (B, cout, Ho, Wo)
+    with torch.no_grad():
+        ref = F.relu(conv(x) + res)
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 3e-5 * scale + 1e-6
+    for b in range(B):
+        one = op(to_nhwc(x[b:b + 1]), act='relu', residual=to_nhwc(res[b:b + 1]))
+        assert (got[b:b + 1] - one).abs().max().item() <= 3e-6 * scale
+    if cout % 8:  # pad channels of own rows are zeroed for every image
+        wide = got.as_strided((B, (cout + 7) // 8 * 8, Ho, Wo), got.stride())
+        assert float(wide[:, cout:].abs().max()) == 0.0
+    # grouped launch on batches
+    outs = group([op, op], [xb, xb], act='relu', residuals=[rb, rb])  # (two members may take another kernel form than one)
+    assert torch.equal(outs[0], outs[1]) and (outs[0] - got).abs().max().item() <= 3e-6 * scale
+
+
+def test_batched_front_end_operators():
+    """max-pool, transposed convolution (pixel-shuffle store per image), squeeze chain (a mean per image) and softmax + max on
+    [B, H, W, C] tensors against the per-image calls."""
+    from online_joint_depthfusion_and_semantic_amd import segconv
+    from online_joint_depthfusion_and_semantic_amd.segconv import SegDeconv, PoolFC
+    g = torch.Generator().manual_seed(77)
+    B, h, w = 3, 15, 20
+    x = torch.randn((B, 64, 2 * h, 2 * w), generator=g).cuda()
+    xb = to_nhwc_batch(x)
+    mp = segconv.maxpool(xb)
+    assert torch.equal(mp, F.max_pool2d(x, 3, 2, 1))
+    de = nn.ConvTranspose2d(64, 24, 4, stride=2, padding=1).cuda()
+    with torch.no_grad():
+        de.weight.copy_(torch.randn(de.weight.shape, generator=g) / 16)
+    dop = SegDeconv(de)
+    y = torch.randn((B, 64, h, w), generator=g).cuda()
+    got = dop(to_nhwc_batch(y), act='relu')
+    with torch.no_grad():
+        ref = F.relu(de(y))
+    assert got.shape == ref.shape and (got - ref).abs().max().item() <= 3e-5 * ref.abs().max().item() + 1e-6
+    for b in range(B):
+        assert (dop(to_nhwc(y[b:b + 1]), act='relu') - got[b:b + 1]).abs().max().item() <= 3e-6 * ref.abs().max().item()
+    fc = nn.Conv2d(64, 24, 1).cuda()
+    pf = PoolFC(fc)
+    skip = torch.rand((B, 24, 2 * h, 2 * w), generator=g).cuda()
+    out = segconv.nhwc(24, 2 * h, 2 * w, x.device, zero=False, batch=B)
+    segconv.pool_fc([pf], [to_nhwc_batch(y)], [out], act='relu', muls=[to_nhwc_batch(skip)])
+    with torch.no_grad():
+        want = F.relu(fc(y.mean(dim=(2, 3), keepdim=True))) * skip
+    assert (out - want).abs().max().item() <= 2e-6 * want.abs().max().item() + 1e-7
+    logits = torch.randn((B, 30, 2 * h, 2 * w), generator=g).cuda()
+    sc, ids = segconv.softmax_max(to_nhwc_batch(logits))
+    ws, wi = torch.softmax(logits, 1).max(1)
+    assert (sc.view(B, -1) - ws.reshape(B, -1)).abs().max().item() <= 1e-6 and torch.equal(ids.view(B, -1).long(), wi.reshape(B, -1))
