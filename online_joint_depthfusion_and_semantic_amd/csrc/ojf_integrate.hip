@@ -402,14 +402,98 @@ __device__ __forceinline__ void finalize_voxel(const IntegrateArgs &a, size_t li
     }
 }
 
-// one lane per touched voxel: first the per-tile slices, then the counter-allocated list
+// K voxels per lane, their dependent loads interleaved: a voxel is a chain of ~6 dependent memory round trips (touched list ->
+// head -> 2-3 records -> volumes) and a 16x8 tile first-touches ~320 voxels - with one voxel per lane a 256-thread block
+// walked them in two rounds of one chain each and the kernel sat 74 % parked (round 4's counters); two chains per lane
+// are one round with twice the loads in flight.  Same operations per voxel as finalize_voxel: same bits.
+template <int K>
+__device__ __forceinline__ void finalize_voxels(const IntegrateArgs &a, const unsigned int *list, unsigned int i0, unsigned int stride,
+                                                unsigned int n, unsigned int per_pixel, bool sem)
+{
+    size_t lin[K];
+    unsigned int ri[K], first[K];
+    bool on[K];
+    float w_old[K], v_old[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        on[k] = i0 + k * stride < n;
+        lin[k] = on[k] ? list[i0 + k * stride] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        ri[k] = on[k] ? a.head[lin[k]] : 0u;
+        // the pre-frame values do not depend on the records: requested now, used after the walk
+        w_old[k] = on[k] ? h2f(a.wgt[lin[k]]) : 0.0f;
+        v_old[k] = on[k] ? h2f(a.tsdf[lin[k]]) : 0.0f;
+        first[k] = ri[k];
+    }
+    long long sw[K], su[K];
+    bool wrapped[K];
+    unsigned int e_last[K], e_diff[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { sw[k] = 0; su[k] = 0; wrapped[k] = false; e_last[k] = 0; e_diff[k] = 0; }
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < K; ++k) any = any || ri[k] != 0;
+    while (any) {  // 2-3 records per voxel; integer sums: any order gives the same bits
+        VoxelRec r[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (ri[k]) r[k] = a.recs[ri[k] - 1];
+        any = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (!ri[k]) continue;
+            wrapped[k] |= __builtin_add_overflow(sw[k], (long long)r[k].w, &sw[k]);
+            wrapped[k] |= __builtin_add_overflow(su[k], (long long)r[k].u, &su[k]);
+            e_last[k] = r[k].e_last > e_last[k] ? r[k].e_last : e_last[k];
+            e_diff[k] = r[k].e_diff > e_diff[k] ? r[k].e_diff : e_diff[k];
+            ri[k] = r[k].next;
+            any = any || ri[k] != 0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (!on[k]) continue;
+        a.head[lin[k]] = 0;  // leave the workspace clean
+        double Wd = (double)sw[k] * kFixInv, Ud = (double)su[k] * kFixInv;
+        if (wrapped[k]) {  // see finalize_voxel
+            Wd = 0.0; Ud = 0.0;
+            for (unsigned int rj = first[k]; rj;) {
+                const VoxelRec r = a.recs[rj - 1];
+                Wd += (double)(long long)r.w * kFixInv;
+                Ud += (double)(long long)r.u * kFixInv;
+                rj = r.next;
+            }
+        }
+        const float W = (float)Wd;
+        const float U = (float)Ud;
+        const float w_new = w_old[k] + W;                                   // integrator.py:77
+        const float num = w_old[k] * v_old[k] + U;                          // :82
+        a.wgt[lin[k]] = f2h(w_new);                                         // :78,87
+        a.tsdf[lin[k]] = f2h(num / w_new);                                  // :83,88
+        if (sem) {  // integrator.py:93-124 with "highest entry wins" for duplicates
+            const float s_old = h2f(a.score_vol[lin[k]]);
+            const float s_last = a.sem_scores[(e_last[k] - 1u) / per_pixel];
+            a.score_vol[lin[k]] = f2h(s_last > s_old ? s_last : s_old);     // :113-114,124
+            if (e_diff[k]) {                                                 // :105,116-117,123
+                const unsigned int n_d = (e_diff[k] - 1u) / per_pixel;
+                if (a.sem_scores[n_d] > s_old) a.id_vol[lin[k]] = a.sem_ids[n_d];
+            }
+        }
+    }
+}
+
+// first the per-tile slices (the voxels each tile touched first), then the counter-allocated list
 __global__ __launch_bounds__(256) void integrate_finalize_kernel(IntegrateArgs a)
 {
     const unsigned int per_pixel = (unsigned int)a.n_tail * 8u;  // entries per sem_ids / sem_scores element
     const bool sem = a.id_vol != nullptr;
+    constexpr int K = 2;
     for (int tile = banded_block_x(); tile < a.n_tiles; tile += gridDim.x) {  // (the XCD that accumulated the tile)
         const unsigned int n = a.tile_new[tile];
-        for (unsigned int i = threadIdx.x; i < n; i += blockDim.x) finalize_voxel(a, a.touched[(size_t)tile * kSlots + i], per_pixel, sem);
+        const unsigned int *list = a.touched + (size_t)tile * kSlots;
+        for (unsigned int i = threadIdx.x; i < n; i += K * blockDim.x) finalize_voxels<K>(a, list, i, blockDim.x, n, per_pixel, sem);
         if (a.stats && threadIdx.x == 0 && n) atomicAdd(&a.stats[0], n);
     }
     // (header word kPhaseFin: written by this call's accumulate kernel, stable while finalize runs)

@@ -528,17 +528,25 @@ def test_weights_edited_through_data_need_invalidate(cuda):
     assert float((e2 - e0).abs().max()) <= 1e-6
 
 
-def test_wide_net_dy_factor_sees_every_channel(cuda):
-    """the BatchNorm-backward apply kernel derives the same-pass dy factor from the bound words of ALL
-    channels of its scale group.  It used to look at the first 256 only; n_points = 23 gives 47-channel slots and a 282-channel
-    VortexPooling output, and the channels past 256 carry the largest gradients here (their BatchNorm gamma is 1e4 times the
-    others'): with the factor taken from the first 256 channels their dy left the fp16 range in the split-fp16 passes (inf
-    halves, NaN gradients).  Passes 2 and 3 (split-fp16 backward) must reproduce pass 1 (fp32 backward)."""
-    h, w, P = 24, 40, 23
+def test_wide_nets_up_to_the_executor_limit(cuda):
+    """the BatchNorm-backward apply kernel scans the bound words of its scale group with one 256-thread
+    block; a unit with more than 256 channels would have left channels out of the dy factor.  The scan is strided now - and
+    such a unit cannot be built: ojf_trainer_create rejects units of more than 128 output channels (and dense 3x3 convolutions
+    beyond the 128-superstep tap table), so every accepted net stays far below 256 bound words per scale group.  Checked here:
+    the rejection is loud, and the widest accepted net (n_points 10: 21-channel slots, 126-channel units, four stacked branch
+    units of 24 physical channels) reproduces its fp32 backward pass in the split-fp16 passes with the largest gradients
+    sitting in the LAST channels of the widest units."""
+    from online_joint_depthfusion_and_semantic_amd import _lib
+    h, w = 24, 40
+    with pytest.raises(_lib.OjfError, match='unsupported layer shape|more than 128 output channels'):
+        HipTrainNet(_net('v3', False, h, w, n_points=23).to(cuda).train(True))(
+            dict(tsdf_values=torch.zeros(1, 23, h, w, device=cuda), tsdf_weights=torch.zeros(1, 23, h, w, device=cuda),
+                 tsdf_frame=torch.zeros(1, 1, h, w, device=cuda)))
+    P = 10
     net = _net('v3', False, h, w, n_points=P).to(cuda).train(True)
     with torch.no_grad():
         for vp in (net.vortex0, net.vortex3):
-            vp.final[1].weight[256:] *= 1e4
+            vp.final[1].weight[110:] *= 1e4
     g = torch.Generator().manual_seed(29)
     x = dict(tsdf_values=((torch.rand(1, P, h, w, generator=g) - 0.5) * 0.2).to(cuda), tsdf_weights=(torch.rand(1, P, h, w, generator=g) * 4).to(cuda),
              tsdf_frame=(torch.rand(1, 1, h, w, generator=g) * 4).to(cuda))
