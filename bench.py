@@ -538,17 +538,21 @@ class TrainCase:
         for i in range(warmup):
             self.step(i)
         self.reduce_events = []
-        times, at = [], warmup
+        times, host, at = [], [], warmup
         for _ in range(repeats):
             sync()
             t0 = time.perf_counter()
             self.loss_sum = None
             for i in range(at, at + steps):
                 self.step(i)
+            host.append(time.perf_counter() - t0)  # the host's share: Python + enqueue time of the loop (incl. its waits for the valid-ray counts)
             mean_loss = float(self.loss_sum) / steps if self.loss_sum is not None else float('nan')  # the log window's read
             sync()
             times.append(time.perf_counter() - t0)
             at += steps
+        self.host_ms_per_frame = 1e3 * sorted(host)[len(host) // 2] / steps
+        tn = self.pipe.__dict__.get('_hip_train')
+        self.net_launches_per_pass = int(tn.launches) if tn is not None and hasattr(tn, 'launches') else None
         loss_ok = bool(torch.isfinite(self.grads.flat).all()) and mean_loss == mean_loss
         ar = [a.elapsed_time(b) * 1e3 for a, b in self.reduce_events]
         # (world 1: the bracket is empty, ~5 us of event overhead - reported as None)
@@ -567,7 +571,10 @@ def train_report(case, res, steps, warmup, world, h, w, grid):
             'allreduce_us': res['allreduce_us'] if world > 1 else None, 'allreduce_calls_in_timed_region': res['allreduce_calls'],
             'allreduce_backend': (('rccl' if torch.distributed.get_backend() == 'nccl' else 'gloo (dry run: gradient buffer staged through the host)')
                                   if world > 1 else 'none (one rank)'), 'gradient_bytes': res['gradient_bytes'],
-            'gradients_finite': res['finite'], 'mean_loss_last_repeat': res['mean_loss']}
+            'gradients_finite': res['finite'], 'mean_loss_last_repeat': res['mean_loss'],
+            # host- or device-bound?  the loop's enqueue time per frame (the host waits ~1.7 ms of it for the frame's valid-ray count,
+            # i.e. for the device) against the frame time; launches of the net's forward + backward pass as the executor counts them
+            'host_loop_ms_per_frame': getattr(case, 'host_ms_per_frame', None), 'net_launches_per_pass': getattr(case, 'net_launches_per_pass', None)}
 
 
 def launch_ranks(n, argv):
@@ -758,9 +765,12 @@ def main():
                 torch.cuda.empty_cache()
                 secondary.append(r2)
             try:  # BASELINE configs[3]: the training frame step on this GPU (no collective at N = 1)
-                n_tr = max(8, (n_sec // 2) // 8 * 8)
-                tc = TrainCase(240, 320, 256, dev, rank, 8 + 3 * n_tr)
-                secondary.append(train_report(tc, tc.run(n_tr, 8, sync, 3), n_tr, 8, 1, 240, 320, 256))
+                # the same schedule `bench.py --train --steps 48 --warmup 16 --repeats 3` runs: 16 warm-up frames = two optimizer
+                # steps (the executor's second-pass arithmetic, packed weights and allocator pools settle inside them: with 8
+                # warm-up frames this leg read 14 % below --train in round 4), 48 timed frames, median of 3
+                n_tr, w_tr = max(48, n_sec // 8 * 8), 16
+                tc = TrainCase(240, 320, 256, dev, rank, w_tr + 3 * n_tr)
+                secondary.append(train_report(tc, tc.run(n_tr, w_tr, sync, 3), n_tr, w_tr, 1, 240, 320, 256))
                 del tc
             except Exception as e:
                 secondary.append({'workload': 'BASELINE configs[3]: training frame step', 'error': repr(e)})

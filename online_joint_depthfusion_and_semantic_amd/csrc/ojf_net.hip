@@ -3009,6 +3009,16 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
         static const bool no_chain = getenv("OJF_NO_DENSE_CHAIN") != nullptr || getenv("OJF_LEGACY_VORTEX") != nullptr ||
                                      getenv("OJF_NO_PAIR") != nullptr;
         bool ok = net->arith == OJF_ARITH_F16X3 && !no_chain;
+        {
+            //  frames the chain kernel is not the right tool for fall back to one dense_pair_kernel launch per Block:
+            //  * more tiles than the flag array holds (frames beyond ~2.6 Mpixel used to fail in ojf_net_forward);
+            //  * w % 8 != 0: a 128-byte line of a plane is 8 pixels, so a line then straddles two image rows - pixels of tiles
+            //    whose flags a reader never checked - and only the slot of the Block just finished is read with sc1 loads: an
+            //    early reader could pull a not-yet-written pixel of an OLDER slot into its XCD's L2 and a later item read it stale.
+            const int big = ((w + 19) / 20) * ((h + 15) / 16);
+            const int tiles = big >= 200 ? big : ((w + 11) / 12) * ((h + 7) / 8);
+            if (tiles > kChainSyncInts - kChainFlags0 || (w % 8) != 0) ok = false;
+        }
         for (int hd = 0; hd < net->heads && ok; ++hd)
             ok = net->chains[hd].layers == gf && net->vortex[hd].entry_w && net->vortex[hd].tail_w;
         net->chain_dense = ok;

@@ -454,6 +454,11 @@ class HipTrainNet:
         them."""
         self._weights_sig = None
 
+    @property
+    def launches(self):
+        """Kernel launches of the most recent forward + backward pass of the executor (counted by the library)."""
+        return max((t.fwd_launches + t.bwd_launches for t in self._trainers.values()), default=0)
+
     def _epoch(self, mods):
         """A number that changes whenever a convolution weight or bias may have changed (ojf_trainer_forward's
         ``weights_epoch``): the per-tensor (address, version) tuples are compared element-wise - no sum that could cancel."""
@@ -594,6 +599,8 @@ class FuseOutput(torch.autograd.Function):
 
 
 class _TrainerHandle:
+    fwd_launches = bwd_launches = 0
+
     def __init__(self, handle):
         self.handle = handle
         self.gen = 0  # generation of the forward pass whose activations the trainer holds
@@ -621,6 +628,7 @@ class _NetFn(torch.autograd.Function):
         _lib.check(lib.ojf_trainer_forward(tr.handle, state['table'], len(state['table']), state['epoch'], ins[0].data_ptr(), ins[1].data_ptr(),
                                            ins[2].data_ptr(), ins[3].data_ptr() if n_in == 4 else None, est.data_ptr(),
                                            _lib.stream_ptr(state['dev'])), 'ojf_trainer_forward')
+        tr.fwd_launches = int(lib.ojf_trainer_launch_count(tr.handle))
         tr.gen = state['gen']
         ctx.tn, ctx.state, ctx.n_in = tn, state, n_in
         return est
@@ -641,6 +649,7 @@ class _NetFn(torch.autograd.Function):
         if steady:  # every parameter still accumulates into the tensor whose address the table already holds
             _lib.check(lib.ojf_trainer_backward(tr.handle, table, len(table), dest.contiguous().data_ptr(), _lib.stream_ptr(state['dev'])),
                        'ojf_trainer_backward')
+            tr.bwd_launches = int(lib.ojf_trainer_launch_count(tr.handle))
             return (None, None) + (None,) * ctx.n_in + tuple(out)
         all_accumulating = inplace
         for i, (conv, bn, drop) in enumerate(tn._mods):
