@@ -32,5 +32,9 @@ python tools/pmc_sq_summary.py $(find $O/sqt -name '*counter_collection.csv' | h
 python tools/adapnet_engine_probe.py 2>&1 | grep -v MIOpen > $O/adapnet_engine_probe.txt
 python bench.py --mode parity --steps 100 --cpu-frames 0 --secondary 0 > $O/bench_parity.json 2>/dev/null
 python bench.py --height 120 --width 160 --grid 64 --cpu-frames 0 --secondary 0 > $O/bench_A.json 2>/dev/null
+# several scenes per GPU (Pipeline.fuse_many) and the 2-D engine on batches
+for S in 2 4; do python bench.py --steps 100 --warmup 10 --repeats 3 --scenes $S >> $O/bench_fuse_many.json 2>/dev/null; done
+python bench.py --steps 60 --warmup 10 --repeats 3 --scenes 4 --semantics --semantic-strategy predict >> $O/bench_fuse_many.json 2>/dev/null
+for B in 1 2 4 8; do python tools/seg_probe.py graph 30 240 320 $B 2>&1 | grep "seg engine" >> $O/seg_engine_batches.txt; done
 rm -rf $O/kt $O/pf $O/pw $O/sq $O/kp $O/ktr $O/cf $O/cw $O/sqp $O/sqt
 ls -la $O
