@@ -75,7 +75,7 @@ struct SegArgs {
     int n_ct;              // packed output-channel tiles (multiple of kMW)
     int c_out;
     int act;               // 0 none, 1 ReLU, 2 sigmoid
-    int vec_store;         // rows are 16-byte aligned: float4 stores
+    int vec_store;         // rows are 16-byte aligned: bit 0 float4 stores, bit 1 float4 residual loads, bit 2 float4 gate loads
     unsigned in_bytes;
     int *ovf;
     int up, up_c, up_cp;   // transposed convolution: upscale factor (1: none), real / padded channels per phase
@@ -189,9 +189,15 @@ __device__ __forceinline__ void seg_epilogue(const SegArgs &a, const f32x4 (&acc
             const bool full = co + 3 < n_co;
             if (a.res) {
                 const float *r = a.res + (size_t)p * a.res_stride + c;
+                if (full && (a.vec_store & 2)) {  // 16-byte aligned residual rows: one load instead of four
+                    const f32x4 q = *reinterpret_cast<const f32x4 *>(r);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (full || co + i < n_co) v[i] += r[i];
+                    for (int i = 0; i < 4; ++i) v[i] += q[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (full || co + i < n_co) v[i] += r[i];
+                }
             }
             gmax = fmaxf(fmaxf(fmaxf(gmax, fabsf(v[0])), fmaxf(fabsf(v[1]), fabsf(v[2]))), fabsf(v[3]));
             if (a.act == 1) {
@@ -203,9 +209,15 @@ __device__ __forceinline__ void seg_epilogue(const SegArgs &a, const f32x4 (&acc
             }
             if (a.mul) {
                 const float *g = a.mul + (size_t)p * a.mul_stride + c;
+                if (full && (a.vec_store & 4)) {
+                    const f32x4 q = *reinterpret_cast<const f32x4 *>(g);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (full || co + i < n_co) v[i] *= g[i];
+                    for (int i = 0; i < 4; ++i) v[i] *= q[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (full || co + i < n_co) v[i] *= g[i];
+                }
             }
             if constexpr (DROP) {  // nn.Dropout(p = 0.5) in training mode, always (adapnet.py:80-82): keep with probability 1/2, scale by 2
                 const unsigned e = (unsigned)p * (unsigned)(a.c_out >> 2) + (unsigned)(c >> 2);
@@ -228,7 +240,7 @@ __device__ __forceinline__ void seg_epilogue(const SegArgs &a, const f32x4 (&acc
                 row = (size_t)b * a.Ho * a.Wo * a.up * a.up + ((size_t)oy * a.up + ay) * ((size_t)a.Wo * a.up) + (size_t)ox * a.up + ax;
             }
             float *o = a.out + row * a.out_stride + co;
-            if ((full || co + 3 < a.pad_to) && a.vec_store) {
+            if ((full || co + 3 < a.pad_to) && (a.vec_store & 1)) {
                 *reinterpret_cast<f32x4 *>(o) = v;
             } else {
 #pragma unroll
@@ -764,7 +776,10 @@ int seg_fill(const ojf_segconv *c, int batch, const float *in, int in_stride, fl
     a.in_stride = in_stride; a.out_stride = out_stride; a.res_stride = res_stride; a.mul_stride = mul_stride;
     a.H = h; a.W = w; a.Ho = Ho; a.Wo = Wo; a.B = batch; a.stride = c->stride; a.pad = c->pad; a.dil = c->dil; a.ksize = c->ksize;
     a.c8 = c->c8; a.n_kb = c->n_kb; a.n_ct = c->n_ct; a.c_out = c->c_out; a.act = act;
-    a.vec_store = (out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) ? 1 : 0;
+    // bit 0: float4 stores, bit 1: float4 residual loads, bit 2: float4 gate loads (rows 16-byte aligned)
+    a.vec_store = ((out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) ? 1 : 0) |
+                  ((res && res_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0) ? 2 : 0) |
+                  ((mul && mul_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(mul) & 15) == 0) ? 4 : 0);
     a.in_bytes = (unsigned)in_bytes;
     a.ovf = range_flag_device();
     a.up = c->up; a.up_c = c->up_c; a.up_cp = c->up_cp;
@@ -809,6 +824,7 @@ int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
     static const int trace = getenv("OJF_SEG_TRACE") ? atoi(getenv("OJF_SEG_TRACE")) : 0;  // tuning only: one line per launch
     static const int wide1_min = getenv("OJF_SEG_WIDE1_MIN") ? atoi(getenv("OJF_SEG_WIDE1_MIN")) : (1 << 30);  // tuning only
     static const int splitk_nw2_min = getenv("OJF_SEG_SPLITK_NW2_MIN") ? atoi(getenv("OJF_SEG_SPLITK_NW2_MIN")) : (1 << 30);  // tuning only
+    static const int splitk_min_kb = getenv("OJF_SEG_SPLITK_MIN_KB") ? atoi(getenv("OJF_SEG_SPLITK_MIN_KB")) : 8;  // tuning only
     static const int tile_u = getenv("OJF_SEG_TILE_U") ? atoi(getenv("OJF_SEG_TILE_U")) : 1;  // tuning only: K blocks per barrier of the tile kernel
     static const int use_tile = getenv("OJF_SEG_TILE") ? atoi(getenv("OJF_SEG_TILE")) : 0;  // tuning only: register-staged tile kernel
     static const int wide_depth = getenv("OJF_SEG_WIDE_DEPTH") ? atoi(getenv("OJF_SEG_WIDE_DEPTH")) : 3;  // tuning only: 3 | 6 | 8
@@ -842,7 +858,7 @@ int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
         else if (wide_depth == 3) hipLaunchKernelGGL((segconv_wide_kernel<1, 3>), dim3(seg_map(g.map, (n_pt + 3) / 4, groups, n)), dim3(256), 0, st, g);
         else if (wide_depth == 8) hipLaunchKernelGGL((segconv_wide_kernel<1, 8>), dim3(seg_map(g.map, (n_pt + 3) / 4, groups, n)), dim3(256), 0, st, g);
         else hipLaunchKernelGGL((segconv_wide_kernel<1, 6>), dim3(seg_map(g.map, (n_pt + 3) / 4, groups, n)), dim3(256), 0, st, g);
-    } else if (waves2 >= 1024 || a.n_kb < 8) {
+    } else if (waves2 >= 1024 || a.n_kb < splitk_min_kb) {
         if (groups == 1) {
             variant = "<4,2,1,1>";
             hipLaunchKernelGGL((segconv_kernel<4, 2, 1, 1, 3>), dim3(seg_map(g.map, (n_pt + 7) / 8, 1, n)), dim3(256), 0, st, g);
