@@ -244,6 +244,15 @@ int ojf_segconv_forward_group(int n, const ojf_segconv *const *convs, const floa
  * tiles, and the forms differ in the order they add the K blocks): equal to the single-image call up to that rounding
  * (a few 1e-7 relative).  The weights of a layer are fetched once per launch whatever the batch: on the 15x20 / 30x40
  * maps, where a single frame leaves the matrix pipe idle behind the weight stream, this is what batching buys. */
+/* n (1..8) convolutions of DIFFERENT shapes that do not depend on each other, as one launch where their kernel forms allow it
+ * (separate launches otherwise; same results either way up to the K-block order of the form): a residual unit's shortcut
+ * convolution next to its first 1x1 (modules/adapnet.py:33-38,75-76 run them one after the other), an encoder's skip projection
+ * (:142-147) next to the next stage's first layers, the three SSMA blocks of the decoder (:367-369,404-408).  Everything is per
+ * member: row strides, residual / gate (NULL entries allowed), act (with OJF_SEG_ACT_ZERO_PAD), input size. */
+int ojf_segconv_forward_multi(int n, int batch, const ojf_segconv *const *convs, const float *const *ins_dev, const int *in_strides,
+                              float *const *outs_dev, const int *out_strides, const float *const *ress_dev, const int *res_strides,
+                              const float *const *muls_dev, const int *mul_strides, const int *acts, const int *hs, const int *ws,
+                              ojf_stream_t stream);
 int ojf_segconv_forward_batch(const ojf_segconv *conv, int batch, const float *in_dev, int in_stride, float *out_dev, int out_stride,
                               const float *res_dev, int res_stride, const float *mul_dev, int mul_stride, int act, int h,
                               int w, ojf_stream_t stream);

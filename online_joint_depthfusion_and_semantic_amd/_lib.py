@@ -82,6 +82,7 @@ SIGNATURES = {
     'ojf_segconv_forward': (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'ojf_segconv_forward_batch': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'ojf_segconv_forward_group': (_i, [_i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    'ojf_segconv_forward_multi': (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'ojf_segconv_forward_group_batch': (_i, [_i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'ojf_train_packed_floats': (_sz, [_i, _i, _i]),
     'ojf_train_pack': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

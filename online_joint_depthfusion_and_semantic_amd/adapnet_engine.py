@@ -53,12 +53,23 @@ class _Unit:
         return self.c3(y, residual=idn, act='relu')
 
 
-def _units(units, xs):
+def _units(units, xs, extra=()):
     """The same unit of several encoders in lock-step (``[u(x) for u, x in zip(units, xs)]``): every layer is ONE grouped
-    launch over the encoders, the two dilations of a multi-scale unit ride in the same launch."""
+    launch over the encoders, the two dilations of a multi-scale unit ride in the same launch.  The unit's shortcut
+    convolution and its first 1x1 read the same input and do not depend on each other: one heterogeneous launch
+    (``segconv.multi``), together with ``extra`` - independent (conv, x, kwargs) calls on the same input, the encoder's skip
+    projection - when given."""
     u0 = units[0]
-    idns = xs if u0.down is None else segconv.group([u.down for u in units], xs)
-    ys = segconv.group([u.c1 for u in units], xs, act='relu')
+    n = len(units)
+    if u0.down is not None or extra:
+        calls = ([(u.down, x, {}) for u, x in zip(units, xs)] if u0.down is not None else []) + \
+                [(u.c1, x, {'act': 'relu'}) for u, x in zip(units, xs)] + list(extra)
+        res = segconv.multi(calls)
+        idns = res[:n] if u0.down is not None else xs
+        ys = res[n:2 * n] if u0.down is not None else res[:n]
+    else:
+        idns = xs
+        ys = segconv.group([u.c1 for u in units], xs, act='relu')
     if u0.multi:
         half = u0.c2a.c_out
         cats = [nhwc(2 * half, y.shape[2], y.shape[3], y.device, zero=False, batch=y.shape[0]) for y in ys]
@@ -73,40 +84,60 @@ def _units(units, xs):
 
 def _encoders(encs, images, skip2_outs, skip1_outs):
     """``[e(image, s2, s1) for ...]`` for encoders of one architecture (the two modalities of the fusion net), layer by
-    layer in grouped launches: half the graph nodes, no side stream."""
+    layer in grouped launches: half the graph nodes, no side stream.  The skip projections (adapnet.py:142-147) ride in the
+    first launch of the stage that follows them."""
     xs = [im if im.shape[1] == 8 else segconv.pack_input(im.contiguous()) for im in images]
     xs = segconv.group([e.stem for e in encs], [x[:, :3] for x in xs], act='relu')
     xs = [segconv.maxpool(x) for x in xs]
     for units in zip(*[e.layers[0] for e in encs]):
         xs = _units(units, xs)
-    segconv.group([e.skip2 for e in encs], xs, outs=skip2_outs)
+    extra = [(e.skip2, x, {'out': o}) for e, x, o in zip(encs, xs, skip2_outs)]
     for units in zip(*[e.layers[1] for e in encs]):
-        xs = _units(units, xs)
-    segconv.group([e.skip1 for e in encs], xs, outs=skip1_outs)
+        xs = _units(units, xs, extra)
+        extra = ()
+    extra = [(e.skip1, x, {'out': o}) for e, x, o in zip(encs, xs, skip1_outs)]
     for li in (2, 3):
         for units in zip(*[e.layers[li] for e in encs]):
-            xs = _units(units, xs)
+            xs = _units(units, xs, extra)
+            extra = ()
     return xs
 
 
 def _easpps(aspps, xs, outs):
-    """``[a(x, out) for ...]`` in grouped launches: branch 1, step i of the three cascades and the closing convolution of
-    every eASPP are one launch each."""
+    """``[a(x, out) for ...]`` in grouped launches: branch 1 together with the first step of the three cascades (all read the
+    eASPP input: one heterogeneous launch), step i of the cascades and the closing convolution of every eASPP one launch each."""
     a0 = aspps[0]
     h, w = xs[0].shape[2:]
     n = a0.b1.c_out
     cats = [nhwc(5 * n, h, w, x.device, zero=False, batch=x.shape[0]) for x in xs]
-    segconv.group([a.b1 for a in aspps], xs, outs=[c[:, :n] for c in cats], act='relu')
     depth = len(a0.cascades[0])
-    ys = [x for x in xs for _ in a0.cascades]  # (eASPP, cascade) pairs, eASPP-major
-    for i in range(depth):
+    n_c = len(a0.cascades)
+    first = [(a.b1, x, {'out': c[:, :n], 'act': 'relu'}) for a, x, c in zip(aspps, xs, cats)] + \
+            [(casc[0], x, {'act': 'relu'}) for a, x in zip(aspps, xs) for casc in a.cascades]  # (eASPP, cascade) pairs, eASPP-major
+    if len(first) <= 8 and depth > 1:
+        ys = segconv.multi(first)[len(aspps):]
+        start = 1
+    else:
+        segconv.group([a.b1 for a in aspps], xs, outs=[c[:, :n] for c in cats], act='relu')
+        ys = [x for x in xs for _ in a0.cascades]
+        start = 0
+    for i in range(start, depth):
         convs = [casc[i] for a in aspps for casc in a.cascades]
         last = i == depth - 1
-        outs_i = [c[:, (k + 1) * n:(k + 2) * n] for c in cats for k in range(len(a0.cascades))] if last else None
+        outs_i = [c[:, (k + 1) * n:(k + 2) * n] for c in cats for k in range(n_c)] if last else None
         ys = segconv.group(convs, ys, outs=outs_i, act='relu')
     # branch 5: pool -> 1x1 conv -> ReLU -> bilinear upsampling of a 1x1 map (= broadcast), both eASPPs in two launches
     segconv.pool_fc([a.b5 for a in aspps], xs, [c[:, 4 * n:] for c in cats], act='relu')
     return segconv.group([a.fin for a in aspps], cats, outs=outs, act='relu')
+
+
+def _ssmas(ssmas, cats):
+    """``[s(cat) for s, cat in zip(ssmas, cats)]`` - the three SSMA blocks of the decoder (skip2 at 1/4, skip1 at 1/8, the
+    eASPP outputs at 1/16 resolution: adapnet.py:404-408) do not depend on each other: squeeze, excite (sigmoid x input) and
+    the closing convolution of all three as one heterogeneous launch each, three launches instead of nine."""
+    sq = segconv.multi([(s.squeeze, c, {'act': 'relu'}) for s, c in zip(ssmas, cats)])
+    gates = segconv.multi([(s.excite, q, {'act': 'sigmoid', 'mul': c}) for s, q, c in zip(ssmas, sq, cats)])
+    return segconv.multi([(s.final, g, {}) for s, g in zip(ssmas, gates)])
 
 
 class _Encoder:
@@ -251,9 +282,7 @@ class SegEngine:
         if self.fusion:
             if not grouped:
                 main.wait_stream(side)
-            skip2 = self.ssma_s2(s2)
-            skip1 = self.ssma_s1(s1)
-            x = self.ssma_res(top)
+            skip2, skip1, x = _ssmas([self.ssma_s2, self.ssma_s1, self.ssma_res], [s2, s1, top])
         else:
             skip2, skip1, x = s2, s1, top
         self.deconv1(x, out=cat2[:, :256], act='relu')

@@ -112,19 +112,36 @@ constexpr int kSegGroup = 8;
 // pixel blocks of a pair are cut into S contiguous chunks ("virtual pairs" v = q S + s, V = Q S a multiple of 8 where S
 // <= 8 allows) so that all XCDs work.  Padding blocks (v >= V or x >= X) exit.  Speed only: any placement computes the same.
 struct SegMap { int X, Y, Z, S, chunk, V; };
-struct SegGroupArgs { SegArgs a[kSegGroup]; SegMap map; };
+// (heterogeneous launches - ojf_segconv_forward_multi - : every member has its own map; member z owns the blocks
+// [off[z], off[z + 1]) of the 1-D grid, each range a multiple of 8 so that a block's XCD is the same in both numberings)
+struct SegHetero { int n; int off[kSegGroup + 1]; SegMap map[kSegGroup]; };
+struct SegGroupArgs { SegArgs a[kSegGroup]; SegMap map; SegHetero het; };
 
-__device__ __forceinline__ bool seg_block(const SegMap &m, int &bx, int &by, int &bz)
+__device__ __forceinline__ bool seg_block_map(const SegMap &m, int b, int &bx, int &by, int &bz);
+
+__device__ __forceinline__ bool seg_block(const SegGroupArgs &g, int &bx, int &by, int &bz)
+{
+    if (g.het.n == 0) return seg_block_map(g.map, (int)blockIdx.x, bx, by, bz);
+    int z = 0;
+#pragma unroll
+    for (int i = 1; i < kSegGroup; ++i)
+        if (i < g.het.n && (int)blockIdx.x >= g.het.off[i]) z = i;
+    int zz;
+    const bool ok = seg_block_map(g.het.map[z], (int)blockIdx.x - g.het.off[z], bx, by, zz);
+    bz = z;
+    return ok;
+}
+
+__device__ __forceinline__ bool seg_block_map(const SegMap &m, int b, int &bx, int &by, int &bz)
 {
     if (m.S == 0) {  // plain numbering (OJF_SEG_XCD=0: A/B switch)
-        const int b = (int)blockIdx.x;
-        bx = b % m.X;
+                bx = b % m.X;
         const int q = b / m.X;
         by = q % m.Y;
         bz = q / m.Y;
         return true;
     }
-    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    const int xcd = b & 7, slot = b >> 3;
     const int vl = slot / m.chunk, xl = slot - vl * m.chunk;
     const int v = vl * 8 + xcd;
     if (v >= m.V) return false;
@@ -260,7 +277,7 @@ template <int MW, int NW, int WM, int KS, int kDepth, bool DROP = false>
 __global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void segconv_kernel(const SegGroupArgs grp)
 {
     int bx, by, bz;
-    if (!seg_block(grp.map, bx, by, bz)) return;  // block-uniform
+    if (!seg_block(grp, bx, by, bz)) return;  // block-uniform
     const SegArgs &a = grp.a[bz];
     constexpr bool SPLITK = KS > 1;  // KS waves of a block split K
     constexpr int WN = SPLITK ? 1 : 4 / WM;
@@ -268,7 +285,9 @@ __global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void segconv_kernel(const S
     const int ct0 = SPLITK ? by * MW : (by * WM + wave % WM) * MW;
     const int pt0 = SPLITK ? bx * NW : (bx * WN + wave / WM) * NW;
     const int n_pix = a.B * a.Ho * a.Wo;
-    if (!SPLITK && (ct0 >= a.n_ct || pt0 * 16 >= n_pix)) return;  // wave-uniform (n_ct is a multiple of 4 >= MW)
+    // wave-uniform (n_ct is a multiple of 4 >= MW); block-uniform for SPLITK: a member of a heterogeneous launch
+    // (ojf_segconv_forward_multi) may have fewer channel / pixel blocks than the grid
+    if (ct0 >= a.n_ct || pt0 * 16 >= n_pix) return;
     const int col = lane & 15, kg = lane >> 4;
     int kb0 = 0, kb1 = a.n_kb;
     if constexpr (SPLITK) {
@@ -393,7 +412,7 @@ template <int NW, int D>
 __global__ __launch_bounds__(256) void segconv_wide_kernel(const SegGroupArgs grp)
 {
     int bx, by, bz;
-    if (!seg_block(grp.map, bx, by, bz)) return;  // block-uniform
+    if (!seg_block(grp, bx, by, bz)) return;  // block-uniform
     const SegArgs &a = grp.a[bz];
     constexpr int MW = 4;  // D = stages of the weight ring / K blocks of pixel operands in flight per wave
     __shared__ f32x4 wtile[D][MW * 2 * 64];
@@ -507,7 +526,7 @@ template <int NW, int U>
 __global__ __launch_bounds__(256) void segconv_tile_kernel(const SegGroupArgs grp)
 {
     int bx, by, bz;
-    if (!seg_block(grp.map, bx, by, bz)) return;  // block-uniform
+    if (!seg_block(grp, bx, by, bz)) return;  // block-uniform
     const SegArgs &a = grp.a[bz];
     // U K blocks per step (= per barrier): with one wave per SIMD - what these launches have - the phases of a step (wait,
     // LDS write, split, loads, LDS reads, MFMAs, barrier) run one after the other, ~1300 cycles per K block at U = 1 for 192
@@ -813,6 +832,7 @@ unsigned seg_map(SegMap &m, int X, int Y, int Z)
 // n members of one shape (the first one's n_kb / n_ct / output size decide the launch)
 int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
 {
+    g.het.n = 0;
     const SegArgs &a = g.a[0];
     const int n_pt = (a.B * a.Ho * a.Wo + 15) / 16, groups = a.n_ct / kMW;  // pixel tiles, 64-channel groups
     // Enough independent waves (>= 4 per CU) to hide the operand latency: waves own their (channels, pixels) pair.
@@ -895,8 +915,100 @@ int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
     return check_hip(hipGetLastError(), "segconv_kernel launch");
 }
 
+// Heterogeneous members (ojf_segconv_forward_multi): convolutions of DIFFERENT shapes that do not depend on each other - a
+// unit's shortcut convolution next to its first 1x1, an encoder's skip projection next to the next unit's first layers, the three
+// SSMA blocks of the decoder in lock-step - as ONE launch: every member keeps its own arguments (SegArgs is per member), the
+// grid covers the largest member and the blocks beyond a member's channel / pixel blocks exit.  One kernel form for all: the
+// in-block split-K form when every member would take it on its own, the plain form when none would; a mix runs as separate
+// launches (the forms differ in what a block is).  Launches cost ~4.7 us each before any work: 17 fewer per frame.
+int seg_launch_multi(SegGroupArgs &g, int n, hipStream_t st)
+{
+    static const int no_multi = getenv("OJF_SEG_NO_MULTI") ? atoi(getenv("OJF_SEG_NO_MULTI")) : 0;  // A/B switch
+    static const int trace = getenv("OJF_SEG_TRACE") ? atoi(getenv("OJF_SEG_TRACE")) : 0;
+    int n_split = 0, n_plain = 0, X1 = 0, Y1 = 0, X2 = 0, Y2 = 0;
+    long sk_blocks4 = 0;
+    bool special = false;
+    // members of one shape (the two encoders' copies of a layer) form a natural group: the form each would take is judged with
+    // the size of ITS group, as ojf_segconv_forward_group would
+    auto same_shape = [&](int i, int j) {
+        const SegArgs &a = g.a[i], &b = g.a[j];
+        return a.n_kb == b.n_kb && a.n_ct == b.n_ct && a.c8 == b.c8 && a.c_out == b.c_out && a.ksize == b.ksize && a.stride == b.stride && a.Ho == b.Ho &&
+               a.Wo == b.Wo && a.up == b.up && a.in_stride == b.in_stride && a.out_stride == b.out_stride && a.res_stride == b.res_stride &&
+               a.mul_stride == b.mul_stride && a.act == b.act && a.pad_to == b.pad_to && (a.res != nullptr) == (b.res != nullptr) && (a.mul != nullptr) == (b.mul != nullptr);
+    };
+    for (int i = 0; i < n; ++i) {
+        const SegArgs &a = g.a[i];
+        const int n_pt = (a.B * a.Ho * a.Wo + 15) / 16, groups = a.n_ct / kMW;
+        int same = 0;
+        for (int j = 0; j < n; ++j) same += same_shape(i, j) ? 1 : 0;
+        special = special || a.rng != nullptr || a.rng_bump != nullptr;
+        const long waves2 = (long)groups * ((n_pt + 1) / 2) * same;
+        if (a.n_kb >= 6 && (long)groups * ((n_pt + 7) / 8) * same >= 256) special = true;  // (a wide-kernel layer: with its own group)
+        if (waves2 >= 1024 || a.n_kb < 8) ++n_plain; else ++n_split;
+        X1 = n_pt > X1 ? n_pt : X1;
+        Y1 = a.n_ct > Y1 ? a.n_ct : Y1;
+        X2 = (n_pt + 3) / 4 > X2 ? (n_pt + 3) / 4 : X2;
+        Y2 = (groups + 1) / 2 > Y2 ? (groups + 1) / 2 : Y2;
+        sk_blocks4 += (long)n_pt * groups;
+    }
+    if (no_multi || special || (n_split && n_plain)) {  // the natural groups, one launch each
+        bool done[kSegGroup] = {};
+        for (int i = 0; i < n; ++i) {
+            if (done[i]) continue;
+            SegGroupArgs grp;
+            int m = 0;
+            for (int j = i; j < n; ++j)
+                if (!done[j] && same_shape(i, j)) { grp.a[m++] = g.a[j]; done[j] = true; }
+            if (int rc = seg_launch(grp, m, st)) return rc;
+        }
+        return 0;
+    }
+    // every member gets its own block map (its own pixel x channel blocks, XCD-aware) and a range of the 1-D grid
+    const char *variant;
+    int mw = 4;
+    if (!n_plain)
+        while (mw > 1 && sk_blocks4 * (4 / mw) < 150) mw /= 2;
+    g.het.n = n;
+    g.het.off[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        const SegArgs &a = g.a[i];
+        const int n_pt = (a.B * a.Ho * a.Wo + 15) / 16, groups = a.n_ct / kMW;
+        const unsigned blocks = n_plain ? seg_map(g.het.map[i], (n_pt + 3) / 4, (groups + 1) / 2, 1) : seg_map(g.het.map[i], n_pt, a.n_ct / mw, 1);
+        g.het.off[i + 1] = g.het.off[i] + (int)((blocks + 7) / 8 * 8);
+    }
+    for (int i = n + 1; i <= kSegGroup; ++i) g.het.off[i] = g.het.off[n];
+    g.map = g.het.map[0];
+    const dim3 grid((unsigned)g.het.off[n]);
+    if (n_plain) { variant = "multi<4,2,2,1>"; hipLaunchKernelGGL((segconv_kernel<4, 2, 2, 1, 3>), grid, dim3(256), 0, st, g); }
+    else if (mw == 1) { variant = "multi<1,1,1,4>"; hipLaunchKernelGGL((segconv_kernel<1, 1, 1, 4, 3>), grid, dim3(256), 0, st, g); }
+    else if (mw == 2) { variant = "multi<2,1,1,4>"; hipLaunchKernelGGL((segconv_kernel<2, 1, 1, 4, 3>), grid, dim3(256), 0, st, g); }
+    else { variant = "multi<4,1,1,4>"; hipLaunchKernelGGL((segconv_kernel<4, 1, 1, 4, 3>), grid, dim3(256), 0, st, g); }
+    if (trace)
+        for (int i = 0; i < n; ++i) {
+            const SegArgs &a = g.a[i];
+            fprintf(stderr, "segconv %-14s member %d/%d  c_in %4d c_out %4d k %d s %d d %2d  in %3dx%3d out %3dx%3d  n_kb %4d  grid %dx%dx%d S %d%s%s\n", variant, i, n,
+                    a.c8 * 8, a.c_out, a.ksize, a.stride, a.dil, a.H, a.W, a.Ho, a.Wo, a.n_kb, g.het.map[i].X, g.het.map[i].Y, g.het.off[n], g.het.map[i].S, a.res ? " +res" : "", a.mul ? " *mul" : "");
+        }
+    return check_hip(hipGetLastError(), "segconv_kernel launch (multi)");
+}
+
 }  // namespace
 }  // namespace ojf
+
+OJF_API int ojf_segconv_forward_multi(int n, int batch, const ojf_segconv *const *convs, const float *const *ins, const int *in_strides,
+                                      float *const *outs, const int *out_strides, const float *const *ress, const int *res_strides,
+                                      const float *const *muls, const int *mul_strides, const int *acts, const int *hs, const int *ws,
+                                      ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (n < 1 || n > kSegGroup || !convs || !ins || !in_strides || !outs || !out_strides || !acts || !hs || !ws)
+        return fail("ojf_segconv_forward_multi: 1..8 members, non-null arrays");
+    SegGroupArgs g;
+    for (int i = 0; i < n; ++i)
+        if (int rc = seg_fill(convs[i], batch, ins[i], in_strides[i], outs[i], out_strides[i], ress ? ress[i] : nullptr, ress && res_strides ? res_strides[i] : 0,
+                              muls ? muls[i] : nullptr, muls && mul_strides ? mul_strides[i] : 0, acts[i], hs[i], ws[i], g.a[i])) return rc;
+    return seg_launch_multi(g, n, as_stream(stream));
+}
 
 OJF_API int ojf_segconv_forward_batch(const ojf_segconv *c, int batch, const float *in, int in_stride, float *out, int out_stride,
                                       const float *res, int res_stride, const float *mul, int mul_stride, int act, int h, int w,

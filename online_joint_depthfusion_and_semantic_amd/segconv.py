@@ -136,6 +136,38 @@ def group(convs, xs, outs=None, act=None, residuals=None, muls=None):
     return list(outs)
 
 
+def multi(calls):
+    """``[conv(x, **kw) for conv, x, kw in calls]`` (kw: out, act, residual, mul) for up to 8 INDEPENDENT convolutions of
+    any shapes as one launch where their kernel forms allow it (``ojf_segconv_forward_multi``).  Returns the outputs."""
+    n = len(calls)
+    assert 1 <= n <= 8
+    c0 = calls[0][0]
+    B = calls[0][1].shape[0]
+    ptr = lambda vals: (ctypes.c_void_p * n)(*vals)
+    ints = lambda vals: (ctypes.c_int * n)(*vals)
+    handles, ins, in_s, outs, out_s, ress, res_s, muls, mul_s, acts, hs, ws, results = ([] for _ in range(13))
+    for conv, x, kw in calls:
+        assert isinstance(conv, SegConv) and x.shape[0] == B
+        H, W = x.shape[2:]
+        Ho, Wo = conv.out_size(H, W)
+        out, flags = kw.get('out'), 0
+        if out is None:
+            out = nhwc((conv.c_out + 7) // 8 * 8, Ho, Wo, x.device, zero=False, batch=B)[:, :conv.c_out]
+            flags = ZERO_PAD if conv.c_out % 8 else 0
+        assert out.shape[1] == conv.c_out and tuple(out.shape[2:]) == (Ho, Wo) and out.shape[0] == B
+        xp, xs = _rows(x)
+        op, os_ = _rows(out)
+        rp, rs = _rows(kw['residual']) if kw.get('residual') is not None else (None, 0)
+        mp, ms = _rows(kw['mul']) if kw.get('mul') is not None else (None, 0)
+        handles.append(conv._h.value); ins.append(xp); in_s.append(xs); outs.append(op); out_s.append(os_)
+        ress.append(rp); res_s.append(rs); muls.append(mp); mul_s.append(ms); acts.append(ACT[kw.get('act')] | flags); hs.append(H); ws.append(W)
+        results.append(out)
+    rc = c0._lib.ojf_segconv_forward_multi(n, B, ptr(handles), ptr(ins), ints(in_s), ptr(outs), ints(out_s), ptr(ress), ints(res_s), ptr(muls), ints(mul_s),
+                                           ints(acts), ints(hs), ints(ws), _lib.stream_ptr(calls[0][1].device))
+    _lib.check(rc, 'ojf_segconv_forward_multi')
+    return results
+
+
 class SegDeconv:
     """``nn.ConvTranspose2d(c_in, c_out, 2*s, stride=s, padding=s//2)`` [+ eval ``bn``] on the SEGCONV kernel
     (``ojf_segdeconv_create``: 3x3 convolution to s*s phase copies + pixel-shuffle store).  Deterministic."""

@@ -274,3 +274,47 @@ def test_batched_front_end_operators():
     sc, ids = segconv.softmax_max(to_nhwc_batch(logits))
     ws, wi = torch.softmax(logits, 1).max(1)
     assert (sc.view(B, -1) - ws.reshape(B, -1)).abs().max().item() <= 1e-6 and torch.equal(ids.view(B, -1).long(), wi.reshape(B, -1))
+
+
+def test_heterogeneous_multi_launch_equals_separate_calls():
+    """segconv.multi: independent convolutions of DIFFERENT shapes (a unit's shortcut next to its first 1x1 and the encoder's
+    skip projection; the three SSMA blocks on three map sizes) in one launch where their kernel forms allow it - every member
+    equals its own single call up to the K-block order of another form (3e-6 of the layer's scale)."""
+    from online_joint_depthfusion_and_semantic_amd.segconv import SegConv, multi
+    g = torch.Generator().manual_seed(123)
+
+    def conv(cin, cout, k, s=1, d=1):
+        m = nn.Conv2d(cin, cout, k, stride=s, dilation=d, padding=d * (k // 2), bias=True).cuda()
+        with torch.no_grad():
+            m.weight.copy_(torch.randn(m.weight.shape, generator=g) / np.sqrt(cin * k * k))
+        return m
+    x15 = to_nhwc((torch.randn((1, 1024, 15, 20), generator=g)).cuda())
+    x30 = to_nhwc((torch.randn((1, 512, 30, 40), generator=g)).cuda())
+    x60 = to_nhwc((torch.randn((1, 48, 60, 80), generator=g)).cuda())
+    x30b = to_nhwc((torch.randn((1, 48, 30, 40), generator=g)).cuda())
+    x15b = to_nhwc((torch.randn((1, 512, 15, 20), generator=g)).cuda())
+    gate = to_nhwc(torch.rand((1, 512, 15, 20), generator=g).cuda())
+    cases = [
+        # layer4 unit 0: shortcut 1024 -> 2048, first 1x1 1024 -> 512 (both in-block split-K), two encoders
+        [(conv(1024, 2048, 1), x15, {}), (conv(1024, 2048, 1), x15, {}), (conv(1024, 512, 1), x15, {'act': 'relu'}), (conv(1024, 512, 1), x15, {'act': 'relu'})],
+        # layer3 unit 0 with the skip projection: stride-2 shortcut, 1x1, 512 -> 24
+        [(conv(512, 1024, 1, s=2), x30, {}), (conv(512, 256, 1), x30, {'act': 'relu'}), (conv(512, 24, 1), x30, {})],
+        # SSMA squeeze on three map sizes, then a plain-form trio (tiny K) with a gate
+        [(conv(48, 4, 3), x60, {'act': 'relu'}), (conv(48, 4, 3), x30b, {'act': 'relu'}), (conv(512, 16, 3), x15b, {'act': 'relu'})],
+        [(conv(16, 512, 3), to_nhwc(torch.randn((1, 16, 15, 20), generator=g).cuda()), {'act': 'sigmoid', 'mul': gate}),
+         (conv(4, 48, 3), to_nhwc(torch.randn((1, 4, 30, 40), generator=g).cuda()), {'act': 'sigmoid'})],
+        # a mix of forms (split-K + plain): falls back to separate launches, same results
+        [(conv(512, 256, 3), x15b, {'act': 'relu'}), (conv(4, 48, 3), to_nhwc(torch.randn((1, 4, 60, 80), generator=g).cuda()), {})],
+    ]
+    for calls in cases:
+        ops = [(SegConv(m), x, kw) for m, x, kw in calls]
+        got = multi(ops)
+        for (op, x, kw), y in zip(ops, got):
+            one = op(x, **kw)
+            scale = one.abs().max().item()
+            assert y.shape == one.shape and (y - one).abs().max().item() <= 3e-6 * scale + 1e-7, (op.c_in, op.c_out)
+            if op.c_out % 8:
+                wide = y.as_strided((1, (op.c_out + 7) // 8 * 8, y.shape[2], y.shape[3]), y.stride())
+                assert float(wide[:, op.c_out:].abs().max()) == 0.0
+    from online_joint_depthfusion_and_semantic_amd import _lib
+    assert _lib.load().ojf_net_check(_lib.stream_ptr(x15.device)) == 0
