@@ -844,6 +844,9 @@ int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
     static const int trace = getenv("OJF_SEG_TRACE") ? atoi(getenv("OJF_SEG_TRACE")) : 0;  // tuning only: one line per launch
     static const int wide1_min = getenv("OJF_SEG_WIDE1_MIN") ? atoi(getenv("OJF_SEG_WIDE1_MIN")) : (1 << 30);  // tuning only
     static const int splitk_nw2_min = getenv("OJF_SEG_SPLITK_NW2_MIN") ? atoi(getenv("OJF_SEG_SPLITK_NW2_MIN")) : (1 << 30);  // tuning only
+    static const int nw2_min_kb = getenv("OJF_SEG_NW2_MIN_KB") ? atoi(getenv("OJF_SEG_NW2_MIN_KB")) : 32;  // tuning only
+    static const int nw2_max_blocks = getenv("OJF_SEG_NW2_MAX_BLOCKS") ? atoi(getenv("OJF_SEG_NW2_MAX_BLOCKS")) : 400;  // tuning only (0: never)
+    static const int plain_nw1_min = getenv("OJF_SEG_PLAIN_NW1_MIN") ? atoi(getenv("OJF_SEG_PLAIN_NW1_MIN")) : 50;  // one pixel tile per wave in the plain form from 50 pixel tiles on (twice the waves in flight for layers that are all latency: -1.4 % of the frame)
     static const int splitk_min_kb = getenv("OJF_SEG_SPLITK_MIN_KB") ? atoi(getenv("OJF_SEG_SPLITK_MIN_KB")) : 8;  // tuning only
     static const int tile_u = getenv("OJF_SEG_TILE_U") ? atoi(getenv("OJF_SEG_TILE_U")) : 1;  // tuning only: K blocks per barrier of the tile kernel
     static const int use_tile = getenv("OJF_SEG_TILE") ? atoi(getenv("OJF_SEG_TILE")) : 0;  // tuning only: register-staged tile kernel
@@ -882,6 +885,9 @@ int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
         if (groups == 1) {
             variant = "<4,2,1,1>";
             hipLaunchKernelGGL((segconv_kernel<4, 2, 1, 1, 3>), dim3(seg_map(g.map, (n_pt + 7) / 8, 1, n)), dim3(256), 0, st, g);
+        } else if (n_pt >= plain_nw1_min) {
+            variant = "<4,1,2,1>";
+            hipLaunchKernelGGL((segconv_kernel<4, 1, 2, 1, 3>), dim3(seg_map(g.map, (n_pt + 1) / 2, (groups + 1) / 2, n)), dim3(256), 0, st, g);
         } else {
             variant = "<4,2,2,1>";
             hipLaunchKernelGGL((segconv_kernel<4, 2, 2, 1, 3>), dim3(seg_map(g.map, (n_pt + 3) / 4, (groups + 1) / 2, n)), dim3(256), 0, st, g);
@@ -900,7 +906,10 @@ int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
         } else if (mw == 2) {
             variant = "<2,1,1,4>";
             hipLaunchKernelGGL((segconv_kernel<2, 1, 1, 4, 3>), dim3(seg_map(g.map, n_pt, a.n_ct / 2, n)), dim3(256), 0, st, g);
-        } else if (n_pt >= splitk_nw2_min) {
+        } else if (n_pt >= splitk_nw2_min || (a.n_kb >= nw2_min_kb && (long)((n_pt + 1) / 2) * groups * n >= 150 && (long)((n_pt + 1) / 2) * groups * n < nw2_max_blocks)) {
+            // two pixel tiles per wave (each weight fragment feeds twice the MFMAs) where that still leaves 150 .. 400 blocks:
+            // measured per layer (round 5): -1 .. -3.4 us on the 30x40 3x3 layers, layer4's 3x3 and 2048 -> 512, the first
+            // transposed convolution; slower with fewer blocks (15x20 maps of 256 channels) and with many (60x80 maps)
             variant = "<4,2,1,4>";
             hipLaunchKernelGGL((segconv_kernel<4, 2, 1, 4, 3>), dim3(seg_map(g.map, (n_pt + 1) / 2, groups, n)), dim3(256), 0, st, g);
         } else {
