@@ -273,6 +273,33 @@ class Case:
                 'stages_all_frames': profile_frames, 'kernels': kernels, 'launches': pipe._engine.launches}
 
 
+def run_lookahead(case, steps, warmup, sync, L, repeats=3):
+    """One scene, Pipeline.fuse_sequence on chunks of L consecutive frames (the 2-D network of the L frames as one batched pass,
+    the frame steps in order): frames/s of a recorded stream handed over in chunks, next to the frame-at-a-time predict leg."""
+    pipe, n = case.pipe, len(case.batches)
+    chunk = lambda i: [case.batches[(i + k) % n] for k in range(L)]
+    times = []
+    with torch.no_grad():
+        for i in range(0, warmup, L):
+            pipe.fuse_sequence(chunk(i), case.db, case.dev)
+        at = (warmup + L - 1) // L * L
+        steps = steps // L * L
+        for _ in range(repeats):
+            sync()
+            t0 = time.perf_counter()
+            for i in range(at, at + steps, L):
+                pipe.fuse_sequence(chunk(i), case.db, case.dev)
+            sync()
+            times.append(time.perf_counter() - t0)
+            at += steps
+        pipe.check()
+    times.sort()
+    med = times[len(times) // 2]
+    return {'workload': workload_name(case.c) + ' - one scene, labels of %d consecutive frames predicted as one batched pass (Pipeline.fuse_sequence), frame steps in order' % L,
+            'lookahead_frames': L, 'value': steps / med, 'unit': 'frames/sec', 'ms_per_step': 1e3 * med / steps, 'steps': steps, 'warmup': warmup,
+            'repeats': repeats, 'value_min': steps / times[-1], 'value_max': steps / times[0]}
+
+
 class ManyScenes:
     """S BenchStreams as one dataset object (Database pulls .scenes / .get_grid from it, modules/database.py:48-58)."""
 
@@ -621,6 +648,7 @@ def main():
                     help="AdapNet++ convolutions: 'hip' = SEGCONV MFMA kernels (default), 'torch' = module forward on MIOpen")
     ap.add_argument('--mode', default='fast', choices=['fast', 'parity'])
     ap.add_argument('--arith', default='f16x3', choices=['f16x3', 'f32'], help='net MFMA arithmetic (include/ojf.h OJF_ARITH_*)')
+    ap.add_argument('--lookahead', type=int, default=0, help='L > 1 (with --semantics --semantic-strategy predict): time Pipeline.fuse_sequence on chunks of L consecutive frames (prints its own line)')
     ap.add_argument('--scenes', type=int, default=0, help='S > 1: time Pipeline.fuse_many over S scenes on this GPU instead (prints its own line)')
     ap.add_argument('--cpu-frames', type=int, default=10, help='timed frames of the CPU baseline (0 = skip)')
     ap.add_argument('--secondary', type=int, default=None,
@@ -703,6 +731,14 @@ def main():
         if world > 1:
             torch.distributed.destroy_process_group()
         return
+    if args.lookahead > 1:
+        case = Case(head, dev, rank, total + args.lookahead)
+        r = run_lookahead(case, args.steps, args.warmup, sync, args.lookahead, args.repeats)
+        if rank == 0:
+            print(json.dumps(dict(r, metric=metric + ', %d-frame look-ahead of the 2-D network (fuse_sequence)' % args.lookahead, n_gpus=world)))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     case = Case(head, dev, rank, total)
     if args.lean:
         res = case.run(args.steps, args.warmup, sync, profile_frames=0, kernel_reps=0, repeats=1)
@@ -754,6 +790,14 @@ def main():
                     r2 = {'workload': workload_name(c2), 'error': repr(e)}
                 torch.cuda.empty_cache()
                 secondary.append(r2)
+            try:  # configs[2] with predicted labels, the 2-D network four frames ahead of the frame steps (one scene)
+                c2 = dict(head, semantics=True, strategy='predict')
+                case2 = Case(c2, dev, rank, 3 * n_sec + 16)
+                secondary.append(run_lookahead(case2, n_sec, 12, sync, 4, 3))
+                del case2
+            except Exception as e:
+                secondary.append({'workload': 'configs[2] predicted labels, 4-frame look-ahead', 'error': repr(e)})
+            torch.cuda.empty_cache()
             for extra, S in ((dict(), 2), (dict(), 4), (dict(semantics=True, strategy='predict'), 4)):
                 c2 = dict(head, **extra)  # several scenes per GPU (fuse_many): aggregate frames/s, next to the S = 1 legs above
                 try:

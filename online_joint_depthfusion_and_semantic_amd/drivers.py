@@ -116,11 +116,23 @@ def test_fusion(config, dataset, device, rank=0, world=1, state_dict=None, log=p
     if state_dict is not None:
         pipeline._fusion_network.load_state_dict(remove_parent(state_dict, '_fusion_network'))
     pipeline = pipeline.to(device).eval()
+    # semantic_strategy 'predict': the 2-D network does not depend on the volumes, so the labels of TESTING.lookahead (default 4)
+    # consecutive frames are predicted as one batched pass (Pipeline.fuse_sequence); the frame steps themselves stay in order
+    lookahead = int(config.TESTING.get('lookahead', 4)) if (config.DATA.semantics and config.DATA.semantic_strategy == 'predict') else 1
     with torch.no_grad():
+        chunk = []
         for batch in _loader(dataset, shard.scenes):
             if not torch.all(torch.isfinite(batch['extrinsics'])):
                 continue
-            pipeline.fuse(_host_pose_batch(batch, device), database, device)
+            if lookahead <= 1:
+                pipeline.fuse(_host_pose_batch(batch, device), database, device)
+                continue
+            chunk.append(_host_pose_batch(batch, device))
+            if len(chunk) == lookahead:
+                pipeline.fuse_sequence(chunk, database, device)
+                chunk = []
+        if chunk:
+            pipeline.fuse_sequence(chunk, database, device)
     pipeline.check()  # loud if the split-fp16 range guard fired
     database.filter(value=config.TESTING.outlier_filter_val)  # on device; to_numpy() only for export
     semantics = bool(config.DATA.semantics)

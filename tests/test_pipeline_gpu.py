@@ -528,3 +528,43 @@ def test_fuse_many_with_predicted_semantics(cuda):
         assert same >= 0.999, (s, same)
         ulp = f16_ulp_distance(db_a.scores[s].volume.cpu().numpy(), db_b.scores[s].volume.cpu().numpy())
         assert ulp.max() <= 1, (s, int(ulp.max()))
+
+
+def test_fuse_sequence_with_predicted_semantics(cuda):
+    """Pipeline.fuse_sequence: consecutive frames of ONE scene, labels of the chunk predicted as one batched AdapNet++ pass,
+    frame steps in order.  Geometry bit for bit as from frame-at-a-time fuse(); label volumes as in the fuse_many test."""
+    from adapnet_golden_util import randomise_net
+    h, w, grid, n_classes, frames = 64, 96, 32, 12, 6
+
+    def build():
+        cfg = default_config(h, w, semantics=True, use_semantics=False, n_classes=n_classes, integrate_mode='fast')
+        cfg.SETTINGS.device = str(cuda)
+        cfg.DATA.semantic_strategy = 'predict'
+        st = make_stream(h, w, grid, n_classes=n_classes)
+        db = Database(st, database_config(cfg))
+        torch.manual_seed(3)
+        pipe = Pipeline(cfg)
+        for m in pipe._fusion_network.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                torch.nn.init.xavier_normal_(m.weight)
+        randomise_net(pipe._semantic_2d_network, 31)
+        for m in pipe._semantic_2d_network.modules():
+            if hasattr(m, 'dropout') and isinstance(m.dropout, bool):
+                m.dropout = False
+        return st, db, pipe.to(cuda).eval()
+    st_a, db_a, seq = build()
+    st_b, db_b, one = build()
+    one.load_state_dict(seq.state_dict())
+    with torch.no_grad():
+        seq.fuse_sequence([_batch(st_a, i, cuda) for i in range(4)], db_a, cuda)
+        seq.fuse_sequence([_batch(st_a, i, cuda) for i in range(4, frames)], db_a, cuda)  # a shorter chunk: another graph
+        for i in range(frames):
+            one.fuse(_batch(st_b, i, cuda), db_b, cuda)
+        seq.check()
+        one.check()
+    s = st_a.scene
+    assert torch.equal(db_a.scenes_est[s].volume.view(torch.int16), db_b.scenes_est[s].volume.view(torch.int16))
+    assert torch.equal(db_a.fusion_weights[s].view(torch.int16), db_b.fusion_weights[s].view(torch.int16))
+    touched = db_b.fusion_weights[s] > 0
+    assert (db_a.ids_est[s].volume[touched] == db_b.ids_est[s].volume[touched]).float().mean().item() >= 0.999
+    assert f16_ulp_distance(db_a.scores[s].volume.cpu().numpy(), db_b.scores[s].volume.cpu().numpy()).max() <= 1
