@@ -644,6 +644,179 @@ __global__ __launch_bounds__(256) void segconv_tile_kernel(const SegGroupArgs gr
     seg_epilogue<MW, NW>(a, acc, ct0, pt0, n_pix, col, kg, rvs, bvs);
 }
 
+// GEMM-shaped form for layers with enough pixels to tile both ways (round 5: the frames of several scenes / a look-ahead
+// chunk as one [B, H, W, C] pass, the 60x80 decoder layers): block = 2 x 2 waves, wave = MT channel tiles x NT pixel tiles
+// (accumulators MT x NT x 4 registers), block tile 32 MT channels x 32 NT pixels.  BOTH operands go through LDS, once per
+// block: the weight fragments as they are packed, the pixel operands ALREADY SPLIT into fp16 halves by the wave that
+// fetched them (one split per element instead of one per consuming wave; the consumers' K loop is ds_read_b128 + MFMA
+// only).  Per K block a wave reads 2 MT + 2 NT fragments for 3 MT NT MFMAs - 16 reads / 48 MFMAs at MT = NT = 4 against
+// 10 / 12 in the split-K form and 8 + 2 loads / 12 in the wide form - and a block fetches 32 KB for 192 MFMAs (the wide form:
+// 16 KB for 48).  Two K blocks in flight per wave in registers, two LDS stages, one barrier per K block.
+// What the first version taught (SQ counters, profiles/r05_seg_experiments.txt): with ONE wave per SIMD the K loop is bound by
+// what the wave must ISSUE - 159 VALU + 48 SALU + 14 scalar loads per K block for 48 MFMAs: per-lane tap / channel-group
+// bookkeeping with a data-dependent loop, bounds tests and 64-bit pointer sums per load, kernel arguments re-fetched
+// from the kernarg segment inside the loop.  Hence: the arguments the loop needs live in locals; the weights are fetched
+// through a buffer resource with the K block as the SCALAR offset (no per-load address VALU); and when the layer's
+// channel groups come in fours (c_in a multiple of 32: every heavy layer) the four lane groups of a K block share the tap,
+// so the tap walk is scalar, the bounds test runs once per tap and a K block's pixel address is one add (ALIGNED).
+template <int MT, int NT, bool DROP, bool ALIGNED>
+__global__ __launch_bounds__(256) void segconv_gemm_kernel(const SegGroupArgs grp)
+{
+    int bx, by, bz;
+    if (!seg_block(grp, bx, by, bz)) return;  // block-uniform
+    const SegArgs &a = grp.a[bz];
+    constexpr int MB = 2 * MT, NB = 2 * NT;   // channel / pixel tiles of the block
+    constexpr int PT = NT / 2 > 0 ? NT / 2 : 1;  // pixel tiles a wave fetches and splits per K block (NB / 4 waves)
+    static_assert(NT == 2 || NT == 4, "NT");
+    __shared__ f32x4 As[2][MB][2][64];
+    __shared__ f32x4 Bs[2][NB][2][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int ct0 = by * MB, pt0 = bx * NB;
+    // (locals: the compiler re-fetches fields of a kernarg-resident struct behind a dynamic index whenever it runs short of SGPRs)
+    const int H = a.H, W = a.W, HoWo = a.Ho * a.Wo, Wo = a.Wo, c8 = a.c8, ksize = a.ksize, dil = a.dil, in_stride = a.in_stride;
+    const int n_pix = a.B * HoWo, n_kb = a.n_kb, n_ct = a.n_ct;
+    const int col = lane & 15, kg = lane >> 4;
+
+    // producer side: this wave's PT pixel tiles (tiles wave * PT .. of the block) and MT weight chunks
+    int iy0[PT], ix0[PT], img0[PT];
+    bool live[PT];
+#pragma unroll
+    for (int n = 0; n < PT; ++n) {
+        const int p = (pt0 + wave * PT + n) * 16 + col;
+        live[n] = p < n_pix;
+        const int b = p / HoWo, q = p - b * HoWo;
+        const int oy = q / Wo, ox = q - oy * Wo;
+        iy0[n] = oy * a.stride - a.pad;
+        ix0[n] = ox * a.stride - a.pad;
+        img0[n] = b * H * W;
+    }
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in), 0, a.in_bytes, 0x00020000);
+    // weights: one resource over the layer's packed fragments; per chunk a lane offset, per K block the scalar offset kb * 2 KB
+    const __amdgpu_buffer_rsrc_t rw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(a.wp), 0, (unsigned)((size_t)n_ct * n_kb * 2048), 0x00020000);
+    unsigned woff[MT];
+#pragma unroll
+    for (int r = 0; r < MT; ++r) {
+        const int c = wave * MT + r, m = c >> 1, h = c & 1;  // chunk c of the block's 2 MB one-KB chunks (channel tile m, half h)
+        int ct = ct0 + m;
+        ct = ct < n_ct ? ct : n_ct - 1;  // (a block past the layer's last channel tile: any valid tile, results unused)
+        woff[r] = (unsigned)(((ct * n_kb) * 128 + h * 64 + lane) * 16);
+    }
+    // K walk of this lane group.  ALIGNED: (tap, first channel group of the K block) are wave-uniform scalars, the lane adds kg
+    int tap_s = 0, cgb_s = 0;                        // ALIGNED: tap, K block inside the tap (c8 / 4 of them)
+    unsigned toff[PT];                               // ALIGNED: byte offset of (tap, channel group kg) per pixel tile, or the out-of-range sentinel
+    int tap = kg / c8, cg = kg - tap * c8;           // general: per-lane walk
+    int ty = tap / ksize, tx = tap - ty * ksize;
+    auto tap_offsets = [&](int t) {
+        const int y = t / ksize, x = t - y * ksize;
+#pragma unroll
+        for (int n = 0; n < PT; ++n) {
+            const int iy = iy0[n] + y * dil, ix = ix0[n] + x * dil;
+            const bool ok = live[n] && y < ksize && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            toff[n] = ok ? (unsigned)(((img0[n] + iy * W + ix) * in_stride + kg * 8) * 4) : 0xfffffff0u;
+        }
+    };
+    if constexpr (ALIGNED) tap_offsets(0);
+    const int n_cgb = c8 >> 2;
+    f32x4 wr[2][MT], xa[2][PT], xb[2][PT];
+    auto issue = [&](int kb, f32x4 (&fw)[MT], f32x4 (&fa)[PT], f32x4 (&fb)[PT]) {
+        const int kbc = kb < n_kb ? kb : n_kb - 1;  // past the end: the last block again (multiplied by zeros)
+#pragma unroll
+        for (int r = 0; r < MT; ++r) fw[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, woff[r], kbc * 2048, 0));
+        if constexpr (ALIGNED) {
+            const unsigned step = (unsigned)cgb_s * 128u;  // four channel groups of 8 floats per K block
+#pragma unroll
+            for (int n = 0; n < PT; ++n) {
+                const bool ok = toff[n] != 0xfffffff0u;
+                const unsigned off = ok ? toff[n] + step : 0xfffffff0u;
+                fa[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+                fb[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off + 16u : 0xfffffff0u, 0, 0));
+            }
+            if (++cgb_s == n_cgb) {  // (uniform) next tap; past the last one every tile is out of range: zeros
+                cgb_s = 0;
+                tap_offsets(++tap_s);
+            }
+        } else {
+            const int dy = ty * dil, dx = tx * dil;
+            const bool in_range = kb < n_kb;
+#pragma unroll
+            for (int n = 0; n < PT; ++n) {
+                const int iy = iy0[n] + dy, ix = ix0[n] + dx;
+                const bool ok = in_range && live[n] && ty < ksize && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                const unsigned off = ok ? (unsigned)(((img0[n] + iy * W + ix) * in_stride + cg * 8) * 4) : 0xfffffff0u;
+                fa[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+                fb[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off + 16u : 0xfffffff0u, 0, 0));
+            }
+            cg += 4;
+            while (cg >= c8) {
+                cg -= c8;
+                if (++tx == ksize) {
+                    tx = 0;
+                    ++ty;
+                }
+            }
+        }
+    };
+    auto stage = [&](int st, const f32x4 (&fw)[MT], const f32x4 (&fa)[PT], const f32x4 (&fb)[PT]) {
+#pragma unroll
+        for (int r = 0; r < MT; ++r) {
+            const int c = wave * MT + r;
+            As[st][c >> 1][c & 1][lane] = fw[r];
+        }
+#pragma unroll
+        for (int n = 0; n < PT; ++n) {
+            f16x8 xh, xl;
+            split8(fa[n], fb[n], xh, xl);
+            Bs[st][wave * PT + n][0][lane] = __builtin_bit_cast(f32x4, xh);
+            Bs[st][wave * PT + n][1][lane] = __builtin_bit_cast(f32x4, xl);
+        }
+    };
+    constexpr int kOps = MT + 2 * PT;  // memory operations of one K block per wave
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ctw = ct0 + wm * MT, ptw = pt0 + wn * NT;  // this wave's accumulator tiles
+
+    issue(0, wr[0], xa[0], xb[0]);
+    issue(1, wr[1], xa[1], xb[1]);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kOps) : "memory");
+    stage(0, wr[0], xa[0], xb[0]);
+    issue(2, wr[0], xa[0], xb[0]);
+    __syncthreads();
+    const int rounds = (n_kb + 1) / 2;
+    for (int r = 0; r < rounds; ++r) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            // K block i = 2 r + s sits in LDS stage s; blocks i + 1 (register slot 1 - s) and i + 2 (slot s) are in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kOps) : "memory");
+            stage(1 - s, wr[1 - s], xa[1 - s], xb[1 - s]);
+            issue(2 * r + s + 3, wr[1 - s], xa[1 - s], xb[1 - s]);
+            f32x4 bh[NT], bl[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                bh[n] = Bs[s][wn * NT + n][0][lane];
+                bl[n] = Bs[s][wn * NT + n][1][lane];
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const f32x4 wh = As[s][wm * MT + m][0][lane], wl = As[s][wm * MT + m][1][lane];
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n] = mfma3(wh, wl, __builtin_bit_cast(f16x8, bh[n]), __builtin_bit_cast(f16x8, bl[n]), acc[m][n]);
+            }
+            __syncthreads();  // stage 1 - s is complete for the next K block; nobody reads stage s any more
+        }
+    }
+    if (ctw >= n_ct || ptw * 16 >= n_pix) return;
+    f32x4 rvs[MT], bvs[MT];
+    seg_vectors<MT>(a, ctw, kg, rvs, bvs);
+    seg_epilogue<MT, NT, DROP>(a, acc, ctw, ptw, n_pix, col, kg, rvs, bvs);
+}
+
 inline float pow2_row_scale(float row_max)
 {
     if (!(row_max > 0.0f) || !std::isfinite(row_max)) return 1.0f;
@@ -852,6 +1025,44 @@ int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
     static const int use_tile = getenv("OJF_SEG_TILE") ? atoi(getenv("OJF_SEG_TILE")) : 0;  // tuning only: register-staged tile kernel
     static const int wide_depth = getenv("OJF_SEG_WIDE_DEPTH") ? atoi(getenv("OJF_SEG_WIDE_DEPTH")) : 3;  // tuning only: 3 | 6 | 8
     const char *variant;
+    // GEMM-shaped form (segconv_gemm_kernel) where both the channels and the pixels tile: the largest block tile that still
+    // gives gemm_min blocks
+    static const int gemm_min = getenv("OJF_SEG_GEMM_MIN") ? atoi(getenv("OJF_SEG_GEMM_MIN")) : (1 << 30);  // tuning (0 < value: on)
+    static const int gemm_min_kb = getenv("OJF_SEG_GEMM_MIN_KB") ? atoi(getenv("OJF_SEG_GEMM_MIN_KB")) : 4;
+    {
+        bool drop_all = true, drop_any = false;
+        for (int i = 0; i < n; ++i) { drop_any = drop_any || g.a[i].rng; drop_all = drop_all && g.a[i].rng; }
+        const long b44 = (long)((a.n_ct + 7) / 8) * ((n_pt + 7) / 8) * n, b24 = (long)((a.n_ct + 3) / 4) * ((n_pt + 7) / 8) * n,
+                   b22 = (long)((a.n_ct + 3) / 4) * ((n_pt + 3) / 4) * n;
+        bool aligned = true;  // every member's channel groups come in fours: the scalar tap walk
+        for (int i = 0; i < n; ++i) aligned = aligned && (g.a[i].c8 % 4) == 0;
+#define OJF_GEMM_LAUNCH(MT_, NT_, GRID_)                                                                                             \
+    do {                                                                                                                             \
+        const dim3 grid__ = GRID_;                                                                                                   \
+        if (drop_any && aligned) hipLaunchKernelGGL((segconv_gemm_kernel<MT_, NT_, true, true>), grid__, dim3(256), 0, st, g);        \
+        else if (drop_any) hipLaunchKernelGGL((segconv_gemm_kernel<MT_, NT_, true, false>), grid__, dim3(256), 0, st, g);             \
+        else if (aligned) hipLaunchKernelGGL((segconv_gemm_kernel<MT_, NT_, false, true>), grid__, dim3(256), 0, st, g);              \
+        else hipLaunchKernelGGL((segconv_gemm_kernel<MT_, NT_, false, false>), grid__, dim3(256), 0, st, g);                          \
+    } while (0)
+        if (a.n_kb >= gemm_min_kb && (drop_all || !drop_any) && b22 >= gemm_min) {
+            g.het.n = 0;
+            if (b44 >= gemm_min && a.n_ct >= 8) {
+                variant = "gemm<4,4>";
+                OJF_GEMM_LAUNCH(4, 4, dim3(seg_map(g.map, (n_pt + 7) / 8, (a.n_ct + 7) / 8, n)));
+            } else if (b24 >= gemm_min) {
+                variant = "gemm<2,4>";
+                OJF_GEMM_LAUNCH(2, 4, dim3(seg_map(g.map, (n_pt + 7) / 8, (a.n_ct + 3) / 4, n)));
+            } else {
+                variant = "gemm<2,2>";
+                OJF_GEMM_LAUNCH(2, 2, dim3(seg_map(g.map, (n_pt + 3) / 4, (a.n_ct + 3) / 4, n)));
+            }
+            if (trace)
+                fprintf(stderr, "segconv %-10s n %d  c_in %4d c_out %4d k %d s %d d %2d  in %3dx%3d out %3dx%3d  n_kb %4d  grid %dx%dx%d S %d%s%s%s\n", variant, n,
+                        a.c8 * 8, a.c_out, a.ksize, a.stride, a.dil, a.H, a.W, a.Ho, a.Wo, a.n_kb, g.map.X, g.map.Y, g.map.Z, g.map.S,
+                        a.res ? " +res" : "", a.mul ? " *mul" : "", a.up > 1 ? " deconv" : "");
+            return check_hip(hipGetLastError(), "segconv_gemm_kernel launch");
+        }
+    }
     // a layer with the always-on dropout in its epilogue (the last convolution of a multi-scale unit): the DROP instantiation of
     // the same kernel - the plain ones do not carry the generator's code (it cost every launch ~0.6 us)
     bool drop = false;

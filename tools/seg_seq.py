@@ -1,12 +1,13 @@
 """Profiling helper: one forward of tools/seg_probe.py in launch order from rocprofv3 csv files -
 python tools/seg_seq.py <kernel_trace.csv> [<counter_collection.csv of an eager run> ...]: start, duration, gap, grid, kernel
 (+ per-dispatch counter values matched by position inside a forward)."""
-import csv, sys, collections
+import csv, sys, collections, os
 def short(n): return n.replace('(anonymous namespace)::', '').replace('void ', '').replace('ojf::', '').replace('at::native::', '').split('(')[0]
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 starts = [i for i, r in enumerate(rows) if 'seg_pack_input' in r['Kernel_Name']]
-f0, f1 = starts[-4], starts[-2]   # two pack launches per forward
+k = int(os.environ.get('SEG_PACKS', 2))  # pack launches per forward (2 x frames per pass)
+f0, f1 = starts[-2 * k], starts[-k]
 ctr = []
 for path in sys.argv[2:]:
     per = collections.OrderedDict()
@@ -14,7 +15,7 @@ for path in sys.argv[2:]:
         per.setdefault(int(r['Dispatch_Id']), [short(r['Kernel_Name']), {}])[1][r['Counter_Name']] = float(r['Counter_Value'])
     d = [v for k, v in sorted(per.items())]
     st = [i for i, v in enumerate(d) if 'seg_pack_input' in v[0]]
-    ctr.append(d[st[-4]:st[-2]])
+    ctr.append(d[st[-2 * k]:st[-k]])
 t0 = int(rows[f0]['Start_Timestamp']); prev = None; tot = 0
 for j, r in enumerate(rows[f0:f1]):
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
