@@ -213,9 +213,9 @@ class SegEngine:
             self.aspp1 = _EASPP(net.eASPP)
         d = net.decoder
         self.deconv1 = SegDeconv(d.deconv1, d.deconv1_bn)
-        self.stage2 = [SegConv(d.stage2[0], d.stage2[1]), SegConv(d.stage2[3], d.stage2[4])]
+        self.stage2 = [SegConv(d.stage2[0], d.stage2[1], pad_in=288), SegConv(d.stage2[3], d.stage2[4])]  # (280 -> 288 input channels: groups of 32)
         self.deconv2 = SegDeconv(d.stage2[6], d.stage2[7])
-        self.stage3 = [SegConv(d.stage3[0], d.stage3[1]), SegConv(d.stage3[3], d.stage3[4]), SegConv(d.stage3[6], d.stage3[7])]
+        self.stage3 = [SegConv(d.stage3[0], d.stage3[1], pad_in=288), SegConv(d.stage3[3], d.stage3[4]), SegConv(d.stage3[6], d.stage3[7])]
         self.deconv3 = SegDeconv(d.stage3[8], d.stage3[9])
         self.fuse1, self.fuse2 = segconv.PoolFC(d.fuse_conv1), segconv.PoolFC(d.fuse_conv2)
         # the always-on dropout of the multi-scale units (adapnet.py:80-82) rides in their last convolution's epilogue: masks
@@ -247,8 +247,14 @@ class SegEngine:
         s2 = nhwc(24 * k, h4, w4, dev, zero=False, batch=B)   # skip2 of both modalities side by side = SSMA's concatenation
         s1 = nhwc(24 * k, h8, w8, dev, zero=False, batch=B)
         top = nhwc(256 * k, h16, w16, dev, zero=False, batch=B)
-        cat2 = nhwc(280, h8, w8, dev, zero=False, batch=B)    # decoder stage 2 input: (deconv1 output, skip1)
-        cat3 = nhwc(280, h4, w4, dev, zero=False, batch=B)    # decoder stage 3 input: (stage 2 output, skip2)
+        # decoder stage inputs: (deconv output 256, gated skip 24, 8 ZERO channels - rows of 288 = 9 x 32 channels let the 3x3
+        # convolutions on them take the scalar tap walk).  Kept per frame shape: the pad is zeroed once, not per frame.
+        key = (B, H, W, str(dev))
+        bufs = self.__dict__.setdefault('_cats', {})
+        if key not in bufs:
+            bufs.clear()
+            bufs[key] = (nhwc(288, h8, w8, dev, zero=True, batch=B), nhwc(288, h4, w4, dev, zero=True, batch=B))
+        cat2, cat3 = bufs[key]
         grouped = self.fusion and not os.environ.get('OJF_SEG_TWO_STREAMS')  # (A/B switch: the round-3 flow on two streams)
         if grouped:
             # The two modality encoders have one architecture: they run in lock-step, every layer ONE grouped launch
@@ -286,10 +292,10 @@ class SegEngine:
         else:
             skip2, skip1, x = s2, s1, top
         self.deconv1(x, out=cat2[:, :256], act='relu')
-        self._skip(cat2[:, :256], skip1, self.fuse1, cat2[:, 256:])
+        self._skip(cat2[:, :256], skip1, self.fuse1, cat2[:, 256:280])
         y = self.stage2[1](self.stage2[0](cat2, act='relu'), act='relu')
         self.deconv2(y, out=cat3[:, :256])
-        self._skip(cat3[:, :256], skip2, self.fuse2, cat3[:, 256:])
+        self._skip(cat3[:, :256], skip2, self.fuse2, cat3[:, 256:280])
         y = self.stage3[1](self.stage3[0](cat3, act='relu'), act='relu')
         y = self.stage3[2](y)
         return self.deconv3(y, zero_pad=False)  # (the classes' pad channels are read by nobody)

@@ -26,6 +26,10 @@
 
 #include "ojf_common.h"
 
+#ifndef OJF_GEMM_ABL
+#define OJF_GEMM_ABL 0
+#endif
+
 namespace ojf {
 
 int *range_flag_device();  // ojf_net.hip: the split-fp16 range guard flag (host-mapped), shared by all kernels
@@ -115,7 +119,7 @@ struct SegMap { int X, Y, Z, S, chunk, V; };
 // (heterogeneous launches - ojf_segconv_forward_multi - : every member has its own map; member z owns the blocks
 // [off[z], off[z + 1]) of the 1-D grid, each range a multiple of 8 so that a block's XCD is the same in both numberings)
 struct SegHetero { int n; int off[kSegGroup + 1]; SegMap map[kSegGroup]; };
-struct SegGroupArgs { SegArgs a[kSegGroup]; SegMap map; SegHetero het; };
+struct SegGroupArgs { SegArgs a[kSegGroup]; SegMap map; SegHetero het; int abl; };  // abl: ablation bits of segconv_gemm_kernel (tools/ only, 0 in production)
 
 __device__ __forceinline__ bool seg_block_map(const SegMap &m, int b, int &bx, int &by, int &bz);
 
@@ -659,8 +663,8 @@ __global__ __launch_bounds__(256) void segconv_tile_kernel(const SegGroupArgs gr
 // through a buffer resource with the K block as the SCALAR offset (no per-load address VALU); and when the layer's
 // channel groups come in fours (c_in a multiple of 32: every heavy layer) the four lane groups of a K block share the tap,
 // so the tap walk is scalar, the bounds test runs once per tap and a K block's pixel address is one add (ALIGNED).
-template <int MT, int NT, bool DROP, bool ALIGNED>
-__global__ __launch_bounds__(256) void segconv_gemm_kernel(const SegGroupArgs grp)
+template <int MT, int NT, bool DROP, bool ALIGNED, int P = 2>  // (P = 3: 218 + 92 registers, one wave per SIMD instead of two - measured slower)
+__global__ __launch_bounds__(256, 2) void segconv_gemm_kernel(const SegGroupArgs grp)
 {
     int bx, by, bz;
     if (!seg_block(grp, bx, by, bz)) return;  // block-uniform
@@ -677,6 +681,7 @@ __global__ __launch_bounds__(256) void segconv_gemm_kernel(const SegGroupArgs gr
     const int H = a.H, W = a.W, HoWo = a.Ho * a.Wo, Wo = a.Wo, c8 = a.c8, ksize = a.ksize, dil = a.dil, in_stride = a.in_stride;
     const int n_pix = a.B * HoWo, n_kb = a.n_kb, n_ct = a.n_ct;
     const int col = lane & 15, kg = lane >> 4;
+    constexpr int abl = OJF_GEMM_ABL;  // build-time ablation (tools/r5_run24.sh): 1 no MFMA, 2 no LDS operand reads, 4 no global loads, 8 no staging, 16 no barrier
 
     // producer side: this wave's PT pixel tiles (tiles wave * PT .. of the block) and MT weight chunks
     int iy0[PT], ix0[PT], img0[PT];
@@ -719,9 +724,10 @@ __global__ __launch_bounds__(256) void segconv_gemm_kernel(const SegGroupArgs gr
     };
     if constexpr (ALIGNED) tap_offsets(0);
     const int n_cgb = c8 >> 2;
-    f32x4 wr[2][MT], xa[2][PT], xb[2][PT];
+    f32x4 wr[P][MT], xa[P][PT], xb[P][PT];  // P K blocks in flight per wave
     auto issue = [&](int kb, f32x4 (&fw)[MT], f32x4 (&fa)[PT], f32x4 (&fb)[PT]) {
         const int kbc = kb < n_kb ? kb : n_kb - 1;  // past the end: the last block again (multiplied by zeros)
+        if (abl & 4) return;
 #pragma unroll
         for (int r = 0; r < MT; ++r) fw[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, woff[r], kbc * 2048, 0));
         if constexpr (ALIGNED) {
@@ -759,6 +765,7 @@ __global__ __launch_bounds__(256) void segconv_gemm_kernel(const SegGroupArgs gr
         }
     };
     auto stage = [&](int st, const f32x4 (&fw)[MT], const f32x4 (&fa)[PT], const f32x4 (&fb)[PT]) {
+        if (abl & 8) return;
 #pragma unroll
         for (int r = 0; r < MT; ++r) {
             const int c = wave * MT + r;
@@ -781,34 +788,53 @@ __global__ __launch_bounds__(256) void segconv_gemm_kernel(const SegGroupArgs gr
         for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ctw = ct0 + wm * MT, ptw = pt0 + wn * NT;  // this wave's accumulator tiles
 
-    issue(0, wr[0], xa[0], xb[0]);
-    issue(1, wr[1], xa[1], xb[1]);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kOps) : "memory");
+#pragma unroll
+    for (int q = 0; q < P; ++q) issue(q, wr[q], xa[q], xb[q]);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * kOps) : "memory");
     stage(0, wr[0], xa[0], xb[0]);
-    issue(2, wr[0], xa[0], xb[0]);
+    issue(P, wr[0], xa[0], xb[0]);
     __syncthreads();
-    const int rounds = (n_kb + 1) / 2;
+    // K block i sits in LDS stage i & 1; blocks i + 1 .. i + P are in flight, block j in register slot j % P
+    const int rounds = (n_kb + 2 * P - 1) / (2 * P);
     for (int r = 0; r < rounds; ++r) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            // K block i = 2 r + s sits in LDS stage s; blocks i + 1 (register slot 1 - s) and i + 2 (slot s) are in flight
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kOps) : "memory");
-            stage(1 - s, wr[1 - s], xa[1 - s], xb[1 - s]);
-            issue(2 * r + s + 3, wr[1 - s], xa[1 - s], xb[1 - s]);
-            f32x4 bh[NT], bl[NT];
+        for (int u = 0; u < 2 * P; ++u) {  // (2 P: a common period of the LDS stage and the register slot)
+            const int i = r * 2 * P + u;
+            if (i >= n_kb) break;  // (uniform; only in the last round)
+            // this block's operands out of LDS FIRST, all sixteen fragments back to back: their latency (hundreds of cycles with
+            // eight waves queueing reads) then passes under the staging of the next block instead of in front of every group of
+            // MFMAs (build-time ablations, round 5: the LDS reads sat 43 us of a 122-us launch in front of the MFMAs)
+            f32x4 bh[NT], bl[NT], ah[2], al[2];
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                bh[n] = Bs[s][wn * NT + n][0][lane];
-                bl[n] = Bs[s][wn * NT + n][1][lane];
+                bh[n] = (abl & 2) ? xa[0][0] : Bs[u & 1][wn * NT + n][0][lane];
+                bl[n] = (abl & 2) ? xb[0][0] : Bs[u & 1][wn * NT + n][1][lane];
             }
+            ah[0] = (abl & 2) ? wr[0][0] : As[u & 1][wm * MT][0][lane];
+            al[0] = (abl & 2) ? wr[1][0] : As[u & 1][wm * MT][1][lane];
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * kOps) : "memory");  // block i + 1 has landed
+            stage((u + 1) & 1, wr[(u + 1) % P], xa[(u + 1) % P], xb[(u + 1) % P]);
+            issue(i + 1 + P, wr[(u + 1) % P], xa[(u + 1) % P], xb[(u + 1) % P]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const f32x4 wh = As[s][wm * MT + m][0][lane], wl = As[s][wm * MT + m][1][lane];
+                if (m + 1 < MT) {  // the next channel tile's weight fragments while this one's twelve MFMAs run
+                    ah[(m + 1) & 1] = (abl & 2) ? wr[0][0] : As[u & 1][wm * MT + m + 1][0][lane];
+                    al[(m + 1) & 1] = (abl & 2) ? wr[1][0] : As[u & 1][wm * MT + m + 1][1][lane];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(abl & 1)) {
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[m][n] = mfma3(wh, wl, __builtin_bit_cast(f16x8, bh[n]), __builtin_bit_cast(f16x8, bl[n]), acc[m][n]);
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n] = mfma3(ah[m & 1], al[m & 1], __builtin_bit_cast(f16x8, bh[n]), __builtin_bit_cast(f16x8, bl[n]), acc[m][n]);
+                } else {
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[m][n][0] += ah[m & 1][0] * bh[n][0] + al[m & 1][1] * bl[n][1];  // (keeps the operands alive)
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __syncthreads();  // stage 1 - s is complete for the next K block; nobody reads stage s any more
+            if (!(abl & 16)) __syncthreads();  // the other stage is complete for the next K block; nobody reads this one any more
         }
     }
     if (ctw >= n_ct || ptw * 16 >= n_pix) return;
@@ -1006,6 +1032,8 @@ unsigned seg_map(SegMap &m, int X, int Y, int Z)
 int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
 {
     g.het.n = 0;
+    static const int abl = getenv("OJF_SEG_ABL") ? atoi(getenv("OJF_SEG_ABL")) : 0;  // tuning only
+    g.abl = abl;
     const SegArgs &a = g.a[0];
     const int n_pt = (a.B * a.Ho * a.Wo + 15) / 16, groups = a.n_ct / kMW;  // pixel tiles, 64-channel groups
     // Enough independent waves (>= 4 per CU) to hide the operand latency: waves own their (channels, pixels) pair.
@@ -1025,9 +1053,11 @@ int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
     static const int use_tile = getenv("OJF_SEG_TILE") ? atoi(getenv("OJF_SEG_TILE")) : 0;  // tuning only: register-staged tile kernel
     static const int wide_depth = getenv("OJF_SEG_WIDE_DEPTH") ? atoi(getenv("OJF_SEG_WIDE_DEPTH")) : 3;  // tuning only: 3 | 6 | 8
     const char *variant;
-    // GEMM-shaped form (segconv_gemm_kernel) where both the channels and the pixels tile: the largest block tile that still
-    // gives gemm_min blocks
-    static const int gemm_min = getenv("OJF_SEG_GEMM_MIN") ? atoi(getenv("OJF_SEG_GEMM_MIN")) : (1 << 30);  // tuning (0 < value: on)
+    // GEMM-shaped form (segconv_gemm_kernel) where both the channels and the pixels tile: the 128 x 128 tile when that alone gives
+    // gemm_min blocks (measured 118 vs 176 us at 300 blocks, but 68 vs 51 at 75), else the 64 x 64 tile from gemm22_min blocks on
+    // (30 vs 38 us at 152 blocks, 23 vs 28 at 640; 53 vs 33 at 76).  The 64 x 128 tile never won a layer (OJF_SEG_GEMM_TILE=1).
+    static const int gemm_min = getenv("OJF_SEG_GEMM_MIN") ? atoi(getenv("OJF_SEG_GEMM_MIN")) : 256;  // (1 << 30: off)
+    static const int gemm22_min = getenv("OJF_SEG_GEMM22_MIN") ? atoi(getenv("OJF_SEG_GEMM22_MIN")) : 128;
     static const int gemm_min_kb = getenv("OJF_SEG_GEMM_MIN_KB") ? atoi(getenv("OJF_SEG_GEMM_MIN_KB")) : 4;
     {
         bool drop_all = true, drop_any = false;
@@ -1044,12 +1074,14 @@ int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
         else if (aligned) hipLaunchKernelGGL((segconv_gemm_kernel<MT_, NT_, false, true>), grid__, dim3(256), 0, st, g);              \
         else hipLaunchKernelGGL((segconv_gemm_kernel<MT_, NT_, false, false>), grid__, dim3(256), 0, st, g);                          \
     } while (0)
-        if (a.n_kb >= gemm_min_kb && (drop_all || !drop_any) && b22 >= gemm_min) {
+        static const int gemm_tile = getenv("OJF_SEG_GEMM_TILE") ? atoi(getenv("OJF_SEG_GEMM_TILE")) : 0;  // tuning: 1 forces <2,4>, 2 <2,2>
+        const bool big = b44 >= gemm_min && a.n_ct >= 8 && gemm_tile < 1;
+        if (a.n_kb >= gemm_min_kb && (drop_all || !drop_any) && (big || b22 >= gemm22_min || (gemm_tile && b22 >= gemm_min))) {
             g.het.n = 0;
-            if (b44 >= gemm_min && a.n_ct >= 8) {
+            if (big) {
                 variant = "gemm<4,4>";
                 OJF_GEMM_LAUNCH(4, 4, dim3(seg_map(g.map, (n_pt + 7) / 8, (a.n_ct + 7) / 8, n)));
-            } else if (b24 >= gemm_min) {
+            } else if (gemm_tile == 1 && b24 >= gemm_min) {
                 variant = "gemm<2,4>";
                 OJF_GEMM_LAUNCH(2, 4, dim3(seg_map(g.map, (n_pt + 7) / 8, (a.n_ct + 3) / 4, n)));
             } else {

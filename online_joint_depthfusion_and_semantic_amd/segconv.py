@@ -46,13 +46,17 @@ def _folded(bias, bn, n):
 class SegConv:
     """``conv`` [+ ``bn`` in eval mode] prepacked for the device; call with NHWC tensors."""
 
-    def __init__(self, conv, bn=None):
+    def __init__(self, conv, bn=None, pad_in=0):
+        """pad_in > c_in: the layer is packed for rows of ``pad_in`` input channels (zero weights for the extra ones, which
+        must hold finite values): a multiple of 32 lets the launch take the scalar tap walk of the GEMM-shaped kernel."""
         _lib.require_gpu()
         lib = _lib.load()
         assert isinstance(conv, torch.nn.Conv2d) and conv.groups == 1 and conv.padding_mode == 'zeros'
         k, s, d, p = conv.kernel_size, conv.stride, conv.dilation, conv.padding
         assert k[0] == k[1] and s[0] == s[1] and d[0] == d[1] and p[0] == p[1], 'square geometry only'
         w = conv.weight.detach().to('cpu', torch.float32).contiguous()
+        if pad_in > w.shape[1]:
+            w = torch.cat([w, torch.zeros(w.shape[0], pad_in - w.shape[1], *w.shape[2:])], dim=1).contiguous()
         scale, bias = _folded(conv.bias, bn, w.shape[0])
         self.c_out, self.c_in = int(w.shape[0]), int(w.shape[1])
         self.k, self.stride, self.dil, self.pad = int(k[0]), int(s[0]), int(d[0]), int(p[0])

@@ -168,14 +168,17 @@ def test_front_end_operators_match_torch(cuda):
         assert torch.allclose(s.cpu().view(19, 23), ws[0], rtol=0, atol=1e-6)
 
 
-@pytest.mark.parametrize('cin,cout,k,stride,dils,h,w', [
-    (256, 64, 1, 1, (1, 1), 60, 80),          # two encoders, one layer (wave-per-tile kernel)
-    (128, 32, 3, 1, (1, 2, 1, 2), 30, 40),    # both dilations of a multi-scale unit of both encoders
-    (64, 64, 3, 1, (3, 6, 12, 3, 6, 12), 15, 20),  # the three cascades of two eASPPs (split-K kernel)
-    (1024, 256, 1, 1, (1, 1), 15, 20), (64, 64, 3, 1, (1, 1), 240, 320)])  # ... and the LDS-shared-weights kernel
-def test_grouped_launch_gives_the_bits_of_single_launches(cin, cout, k, stride, dils, h, w):
+@pytest.mark.parametrize('cin,cout,k,stride,dils,h,w,same_form', [
+    (256, 64, 1, 1, (1, 1), 60, 80, False),   # two encoders, one layer: split-K alone, the 64 x 64 GEMM-shaped form as a pair
+    (256, 256, 3, 1, (1, 2), 60, 80, True),   # the GEMM-shaped form alone and as a pair
+    (128, 32, 3, 1, (1, 2, 1, 2), 30, 40, True),    # both dilations of a multi-scale unit of both encoders
+    (64, 64, 3, 1, (3, 6, 12, 3, 6, 12), 15, 20, True),  # the three cascades of two eASPPs (split-K kernel)
+    (1024, 256, 1, 1, (1, 1), 15, 20, True), (64, 64, 3, 1, (1, 1), 240, 320, True)])  # ... and the LDS-shared-weights kernel
+def test_grouped_launch_gives_the_bits_of_single_launches(cin, cout, k, stride, dils, h, w, same_form):
     """ojf_segconv_forward_group (blockIdx.z = member) against one ojf_segconv_forward per member: same kernels, same
-    arithmetic, same order - identical bits, with residuals and ReLU, on members of different dilation."""
+    arithmetic, same order - identical bits, with residuals and ReLU, on members of different dilation.  Where the block
+    count of the pair moves the launch to another kernel form (same_form False: the K sum is then split differently),
+    the bar is the fp32 rounding of that sum instead."""
     from online_joint_depthfusion_and_semantic_amd import segconv
     dev = torch.device('cuda:0')
     torch.manual_seed(cin + cout + len(dils))
@@ -192,7 +195,10 @@ def test_grouped_launch_gives_the_bits_of_single_launches(cin, cout, k, stride, 
     grouped = segconv.group(convs, xs, act='relu', residuals=ress)
     torch.cuda.synchronize()
     for a, b in zip(single, grouped):
-        assert torch.equal(a, b)
+        if same_form:
+            assert torch.equal(a, b)
+        else:
+            assert torch.allclose(a, b, rtol=0, atol=4e-6 * float(a.abs().max()))
 
 
 # ---- batches: [B, H, W, C] tensors, the frames of several scenes in one pass (round 5) ------------------------------------

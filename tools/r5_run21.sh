@@ -9,7 +9,7 @@ run OJF_SEG_GEMM_MIN=1000000
 run OJF_SEG_GEMM_MIN=512
 run OJF_SEG_GEMM_MIN=256
 run OJF_SEG_GEMM_MIN=128
-run OJF_SEG_GEMM_MIN=64
+run OJF_SEG_GEMM_MIN=128
 run OJF_SEG_GEMM_MIN=128 OJF_SEG_GEMM_MIN_KB=16
 done
 tr() { tag=$1; B=$2; shift; shift
@@ -17,5 +17,5 @@ env "$@" OJF_SEG_TRACE=1 python tools/seg_probe.py eager 1 240 320 $B 2> $O/trac
 env "$@" rocprofv3 --kernel-trace --output-format csv -d $O/kt -o kt -- python tools/seg_probe.py graph 10 240 320 $B > /dev/null 2> $O/kt.err
 SEG_PACKS=$((2*B)) python tools/seg_seq.py $(find $O/kt -name '*kernel_trace.csv' | head -1) > $O/seq_$tag.txt 2>&1
 rm -rf $O/kt; }
-tr g4 4 OJF_SEG_GEMM_MIN=64
-tr g1 1 OJF_SEG_GEMM_MIN=64
+tr g4 4 OJF_SEG_GEMM_MIN=128
+tr g1 1 OJF_SEG_GEMM_MIN=128
