@@ -26,6 +26,12 @@
 
 #include "ojf_common.h"
 
+#ifndef OJF_GEMM_P22
+#define OJF_GEMM_P22 2  // K blocks in flight per wave in the 64 x 64 form
+#endif
+#ifndef OJF_GEMM_PIPE
+#define OJF_GEMM_PIPE 1  // (0: the 64 x 64 tile in the plain order, for A/Bs)
+#endif
 #ifndef OJF_GEMM_ABL
 #define OJF_GEMM_ABL 0
 #endif
@@ -663,8 +669,12 @@ __global__ __launch_bounds__(256) void segconv_tile_kernel(const SegGroupArgs gr
 // through a buffer resource with the K block as the SCALAR offset (no per-load address VALU); and when the layer's
 // channel groups come in fours (c_in a multiple of 32: every heavy layer) the four lane groups of a K block share the tap,
 // so the tap walk is scalar, the bounds test runs once per tap and a K block's pixel address is one add (ALIGNED).
-template <int MT, int NT, bool DROP, bool ALIGNED, int P = 2>  // (P = 3: 218 + 92 registers, one wave per SIMD instead of two - measured slower)
-__global__ __launch_bounds__(256, 2) void segconv_gemm_kernel(const SegGroupArgs grp)
+// KG > 1 (the 64 x 64 tile only): KG such 2 x 2 wave sets per block, set j walking the K blocks j, j + KG, ... with its own LDS
+// stages; at the end sets 1 .. KG - 1 hand their accumulators over through LDS and set 0 adds them IN SET ORDER (deterministic)
+// and runs the epilogue.  For layers whose 64 x 64 tiles give about one block per CU: the K loop is a chain of dependent
+// steps (load -> split -> LDS -> barrier -> MFMA), KG chains per CU run interleaved and each is 1 / KG as long.
+template <int MT, int NT, bool DROP, bool ALIGNED, int P = 2, int KG = 1>  // (P = 3: 218 + 92 registers, one wave per SIMD instead of two - measured slower)
+__global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 4) void segconv_gemm_kernel(const SegGroupArgs grp)
 {
     int bx, by, bz;
     if (!seg_block(grp, bx, by, bz)) return;  // block-uniform
@@ -672,16 +682,20 @@ __global__ __launch_bounds__(256, 2) void segconv_gemm_kernel(const SegGroupArgs
     constexpr int MB = 2 * MT, NB = 2 * NT;   // channel / pixel tiles of the block
     constexpr int PT = NT / 2 > 0 ? NT / 2 : 1;  // pixel tiles a wave fetches and splits per K block (NB / 4 waves)
     static_assert(NT == 2 || NT == 4, "NT");
-    __shared__ f32x4 As[2][MB][2][64];
-    __shared__ f32x4 Bs[2][NB][2][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    static_assert(KG == 1 || (MT == 2 && NT == 2), "K groups: the 64 x 64 tile (a set's accumulators fit its weight stages)");
+    __shared__ f32x4 Asm[KG][2][MB][2][64];
+    __shared__ f32x4 Bsm[KG][2][NB][2][64];
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+    const int kgp = KG == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);  // this wave set's K group
+    f32x4 (&As)[2][MB][2][64] = Asm[kgp];
+    f32x4 (&Bs)[2][NB][2][64] = Bsm[kgp];
     const int wm = wave & 1, wn = wave >> 1;
     const int ct0 = by * MB, pt0 = bx * NB;
     // (locals: the compiler re-fetches fields of a kernarg-resident struct behind a dynamic index whenever it runs short of SGPRs)
     const int H = a.H, W = a.W, HoWo = a.Ho * a.Wo, Wo = a.Wo, c8 = a.c8, ksize = a.ksize, dil = a.dil, in_stride = a.in_stride;
     const int n_pix = a.B * HoWo, n_kb = a.n_kb, n_ct = a.n_ct;
     const int col = lane & 15, kg = lane >> 4;
-    constexpr int abl = OJF_GEMM_ABL;  // build-time ablation (tools/r5_run24.sh): 1 no MFMA, 2 no LDS operand reads, 4 no global loads, 8 no staging, 16 no barrier
+    constexpr int abl = OJF_GEMM_ABL;  // build-time ablation (tools/r5_run24.sh): 1 no MFMA, 2 no LDS operand reads, 4 no global loads, 8 no staging, 16 no barrier, 32 weight walk rotated per pixel block, 64 taps inner
 
     // producer side: this wave's PT pixel tiles (tiles wave * PT .. of the block) and MT weight chunks
     int iy0[PT], ix0[PT], img0[PT];
@@ -709,9 +723,10 @@ __global__ __launch_bounds__(256, 2) void segconv_gemm_kernel(const SegGroupArgs
         woff[r] = (unsigned)(((ct * n_kb) * 128 + h * 64 + lane) * 16);
     }
     // K walk of this lane group.  ALIGNED: (tap, first channel group of the K block) are wave-uniform scalars, the lane adds kg
-    int tap_s = 0, cgb_s = 0;                        // ALIGNED: tap, K block inside the tap (c8 / 4 of them)
+    const int n_cgb = c8 >> 2;
+    int tap_s = KG == 1 ? 0 : kgp / n_cgb, cgb_s = KG == 1 ? 0 : kgp - tap_s * n_cgb;  // ALIGNED: tap, K block inside the tap (c8 / 4 of them)
     unsigned toff[PT];                               // ALIGNED: byte offset of (tap, channel group kg) per pixel tile, or the out-of-range sentinel
-    int tap = kg / c8, cg = kg - tap * c8;           // general: per-lane walk
+    int tap = (kg + 4 * kgp) / c8, cg = (kg + 4 * kgp) - tap * c8;  // general: per-lane walk
     int ty = tap / ksize, tx = tap - ty * ksize;
     auto tap_offsets = [&](int t) {
         const int y = t / ksize, x = t - y * ksize;
@@ -722,11 +737,12 @@ __global__ __launch_bounds__(256, 2) void segconv_gemm_kernel(const SegGroupArgs
             toff[n] = ok ? (unsigned)(((img0[n] + iy * W + ix) * in_stride + kg * 8) * 4) : 0xfffffff0u;
         }
     };
-    if constexpr (ALIGNED) tap_offsets(0);
-    const int n_cgb = c8 >> 2;
+    if constexpr (ALIGNED) tap_offsets(tap_s);
     f32x4 wr[P][MT], xa[P][PT], xb[P][PT];  // P K blocks in flight per wave
-    auto issue = [&](int kb, f32x4 (&fw)[MT], f32x4 (&fa)[PT], f32x4 (&fb)[PT]) {
-        const int kbc = kb < n_kb ? kb : n_kb - 1;  // past the end: the last block again (multiplied by zeros)
+    auto issue = [&](int it, f32x4 (&fw)[MT], f32x4 (&fa)[PT], f32x4 (&fb)[PT]) {  // it: this set's it-th K block
+        const int kb = kgp + KG * it;
+        int kbc = kb < n_kb ? kb : n_kb - 1;  // past the end: the last block again (multiplied by zeros)
+        if (abl & 32) kbc = (kbc + bx * 5) % n_kb;  // (timing only, wrong sums) every pixel block of a channel block on another weight line at any time
         if (abl & 4) return;
 #pragma unroll
         for (int r = 0; r < MT; ++r) fw[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, woff[r], kbc * 2048, 0));
@@ -739,9 +755,14 @@ __global__ __launch_bounds__(256, 2) void segconv_gemm_kernel(const SegGroupArgs
                 fa[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
                 fb[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off + 16u : 0xfffffff0u, 0, 0));
             }
-            if (++cgb_s == n_cgb) {  // (uniform) next tap; past the last one every tile is out of range: zeros
-                cgb_s = 0;
-                tap_offsets(++tap_s);
+            if (abl & 64) {  // (timing only, wrong sums) taps inner, channel groups outer: a K block's pixel lines are the previous block's, shifted
+                if (++tap_s == ksize * ksize) { tap_s = 0; ++cgb_s; }
+                tap_offsets(tap_s);
+            } else
+            cgb_s += KG;
+            if (!(abl & 64) && cgb_s >= n_cgb) {  // (uniform) next tap; past the last one every tile is out of range: zeros
+                do { cgb_s -= n_cgb; ++tap_s; } while (KG > 1 && cgb_s >= n_cgb);
+                tap_offsets(tap_s);
             }
         } else {
             const int dy = ty * dil, dx = tx * dil;
@@ -754,7 +775,7 @@ __global__ __launch_bounds__(256, 2) void segconv_gemm_kernel(const SegGroupArgs
                 fa[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
                 fb[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off + 16u : 0xfffffff0u, 0, 0));
             }
-            cg += 4;
+            cg += 4 * KG;
             while (cg >= c8) {
                 cg -= c8;
                 if (++tx == ksize) {
@@ -764,8 +785,15 @@ __global__ __launch_bounds__(256, 2) void segconv_gemm_kernel(const SegGroupArgs
             }
         }
     };
+    f32x4 sink{0.f, 0.f, 0.f, 0.f};
     auto stage = [&](int st, const f32x4 (&fw)[MT], const f32x4 (&fa)[PT], const f32x4 (&fb)[PT]) {
-        if (abl & 8) return;
+        if (abl & 8) {  // (the loads stay alive: their sum goes into an accumulator)
+#pragma unroll
+            for (int r = 0; r < MT; ++r) sink += fw[r];
+#pragma unroll
+            for (int n = 0; n < PT; ++n) sink += fa[n] + fb[n];
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < MT; ++r) {
             const int c = wave * MT + r;
@@ -793,14 +821,61 @@ __global__ __launch_bounds__(256, 2) void segconv_gemm_kernel(const SegGroupArgs
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * kOps) : "memory");
     stage(0, wr[0], xa[0], xb[0]);
     issue(P, wr[0], xa[0], xb[0]);
+    const int n_it = (n_kb + KG - 1) / KG;  // K blocks per wave set (a set short of one block runs it on zeros)
+    const int rounds = (n_it + 2 * P - 1) / (2 * P);
+    // The 64 x 64 tile has the registers for TWO sets of operand fragments: block i + 1's come out of LDS, and block i + 2 is
+    // split and staged, while block i's twelve MFMAs run - the SQ counters of the plain order (reads -> stage -> MFMAs ->
+    // barrier, one block per CU) had every unit under 25 % busy and the wave waiting 2 / 3 of its time.
+    constexpr bool PIPE = MT == 2 && NT == 2 && KG == 1 && OJF_GEMM_PIPE;
+    if constexpr (PIPE) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * kOps) : "memory");
+        stage(1, wr[1 % P], xa[1 % P], xb[1 % P]);
+        issue(P + 1, wr[1 % P], xa[1 % P], xb[1 % P]);
+        __syncthreads();
+        f32x4 fah[2][MT], fal[2][MT], fbh[2][NT], fbl[2][NT];
+        auto frags = [&](int st, f32x4 (&ah)[MT], f32x4 (&al)[MT], f32x4 (&bh)[NT], f32x4 (&bl)[NT]) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                bh[n] = Bs[st][wn * NT + n][0][lane];
+                bl[n] = Bs[st][wn * NT + n][1][lane];
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                ah[m] = As[st][wm * MT + m][0][lane];
+                al[m] = As[st][wm * MT + m][1][lane];
+            }
+        };
+        frags(0, fah[0], fal[0], fbh[0], fbl[0]);
+        __syncthreads();  // everybody has block 0's fragments: stage 0 may take block 2
+        // blocks i + 1 (stage (i + 1) & 1) and i (in registers) are at hand; i + 2 .. i + 1 + P in flight, block j in register slot j % P
+        for (int r = 0; r < rounds; ++r) {
+#pragma unroll
+            for (int u = 0; u < 2 * P; ++u) {
+                const int i = r * 2 * P + u;
+                if (i >= n_it) break;  // (uniform; only in the last round)
+                frags((u + 1) & 1, fah[(u + 1) & 1], fal[(u + 1) & 1], fbh[(u + 1) & 1], fbl[(u + 1) & 1]);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[0][n] = mfma3(fah[u & 1][0], fal[u & 1][0], __builtin_bit_cast(f16x8, fbh[u & 1][n]), __builtin_bit_cast(f16x8, fbl[u & 1][n]), acc[0][n]);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * kOps) : "memory");  // block i + 2 has landed
+                stage(u & 1, wr[(u + 2) % P], xa[(u + 2) % P], xb[(u + 2) % P]);
+                issue(i + 2 + P, wr[(u + 2) % P], xa[(u + 2) % P], xb[(u + 2) % P]);
+#pragma unroll
+                for (int m = 1; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n] = mfma3(fah[u & 1][m], fal[u & 1][m], __builtin_bit_cast(f16x8, fbh[u & 1][n]), __builtin_bit_cast(f16x8, fbl[u & 1][n]), acc[m][n]);
+                __syncthreads();  // block i + 2 is complete in its stage; nobody reads block i + 1's stage after the next iteration's top
+            }
+        }
+    } else {
     __syncthreads();
     // K block i sits in LDS stage i & 1; blocks i + 1 .. i + P are in flight, block j in register slot j % P
-    const int rounds = (n_kb + 2 * P - 1) / (2 * P);
     for (int r = 0; r < rounds; ++r) {
 #pragma unroll
         for (int u = 0; u < 2 * P; ++u) {  // (2 P: a common period of the LDS stage and the register slot)
             const int i = r * 2 * P + u;
-            if (i >= n_kb) break;  // (uniform; only in the last round)
+            if (i >= n_it) break;  // (uniform; only in the last round)
             // this block's operands out of LDS FIRST, all sixteen fragments back to back: their latency (hundreds of cycles with
             // eight waves queueing reads) then passes under the staging of the next block instead of in front of every group of
             // MFMAs (build-time ablations, round 5: the LDS reads sat 43 us of a 122-us launch in front of the MFMAs)
@@ -837,6 +912,28 @@ __global__ __launch_bounds__(256, 2) void segconv_gemm_kernel(const SegGroupArgs
             if (!(abl & 16)) __syncthreads();  // the other stage is complete for the next K block; nobody reads this one any more
         }
     }
+    }
+    if constexpr (KG > 1) {
+        // (the loop's last barrier has passed: nobody reads the stages any more) a set's accumulators = its 16 KB of weight stages
+        f32x4 *red = &Asm[kgp][0][0][0][0];
+        if (kgp > 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) red[((m * NT + n) * 4 + wave) * 64 + lane] = acc[m][n];
+        }
+        __syncthreads();
+        if (kgp > 0) return;
+#pragma unroll
+        for (int j = 1; j < KG; ++j) {
+            const f32x4 *rj = &Asm[j][0][0][0][0];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] += rj[((m * NT + n) * 4 + wave) * 64 + lane];
+        }
+    }
+    if (abl & 8) acc[0][0] += sink;
     if (ctw >= n_ct || ptw * 16 >= n_pix) return;
     f32x4 rvs[MT], bvs[MT];
     seg_vectors<MT>(a, ctw, kg, rvs, bvs);
@@ -1069,10 +1166,10 @@ int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
 #define OJF_GEMM_LAUNCH(MT_, NT_, GRID_)                                                                                             \
     do {                                                                                                                             \
         const dim3 grid__ = GRID_;                                                                                                   \
-        if (drop_any && aligned) hipLaunchKernelGGL((segconv_gemm_kernel<MT_, NT_, true, true>), grid__, dim3(256), 0, st, g);        \
-        else if (drop_any) hipLaunchKernelGGL((segconv_gemm_kernel<MT_, NT_, true, false>), grid__, dim3(256), 0, st, g);             \
-        else if (aligned) hipLaunchKernelGGL((segconv_gemm_kernel<MT_, NT_, false, true>), grid__, dim3(256), 0, st, g);              \
-        else hipLaunchKernelGGL((segconv_gemm_kernel<MT_, NT_, false, false>), grid__, dim3(256), 0, st, g);                          \
+        if (drop_any && aligned) hipLaunchKernelGGL((segconv_gemm_kernel<MT_, NT_, true, true, (MT_ == 2 && NT_ == 2 ? OJF_GEMM_P22 : 2)>), grid__, dim3(256), 0, st, g);        \
+        else if (drop_any) hipLaunchKernelGGL((segconv_gemm_kernel<MT_, NT_, true, false, (MT_ == 2 && NT_ == 2 ? OJF_GEMM_P22 : 2)>), grid__, dim3(256), 0, st, g);             \
+        else if (aligned) hipLaunchKernelGGL((segconv_gemm_kernel<MT_, NT_, false, true, (MT_ == 2 && NT_ == 2 ? OJF_GEMM_P22 : 2)>), grid__, dim3(256), 0, st, g);              \
+        else hipLaunchKernelGGL((segconv_gemm_kernel<MT_, NT_, false, false, (MT_ == 2 && NT_ == 2 ? OJF_GEMM_P22 : 2)>), grid__, dim3(256), 0, st, g);                          \
     } while (0)
         static const int gemm_tile = getenv("OJF_SEG_GEMM_TILE") ? atoi(getenv("OJF_SEG_GEMM_TILE")) : 0;  // tuning: 1 forces <2,4>, 2 <2,2>
         const bool big = b44 >= gemm_min && a.n_ct >= 8 && gemm_tile < 1;
@@ -1085,8 +1182,21 @@ int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
                 variant = "gemm<2,4>";
                 OJF_GEMM_LAUNCH(2, 4, dim3(seg_map(g.map, (n_pt + 7) / 8, (a.n_ct + 3) / 4, n)));
             } else {
-                variant = "gemm<2,2>";
-                OJF_GEMM_LAUNCH(2, 2, dim3(seg_map(g.map, (n_pt + 3) / 4, (a.n_ct + 3) / 4, n)));
+                // K groups: 2 (4) wave sets per block while the layer's 64 x 64 tiles are about a block per CU and K is long
+                static const int kg2_max = getenv("OJF_SEG_GEMM_KG2_MAX") ? atoi(getenv("OJF_SEG_GEMM_KG2_MAX")) : 0;  // blocks (0: off)
+                static const int kg4_max = getenv("OJF_SEG_GEMM_KG4_MAX") ? atoi(getenv("OJF_SEG_GEMM_KG4_MAX")) : 0;
+                static const int kg_min_kb = getenv("OJF_SEG_GEMM_KG_MIN_KB") ? atoi(getenv("OJF_SEG_GEMM_KG_MIN_KB")) : 16;
+                const dim3 grid22(seg_map(g.map, (n_pt + 3) / 4, (a.n_ct + 3) / 4, n));
+                if (!drop_any && aligned && a.n_kb >= kg_min_kb && b22 <= kg4_max) {
+                    variant = "gemm<2,2>x4";
+                    hipLaunchKernelGGL((segconv_gemm_kernel<2, 2, false, true, 2, 4>), grid22, dim3(1024), 0, st, g);
+                } else if (!drop_any && aligned && a.n_kb >= kg_min_kb && b22 <= kg2_max) {
+                    variant = "gemm<2,2>x2";
+                    hipLaunchKernelGGL((segconv_gemm_kernel<2, 2, false, true, 2, 2>), grid22, dim3(512), 0, st, g);
+                } else {
+                    variant = "gemm<2,2>";
+                    OJF_GEMM_LAUNCH(2, 2, grid22);
+                }
             }
             if (trace)
                 fprintf(stderr, "segconv %-10s n %d  c_in %4d c_out %4d k %d s %d d %2d  in %3dx%3d out %3dx%3d  n_kb %4d  grid %dx%dx%d S %d%s%s%s\n", variant, n,
