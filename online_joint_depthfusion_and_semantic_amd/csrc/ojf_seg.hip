@@ -26,12 +26,6 @@
 
 #include "ojf_common.h"
 
-#ifndef OJF_GEMM_P22
-#define OJF_GEMM_P22 2  // K blocks in flight per wave in the 64 x 64 form
-#endif
-#ifndef OJF_GEMM_PIPE
-#define OJF_GEMM_PIPE 1  // (0: the 64 x 64 tile in the plain order, for A/Bs)
-#endif
 #ifndef OJF_GEMM_ABL
 #define OJF_GEMM_ABL 0
 #endif
@@ -655,55 +649,53 @@ __global__ __launch_bounds__(256) void segconv_tile_kernel(const SegGroupArgs gr
 }
 
 // GEMM-shaped form for layers with enough pixels to tile both ways (round 5: the frames of several scenes / a look-ahead
-// chunk as one [B, H, W, C] pass, the 60x80 decoder layers): block = 2 x 2 waves, wave = MT channel tiles x NT pixel tiles
-// (accumulators MT x NT x 4 registers), block tile 32 MT channels x 32 NT pixels.  BOTH operands go through LDS, once per
-// block: the weight fragments as they are packed, the pixel operands ALREADY SPLIT into fp16 halves by the wave that
-// fetched them (one split per element instead of one per consuming wave; the consumers' K loop is ds_read_b128 + MFMA
-// only).  Per K block a wave reads 2 MT + 2 NT fragments for 3 MT NT MFMAs - 16 reads / 48 MFMAs at MT = NT = 4 against
-// 10 / 12 in the split-K form and 8 + 2 loads / 12 in the wide form - and a block fetches 32 KB for 192 MFMAs (the wide form:
-// 16 KB for 48).  Two K blocks in flight per wave in registers, two LDS stages, one barrier per K block.
-// What the first version taught (SQ counters, profiles/r05_seg_experiments.txt): with ONE wave per SIMD the K loop is bound by
-// what the wave must ISSUE - 159 VALU + 48 SALU + 14 scalar loads per K block for 48 MFMAs: per-lane tap / channel-group
-// bookkeeping with a data-dependent loop, bounds tests and 64-bit pointer sums per load, kernel arguments re-fetched
-// from the kernarg segment inside the loop.  Hence: the arguments the loop needs live in locals; the weights are fetched
-// through a buffer resource with the K block as the SCALAR offset (no per-load address VALU); and when the layer's
-// channel groups come in fours (c_in a multiple of 32: every heavy layer) the four lane groups of a K block share the tap,
-// so the tap walk is scalar, the bounds test runs once per tap and a K block's pixel address is one add (ALIGNED).
-// KG > 1 (the 64 x 64 tile only): KG such 2 x 2 wave sets per block, set j walking the K blocks j, j + KG, ... with its own LDS
-// stages; at the end sets 1 .. KG - 1 hand their accumulators over through LDS and set 0 adds them IN SET ORDER (deterministic)
-// and runs the epilogue.  For layers whose 64 x 64 tiles give about one block per CU: the K loop is a chain of dependent
-// steps (load -> split -> LDS -> barrier -> MFMA), KG chains per CU run interleaved and each is 1 / KG as long.
-template <int MT, int NT, bool DROP, bool ALIGNED, int P = 2, int KG = 1>  // (P = 3: 218 + 92 registers, one wave per SIMD instead of two - measured slower)
-__global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 4) void segconv_gemm_kernel(const SegGroupArgs grp)
+// chunk as one [B, H, W, C] pass, the 60x80 decoder layers): block = WM x WN waves (WN = 4 / WM), wave = MT channel tiles x
+// NT pixel tiles (accumulators MT x NT x 4 registers), block tile 16 WM MT channels x 16 WN NT pixels.  BOTH operands go
+// through LDS, once per block: the weight fragments as they are packed, the pixel operands ALREADY SPLIT into fp16 halves
+// by the wave that fetched them (one split per element instead of one per consuming wave; the consumers' K loop is
+// ds_read_b128 + MFMA only).  Two K blocks in flight per wave in registers, two LDS stages, one barrier per K block.
+// What the measurements of round 5 say about this form (profiles/r05_seg_experiments.txt):
+// * with ONE wave per SIMD the K loop is bound by what the wave must ISSUE: the arguments the loop needs live in locals;
+//   the weights are fetched through a buffer resource with the K block as the SCALAR offset (no per-load address VALU);
+//   and when the layer's channel groups come in fours (c_in a multiple of 32: every heavy layer) the four lane groups
+//   of a K block share the tap, so the tap walk is scalar, the bounds test runs once per tap and a K block's pixel
+//   address is one add (ALIGNED).
+// * a launch's time is a STEP function of its block count: 120 .. 256 blocks of the 64 x 64 tile on a 256 -> 256 3x3 layer
+//   take 29 .. 31 us, 260 .. 512 blocks 43 .. 54 us, 520 blocks 69 us (one block per CU runs no faster when its
+//   neighbour idles).  Neither more waves per CU (K groups inside a block), nor a second set of operand registers
+//   (next block's LDS reads under this block's MFMAs), nor 3 / 4 K blocks in flight, nor another K order moved the
+//   time of a given grid by more than 2 %.  Hence the MENU of tile shapes in seg_launch: the shape is chosen so that
+//   the block count lands just under a multiple of the CU count.
+template <int MT, int NT, bool DROP, bool ALIGNED, int WM = 2, int P = 2>  // (P = 3 / 4: measured no faster)
+__global__ __launch_bounds__(256, 2) void segconv_gemm_kernel(const SegGroupArgs grp)
 {
     int bx, by, bz;
     if (!seg_block(grp, bx, by, bz)) return;  // block-uniform
     const SegArgs &a = grp.a[bz];
-    constexpr int MB = 2 * MT, NB = 2 * NT;   // channel / pixel tiles of the block
-    constexpr int PT = NT / 2 > 0 ? NT / 2 : 1;  // pixel tiles a wave fetches and splits per K block (NB / 4 waves)
-    static_assert(NT == 2 || NT == 4, "NT");
-    static_assert(KG == 1 || (MT == 2 && NT == 2), "K groups: the 64 x 64 tile (a set's accumulators fit its weight stages)");
-    __shared__ f32x4 Asm[KG][2][MB][2][64];
-    __shared__ f32x4 Bsm[KG][2][NB][2][64];
-    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
-    const int kgp = KG == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);  // this wave set's K group
-    f32x4 (&As)[2][MB][2][64] = Asm[kgp];
-    f32x4 (&Bs)[2][NB][2][64] = Bsm[kgp];
-    const int wm = wave & 1, wn = wave >> 1;
+    static_assert(WM == 1 || WM == 2 || WM == 4, "WM");
+    constexpr int WN = 4 / WM;
+    constexpr int MB = WM * MT, NB = WN * NT;  // channel / pixel tiles of the block
+    constexpr int PT = (NB + 3) / 4;           // pixel tiles a wave fetches and splits per K block
+    constexpr int CW = (2 * MB + 3) / 4;       // one-KB weight chunks (channel tile, half) a wave fetches per K block
+    __shared__ f32x4 As[2][MB][2][64];
+    __shared__ f32x4 Bs[2][NB][2][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (a scalar: the guards below are branches, not lane masks)
+    const int wm = wave % WM, wn = wave / WM;
+    constexpr bool kShortPix = 4 * PT > NB, kShortW = 4 * CW > 2 * MB;  // the last wave(s) fetch less than a full share
     const int ct0 = by * MB, pt0 = bx * NB;
     // (locals: the compiler re-fetches fields of a kernarg-resident struct behind a dynamic index whenever it runs short of SGPRs)
     const int H = a.H, W = a.W, HoWo = a.Ho * a.Wo, Wo = a.Wo, c8 = a.c8, ksize = a.ksize, dil = a.dil, in_stride = a.in_stride;
     const int n_pix = a.B * HoWo, n_kb = a.n_kb, n_ct = a.n_ct;
     const int col = lane & 15, kg = lane >> 4;
-    constexpr int abl = OJF_GEMM_ABL;  // build-time ablation (tools/r5_run24.sh): 1 no MFMA, 2 no LDS operand reads, 4 no global loads, 8 no staging, 16 no barrier, 32 weight walk rotated per pixel block, 64 taps inner
+    constexpr int abl = OJF_GEMM_ABL;  // build-time ablation (tools/r5_run24.sh, r5_run36.sh): 1 no MFMA, 2 no LDS operand reads, 4 no global loads, 8 no staging, 16 no barrier, 32 weight walk rotated per pixel block, 64 taps inner
 
-    // producer side: this wave's PT pixel tiles (tiles wave * PT .. of the block) and MT weight chunks
+    // producer side: this wave's PT pixel tiles (tiles wave * PT .. of the block) and CW weight chunks
     int iy0[PT], ix0[PT], img0[PT];
     bool live[PT];
 #pragma unroll
     for (int n = 0; n < PT; ++n) {
         const int p = (pt0 + wave * PT + n) * 16 + col;
-        live[n] = p < n_pix;
+        live[n] = p < n_pix && (!kShortPix || wave * PT + n < NB);
         const int b = p / HoWo, q = p - b * HoWo;
         const int oy = q / Wo, ox = q - oy * Wo;
         iy0[n] = oy * a.stride - a.pad;
@@ -714,19 +706,19 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 4) void segconv_gemm_kernel
     // weights: one resource over the layer's packed fragments; per chunk a lane offset, per K block the scalar offset kb * 2 KB
     const __amdgpu_buffer_rsrc_t rw =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(a.wp), 0, (unsigned)((size_t)n_ct * n_kb * 2048), 0x00020000);
-    unsigned woff[MT];
+    unsigned woff[CW];
 #pragma unroll
-    for (int r = 0; r < MT; ++r) {
-        const int c = wave * MT + r, m = c >> 1, h = c & 1;  // chunk c of the block's 2 MB one-KB chunks (channel tile m, half h)
+    for (int r = 0; r < CW; ++r) {
+        const int c = wave * CW + r, m = c >> 1, h = c & 1;  // chunk c of the block's 2 MB one-KB chunks (channel tile m, half h)
         int ct = ct0 + m;
         ct = ct < n_ct ? ct : n_ct - 1;  // (a block past the layer's last channel tile: any valid tile, results unused)
         woff[r] = (unsigned)(((ct * n_kb) * 128 + h * 64 + lane) * 16);
     }
     // K walk of this lane group.  ALIGNED: (tap, first channel group of the K block) are wave-uniform scalars, the lane adds kg
     const int n_cgb = c8 >> 2;
-    int tap_s = KG == 1 ? 0 : kgp / n_cgb, cgb_s = KG == 1 ? 0 : kgp - tap_s * n_cgb;  // ALIGNED: tap, K block inside the tap (c8 / 4 of them)
+    int tap_s = 0, cgb_s = 0;                        // ALIGNED: tap, K block inside the tap (c8 / 4 of them)
     unsigned toff[PT];                               // ALIGNED: byte offset of (tap, channel group kg) per pixel tile, or the out-of-range sentinel
-    int tap = (kg + 4 * kgp) / c8, cg = (kg + 4 * kgp) - tap * c8;  // general: per-lane walk
+    int tap = kg / c8, cg = kg - tap * c8;           // general: per-lane walk
     int ty = tap / ksize, tx = tap - ty * ksize;
     auto tap_offsets = [&](int t) {
         const int y = t / ksize, x = t - y * ksize;
@@ -737,19 +729,20 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 4) void segconv_gemm_kernel
             toff[n] = ok ? (unsigned)(((img0[n] + iy * W + ix) * in_stride + kg * 8) * 4) : 0xfffffff0u;
         }
     };
-    if constexpr (ALIGNED) tap_offsets(tap_s);
-    f32x4 wr[P][MT], xa[P][PT], xb[P][PT];  // P K blocks in flight per wave
-    auto issue = [&](int it, f32x4 (&fw)[MT], f32x4 (&fa)[PT], f32x4 (&fb)[PT]) {  // it: this set's it-th K block
-        const int kb = kgp + KG * it;
+    if constexpr (ALIGNED) tap_offsets(0);
+    f32x4 wr[P][CW], xa[P][PT], xb[P][PT];  // P K blocks in flight per wave
+    auto issue = [&](int kb, f32x4 (&fw)[CW], f32x4 (&fa)[PT], f32x4 (&fb)[PT]) {
         int kbc = kb < n_kb ? kb : n_kb - 1;  // past the end: the last block again (multiplied by zeros)
         if (abl & 32) kbc = (kbc + bx * 5) % n_kb;  // (timing only, wrong sums) every pixel block of a channel block on another weight line at any time
         if (abl & 4) return;
 #pragma unroll
-        for (int r = 0; r < MT; ++r) fw[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, woff[r], kbc * 2048, 0));
+        for (int r = 0; r < CW; ++r)
+            if (!kShortW || wave * CW + r < 2 * MB) fw[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, woff[r], kbc * 2048, 0));
         if constexpr (ALIGNED) {
             const unsigned step = (unsigned)cgb_s * 128u;  // four channel groups of 8 floats per K block
 #pragma unroll
             for (int n = 0; n < PT; ++n) {
+                if (kShortPix && wave * PT + n >= NB) continue;  // (wave-uniform: the block's NB tiles do not fill the last wave's share)
                 const bool ok = toff[n] != 0xfffffff0u;
                 const unsigned off = ok ? toff[n] + step : 0xfffffff0u;
                 fa[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
@@ -758,24 +751,23 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 4) void segconv_gemm_kernel
             if (abl & 64) {  // (timing only, wrong sums) taps inner, channel groups outer: a K block's pixel lines are the previous block's, shifted
                 if (++tap_s == ksize * ksize) { tap_s = 0; ++cgb_s; }
                 tap_offsets(tap_s);
-            } else
-            cgb_s += KG;
-            if (!(abl & 64) && cgb_s >= n_cgb) {  // (uniform) next tap; past the last one every tile is out of range: zeros
-                do { cgb_s -= n_cgb; ++tap_s; } while (KG > 1 && cgb_s >= n_cgb);
-                tap_offsets(tap_s);
+            } else if (++cgb_s == n_cgb) {  // (uniform) next tap; past the last one every tile is out of range: zeros
+                cgb_s = 0;
+                tap_offsets(++tap_s);
             }
         } else {
             const int dy = ty * dil, dx = tx * dil;
             const bool in_range = kb < n_kb;
 #pragma unroll
             for (int n = 0; n < PT; ++n) {
+                if (kShortPix && wave * PT + n >= NB) continue;
                 const int iy = iy0[n] + dy, ix = ix0[n] + dx;
                 const bool ok = in_range && live[n] && ty < ksize && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
                 const unsigned off = ok ? (unsigned)(((img0[n] + iy * W + ix) * in_stride + cg * 8) * 4) : 0xfffffff0u;
                 fa[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
                 fb[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off + 16u : 0xfffffff0u, 0, 0));
             }
-            cg += 4 * KG;
+            cg += 4;
             while (cg >= c8) {
                 cg -= c8;
                 if (++tx == ksize) {
@@ -786,28 +778,59 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 4) void segconv_gemm_kernel
         }
     };
     f32x4 sink{0.f, 0.f, 0.f, 0.f};
-    auto stage = [&](int st, const f32x4 (&fw)[MT], const f32x4 (&fa)[PT], const f32x4 (&fb)[PT]) {
+    auto stage = [&](int st, const f32x4 (&fw)[CW], const f32x4 (&fa)[PT], const f32x4 (&fb)[PT]) {
         if (abl & 8) {  // (the loads stay alive: their sum goes into an accumulator)
 #pragma unroll
-            for (int r = 0; r < MT; ++r) sink += fw[r];
+            for (int r = 0; r < CW; ++r) sink += fw[r];
 #pragma unroll
             for (int n = 0; n < PT; ++n) sink += fa[n] + fb[n];
             return;
         }
 #pragma unroll
-        for (int r = 0; r < MT; ++r) {
-            const int c = wave * MT + r;
-            As[st][c >> 1][c & 1][lane] = fw[r];
+        for (int r = 0; r < CW; ++r) {
+            const int c = wave * CW + r;
+            if (!kShortW || c < 2 * MB) As[st][c >> 1][c & 1][lane] = fw[r];
         }
 #pragma unroll
         for (int n = 0; n < PT; ++n) {
+            if (kShortPix && wave * PT + n >= NB) continue;
             f16x8 xh, xl;
             split8(fa[n], fb[n], xh, xl);
             Bs[st][wave * PT + n][0][lane] = __builtin_bit_cast(f32x4, xh);
             Bs[st][wave * PT + n][1][lane] = __builtin_bit_cast(f32x4, xl);
         }
     };
-    constexpr int kOps = MT + 2 * PT;  // memory operations of one K block per wave
+    // memory operations of one K block of THIS wave (the count s_waitcnt works with); the waves of a block differ when NB or
+    // 2 MB is not a multiple of four: a wave with a short share waits for all of its few loads
+    constexpr int kOpsFull = CW + 2 * PT;
+    int my_ops = kOpsFull;
+    if constexpr (kShortPix || kShortW) {
+        my_ops = 0;
+        for (int r = 0; r < CW; ++r) my_ops += !kShortW || wave * CW + r < 2 * MB;
+        for (int t = 0; t < PT; ++t) my_ops += 2 * (!kShortPix || wave * PT + t < NB);
+    }
+    auto wait_landed = [&]() {  // all but the newest P - 1 blocks of this wave have landed
+        if constexpr (kShortPix || kShortW) {
+            static_assert(kOpsFull <= 12 && P == 2, "wait_landed: cases");
+            switch (my_ops) {  // (s_waitcnt takes an immediate)
+            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+            case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+            case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * kOpsFull) : "memory");
+        }
+    };
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -818,67 +841,20 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 4) void segconv_gemm_kernel
 
 #pragma unroll
     for (int q = 0; q < P; ++q) issue(q, wr[q], xa[q], xb[q]);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * kOps) : "memory");
+    wait_landed();
     stage(0, wr[0], xa[0], xb[0]);
     issue(P, wr[0], xa[0], xb[0]);
-    const int n_it = (n_kb + KG - 1) / KG;  // K blocks per wave set (a set short of one block runs it on zeros)
-    const int rounds = (n_it + 2 * P - 1) / (2 * P);
-    // The 64 x 64 tile has the registers for TWO sets of operand fragments: block i + 1's come out of LDS, and block i + 2 is
-    // split and staged, while block i's twelve MFMAs run - the SQ counters of the plain order (reads -> stage -> MFMAs ->
-    // barrier, one block per CU) had every unit under 25 % busy and the wave waiting 2 / 3 of its time.
-    constexpr bool PIPE = MT == 2 && NT == 2 && KG == 1 && OJF_GEMM_PIPE;
-    if constexpr (PIPE) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * kOps) : "memory");
-        stage(1, wr[1 % P], xa[1 % P], xb[1 % P]);
-        issue(P + 1, wr[1 % P], xa[1 % P], xb[1 % P]);
-        __syncthreads();
-        f32x4 fah[2][MT], fal[2][MT], fbh[2][NT], fbl[2][NT];
-        auto frags = [&](int st, f32x4 (&ah)[MT], f32x4 (&al)[MT], f32x4 (&bh)[NT], f32x4 (&bl)[NT]) {
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                bh[n] = Bs[st][wn * NT + n][0][lane];
-                bl[n] = Bs[st][wn * NT + n][1][lane];
-            }
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                ah[m] = As[st][wm * MT + m][0][lane];
-                al[m] = As[st][wm * MT + m][1][lane];
-            }
-        };
-        frags(0, fah[0], fal[0], fbh[0], fbl[0]);
-        __syncthreads();  // everybody has block 0's fragments: stage 0 may take block 2
-        // blocks i + 1 (stage (i + 1) & 1) and i (in registers) are at hand; i + 2 .. i + 1 + P in flight, block j in register slot j % P
-        for (int r = 0; r < rounds; ++r) {
-#pragma unroll
-            for (int u = 0; u < 2 * P; ++u) {
-                const int i = r * 2 * P + u;
-                if (i >= n_it) break;  // (uniform; only in the last round)
-                frags((u + 1) & 1, fah[(u + 1) & 1], fal[(u + 1) & 1], fbh[(u + 1) & 1], fbl[(u + 1) & 1]);
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[0][n] = mfma3(fah[u & 1][0], fal[u & 1][0], __builtin_bit_cast(f16x8, fbh[u & 1][n]), __builtin_bit_cast(f16x8, fbl[u & 1][n]), acc[0][n]);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * kOps) : "memory");  // block i + 2 has landed
-                stage(u & 1, wr[(u + 2) % P], xa[(u + 2) % P], xb[(u + 2) % P]);
-                issue(i + 2 + P, wr[(u + 2) % P], xa[(u + 2) % P], xb[(u + 2) % P]);
-#pragma unroll
-                for (int m = 1; m < MT; ++m)
-#pragma unroll
-                    for (int n = 0; n < NT; ++n)
-                        acc[m][n] = mfma3(fah[u & 1][m], fal[u & 1][m], __builtin_bit_cast(f16x8, fbh[u & 1][n]), __builtin_bit_cast(f16x8, fbl[u & 1][n]), acc[m][n]);
-                __syncthreads();  // block i + 2 is complete in its stage; nobody reads block i + 1's stage after the next iteration's top
-            }
-        }
-    } else {
     __syncthreads();
     // K block i sits in LDS stage i & 1; blocks i + 1 .. i + P are in flight, block j in register slot j % P
+    const int rounds = (n_kb + 2 * P - 1) / (2 * P);
     for (int r = 0; r < rounds; ++r) {
 #pragma unroll
         for (int u = 0; u < 2 * P; ++u) {  // (2 P: a common period of the LDS stage and the register slot)
             const int i = r * 2 * P + u;
-            if (i >= n_it) break;  // (uniform; only in the last round)
-            // this block's operands out of LDS FIRST, all sixteen fragments back to back: their latency (hundreds of cycles with
-            // eight waves queueing reads) then passes under the staging of the next block instead of in front of every group of
-            // MFMAs (build-time ablations, round 5: the LDS reads sat 43 us of a 122-us launch in front of the MFMAs)
+            if (i >= n_kb) break;  // (uniform; only in the last round)
+            // this block's pixel operands and the first channel tile's weights out of LDS FIRST, back to back: their latency
+            // (hundreds of cycles with the block's waves queueing reads) then passes under the staging of the next block instead
+            // of in front of every group of MFMAs
             f32x4 bh[NT], bl[NT], ah[2], al[2];
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
@@ -886,17 +862,17 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 4) void segconv_gemm_kernel
                 bl[n] = (abl & 2) ? xb[0][0] : Bs[u & 1][wn * NT + n][1][lane];
             }
             ah[0] = (abl & 2) ? wr[0][0] : As[u & 1][wm * MT][0][lane];
-            al[0] = (abl & 2) ? wr[1][0] : As[u & 1][wm * MT][1][lane];
+            al[0] = (abl & 2) ? wr[1 % P][0] : As[u & 1][wm * MT][1][lane];
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * kOps) : "memory");  // block i + 1 has landed
+            wait_landed();  // block i + 1 has landed
             stage((u + 1) & 1, wr[(u + 1) % P], xa[(u + 1) % P], xb[(u + 1) % P]);
             issue(i + 1 + P, wr[(u + 1) % P], xa[(u + 1) % P], xb[(u + 1) % P]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                if (m + 1 < MT) {  // the next channel tile's weight fragments while this one's twelve MFMAs run
+                if (m + 1 < MT) {  // the next channel tile's weight fragments while this one's MFMAs run
                     ah[(m + 1) & 1] = (abl & 2) ? wr[0][0] : As[u & 1][wm * MT + m + 1][0][lane];
-                    al[(m + 1) & 1] = (abl & 2) ? wr[1][0] : As[u & 1][wm * MT + m + 1][1][lane];
+                    al[(m + 1) & 1] = (abl & 2) ? wr[1 % P][0] : As[u & 1][wm * MT + m + 1][1][lane];
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(abl & 1)) {
@@ -910,27 +886,6 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 4) void segconv_gemm_kernel
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (!(abl & 16)) __syncthreads();  // the other stage is complete for the next K block; nobody reads this one any more
-        }
-    }
-    }
-    if constexpr (KG > 1) {
-        // (the loop's last barrier has passed: nobody reads the stages any more) a set's accumulators = its 16 KB of weight stages
-        f32x4 *red = &Asm[kgp][0][0][0][0];
-        if (kgp > 0) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) red[((m * NT + n) * 4 + wave) * 64 + lane] = acc[m][n];
-        }
-        __syncthreads();
-        if (kgp > 0) return;
-#pragma unroll
-        for (int j = 1; j < KG; ++j) {
-            const f32x4 *rj = &Asm[j][0][0][0][0];
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] += rj[((m * NT + n) * 4 + wave) * 64 + lane];
         }
     }
     if (abl & 8) acc[0][0] += sink;
@@ -1150,59 +1105,59 @@ int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
     static const int use_tile = getenv("OJF_SEG_TILE") ? atoi(getenv("OJF_SEG_TILE")) : 0;  // tuning only: register-staged tile kernel
     static const int wide_depth = getenv("OJF_SEG_WIDE_DEPTH") ? atoi(getenv("OJF_SEG_WIDE_DEPTH")) : 3;  // tuning only: 3 | 6 | 8
     const char *variant;
-    // GEMM-shaped form (segconv_gemm_kernel) where both the channels and the pixels tile: the 128 x 128 tile when that alone gives
-    // gemm_min blocks (measured 118 vs 176 us at 300 blocks, but 68 vs 51 at 75), else the 64 x 64 tile from gemm22_min blocks on
-    // (30 vs 38 us at 152 blocks, 23 vs 28 at 640; 53 vs 33 at 76).  The 64 x 128 tile never won a layer (OJF_SEG_GEMM_TILE=1).
-    static const int gemm_min = getenv("OJF_SEG_GEMM_MIN") ? atoi(getenv("OJF_SEG_GEMM_MIN")) : 256;  // (1 << 30: off)
-    static const int gemm22_min = getenv("OJF_SEG_GEMM22_MIN") ? atoi(getenv("OJF_SEG_GEMM22_MIN")) : 128;
+    // GEMM-shaped form (segconv_gemm_kernel) where both the channels and the pixels tile: the 128 x 128 tile when that alone
+    // gives gemm_min blocks (measured 118 vs 176 us at 300 blocks, but 68 vs 51 at 75), else the 64 x 64 tile from gemm22_min
+    // blocks on (30 vs 38 us at 152 blocks, 23 vs 28 at 640; 53 vs 33 at 76).  A launch's time is a step function of its
+    // block count (120 .. 256 blocks of one layer 29 .. 31 us, 260 .. 512 blocks 43 .. 54 us, 520 blocks 69 us), so the
+    // 128 x 160 tile takes over where it saves a round of 256 blocks (four frames of a 60x80 map: 240 blocks for 300, 94 vs
+    // 103 us).  Measured and not in the menu: 64 x 80 / 64 x 96 / 64 x 160 tiles (44 / 46 / 65 us against 46 for 64 x 64 on the
+    // 60x80 256 -> 256 3x3 layer of one frame, although 240 / 200 / 120 blocks instead of 300: a block with more work per K
+    // block is slower by more than its share), the 64 x 128 tile (never won a layer).
+    static const int gemm_min = getenv("OJF_SEG_GEMM_MIN") ? atoi(getenv("OJF_SEG_GEMM_MIN")) : 256;  // 128 x 128 tile alone gives this many blocks (1 << 30: off)
+    static const int gemm22_min = getenv("OJF_SEG_GEMM22_MIN") ? atoi(getenv("OJF_SEG_GEMM22_MIN")) : 128;  // ... or the 64 x 64 tile this many
     static const int gemm_min_kb = getenv("OJF_SEG_GEMM_MIN_KB") ? atoi(getenv("OJF_SEG_GEMM_MIN_KB")) : 4;
+    static const int gemm_shape = getenv("OJF_SEG_GEMM_SHAPE") ? atoi(getenv("OJF_SEG_GEMM_SHAPE")) : -1;  // tuning: force menu entry
+    static const int gemm_menu = getenv("OJF_SEG_GEMM_MENU") ? atoi(getenv("OJF_SEG_GEMM_MENU")) : 0xff;  // tuning: bit 2 = the 128 x 160 tile allowed
     {
         bool drop_all = true, drop_any = false;
         for (int i = 0; i < n; ++i) { drop_any = drop_any || g.a[i].rng; drop_all = drop_all && g.a[i].rng; }
-        const long b44 = (long)((a.n_ct + 7) / 8) * ((n_pt + 7) / 8) * n, b24 = (long)((a.n_ct + 3) / 4) * ((n_pt + 7) / 8) * n,
-                   b22 = (long)((a.n_ct + 3) / 4) * ((n_pt + 3) / 4) * n;
+        const long b44 = (long)((a.n_ct + 7) / 8) * ((n_pt + 7) / 8) * n, b22 = (long)((a.n_ct + 3) / 4) * ((n_pt + 3) / 4) * n;
         bool aligned = true;  // every member's channel groups come in fours: the scalar tap walk
         for (int i = 0; i < n; ++i) aligned = aligned && (g.a[i].c8 % 4) == 0;
-#define OJF_GEMM_LAUNCH(MT_, NT_, GRID_)                                                                                             \
+#define OJF_GEMM_LAUNCH(MT_, NT_, WM_, GRID_)                                                                                         \
     do {                                                                                                                             \
         const dim3 grid__ = GRID_;                                                                                                   \
-        if (drop_any && aligned) hipLaunchKernelGGL((segconv_gemm_kernel<MT_, NT_, true, true, (MT_ == 2 && NT_ == 2 ? OJF_GEMM_P22 : 2)>), grid__, dim3(256), 0, st, g);        \
-        else if (drop_any) hipLaunchKernelGGL((segconv_gemm_kernel<MT_, NT_, true, false, (MT_ == 2 && NT_ == 2 ? OJF_GEMM_P22 : 2)>), grid__, dim3(256), 0, st, g);             \
-        else if (aligned) hipLaunchKernelGGL((segconv_gemm_kernel<MT_, NT_, false, true, (MT_ == 2 && NT_ == 2 ? OJF_GEMM_P22 : 2)>), grid__, dim3(256), 0, st, g);              \
-        else hipLaunchKernelGGL((segconv_gemm_kernel<MT_, NT_, false, false, (MT_ == 2 && NT_ == 2 ? OJF_GEMM_P22 : 2)>), grid__, dim3(256), 0, st, g);                          \
+        if (drop_any && aligned) hipLaunchKernelGGL((segconv_gemm_kernel<MT_, NT_, true, true, WM_>), grid__, dim3(256), 0, st, g);   \
+        else if (drop_any) hipLaunchKernelGGL((segconv_gemm_kernel<MT_, NT_, true, false, WM_>), grid__, dim3(256), 0, st, g);        \
+        else if (aligned) hipLaunchKernelGGL((segconv_gemm_kernel<MT_, NT_, false, true, WM_>), grid__, dim3(256), 0, st, g);         \
+        else hipLaunchKernelGGL((segconv_gemm_kernel<MT_, NT_, false, false, WM_>), grid__, dim3(256), 0, st, g);                     \
     } while (0)
-        static const int gemm_tile = getenv("OJF_SEG_GEMM_TILE") ? atoi(getenv("OJF_SEG_GEMM_TILE")) : 0;  // tuning: 1 forces <2,4>, 2 <2,2>
-        const bool big = b44 >= gemm_min && a.n_ct >= 8 && gemm_tile < 1;
-        if (a.n_kb >= gemm_min_kb && (drop_all || !drop_any) && (big || b22 >= gemm22_min || (gemm_tile && b22 >= gemm_min))) {
-            g.het.n = 0;
-            if (big) {
-                variant = "gemm<4,4>";
-                OJF_GEMM_LAUNCH(4, 4, dim3(seg_map(g.map, (n_pt + 7) / 8, (a.n_ct + 7) / 8, n)));
-            } else if (gemm_tile == 1 && b24 >= gemm_min) {
-                variant = "gemm<2,4>";
-                OJF_GEMM_LAUNCH(2, 4, dim3(seg_map(g.map, (n_pt + 7) / 8, (a.n_ct + 3) / 4, n)));
-            } else {
-                // K groups: 2 (4) wave sets per block while the layer's 64 x 64 tiles are about a block per CU and K is long
-                static const int kg2_max = getenv("OJF_SEG_GEMM_KG2_MAX") ? atoi(getenv("OJF_SEG_GEMM_KG2_MAX")) : 0;  // blocks (0: off)
-                static const int kg4_max = getenv("OJF_SEG_GEMM_KG4_MAX") ? atoi(getenv("OJF_SEG_GEMM_KG4_MAX")) : 0;
-                static const int kg_min_kb = getenv("OJF_SEG_GEMM_KG_MIN_KB") ? atoi(getenv("OJF_SEG_GEMM_KG_MIN_KB")) : 16;
-                const dim3 grid22(seg_map(g.map, (n_pt + 3) / 4, (a.n_ct + 3) / 4, n));
-                if (!drop_any && aligned && a.n_kb >= kg_min_kb && b22 <= kg4_max) {
-                    variant = "gemm<2,2>x4";
-                    hipLaunchKernelGGL((segconv_gemm_kernel<2, 2, false, true, 2, 4>), grid22, dim3(1024), 0, st, g);
-                } else if (!drop_any && aligned && a.n_kb >= kg_min_kb && b22 <= kg2_max) {
-                    variant = "gemm<2,2>x2";
-                    hipLaunchKernelGGL((segconv_gemm_kernel<2, 2, false, true, 2, 2>), grid22, dim3(512), 0, st, g);
-                } else {
-                    variant = "gemm<2,2>";
-                    OJF_GEMM_LAUNCH(2, 2, grid22);
-                }
+        struct Shape { int a, b; const char *name; };  // channel / pixel tiles of the block
+        static const Shape menu[] = {{4, 4, "gemm 64x64"}, {8, 8, "gemm 128x128"}, {8, 10, "gemm 128x160"}};
+        const bool big = b44 >= gemm_min && a.n_ct >= 8;
+        if (a.n_kb >= gemm_min_kb && (drop_all || !drop_any) && (big || b22 >= gemm22_min)) {
+            int best = big ? 1 : 0;
+            if (big && ((gemm_menu >> 2) & 1)) {
+                const long b810 = (long)((a.n_ct + 7) / 8) * ((n_pt + 9) / 10) * n;
+                if (b810 >= 200 && (b810 + 255) / 256 < (b44 + 255) / 256) best = 2;
             }
-            if (trace)
-                fprintf(stderr, "segconv %-10s n %d  c_in %4d c_out %4d k %d s %d d %2d  in %3dx%3d out %3dx%3d  n_kb %4d  grid %dx%dx%d S %d%s%s%s\n", variant, n,
-                        a.c8 * 8, a.c_out, a.ksize, a.stride, a.dil, a.H, a.W, a.Ho, a.Wo, a.n_kb, g.map.X, g.map.Y, g.map.Z, g.map.S,
-                        a.res ? " +res" : "", a.mul ? " *mul" : "", a.up > 1 ? " deconv" : "");
-            return check_hip(hipGetLastError(), "segconv_gemm_kernel launch");
+            if (gemm_shape >= 0) best = gemm_shape > 2 ? 2 : gemm_shape;
+            if (best >= 0) {
+                g.het.n = 0;
+                const Shape &sh = menu[best];
+                variant = sh.name;
+                const dim3 grid(seg_map(g.map, (n_pt + sh.b - 1) / sh.b, (a.n_ct + sh.a - 1) / sh.a, n));
+                switch (best) {
+                case 0: OJF_GEMM_LAUNCH(2, 2, 2, grid); break;
+                case 1: OJF_GEMM_LAUNCH(4, 4, 2, grid); break;
+                default: OJF_GEMM_LAUNCH(4, 5, 2, grid); break;
+                }
+                if (trace)
+                    fprintf(stderr, "segconv %-12s n %d  c_in %4d c_out %4d k %d s %d d %2d  in %3dx%3d out %3dx%3d  n_kb %4d  grid %dx%dx%d S %d%s%s%s\n", variant, n,
+                            a.c8 * 8, a.c_out, a.ksize, a.stride, a.dil, a.H, a.W, a.Ho, a.Wo, a.n_kb, g.map.X, g.map.Y, g.map.Z, g.map.S,
+                            a.res ? " +res" : "", a.mul ? " *mul" : "", a.up > 1 ? " deconv" : "");
+                return check_hip(hipGetLastError(), "segconv_gemm_kernel launch");
+            }
         }
     }
     // a layer with the always-on dropout in its epilogue (the last convolution of a multi-scale unit): the DROP instantiation of
