@@ -790,14 +790,16 @@ def main():
                     r2 = {'workload': workload_name(c2), 'error': repr(e)}
                 torch.cuda.empty_cache()
                 secondary.append(r2)
-            try:  # configs[2] with predicted labels, the 2-D network four frames ahead of the frame steps (one scene)
-                c2 = dict(head, semantics=True, strategy='predict')
-                case2 = Case(c2, dev, rank, 3 * n_sec + 16)
-                secondary.append(run_lookahead(case2, n_sec, 12, sync, 4, 3))
-                del case2
-            except Exception as e:
-                secondary.append({'workload': 'configs[2] predicted labels, 4-frame look-ahead', 'error': repr(e)})
-            torch.cuda.empty_cache()
+            for L in (4, 8):  # configs[2] with predicted labels, the 2-D network L frames ahead of the frame steps (one scene)
+                try:
+                    c2 = dict(head, semantics=True, strategy='predict')
+                    n_la = (n_sec + L - 1) // L * L
+                    case2 = Case(c2, dev, rank, 3 * n_la + 4 * L)
+                    secondary.append(run_lookahead(case2, n_la, 2 * L, sync, L, 3))
+                    del case2
+                except Exception as e:
+                    secondary.append({'workload': 'configs[2] predicted labels, %d-frame look-ahead' % L, 'error': repr(e)})
+                torch.cuda.empty_cache()
             for extra, S in ((dict(), 2), (dict(), 4), (dict(semantics=True, strategy='predict'), 4)):
                 c2 = dict(head, **extra)  # several scenes per GPU (fuse_many): aggregate frames/s, next to the S = 1 legs above
                 try:

@@ -36,5 +36,11 @@ python bench.py --height 120 --width 160 --grid 64 --cpu-frames 0 --secondary 0 
 for S in 2 4; do python bench.py --steps 100 --warmup 10 --repeats 3 --scenes $S >> $O/bench_fuse_many.json 2>/dev/null; done
 python bench.py --steps 60 --warmup 10 --repeats 3 --scenes 4 --semantics --semantic-strategy predict >> $O/bench_fuse_many.json 2>/dev/null
 for B in 1 2 4 8; do python tools/seg_probe.py graph 30 240 320 $B 2>&1 | grep "seg engine" >> $O/seg_engine_batches.txt; done
+# per-launch timeline of the 2-D engine (one frame per pass) and the kernel form every layer runs in
+OJF_SEG_TRACE=1 python tools/seg_probe.py eager 1 240 320 1 2>&1 | grep "^segconv" | tail -100 > $O/seg_forms_b1.txt
+rocprofv3 --kernel-trace --output-format csv -d $O/kts -o kts -- python tools/seg_probe.py graph 10 240 320 1 > /dev/null 2> $O/kts.err
+SEG_PACKS=2 python tools/seg_seq.py $(find $O/kts -name '*kernel_trace.csv' | head -1) > $O/seg_launch_timeline.txt 2>&1
+timeout 120 tools/microbench/grid_barrier > $O/grid_barrier.txt 2>&1
+rm -rf $O/kts
 rm -rf $O/kt $O/pf $O/pw $O/sq $O/kp $O/ktr $O/cf $O/cw $O/sqp $O/sqt
 ls -la $O
