@@ -273,7 +273,7 @@ class Case:
                 'stages_all_frames': profile_frames, 'kernels': kernels, 'launches': pipe._engine.launches}
 
 
-def run_lookahead(case, steps, warmup, sync, L, repeats=3):
+def run_lookahead(case, steps, warmup, sync, L, repeats=3, prefetch=True):
     """One scene, Pipeline.fuse_sequence on chunks of L consecutive frames (the 2-D network of the L frames as one batched pass,
     the frame steps in order): frames/s of a recorded stream handed over in chunks, next to the frame-at-a-time predict leg."""
     pipe, n = case.pipe, len(case.batches)
@@ -281,14 +281,14 @@ def run_lookahead(case, steps, warmup, sync, L, repeats=3):
     times = []
     with torch.no_grad():
         for i in range(0, warmup, L):
-            pipe.fuse_sequence(chunk(i), case.db, case.dev)
+            pipe.fuse_sequence(chunk(i), case.db, case.dev, prefetch=chunk(i + L) if prefetch else None)
         at = (warmup + L - 1) // L * L
         steps = steps // L * L
         for _ in range(repeats):
             sync()
             t0 = time.perf_counter()
             for i in range(at, at + steps, L):
-                pipe.fuse_sequence(chunk(i), case.db, case.dev)
+                pipe.fuse_sequence(chunk(i), case.db, case.dev, prefetch=chunk(i + L) if prefetch else None)
             sync()
             times.append(time.perf_counter() - t0)
             at += steps
@@ -296,7 +296,7 @@ def run_lookahead(case, steps, warmup, sync, L, repeats=3):
     times.sort()
     med = times[len(times) // 2]
     return {'workload': workload_name(case.c) + ' - one scene, labels of %d consecutive frames predicted as one batched pass (Pipeline.fuse_sequence), frame steps in order' % L,
-            'lookahead_frames': L, 'value': steps / med, 'unit': 'frames/sec', 'ms_per_step': 1e3 * med / steps, 'steps': steps, 'warmup': warmup,
+            'lookahead_frames': L, 'next_chunk_prefetched_on_side_stream': bool(prefetch), 'value': steps / med, 'unit': 'frames/sec', 'ms_per_step': 1e3 * med / steps, 'steps': steps, 'warmup': warmup,
             'repeats': repeats, 'value_min': steps / times[-1], 'value_max': steps / times[0]}
 
 

@@ -120,7 +120,7 @@ def test_fusion(config, dataset, device, rank=0, world=1, state_dict=None, log=p
     # consecutive frames are predicted as one batched pass (Pipeline.fuse_sequence); the frame steps themselves stay in order
     lookahead = int(config.TESTING.get('lookahead', 4)) if (config.DATA.semantics and config.DATA.semantic_strategy == 'predict') else 1
     with torch.no_grad():
-        chunk = []
+        chunk, ahead = [], None  # `ahead`: the chunk in front of `chunk`, fused once `chunk` is complete (its 2-D pass then runs beside ahead's frame steps)
         for batch in _loader(dataset, shard.scenes):
             if not torch.all(torch.isfinite(batch['extrinsics'])):
                 continue
@@ -129,8 +129,11 @@ def test_fusion(config, dataset, device, rank=0, world=1, state_dict=None, log=p
                 continue
             chunk.append(_host_pose_batch(batch, device))
             if len(chunk) == lookahead:
-                pipeline.fuse_sequence(chunk, database, device)
-                chunk = []
+                if ahead is not None:
+                    pipeline.fuse_sequence(ahead, database, device, prefetch=chunk)
+                ahead, chunk = chunk, []
+        if ahead is not None:
+            pipeline.fuse_sequence(ahead, database, device, prefetch=chunk or None)
         if chunk:
             pipeline.fuse_sequence(chunk, database, device)
     pipeline.check()  # loud if the split-fp16 range guard fired

@@ -282,19 +282,73 @@ class Pipeline(torch.nn.Module):
         scores = scores.to(self.device).float().reshape(h * w).contiguous()
         return sem_ids, scores
 
-    def fuse_sequence(self, batches, database, device):
+    def fuse_sequence(self, batches, database, device, prefetch=None):
         """``for b in batches: fuse(b, database, device)`` for CONSECUTIVE frames (of one scene, or any mix of scenes in stream
         order).  The frame steps stay strictly in order - frame t+1 is extracted from the volume frame t was integrated into -
         but the 2-D network does not depend on the volumes: with ``semantic_strategy: predict`` the labels of all the frames
-        are predicted first, as ONE batched AdapNet++ pass (SegEngine.predict_many: 0.77 ms per frame at four frames per pass
-        against 1.28 ms one at a time).  Same volumes as the separate calls, with the batched pass's rounding of
-        the scores (include/ojf.h, ojf_segconv_forward_batch).  The reference predicts and fuses one frame at a time
-        (test_fusion.py:68-80); a driver that reads a recorded stream can hand over chunks (drivers.test_fusion does, 4 frames)."""
+        are predicted first, as ONE batched AdapNet++ pass (SegEngine.predict_many: 0.62 / 0.48 ms per frame at four / eight
+        frames per pass against 1.20 ms one at a time).  Same volumes as the separate calls, with the batched
+        pass's rounding of the scores (include/ojf.h, ojf_segconv_forward_batch).  The reference predicts and fuses one frame
+        at a time (test_fusion.py:68-80); a driver that reads a recorded stream can hand over chunks (drivers.test_fusion does).
+
+        ``prefetch``: the chunk the NEXT call will bring (the same batch objects).  Its batched 2-D pass is enqueued on a
+        side stream before this chunk's frame steps and runs beside them; the next call finds the labels ready.  Bits do not
+        depend on it (the same graph replay, another stream)."""
         self.device = torch.device(device)
-        sems = self._frame_semantics_many(batches)
+        sems = self._take_prefetched(batches)
+        if sems is None:
+            sems = self._frame_semantics_many(batches)
+        if prefetch and self._batched_2d_pass_applies(prefetch):
+            if sems and sems[0][0] is not None and not self.__dict__.get('_prefetch', {}).get('taken'):
+                sems = [(i.clone(), sc.clone()) for i, sc in sems]  # (this chunk's labels sit in the graph's output buffers, which the prefetched pass overwrites)
+            self._prefetch_semantics(prefetch)
         fp = self._weights_fingerprint()
         for b, sem in zip(batches, sems):
             self._fuse_frame(b, database, 0, sem, fp)
+
+    def _batched_2d_pass_applies(self, batches):
+        cfg = self.config
+        return bool(cfg.DATA.semantics and cfg.DATA.semantic_strategy == 'predict' and len(batches) > 1
+                    and not self._semantic_2d_network.training and cfg.SEMANTIC_2D_MODEL.get('stage', 2) != 1)
+
+    def _prefetch_semantics(self, batches):
+        """The batched 2-D pass of ``batches`` on the side stream; the labels land in one of two persistent result slots
+        (the graph's own output buffers belong to the next replay).  Slot k % 2 was last read by the frame steps of the
+        chunk two calls ago: they are in front of the side stream's wait on the caller's stream."""
+        if not self._batched_2d_pass_applies(batches):
+            return
+        cur = torch.cuda.current_stream(self.device)
+        pf = self.__dict__.setdefault('_prefetch', {'stream': torch.cuda.Stream(device=self.device), 'n': 0, 'slots': [None, None], 'ready': None, 'taken': False})
+        side = pf['stream']
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), torch.no_grad():
+            sems = self._frame_semantics_many(batches)
+            if sems[0][0] is None:
+                return
+            k = pf['n'] % 2
+            slot = pf['slots'][k]
+            if slot is None or len(slot) != len(sems) or slot[0][0].shape != sems[0][0].shape:
+                side.synchronize(); cur.synchronize()  # (first use / another chunk shape: allocate the slot once, outside any overlap)
+                slot = pf['slots'][k] = [(torch.empty_like(i), torch.empty_like(sc)) for i, sc in sems]
+            for (di, dsc), (i, sc) in zip(slot, sems):
+                di.copy_(i, non_blocking=True)
+                dsc.copy_(sc, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        pf['n'] += 1
+        pf['ready'] = {'ids': [id(b) for b in batches], 'sems': slot, 'event': ev}
+
+    def _take_prefetched(self, batches):
+        pf = self.__dict__.get('_prefetch')
+        if pf:
+            pf['taken'] = False
+        if not pf or not pf['ready']:
+            return None
+        ready, pf['ready'] = pf['ready'], None
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ready['event'])  # (also orders this call's own 2-D pass, if the chunk is another one, behind the side stream's use of the graph buffers)
+        pf['taken'] = ready['ids'] == [id(b) for b in batches]
+        return ready['sems'] if pf['taken'] else None
 
     def _frame_semantics_many(self, batches):
         """``[_frame_semantics(b) for b in batches]``; with ``semantic_strategy: predict`` on the HIP engine the S frames go

@@ -568,3 +568,49 @@ def test_fuse_sequence_with_predicted_semantics(cuda):
     touched = db_b.fusion_weights[s] > 0
     assert (db_a.ids_est[s].volume[touched] == db_b.ids_est[s].volume[touched]).float().mean().item() >= 0.999
     assert f16_ulp_distance(db_a.scores[s].volume.cpu().numpy(), db_b.scores[s].volume.cpu().numpy()).max() <= 1
+
+
+@pytest.mark.gpu
+def test_fuse_sequence_prefetch_changes_no_bit(cuda):
+    """fuse_sequence(chunk, prefetch=next chunk): the next chunk's batched 2-D pass runs on a side stream beside this chunk's
+    frame steps.  The same graph replays, on another stream: all four volumes bit for bit as without the prefetch, also when
+    the announced chunk is NOT the one that comes (its labels are dropped) and across a change of chunk length."""
+    from adapnet_golden_util import randomise_net
+    h, w, grid, n_classes, frames = 64, 96, 32, 12, 14
+
+    def build():
+        cfg = default_config(h, w, semantics=True, use_semantics=False, n_classes=n_classes, integrate_mode='fast')
+        cfg.SETTINGS.device = str(cuda)
+        cfg.DATA.semantic_strategy = 'predict'
+        st = make_stream(h, w, grid, n_classes=n_classes)
+        db = Database(st, database_config(cfg))
+        torch.manual_seed(3)
+        pipe = Pipeline(cfg)
+        for m in pipe._fusion_network.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                torch.nn.init.xavier_normal_(m.weight)
+        randomise_net(pipe._semantic_2d_network, 31)
+        for m in pipe._semantic_2d_network.modules():
+            if hasattr(m, 'dropout') and isinstance(m.dropout, bool):
+                m.dropout = False
+        return st, db, pipe.to(cuda).eval()
+    st_a, db_a, pre = build()
+    st_b, db_b, plain = build()
+    plain.load_state_dict(pre.state_dict())
+    chunks = [(0, 4), (4, 8), (8, 12), (12, 14)]
+    with torch.no_grad():
+        ba = [[_batch(st_a, i, cuda) for i in range(a, b)] for a, b in chunks]
+        bb = [[_batch(st_b, i, cuda) for i in range(a, b)] for a, b in chunks]
+        pre.fuse_sequence(ba[0], db_a, cuda, prefetch=ba[1])
+        pre.fuse_sequence(ba[1], db_a, cuda, prefetch=ba[3])   # announces the wrong chunk: ba[2] comes
+        pre.fuse_sequence(ba[2], db_a, cuda, prefetch=ba[3])   # ... and a shorter one next
+        pre.fuse_sequence(ba[3], db_a, cuda)
+        for c in bb:
+            plain.fuse_sequence(c, db_b, cuda)
+        pre.check()
+        plain.check()
+    s = st_a.scene
+    assert torch.equal(db_a.scenes_est[s].volume.view(torch.int16), db_b.scenes_est[s].volume.view(torch.int16))
+    assert torch.equal(db_a.fusion_weights[s].view(torch.int16), db_b.fusion_weights[s].view(torch.int16))
+    assert torch.equal(db_a.ids_est[s].volume, db_b.ids_est[s].volume)
+    assert torch.equal(db_a.scores[s].volume.view(torch.int16), db_b.scores[s].volume.view(torch.int16))
