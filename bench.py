@@ -648,6 +648,7 @@ def main():
                     help="AdapNet++ convolutions: 'hip' = SEGCONV MFMA kernels (default), 'torch' = module forward on MIOpen")
     ap.add_argument('--mode', default='fast', choices=['fast', 'parity'])
     ap.add_argument('--arith', default='f16x3', choices=['f16x3', 'f32'], help='net MFMA arithmetic (include/ojf.h OJF_ARITH_*)')
+    ap.add_argument('--no-prefetch', action='store_true', help='with --lookahead: the next chunk is NOT announced to fuse_sequence (its 2-D pass then runs in front of its frame steps instead of beside the previous chunk\'s)')
     ap.add_argument('--lookahead', type=int, default=0, help='L > 1 (with --semantics --semantic-strategy predict): time Pipeline.fuse_sequence on chunks of L consecutive frames (prints its own line)')
     ap.add_argument('--scenes', type=int, default=0, help='S > 1: time Pipeline.fuse_many over S scenes on this GPU instead (prints its own line)')
     ap.add_argument('--cpu-frames', type=int, default=10, help='timed frames of the CPU baseline (0 = skip)')
@@ -733,7 +734,7 @@ def main():
         return
     if args.lookahead > 1:
         case = Case(head, dev, rank, total + args.lookahead)
-        r = run_lookahead(case, args.steps, args.warmup, sync, args.lookahead, args.repeats)
+        r = run_lookahead(case, args.steps, args.warmup, sync, args.lookahead, args.repeats, prefetch=not args.no_prefetch)
         if rank == 0:
             print(json.dumps(dict(r, metric=metric + ', %d-frame look-ahead of the 2-D network (fuse_sequence)' % args.lookahead, n_gpus=world)))
         if world > 1:

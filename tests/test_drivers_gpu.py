@@ -163,3 +163,28 @@ def test_test_fusion_on_a_replica_layout(cuda, tmp_path):
     a, b = db.scenes_est[st.scene].volume, db2.scenes_est[st.scene].volume
     assert torch.equal(torch.as_tensor(a).cpu().view(torch.int16), torch.as_tensor(b).cpu().view(torch.int16))
     assert int((torch.as_tensor(db.fusion_weights[st.scene]).float() > 0).sum()) > 1000
+
+
+def test_test_fusion_lookahead_chunks(cuda):
+    """test_fusion with ``semantic_strategy: predict``: the driver hands Pipeline.fuse_sequence chunks of TESTING.lookahead
+    frames and announces the next chunk (its 2-D pass on the side stream).  Ten frames in chunks of 3 (3 + 3 + 3 + 1) and of
+    8 (8 + 2) against frame at a time: the geometry does not depend on the labels here (use_semantics False) - bit for bit;
+    the label volumes agree where the per-frame argmax is not a near-tie."""
+    h, w, grid, n_classes = 64, 96, 32, 12
+
+    def run(lookahead):
+        cfg = _training_defaults(default_config(h, w, semantics=True, use_semantics=False, n_classes=n_classes))
+        cfg.SETTINGS.device = str(cuda)
+        cfg.DATA.semantic_strategy = 'predict'
+        cfg.TESTING.lookahead = lookahead
+        ds = SyntheticDataset(h, w, grid, 10, scenes=['room_0'], n_classes=n_classes)
+        torch.manual_seed(5)  # the same randomly initialised networks in every run
+        return run_test_fusion(cfg, ds, cuda, log=lambda *a: None)
+    r1, _, db1 = run(1)
+    for lookahead in (3, 8):
+        r, _, db = run(lookahead)
+        assert torch.equal(db.scenes_est['room_0'].volume.view(torch.int16), db1.scenes_est['room_0'].volume.view(torch.int16))
+        assert torch.equal(db.fusion_weights['room_0'].view(torch.int16), db1.fusion_weights['room_0'].view(torch.int16))
+        assert r['mse'] == r1['mse'] and r['iou'] == r1['iou']
+        touched = db1.fusion_weights['room_0'] > 0
+        assert (db.ids_est['room_0'].volume[touched] == db1.ids_est['room_0'].volume[touched]).float().mean().item() >= 0.98

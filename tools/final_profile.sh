@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/final
 rm -rf $O; mkdir -p $O
-python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/pytest_gpu.txt
+python -m pytest tests -m gpu -q 2>&1 | tail -60 > $O/pytest_gpu_tail.txt; tail -3 $O/pytest_gpu_tail.txt > $O/pytest_gpu.txt
 python bench.py > $O/bench.json 2> $O/bench.err
 B="python bench.py --steps 100 --warmup 10 --lean"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- $B > $O/bench_under_rocprof.json 2> $O/kt.err
