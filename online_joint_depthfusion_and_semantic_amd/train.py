@@ -461,8 +461,19 @@ class HipTrainNet:
 
     def _epoch(self, mods):
         """A number that changes whenever a convolution weight or bias may have changed (ojf_trainer_forward's
-        ``weights_epoch``): the per-tensor (address, version) tuples are compared element-wise - no sum that could cancel."""
-        sig = tuple((c.weight.data_ptr(), c.weight._version, _p(c.bias), c.bias._version if c.bias is not None else -1) for c, _, _ in mods)
+        ``weights_epoch``).  Per pass only the version counters of the cached tensor list are compared (element-wise - no
+        sum that could cancel): in-place updates (optimizer steps, ``load_state_dict``) bump them.  The storage addresses
+        (``p.data = ...``, replaced Parameter objects) are compared on every 64th pass; ``invalidate()`` covers writes that
+        bump nothing (``dist.broadcast(p.data)``)."""
+        cache = self.__dict__.get('_epoch_cache')
+        self._epoch_calls = self.__dict__.get('_epoch_calls', 0) + 1
+        if cache is None or self._weights_sig is None or self._epoch_calls % 64 == 0:
+            tensors = [t for c, _, _ in mods for t in (c.weight, c.bias) if t is not None]
+            addr = tuple(t.data_ptr() for t in tensors)
+            if cache is None or addr != cache[1] or self._weights_sig is None:
+                self._weights_sig = None
+            cache = self._epoch_cache = (tensors, addr)
+        sig = [t._version for t in cache[0]]
         if sig != self._weights_sig:
             self._weights_sig = sig
             self._weights_epoch += 1
