@@ -1621,6 +1621,7 @@ static int guard_take(int *skipped, bool clear)
     if (skipped) *skipped = blk[1];
     if (clear) {
         (void)hipMemset(g_ovf_dev, 0, 2 * sizeof(int));
+        (void)hipStreamSynchronize(nullptr);  // (non-blocking streams do not order against the null stream's fill: see alloc_planes)
         *g_ovf_host = 0;
     }
     return what;
@@ -2026,6 +2027,7 @@ static int finish_chain(const std::vector<ConvBuilder> &ba, const std::vector<Co
     if (upload(w, &pc.w) || upload(vec, &pc.vec)) return -2;
     OJF_HIP(hipMalloc(reinterpret_cast<void **>(&pc.sync), kChainSyncInts * sizeof(int)));
     OJF_HIP(hipMemset(pc.sync, 0, kChainSyncInts * sizeof(int)));
+    OJF_HIP(hipStreamSynchronize(nullptr));  // (see alloc_planes)
     const int epoch0 = kChainEpoch;
     OJF_HIP(hipMemcpy(pc.sync, &epoch0, sizeof(int), hipMemcpyHostToDevice));
     return 0;
@@ -2524,6 +2526,11 @@ static int alloc_planes(float **p, size_t npix, int ch)
     float *raw = nullptr;
     OJF_HIP(hipMalloc(reinterpret_cast<void **>(&raw), (npix * ch + kPrefix) * sizeof(float)));
     OJF_HIP(hipMemset(raw, 0, (npix * ch + kPrefix) * sizeof(float)));
+    // The fill runs on the null stream; the second head's stream and the side streams are hipStreamNonBlocking and do NOT
+    // order against it.  A buffer allocated at its first use inside a forward pass (ensure_planes) could be written by a
+    // convolution on such a stream and zeroed afterwards (round 5: one wrong output in ~8 suite runs of the generic two-head
+    // topology, never in isolation).  The fill is therefore complete before anybody learns the pointer.
+    OJF_HIP(hipStreamSynchronize(nullptr));
     *p = raw + kPrefix;
     return 0;
 }
@@ -3038,6 +3045,7 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
         if (!rc) rc = alloc_planes(&sc.partial, kSumBlocks, 256);
         if (!rc) rc = check_hip(hipMalloc(reinterpret_cast<void **>(&sc.colsum), sizeof(ColSums)), "hipMalloc");
         if (!rc) rc = check_hip(hipMemset(sc.colsum, 0, sizeof(ColSums)), "hipMemset");
+        if (!rc) rc = check_hip(hipStreamSynchronize(nullptr), "hipStreamSynchronize");  // (see alloc_planes)
         if (!rc) rc = check_hip(hipStreamCreateWithFlags(&sc.side, hipStreamNonBlocking), "hipStreamCreate");
         if (!rc) rc = check_hip(hipEventCreateWithFlags(&sc.ev_fork, event_flags()), "hipEventCreate");
         if (!rc) rc = check_hip(hipEventCreateWithFlags(&sc.ev_join, event_flags()), "hipEventCreate");

@@ -674,6 +674,7 @@ OJF_API int ojf_train_conv(const float *in, int in_g0, int c_in_phys, float *out
     if (!g_train_zero_bias) {
         OJF_HIP(hipMalloc(reinterpret_cast<void **>(&g_train_zero_bias), 4096 * sizeof(float)));
         OJF_HIP(hipMemset(g_train_zero_bias, 0, 4096 * sizeof(float)));
+        OJF_HIP(hipStreamSynchronize(nullptr));
     }
     const int taps = ksize * ksize, c4 = c_in_phys / 4, nsteps = (taps * c4 + 3) / 4;
     const int n_ot = round_up(round_up(c_out_phys, 16) / 16, kNT), og_total = round_up(c_out_phys, 4) / 4;

@@ -580,7 +580,10 @@ static int t_alloc(ojf_trainer *t, void **p, size_t bytes, bool zero = false)
 {
     OJF_HIP(hipMalloc(p, bytes ? bytes : 16));
     t->allocs.push_back(*p);
-    if (zero) OJF_HIP(hipMemset(*p, 0, bytes ? bytes : 16));
+    if (zero) {
+        OJF_HIP(hipMemset(*p, 0, bytes ? bytes : 16));
+        OJF_HIP(hipStreamSynchronize(nullptr));  // (the trainer's streams may be non-blocking: ojf_net.hip alloc_planes)
+    }
     return 0;
 }
 
