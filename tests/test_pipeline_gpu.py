@@ -614,3 +614,43 @@ def test_fuse_sequence_prefetch_changes_no_bit(cuda):
     assert torch.equal(db_a.fusion_weights[s].view(torch.int16), db_b.fusion_weights[s].view(torch.int16))
     assert torch.equal(db_a.ids_est[s].volume, db_b.ids_est[s].volume)
     assert torch.equal(db_a.scores[s].volume.view(torch.int16), db_b.scores[s].volume.view(torch.int16))
+
+
+@pytest.mark.parametrize('sem', [False, True])
+def test_fuse_sequence_without_a_2d_network(cuda, sem):
+    """fuse_sequence on streams that need no 2-D pass (geometry only / gt labels): an empty chunk is a no-op, a chunk of one
+    frame is fuse(), ``prefetch`` is ignored - all volumes bit for bit as from frame-at-a-time fuse()."""
+    h, w, grid, frames = 48, 64, 32, 7
+
+    def build():
+        cfg = default_config(h, w, semantics=sem, use_semantics=sem, integrate_mode='fast')
+        cfg.SETTINGS.device = str(cuda)
+        st = make_stream(h, w, grid)
+        db = Database(st, database_config(cfg))
+        torch.manual_seed(3)
+        pipe = Pipeline(cfg)
+        for m in pipe._fusion_network.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                torch.nn.init.xavier_normal_(m.weight)
+        return st, db, pipe.to(cuda).eval()
+    st_a, db_a, seq = build()
+    st_b, db_b, one = build()
+    one._fusion_network.load_state_dict(seq._fusion_network.state_dict())
+    with torch.no_grad():
+        ba = [_batch(st_a, i, cuda) for i in range(frames)]
+        seq.fuse_sequence([], db_a, cuda)
+        seq.fuse_sequence(ba[0:1], db_a, cuda, prefetch=ba[1:4])
+        seq.fuse_sequence(ba[1:4], db_a, cuda, prefetch=ba[4:7])
+        seq.fuse_sequence(ba[4:7], db_a, cuda, prefetch=[])
+        for i in range(frames):
+            one.fuse(_batch(st_b, i, cuda), db_b, cuda)
+        seq.check()
+        one.check()
+    s = st_a.scene
+    pairs = [(db_a.scenes_est[s].volume, db_b.scenes_est[s].volume), (db_a.fusion_weights[s], db_b.fusion_weights[s])]
+    if sem:
+        pairs += [(db_a.scores[s].volume, db_b.scores[s].volume)]
+        assert torch.equal(db_a.ids_est[s].volume, db_b.ids_est[s].volume)
+    for a, b in pairs:
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    assert float((db_a.fusion_weights[s].float() > 0).sum()) > 1000
