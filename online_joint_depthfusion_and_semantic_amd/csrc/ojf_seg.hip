@@ -687,7 +687,7 @@ __global__ __launch_bounds__(256, 2) void segconv_gemm_kernel(const SegGroupArgs
     const int H = a.H, W = a.W, HoWo = a.Ho * a.Wo, Wo = a.Wo, c8 = a.c8, ksize = a.ksize, dil = a.dil, in_stride = a.in_stride;
     const int n_pix = a.B * HoWo, n_kb = a.n_kb, n_ct = a.n_ct;
     const int col = lane & 15, kg = lane >> 4;
-    constexpr int abl = OJF_GEMM_ABL;  // build-time ablation (tools/r5_run24.sh, r5_run36.sh): 1 no MFMA, 2 no LDS operand reads, 4 no global loads, 8 no staging, 16 no barrier, 32 weight walk rotated per pixel block, 64 taps inner
+    constexpr int abl = OJF_GEMM_ABL;  // build-time ablation (tools/r5_run24.sh, r5_run36.sh): 1 no MFMA, 2 no LDS operand reads, 4 no global loads, 8 no staging, 16 no barrier, 32 weight walk rotated per pixel block, 64 taps inner, 128 no fp16 split of the pixel operands
 
     // producer side: this wave's PT pixel tiles (tiles wave * PT .. of the block) and CW weight chunks
     int iy0[PT], ix0[PT], img0[PT];
@@ -794,6 +794,11 @@ __global__ __launch_bounds__(256, 2) void segconv_gemm_kernel(const SegGroupArgs
 #pragma unroll
         for (int n = 0; n < PT; ++n) {
             if (kShortPix && wave * PT + n >= NB) continue;
+            if (abl & 128) {  // (timing only, wrong sums) as if the producer had stored the activations as fp16 halves: no split
+                Bs[st][wave * PT + n][0][lane] = fa[n];
+                Bs[st][wave * PT + n][1][lane] = fb[n];
+                continue;
+            }
             f16x8 xh, xl;
             split8(fa[n], fb[n], xh, xl);
             Bs[st][wave * PT + n][0][lane] = __builtin_bit_cast(f32x4, xh);
