@@ -1122,7 +1122,7 @@ int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
     static const int gemm22_min = getenv("OJF_SEG_GEMM22_MIN") ? atoi(getenv("OJF_SEG_GEMM22_MIN")) : 128;  // ... or the 64 x 64 tile this many
     static const int gemm_min_kb = getenv("OJF_SEG_GEMM_MIN_KB") ? atoi(getenv("OJF_SEG_GEMM_MIN_KB")) : 4;
     static const int gemm_shape = getenv("OJF_SEG_GEMM_SHAPE") ? atoi(getenv("OJF_SEG_GEMM_SHAPE")) : -1;  // tuning: force menu entry
-    static const int gemm_menu = getenv("OJF_SEG_GEMM_MENU") ? atoi(getenv("OJF_SEG_GEMM_MENU")) : 0xff;  // tuning: bit 2 = the 128 x 160 tile allowed
+    static const int gemm_menu = getenv("OJF_SEG_GEMM_MENU") ? atoi(getenv("OJF_SEG_GEMM_MENU")) : 0xff;  // tuning: bit 2 = the 128 x 160 tile allowed, bit 3 = the long-K model
     {
         bool drop_all = true, drop_any = false;
         for (int i = 0; i < n; ++i) { drop_any = drop_any || g.a[i].rng; drop_all = drop_all && g.a[i].rng; }
@@ -1138,7 +1138,7 @@ int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
         else hipLaunchKernelGGL((segconv_gemm_kernel<MT_, NT_, false, false, WM_>), grid__, dim3(256), 0, st, g);                     \
     } while (0)
         struct Shape { int a, b; const char *name; };  // channel / pixel tiles of the block
-        static const Shape menu[] = {{4, 4, "gemm 64x64"}, {8, 8, "gemm 128x128"}, {8, 10, "gemm 128x160"}};
+        static const Shape menu[] = {{4, 4, "gemm 64x64"}, {8, 8, "gemm 128x128"}, {8, 10, "gemm 128x160"}, {8, 5, "gemm 128x80"}};
         const bool big = b44 >= gemm_min && a.n_ct >= 8;
         if (a.n_kb >= gemm_min_kb && (drop_all || !drop_any) && (big || b22 >= gemm22_min)) {
             int best = big ? 1 : 0;
@@ -1146,7 +1146,26 @@ int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
                 const long b810 = (long)((a.n_ct + 7) / 8) * ((n_pt + 9) / 10) * n;
                 if (b810 >= 200 && (b810 + 255) / 256 < (b44 + 255) / 256) best = 2;
             }
-            if (gemm_shape >= 0) best = gemm_shape > 2 ? 2 : gemm_shape;
+            // long K (3x3 layers from 256 input channels on): the tile by a two-factor model of the measurements - a block of
+            // each shape alone on a CU (us per 72 K blocks: 28 / 59.5 / 94.5 / 51), times what the launch's block count costs
+            // in rounds of 256 (two blocks share a CU at 1.65x the time of one: 1, 1.65, 2.65, 3.3, 4.3 ... for 1, 2, 3, 4, 5
+            // rounds).  Checked against the layers it re-decides (profiles/r05_seg_experiments.txt): 60x80 256 -> 256 at 2 / 4
+            // frames 128x80 (57 against 70 us, 87 against 94), 15x20 512 -> 512 of both encoders at 8 frames 128x80 (108 against 127).
+            if (a.n_kb >= 64 && ((gemm_menu >> 3) & 1)) {
+                static const double alone[4] = {28.0, 59.5, 94.5, 51.0};
+                double best_t = 0.0;
+                int pick = -1;
+                for (int i = 0; i < 4; ++i) {
+                    if (menu[i].a == 8 && a.n_ct < 8) continue;
+                    const long blocks = (long)((a.n_ct + menu[i].a - 1) / menu[i].a) * ((n_pt + menu[i].b - 1) / menu[i].b) * n;
+                    if (blocks < 100) continue;
+                    const long k = (blocks + 255) / 256;
+                    const double t = alone[i] * (1.65 * (double)(k / 2) + (double)(k & 1));
+                    if (pick < 0 || t < best_t) { pick = i; best_t = t; }
+                }
+                if (pick >= 0) best = pick;
+            }
+            if (gemm_shape >= 0) best = gemm_shape > 3 ? 3 : gemm_shape;
             if (best >= 0) {
                 g.het.n = 0;
                 const Shape &sh = menu[best];
@@ -1155,7 +1174,8 @@ int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
                 switch (best) {
                 case 0: OJF_GEMM_LAUNCH(2, 2, 2, grid); break;
                 case 1: OJF_GEMM_LAUNCH(4, 4, 2, grid); break;
-                default: OJF_GEMM_LAUNCH(4, 5, 2, grid); break;
+                case 2: OJF_GEMM_LAUNCH(4, 5, 2, grid); break;
+                default: OJF_GEMM_LAUNCH(2, 5, 4, grid); break;
                 }
                 if (trace)
                     fprintf(stderr, "segconv %-12s n %d  c_in %4d c_out %4d k %d s %d d %2d  in %3dx%3d out %3dx%3d  n_kb %4d  grid %dx%dx%d S %d%s%s%s\n", variant, n,
