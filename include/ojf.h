@@ -183,6 +183,12 @@ int ojf_net_check(ojf_stream_t stream);
 int ojf_guard_status(ojf_stream_t stream, int *flag, int *skipped);
 /* The flag as the host sees it right now (no synchronisation: what ojf_net_forward tests). */
 int ojf_guard_poll(void);
+/* 1 when kernels on `a` and `b` run side by side, 0 when the runtime mapped the two streams to one hardware queue (they
+ * then take turns: a small round-robin pool of queues backs all streams), < 0 on error.  Synchronises both streams and
+ * runs two ~130-us one-wave spin kernels: for set-up code that creates side streams (Pipeline.fuse_many's slot streams,
+ * the look-ahead stream of Pipeline.fuse_sequence), not for the frame path.  (No counterpart in the reference, which
+ * runs on one stream.) */
+int ojf_streams_overlap(ojf_stream_t a, ojf_stream_t b);
 
 /* Stand-alone fused convolution on NHWC fp32 rows (the kernel the net is built from; exported so
  * the parity tests can pin it layer by layer against torch.nn.functional.conv2d).

@@ -69,6 +69,7 @@ SIGNATURES = {
     'ojf_net_check': (_i, [_vp]),
     'ojf_guard_status': (_i, [_vp, _c.POINTER(_i), _c.POINTER(_i)]),
     'ojf_guard_poll': (_i, []),
+    'ojf_streams_overlap': (_i, [_vp, _vp]),
     'ojf_conv2d': (_i, [_vp, _i, _i, _vp, _i, _i, _c.POINTER(ConvLayer), _i, _i, _i, _vp]),
     'ojf_volume_fill_f16': (_i, [_vp, _sz, _f, _vp]),
     'ojf_volume_fill_u8': (_i, [_vp, _sz, _c.c_uint8, _vp]),

@@ -3156,6 +3156,30 @@ static void pair_stream(hipStream_t &s, const hipStream_t *others, int n, double
     for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
 }
 
+}  // namespace ojf
+
+OJF_API int ojf_streams_overlap(ojf_stream_t a, ojf_stream_t b)
+{
+    using namespace ojf;
+    hipStream_t sa = as_stream(a), sb = as_stream(b);
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(sa, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return fail("ojf_streams_overlap: stream a is capturing");
+    if (hipStreamIsCapturing(sb, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return fail("ojf_streams_overlap: stream b is capturing");
+    const long long cycles = 300000;  // ~130 us
+    (void)spin_pair_us(sa, sb, 1000);  // (the first launch of the kernel in a process loads its code object)
+    double alone = 1e30, both = 1e30;
+    for (int rep = 0; rep < 2; ++rep) {
+        const double t1 = spin_pair_us(sa, sa, cycles) * 0.5;  // two spins back to back on one stream
+        const double t2 = spin_pair_us(sa, sb, cycles);
+        alone = t1 < alone ? t1 : alone;
+        both = t2 < both ? t2 : both;
+    }
+    if (hipGetLastError() != hipSuccess) return fail("ojf_streams_overlap: spin kernel launch failed");
+    return both < 1.5 * alone ? 1 : 0;
+}
+
+namespace ojf {
+
 static void pair_head_stream(ojf_net *net, hipStream_t st)
 {
     if (net->heads != 2 || (net->head_paired && net->head_paired_with == st) || !net->head1) return;
@@ -3164,6 +3188,7 @@ static void pair_head_stream(ojf_net *net, hipStream_t st)
     net->head_paired_with = st;
     net->head_paired = true;
     const long long cycles = 300000;  // ~130 us
+    (void)spin_pair_us(st, st, 1000);  // (the first launch of the kernel in a process loads its code object: not in the yardstick)
     const double alone = spin_pair_us(st, st, cycles) * 0.5;  // two spins back to back on one stream
     pair_stream(net->head1, &st, 1, alone, cycles, "second head");
     // the side streams of the legacy VortexPooling flow (global-average branch, branch 0): each must overlap with the

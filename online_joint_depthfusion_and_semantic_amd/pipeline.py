@@ -311,6 +311,22 @@ class Pipeline(torch.nn.Module):
         return bool(cfg.DATA.semantics and cfg.DATA.semantic_strategy == 'predict' and len(batches) > 1
                     and not self._semantic_2d_network.training and cfg.SEMANTIC_2D_MODEL.get('stage', 2) != 1)
 
+    def _side_stream(self, others):
+        """A torch stream whose kernels really run beside those of ``others``: the runtime backs all streams by a small
+        round-robin pool of hardware queues, and two streams on one queue take turns (measured: the look-ahead pass beside
+        the frame steps 933 frames/s on two queues, 775 on one).  Up to eight candidates are tried (ojf_streams_overlap, a
+        set-up cost of ~0.5 ms each); the rejected ones stay referenced until the choice is made, so that the next candidate
+        is another pool member."""
+        lib = _lib.load()
+        rejected, best = [], None
+        for _ in range(8):
+            cand = torch.cuda.Stream(device=self.device)
+            if all(lib.ojf_streams_overlap(o.cuda_stream, cand.cuda_stream) == 1 for o in others):
+                return cand
+            best = best or cand
+            rejected.append(cand)
+        return best
+
     def _prefetch_semantics(self, batches):
         """The batched 2-D pass of ``batches`` on the side stream; the labels land in one of two persistent result slots
         (the graph's own output buffers belong to the next replay).  Slot k % 2 was last read by the frame steps of the
@@ -318,7 +334,9 @@ class Pipeline(torch.nn.Module):
         if not self._batched_2d_pass_applies(batches):
             return
         cur = torch.cuda.current_stream(self.device)
-        pf = self.__dict__.setdefault('_prefetch', {'stream': torch.cuda.Stream(device=self.device), 'n': 0, 'slots': [None, None], 'ready': None, 'taken': False})
+        pf = self.__dict__.get('_prefetch')
+        if pf is None:
+            pf = self.__dict__['_prefetch'] = {'stream': self._side_stream([cur]), 'n': 0, 'slots': [None, None], 'ready': None, 'taken': False}
         side = pf['stream']
         side.wait_stream(cur)
         with torch.cuda.stream(side), torch.no_grad():
@@ -568,7 +586,7 @@ class Pipeline(torch.nn.Module):
         fp = self._weights_fingerprint()
         streams = self.__dict__.setdefault('_slot_streams', [])
         while len(streams) < len(batches) - 1:
-            streams.append(torch.cuda.Stream(device=self.device))
+            streams.append(self._side_stream([main] + streams))  # (a stream that runs beside the caller's and the other slots')
         for i, (b, sem) in enumerate(zip(batches, sems)):
             if i == 0:
                 self._fuse_frame(b, database, 0, sem, fp)

@@ -654,3 +654,21 @@ def test_fuse_sequence_without_a_2d_network(cuda, sem):
     for a, b in pairs:
         assert torch.equal(a.view(torch.int16), b.view(torch.int16))
     assert float((db_a.fusion_weights[s].float() > 0).sum()) > 1000
+
+
+def test_streams_overlap_probe(cuda):
+    """ojf_streams_overlap (set-up helper behind Pipeline._side_stream): a stream never runs beside itself; two streams give
+    0 or 1 (the runtime's queue mapping decides); _side_stream returns a stream that passed the probe when one of its eight
+    candidates does."""
+    from online_joint_depthfusion_and_semantic_amd import _lib
+    lib = _lib.load()
+    a, b = torch.cuda.Stream(device=cuda), torch.cuda.Stream(device=cuda)
+    assert lib.ojf_streams_overlap(a.cuda_stream, a.cuda_stream) == 0
+    assert lib.ojf_streams_overlap(a.cuda_stream, b.cuda_stream) in (0, 1)
+    cfg = default_config(24, 32)
+    cfg.SETTINGS.device = str(cuda)
+    pipe = Pipeline(cfg).to(cuda).eval()
+    pipe.device = torch.device(cuda)
+    main = torch.cuda.current_stream(cuda)
+    side = pipe._side_stream([main])
+    assert isinstance(side, torch.cuda.Stream) and side.cuda_stream != main.cuda_stream
