@@ -215,6 +215,14 @@ __global__ __launch_bounds__(256) void train_bn_act_fwd_kernel(const BnGroup grp
     const BnActArgs &a = grp.g[blockIdx.z];
     const int cg = blockIdx.y;
     __shared__ float stat[8];  // mean[4], invstd[4] of this group
+    // the first three loads of the streaming loop are requested BEFORE the statistics are finished (a chain of dependent
+    // loads, shuffles and a barrier in front of them cost every one of ~30 launches per pass 2-3 us)
+    const f32x4 *yp = a.y + (size_t)(a.y_g0 + cg) * a.npix;
+    const int stride = gridDim.x * blockDim.x;
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool first3 = p + 2 * stride < a.npix;
+    f32x4 py0{0.f, 0.f, 0.f, 0.f}, py1 = py0, py2 = py0;
+    if (first3) { py0 = yp[p]; py1 = yp[p + stride]; py2 = yp[p + 2 * stride]; }
     if (a.has_bn) {
         if (threadIdx.x < 64) {
             double tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -250,9 +258,7 @@ __global__ __launch_bounds__(256) void train_bn_act_fwd_kernel(const BnGroup grp
 #pragma unroll
         for (int j = 0; j < 4; ++j) { mu[j] = stat[j]; is[j] = 4 * cg + j < a.C ? stat[4 + j] : 0.0f; }
     }
-    const f32x4 *yp = a.y + (size_t)(a.y_g0 + cg) * a.npix;
     f32x4 *op = a.out + (size_t)(a.out_g0 + cg) * a.npix;
-    const int stride = gridDim.x * blockDim.x;
     auto one = [&](const f32x4 &y) {
         f32x4 o;
 #pragma unroll
@@ -263,7 +269,10 @@ __global__ __launch_bounds__(256) void train_bn_act_fwd_kernel(const BnGroup grp
         }
         return o;
     };
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (first3) {
+        op[p] = one(py0); op[p + stride] = one(py1); op[p + 2 * stride] = one(py2);
+        p += 3 * stride;
+    }
     for (; p + 2 * stride < a.npix; p += 3 * stride) {  // three loads in flight per lane
         const f32x4 y0 = yp[p], y1 = yp[p + stride], y2 = yp[p + 2 * stride];
         op[p] = one(y0); op[p + stride] = one(y1); op[p + 2 * stride] = one(y2);
@@ -352,6 +361,18 @@ __global__ __launch_bounds__(256) void train_bn_bwd_apply_kernel(const BnGroup g
     const int cg = blockIdx.y;
     f32x4 mu, is, ga, be, dr;
     train_channel_consts(a, cg, mu, is, ga, be, dr);
+    // (the first six loads of the streaming loop go out before the reductions are finished and the bound is scanned: see
+    // train_bn_act_fwd_kernel)
+    const f32x4 *yp = a.y + (size_t)(a.y_g0 + cg) * a.npix;
+    const f32x4 *gp = a.dout + (size_t)(a.dout_g0 + cg) * a.npix;
+    const int stride = gridDim.x * blockDim.x;
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool first3 = p + 2 * stride < a.npix;
+    f32x4 py0{0.f, 0.f, 0.f, 0.f}, py1 = py0, py2 = py0, pg0 = py0, pg1 = py0, pg2 = py0;
+    if (first3) {
+        py0 = yp[p]; py1 = yp[p + stride]; py2 = yp[p + 2 * stride];
+        pg0 = gp[p]; pg1 = gp[p + stride]; pg2 = gp[p + 2 * stride];
+    }
     // the two reductions are finished here (see train_group_totals); block column 0 publishes the parameter gradients
     __shared__ float means[8];
     if (threadIdx.x < 64) {
@@ -378,10 +399,7 @@ __global__ __launch_bounds__(256) void train_bn_bwd_apply_kernel(const BnGroup g
     f32x4 m1, m2;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { m1[j] = means[j]; m2[j] = means[4 + j]; }
-    const f32x4 *yp = a.y + (size_t)(a.y_g0 + cg) * a.npix;
-    const f32x4 *gp = a.dout + (size_t)(a.dout_g0 + cg) * a.npix;
     f32x4 *dp = a.dy + (size_t)(a.dy_g0 + cg) * a.npix;
-    const int stride = gridDim.x * blockDim.x;
     float dys = 1.0f;
     if (a.bnd) {  // this pass's factor from the bound the reduce launch left (the same value in every block of the scale group)
         __shared__ float bw[4];
@@ -416,7 +434,10 @@ __global__ __launch_bounds__(256) void train_bn_bwd_apply_kernel(const BnGroup g
         }
         return d;
     };
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (first3) {
+        dp[p] = one(py0, pg0); dp[p + stride] = one(py1, pg1); dp[p + 2 * stride] = one(py2, pg2);
+        p += 3 * stride;
+    }
     for (; p + 2 * stride < a.npix; p += 3 * stride) {  // six loads in flight per lane
         const f32x4 y0 = yp[p], y1 = yp[p + stride], y2 = yp[p + 2 * stride];
         const f32x4 g0 = gp[p], g1 = gp[p + stride], g2 = gp[p + 2 * stride];
