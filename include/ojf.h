@@ -154,6 +154,11 @@ int ojf_net_forward(ojf_net *net, float *est_dev, int est_stride, ojf_stream_t s
 int64_t ojf_net_macs_per_pixel(const ojf_net *net);
 /* Kernel launches of the most recent ojf_net_forward on this net (all streams; 0 before the first call). */
 int ojf_net_launch_count(const ojf_net *net);
+/* The streams the net launches on beside `stream` (the second head of a two-head net, the side streams of the unfused
+ * VortexPooling flow), after pairing them with `stream` as the first forward pass would: out[0..2], NULL where there is
+ * none; returns how many are non-NULL.  For callers that run other work beside the net (Pipeline's look-ahead pass) and
+ * want a stream that shares a hardware queue with none of them (ojf_streams_overlap). */
+int ojf_net_side_streams(ojf_net *net, ojf_stream_t stream, ojf_stream_t out[3]);
 /* Profiling run of one forward pass (same launches as ojf_net_forward, plus one fence-free HIP event behind every
  * launch): kernel names ('\n'-separated, in launch order) into `names` and each launch's duration in microseconds as
  * its stream saw it (time since the previous launch of that stream completed) into `micros`.  Synchronises the

@@ -63,6 +63,7 @@ SIGNATURES = {
     'ojf_net_forward': (_i, [_vp, _vp, _i, _vp]),
     'ojf_net_macs_per_pixel': (_c.c_int64, [_vp]),
     'ojf_net_launch_count': (_i, [_vp]),
+    'ojf_net_side_streams': (_i, [_vp, _vp, _vp]),
     'ojf_net_profile': (_i, [_vp, _vp, _i, _vp, _c.c_char_p, _i, _c.POINTER(_f), _i]),
     'ojf_net_set_arithmetic': (_i, [_i]),
     'ojf_net_get_arithmetic': (_i, [_vp]),

