@@ -587,7 +587,7 @@ class TrainCase:
                 'gradient_bytes': self.grads.nbytes, 'finite': loss_ok, 'mean_loss': mean_loss}
 
 
-def train_report(case, res, steps, warmup, world, h, w, grid):
+def train_report(case, res, steps, warmup, world, h, w, grid, grouped=False):
     times = sorted(res['times'])
     med = times[len(times) // 2] if len(times) % 2 else 0.5 * (times[len(times) // 2 - 1] + times[len(times) // 2])
     return {'workload': 'BASELINE configs[3]: training frame step (fuse_training + FusionLoss + backward per frame; flat-gradient '
@@ -595,13 +595,38 @@ def train_report(case, res, steps, warmup, world, h, w, grid):
                         '(batch statistics, dropout), split-fp16 forward / backward-data convolutions and weight gradients, one scene per GPU' % (case.accum, w, h, grid),
             'value': world * steps / med, 'unit': 'frames/sec', 'ms_per_step': 1e3 * med / steps, 'steps': steps, 'warmup': warmup,
             'repeats': len(times), 'value_min': world * steps / times[-1], 'value_max': world * steps / times[0],
-            'allreduce_us': res['allreduce_us'] if world > 1 else None, 'allreduce_calls_in_timed_region': res['allreduce_calls'],
-            'allreduce_backend': (('rccl' if torch.distributed.get_backend() == 'nccl' else 'gloo (dry run: gradient buffer staged through the host)')
-                                  if world > 1 else 'none (one rank)'), 'gradient_bytes': res['gradient_bytes'],
+            'allreduce_us': res['allreduce_us'] if (world > 1 or grouped) else None, 'allreduce_calls_in_timed_region': res['allreduce_calls'],
+            'allreduce_backend': ((('rccl' if torch.distributed.get_backend() == 'nccl' else 'gloo (dry run: gradient buffer staged through the host)')
+                                   + (' (a group of one rank: --force-group)' if world == 1 else ''))
+                                  if (world > 1 or grouped) else 'none (one rank)'), 'gradient_bytes': res['gradient_bytes'],
             'gradients_finite': res['finite'], 'mean_loss_last_repeat': res['mean_loss'],
             # host- or device-bound?  the loop's enqueue time per frame (the host waits ~1.7 ms of it for the frame's valid-ray count,
             # i.e. for the device) against the frame time; launches of the net's forward + backward pass as the executor counts them
-            'host_loop_ms_per_frame': getattr(case, 'host_ms_per_frame', None), 'net_launches_per_pass': getattr(case, 'net_launches_per_pass', None)}
+            'host_loop_ms_per_frame': getattr(case, 'host_ms_per_frame', None), 'net_launches_per_pass': getattr(case, 'net_launches_per_pass', None),
+            # < 0.8: the device paces the step; ~1: the host does (the number then moves with the host CPU, not the GPU)
+            'host_bound_ratio': (getattr(case, 'host_ms_per_frame', 0.0) or 0.0) / (1e3 * med / steps)}
+
+
+def rccl_world1_probe(timeout=240):
+    """The 8-GPU path's collective on a one-GPU box: ``bench.py --train --force-group`` in a process of its own - RCCL is loaded,
+    a communicator of one rank set up and the flat 1.44-MB gradient buffer all-reduced at every accumulation boundary of a short
+    training loop.  A failure is reported, never fatal to the headline line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--train', '--force-group', '--steps', '16', '--warmup', '8', '--repeats', '2', '--cpu-frames', '0']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    name = 'RCCL on one rank: training frame step with the flat-gradient all-reduce through a process group of ONE rank (nccl backend)'
+    try:
+        pr = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+        line = [ln for ln in pr.stdout.splitlines() if ln.startswith('{')]
+        if pr.returncode != 0 or not line:
+            return {'workload': name, 'error': 'rc %d: %s' % (pr.returncode, (pr.stderr or pr.stdout)[-400:])}
+        j = json.loads(line[-1])
+        return {'workload': name, 'value': j['value'], 'unit': j['unit'], 'ms_per_step': j['ms_per_step'], 'allreduce_us': j.get('allreduce_us'),
+                'allreduce_backend': j.get('allreduce_backend'), 'allreduce_calls_in_timed_region': j.get('allreduce_calls_in_timed_region'),
+                'gradient_bytes': j.get('gradient_bytes'), 'gradients_finite': j.get('gradients_finite')}
+    except Exception as e:
+        return {'workload': name, 'error': repr(e)}
 
 
 def launch_ranks(n, argv):
@@ -658,6 +683,10 @@ def main():
                     help='counter-collection runs (tools/final_profile.sh): only warm-up + timed frames are fused - no stage-mark '
                          'pass, no profiled forwards, no secondary / CPU legs - so every kernel runs exactly steps + warmup times per launch site')
     ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL, default) | gloo (validation of the N>1 path on a 1-GPU box)')
+    ap.add_argument('--force-group', action='store_true',
+                    help='N = 1: create a process group of ONE rank anyway (with --train the flat-gradient all-reduce then goes through RCCL: '
+                         'library load, communicator set-up and the collective launch of the 8-GPU path on a one-GPU box)')
+    ap.add_argument('--no-pin', action='store_true', help='N > 1: do not pin the ranks to disjoint core sets')
     args = ap.parse_args()
     if args.gpus < 1 or args.steps < 1 or args.repeats < 1:
         raise SystemExit('bench.py: --gpus, --steps and --repeats must be positive')
@@ -680,25 +709,47 @@ def main():
         raise SystemExit('bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)')
     dev = torch.device('cuda', local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
-    if world > 1:
+    affinity = ''
+    if world > 1 and not args.no_pin:
+        # one disjoint core slice per rank (cores / ranks): the training leg is host-paced, unpinned ranks migrate
+        from online_joint_depthfusion_and_semantic_amd.distributed import pin_rank_to_cores
+        affinity = pin_rank_to_cores(rank, world)
+    grouped = world > 1 or args.force_group
+    if grouped:
         import torch.distributed as dist
         # RCCL: barrier + max-reduce of the times; with --train also the gradient all-reduce (the path's only collective)
+        if world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            if 'MASTER_PORT' not in os.environ:
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(('127.0.0.1', 0))
+                    os.environ['MASTER_PORT'] = str(sk.getsockname()[1])
         if args.dist_backend == 'nccl':
-            dist.init_process_group('nccl', device_id=dev)
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
-            dist.init_process_group(args.dist_backend)
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     def sync():
-        if world > 1:
+        if grouped:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
     def max_over_ranks(times):
-        if world > 1:
+        if grouped:
             t = torch.tensor(times, dtype=torch.float64, device=dev if args.dist_backend == 'nccl' else 'cpu')
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             return [float(x) for x in t.tolist()]
         return times
+
+    def per_rank(value):
+        """[value of rank 0, .., value of rank N-1] on every rank (what a first scaling curve is read with: which rank is slow)."""
+        if not grouped:
+            return [float(value)]
+        t = torch.zeros(world, dtype=torch.float64, device=dev if args.dist_backend == 'nccl' else 'cpu')
+        t[rank] = float(value)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
+        return [float(x) for x in t.tolist()]
 
     head = dict(h=args.height, w=args.width, grid=args.grid, semantics=args.semantics, strategy=args.semantic_strategy,
                 seg_engine=args.seg_engine, mode=args.mode, arith=args.arith, n_classes=args.n_classes)
@@ -711,17 +762,25 @@ def main():
         # max over ranks; FlatGradientAllReduce stages the gradient buffer through the host for gloo, 'allreduce_backend' says so)
         tc = TrainCase(args.height, args.width, args.grid, dev, rank, total)
         res = tc.run(args.steps, args.warmup, sync, args.repeats)
+        own = sorted(res['times'])[len(res['times']) // 2]
+        rank_ms = [1e3 * t / args.steps for t in per_rank(own)]      # each rank's own median loop time per frame
+        rank_host = per_rank(tc.host_ms_per_frame)
+        rank_ar = per_rank(res['allreduce_us'] or 0.0)
         res['times'] = max_over_ranks(res['times'])
         if rank == 0:
-            r = train_report(tc, res, args.steps, args.warmup, world, args.height, args.width, args.grid)
+            r = train_report(tc, res, args.steps, args.warmup, world, args.height, args.width, args.grid, grouped=grouped)
+            r['per_rank'] = {'ms_per_step': rank_ms, 'host_loop_ms_per_frame': rank_host, 'allreduce_us': rank_ar,
+                             'ms_per_step_min': min(rank_ms), 'ms_per_step_max': max(rank_ms)}
             print(json.dumps({'metric': metric + ', training frame step', 'value': r['value'], 'unit': 'frames/sec', 'n_gpus': world,
                               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': r['ms_per_step'], 'higher_is_better': True,
                               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16x3', 'data': 'synthetic',
                               'config': {'workload': r['workload'], 'frame': [args.height, args.width], 'grid': args.grid,
-                                         'parallelism': 'scene-sharded x%d, gradient all-reduce every %d frames' % (world, tc.accum)},
+                                         'parallelism': 'scene-sharded x%d, gradient all-reduce every %d frames' % (world, tc.accum),
+                                         'cpu_affinity': affinity or 'not pinned'},
                               **{k: r[k] for k in ('repeats', 'value_min', 'value_max', 'allreduce_us', 'allreduce_calls_in_timed_region',
-                                                   'allreduce_backend', 'gradient_bytes', 'gradients_finite')}}))
-        if world > 1:
+                                                   'allreduce_backend', 'gradient_bytes', 'gradients_finite', 'host_loop_ms_per_frame',
+                                                   'host_bound_ratio', 'net_launches_per_pass', 'per_rank')}}))
+        if grouped:
             torch.distributed.destroy_process_group()
         return
     if args.scenes > 1:  # aggregate of S scenes on one GPU (a secondary measurement: the headline stays one scene per GPU)
@@ -729,7 +788,7 @@ def main():
         r = mc.run(args.steps, args.warmup, sync, args.repeats)
         if rank == 0:
             print(json.dumps(dict(r, metric=metric + ', %d scenes per GPU (fuse_many)' % args.scenes, n_gpus=world)))
-        if world > 1:
+        if grouped:
             torch.distributed.destroy_process_group()
         return
     if args.lookahead > 1:
@@ -737,7 +796,7 @@ def main():
         r = run_lookahead(case, args.steps, args.warmup, sync, args.lookahead, args.repeats, prefetch=not args.no_prefetch)
         if rank == 0:
             print(json.dumps(dict(r, metric=metric + ', %d-frame look-ahead of the 2-D network (fuse_sequence)' % args.lookahead, n_gpus=world)))
-        if world > 1:
+        if grouped:
             torch.distributed.destroy_process_group()
         return
     case = Case(head, dev, rank, total)
@@ -748,7 +807,7 @@ def main():
             print(json.dumps({'metric': metric, 'value': r['value'],
                               'unit': 'frames/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': r['ms_per_step'],
                               'lean': True, 'frames_fused': args.steps + args.warmup, 'stages_ms': r['stages_ms']}))
-        if world > 1:
+        if grouped:
             torch.distributed.destroy_process_group()
         return
     res = case.run(args.steps, args.warmup, sync, repeats=args.repeats)
@@ -764,7 +823,7 @@ def main():
             'config': {'workload': r['workload'], 'frame': [args.height, args.width], 'grid': args.grid,
                        'n_points': cfg.FUSION_MODEL.n_points, 'n_tail_points': cfg.FUSION_MODEL.n_tail_points,
                        'integrate_mode': args.mode, 'volume_dtype': 'f16', 'net_arithmetic': ARITH[args.arith][1],
-                       'parallelism': 'scene-sharded x%d' % world},
+                       'parallelism': 'scene-sharded x%d' % world, 'cpu_affinity': affinity or 'not pinned'},
             'timing': 'median of %d back-to-back repeats of the %d-step timed loop (each bracketed by barrier + synchronize, max over ranks)'
                       % (args.repeats, args.steps),
         }
@@ -822,12 +881,13 @@ def main():
             except Exception as e:
                 secondary.append({'workload': 'BASELINE configs[3]: training frame step', 'error': repr(e)})
             torch.cuda.empty_cache()
+            secondary.append(rccl_world1_probe())
             out['secondary'] = secondary
         if world == 1 and args.cpu_frames > 0:
             out['cpu_baseline'] = cpu_baseline(args, args.height, args.width, args.grid, args.semantics)
             out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
         print(json.dumps(out))
-    if world > 1:
+    if grouped:
         torch.distributed.destroy_process_group()
 
 

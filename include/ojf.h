@@ -347,7 +347,10 @@ typedef struct ojf_train_layer {
 int ojf_trainer_create(ojf_trainer **out, int version, int n_points, int growth, int use_semantics, float output_scale, int h, int w);
 void ojf_trainer_destroy(ojf_trainer *t);
 /* arithmetic of the convolutions: OJF_ARITH_F16X3 (default; activations must stay inside the fp16 range like in
- * ojf_net_forward - a violation makes the next ojf_trainer_forward fail, which also clears the flag) or OJF_ARITH_F32.
+ * ojf_net_forward - a violation makes the next ojf_trainer_forward fail; the flag STAYS set (it is shared with the inference
+ * executors and the integrate calls, which skip while it is set): the caller reports and clears it with ojf_net_check
+ * before it continues - a loop that catches the error and carries on without that call has every later ojf_integrate* skip.
+ * Pipeline.fuse_training does this before it re-raises) or OJF_ARITH_F32.
  * Under OJF_ARITH_F16X3 backward-data AND the weight gradients run in split-fp16 as well: every dy tensor is stored under a
  * per-unit power-of-two factor that the SAME pass derives from a guaranteed bound on |dy| (max|dz| and max|xhat| collected by
  * the BatchNorm-backward reduction), so gradients of any magnitude stay inside the fp16 range; the factor is divided out

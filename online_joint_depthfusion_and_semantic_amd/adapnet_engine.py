@@ -248,11 +248,13 @@ class SegEngine:
         s1 = nhwc(24 * k, h8, w8, dev, zero=False, batch=B)
         top = nhwc(256 * k, h16, w16, dev, zero=False, batch=B)
         # decoder stage inputs: (deconv output 256, gated skip 24, 8 ZERO channels - rows of 288 = 9 x 32 channels let the 3x3
-        # convolutions on them take the scalar tap walk).  Kept per frame shape: the pad is zeroed once, not per frame.
+        # convolutions on them take the scalar tap walk).  Kept per (batch, frame shape) for the life of the engine: the pad
+        # is zeroed once, not per frame, and a device graph captured around a forward pass (Pipeline keeps one per batch
+        # size: fuse() and fuse_many / fuse_sequence) addresses ITS pair by raw pointer - so a pair is never evicted while
+        # the engine lives (a new key does not free the others: their graphs would replay into freed memory).
         key = (B, H, W, str(dev))
         bufs = self.__dict__.setdefault('_cats', {})
         if key not in bufs:
-            bufs.clear()
             bufs[key] = (nhwc(288, h8, w8, dev, zero=True, batch=B), nhwc(288, h4, w4, dev, zero=True, batch=B))
         cat2, cat3 = bufs[key]
         grouped = self.fusion and not os.environ.get('OJF_SEG_TWO_STREAMS')  # (A/B switch: the round-3 flow on two streams)

@@ -93,7 +93,8 @@ __global__ __launch_bounds__(kAccThreads) void integrate_accumulate_tiled_kernel
         keys[s] = kEmpty; accw[s] = 0; accu[s] = 0;
         if constexpr (SEM) { elast[s] = 0; ediff[s] = 0; }
     }
-    if (threadIdx.x == 0) { n_entries = 0; n_new = 0; n_rec = 0; }
+    __shared__ int guard_seen;
+    if (threadIdx.x == 0) { n_entries = 0; n_new = 0; n_rec = 0; guard_seen = guard_set(a) ? 1 : 0; }
     // the counter set of this call (header word kPhaseAcc: flipped by the previous call's finalize kernel, nobody writes it now)
     const unsigned int phase = a.phased ? a.counters[kPhaseAcc] & 1u : 0u;
     unsigned int *const counters = a.counters + 32 * phase;
@@ -101,7 +102,11 @@ __global__ __launch_bounds__(kAccThreads) void integrate_accumulate_tiled_kernel
     const int tiles_x = (a.w + kTileW - 1) / kTileW;
     const int tile = banded_block_x();  // one band of the image per XCD: neighbouring tiles hit the same voxels
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    if (guard_set(a)) {  // block-uniform: the net's range guard fired - this frame must not reach the volumes
+    // ONE read per block (thread 0, above), handed over through LDS: the flag has concurrent producers (the look-ahead 2-D pass
+    // on its side stream, the nets of fuse_many's other slots), so per-thread reads could disagree inside a block and some
+    // waves would run on into the barriers below without the others.
+    __syncthreads();
+    if (guard_seen) {  // block-uniform: the net's range guard fired - this frame must not reach the volumes
         if (threadIdx.x == 0) {
             a.tile_new[tile] = 0;  // nothing for the finalize kernel (which still flips the counter sets)
             if (blockIdx.x == 0) atomicAdd(a.guard + 1, 1);

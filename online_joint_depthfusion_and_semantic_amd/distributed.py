@@ -17,21 +17,51 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, force_group=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).
-    Returns (rank, world_size, local_rank).  World size 1 needs no process group."""
+    Returns (rank, world_size, local_rank).  World size 1 needs no process group; ``force_group`` (or
+    ``OJF_DIST_FORCE_GROUP=1``) creates one anyway - the same RCCL load / communicator set-up / all-reduce launch as on the
+    8-GPU node, on a one-GPU box (bench.py --train --force-group, tests/test_bench_gpu.py)."""
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
-    if world > 1 and not dist.is_initialized():
+    if force_group is None:
+        force_group = os.environ.get('OJF_DIST_FORCE_GROUP', '0') not in ('', '0')
+    if (world > 1 or force_group) and not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if world == 1:  # nobody launched us: a rendezvous with ourselves
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            if 'MASTER_PORT' not in os.environ:
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(('127.0.0.1', 0))
+                    os.environ['MASTER_PORT'] = str(sk.getsockname()[1])
         kw = {}
         if backend == 'nccl':
             torch.cuda.set_device(local)
             kw['device_id'] = torch.device('cuda', local)
-        dist.init_process_group(backend, **kw)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, local
+
+
+def pin_rank_to_cores(rank, world):
+    """One disjoint slice of the process's allowed cores per rank (cores / ranks, contiguous): the training step is host-paced
+    (292 launches per frame), and N unpinned Python processes migrating over one socket's cores show up as a scaling loss that
+    is not the GPUs'.  Returns the slice as a string for the bench line ('' where the platform has no affinity call)."""
+    if world <= 1 or not hasattr(os, 'sched_setaffinity'):
+        return ''
+    cores = sorted(os.sched_getaffinity(0))
+    per = len(cores) // world
+    if per < 1:
+        return ''
+    mine = cores[rank * per:(rank + 1) * per]
+    os.sched_setaffinity(0, mine)
+    try:
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), per)))
+    except RuntimeError:
+        pass
+    return '%d-%d' % (mine[0], mine[-1]) if mine == list(range(mine[0], mine[-1] + 1)) else ','.join(map(str, mine))
 
 
 def shard_scenes(scenes, rank, world):
@@ -89,7 +119,9 @@ class FlatGradientAllReduce:
         return norm
 
     def reduce(self):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        # (a group of ONE rank - init_from_env(force_group=True) - still goes through the collective: the identity, and the
+        # first RCCL launch of this code path on a one-GPU box)
+        if dist.is_available() and dist.is_initialized():
             if self.flat.is_cuda and dist.get_backend(self.group) == 'gloo':
                 # dry runs of the schedule on one device (bench.py --dist-backend gloo, tests): gloo reduces host tensors
                 host = self.flat.cpu()
@@ -97,6 +129,6 @@ class FlatGradientAllReduce:
                 self.flat.copy_(host)
             else:
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            if self.average:
+            if self.average and dist.get_world_size(self.group) > 1:
                 self.flat.div_(dist.get_world_size(self.group))
         return self.flat

@@ -117,8 +117,9 @@ class Pipeline(torch.nn.Module):
                 self._guard_recover()  # (a tripped frame at the end of a scene: nothing after it polled the flag)
             torch.cuda.synchronize(self.device)  # (every slot's stream)
             self._engine.check()
-        elif self.__dict__.get('_hip_train') is not None:  # training only: the executor's forward pass shares the guard
-            from . import _lib
+        elif torch.device(getattr(self, 'device', 'cpu')).type == 'cuda':
+            # no inference engine yet (training only, or only the 2-D engine ran): the executors share the one flag
+            torch.cuda.synchronize(self.device)
             _lib.check(_lib.load().ojf_net_check(_lib.stream_ptr(self.device)), 'ojf_net_check')
 
     # ---- cached device objects ----------------------------------------------------------------
@@ -204,7 +205,15 @@ class Pipeline(torch.nn.Module):
         Rebuilt when the parameters change (version counters, checked like the fusion net's)."""
         net = self._semantic_2d_network
         if (self.config.SEMANTIC_2D_MODEL.get('engine', 'hip') != 'hip' or net.training or torch.is_grad_enabled()
-                or torch.device(self.device).type != 'cuda' or shape[0] != 1 or shape[-2] % 16 or shape[-1] % 16):
+                or torch.device(self.device).type != 'cuda' or shape[0] != 1):
+            return None
+        if shape[-2] % 16 or shape[-1] % 16:
+            if not self.__dict__.get('_warned_seg_fallback'):
+                import warnings
+                self.__dict__['_warned_seg_fallback'] = True
+                warnings.warn('SEMANTIC_2D_MODEL.engine = hip needs frame sides that are multiples of 16 (the 1/16-resolution '
+                              'stage of AdapNet++): %dx%d frames run on the torch module forward instead' % (shape[-2], shape[-1]),
+                              RuntimeWarning)
             return None
         cache = self.__dict__.get('_seg_cache')
         if cache is None or cache['net'] != id(net) or cache['age'] >= 64:
@@ -303,8 +312,27 @@ class Pipeline(torch.nn.Module):
                 sems = [(i.clone(), sc.clone()) for i, sc in sems]  # (this chunk's labels sit in the graph's output buffers, which the prefetched pass overwrites)
             self._prefetch_semantics(prefetch)
         fp = self._weights_fingerprint()
+        recover = self._guard_policy() == 'f32'
         for b, sem in zip(batches, sems):
-            self._fuse_frame(b, database, 0, sem, fp)
+            self._fuse_guarded(b, database, sem, fp, recover)
+
+    def _fuse_guarded(self, batch, database, sem=None, fingerprint=None, recover=False):
+        """One frame step of fuse_sequence / fuse_many's sequential paths under FUSION_MODEL.guard_policy (what ``fuse`` does
+        for its one frame): with 'f32' a fired range guard switches the arithmetic, fuses the skipped frames again and goes
+        on with this one; the frame joins the ring of remembered batches.  ``sem`` (the frame's labels from a batched 2-D
+        pass) does not depend on the fusion net's arithmetic and is used either way; the re-fused frames predict theirs
+        again, one frame at a time."""
+        if not recover:
+            return self._fuse_frame(batch, database, 0, sem, fingerprint)
+        try:
+            self._fuse_frame(batch, database, 0, sem, fingerprint)
+        except _lib.OjfError as err:
+            if 'fp16 range' not in str(err):
+                raise
+            self._guard_recover(err)
+            self._fuse_frame(batch, database, 0, sem)  # (fp32 engine: a new fingerprint)
+            return
+        self._guard_remember(batch, database)
 
     def _batched_2d_pass_applies(self, batches):
         cfg = self.config
@@ -404,7 +432,9 @@ class Pipeline(torch.nn.Module):
             ev = torch.cuda.Event()
             ev.record(side)
         pf['n'] += 1
-        pf['ready'] = {'ids': [id(b) for b in batches], 'sems': slot, 'event': ev}
+        # the announced batch OBJECTS are held (and compared with `is`): an id() of a dict the caller has dropped can be handed to a
+        # new dict, and the stale labels of other frames would be fused silently
+        pf['ready'] = {'batches': list(batches), 'sems': slot, 'event': ev}
 
     def _take_prefetched(self, batches):
         pf = self.__dict__.get('_prefetch')
@@ -415,7 +445,7 @@ class Pipeline(torch.nn.Module):
         ready, pf['ready'] = pf['ready'], None
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(ready['event'])  # (also orders this call's own 2-D pass, if the chunk is another one, behind the side stream's use of the graph buffers)
-        pf['taken'] = ready['ids'] == [id(b) for b in batches]
+        pf['taken'] = len(ready['batches']) == len(batches) and all(a is b for a, b in zip(ready['batches'], batches))
         pf['hits'] = pf.get('hits', 0) + int(pf['taken'])
         return ready['sems'] if pf['taken'] else None
 
@@ -548,24 +578,21 @@ class Pipeline(torch.nn.Module):
 
     def fuse(self, batch, database, device):
         self.device = torch.device(device)
-        if self._guard_policy() != 'f32':
-            return self._fuse_frame(batch, database)
-        try:
-            self._fuse_frame(batch, database)
-        except _lib.OjfError as err:
-            if 'fp16 range' not in str(err):
-                raise
-            # raised by the forward call's poll BEFORE this frame's net / integrate were enqueued: the frame is not among the
-            # skipped ones, it follows them
-            self._guard_recover(err)
-            self._fuse_frame(batch, database)
-            return
-        self._guard_remember(batch, database)
+        # (a frame the forward call's poll refuses was raised BEFORE its net / integrate were enqueued: it is not among the
+        # skipped ones, it follows them - _fuse_guarded)
+        return self._fuse_guarded(batch, database, recover=self._guard_policy() == 'f32')
 
     def _fuse_frame(self, batch, database, slot=0, semantics=None, fingerprint=None):
         """One frame step on the current stream with the device state of ``slot``; ``semantics`` = (sem_ids, scores) computed
         by the caller (fuse_many) instead of here."""
         self._shape = batch['image'].shape
+        # The range-guard flag is process-wide and raised by EVERY split-fp16 executor (the 2-D engine's kernels always are,
+        # whatever FUSION_MODEL.arithmetic says), while the integrate calls skip as long as it is set: a host read of the mapped
+        # word here, in front of anything this frame enqueues, keeps a tripped 2-D pass from dropping frames silently when the
+        # fusion net itself runs fp32 (whose forward call does not poll).
+        if self.device.type == 'cuda' and _lib.load().ojf_guard_poll():
+            raise _lib.OjfError('Pipeline.fuse: the split-fp16 range guard is set (fp16 range exceeded in a network pass since '
+                                'the last check()): the integrate calls skip until check() has reported it')
         profiled = slot == 0 and semantics is None
         seg0 = self._mark_segmentation() if profiled else None
         sem_ids, scores = self._frame_semantics(batch) if semantics is None else semantics
@@ -628,9 +655,10 @@ class Pipeline(torch.nn.Module):
         ids = [b['frame_id'][0].split('/')[0] for b in batches]
         if len(set(ids)) != len(ids):
             raise ValueError('Pipeline.fuse_many: one frame per scene (the frames of ONE scene depend on each other)')
+        recover = self._guard_policy() == 'f32'
         if len(batches) == 1 or self.device.type != 'cuda':
             for b in batches:
-                self._fuse_frame(b, database)
+                self._fuse_guarded(b, database, recover=recover)
             return
         main = torch.cuda.current_stream(self.device)
         sems = self._frame_semantics_many(batches)  # (None, None) without semantics; predict: ONE batched pass, this stream
@@ -638,16 +666,35 @@ class Pipeline(torch.nn.Module):
         streams = self.__dict__.setdefault('_slot_streams', [])
         while len(streams) < len(batches) - 1:
             streams.append(self._side_stream([main] + streams))  # (a stream that runs beside the caller's and the other slots')
-        for i, (b, sem) in enumerate(zip(batches, sems)):
-            if i == 0:
-                self._fuse_frame(b, database, 0, sem, fp)
-                continue
-            st = streams[i - 1]
-            st.wait_stream(main)  # (the frame tensors and the labels were produced on the current stream)
-            with torch.cuda.stream(st):
-                self._fuse_frame(b, database, i, sem, fp)
+        enqueued = 0
+        try:
+            for i, (b, sem) in enumerate(zip(batches, sems)):
+                if i == 0:
+                    self._fuse_frame(b, database, 0, sem, fp)
+                else:
+                    st = streams[i - 1]
+                    st.wait_stream(main)  # (the frame tensors and the labels were produced on the current stream)
+                    with torch.cuda.stream(st):
+                        self._fuse_frame(b, database, i, sem, fp)
+                enqueued = i + 1
+        except _lib.OjfError as err:
+            for st in streams[:len(batches) - 1]:
+                main.wait_stream(st)
+            if not recover or 'fp16 range' not in str(err):
+                raise
+            # guard_policy 'f32': the frames of this call that were enqueued behind the event are among the skipped ones
+            # (remember them first); the one the poll refused and those after it follow, one at a time on the fp32 engine
+            for b in batches[:enqueued]:
+                self._guard_remember(b, database)
+            self._guard_recover(err)
+            for b, sem in zip(batches[enqueued:], sems[enqueued:]):
+                self._fuse_guarded(b, database, sem, None, True)
+            return
         for st in streams[:len(batches) - 1]:
             main.wait_stream(st)
+        if recover:
+            for b in batches:
+                self._guard_remember(b, database)
 
     def _training_forward(self, inputs):
         """The net forward of pipeline.py:322 with a graph for ``loss.backward()``: on the libojf training kernels
@@ -718,7 +765,15 @@ class Pipeline(torch.nn.Module):
         inputs = {'tsdf_values': fv.view(1, P, h, w), 'tsdf_weights': fw.view(1, P, h, w), 'tsdf_frame': frame.view(1, 1, h, w)}
         if self.config.FUSION_MODEL.use_semantics:
             inputs['semantic_frame'] = ((1 + sem_ids.float()) / self.n_classes).view(1, 1, h, w)
-        est_pn = self._training_forward(inputs)[:, :P].reshape(1, P, n)  # differentiable; BN / dropout follow the modules' modes
+        try:
+            est_pn = self._training_forward(inputs)[:, :P].reshape(1, P, n)  # differentiable; BN / dropout follow the modules' modes
+        except _lib.OjfError as err:
+            # the executor's forward refuses to run while the shared range-guard flag is set and leaves it set (include/ojf.h):
+            # report + clear it here, so that a training loop that catches the error and carries on (another arithmetic, the
+            # next scene) does not have every later integrate call skip silently
+            if 'fp16 range' in str(err) and self.device.type == 'cuda':
+                _lib.load().ojf_net_check(_lib.stream_ptr(self.device))
+            raise
         valid = self._valid_index(valid_mask, count)
 
         # pipeline.py:104-135 in the plane layout, one launch each way; the [1, n, P] tensor of the API is a transposed view

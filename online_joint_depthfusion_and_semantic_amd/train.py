@@ -461,19 +461,19 @@ class HipTrainNet:
 
     def _epoch(self, mods):
         """A number that changes whenever a convolution weight or bias may have changed (ojf_trainer_forward's
-        ``weights_epoch``).  Per pass only the version counters of the cached tensor list are compared (element-wise - no
-        sum that could cancel): in-place updates (optimizer steps, ``load_state_dict``) bump them.  The storage addresses
-        (``p.data = ...``, replaced Parameter objects) are compared on every 64th pass; ``invalidate()`` covers writes that
-        bump nothing (``dist.broadcast(p.data)``)."""
+        ``weights_epoch``).  Per pass the (storage address, version counter) pairs of the cached tensor list are compared
+        element-wise (no sum that could cancel): in-place updates (optimizer steps, ``load_state_dict``) bump the counters,
+        ``p.data = ...`` / ``module.to()`` / ``.float()`` move the storage of the same Parameter object.  REPLACED Parameter
+        objects (``load_state_dict(assign=True)``, a swapped sub-module) are seen when the list is collected again from the
+        live modules, every 64th pass; ``invalidate()`` covers writes that bump nothing (``dist.broadcast(p.data)``)."""
         cache = self.__dict__.get('_epoch_cache')
         self._epoch_calls = self.__dict__.get('_epoch_calls', 0) + 1
         if cache is None or self._weights_sig is None or self._epoch_calls % 64 == 0:
             tensors = [t for c, _, _ in mods for t in (c.weight, c.bias) if t is not None]
-            addr = tuple(t.data_ptr() for t in tensors)
-            if cache is None or addr != cache[1] or self._weights_sig is None:
+            if cache is None or len(tensors) != len(cache) or any(a is not b for a, b in zip(tensors, cache)):
                 self._weights_sig = None
-            cache = self._epoch_cache = (tensors, addr)
-        sig = [t._version for t in cache[0]]
+            cache = self._epoch_cache = tensors
+        sig = [(t.data_ptr(), t._version) for t in cache]
         if sig != self._weights_sig:
             self._weights_sig = sig
             self._weights_epoch += 1

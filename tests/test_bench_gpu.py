@@ -76,3 +76,26 @@ def test_gpus_2_over_rccl(cuda, train):
     assert out['n_gpus'] == 2
     if train:
         assert out['allreduce_backend'] == 'rccl' and out['allreduce_us'] > 0 and out['gradients_finite'] is True
+
+
+def test_train_force_group_runs_the_gradient_all_reduce_through_rccl_on_one_rank(cuda):
+    """the first RCCL load + communicator + all-reduce launch of this code on hardware - a process group
+    of ONE rank (nccl backend) around the training frame step; the flat 1.44-MB gradient buffer goes through
+    ``dist.all_reduce`` at every accumulation boundary (FlatGradientAllReduce.reduce; insertion point in the reference:
+    train_fusion.py:186-189).  The line says which backend ran and how long the collective took."""
+    out = _bench('--train', '--force-group', '--steps', '16', '--warmup', '8', '--repeats', '2')
+    assert out['n_gpus'] == 1 and out['allreduce_backend'].startswith('rccl') and 'one rank' in out['allreduce_backend']
+    assert out['allreduce_calls_in_timed_region'] == 4 and out['gradients_finite'] is True
+    assert out['allreduce_us'] > 0 and 1.4e6 < out['gradient_bytes'] < 1.5e6
+    assert len(out['per_rank']['ms_per_step']) == 1 and out['per_rank']['ms_per_step_min'] > 0
+    print('RCCL on one rank: all-reduce of %d bytes %.1f us, training step %.1f frames/s' % (out['gradient_bytes'], out['allreduce_us'], out['value']))
+
+
+def test_gpus_2_pins_the_ranks_to_disjoint_cores(cuda):
+    """N > 1 ranks pin themselves to cores / ranks disjoint slices (the training leg is host-paced)."""
+    if len(os.sched_getaffinity(0)) < 2:
+        pytest.skip('one core')
+    out = _bench('--train', '--gpus', '2', '--dist-backend', 'gloo', '--steps', '8', '--warmup', '8', '--repeats', '2',
+                 '--height', '48', '--width', '64', '--grid', '64')
+    assert out['config']['cpu_affinity'] not in ('', 'not pinned')
+    assert len(out['per_rank']['ms_per_step']) == 2 and out['per_rank']['ms_per_step_max'] >= out['per_rank']['ms_per_step_min'] > 0

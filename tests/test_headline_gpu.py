@@ -451,3 +451,78 @@ def test_fuse_predict_strategy_at_B_matches_reference_golden(cuda, engine):
         assert id_bad <= 56 * flips_total + 1e-3 * touched.sum()
         assert (sc_ulp > 1).sum() <= 56 * flips_total + 1e-3 * touched.sum()
         assert td.max() <= 2e-3 and float((td > F16_ULP_BAND).mean()) <= 0.02
+
+
+# ---- the BATCHED 2-D pass (look-ahead chunks, what drivers.test_fusion runs by default) against the same reference golden ----
+@pytest.mark.parametrize('B', [4, 8])
+def test_batched_2d_pass_at_B_matches_reference_golden(cuda, B):
+    """modules/pipeline.py:42-60,181-185 at 320x240 -> 256^3, 30 classes, with the labels predicted as ONE batched AdapNet++
+    pass of B frames (SegEngine.predict_many: at this size the GEMM-shaped kernel picks tile forms a single frame never uses).
+    The two frames the reference's own ``Pipeline.fuse`` + AdapNet golden holds sit at DIFFERENT batch positions, the other
+    positions carry frames of a second scene: per golden frame softmax scores within 1e-6, arg-max ids equal wherever the
+    reference's top-1 / top-2 margin exceeds 1e-4; then ``fuse_sequence`` over the same chunk (stream order: the golden scene
+    sees frame 0, then frame 1) - the golden scene's weight volume by sha256 (PARITY integrate), id / score / TSDF volumes at the
+    touched voxels as in the frame-at-a-time test."""
+    from adapnet_golden_util import randomise_net
+    from online_joint_depthfusion_and_semantic_amd.synthetic import SyntheticDataset
+    g = golden('pipeline_predict_240x320_g256.npz')
+    small = golden('pipeline_v3_sem_24x32_g32.npz')
+    h, w, grid, n_classes = 240, 320, 256, 30
+    cfg = default_config(h, w, semantics=True, use_semantics=True, n_classes=n_classes, integrate_mode='parity')
+    cfg.SETTINGS.device = str(cuda)
+    cfg.DATA.semantic_strategy = 'predict'
+    scenes = ('room_0', 'room_1')  # room_0 = the golden's stream (seed 1911, 20 frames), room_1 fills the other positions
+    ds = SyntheticDataset(h, w, grid, 20, scenes=scenes, n_classes=n_classes)
+    db = Database(ds, database_config(cfg))
+    pipe = Pipeline(cfg)
+    pipe._fusion_network.load_state_dict({k[len('state_'):]: torch.from_numpy(small[k]) for k in small.files if k.startswith('state_')})
+    randomise_net(pipe._semantic_2d_network, 31)
+    pipe = pipe.to(cuda).eval()
+    pipe.device = torch.device(cuda)
+    pos = {4: (1, 3), 8: (2, 6)}[B]  # batch positions of golden frames 0 and 1
+
+    def batch(s, i):
+        return {k: (v.to(cuda) if torch.is_tensor(v) else v) for k, v in ds.streams[s].batch(i).items()}
+    chunk, filler = [], 0
+    for p in range(B):
+        if p in pos:
+            chunk.append(batch('room_0', pos.index(p)))
+        else:
+            chunk.append(batch('room_1', filler))
+            filler += 1
+    flips_total = 0
+    with torch.no_grad():
+        sems = pipe._frame_semantics_many(chunk)
+        assert pipe.__dict__['_seg_graph_many']['graph'] is not None  # the batched pass, captured and replayed
+        for i, p in enumerate(pos):
+            ids, scores = sems[p]
+            scores, ids = scores.reshape(h, w).cpu().numpy(), ids.reshape(h, w).cpu().numpy()
+            clear = g['f%d_seg_margin' % i].astype(np.float32) > 1e-4
+            flips = int((ids != g['f%d_seg_ids' % i]).sum())
+            flips_total += flips
+            ds_ = float(np.abs(scores - g['f%d_seg_scores' % i]).max())
+            print('batched 2-D pass B = %d, golden frame %d at position %d: max |d score| %.2e, %d arg-max flips (%d pixels with margin < 1e-4)'
+                  % (B, i, p, ds_, flips, int((~clear).sum())))
+            assert ds_ <= 1e-6
+            assert (ids[clear] == g['f%d_seg_ids' % i][clear]).all() and flips <= (~clear).sum()
+        pipe.fuse_sequence(chunk, db, cuda)
+    pipe.check()
+    s = 'room_0'
+    wgt = db.fusion_weights[s]
+    assert int((wgt > 0).sum()) == int(g['f1_touched'])
+    assert sha(wgt) == str(g['f1_wgt_sha256'])
+    touched = wgt.cpu().numpy() > 0
+    got_ids = db.ids_est[s].volume.cpu().numpy()[touched]
+    got_sc = db.scores[s].volume.cpu().numpy()[touched]
+    got_t = db.scenes_est[s].volume.cpu().numpy()[touched]
+    id_bad = int((got_ids != g['last_ids_touched']).sum())
+    sc_ulp = f16_ulp_distance(got_sc, g['last_scores_touched'])
+    assert (np.isnan(got_t) == np.isnan(g['last_tsdf_touched'])).all()
+    td = np.nan_to_num(np.abs(got_t.astype(np.float32) - g['last_tsdf_touched'].astype(np.float32)))
+    print('   volumes: %d of %d touched voxels with another id, score ulps max %d (%d voxels > 0), max |dTSDF| %.2e, %.4f %% differ'
+          % (id_bad, int(touched.sum()), int(sc_ulp.max()), int((sc_ulp > 0).sum()), float(td.max()), 100 * float((td > 0).mean())))
+    assert id_bad <= 56 * flips_total
+    assert sc_ulp.max() <= 1 or (sc_ulp > 1).sum() <= 56 * flips_total
+    assert td.max() <= (F16_ULP_BAND if flips_total == 0 else 2e-3)
+    assert float((td > 0).mean()) <= (0.004 if flips_total == 0 else 0.02)
+    assert float((db.fusion_weights['room_1'].float() > 0).sum()) > 1000  # (the filler frames were fused too, into their own scene)

@@ -672,3 +672,210 @@ def test_streams_overlap_probe(cuda):
     main = torch.cuda.current_stream(cuda)
     side = pipe._side_stream([main])
     assert isinstance(side, torch.cuda.Stream) and side.cuda_stream != main.cuda_stream
+
+
+# ---- round 6: the gaps the look-ahead / multi-scene entry points opened ---------------------
+def _predict_pipeline(cuda, h, w, grid, n_classes, scenes=None, frames=16):
+    from adapnet_golden_util import randomise_net
+    from online_joint_depthfusion_and_semantic_amd.synthetic import SyntheticDataset
+    cfg = default_config(h, w, semantics=True, use_semantics=False, n_classes=n_classes, integrate_mode='fast')
+    cfg.SETTINGS.device = str(cuda)
+    cfg.DATA.semantic_strategy = 'predict'
+    if scenes:
+        st = SyntheticDataset(h, w, grid, frames, scenes=scenes, n_classes=n_classes)
+    else:
+        st = make_stream(h, w, grid, n_classes=n_classes)
+    db = Database(st, database_config(cfg))
+    torch.manual_seed(3)
+    pipe = Pipeline(cfg)
+    for m in pipe._fusion_network.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            torch.nn.init.xavier_normal_(m.weight)
+    randomise_net(pipe._semantic_2d_network, 31)
+    for m in pipe._semantic_2d_network.modules():
+        if hasattr(m, 'dropout') and isinstance(m.dropout, bool):
+            m.dropout = False
+    return cfg, st, db, pipe.to(cuda).eval()
+
+
+def _same_volumes(db_a, db_b, s):
+    assert torch.equal(db_a.scenes_est[s].volume.view(torch.int16), db_b.scenes_est[s].volume.view(torch.int16))
+    assert torch.equal(db_a.fusion_weights[s].view(torch.int16), db_b.fusion_weights[s].view(torch.int16))
+    assert torch.equal(db_a.ids_est[s].volume, db_b.ids_est[s].volume)
+    assert torch.equal(db_a.scores[s].volume.view(torch.int16), db_b.scores[s].volume.view(torch.int16))
+
+
+def test_fuse_sequence_prefetch_of_a_dropped_chunk_is_never_taken(cuda):
+    """The announced chunk is matched by OBJECT IDENTITY of batch dicts the pipeline keeps alive: a caller that announces a
+    chunk, drops it and builds new dicts (which CPython may give the freed addresses - the old id()-keyed match could then
+    fuse the stale labels of OTHER frames) must get its own labels.  The new dicts here carry different frames."""
+    import gc
+    h, w, grid, n_classes = 64, 96, 32, 12
+    _, st_a, db_a, pre = _predict_pipeline(cuda, h, w, grid, n_classes)
+    _, st_b, db_b, plain = _predict_pipeline(cuda, h, w, grid, n_classes)
+    plain.load_state_dict(pre.state_dict())
+    with torch.no_grad():
+        first = [_batch(st_a, i, cuda) for i in range(0, 4)]
+        for attempt in range(6):  # several rounds: address reuse needs luck, the assertion must hold every time
+            announced = [_batch(st_a, i, cuda) for i in range(4, 8)]
+            pre.fuse_sequence(first, db_a, cuda, prefetch=announced)
+            del announced
+            gc.collect()
+            other = [_batch(st_a, i, cuda) for i in range(8, 12)]  # new dicts, other frames, maybe the old addresses
+            pre.fuse_sequence(other, db_a, cuda)
+            assert pre.__dict__['_prefetch'].get('hits', 0) == 0
+            plain.fuse_sequence([_batch(st_b, i, cuda) for i in range(0, 4)], db_b, cuda)
+            plain.fuse_sequence([_batch(st_b, i, cuda) for i in range(8, 12)], db_b, cuda)
+        pre.check()
+        plain.check()
+    _same_volumes(db_a, db_b, st_a.scene)
+    # ... and the same objects ARE taken
+    with torch.no_grad():
+        nxt = [_batch(st_a, i, cuda) for i in range(12, 16)]
+        pre.fuse_sequence(first, db_a, cuda, prefetch=nxt)
+        pre.fuse_sequence(nxt, db_a, cuda)
+        pre.check()
+    assert pre.__dict__['_prefetch']['hits'] == 1
+
+
+@pytest.mark.parametrize('entry', ['fuse_sequence', 'fuse_many'])
+def test_range_guard_policy_f32_covers_fuse_sequence_and_fuse_many(cuda, entry):
+    """guard_policy 'f32' through the chunked / multi-scene entry points: the tripped frames are fused again on the fp32-input
+    path, in order - volumes bit for bit those of a pipeline that ran arithmetic f32 from the first frame through fuse()."""
+    from online_joint_depthfusion_and_semantic_amd.synthetic import SyntheticDataset
+    h, w, grid, S, steps = 48, 64, 64, 3, 3
+    scenes = tuple('room_%d' % k for k in range(S))
+
+    def build(policy, arithmetic):
+        cfg = default_config(h, w, semantics=False, use_semantics=False, integrate_mode='fast')
+        cfg.SETTINGS.device = str(cuda)
+        cfg.FUSION_MODEL.guard_policy = policy
+        cfg.FUSION_MODEL.arithmetic = arithmetic
+        ds = SyntheticDataset(h, w, grid, 8, scenes=scenes)
+        db = Database(ds, database_config(cfg))
+        torch.manual_seed(5)
+        pipe = Pipeline(cfg)
+        for m in pipe._fusion_network.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                torch.nn.init.xavier_normal_(m.weight)
+        with torch.no_grad():
+            pipe._fusion_network.block0[0].block[0].weight.mul_(1e9)  # trips the split-fp16 range guard
+        return cfg, ds, db, pipe.to(cuda).eval()
+    cfg, ds_a, db_a, pipe = build('f32', 'f16x3')
+    _, ds_b, db_b, ref = build('raise', 'f32')
+    ref._fusion_network.load_state_dict(pipe._fusion_network.state_dict())
+
+    def batch(ds, s, i):
+        return {k: (v.to(cuda) if torch.is_tensor(v) else v) for k, v in ds.streams[s].batch(i).items()}
+    with torch.no_grad(), pytest.warns(RuntimeWarning, match='switched to f32'):
+        for i in range(steps):
+            if entry == 'fuse_many':
+                pipe.fuse_many([batch(ds_a, s, i) for s in scenes], db_a, cuda)
+            else:  # a chunk = the step's frames of all scenes in stream order
+                pipe.fuse_sequence([batch(ds_a, s, i) for s in scenes], db_a, cuda)
+        pipe.check()
+    with torch.no_grad():
+        for i in range(steps):
+            for s in scenes:
+                ref.fuse(batch(ds_b, s, i), db_b, cuda)
+        ref.check()
+    assert pipe.guard_events == 1 and cfg.FUSION_MODEL.arithmetic == 'f32'
+    for s in scenes:
+        assert float((db_a.fusion_weights[s].float() > 0).sum()) > 1000
+        for a, b in zip(_volumes(db_a, s), _volumes(db_b, s)):
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16)), s
+
+
+def test_single_frame_and_batched_2d_graphs_share_one_engine(cuda):
+    """fuse() (B = 1 graph of the 2-D engine), fuse_many() (B = S graph), fuse() again on ONE pipeline: each captured graph
+    addresses its own decoder concat buffers by raw pointer, so neither batch size may evict the other's (the
+    second fuse() replayed into freed memory; the zero pad channels 280..287 could come back as NaN logits).  Volumes against
+    pipelines that only ever ran one of the two paths, with the allocator's cache emptied in between."""
+    h, w, grid, n_classes, S = 64, 96, 32, 12, 3
+    scenes = tuple('room_%d' % k for k in range(S))
+    _, ds_a, db_a, mixed = _predict_pipeline(cuda, h, w, grid, n_classes, scenes)
+    _, ds_b, db_b, single = _predict_pipeline(cuda, h, w, grid, n_classes, scenes)
+    single.load_state_dict(mixed.state_dict())
+
+    def batch(ds, s, i):
+        return {k: (v.to(cuda) if torch.is_tensor(v) else v) for k, v in ds.streams[s].batch(i).items()}
+    with torch.no_grad():
+        for rnd in range(2):
+            i0 = 3 * rnd
+            for s in scenes:
+                mixed.fuse(batch(ds_a, s, i0), db_a, cuda)
+            torch.cuda.synchronize(); torch.cuda.empty_cache()
+            junk = torch.full((64 << 20,), float('nan'), device=cuda)  # whatever was freed is NaN now
+            mixed.fuse_many([batch(ds_a, s, i0 + 1) for s in scenes], db_a, cuda)
+            del junk
+            torch.cuda.synchronize(); torch.cuda.empty_cache()
+            junk = torch.full((64 << 20,), float('nan'), device=cuda)
+            for s in scenes:
+                mixed.fuse(batch(ds_a, s, i0 + 2), db_a, cuda)
+            del junk
+        mixed.check()
+        # the label images of the mixed pipeline's LAST single-frame pass against a pipeline that never ran a batch
+        for i in range(6):
+            for s in scenes:
+                single.fuse(batch(ds_b, s, i), db_b, cuda)
+        single.check()
+        b = batch(ds_a, scenes[0], 7)
+        ids_m, sc_m = mixed._frame_semantics(b)
+        ids_s, sc_s = single._frame_semantics(b)
+        assert torch.isfinite(sc_m).all() and torch.equal(ids_m, ids_s) and torch.equal(sc_m, sc_s)
+    for s in scenes:
+        # geometry does not see the labels: bit for bit; labels: the batched pass's rounding at near-ties only
+        assert torch.equal(db_a.scenes_est[s].volume.view(torch.int16), db_b.scenes_est[s].volume.view(torch.int16))
+        assert torch.equal(db_a.fusion_weights[s].view(torch.int16), db_b.fusion_weights[s].view(torch.int16))
+        touched = db_b.fusion_weights[s] > 0
+        assert (db_a.ids_est[s].volume[touched] == db_b.ids_est[s].volume[touched]).float().mean().item() >= 0.999
+        assert torch.isfinite(db_a.scores[s].volume.float()).all()
+
+
+def test_a_tripped_2d_pass_is_loud_when_the_fusion_net_runs_fp32(cuda):
+    """The 2-D engine's kernels are split-fp16 whatever FUSION_MODEL.arithmetic says, and they raise the same process-wide
+    flag the integrate calls honour.  With arithmetic 'f32' the fusion net's forward does not poll it: the frame step itself
+    must (every later frame was dropped silently until check()).  Volumes hold every frame before the event and
+    nothing after it; the next fuse() raises; check() reports and clears."""
+    from online_joint_depthfusion_and_semantic_amd import _lib
+    h, w, grid, n_classes = 64, 96, 32, 12
+    cfg, st, db, pipe = _predict_pipeline(cuda, h, w, grid, n_classes)
+    cfg.FUSION_MODEL.arithmetic = 'f32'
+    s = st.scene
+    with torch.no_grad():
+        pipe.fuse(_batch(st, 0, cuda), db, cuda)
+        pipe.check()
+        before = _volumes(db, s) + [db.ids_est[s].volume.clone(), db.scores[s].volume.clone()]
+        pipe._semantic_2d_network.encoder_mod1.res_n50_enc.conv1.weight.mul_(1e12)  # the stem's output leaves the fp16 range
+        raised = False
+        for i in range(1, 4):
+            try:
+                pipe.fuse(_batch(st, i, cuda), db, cuda)
+            except _lib.OjfError as err:
+                assert 'fp16 range' in str(err)
+                raised = True
+                break
+            torch.cuda.synchronize()  # (the flag is raised by the device: the NEXT frame step must see it)
+        assert raised, 'three frames went by after the 2-D engine left the fp16 range and no fuse() raised'
+        after = _volumes(db, s) + [db.ids_est[s].volume.clone(), db.scores[s].volume.clone()]
+        for a, b in zip(before, after):
+            assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))
+        with pytest.raises(_lib.OjfError, match='fp16 range'):
+            pipe.check()
+        pipe.check()  # cleared
+
+
+def test_segmentation_fallback_for_odd_frame_sizes_warns_once(cuda):
+    """SEMANTIC_2D_MODEL.engine 'hip' needs frame sides that are multiples of 16; other sizes run the module forward - said
+    once, not silently."""
+    import warnings
+    h, w, grid, n_classes = 40, 56, 32, 12
+    cfg, st, db, pipe = _predict_pipeline(cuda, h, w, grid, n_classes)
+    with torch.no_grad():
+        with pytest.warns(RuntimeWarning, match='multiples of 16'):
+            pipe.fuse(_batch(st, 0, cuda), db, cuda)
+        with warnings.catch_warnings():
+            warnings.simplefilter('error')
+            pipe.fuse(_batch(st, 1, cuda), db, cuda)
+        pipe.check()
+    assert float((db.fusion_weights[st.scene].float() > 0).sum()) > 100
