@@ -329,6 +329,7 @@ class ManyCase:
         streams = [BenchStream(h, w, grid, max(n_distinct, 40), scene='room_%d_%d' % (rank, k), seed=1911 + rank + 101 * k, n_classes=c['n_classes'])
                    for k in range(S)]
         self.db = Database(ManyScenes(streams), database_config(cfg))
+        self.streams0 = streams[0]
         pipe = Pipeline(cfg)
         seeded_weights(pipe)
         self.pipe = pipe.to(dev).eval()
@@ -364,13 +365,41 @@ class ManyCase:
                 times.append(time.perf_counter() - t0)
                 at += steps
             self.pipe.check()
+            # stage times of the joint launches (events around extract_many / integrate_many on every call of an untimed pass)
+            stages = {}
+            try:
+                self.pipe.profile = True
+                self.pipe.reset_profile()
+                for i in range(at, at + 12):
+                    self.pipe.fuse_many(self.batches[i % len(self.batches)], self.db, self.dev)
+                stages = self.pipe.stage_times_ms()
+                self.pipe.profile = False
+                self.pipe.check()
+            except Exception as e:
+                stages = {'error': repr(e)}
         self.host_ms_per_call = 1e3 * sorted(host)[len(host) // 2] / steps
         times.sort()
         med = times[len(times) // 2]
-        return {'workload': workload_name(self.c) + ' - %d scenes per GPU, one frame of each per Pipeline.fuse_many call' % self.S, 'scenes_per_gpu': self.S,
-                'value': self.S * steps / med, 'unit': 'frames/sec (all scenes)', 'ms_per_call': 1e3 * med / steps, 'steps': steps, 'warmup': warmup,
-                'repeats': repeats, 'value_min': self.S * steps / times[-1], 'value_max': self.S * steps / times[0],
-                'host_enqueue_ms_per_call': self.host_ms_per_call}
+        out = {'workload': workload_name(self.c) + ' - %d scenes per GPU, one frame of each per Pipeline.fuse_many call' % self.S, 'scenes_per_gpu': self.S,
+               'value': self.S * steps / med, 'unit': 'frames/sec (all scenes)', 'ms_per_call': 1e3 * med / steps, 'steps': steps, 'warmup': warmup,
+               'repeats': repeats, 'value_min': self.S * steps / times[-1], 'value_max': self.S * steps / times[0],
+               'host_enqueue_ms_per_call': self.host_ms_per_call}
+        if 'extract' in stages:
+            # the S scenes' gather and scatter are ONE launch each (ojf_extract_many / ojf_integrate_many): per-frame time = call / S
+            cfg = self.cfg
+            st0 = self.streams0
+            bytes_frame, ug, us = algorithmic_bytes(st0, [warmup % st0.n_frames, (warmup + 7) % st0.n_frames], cfg.FUSION_MODEL.n_points,
+                                                    cfg.FUSION_MODEL.n_tail_points, self.c['semantics'])
+            ei_us = 1e3 * (stages['extract'] + stages['integrate']) / self.S
+            out['stages_ms_per_call'] = stages
+            out['extract_integrate_us_per_frame'] = ei_us
+            out['roofline_hbm'] = {'bound': 'hbm', 'kernel': 'extract_tile_many_kernel + integrate_*_many_kernel (blockIdx.y = scene)',
+                                   'achieved': bytes_frame / (ei_us * 1e-6) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                   'frac': bytes_frame / (ei_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 'bytes_per_frame': bytes_frame,
+                                   'note': 'algorithmic bytes of one frame (scene 0 of the call, SURVEY.md 8d) x S / HIP-event time of the two joint launches'}
+        elif stages:
+            out['stages_ms_per_call'] = stages
+        return out
 
 
 def kernel_table(kernels, c, N, peak_tf, total_macs):

@@ -393,6 +393,49 @@ int ojf_extract_to_net(const float *depth_dev, const float *Kinv_host, const flo
                        double resolution, const uint16_t *tsdf_dev, const uint16_t *weights_dev, int X, int Y, int Z, int h,
                        int w, int n_points, float pad_value, ojf_net *net, ojf_stream_t stream);
 
+/* ---- one frame of each of SEVERAL scenes as single launches (round 6; Pipeline.fuse_many) ------------------------------
+ * modules/extractor.py:24-79 and modules/integrator.py:15-124 for n <= OJF_MAX_SCENES frames of DISTINCT scenes (one frame
+ * size, one sample count, one grid size; every job with its own volumes, camera, outputs and integrate workspace): the
+ * kernels of ojf_extract / ojf_extract_to_net and of ojf_integrate_masked with the scene as blockIdx.y, so that the
+ * dependent-step chains of S frames share one launch ramp and fill the chip while other blocks wait.  Per scene the same
+ * blocks run the same code on the same arguments: every output and every volume comes out bit for bit as from the n
+ * separate calls.  The reference has no counterpart (its drivers fuse one frame at a time: test_fusion.py:68-80).
+ * ojf_extract_job: `net` set = ojf_extract_to_net into that net's input planes (out_* ignored); else out_values /
+ *   out_weights with out_stride / out_layout as in ojf_extract.
+ * ojf_integrate_job: the arguments of ojf_integrate_masked (mask / semantic pointers NULL where unused, semantics for all
+ *   jobs or none); OJF_MODE_FAST only - the PARITY mode's sort is per scene, call ojf_integrate_masked for it. */
+#define OJF_MAX_SCENES 8
+typedef struct ojf_extract_job {
+    const float *depth_dev;
+    const float *Kinv_host, *E_host;
+    const double *origin_host;
+    double resolution;
+    const uint16_t *tsdf_dev, *weights_dev;
+    ojf_net *net;
+    float *out_values_dev, *out_weights_dev;
+    int out_stride, out_layout;
+} ojf_extract_job;
+typedef struct ojf_integrate_job {
+    const float *depth_dev;
+    const uint8_t *mask_dev;
+    const float *Kinv_host, *E_host;
+    const double *origin_host;
+    double resolution;
+    const float *est_dev;
+    int est_stride;
+    uint16_t *tsdf_dev, *weights_dev;
+    const uint8_t *sem_ids_dev;
+    const float *sem_scores_dev;
+    uint8_t *id_vol_dev;
+    uint16_t *score_vol_dev;
+    void *workspace_dev;
+    size_t workspace_bytes;
+} ojf_integrate_job;
+int ojf_extract_many(int n, const ojf_extract_job *jobs, int X, int Y, int Z, int h, int w, int n_points, float pad_value,
+                     ojf_stream_t stream);
+int ojf_integrate_many(int n, const ojf_integrate_job *jobs, int n_points, int n_tail, float trunc, int X, int Y, int Z, int h,
+                       int w, ojf_stream_t stream);
+
 /* ---- AdapNet++ front end: the operators around the convolutions (csrc/ojf_seg_ops.hip) --------------------
  * NHWC fp32 rows of batch 1 like ojf_segconv_forward (pointer to channel 0 of pixel 0 + floats per pixel row).
  * ojf_seg_pack_input: modules/pipeline.py:44,50 - three source planes (src[c * chan_stride + p]; chan_stride 0 =

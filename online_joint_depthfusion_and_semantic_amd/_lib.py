@@ -41,6 +41,23 @@ class TrainLayer(ctypes.Structure):
 _c = ctypes
 _vp, _i, _f, _d, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_double, _c.c_size_t
 
+MAX_SCENES = 8  # include/ojf.h OJF_MAX_SCENES
+
+
+class ExtractJob(ctypes.Structure):
+    """include/ojf.h ojf_extract_job: one scene's frame of ojf_extract_many."""
+    _fields_ = [('depth_dev', _vp), ('Kinv_host', _vp), ('E_host', _vp), ('origin_host', _vp), ('resolution', _d),
+                ('tsdf_dev', _vp), ('weights_dev', _vp), ('net', _vp), ('out_values_dev', _vp), ('out_weights_dev', _vp),
+                ('out_stride', _i), ('out_layout', _i)]
+
+
+class IntegrateJob(ctypes.Structure):
+    """include/ojf.h ojf_integrate_job: one scene's frame of ojf_integrate_many."""
+    _fields_ = [('depth_dev', _vp), ('mask_dev', _vp), ('Kinv_host', _vp), ('E_host', _vp), ('origin_host', _vp), ('resolution', _d),
+                ('est_dev', _vp), ('est_stride', _i), ('tsdf_dev', _vp), ('weights_dev', _vp), ('sem_ids_dev', _vp),
+                ('sem_scores_dev', _vp), ('id_vol_dev', _vp), ('score_vol_dev', _vp), ('workspace_dev', _vp), ('workspace_bytes', _sz)]
+
+
 # name -> (restype, argtypes); must list every symbol include/ojf.h declares
 SIGNATURES = {
     'ojf_version': (_c.c_char_p, []),
@@ -49,6 +66,8 @@ SIGNATURES = {
     'ojf_extract': (_i, [_vp, _vp, _vp, _vp, _d, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _i,
                          _vp, _vp, _vp, _vp, _vp]),
     'ojf_extract_to_net': (_i, [_vp, _vp, _vp, _vp, _d, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),
+    'ojf_extract_many': (_i, [_i, _c.POINTER(ExtractJob), _i, _i, _i, _i, _i, _i, _f, _vp]),
+    'ojf_integrate_many': (_i, [_i, _c.POINTER(IntegrateJob), _i, _i, _f, _i, _i, _i, _i, _i, _vp]),
     'ojf_integrate_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     'ojf_integrate_workspace_init': (_i, [_vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ojf_integrate': (_i, [_vp, _vp, _vp, _vp, _d, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp,

@@ -123,7 +123,7 @@ __device__ __forceinline__ void extract_item(const ExtractArgs &a, int n, int k,
 }
 
 // n_points <= kMaxTilePoints: blockDim.x = 64 * n_points, wave k = sample k of the block's 64 pixels
-__global__ __launch_bounds__(64 * kMaxTilePoints) void extract_tile_kernel(ExtractArgs a, Camera cam)
+__device__ __forceinline__ void extract_tile_body(const ExtractArgs &a, const Camera &cam)
 {
     __shared__ double frame[6][64];
     __shared__ float pcl[3][64];
@@ -176,6 +176,19 @@ __global__ __launch_bounds__(64 * kMaxTilePoints) void extract_tile_kernel(Extra
         bad = bad || fabsf(v.x) > 65504.0f || fabsf(v.y) > 65504.0f || fabsf(v.z) > 65504.0f || fabsf(v.w) > 65504.0f;
     }
     if (bad && a.ovf) guard_raise(a.ovf, 1);  // split-fp16 range guard of the net input (NaN passes, like everywhere else)
+}
+
+__global__ __launch_bounds__(64 * kMaxTilePoints) void extract_tile_kernel(ExtractArgs a, Camera cam) { extract_tile_body(a, cam); }
+
+// The frames of up to kMaxScenes SCENES in one launch (ojf_extract_many, round 6): blockIdx.y = scene, every scene with its
+// own volumes, camera and outputs.  One frame's launch is one round of 1200 blocks that each walk a chain of dependent steps
+// (ray frame -> gathers -> sums -> transposed store): S frames side by side in ONE launch share the ramp and
+// fill the CUs while other blocks wait - which S launches on S streams do not (they take turns on the queue).  The same
+// blocks, the same code per block: the same bits as S separate calls.
+struct ExtractMany { ExtractArgs a[OJF_MAX_SCENES]; Camera cam[OJF_MAX_SCENES]; };
+__global__ __launch_bounds__(64 * kMaxTilePoints) void extract_tile_many_kernel(ExtractMany m)
+{
+    extract_tile_body(m.a[blockIdx.y], m.cam[blockIdx.y]);
 }
 
 // any n_points: one lane per (sample k, pixel n), k-major; every item computes its own ray frame
@@ -244,4 +257,42 @@ OJF_API int ojf_extract_to_net(const float *depth, const float *Ki, const float 
     const Camera cam = make_camera(Ki, E, origin, res);
     hipLaunchKernelGGL(extract_tile_kernel, dim3((h * w + 63) / 64), dim3(64 * n_points), 0, as_stream(stream), a, cam);
     return check_hip(hipGetLastError(), "ojf_extract_to_net launch");
+}
+
+// One frame of each of n scenes (1 <= n <= OJF_MAX_SCENES) of ONE frame size and sample count as a single launch.
+OJF_API int ojf_extract_many(int n, const ojf_extract_job *jobs, int X, int Y, int Z, int h, int w, int n_points, float pad_value,
+                             ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (n < 1 || n > OJF_MAX_SCENES || !jobs) return fail("ojf_extract_many: 1..OJF_MAX_SCENES jobs");
+    if (X <= 0 || Y <= 0 || Z <= 0 || h <= 0 || w <= 0) return fail("ojf_extract_many: non-positive volume or frame size");
+    if (n_points < 1 || (n_points & 1) == 0 || n_points > kMaxTilePoints) return fail("ojf_extract_many: n_points must be odd, 1..16");
+    if ((int64_t)h * w * n_points > 0x7fffffffLL) return fail("ojf_extract_many: frame too large");
+    ExtractMany m;
+    for (int i = 0; i < n; ++i) {
+        const ojf_extract_job &j = jobs[i];
+        if (!j.depth_dev || !j.Kinv_host || !j.E_host || !j.origin_host || !j.tsdf_dev || !j.weights_dev) return fail("ojf_extract_many: null pointer in a job");
+        if (!(j.resolution > 0.0)) return fail("ojf_extract_many: resolution must be > 0");
+        for (int k = 0; k < i; ++k)
+            if ((j.net && j.net == jobs[k].net) || (j.out_values_dev && j.out_values_dev == jobs[k].out_values_dev))
+                return fail("ojf_extract_many: two jobs write the same output");
+        if (j.net) {
+            NetInputSlot slot;
+            if (net_input_slot(j.net, &slot))
+                return fail("ojf_extract_many: this net takes a semantic channel or has two heads: hand over sample planes instead");
+            if (slot.h != h || slot.w != w || slot.P != n_points) return fail("ojf_extract_many: frame size / n_points differ from the net's");
+            if (4 * slot.cs4 > kNetPitch || 2 * n_points + 1 > 4 * slot.cs4) return fail("ojf_extract_many: unsupported slot width");
+            m.a[i] = ExtractArgs{j.depth_dev, j.tsdf_dev, j.weights_dev, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                 X, Y, Z, h, w, n_points, h * w, 2, pad_value, reinterpret_cast<float4 *>(slot.x0), slot.cs4, slot.ovf, slot.split};
+        } else {
+            if (!j.out_values_dev || !j.out_weights_dev) return fail("ojf_extract_many: a job needs a net or output buffers");
+            if (j.out_layout != 0 && j.out_layout != 1) return fail("ojf_extract_many: out_layout must be 0 (rows) or 1 (sample planes)");
+            if (j.out_layout == 0 ? j.out_stride < n_points : j.out_stride < h * w) return fail("ojf_extract_many: output stride too small");
+            m.a[i] = ExtractArgs{j.depth_dev, j.tsdf_dev, j.weights_dev, j.out_values_dev, j.out_weights_dev, nullptr, nullptr, nullptr, nullptr,
+                                 X, Y, Z, h, w, n_points, j.out_stride, j.out_layout, pad_value, nullptr, 0, nullptr, 0};
+        }
+        m.cam[i] = make_camera(j.Kinv_host, j.E_host, j.origin_host, j.resolution);
+    }
+    hipLaunchKernelGGL(extract_tile_many_kernel, dim3((h * w + 63) / 64, n), dim3(64 * n_points), 0, as_stream(stream), m);
+    return check_hip(hipGetLastError(), "ojf_extract_many launch");
 }

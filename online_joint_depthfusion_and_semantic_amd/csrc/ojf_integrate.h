@@ -24,6 +24,12 @@ constexpr double kFixScale = 17592186044416.0;        // 2^44
 constexpr double kFixInv = 1.0 / 17592186044416.0;
 constexpr size_t kHeaderBytes = 512;                  // two sets of 32 counters ([0] counter-allocated touched voxels, [2] counter-allocated records), then the two phase words (kPhaseAcc, kPhaseFin)
 constexpr int kPhaseAcc = 64, kPhaseFin = 65;         // uint index in the header: counter set the next accumulate / the coming finalize uses
+// The range-guard decision of ONE integrate call (round 6): the flag has concurrent producers (the look-ahead 2-D pass on its side
+// stream, the nets of fuse_many's other slots), so blocks - even threads - that each read it could disagree and a frame would be
+// integrated in part.  The kernels that only fill the workspace (accumulate, the entry-list kernel, PARITY emit) therefore never
+// skip; ONE thread of them copies the flag into this header word, and the kernel that writes the volumes (finalize, PARITY walk),
+// a later launch on the same stream, reads nothing else: all of a call's voxels are updated or none is.
+constexpr int kGuardLatch = 66;
 
 struct IntegrateArgs {
     const float *depth;  // filtered frame, or the raw frame when `mask` is set

@@ -76,7 +76,7 @@ constexpr int kAccThreads = 512;
 // before they reach the LDS hash - measured 60.2 against 56.8 us per frame for the integrate stage at 320x240 -> 256^3 (the
 // exchanges cost more VALU time than the same-address LDS atomics they spare; results identical bit for bit)
 template <bool SEM, bool WCOMB>
-__global__ __launch_bounds__(kAccThreads) void integrate_accumulate_tiled_kernel(IntegrateArgs a, Camera cam)
+__device__ __forceinline__ void accumulate_tiled_body(const IntegrateArgs &a, const Camera &cam)
 {
     __shared__ unsigned int keys[kSlots];
     __shared__ unsigned long long accw[kSlots];
@@ -93,8 +93,7 @@ __global__ __launch_bounds__(kAccThreads) void integrate_accumulate_tiled_kernel
         keys[s] = kEmpty; accw[s] = 0; accu[s] = 0;
         if constexpr (SEM) { elast[s] = 0; ediff[s] = 0; }
     }
-    __shared__ int guard_seen;
-    if (threadIdx.x == 0) { n_entries = 0; n_new = 0; n_rec = 0; guard_seen = guard_set(a) ? 1 : 0; }
+    if (threadIdx.x == 0) { n_entries = 0; n_new = 0; n_rec = 0; }
     // the counter set of this call (header word kPhaseAcc: flipped by the previous call's finalize kernel, nobody writes it now)
     const unsigned int phase = a.phased ? a.counters[kPhaseAcc] & 1u : 0u;
     unsigned int *const counters = a.counters + 32 * phase;
@@ -102,17 +101,9 @@ __global__ __launch_bounds__(kAccThreads) void integrate_accumulate_tiled_kernel
     const int tiles_x = (a.w + kTileW - 1) / kTileW;
     const int tile = banded_block_x();  // one band of the image per XCD: neighbouring tiles hit the same voxels
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    // ONE read per block (thread 0, above), handed over through LDS: the flag has concurrent producers (the look-ahead 2-D pass
-    // on its side stream, the nets of fuse_many's other slots), so per-thread reads could disagree inside a block and some
-    // waves would run on into the barriers below without the others.
-    __syncthreads();
-    if (guard_seen) {  // block-uniform: the net's range guard fired - this frame must not reach the volumes
-        if (threadIdx.x == 0) {
-            a.tile_new[tile] = 0;  // nothing for the finalize kernel (which still flips the counter sets)
-            if (blockIdx.x == 0) atomicAdd(a.guard + 1, 1);
-        }
-        return;
-    }
+    // the call's range-guard decision (kGuardLatch): this kernel fills the workspace only and never skips; the finalize kernel
+    // reads the latch and leaves the volumes alone when the net's range guard had fired
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.counters[kGuardLatch] = guard_set(a) ? 1u : 0u;
     if (threadIdx.x < kTilePix) {  // once per pixel instead of once per (pixel, sample): three fp64 divisions and a sqrt each
         const int p = threadIdx.x;
         const int r = ty * kTileH + p / kTileW, c = tx * kTileW + p % kTileW;
@@ -307,6 +298,21 @@ __global__ __launch_bounds__(kAccThreads) void integrate_accumulate_tiled_kernel
     for (unsigned int i = threadIdx.x; i < n_new; i += kAccThreads) a.touched[tile * kSlots + i] = keys[newlist[i]];
 }
 
+template <bool SEM, bool WCOMB>
+__global__ __launch_bounds__(kAccThreads) void integrate_accumulate_tiled_kernel(IntegrateArgs a, Camera cam)
+{
+    accumulate_tiled_body<SEM, WCOMB>(a, cam);
+}
+
+// One frame of each of up to OJF_MAX_SCENES scenes in one launch (ojf_integrate_many): blockIdx.y = scene, every scene with its
+// own volumes, camera, est rows and workspace.  The same blocks run the same code per scene: the same bits as separate calls.
+struct IntegrateMany { IntegrateArgs a[OJF_MAX_SCENES]; Camera cam[OJF_MAX_SCENES]; };
+template <bool SEM>
+__global__ __launch_bounds__(kAccThreads) void integrate_accumulate_many_kernel(IntegrateMany m)
+{
+    accumulate_tiled_body<SEM, false>(m.a[blockIdx.y], m.cam[blockIdx.y]);
+}
+
 // Entry-list variant for the reference's own Integrator.forward signature (modules/integrator.py:15-126):
 // the caller hands over materialised updates - per row r (valid pixel x sample) a clamped value, 8 int64
 // corner indices and 8 fp64 corner weights - exactly the tensors Pipeline._prepare_volume_update builds
@@ -328,9 +334,8 @@ __global__ __launch_bounds__(256) void integrate_entries_kernel(IntegrateArgs a,
     __syncthreads();
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned int n_in = 0;
-    const bool skip = guard_set(a);  // the net's range guard fired: nothing reaches the volumes
-    if (skip && r == 0) atomicAdd(a.guard + 1, 1);
-    if (r < e.R && !skip) {
+    if (r == 0) a.counters[kGuardLatch] = guard_set(a) ? 1u : 0u;  // (the call's range-guard decision: see kGuardLatch)
+    if (r < e.R) {
         const float v = e.values[r];
         const bool sem = a.id_vol != nullptr;
         const uint8_t id_e = sem ? e.row_ids[r] : 0;
@@ -360,10 +365,11 @@ __global__ __launch_bounds__(256) void integrate_entries_kernel(IntegrateArgs a,
     for (unsigned int i = threadIdx.x; i < n_new; i += 256) a.touched[a.list_base + base_new + i] = newlist[i];
 }
 
-__device__ __forceinline__ void finalize_voxel(const IntegrateArgs &a, size_t lin, unsigned int per_pixel, bool sem)
+__device__ __forceinline__ void finalize_voxel(const IntegrateArgs &a, size_t lin, unsigned int per_pixel, bool sem, bool skip)
 {
     unsigned int ri = a.head[lin];
     a.head[lin] = 0;  // leave the workspace clean
+    if (skip) return;  // (block-uniform: the call's range-guard latch) the records are dropped, the volumes stay as they are
     const unsigned int first = ri;
     long long sw = 0, su = 0;
     bool wrapped = false;
@@ -413,7 +419,7 @@ __device__ __forceinline__ void finalize_voxel(const IntegrateArgs &a, size_t li
 // are one round with twice the loads in flight.  Same operations per voxel as finalize_voxel: same bits.
 template <int K>
 __device__ __forceinline__ void finalize_voxels(const IntegrateArgs &a, const unsigned int *list, unsigned int i0, unsigned int stride,
-                                                unsigned int n, unsigned int per_pixel, bool sem)
+                                                unsigned int n, unsigned int per_pixel, bool sem, bool skip)
 {
     size_t lin[K];
     unsigned int ri[K], first[K];
@@ -423,6 +429,12 @@ __device__ __forceinline__ void finalize_voxels(const IntegrateArgs &a, const un
     for (int k = 0; k < K; ++k) {
         on[k] = i0 + k * stride < n;
         lin[k] = on[k] ? list[i0 + k * stride] : 0;
+    }
+    if (skip) {  // (block-uniform: the call's range-guard latch) drop the records, leave the workspace clean, touch no volume
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (on[k]) a.head[lin[k]] = 0;
+        return;
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -490,28 +502,37 @@ __device__ __forceinline__ void finalize_voxels(const IntegrateArgs &a, const un
 }
 
 // first the per-tile slices (the voxels each tile touched first), then the counter-allocated list
-__global__ __launch_bounds__(256) void integrate_finalize_kernel(IntegrateArgs a)
+__device__ __forceinline__ void finalize_body(const IntegrateArgs &a)
 {
     const unsigned int per_pixel = (unsigned int)a.n_tail * 8u;  // entries per sem_ids / sem_scores element
     const bool sem = a.id_vol != nullptr;
+    // the call's range-guard decision, latched by ONE thread of the kernel that filled the workspace (kGuardLatch): stable while
+    // this kernel runs, the same for every block - all of the call's voxels are updated or none
+    const bool skip = a.guard != nullptr && a.counters[kGuardLatch] != 0u;
     constexpr int K = 2;
     for (int tile = banded_block_x(); tile < a.n_tiles; tile += gridDim.x) {  // (the XCD that accumulated the tile)
         const unsigned int n = a.tile_new[tile];
         const unsigned int *list = a.touched + (size_t)tile * kSlots;
-        for (unsigned int i = threadIdx.x; i < n; i += K * blockDim.x) finalize_voxels<K>(a, list, i, blockDim.x, n, per_pixel, sem);
+        for (unsigned int i = threadIdx.x; i < n; i += K * blockDim.x) finalize_voxels<K>(a, list, i, blockDim.x, n, per_pixel, sem, skip);
         if (a.stats && threadIdx.x == 0 && n) atomicAdd(&a.stats[0], n);
     }
     // (header word kPhaseFin: written by this call's accumulate kernel, stable while finalize runs)
     const unsigned int phase = a.phased ? a.counters[kPhaseFin] & 1u : 0u;
     const unsigned int count = a.counters[32 * phase];
     for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x)
-        finalize_voxel(a, a.touched[a.list_base + t], per_pixel, sem);
+        finalize_voxel(a, a.touched[a.list_base + t], per_pixel, sem, skip);
     if (a.stats && blockIdx.x == 0 && threadIdx.x == 0 && count) atomicAdd(&a.stats[0], count);
+    if (skip && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.guard + 1, 1);  // one more call whose frame did not reach the volumes
     // the counter set the NEXT call will use (nobody touches it during this one): clean it here instead of a memset
     // launch in front of every frame's accumulate kernel
     if (a.phased && blockIdx.x == 0 && threadIdx.x < 32) a.counters[32 * (1 - phase) + threadIdx.x] = 0;
     if (a.phased && blockIdx.x == 0 && threadIdx.x == 0) a.counters[kPhaseAcc] = phase ^ 1u;  // (the next call's accumulate kernel reads it)
 }
+
+__global__ __launch_bounds__(256) void integrate_finalize_kernel(IntegrateArgs a) { finalize_body(a); }
+
+struct FinalizeMany { IntegrateArgs a[OJF_MAX_SCENES]; };
+__global__ __launch_bounds__(256) void integrate_finalize_many_kernel(FinalizeMany m) { finalize_body(m.a[blockIdx.y]); }
 
 }  // namespace ojf
 
@@ -619,6 +640,66 @@ OJF_API int ojf_integrate_masked(const float *depth_filtered, const uint8_t *mas
     OJF_HIP(hipGetLastError());
     hipLaunchKernelGGL(integrate_finalize_kernel, dim3(tiles < 1024 ? 1024 : tiles), dim3(256), 0, st, a);
     return check_hip(hipGetLastError(), "ojf_integrate launch");
+}
+
+// One frame of each of n scenes (1 <= n <= OJF_MAX_SCENES; one frame / grid size): ojf_integrate_masked's two FAST kernels with
+// the scene as blockIdx.y (include/ojf.h).
+OJF_API int ojf_integrate_many(int n, const ojf_integrate_job *jobs, int n_points, int n_tail, float trunc, int X, int Y, int Z, int h,
+                               int w, ojf_stream_t stream)
+{
+    using namespace ojf;
+    if (n < 1 || n > OJF_MAX_SCENES || !jobs) return fail("ojf_integrate_many: 1..OJF_MAX_SCENES jobs");
+    if (X <= 0 || Y <= 0 || Z <= 0 || h <= 0 || w <= 0) return fail("ojf_integrate_many: non-positive size");
+    if (n_points < 1 || (n_points & 1) == 0) return fail("ojf_integrate_many: n_points must be odd and >= 1");
+    if (n_tail < 1 || n_tail > n_points) return fail("ojf_integrate_many: need 1 <= n_tail <= n_points");
+    if ((uint64_t)X * Y * Z >= 0xffffffffull) return fail("ojf_integrate_many: volume has >= 2^32 voxels");
+    if ((uint64_t)h * w * n_tail * 8 >= 0xffffffffull) return fail("ojf_integrate_many: frame too large");
+    const size_t need = fast_workspace_bytes(X, Y, Z, h, w, n_tail);
+    const int tiles = (int)tile_count(h, w);
+    const size_t nvox = (size_t)X * Y * Z, cap = list_capacity(h, w, n_tail);
+    IntegrateMany m;
+    FinalizeMany f;
+    int n_with_sem = 0;
+    for (int i = 0; i < n; ++i) {
+        const ojf_integrate_job &j = jobs[i];
+        if (!j.depth_dev || !j.Kinv_host || !j.E_host || !j.origin_host || !j.est_dev || !j.tsdf_dev || !j.weights_dev || !j.workspace_dev)
+            return fail("ojf_integrate_many: null pointer in a job");
+        if (j.est_stride < n_tail) return fail("ojf_integrate_many: est_stride < n_tail");
+        if (!(j.resolution > 0.0)) return fail("ojf_integrate_many: resolution must be > 0");
+        const int n_sem = (j.sem_ids_dev != nullptr) + (j.sem_scores_dev != nullptr) + (j.id_vol_dev != nullptr) + (j.score_vol_dev != nullptr);
+        if (n_sem != 0 && n_sem != 4) return fail("ojf_integrate_many: sem_ids, sem_scores, id_vol, score_vol must be all set or all NULL");
+        n_with_sem += n_sem == 4;
+        if (j.workspace_bytes < need) return fail("ojf_integrate_many: workspace too small");
+        for (int k = 0; k < i; ++k)
+            if (jobs[k].workspace_dev == j.workspace_dev || jobs[k].tsdf_dev == j.tsdf_dev || jobs[k].weights_dev == j.weights_dev)
+                return fail("ojf_integrate_many: two jobs share a workspace or a volume (one frame per SCENE, one workspace per job)");
+        IntegrateArgs &a = m.a[i];
+        char *base = static_cast<char *>(j.workspace_dev);
+        a.depth = j.depth_dev; a.mask = j.mask_dev; a.est = j.est_dev; a.tsdf = j.tsdf_dev; a.wgt = j.weights_dev;
+        a.sem_ids = j.sem_ids_dev; a.sem_scores = j.sem_scores_dev; a.id_vol = j.id_vol_dev; a.score_vol = j.score_vol_dev;
+        a.counters = reinterpret_cast<unsigned int *>(base);
+        a.counters_next = nullptr; a.phased = 1;
+        a.guard = const_cast<int *>(range_guard_if_any());
+        char *q = base + kHeaderBytes;
+        a.head = reinterpret_cast<unsigned int *>(q); q += nvox * sizeof(unsigned int);
+        a.recs = reinterpret_cast<VoxelRec *>(q); q += cap * sizeof(VoxelRec);
+        a.touched = reinterpret_cast<unsigned int *>(q); q += cap * sizeof(unsigned int);
+        a.tile_new = reinterpret_cast<unsigned int *>(q);
+        a.n_tiles = tiles;
+        a.list_base = (unsigned int)tiles * kSlots;
+        a.stats = nullptr;
+        a.X = X; a.Y = Y; a.Z = Z; a.h = h; a.w = w; a.n_points = n_points; a.n_tail = n_tail;
+        a.est_stride = j.est_stride; a.trunc = trunc;
+        m.cam[i] = make_camera(j.Kinv_host, j.E_host, j.origin_host, j.resolution);
+        f.a[i] = a;
+    }
+    if (n_with_sem != 0 && n_with_sem != n) return fail("ojf_integrate_many: semantics for all jobs or for none");
+    hipStream_t st = as_stream(stream);
+    if (n_with_sem) hipLaunchKernelGGL((integrate_accumulate_many_kernel<true>), dim3(tiles, n), dim3(kAccThreads), 0, st, m);
+    else hipLaunchKernelGGL((integrate_accumulate_many_kernel<false>), dim3(tiles, n), dim3(kAccThreads), 0, st, m);
+    OJF_HIP(hipGetLastError());
+    hipLaunchKernelGGL(integrate_finalize_many_kernel, dim3(tiles < 1024 ? 1024 : tiles, n), dim3(256), 0, st, f);
+    return check_hip(hipGetLastError(), "ojf_integrate_many launch");
 }
 
 OJF_API int ojf_integrate_entries(const float *values, const int64_t *indices, const double *weights,

@@ -69,9 +69,8 @@ __global__ __launch_bounds__(256) void parity_emit_kernel(IntegrateArgs a, Camer
     const int k = item - n * a.n_tail;
     const size_t slot0 = (size_t)item * 8;
     const float z = frame_depth(a, n);
-    const bool skip = guard_set(a);  // the net's range guard fired: every key becomes the sentinel, the walk finds nothing
-    if (skip && item == 0) atomicAdd(a.guard + 1, 1);
-    const bool valid = (z != 0.0f) && !skip;
+    if (item == 0) a.counters[kGuardLatch] = guard_set(a) ? 1u : 0u;  // the call's range-guard decision (ojf_integrate.h kGuardLatch); this kernel never skips
+    const bool valid = z != 0.0f;
     RaySample s;
     if (valid) {
         const int r = n / a.w, c = n - r * a.w;
@@ -103,6 +102,10 @@ __global__ __launch_bounds__(256) void parity_walk_kernel(IntegrateArgs a, const
                                                            size_t M, unsigned int sentinel)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a.guard && a.counters[kGuardLatch]) {  // (uniform) the net's range guard had fired when this call began: no volume is touched
+        if (i == 0) atomicAdd(a.guard + 1, 1);
+        return;
+    }
     if (i >= M) return;
     const unsigned int key = keys[i];
     if (key == sentinel) return;

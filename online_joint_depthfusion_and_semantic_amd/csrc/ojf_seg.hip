@@ -900,6 +900,192 @@ __global__ __launch_bounds__(256, 2) void segconv_gemm_kernel(const SegGroupArgs
     seg_epilogue<MT, NT, DROP>(a, acc, ctw, ptw, n_pix, col, kg, rvs, bvs);
 }
 
+// Producer / consumer form of the GEMM-shaped kernel (round 6).  What round 5's ablations said about segconv_gemm_kernel: with
+// the SAME four waves fetching, splitting, staging and multiplying, the pieces of a K block ADD - loads + split + ds_write + barrier
+// cost 42 us on top of the 60 us of LDS reads + MFMAs of the 60x80 256 -> 256 layer - because a wave is in one phase at a time and a
+// SIMD holds one such wave.  Here the phases belong to DIFFERENT waves of one block: waves 0 .. 3 (one per SIMD, 2 x 2 over the block
+// tile) only read operands from LDS and issue MFMAs; waves 4 .. 7 (one per SIMD, beside a consumer) only move data - plain 16-byte
+// loads of the packed weight chunks and of the fp32 pixel rows, P K blocks in flight in registers, the fp16 split of the pixel
+// operands, ds_write_b128 into the other LDS stage.  A SIMD's MFMA pipe runs the consumer's 16-cycle instructions while its VALU /
+// memory ports take the producer's; one block-wide barrier per K block hands a finished stage over.  Same K order and the same
+// arithmetic as segconv_gemm_kernel (one accumulator walks the K blocks in order): the same bits.
+template <int MT, int NT, bool DROP, bool ALIGNED, int P = 3>
+__global__ __launch_bounds__(512) void segconv_ws_kernel(const SegGroupArgs grp)
+{
+    int bx, by, bz;
+    if (!seg_block(grp, bx, by, bz)) return;  // block-uniform
+    const SegArgs &a = grp.a[bz];
+    constexpr int WM = 2, WN = 2;
+    constexpr int MB = WM * MT, NB = WN * NT;  // channel / pixel tiles of the block
+    static_assert(NB % 4 == 0 && (2 * MB) % 4 == 0, "every producer wave moves the same share");
+    constexpr int PT = NB / 4;                 // pixel tiles a producer wave fetches and splits per K block
+    constexpr int CW = 2 * MB / 4;             // one-KB weight chunks (channel tile, half) a producer wave fetches per K block
+    __shared__ f32x4 As[2][MB][2][64];
+    __shared__ f32x4 Bs[2][NB][2][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ct0 = by * MB, pt0 = bx * NB;
+    const int n_kb = a.n_kb, n_ct = a.n_ct;
+    const int col = lane & 15, kg = lane >> 4;
+
+    if (wave >= 4) {
+        // ---------------- producer ----------------
+        const int pw = wave - 4;
+        const int H = a.H, W = a.W, HoWo = a.Ho * a.Wo, Wo = a.Wo, c8 = a.c8, ksize = a.ksize, dil = a.dil, in_stride = a.in_stride;
+        const int n_pix = a.B * HoWo;
+        int iy0[PT], ix0[PT], img0[PT];
+        bool live[PT];
+#pragma unroll
+        for (int n = 0; n < PT; ++n) {
+            const int p = (pt0 + pw * PT + n) * 16 + col;
+            live[n] = p < n_pix;
+            const int b = p / HoWo, q = p - b * HoWo;
+            const int oy = q / Wo, ox = q - oy * Wo;
+            iy0[n] = oy * a.stride - a.pad;
+            ix0[n] = ox * a.stride - a.pad;
+            img0[n] = b * H * W;
+        }
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in), 0, a.in_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rw =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(a.wp), 0, (unsigned)((size_t)n_ct * n_kb * 2048), 0x00020000);
+        unsigned woff[CW];
+#pragma unroll
+        for (int r = 0; r < CW; ++r) {
+            const int c = pw * CW + r, m = c >> 1, h = c & 1;
+            int ct = ct0 + m;
+            ct = ct < n_ct ? ct : n_ct - 1;  // (a block past the layer's last channel tile: any valid tile, results unused)
+            woff[r] = (unsigned)(((ct * n_kb) * 128 + h * 64 + lane) * 16);
+        }
+        const int n_cgb = c8 >> 2;
+        int tap_s = 0, cgb_s = 0;
+        unsigned toff[PT];
+        int tap = kg / c8, cg = kg - tap * c8;
+        int ty = tap / ksize, tx = tap - ty * ksize;
+        auto tap_offsets = [&](int t) {
+            const int y = t / ksize, x = t - y * ksize;
+#pragma unroll
+            for (int n = 0; n < PT; ++n) {
+                const int iy = iy0[n] + y * dil, ix = ix0[n] + x * dil;
+                const bool ok = live[n] && y < ksize && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                toff[n] = ok ? (unsigned)(((img0[n] + iy * W + ix) * in_stride + kg * 8) * 4) : 0xfffffff0u;
+            }
+        };
+        if constexpr (ALIGNED) tap_offsets(0);
+        f32x4 wr[P][CW], xa[P][PT], xb[P][PT];
+        auto issue = [&](int kb, f32x4 (&fw)[CW], f32x4 (&fa)[PT], f32x4 (&fb)[PT]) {
+            const int kbc = kb < n_kb ? kb : n_kb - 1;  // past the end: the last block again (never staged)
+#pragma unroll
+            for (int r = 0; r < CW; ++r) fw[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, woff[r], kbc * 2048, 0));
+            if constexpr (ALIGNED) {
+                const unsigned step = (unsigned)cgb_s * 128u;
+#pragma unroll
+                for (int n = 0; n < PT; ++n) {
+                    const bool ok = toff[n] != 0xfffffff0u;
+                    const unsigned off = ok ? toff[n] + step : 0xfffffff0u;
+                    fa[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+                    fb[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off + 16u : 0xfffffff0u, 0, 0));
+                }
+                if (++cgb_s == n_cgb) {
+                    cgb_s = 0;
+                    tap_offsets(++tap_s);
+                }
+            } else {
+                const int dy = ty * dil, dx = tx * dil;
+                const bool in_range = kb < n_kb;
+#pragma unroll
+                for (int n = 0; n < PT; ++n) {
+                    const int iy = iy0[n] + dy, ix = ix0[n] + dx;
+                    const bool ok = in_range && live[n] && ty < ksize && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                    const unsigned off = ok ? (unsigned)(((img0[n] + iy * W + ix) * in_stride + cg * 8) * 4) : 0xfffffff0u;
+                    fa[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+                    fb[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off + 16u : 0xfffffff0u, 0, 0));
+                }
+                cg += 4;
+                while (cg >= c8) {
+                    cg -= c8;
+                    if (++tx == ksize) {
+                        tx = 0;
+                        ++ty;
+                    }
+                }
+            }
+        };
+        auto stage = [&](int st, const f32x4 (&fw)[CW], const f32x4 (&fa)[PT], const f32x4 (&fb)[PT]) {
+#pragma unroll
+            for (int r = 0; r < CW; ++r) {
+                const int c = pw * CW + r;
+                As[st][c >> 1][c & 1][lane] = fw[r];
+            }
+#pragma unroll
+            for (int n = 0; n < PT; ++n) {
+                f16x8 xh, xl;
+                split8(fa[n], fb[n], xh, xl);
+                Bs[st][pw * PT + n][0][lane] = __builtin_bit_cast(f32x4, xh);
+                Bs[st][pw * PT + n][1][lane] = __builtin_bit_cast(f32x4, xl);
+            }
+        };
+        constexpr int kOps = CW + 2 * PT;  // memory operations of one K block of a producer wave
+#pragma unroll
+        for (int q = 0; q < P; ++q) issue(q, wr[q], xa[q], xb[q]);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * kOps) : "memory");
+        stage(0, wr[0], xa[0], xb[0]);
+        issue(P, wr[0], xa[0], xb[0]);
+        __syncthreads();  // stage 0 is complete
+        // at iteration i: K blocks i + 1 .. i + P are in flight, block j in register slot j % P; block i + 1 goes into stage (i + 1) & 1
+        const int rounds = (n_kb + 2 * P - 1) / (2 * P);
+        for (int r = 0; r < rounds; ++r) {
+#pragma unroll
+            for (int u = 0; u < 2 * P; ++u) {  // (2 P: a common period of the LDS stage and the register slot)
+                const int i = r * 2 * P + u;
+                if (i >= n_kb) break;  // (uniform; only in the last round)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * kOps) : "memory");  // block i + 1 has landed
+                if (i + 1 < n_kb) stage((u + 1) & 1, wr[(u + 1) % P], xa[(u + 1) % P], xb[(u + 1) % P]);
+                issue(i + 1 + P, wr[(u + 1) % P], xa[(u + 1) % P], xb[(u + 1) % P]);
+                __syncthreads();  // stage (i + 1) & 1 is complete; the consumers are done with stage i & 1
+            }
+        }
+        return;
+    }
+
+    // ---------------- consumer ----------------
+    const int wm = wave % WM, wn = wave / WM;
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ctw = ct0 + wm * MT, ptw = pt0 + wn * NT;  // this wave's accumulator tiles
+    __syncthreads();  // stage 0 is complete
+    for (int i = 0; i < n_kb; ++i) {
+        const int st = i & 1;
+        f32x4 bh[NT], bl[NT], ah[2], al[2];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            bh[n] = Bs[st][wn * NT + n][0][lane];
+            bl[n] = Bs[st][wn * NT + n][1][lane];
+        }
+        ah[0] = As[st][wm * MT][0][lane];
+        al[0] = As[st][wm * MT][1][lane];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (m + 1 < MT) {  // the next channel tile's weight fragments while this one's MFMAs run
+                ah[(m + 1) & 1] = As[st][wm * MT + m + 1][0][lane];
+                al[(m + 1) & 1] = As[st][wm * MT + m + 1][1][lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                acc[m][n] = mfma3(ah[m & 1], al[m & 1], __builtin_bit_cast(f16x8, bh[n]), __builtin_bit_cast(f16x8, bl[n]), acc[m][n]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();  // the other stage is complete for the next K block; nobody reads this one any more
+    }
+    const int n_pix = a.B * a.Ho * a.Wo;
+    if (ctw >= n_ct || ptw * 16 >= n_pix) return;
+    f32x4 rvs[MT], bvs[MT];
+    seg_vectors<MT>(a, ctw, kg, rvs, bvs);
+    seg_epilogue<MT, NT, DROP>(a, acc, ctw, ptw, n_pix, col, kg, rvs, bvs);
+}
+
 inline float pow2_row_scale(float row_max)
 {
     if (!(row_max > 0.0f) || !std::isfinite(row_max)) return 1.0f;
@@ -1129,6 +1315,14 @@ int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
         const long b44 = (long)((a.n_ct + 7) / 8) * ((n_pt + 7) / 8) * n, b22 = (long)((a.n_ct + 3) / 4) * ((n_pt + 3) / 4) * n;
         bool aligned = true;  // every member's channel groups come in fours: the scalar tap walk
         for (int i = 0; i < n; ++i) aligned = aligned && (g.a[i].c8 % 4) == 0;
+#define OJF_WS_LAUNCH(MT_, NT_, GRID_)                                                                                                \
+    do {                                                                                                                             \
+        const dim3 grid__ = GRID_;                                                                                                   \
+        if (drop_any && aligned) hipLaunchKernelGGL((segconv_ws_kernel<MT_, NT_, true, true>), grid__, dim3(512), 0, st, g);          \
+        else if (drop_any) hipLaunchKernelGGL((segconv_ws_kernel<MT_, NT_, true, false>), grid__, dim3(512), 0, st, g);               \
+        else if (aligned) hipLaunchKernelGGL((segconv_ws_kernel<MT_, NT_, false, true>), grid__, dim3(512), 0, st, g);                \
+        else hipLaunchKernelGGL((segconv_ws_kernel<MT_, NT_, false, false>), grid__, dim3(512), 0, st, g);                            \
+    } while (0)
 #define OJF_GEMM_LAUNCH(MT_, NT_, WM_, GRID_)                                                                                         \
     do {                                                                                                                             \
         const dim3 grid__ = GRID_;                                                                                                   \
@@ -1171,6 +1365,15 @@ int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
                 const Shape &sh = menu[best];
                 variant = sh.name;
                 const dim3 grid(seg_map(g.map, (n_pt + sh.b - 1) / sh.b, (a.n_ct + sh.a - 1) / sh.a, n));
+                static const int ws = getenv("OJF_SEG_WS") ? atoi(getenv("OJF_SEG_WS")) : 0;  // producer / consumer form (round 6)
+                if (ws && best <= 1) {
+                    variant = best ? "ws 128x128" : "ws 64x64";
+                    if (best) OJF_WS_LAUNCH(4, 4, grid); else OJF_WS_LAUNCH(2, 2, grid);
+                    if (trace)
+                        fprintf(stderr, "segconv %-12s n %d  c_in %4d c_out %4d k %d  in %3dx%3d  n_kb %4d  grid %dx%dx%d\n", variant, n, a.c8 * 8, a.c_out, a.ksize,
+                                a.H, a.W, a.n_kb, g.map.X, g.map.Y, g.map.Z);
+                    return check_hip(hipGetLastError(), "segconv_ws_kernel launch");
+                }
                 switch (best) {
                 case 0: OJF_GEMM_LAUNCH(2, 2, 2, grid); break;
                 case 1: OJF_GEMM_LAUNCH(4, 4, 2, grid); break;

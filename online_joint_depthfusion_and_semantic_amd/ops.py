@@ -148,6 +148,78 @@ def integrate(depth_filtered, Ki, E, origin, resolution, est, tsdf, weights, wor
     _lib.check(rc, 'ojf_integrate')
 
 
+def extract_many(jobs, n_points=9, pad_value=-0.1):
+    """One frame of each of several SCENES as a single launch (ojf_extract_many).  ``jobs``: dicts with depth (cuda f32 [h, w]),
+    Ki, E (camera_arrays), origin, resolution, tsdf, weights and either ``engine`` (a FusionNetEngine with ``fused_input``: the
+    results land in its input planes) or ``out_values`` / ``out_weights`` sample planes [n_points, h*w].  Bit for bit what the
+    separate ``extract`` / ``extract_to_net`` calls write."""
+    lib = _lib.load()
+    n = len(jobs)
+    assert 1 <= n <= _lib.MAX_SCENES
+    h, w = jobs[0]['depth'].shape
+    X, Y, Z = _vol16(jobs[0]['tsdf']).shape
+    arr = (_lib.ExtractJob * n)()
+    keep = []
+    for a, j in zip(arr, jobs):
+        depth = j['depth']
+        assert depth.is_cuda and depth.dtype == torch.float32 and depth.is_contiguous() and tuple(depth.shape) == (h, w)
+        assert _vol16(j['tsdf']).shape == (X, Y, Z) and _vol16(j['weights']).shape == (X, Y, Z)
+        origin = _origin_array(j['origin'])
+        keep += [origin, j['Ki'], j['E']]
+        a.depth_dev, a.Kinv_host, a.E_host, a.origin_host = _lib.ptr(depth), _lib.ptr(j['Ki']), _lib.ptr(j['E']), _lib.ptr(origin)
+        a.resolution = float(j['resolution'])
+        a.tsdf_dev, a.weights_dev = _lib.ptr(j['tsdf']), _lib.ptr(j['weights'])
+        eng = j.get('engine')
+        if eng is not None:
+            assert eng.fused_input and int(eng.n_points) == n_points
+            a.net = eng.handle
+        else:
+            ov, ow = j['out_values'], j['out_weights']
+            assert ov.is_cuda and ov.dtype == torch.float32 and ov.is_contiguous() and tuple(ov.shape) == (n_points, h * w) == tuple(ow.shape)
+            a.out_values_dev, a.out_weights_dev, a.out_stride, a.out_layout = _lib.ptr(ov), _lib.ptr(ow), h * w, 1
+    rc = lib.ojf_extract_many(n, arr, X, Y, Z, h, w, int(n_points), float(pad_value), _lib.stream_ptr(jobs[0]['depth'].device))
+    _lib.check(rc, 'ojf_extract_many')
+
+
+def integrate_many(jobs, n_points=9, n_tail=7, trunc=0.1):
+    """One frame of each of several SCENES through ojf_integrate_masked's FAST kernels as two launches (ojf_integrate_many).
+    ``jobs``: dicts with depth, mask (or None), Ki, E, origin, resolution, est (rows [h*w, stride]), tsdf, weights, workspace (an
+    IntegrateWorkspace of its own per job) and optionally sem_ids, sem_scores, id_vol, score_vol (all jobs or none).  The
+    volumes come out bit for bit as from the separate ``integrate`` calls."""
+    lib = _lib.load()
+    n = len(jobs)
+    assert 1 <= n <= _lib.MAX_SCENES
+    h, w = jobs[0]['depth'].shape
+    X, Y, Z = _vol16(jobs[0]['tsdf']).shape
+    arr = (_lib.IntegrateJob * n)()
+    keep = []
+    for a, j in zip(arr, jobs):
+        depth, est, ws = j['depth'], j['est'], j['workspace']
+        assert depth.is_cuda and depth.dtype == torch.float32 and depth.is_contiguous() and tuple(depth.shape) == (h, w)
+        assert est.is_cuda and est.dtype == torch.float32 and est.is_contiguous()
+        assert _vol16(j['tsdf']).shape == (X, Y, Z) and _vol16(j['weights']).shape == (X, Y, Z)
+        assert ws.key == ((X, Y, Z), h, w, n_tail, MODE_FAST), 'workspace built for another configuration'
+        mask = j.get('mask')
+        if mask is not None:
+            assert mask.is_cuda and mask.dtype == torch.bool and mask.is_contiguous() and mask.numel() == h * w
+        origin = _origin_array(j['origin'])
+        keep += [origin, j['Ki'], j['E']]
+        a.depth_dev, a.mask_dev = _lib.ptr(depth), _lib.ptr(mask)
+        a.Kinv_host, a.E_host, a.origin_host, a.resolution = _lib.ptr(j['Ki']), _lib.ptr(j['E']), _lib.ptr(origin), float(j['resolution'])
+        a.est_dev, a.est_stride = _lib.ptr(est), int(est.shape[-1])
+        a.tsdf_dev, a.weights_dev = _lib.ptr(j['tsdf']), _lib.ptr(j['weights'])
+        if j.get('sem_ids') is not None:
+            ids, sc, iv, sv = j['sem_ids'], j['sem_scores'], j['id_vol'], j['score_vol']
+            assert ids.dtype == torch.uint8 and ids.is_contiguous() and ids.numel() == h * w
+            assert sc.dtype == torch.float32 and sc.is_contiguous() and sc.numel() == h * w
+            assert iv.dtype == torch.uint8 and iv.is_contiguous() and iv.shape == j['tsdf'].shape
+            assert sv.dtype == torch.float16 and sv.is_contiguous() and sv.shape == j['tsdf'].shape
+            a.sem_ids_dev, a.sem_scores_dev, a.id_vol_dev, a.score_vol_dev = _lib.ptr(ids), _lib.ptr(sc), _lib.ptr(iv), _lib.ptr(sv)
+        a.workspace_dev, a.workspace_bytes = _lib.ptr(ws.buf), ws.bytes
+    rc = lib.ojf_integrate_many(n, arr, int(n_points), int(n_tail), float(trunc), X, Y, Z, h, w, _lib.stream_ptr(jobs[0]['depth'].device))
+    _lib.check(rc, 'ojf_integrate_many')
+
+
 class EntryWorkspace:
     """FAST-mode scratch for ``integrate_entries``: header + 4 B/voxel head table + one 32-B record per entry
     + touched list (layout of csrc/ojf_integrate.hip)."""

@@ -660,6 +660,10 @@ class Pipeline(torch.nn.Module):
             for b in batches:
                 self._fuse_guarded(b, database, recover=recover)
             return
+        if len(batches) > _lib.MAX_SCENES:  # (the launches take up to MAX_SCENES scenes: larger calls go in groups)
+            for i in range(0, len(batches), _lib.MAX_SCENES):
+                self.fuse_many(batches[i:i + _lib.MAX_SCENES], database, device)
+            return
         main = torch.cuda.current_stream(self.device)
         sems = self._frame_semantics_many(batches)  # (None, None) without semantics; predict: ONE batched pass, this stream
         fp = self._weights_fingerprint()
@@ -668,15 +672,19 @@ class Pipeline(torch.nn.Module):
             streams.append(self._side_stream([main] + streams))  # (a stream that runs beside the caller's and the other slots')
         enqueued = 0
         try:
-            for i, (b, sem) in enumerate(zip(batches, sems)):
-                if i == 0:
-                    self._fuse_frame(b, database, 0, sem, fp)
-                else:
-                    st = streams[i - 1]
-                    st.wait_stream(main)  # (the frame tensors and the labels were produced on the current stream)
-                    with torch.cuda.stream(st):
-                        self._fuse_frame(b, database, i, sem, fp)
-                enqueued = i + 1
+            if self._integrate_mode == MODE_FAST and self.config.SETTINGS.get('fuse_many_launches', 'joint') == 'joint':
+                self._fuse_many_joint(batches, database, sems, fp, main, streams)
+                enqueued = len(batches)
+            else:  # PARITY integrate (its sort is per scene) / A-B switch: every slot runs fuse()'s own launches on its stream
+                for i, (b, sem) in enumerate(zip(batches, sems)):
+                    if i == 0:
+                        self._fuse_frame(b, database, 0, sem, fp)
+                    else:
+                        st = streams[i - 1]
+                        st.wait_stream(main)  # (the frame tensors and the labels were produced on the current stream)
+                        with torch.cuda.stream(st):
+                            self._fuse_frame(b, database, i, sem, fp)
+                    enqueued = i + 1
         except _lib.OjfError as err:
             for st in streams[:len(batches) - 1]:
                 main.wait_stream(st)
@@ -695,6 +703,67 @@ class Pipeline(torch.nn.Module):
         if recover:
             for b in batches:
                 self._guard_remember(b, database)
+
+    def _fuse_many_joint(self, batches, database, sems, fp, main, streams):
+        """fuse_many's frame steps with the gather and the scatter of ALL scenes as single launches (round 6):
+
+            ops.extract_many     one launch, blockIdx.y = scene       caller's stream
+            S fusion nets        slot i on its own stream, forked from / joined to the caller's (as before)
+            ops.integrate_many   accumulate + finalize of all scenes  caller's stream
+
+        extract / accumulate / finalize are one round of blocks that each walk a chain of dependent steps (DESIGN.md 5.0c:
+        0.017 of the HBM roofline, 70 % parked): S scenes in ONE launch share the ramp and keep the CUs busy while other
+        blocks wait, which S launches on S streams do not.  Per scene the same blocks run the same code as in ``fuse``: the
+        volumes come out bit for bit the same.  Raises (the poll below, a net's forward call) before ANY integrate launch of
+        the call has been enqueued: none of the call's frames is among the skipped ones."""
+        if _lib.load().ojf_guard_poll():
+            raise _lib.OjfError('Pipeline.fuse_many: the split-fp16 range guard is set (fp16 range exceeded in a network pass since '
+                                'the last check()): the integrate calls skip until check() has reported it')
+        P, n_tail = self.n_points, self.config.FUSION_MODEL.n_tail_points
+        use_sem, sem = self.config.FUSION_MODEL.use_semantics, bool(self.config.DATA.semantics)
+        prep = []
+        for i, (b, (sem_ids, scores)) in enumerate(zip(batches, sems)):
+            self._shape = b['image'].shape
+            frame, mask = self._frames(b, filtered=False)
+            h, w = frame.shape
+            scene_id = b['frame_id'][0].split('/')[0]
+            volume = database[scene_id]
+            Ki, E = ops.camera_arrays(b['intrinsics'][0], b['extrinsics'][0])
+            sl = self._get_slot(h, w, self.device, i, fp)
+            ws = self._get_workspace(volume['current'].shape, h, w, self.device, i)
+            prep.append(dict(scene=scene_id, frame=frame, mask=mask, volume=volume, Ki=Ki, E=E, slot=sl, ws=ws, sem_ids=sem_ids, scores=scores))
+        if len({(p['frame'].shape, p['volume']['current'].shape) for p in prep}) != 1:
+            raise ValueError('Pipeline.fuse_many: one frame size and one grid size per call')
+        fused = prep[0]['slot'].engine.fused_input
+        self._mark(first=True)  # (profile: four events per CALL - gather of all scenes | nets | scatter of all scenes)
+        ops.extract_many([dict(depth=p['frame'], Ki=p['Ki'], E=p['E'], origin=p['volume']['origin'], resolution=p['volume']['resolution'],
+                               tsdf=p['volume']['current'], weights=p['volume']['weights'],
+                               **(dict(engine=p['slot'].engine) if fused else dict(out_values=p['slot'].fv, out_weights=p['slot'].fw)))
+                          for p in prep], n_points=P)
+        self._mark()
+        for i, p in enumerate(prep):
+            sl = p['slot']
+            if i:
+                streams[i - 1].wait_stream(main)
+            with torch.cuda.stream(streams[i - 1] if i else main):
+                if not fused:
+                    sl.engine.prepare_input(sl.fv, sl.fw, p['frame'], p['sem_ids'] if use_sem else None, self.n_classes if use_sem else 0, planes=True)
+                sl.engine.forward(sl.est)
+        for st in streams[:len(prep) - 1]:
+            main.wait_stream(st)
+        self._mark()
+        ops.integrate_many([dict(depth=p['frame'], mask=p['mask'], Ki=p['Ki'], E=p['E'], origin=p['volume']['origin'],
+                                 resolution=p['volume']['resolution'], est=p['slot'].est, tsdf=p['volume']['current'],
+                                 weights=p['volume']['weights'], workspace=p['ws'],
+                                 **(dict(sem_ids=p['sem_ids'], sem_scores=p['scores'], id_vol=p['volume']['ids_est'],
+                                         score_vol=p['volume']['scores']) if sem else {}))
+                            for p in prep], n_points=P, n_tail=n_tail, trunc=self.config.DATA.init_value)
+        self._mark()
+        self._frames_fused += len(prep) - 1  # (the first mark counted one)
+        for p in prep:
+            database.state[p['scene']] = True  # volumes were updated in place (pipeline.py:239-244)
+            database.scenes_est[p['scene']].volume = p['volume']['current']
+            database.fusion_weights[p['scene']] = p['volume']['weights']
 
     def _training_forward(self, inputs):
         """The net forward of pipeline.py:322 with a graph for ``loss.backward()``: on the libojf training kernels

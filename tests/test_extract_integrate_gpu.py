@@ -476,3 +476,67 @@ def test_fast_integrate_inside_a_graph(cuda):
     # (the capture itself does not execute: side 0 ran 1 + 3 times, side 1 ran 1 + 3 times)
     for key in ('tsdf', 'wgt'):
         assert n_mismatch(vols[0][key].cpu().numpy(), vols[1][key].cpu().numpy()) == 0, key
+
+
+# ---- round 6: the frames of several scenes as single launches (ojf_extract_many / ojf_integrate_many) -----------------------
+@pytest.mark.parametrize('semantics', [False, True])
+@pytest.mark.parametrize('h,w,grid,S', [(60, 80, 64, 3), (13, 15, 32, 2), (240, 320, 128, 4), (48, 64, 64, 8)])
+def test_many_scene_launches_equal_the_separate_calls(cuda, h, w, grid, S, semantics):
+    """modules/extractor.py:24-79 / modules/integrator.py:15-124 for S scenes per launch (blockIdx.y = scene): sample planes,
+    TSDF / weight / id / score volumes bit for bit those of S separate ojf_extract / ojf_integrate_masked calls, over three
+    frames per scene from different pre-frame states (scene s starts s frames into its stream), with masks."""
+    n_tail = 7
+    streams = [make_stream(h, w, grid, scene='room_%d' % s, seed=1911 + 17 * s) for s in range(S)]
+    one = [to_cuda(fresh_volumes(grid, semantics), cuda) for _ in range(S)]
+    many = [to_cuda(fresh_volumes(grid, semantics), cuda) for _ in range(S)]
+    ws_one = ops.IntegrateWorkspace((grid,) * 3, h, w, n_tail, ops.MODE_FAST, cuda)
+    ws_many = [ops.IntegrateWorkspace((grid,) * 3, h, w, n_tail, ops.MODE_FAST, cuda) for _ in range(S)]
+    for step in range(3):
+        fis = [frame_inputs(st, step + s) for s, st in enumerate(streams)]
+        depth = [_t(fi['depth'], cuda) for fi in fis]
+        mask = [_t(fi['fd'] != 0, cuda) for fi in fis]
+        est = [_t(fi['est'], cuda) for fi in fis]
+        ids = [_t(fi['sem_ids'].reshape(-1), cuda) for fi in fis]
+        sc = [_t(fi['sem_scores'].reshape(-1), cuda) for fi in fis]
+        # gather
+        ref = [ops.extract(depth[s], fis[s]['Ki'], fis[s]['E'], streams[s].origin, streams[s].resolution, one[s]['tsdf'], one[s]['wgt'], planes=True)
+               for s in range(S)]
+        outs = [(torch.empty((9, h * w), device=cuda), torch.empty((9, h * w), device=cuda)) for _ in range(S)]
+        ops.extract_many([dict(depth=depth[s], Ki=fis[s]['Ki'], E=fis[s]['E'], origin=streams[s].origin, resolution=streams[s].resolution,
+                               tsdf=many[s]['tsdf'], weights=many[s]['wgt'], out_values=outs[s][0], out_weights=outs[s][1]) for s in range(S)])
+        for s in range(S):
+            assert torch.equal(ref[s]['fusion_values'].view(torch.int32), outs[s][0].view(torch.int32)), (step, s)
+            assert torch.equal(ref[s]['fusion_weights'].view(torch.int32), outs[s][1].view(torch.int32)), (step, s)
+        # scatter
+        for s in range(S):
+            kw = dict(sem_ids=ids[s], sem_scores=sc[s], id_vol=one[s]['ids'], score_vol=one[s]['scores']) if semantics else {}
+            ops.integrate(depth[s], fis[s]['Ki'], fis[s]['E'], streams[s].origin, streams[s].resolution, est[s], one[s]['tsdf'], one[s]['wgt'],
+                          ws_one, n_tail=n_tail, mask=mask[s], **kw)
+        ops.integrate_many([dict(depth=depth[s], mask=mask[s], Ki=fis[s]['Ki'], E=fis[s]['E'], origin=streams[s].origin,
+                                 resolution=streams[s].resolution, est=est[s], tsdf=many[s]['tsdf'], weights=many[s]['wgt'], workspace=ws_many[s],
+                                 **(dict(sem_ids=ids[s], sem_scores=sc[s], id_vol=many[s]['ids'], score_vol=many[s]['scores']) if semantics else {}))
+                            for s in range(S)], n_tail=n_tail)
+        for s in range(S):
+            for k in one[s]:
+                a, b = one[s][k], many[s][k]
+                assert torch.equal(a.view(torch.uint8), b.view(torch.uint8)), (step, s, k)
+    assert float((many[0]['wgt'].float() > 0).sum()) > 100
+    assert not torch.equal(many[0]['wgt'], many[1]['wgt'])  # (the scenes differ)
+
+
+def test_many_scene_launches_refuse_shared_state(cuda):
+    from online_joint_depthfusion_and_semantic_amd import _lib
+    h, w, grid = 24, 32, 32
+    st = make_stream(h, w, grid)
+    fi = frame_inputs(st, 0)
+    v = to_cuda(fresh_volumes(grid, False), cuda)
+    ws = ops.IntegrateWorkspace((grid,) * 3, h, w, 7, ops.MODE_FAST, cuda)
+    job = dict(depth=_t(fi['depth'], cuda), mask=None, Ki=fi['Ki'], E=fi['E'], origin=st.origin, resolution=st.resolution,
+               est=_t(fi['est'], cuda), tsdf=v['tsdf'], weights=v['wgt'], workspace=ws)
+    with pytest.raises(_lib.OjfError, match='share'):
+        ops.integrate_many([job, dict(job)])
+    out = torch.empty((9, h * w), device=cuda)
+    ej = dict(depth=job['depth'], Ki=fi['Ki'], E=fi['E'], origin=st.origin, resolution=st.resolution, tsdf=v['tsdf'], weights=v['wgt'],
+              out_values=out, out_weights=torch.empty_like(out))
+    with pytest.raises(_lib.OjfError, match='same output'):
+        ops.extract_many([ej, dict(ej)])
