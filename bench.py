@@ -570,8 +570,15 @@ class TrainCase:
                                  'intrinsics': torch.from_numpy(f['intrinsics']).unsqueeze(0)})
         self.reduce_events = []
         self.loss_sum = None
+        # A/B switch.  Measured (round 6, profiles/r06_train_host.txt): announcing does not move the step on the boxes seen (211 against 214
+        # frames/s): the host's enqueue time under a busy queue, not the wait for the count, is what paces it - off by default
+        self.announce = os.environ.get('OJF_BENCH_ANNOUNCE', '0') not in ('', '0')
 
     def step(self, i):
+        # (what drivers.train_fusion does: the next frame is announced, so that its valid-ray count - the frame step's one host
+        # read - is requested a frame ahead and the host is never tied to the device inside a frame)
+        if self.announce:
+            self.pipe.announce_training_frame(self.batches[(i + 1) % len(self.batches)], self.dev)
         out = self.pipe.fuse_training(self.batches[i % len(self.batches)], self.db, self.dev)
         if out['tsdf_fused'].shape[1]:
             loss = self.crit.forward(out['tsdf_fused'], out['tsdf_target'])

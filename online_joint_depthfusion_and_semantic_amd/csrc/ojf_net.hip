@@ -169,7 +169,26 @@ struct ConvArgs {
     const float *dscale;  // training backward-data: the input carries a power-of-two factor *dscale - the result is divided by it; NULL = off
     unsigned w_magic, c4_magic;  // ceil(2^32 / w), ceil(2^32 / c4): x / d == umulhi(x, magic) while x * d < 2^32 (0: divide)
     int in_split = 0, out_split = 0;  // split-fp16 launches: the input / output planes are split planes (split_pack4)
+    // Banded split-fp16 3x3 launches with dilation r > 1 (round 6): the rows of the image are handed to the blocks in the order
+    // (y mod r, y div r) instead of y.  An XCD's band of 30 rows of a 240-row frame then holds rows that are r apart - the
+    // very rows its taps read - instead of 30 neighbours whose taps reach 27 rows into both neighbouring bands: with plain
+    // bands every private L2 pulled (30 + 2 r) / 30 of its share through the fabric (2.8x for r = 27, 1.6x for r = 9: the
+    // grouped launch fetched 40 MB for a 24.6-MB input, profiles/r05_final_traffic_pmc.txt); in class order the halo is one
+    // row on either side of the band.  Which block computes which pixels changes, nothing else: the same bits.
+    int row_perm = 0, perm_q = 0, perm_rem = 0;  // r (0: off), h / r, h % r
 };
+
+// position `pr` of the row order (y mod r, y div r) -> row y; classes c < h % r have h / r + 1 rows, the others h / r
+__device__ __forceinline__ int perm_row(int pr, int r, int q, int rem)
+{
+    const int big = rem * (q + 1);
+    if (pr < big) {
+        const int c = pr / (q + 1);
+        return c + (pr - c * (q + 1)) * r;
+    }
+    const int p2 = pr - big, c = p2 / q;
+    return rem + c + (p2 - c * q) * r;
+}
 
 __device__ __forceinline__ int fast_div(int x, int d, unsigned magic) { return magic ? (int)__umulhi((unsigned)x, magic) : x / d; }
 
@@ -346,6 +365,11 @@ __device__ __forceinline__ void build_tap_table16(int2 *tab, const ConvArgs &a, 
 struct ConvGroup {
     ConvArgs g[4];  // independent convolutions of identical tile shape run as one launch (blockIdx.y)
     int nblocks;    // XCD-banded launches: pixel blocks of the image (gridDim.x is that rounded up to 8); 0 = plain order
+    // PERSISTENT split-fp16 launches (round 6; layers whose whole packed weights are ONE LDS chunk: the grouped 19 -> 19 3x3): a
+    // block walks `band` = round_up(nblocks, 8) / 8 logical pixel blocks of ITS XCD's band in steps of gridDim.x / 8 and
+    // copies the tap table and the 24 KB of weights ONCE - with one pixel block per launch block every 128 pixels (10 KB of
+    // input) paid a 24-KB weight copy, a table build and three barriers, 2400 times per branch and launch.  0 = off.
+    int band = 0;
 };
 
 // (xcd_band_block / banded_block_x: ojf_common.h)
@@ -551,19 +575,42 @@ constexpr int conv16_chunk(int nt) { return nt <= 2 ? 6 : 3; }  // supersteps pe
 // 4 = no MFMA, 8 = no fp16 split.  Product launches always use ABL = 0.
 // INS: the input planes are split planes (every convolution of the launch: the host checks)
 template <int MT, int NT, bool SKIP = true, int ABL = 0, bool LEAN = false, bool INS = false>
-__global__ __launch_bounds__(256) void conv_f16x3_kernel(const ConvGroup grp)
+#ifndef OJF_CONV_LB
+#define OJF_CONV_LB 1
+#endif
+// (the lean grouped 3x3 form keeps four waves per SIMD - 128 registers - now that its blocks are persistent: the pixel-block loop costs
+// 12 registers, which without the bound dropped it to three; OJF_CONV_LB=0 builds the unbounded form for A/B runs)
+__global__ __launch_bounds__(256, (OJF_CONV_LB && MT == 2 && NT == 2 && LEAN) ? 4 : 1) void conv_f16x3_kernel(const ConvGroup grp)
 {
     constexpr int CS = conv16_chunk(NT);
     const ConvArgs &a = grp.g[blockIdx.y];
-    const int sb = grp.nblocks ? xcd_band_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    const bool persist = grp.band != 0;  // (uniform)
+    int sb = grp.nblocks ? xcd_band_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    int sb_end = sb + 1, sb_step = 1;
+    if (persist) {  // block j of XCD x walks positions j, j + P, j + 2 P .. of the XCD's band [x band, (x + 1) band)
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        sb = x * grp.band + j;
+        sb_end = (x + 1) * grp.band;
+        sb_step = (int)(gridDim.x >> 3);
+    }
     if (grp.nblocks && sb >= grp.nblocks) return;  // padding block of a banded launch
     extern __shared__ int2 tab[];  // (nsteps + kPad16) * 8 entries, sized by the launch: LDS per block bounds the waves in flight
     __shared__ f32x4 wl[CS * NT * 128];
     build_tap_table16(tab, a, (a.nsteps + kPad16) * 8);
+    if (persist) {  // the layer's weights are one chunk (the host checks): copied once for all of the block's pixel blocks
+#pragma unroll
+        for (int i = 0; i < CS * NT * 128 / 256; ++i) wl[i * 256 + threadIdx.x] = a.wp[i * 256 + threadIdx.x];
+    }
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
-    const int strip = (sb * 4 + wave) * (MT * 16);  // waves past the image still take part in the barriers
+    __syncthreads();  // tap table (and the persistent form's weights)
+    for (; sb < sb_end && (!grp.nblocks || sb < grp.nblocks); sb += sb_step) {
+    int strip = (sb * 4 + wave) * (MT * 16);  // waves past the image still take part in the barriers
+    if (a.row_perm) {  // (the host sets it only when w is a multiple of MT * 16: a wave's pixel tiles lie in one row)
+        const int pr = fast_div(strip, a.w, a.w_magic);
+        if (pr < a.h) strip = perm_row(pr, a.row_perm, a.perm_q, a.perm_rem) * a.w + (strip - pr * a.w);
+    }
 
     // vm: bit t set <=> tap t of this lane's pixel lies inside the image (bit 0 only for 1x1); p16: byte offset
     int p16[MT];
@@ -666,12 +713,11 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const ConvGroup grp)
         }
     };
 
-    __syncthreads();  // tap table
     f32x4 xa0[MT], xb0[MT], xa1[MT], xb1[MT], xa2[MT], xb2[MT];
     bool v0, v1, v2;
     fetch(xa0, xb0, tab4[0], v0);
     fetch(xa1, xb1, tab4[4], v1);
-    int sl = CS;
+    int sl = persist ? 0 : CS;
     for (int S = 0; S < a.nsteps; S += 3) {
         // the three table reads of this iteration are issued together (one LDS latency instead of three)
         const int4 t2 = tab4[(S + 2) * 4], t3 = tab4[(S + 3) * 4], t4 = tab4[(S + 4) * 4];
@@ -702,6 +748,7 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(const ConvGroup grp)
     }
     if constexpr (LEAN) conv_epilogue_lean<MT, NT>(a, acc, strip, i16, g, bvec, rvec);
     else conv_epilogue<MT, NT, true>(a, acc, strip, i16, g, bvec, rvec);
+    }  // (pixel blocks of a persistent block)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2302,6 +2349,27 @@ static int launch_conv_args(const ConvArgs *args, int n, int nt, hipStream_t st,
     if (arith == OJF_ARITH_F16X3 && !no_band && grid.x >= 64) {
         grp.nblocks = (int)grid.x;
         grid16.x = round_up((int)grid.x, 8);
+    }
+    static const bool no_perm = getenv("OJF_CONV_ROW_PERM") && atoi(getenv("OJF_CONV_ROW_PERM")) == 0;  // A/B switch
+    if (grp.nblocks && !no_perm)
+        for (int i = 0; i < n; ++i) {
+            ConvArgs &g = grp.g[i];
+            if (g.taps == 9 && g.dil > 1 && g.dil < g.h && g.w % (mt * 16) == 0) {
+                g.row_perm = g.dil; g.perm_q = g.h / g.dil; g.perm_rem = g.h % g.dil;
+            }
+        }
+    // persistent blocks for single-chunk layers (ConvGroup::band): `bpc` blocks per CU over all members of the group
+    static const int persist_bpc = getenv("OJF_CONV_PERSIST") ? atoi(getenv("OJF_CONV_PERSIST")) : 4;  // A/B switch (0: one pixel block per launch block)
+    if (grp.nblocks && persist_bpc > 0 && arith == OJF_ARITH_F16X3) {
+        bool single = true;
+        for (int i = 0; i < n; ++i) single = single && args[i].nsteps <= conv16_chunk(nt);
+        const int cus = device_cu_count();
+        const int n8 = round_up(grp.nblocks, 8);
+        int G = cus > 0 ? (cus * persist_bpc / n) / 8 * 8 : 0;
+        if (single && G >= 8 && G < n8) {
+            grp.band = n8 / 8;
+            grid16.x = (unsigned)G;
+        }
     }
     static const bool no_lean = getenv("OJF_CONV_LEAN") && atoi(getenv("OJF_CONV_LEAN")) == 0;  // A/B switch
     bool lean = arith == OJF_ARITH_F16X3 && !no_lean;

@@ -36,8 +36,12 @@ def weights_init(m):
 def _host_pose_batch(batch, device):
     """transform.to_device (utils/transform.py:33-37) for everything but the poses, which are kernel
     arguments and stay on the host."""
-    return {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) and k not in ('extrinsics', 'intrinsics') else v)
-            for k, v in batch.items()}
+    if batch.get('_ojf_on_device') == str(device):  # (idempotent: the training loop prepares a batch once and announces THAT object)
+        return batch
+    out = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) and k not in ('extrinsics', 'intrinsics') else v)
+           for k, v in batch.items()}
+    out['_ojf_on_device'] = str(device)
+    return out
 
 
 def _loader(dataset, scenes, shuffle=False):
@@ -314,8 +318,16 @@ def train_fusion(config, dataset, device, rank=0, world=1, max_steps=None, log=p
         loader = _loader(dataset, shard.scenes)
         n_steps = int(_agree(len(loader), 'max'))  # the common step count of this epoch
         frames = iter(loader)
+        ahead = next(frames, None)
         for i in range(n_steps):
-            batch = next(frames, None)
+            batch, ahead = ahead, next(frames, None)
+            if batch is not None:
+                batch = _host_pose_batch(batch, device)
+            if (ahead is not None and config.SETTINGS.get('announce_frames', False) and torch.all(torch.isfinite(ahead['extrinsics']))
+                    and hasattr(pipeline, 'announce_training_frame')):
+                # one frame of look-ahead for the ONE host read of the frame step (Pipeline.announce_training_frame)
+                ahead = _host_pose_batch(ahead, device)
+                pipeline.announce_training_frame(ahead, device)
             boundary = (i + 1) % accum == 0 or i == n_steps - 1  # decided on the common counter, before any skip
             evaluate_now = (eval_freq > 0 and (i + 1) % eval_freq == 0) or i == n_steps - 1
             if batch is not None and torch.all(torch.isfinite(batch['extrinsics'])):

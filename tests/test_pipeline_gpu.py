@@ -876,3 +876,47 @@ def test_segmentation_on_odd_frame_sizes_says_why(cuda):
         with pytest.warns(RuntimeWarning, match='multiples of 16'), pytest.raises(RuntimeError):
             pipe.fuse(_batch(st, 0, cuda), db, cuda)
     assert pipe.__dict__.get('_warned_seg_fallback') is True
+
+
+def test_announced_training_frames_change_no_bit(cuda):
+    """Pipeline.announce_training_frame(next batch): the filtered frame and the valid-ray count of the next training frame are
+    requested one frame ahead (the frame step's only host read; pipeline.py:125-131 reads it with a blocking ``nonzero``).  The same
+    launches, earlier: outputs, gradients, BatchNorm buffers and volumes bit for bit those of the un-announced loop - in train()
+    mode with Dropout2d active (the persistent mask buffer draws what the per-pass tensor drew) - also when the announced batch is
+    NOT the one that comes, and across an optimizer step (the cached layer table must follow the weights)."""
+    h, w, grid, frames = 48, 64, 64, 6
+
+    def run(announce):
+        torch.manual_seed(10)  # (the modules' default initialisation draws too)
+        cfg, st, db, pipe = _setup(h, w, grid, False, False, 'fast', cuda)
+        torch.manual_seed(11)
+        for m in pipe._fusion_network.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                torch.nn.init.xavier_normal_(m.weight)
+        pipe.train()
+        opt = torch.optim.RMSprop(pipe._fusion_network.parameters(), lr=1e-3)
+        torch.manual_seed(12)  # the Dropout2d draws
+        batches = [_batch(st, i, cuda) for i in range(frames + 1)]
+        outs = []
+        for i in range(frames):
+            if announce:  # frame 3 is announced wrongly (another object): its own count is computed in the call
+                pipe.announce_training_frame(batches[i + 1] if i != 2 else _batch(st, 0, cuda), cuda)
+            out = pipe.fuse_training(batches[i], db, cuda)
+            loss = (out['tsdf_fused'] - out['tsdf_target']).abs().mean()
+            loss.backward()
+            outs.append((out['tsdf_est'].detach().clone(), out['tsdf_fused'].detach().clone(), loss.detach().clone()))
+            if i % 2 == 1:
+                opt.step()
+                opt.zero_grad(set_to_none=False)
+        torch.cuda.synchronize()
+        net = pipe._fusion_network
+        return (outs, [p.detach().clone() for p in net.parameters()], [b.detach().clone() for b in net.buffers()],
+                [db.scenes_est[st.scene].volume.clone(), db.fusion_weights[st.scene].clone()])
+    a, b = run(True), run(False)
+    for (e1, f1, l1), (e2, f2, l2) in zip(a[0], b[0]):
+        assert torch.equal(e1, e2) and torch.equal(f1, f2) and torch.equal(l1, l2)
+    for x, y in zip(a[1] + a[2], b[1] + b[2]):
+        assert torch.equal(x, y)
+    for x, y in zip(a[3], b[3]):
+        assert torch.equal(x.view(torch.int16), y.view(torch.int16))
+    assert float((a[3][1].float() > 0).sum()) > 1000
