@@ -2359,7 +2359,7 @@ static int launch_conv_args(const ConvArgs *args, int n, int nt, hipStream_t st,
             }
         }
     // persistent blocks for single-chunk layers (ConvGroup::band): `bpc` blocks per CU over all members of the group
-    static const int persist_bpc = getenv("OJF_CONV_PERSIST") ? atoi(getenv("OJF_CONV_PERSIST")) : 4;  // A/B switch (0: one pixel block per launch block)
+    static const int persist_bpc = getenv("OJF_CONV_PERSIST") ? atoi(getenv("OJF_CONV_PERSIST")) : 3;  // A/B switch (0: one pixel block per launch block; measured 2 / 3 / 4 / 6: 3 is best, profiles/r06_fusion_net_experiments.txt)
     if (grp.nblocks && persist_bpc > 0 && arith == OJF_ARITH_F16X3) {
         bool single = true;
         for (int i = 0; i < n; ++i) single = single && args[i].nsteps <= conv16_chunk(nt);

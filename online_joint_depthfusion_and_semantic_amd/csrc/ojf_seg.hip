@@ -177,10 +177,28 @@ __device__ __forceinline__ void seg_vectors(const SegArgs &a, int ct0, int kg, f
 }
 
 template <int MW, int NW, bool DROP = false>
+__device__ __forceinline__ void seg_epilogue_px(const SegArgs &a, const f32x4 (&acc)[MW][NW], int ct0, const int (&pidx)[NW], int kg,
+                                                const f32x4 (&rvs)[MW], const f32x4 (&bvs)[MW]);
+
+template <int MW, int NW, bool DROP = false>
 __device__ __forceinline__ void seg_epilogue(const SegArgs &a, const f32x4 (&acc)[MW][NW], int ct0, int pt0, int n_pix, int col, int kg,
                                              const f32x4 (&rvs)[MW], const f32x4 (&bvs)[MW])
 {
-    // epilogue: lane holds output channels c .. c+3 of pixel (pt0+n)*16 + col
+    int pidx[NW];
+#pragma unroll
+    for (int n = 0; n < NW; ++n) {
+        const int p = (pt0 + n) * 16 + col;
+        pidx[n] = p < n_pix ? p : -1;
+    }
+    seg_epilogue_px<MW, NW, DROP>(a, acc, ct0, pidx, kg, rvs, bvs);
+}
+
+// pidx[n]: the (batch-major, row-major) output pixel this lane holds in accumulator column n, or -1
+template <int MW, int NW, bool DROP>
+__device__ __forceinline__ void seg_epilogue_px(const SegArgs &a, const f32x4 (&acc)[MW][NW], int ct0, const int (&pidx)[NW], int kg,
+                                                const f32x4 (&rvs)[MW], const f32x4 (&bvs)[MW])
+{
+    // epilogue: lane holds output channels c .. c+3 of pixel pidx[n]
     float gmax = 0.0f;
     unsigned long long seed = 0, frame = 0;
     if constexpr (DROP) { seed = a.rng[0]; frame = a.rng[1]; }
@@ -202,8 +220,8 @@ __device__ __forceinline__ void seg_epilogue(const SegArgs &a, const f32x4 (&acc
         }
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
-            const int p = (pt0 + n) * 16 + col;
-            if (p >= n_pix) continue;
+            const int p = pidx[n];
+            if (p < 0) continue;
             f32x4 v;
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(acc[m][n][i], rv[i], bv[i]);
@@ -1086,6 +1104,172 @@ __global__ __launch_bounds__(512) void segconv_ws_kernel(const SegGroupArgs grp)
     seg_epilogue<MT, NT, DROP>(a, acc, ctw, ptw, n_pix, col, kg, rvs, bvs);
 }
 
+// WINDOW form (round 6) for 3x3 / stride 1 / dilation 1 / padding 1 layers whose channel groups come in fours (c_in % 32 == 0).  What
+// this round's gate measured (profiles/r06_seg_ws_gate.txt): the GEMM-shaped launches sit on an L2 -> CU plateau of ~8 TB/s because every
+// (tap, channel block) of a K walk re-fetches its pixel rows - nine times per 3x3 layer - and every pixel block re-fetches the weights.
+// Here the K walk is (32-channel chunk) outer, (tap) inner: the chunk's pixels of the block's TH x 16 output tile PLUS its one-pixel halo
+// are fetched ONCE, split into fp16 halves once, and stay in LDS for all nine taps, which read them at shifted positions (pixel pitch 144
+// bytes: the 16 lanes of an operand read hit 16 different 16-byte bank groups).  The weights of a (tap, chunk) K block stream through a
+// two-stage LDS buffer, two K blocks in flight in registers, one barrier per K block, the next chunk's window loads ride along (issued at
+// tap 0, written at tap 3).  Block = 2 x 2 waves over (2 MT channel tiles) x (TH rows of 16 pixels).  K blocks are added chunk-major
+// instead of tap-major: the same products, another rounding order than the other forms (like every change of form: include/ojf.h).
+template <int MT, int TH, bool DROP = false>
+__global__ __launch_bounds__(256) void segconv_win_kernel(const SegGroupArgs grp)
+{
+    int bx, by, bz;
+    if (!seg_block(grp, bx, by, bz)) return;  // block-uniform
+    const SegArgs &a = grp.a[bz];
+    constexpr int MB = 2 * MT, NT = TH / 2, WW = 18, WH = TH + 2, WPIX = WW * WH, PIXB = 144;
+    constexpr int WI = (WPIX * 4 + 255) / 256;  // window items (pixel, 8-channel group) per thread
+    constexpr int CW = 2 * MB / 4;              // one-KB weight chunks per wave and K block
+    static_assert(TH % 2 == 0 && (2 * MB) % 4 == 0, "tile");
+    extern __shared__ __attribute__((aligned(16))) unsigned char win_lds[];
+    unsigned char *Ws = win_lds;                                             // [2][WPIX * PIXB]
+    f32x4 *As = reinterpret_cast<f32x4 *>(win_lds + 2 * WPIX * PIXB);        // [2][MB][2][64]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int col = lane & 15, kg = lane >> 4;
+    const int H = a.H, W = a.W, in_stride = a.in_stride, n_kb = a.n_kb, n_ct = a.n_ct;
+    const int n_chunks = a.c8 >> 2, total = 9 * n_chunks;
+    const int tiles_x = (W + 15) >> 4, tiles_y = (H + TH - 1) / TH;
+    const int img = bx / (tiles_x * tiles_y), rb = bx - img * (tiles_x * tiles_y);
+    const int tyb = rb / tiles_x, txb = rb - tyb * tiles_x;
+    const int y0 = tyb * TH, x0 = txb * 16;
+    const int ct0 = by * MB;
+
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in), 0, a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(a.wp), 0, (unsigned)((size_t)n_ct * n_kb * 2048), 0x00020000);
+    unsigned woff[CW];
+#pragma unroll
+    for (int r = 0; r < CW; ++r) {
+        const int c = wave * CW + r, m = c >> 1, h = c & 1;
+        int ct = ct0 + m;
+        ct = ct < n_ct ? ct : n_ct - 1;  // (a block past the layer's last channel tile: any valid tile, results unused)
+        woff[r] = (unsigned)(((ct * n_kb) * 128 + h * 64 + lane) * 16);
+    }
+    // this thread's window items: global byte offset of channel group 0 of its pixel (or the out-of-range sentinel), LDS byte offset
+    unsigned goff[WI], loff[WI];
+#pragma unroll
+    for (int j = 0; j < WI; ++j) {
+        const int item = (int)threadIdx.x + 256 * j;
+        const int wp = item >> 2, q = item & 3;
+        const int wy = wp / WW, wx = wp - wy * WW;
+        const int iy = y0 - 1 + wy, ix = x0 - 1 + wx;
+        const bool ok = item < WPIX * 4 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        goff[j] = ok ? (unsigned)((((img * H + iy) * W + ix) * in_stride + q * 8) * 4) : 0xfffffff0u;
+        loff[j] = item < WPIX * 4 ? (unsigned)(wp * PIXB + q * 32) : 0xffffffffu;
+    }
+    f32x4 wa[WI], wb[WI];
+    auto issue_window = [&](int chunk) {  // (a chunk past the last one: zeros, no traffic)
+        const unsigned step = (unsigned)chunk * 128u;
+#pragma unroll
+        for (int j = 0; j < WI; ++j) {
+            const bool ok = goff[j] != 0xfffffff0u && chunk < n_chunks;
+            const unsigned off = ok ? goff[j] + step : 0xfffffff0u;
+            wa[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+            wb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off + 16u : 0xfffffff0u, 0, 0));
+        }
+    };
+    auto stage_window = [&](int st) {
+#pragma unroll
+        for (int j = 0; j < WI; ++j) {
+            if (loff[j] == 0xffffffffu) continue;
+            f16x8 xh, xl;
+            split8(wa[j], wb[j], xh, xl);
+            unsigned char *dst = Ws + st * (WPIX * PIXB) + loff[j];
+            *reinterpret_cast<f32x4 *>(dst) = __builtin_bit_cast(f32x4, xh);
+            *reinterpret_cast<f32x4 *>(dst + 16) = __builtin_bit_cast(f32x4, xl);
+        }
+    };
+    // the K block of step s = (chunk c, tap t) sits at index t * n_chunks + c of the layer's packed K blocks
+    f32x4 wr[2][CW];
+    int it = 0, ic = 0;  // (tap, chunk) of the next weight K block to request
+    auto issue_weights = [&](f32x4 (&fw)[CW]) {
+        const int kb = ic < n_chunks ? it * n_chunks + ic : n_kb - 1;  // past the end: the last block again (never used)
+#pragma unroll
+        for (int r = 0; r < CW; ++r) fw[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, woff[r], kb * 2048, 0));
+        if (++it == 9) { it = 0; ++ic; }
+    };
+    auto stage_weights = [&](int st, const f32x4 (&fw)[CW]) {
+#pragma unroll
+        for (int r = 0; r < CW; ++r) {
+            const int c = wave * CW + r;
+            As[((st * MB + (c >> 1)) * 2 + (c & 1)) * 64 + lane] = fw[r];
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // prologue: window of chunk 0, weights of steps 0 (staged), 1 and 2 (in flight)
+    issue_window(0);
+    issue_weights(wr[0]);
+    issue_weights(wr[1]);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CW) : "memory");
+    stage_window(0);
+    stage_weights(0, wr[0]);
+    issue_weights(wr[0]);
+    __syncthreads();
+    // this lane's operand position in the window: output pixel (row wn * NT + n, column col) reads window pixel (row + ky, col + kx)
+    const unsigned bbase = (unsigned)(((wn * NT) * WW + col) * PIXB + kg * 32);
+    int t = 0, c = 0;
+    for (int s2 = 0; s2 < total; s2 += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int s = s2 + u;
+            if (s >= total) break;  // (uniform; only in the last round)
+            // weights of step s sit in As stage u (= s & 1: s2 is even), of step s + 1 in register slot (u + 1) & 1
+            const unsigned char *wsrc = Ws + (c & 1) * (WPIX * PIXB) + bbase + (unsigned)(((t / 3) * WW + (t % 3)) * PIXB);
+            f32x4 bh[NT], bl[NT], ah[2], al[2];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                bh[n] = *reinterpret_cast<const f32x4 *>(wsrc + n * (WW * PIXB));
+                bl[n] = *reinterpret_cast<const f32x4 *>(wsrc + n * (WW * PIXB) + 16);
+            }
+            ah[0] = As[((u * MB + wm * MT) * 2 + 0) * 64 + lane];
+            al[0] = As[((u * MB + wm * MT) * 2 + 1) * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);
+            // landed: the weights of step s + 1 (and, at tap 3, the next chunk's window, requested at tap 0 behind tap 0's weights)
+            if (t == 1 || t == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CW + 2 * WI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CW) : "memory");
+            stage_weights((u + 1) & 1, wr[(u + 1) & 1]);
+            if (t == 3) stage_window((c + 1) & 1);
+            issue_weights(wr[(u + 1) & 1]);
+            if (t == 0) issue_window(c + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                if (m + 1 < MT) {
+                    ah[(m + 1) & 1] = As[((u * MB + wm * MT + m + 1) * 2 + 0) * 64 + lane];
+                    al[(m + 1) & 1] = As[((u * MB + wm * MT + m + 1) * 2 + 1) * 64 + lane];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n] = mfma3(ah[m & 1], al[m & 1], __builtin_bit_cast(f16x8, bh[n]), __builtin_bit_cast(f16x8, bl[n]), acc[m][n]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+            if (++t == 9) { t = 0; ++c; }
+        }
+    }
+    const int ctw = ct0 + wm * MT;
+    if (ctw >= n_ct) return;
+    int pidx[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int y = y0 + wn * NT + n, x = x0 + col;
+        pidx[n] = (y < H && x < W) ? (img * H + y) * W + x : -1;
+    }
+    f32x4 rvs[MT], bvs[MT];
+    seg_vectors<MT>(a, ctw, kg, rvs, bvs);
+    seg_epilogue_px<MT, NT, DROP>(a, acc, ctw, pidx, kg, rvs, bvs);
+}
+
 inline float pow2_row_scale(float row_max)
 {
     if (!(row_max > 0.0f) || !std::isfinite(row_max)) return 1.0f;
@@ -1331,6 +1515,36 @@ int seg_launch(SegGroupArgs &g, int n, hipStream_t st)
         else if (aligned) hipLaunchKernelGGL((segconv_gemm_kernel<MT_, NT_, false, true, WM_>), grid__, dim3(256), 0, st, g);         \
         else hipLaunchKernelGGL((segconv_gemm_kernel<MT_, NT_, false, false, WM_>), grid__, dim3(256), 0, st, g);                     \
     } while (0)
+        // WINDOW form (segconv_win_kernel): 3x3 / stride 1 / dilation 1 layers with c_in % 32 == 0 and rows of >= 40 pixels (or a multiple of 16)
+        static const int win = getenv("OJF_SEG_WIN") ? atoi(getenv("OJF_SEG_WIN")) : 0;  // 0 off | 1 by block count | 2 force 64 ch x 4 rows | 3 force 128 ch x 8 rows
+        if (win && a.ksize == 3 && a.stride == 1 && a.dil == 1 && a.pad == 1 && aligned && !drop_any && a.c8 >= 8 && (a.W % 16 == 0 || a.W >= 40)) {
+            const int tx = (a.W + 15) / 16;
+            const long blocksB = (long)a.B * ((a.H + 7) / 8) * tx * ((a.n_ct + 7) / 8) * n, blocksA = (long)a.B * ((a.H + 3) / 4) * tx * ((a.n_ct + 3) / 4) * n;
+            const int pick = win == 2 ? 0 : (win == 3 ? 1 : (blocksB >= 192 ? 1 : (blocksA >= 128 ? 0 : -1)));
+            if (pick >= 0) {
+                g.het.n = 0;
+                static bool configured = false;
+                constexpr int ldsA = 2 * (18 * 6) * 144 + 2 * 4 * 2 * 64 * 16, ldsB = 2 * (18 * 10) * 144 + 2 * 8 * 2 * 64 * 16;
+                if (!configured) {
+                    if (int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(&segconv_win_kernel<4, 8, false>),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, ldsB), "segconv_win_kernel LDS")) return rc;
+                    if (int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(&segconv_win_kernel<2, 4, false>),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, ldsA), "segconv_win_kernel LDS")) return rc;
+                    configured = true;
+                }
+                if (pick) {
+                    variant = "win 128x(8x16)";
+                    hipLaunchKernelGGL((segconv_win_kernel<4, 8, false>), dim3(seg_map(g.map, a.B * ((a.H + 7) / 8) * tx, (a.n_ct + 7) / 8, n)), dim3(256), ldsB, st, g);
+                } else {
+                    variant = "win 64x(4x16)";
+                    hipLaunchKernelGGL((segconv_win_kernel<2, 4, false>), dim3(seg_map(g.map, a.B * ((a.H + 3) / 4) * tx, (a.n_ct + 3) / 4, n)), dim3(256), ldsA, st, g);
+                }
+                if (trace)
+                    fprintf(stderr, "segconv %-14s n %d  c_in %4d c_out %4d k 3  in %3dx%3d B %d  n_kb %4d  grid %dx%dx%d%s\n", variant, n, a.c8 * 8, a.c_out, a.H, a.W, a.B,
+                            a.n_kb, g.map.X, g.map.Y, g.map.Z, a.up > 1 ? " deconv" : "");
+                return check_hip(hipGetLastError(), "segconv_win_kernel launch");
+            }
+        }
         struct Shape { int a, b; const char *name; };  // channel / pixel tiles of the block
         static const Shape menu[] = {{4, 4, "gemm 64x64"}, {8, 8, "gemm 128x128"}, {8, 10, "gemm 128x160"}, {8, 5, "gemm 128x80"}};
         const bool big = b44 >= gemm_min && a.n_ct >= 8;

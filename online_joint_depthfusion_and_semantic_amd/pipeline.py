@@ -388,6 +388,13 @@ class Pipeline(torch.nn.Module):
                     best, best_ms = cand, t
         return best
 
+    def _lookahead_stream_choice(self):
+        """SETTINGS.lookahead_stream (env OJF_LOOKAHEAD_STREAM for A/B runs): 'measured' - six candidate streams timed once against
+        the real work (round 5) | 'priority' - one high-priority stream (its own hardware-queue pool) | 'probe' - the first stream that
+        passes ojf_streams_overlap."""
+        import os
+        return os.environ.get('OJF_LOOKAHEAD_STREAM') or self.config.SETTINGS.get('lookahead_stream', 'measured')
+
     def _net_side_streams(self):
         """Raw handles of the fusion net's own side streams (the second head of the two-head net runs on one): the look-ahead
         pass must not share a hardware queue with them either (measured: 775 frames/s when it does, 930-1070 when not)."""
@@ -405,9 +412,16 @@ class Pipeline(torch.nn.Module):
             return
         cur = torch.cuda.current_stream(self.device)
         pf = self.__dict__.get('_prefetch')
+        how = self._lookahead_stream_choice()
         if pf is None:
             net_streams = self._net_side_streams()
-            pf = self.__dict__['_prefetch'] = {'stream': self._side_stream([cur] + net_streams), 'n': 0, 'slots': [None, None], 'ready': None, 'taken': False,
+            if how == 'priority':
+                # a stream of ANOTHER priority class: the runtime keeps one pool of hardware queues per priority, so this stream never
+                # shares a queue with the caller's (normal-priority) stream or the net's side streams - by construction, not by probing
+                side = torch.cuda.Stream(device=self.device, priority=-1)
+            else:
+                side = self._side_stream([cur] + net_streams)
+            pf = self.__dict__['_prefetch'] = {'stream': side, 'n': 0, 'slots': [None, None], 'ready': None, 'taken': False, 'measured': how != 'measured',
                                                 'net_seen': bool(net_streams) or getattr(self, '_engine', None) is not None}
         elif not pf.get('measured') and getattr(self, '_engine', None) is not None and self.__dict__.get('_seg_graph_many', {}).get('graph') is not None:
             # (once, when both networks' launch sequences exist: the stream is chosen by what it does to the real work)

@@ -26,7 +26,10 @@ with torch.cuda.stream(stream):
     torch.cuda.synchronize()
 us = (time.perf_counter() - t0) / (5 * reps) * 1e6
 import hashlib
+with torch.no_grad():
+    ref = torch.relu(torch.nn.functional.conv2d(x[:, :cin].contiguous().double(), conv.weight.double(), padding=k // 2))
+    err = float((out[:, :cout].double() - ref).abs().max() / ref.abs().max())
 sha = hashlib.sha256(out.contiguous().cpu().numpy().tobytes()).hexdigest()[:12]
-print('%4d -> %4d k%d %dx%d B%d: %.1f us per launch, out sha %s (graph of %d, %d weight set(s) = %.0f MB, %s)' % (
-    cin, cout, k, h, w, B, us, sha, reps, copies, copies * cin * cout * k * k * 4 / 1e6,
+print('%4d -> %4d k%d %dx%d B%d: %.1f us per launch, out sha %s rel err %.1e (graph of %d, %d weight set(s) = %.0f MB, %s)' % (
+    cin, cout, k, h, w, B, us, sha, err, reps, copies, copies * cin * cout * k * k * 4 / 1e6,
     ' '.join('%s=%s' % (a, b) for a, b in sorted(os.environ.items()) if a.startswith('OJF_SEG'))))
