@@ -648,7 +648,7 @@ def rccl_world1_probe(timeout=240):
     a communicator of one rank set up and the flat 1.44-MB gradient buffer all-reduced at every accumulation boundary of a short
     training loop.  A failure is reported, never fatal to the headline line."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), '--train', '--force-group', '--steps', '16', '--warmup', '8', '--repeats', '2', '--cpu-frames', '0']
+    cmd = [sys.executable, os.path.abspath(__file__), '--train', '--force-group', '--steps', '32', '--warmup', '16', '--repeats', '2', '--cpu-frames', '0']
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     name = 'RCCL on one rank: training frame step with the flat-gradient all-reduce through a process group of ONE rank (nccl backend)'

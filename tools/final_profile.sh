@@ -24,6 +24,8 @@ cp $(find $O/kp -name '*kernel_stats.csv' | head -1) $O/predict_kernel_stats.csv
 python tools/train_throughput.py > $O/train_throughput.txt 2>&1
 python tools/train_throughput.py >> $O/train_throughput.txt 2>&1
 python bench.py --train --steps 64 --warmup 16 --repeats 5 > $O/bench_train.json 2>/dev/null
+python bench.py --train --force-group --steps 64 --warmup 16 --repeats 3 > $O/bench_train_rccl_one_rank.json 2>/dev/null
+python tools/train_host_split.py 2>&1 | grep -v amdgpu.ids > $O/train_host_split.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktr -o ktr -- python tools/train_throughput.py > /dev/null 2> $O/ktr.err
 cp $(find $O/ktr -name '*kernel_stats.csv' | head -1) $O/train_kernel_stats.csv
 python tools/train_timeline.py $(find $O/ktr -name '*kernel_trace.csv' | head -1) > $O/train_timeline.txt 2>&1
@@ -33,13 +35,17 @@ python tools/adapnet_engine_probe.py 2>&1 | grep -v MIOpen > $O/adapnet_engine_p
 python bench.py --mode parity --steps 100 --cpu-frames 0 --secondary 0 > $O/bench_parity.json 2>/dev/null
 python bench.py --height 120 --width 160 --grid 64 --cpu-frames 0 --secondary 0 > $O/bench_A.json 2>/dev/null
 # several scenes per GPU (Pipeline.fuse_many) and the 2-D engine on batches
-for S in 2 4; do python bench.py --steps 100 --warmup 10 --repeats 3 --scenes $S >> $O/bench_fuse_many.json 2>/dev/null; done
+for S in 2 4 8; do python bench.py --steps 100 --warmup 10 --repeats 3 --scenes $S >> $O/bench_fuse_many.json 2>/dev/null; done
 python bench.py --steps 60 --warmup 10 --repeats 3 --scenes 4 --semantics --semantic-strategy predict >> $O/bench_fuse_many.json 2>/dev/null
 for B in 1 2 4 8; do python tools/seg_probe.py graph 30 240 320 $B 2>&1 | grep "seg engine" >> $O/seg_engine_batches.txt; done
 # per-launch timeline of the 2-D engine (one frame per pass) and the kernel form every layer runs in
 OJF_SEG_TRACE=1 python tools/seg_probe.py eager 1 240 320 1 2>&1 | grep "^segconv" | tail -100 > $O/seg_forms_b1.txt
 rocprofv3 --kernel-trace --output-format csv -d $O/kts -o kts -- python tools/seg_probe.py graph 10 240 320 1 > /dev/null 2> $O/kts.err
 SEG_PACKS=2 python tools/seg_seq.py $(find $O/kts -name '*kernel_trace.csv' | head -1) > $O/seg_launch_timeline.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/kts8 -o kts8 -- python tools/seg_probe.py graph 10 240 320 8 > /dev/null 2> $O/kts8.err
+SEG_PACKS=16 python tools/seg_seq.py $(find $O/kts8 -name '*kernel_trace.csv' | head -1) > $O/seg_launch_timeline_b8.txt 2>&1
+rm -rf $O/kts8
+python tools/fabric_rate.py 2>&1 | grep -v amdgpu.ids > $O/fabric_rate.txt
 timeout 120 tools/microbench/grid_barrier > $O/grid_barrier.txt 2>&1
 rm -rf $O/kts
 rm -rf $O/kt $O/pf $O/pw $O/sq $O/kp $O/ktr $O/cf $O/cw $O/sqp $O/sqt
