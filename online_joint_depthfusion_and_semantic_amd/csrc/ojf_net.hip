@@ -1101,15 +1101,18 @@ __global__ __launch_bounds__(kChainThreads, OJF_CHAIN_BLOCKS) void chain1x1_kern
 constexpr int kColShards = 16;
 constexpr float kColScale = 1048576.0f;  // 2^20; |block sum| <= 64 * 65504 -> 4.4e12, 1200 blocks: far inside int64
 
+constexpr int kColMax = 256;  // channels (round 6: the 228-channel entry of the two-head net's last VortexPooling)
 struct ColSums {
-    long long fix[kColShards][128];
-    unsigned bad[128];
+    long long fix[kColShards][kColMax];
+    unsigned bad[kColMax];
 };
+constexpr int colsum_row(int nt) { return nt > 8 ? 256 : 128; }  // floats per wave row of block_colsum's LDS scratch
 
 template <int MT, int NT, int NA>
-__device__ __forceinline__ void block_colsum(const f32x4 (&x)[MT][NA], const int (&p)[MT], int npix, float *red /* LDS [4][128] */,
-                                             ColSums *out, int lane, int wave)
+__device__ __forceinline__ void block_colsum(const f32x4 (&x)[MT][NA], const int (&p)[MT], int npix, float *red /* LDS [waves][colsum_row(NT)] */,
+                                             ColSums *out, int lane, int wave, int off = 0)
 {
+    constexpr int RS = colsum_row(NT);
     const int g = lane >> 4;
 #pragma unroll
     for (int S = 0; S < NT; ++S) {
@@ -1126,20 +1129,21 @@ __device__ __forceinline__ void block_colsum(const f32x4 (&x)[MT][NA], const int
             v += __shfl_xor(v, 1, 64);
             s[j] = v;
         }
-        if ((lane & 15) == 0) *reinterpret_cast<f32x4 *>(red + wave * 128 + S * 16 + 4 * g) = s;
+        if ((lane & 15) == 0) *reinterpret_cast<f32x4 *>(red + wave * RS + S * 16 + 4 * g) = s;
     }
     __syncthreads();
+    static_assert(NT * 16 <= kChainThreads && NT * 16 <= kColMax, "one thread per channel");
     if ((int)threadIdx.x < NT * 16) {
         const int t = threadIdx.x;
-        float v = (red[t] + red[128 + t]) + (red[256 + t] + red[384 + t]);
+        float v = (red[t] + red[RS + t]) + (red[2 * RS + t] + red[3 * RS + t]);
 #pragma unroll
         for (int w4 = 4; w4 < kChainWaves; w4 += 4)  // further waves of the block, four at a time in the same fixed order
-            v += (red[w4 * 128 + t] + red[(w4 + 1) * 128 + t]) + (red[(w4 + 2) * 128 + t] + red[(w4 + 3) * 128 + t]);
+            v += (red[w4 * RS + t] + red[(w4 + 1) * RS + t]) + (red[(w4 + 2) * RS + t] + red[(w4 + 3) * RS + t]);
         if (v - v == 0.0f) {  // finite
             const long long q = (long long)__builtin_rintf(v * kColScale);  // |v| < 2^23: the product is exact up to the rounding of rintf
-            if (q) atomicAdd(reinterpret_cast<unsigned long long *>(&out->fix[blockIdx.x % kColShards][t]), (unsigned long long)q);
+            if (q) atomicAdd(reinterpret_cast<unsigned long long *>(&out->fix[blockIdx.x % kColShards][t + off]), (unsigned long long)q);
         } else {
-            atomicOr(&out->bad[t], 1u);
+            atomicOr(&out->bad[t + off], 1u);
         }
     }
 }
@@ -1154,7 +1158,7 @@ __global__ __launch_bounds__(kChainThreads, OJF_CHAIN_BLOCKS) void entry1x1_kern
 {
     __shared__ f32x4 wlds[chain_dma(ARITH) ? 2 * kChainDmaHalf : kChainLdsFloat4];
     __shared__ f32x4 vec_lds[2 * kVecF4];
-    __shared__ float red[kChainWaves * 128];
+    __shared__ float red[kChainWaves * colsum_row(NTIN)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g = lane >> 4;
     const int strip = (banded_block_x() * kChainWaves + wave) * (MT * 16);
@@ -1225,6 +1229,7 @@ struct TailArgs {
     int entry_og, entry_act_n;
     struct ColSums *colsum;
     int entry_split;  // ChainArgs::split_groups of the fused entry layer
+    int colsum_off = 0;  // two-head nets: this head's channels start here in the next VortexPooling's input (hd * os)
 };
 
 constexpr int kTailEntry = 1;
@@ -1337,7 +1342,7 @@ __global__ __launch_bounds__(kChainThreads, OJF_CHAIN_BLOCKS) void vortex_tail_k
     if constexpr (ARITH == OJF_ARITH_F16X3)
         if (gmax > 65504.0f && a.ovf) guard_raise(a.ovf, 1);
     if constexpr (CHAIN == kTailEntry) {
-        block_colsum<MT, NO>(y, p, a.npix, red, a.colsum, lane, wave);
+        block_colsum<MT, NO>(y, p, a.npix, red, a.colsum, lane, wave, a.colsum_off);
         ca.out_planes = a.entry_out; ca.out_g0 = 0; ca.og_store = a.entry_og; ca.act_n = a.entry_act_n; ca.split_groups = a.entry_split;
         chain_layer<ARITH, MT, 8, 5, kChainEntry, 0>(y, t, wlds, a.entry_w, ca, p, lane, pre, buf, vs);
     } else if constexpr (CHAIN) {
@@ -1369,6 +1374,11 @@ struct PyramidArgs {
     int h, w, c4;
     int tiles;      // pixel tiles; with fold_gave, block column `tiles` folds the global-average branch instead
     int fold_gave;
+    // two-head nets: the entry GEMM arrives as two partial sums (one per head, no bias, no activation): z + z2 on load; block rows
+    // [3 c4, 4 c4) form branch 0 = ReLU(z + z2 + bias0) (no pooling) into q0
+    const f32x4 *z2 = nullptr;
+    f32x4 *q0 = nullptr;
+    const float *bias0 = nullptr;
     int split_out;  // q[] are split planes (split_pack4): their only reader is the branch's first 3x3 convolution
     GaveArgs gave;
 };
@@ -1385,6 +1395,7 @@ __device__ __forceinline__ void pool_pyramid_body(const PyramidArgs &a, f32x4 (&
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int x0 = tx * kPoolTW, y0 = ty * kPoolTH, npix = a.h * a.w;
     const f32x4 *plane = a.z + (size_t)(LV * a.c4 + cg) * npix;
+    const f32x4 *plane2 = a.z2 ? a.z2 + (size_t)(LV * a.c4 + cg) * npix : nullptr;  // (uniform)
     const f32x4 zero{0.f, 0.f, 0.f, 0.f};
     {
         constexpr int W0 = kPoolTW + 2 * LV, H0 = kPoolTH + 2 * LV;
@@ -1395,7 +1406,9 @@ __device__ __forceinline__ void pool_pyramid_body(const PyramidArgs &a, f32x4 (&
             const int ly = i / W0, lx = i - ly * W0;
             const int gy = y0 - LV + ly, gx = x0 - LV + lx;
             const bool in = (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
-            buf[0][ly * kPoolStride + lx] = in ? plane[gy * a.w + gx] : zero;
+            f32x4 v = in ? plane[gy * a.w + gx] : zero;
+            if (plane2 && in) v += plane2[gy * a.w + gx];
+            buf[0][ly * kPoolStride + lx] = v;
         }
     }
     __syncthreads();
@@ -1441,6 +1454,20 @@ __global__ __launch_bounds__(256) void pool_pyramid_kernel(const PyramidArgs a)
         return;
     }
     const int lv = blockIdx.y / a.c4 + 1, cg = blockIdx.y - (lv - 1) * a.c4;  // levels of this block's group
+    if (lv == 4) {  // two-head nets: branch 0 of the VortexPooling = ReLU(sum of the two heads' partial entry sums + bias), no pooling
+        const int tiles_x = (a.w + kPoolTW - 1) / kPoolTW;
+        const int tile = banded_block_x();
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int gy = ty * kPoolTH + (int)threadIdx.x / kPoolTW, gx = tx * kPoolTW + (int)threadIdx.x % kPoolTW;
+        if (gy < a.h && gx < a.w) {
+            const size_t at = (size_t)cg * a.h * a.w + gy * a.w + gx;
+            f32x4 v = a.z[at] + a.z2[at] + *reinterpret_cast<const f32x4 *>(a.bias0 + 4 * cg);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = v[j] < 0.0f ? 0.0f : v[j];  // keeps NaN, like torch.relu
+            a.q0[at] = a.split_out ? split_pack4(v) : v;
+        }
+        return;
+    }
     if (lv == 1) pool_pyramid_body<1>(a, buf, cg);
     else if (lv == 2) pool_pyramid_body<2>(a, buf, cg);
     else pool_pyramid_body<3>(a, buf, cg);
@@ -1478,7 +1505,7 @@ __device__ __forceinline__ void gave_bias_block(const GaveArgs &a, float *mean /
 {
     const int t = threadIdx.x;
     if (a.fixed) {
-        if (t < 128) {
+        if (t < kColMax) {
             long long q = 0;
 #pragma unroll
             for (int sh = 0; sh < kColShards; ++sh) {
@@ -2528,7 +2555,12 @@ struct Vortex {
     float *pool_bias[4] = {nullptr, nullptr, nullptr, nullptr};
     float *Wg = nullptr, *bg = nullptr, *Wfg = nullptr, *bf = nullptr, *bias_final = nullptr;
     float *tail_w = nullptr, *tail_b1 = nullptr, *tail_rinv = nullptr;  // fused tail (closing 1x1s + final conv), when supported
-    float *entry_w = nullptr, *entry_b = nullptr;  // the stacked entry GEMM as one chain layer (8 input tiles -> 5), when supported
+    float *entry_w = nullptr, *entry_b = nullptr;  // the stacked entry GEMM as one chain layer (8 or 16 input tiles -> 5), when supported
+    int entry_ntin = 8;
+    // two-head nets (round 6): the last VortexPooling's entry GEMM over the concatenation of the two heads' outputs splits into
+    // one 8-tile -> 5 layer per head (columns [hd * os, (hd + 1) * os) of the stacked weights, no bias, no activation): each head's
+    // tail runs ITS half on its register-resident result; the pool pyramid adds the halves (and forms branch 0)
+    float *entry_wh[2] = {nullptr, nullptr}, *entry_bh[2] = {nullptr, nullptr}, *bias0 = nullptr;
     PackedBranches branches;  // both 3x3 of the four branches for vortex_branch_kernel (split-fp16, 20-channel slots)
 };
 
@@ -2556,6 +2588,7 @@ struct ojf_net {
     // own intermediates, side stream and events; everything else (and the last VortexPooling) uses set 0.
     struct Scratch {
         float *T = nullptr, *Z = nullptr, *Q1 = nullptr, *Q2 = nullptr, *Q3 = nullptr, *U = nullptr, *V = nullptr;
+        float *Q0 = nullptr;  // two-head nets: branch 0 of the last VortexPooling (the pyramid's level-0 pass)
         float *partial = nullptr;
         ojf::ColSums *colsum = nullptr;  // chain flow: fixed-point channel sums of the entry layer's input (zero between frames)
         float *CAT = nullptr;  // 4*os, unfused tail only (allocated at first use)
@@ -2568,6 +2601,9 @@ struct ojf_net {
     hipEvent_t ev_head_fork = nullptr, ev_head_join = nullptr;
     // (per set: T cs | Z 4*cs entry-conv output | Q1..Q3 cs pool-pyramid outputs | U, V 4*cs outputs of the branches'
     //  first / closing 3x3 | partial kSumBlocks*256 | side stream + events of the global-average branch)
+    // two-head nets: the channel sums of the LAST VortexPooling's input come from the two heads' tails, which run on two streams beside
+    // the first head's own VortexPooling - whose pyramid reads and zeroes sc[0].colsum: they need an accumulator of their own
+    ojf::ColSums *colsum3 = nullptr;
     float *YY = nullptr;               // heads*os (vortex0 | vortex2 outputs)
     float *Y3 = nullptr;               // os
     float *PA = nullptr, *PB = nullptr;  // pred ping-pong, os each
@@ -2640,13 +2676,32 @@ static int build_vortex(ojf_net *net, Vortex &v, const ojf_conv_layer *L, int c_
             }
         }
         if (finish(b, v.stacked, net->arith)) return -2;
-        if (c_in_phys <= 128 && 4 * cs <= 80) {  // chain-layer form (entry1x1_kernel / the previous tail): 8 tiles -> 5
+        static const bool no_wide_entry = getenv("OJF_NO_WIDE_ENTRY") != nullptr;  // A/B switch (round 6)
+        if ((c_in_phys <= 128 || (c_in_phys <= 256 && !no_wide_entry)) && 4 * cs <= 80) {
+            // chain-layer form (entry1x1_kernel / the previous tail): 8 input tiles -> 5; the two-head net's last VortexPooling
+            // (228 = 2 x 114 input channels): 16 -> 5 (round 6: it ran the generic convolution + two side-stream kernels + three events)
+            v.entry_ntin = c_in_phys <= 128 ? 8 : 16;
             auto we = [&](int oc, int k) { return oc < 4 * cs && k < c_in_phys ? b.W[(size_t)oc * c_in_phys + k] : 0.0f; };
             const std::vector<float> re = chain_row_scales(net->arith, 5, c_in_phys, we);
             std::vector<float> ew, eb;
-            pack_chain_layer(ew, net->arith, 5, 8, re, we);
+            pack_chain_layer(ew, net->arith, 5, v.entry_ntin, re, we);
             append_chain_bias(eb, net->arith, 5, 4 * cs, b.B.data(), re);
             if (upload(ew, &v.entry_w) || upload(eb, &v.entry_b)) return -2;
+            static const bool no_half = getenv("OJF_NO_HALF_ENTRY") != nullptr;  // A/B switch (round 6)
+            if (v.entry_ntin == 16 && c_in_phys == 2 * net->os && !no_half) {
+                const std::vector<float> zero_bias(4 * cs, 0.0f);
+                for (int hd = 0; hd < 2; ++hd) {
+                    auto wh = [&](int oc, int k) { return oc < 4 * cs && k < net->os ? b.W[(size_t)oc * c_in_phys + hd * net->os + k] : 0.0f; };
+                    const std::vector<float> rh = chain_row_scales(net->arith, 5, net->os, wh);
+                    std::vector<float> hw, hb;
+                    pack_chain_layer(hw, net->arith, 5, 8, rh, wh);
+                    append_chain_bias(hb, net->arith, 5, 4 * cs, zero_bias.data(), rh);
+                    if (upload(hw, &v.entry_wh[hd]) || upload(hb, &v.entry_bh[hd])) return -2;
+                }
+                std::vector<float> b0(cs, 0.0f);
+                for (int o = 0; o < cs; ++o) b0[o] = b.B[o];  // branch 0's bias (+ ReLU): applied by the pyramid's level-0 pass
+                if (upload(b0, &v.bias0)) return -2;
+            }
         }
     }
     const std::vector<int> id_c = slot_map(c, c, cs);
@@ -2719,7 +2774,8 @@ static void free_vortex(Vortex &v)
         if (v.pool_bias[b]) (void)hipFree(v.pool_bias[b]);
     }
     release(v.branches);
-    float *ptrs[] = {v.Wg, v.bg, v.Wfg, v.bf, v.bias_final, v.tail_w, v.tail_b1, v.tail_rinv, v.entry_w, v.entry_b};
+    float *ptrs[] = {v.Wg, v.bg, v.Wfg, v.bf, v.bias_final, v.tail_w, v.tail_b1, v.tail_rinv, v.entry_w, v.entry_b,
+                     v.entry_wh[0], v.entry_wh[1], v.entry_bh[0], v.entry_bh[1], v.bias0};
     for (float *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -2740,9 +2796,13 @@ static int chain_blocks(const ojf_net *net) { return ((net->npix + 15) / 16 + oj
 // entry_done: the previous VortexPooling's tail already left this one's entry planes (sc.Z) and column sums (sc.colsum).
 // next: when given (and supported), this tail runs the NEXT VortexPooling's entry GEMM on its register-resident result
 //       instead of writing `out`; *next_done reports it.
+// half / next_colsum (two-head nets): this head's tail runs half `half` of `next`'s entry GEMM (partial sums into sc.Z, the channel
+//       sums of its result into next_colsum at channel half * os).  z2: the OTHER head's partial entry planes - this
+//       VortexPooling's pyramid adds them to sc.Z and forms branch 0 (entry_done must be set).
 static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float *out, int out_g0, hipStream_t st,
                       ojf_net::Scratch &sc, const ChainArgs *head = nullptr, bool *head_done = nullptr,
-                      bool entry_done = false, const Vortex *next = nullptr, bool *next_done = nullptr, bool in_split = false)
+                      bool entry_done = false, const Vortex *next = nullptr, bool *next_done = nullptr, bool in_split = false,
+                      int half = -1, ColSums *next_colsum = nullptr, const float *z2 = nullptr)
 {
     const int h = net->h, w = net->w, c4 = net->cs / 4, o4 = net->os / 4;
     const bool h16 = net->arith == OJF_ARITH_F16X3;
@@ -2779,7 +2839,9 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
         ea.split_groups = split ? c4 : 0;
         ea.in_split = in_split ? 1 : 0;
         const dim3 grid(chain_blocks(net)), block(ojf::kChainThreads);
-        if (h16) hipLaunchKernelGGL((entry1x1_kernel<OJF_ARITH_F16X3, 1, 8, 5>), grid, block, 0, st, ea);
+        if (v.entry_ntin == 16 && h16) hipLaunchKernelGGL((entry1x1_kernel<OJF_ARITH_F16X3, 1, 16, 5>), grid, block, 0, st, ea);
+        else if (v.entry_ntin == 16) hipLaunchKernelGGL((entry1x1_kernel<OJF_ARITH_F32, 1, 16, 5>), grid, block, 0, st, ea);
+        else if (h16) hipLaunchKernelGGL((entry1x1_kernel<OJF_ARITH_F16X3, 1, 8, 5>), grid, block, 0, st, ea);
         else hipLaunchKernelGGL((entry1x1_kernel<OJF_ARITH_F32, 1, 8, 5>), grid, block, 0, st, ea);
         mark_launch("entry1x1_kernel", st);
         OJF_HIP(hipGetLastError());
@@ -2791,15 +2853,19 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
         for (int b = 0; b < 3; ++b) pa.bias[b] = v.pool_bias[b + 1];
         pa.h = h; pa.w = w; pa.c4 = c4;
         pa.tiles = ((w + kPoolTW - 1) / kPoolTW) * ((h + kPoolTH - 1) / kPoolTH);
-        pa.gave = gave_args(net, v, nullptr, 0, 0, sc.colsum);
+        pa.gave = gave_args(net, v, nullptr, 0, 0, (z2 && net->colsum3) ? net->colsum3 : sc.colsum);
         pa.fold_gave = chain_flow ? 1 : 0;
         pa.split_out = split ? 1 : 0;
+        if (z2) {
+            if (!entry_done || !chain_flow || !sc.Q0 || !v.bias0) return fail("run_vortex: internal error (partial entry sums without the chain flow)");
+            pa.z2 = planes(z2); pa.q0 = planes(sc.Q0); pa.bias0 = v.bias0;
+        }
         // grid.x: the tiles (+ the global-average block of the chain flow) rounded up to a multiple of 8 (XCD bands)
-        hipLaunchKernelGGL(pool_pyramid_kernel, dim3(round_up(pa.tiles + (chain_flow ? 1 : 0), 8), 3 * c4), dim3(256), 0, st, pa);
+        hipLaunchKernelGGL(pool_pyramid_kernel, dim3(round_up(pa.tiles + (chain_flow ? 1 : 0), 8), (z2 ? 4 : 3) * c4), dim3(256), 0, st, pa);
         mark_launch("pool_pyramid_kernel", st);
         OJF_HIP(hipGetLastError());
     }
-    const float *bin[4] = {sc.Z, sc.Q1, sc.Q2, sc.Q3};
+    const float *bin[4] = {z2 ? sc.Q0 : sc.Z, sc.Q1, sc.Q2, sc.Q3};
     static const bool unfused = getenv("OJF_NO_TAIL") != nullptr;  // ablation switch only
     const bool fused = v.tail_w && !unfused;
     // (measured equal to the two grouped launches, not faster - 82 against 79-80 us per frame, profiles/r04_pair_experiments.txt -
@@ -2869,6 +2935,16 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
         else hipLaunchKernelGGL((vortex_tail_kernel<OJF_ARITH_F32, 1, 2, 8, 20>), grid, block, 0, st, ta);
         mark_launch("vortex_tail_kernel (+ prediction head)", st);
         if (head_done) *head_done = true;
+    } else if (chain_flow && next && half >= 0 && half < 2 && next->entry_wh[half] && next->tail_w && next_colsum && !legacy_env && !no_entry_fusion) {
+        // two-head net: this head's HALF of the next VortexPooling's entry GEMM rides along (partial sums: no bias, no activation,
+        // plain planes); `out` is never written
+        ta.entry_w = planes(next->entry_wh[half]); ta.entry_b = next->entry_bh[half]; ta.entry_out = planes(sc.Z);
+        ta.entry_og = 4 * c4; ta.entry_act_n = 0; ta.colsum = next_colsum; ta.colsum_off = half * net->os;
+        ta.entry_split = 0;
+        if (h16) hipLaunchKernelGGL((vortex_tail_kernel<OJF_ARITH_F16X3, 1, 2, 8, kTailEntry>), grid, block, 0, st, ta);
+        else hipLaunchKernelGGL((vortex_tail_kernel<OJF_ARITH_F32, 1, 2, 8, kTailEntry>), grid, block, 0, st, ta);
+        mark_launch("vortex_tail_kernel (+ half of the next entry GEMM)", st);
+        if (next_done) *next_done = true;
     } else if (chain_flow && next && next->entry_w && next->tail_w && next->c_in_phys == net->os && !legacy_env && !no_entry_fusion) {
         // this VortexPooling feeds the next one: its entry GEMM and column sums ride along, `out` is never written
         ta.entry_w = planes(next->entry_w); ta.entry_b = next->entry_b; ta.entry_out = planes(sc.Z);
@@ -2940,7 +3016,7 @@ OJF_API void ojf_net_destroy(ojf_net *net)
     float *bufs[] = {net->X[0], net->X[1], net->YY, net->Y3, net->PA, net->PB};
     for (float *p : bufs) free_planes(p);
     for (auto &sc : net->sc) {
-        float *sb[] = {sc.T, sc.Z, sc.Q1, sc.Q2, sc.Q3, sc.U, sc.V, sc.partial, sc.CAT};
+        float *sb[] = {sc.T, sc.Z, sc.Q0, sc.Q1, sc.Q2, sc.Q3, sc.U, sc.V, sc.partial, sc.CAT};
         if (sc.colsum) (void)hipFree(sc.colsum);
         for (float *p : sb) free_planes(p);
         if (sc.ev_fork) (void)hipEventDestroy(sc.ev_fork);
@@ -2948,6 +3024,7 @@ OJF_API void ojf_net_destroy(ojf_net *net)
         if (sc.ev_entry) (void)hipEventDestroy(sc.ev_entry);
         if (sc.side) (void)hipStreamDestroy(sc.side);
     }
+    if (net->colsum3) (void)hipFree(net->colsum3);
     if (net->ev_head_fork) (void)hipEventDestroy(net->ev_head_fork);
     if (net->ev_head_join) (void)hipEventDestroy(net->ev_head_join);
     if (net->head1) (void)hipStreamDestroy(net->head1);
@@ -3105,6 +3182,7 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
         ojf_net::Scratch &sc = net->sc[hd];
         rc = alloc_planes(&sc.T, np, cs);
         if (!rc) rc = alloc_planes(&sc.Z, np, 4 * cs);
+        if (!rc && hd == 0 && net->heads == 2) rc = alloc_planes(&sc.Q0, np, cs);
         if (!rc) rc = alloc_planes(&sc.Q1, np, cs);
         if (!rc) rc = alloc_planes(&sc.Q2, np, cs);
         if (!rc) rc = alloc_planes(&sc.Q3, np, cs);
@@ -3113,6 +3191,11 @@ OJF_API int ojf_net_create(ojf_net **out, int version, int n_points, int growth,
         if (!rc) rc = alloc_planes(&sc.partial, kSumBlocks, 256);
         if (!rc) rc = check_hip(hipMalloc(reinterpret_cast<void **>(&sc.colsum), sizeof(ColSums)), "hipMalloc");
         if (!rc) rc = check_hip(hipMemset(sc.colsum, 0, sizeof(ColSums)), "hipMemset");
+        if (!rc && hd == 0 && net->heads == 2) {
+            rc = check_hip(hipMalloc(reinterpret_cast<void **>(&net->colsum3), sizeof(ColSums)), "hipMalloc");
+            if (!rc) rc = check_hip(hipMemset(net->colsum3, 0, sizeof(ColSums)), "hipMemset");
+            if (!rc) rc = check_hip(hipStreamSynchronize(nullptr), "hipStreamSynchronize");  // (the heads' streams are non-blocking: see alloc_planes)
+        }
         if (!rc) rc = check_hip(hipStreamSynchronize(nullptr), "hipStreamSynchronize");  // (see alloc_planes)
         if (!rc) rc = check_hip(hipStreamCreateWithFlags(&sc.side, hipStreamNonBlocking), "hipStreamCreate");
         if (!rc) rc = check_hip(hipEventCreateWithFlags(&sc.ev_fork, event_flags()), "hipEventCreate");
@@ -3292,20 +3375,25 @@ static int forward_launches(ojf_net *net, float *est, int est_stride, hipStream_
             OJF_HIP(hipEventRecord(net->ev_head_fork, st));
             OJF_HIP(hipStreamWaitEvent(s1, net->ev_head_fork, 0));
         }
+        // two heads: each head's tail runs ITS half of vortex3's entry GEMM (the concatenation YY is then never written)
+        const bool halves = two && net->vortex[2].entry_wh[0] && net->vortex[2].entry_wh[1] && net->sc[0].Q0 && net->colsum3;
+        bool done1 = false;
         if (two) {
             if (run_dense(net, 1, s1)) return -2;
-            if (run_vortex(net, net->vortex[1], net->X[1], 0, net->YY, o4, s1, net->sc[1], nullptr, nullptr, false, nullptr, nullptr,
-                           net->chain_dense)) return -2;
+            if (run_vortex(net, net->vortex[1], net->X[1], 0, net->YY, o4, s1, net->sc[1], nullptr, nullptr, false,
+                           halves ? &net->vortex[2] : nullptr, &done1, net->chain_dense, halves ? 1 : -1, net->colsum3)) return -2;
         }
         if (run_dense(net, 0, st)) return -2;
         bool entry_done = false;  // single head: vortex0's tail runs vortex3's entry GEMM (its own output is never written)
         if (run_vortex(net, net->vortex[0], net->X[0], 0, net->YY, 0, st, net->sc[0], nullptr, nullptr, false,
-                       two ? nullptr : &net->vortex[2], &entry_done, net->chain_dense)) return -2;
+                       (two && !halves) ? nullptr : &net->vortex[2], &entry_done, net->chain_dense, halves ? 0 : -1, halves ? net->colsum3 : net->sc[0].colsum)) return -2;
         if (two && s1 != st) {
             OJF_HIP(hipEventRecord(net->ev_head_join, s1));
             OJF_HIP(hipStreamWaitEvent(st, net->ev_head_join, 0));
         }
-        if (run_vortex(net, net->vortex[2], net->YY, 0, net->Y3, 0, st, net->sc[0], head, &head_done, entry_done)) return -2;
+        if (halves && entry_done != done1) return fail("ojf_net_forward: internal error (one head ran its half of the entry GEMM, the other did not)");
+        if (run_vortex(net, net->vortex[2], net->YY, 0, net->Y3, 0, st, net->sc[0], head, &head_done, entry_done, nullptr, nullptr, false, -1,
+                       nullptr, (halves && entry_done) ? net->sc[1].Z : nullptr)) return -2;
     } else {
         if (run_dense(net, 0, st)) return -2;
         bool entry_done = false;

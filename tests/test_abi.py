@@ -84,3 +84,20 @@ def test_segconv_and_mesh_argument_validation_without_device():
     assert lib.ojf_mesh_workspace_bytes(1, 4, 4) == 0 and lib.ojf_mesh_workspace_bytes(65, 5, 3) == 4 * 1 * 1 * 64
     assert lib.ojf_mesh_extract(None, None, None, 4, 4, 4, 0.0, None, 1.0, None, 0, None, None, None, 0, None, None) != 0
     assert lib.ojf_points_within(None, 0, None, None, None, 1.0, 1, 1, 1, 0.5, None, None, None) != 0
+
+
+def test_many_scene_entry_points_validate_without_a_device():
+    """ojf_extract_many / ojf_integrate_many (round 6): job count and null jobs are refused before any HIP call; the ctypes job
+    structures have the C layout (sizes as a C compiler lays them out on x86-64)."""
+    import ctypes
+    lib = _lib.load()
+    assert ctypes.sizeof(_lib.ExtractJob) == 88 and ctypes.sizeof(_lib.IntegrateJob) == 128
+    assert lib.ojf_extract_many(0, None, 8, 8, 8, 4, 4, 9, -0.1, None) != 0
+    assert lib.ojf_extract_many(_lib.MAX_SCENES + 1, (_lib.ExtractJob * 9)(), 8, 8, 8, 4, 4, 9, -0.1, None) != 0
+    jobs = (_lib.ExtractJob * 2)()
+    assert lib.ojf_extract_many(2, jobs, 8, 8, 8, 4, 4, 9, -0.1, None) != 0 and b'null' in lib.ojf_last_error()
+    assert lib.ojf_extract_many(2, jobs, 8, 8, 8, 4, 4, 8, -0.1, None) != 0 and b'odd' in lib.ojf_last_error()
+    ij = (_lib.IntegrateJob * 2)()
+    assert lib.ojf_integrate_many(2, ij, 9, 7, 0.1, 8, 8, 8, 4, 4, None) != 0 and b'null' in lib.ojf_last_error()
+    assert lib.ojf_integrate_many(0, ij, 9, 7, 0.1, 8, 8, 8, 4, 4, None) != 0
+    assert lib.ojf_integrate_many(2, ij, 9, 11, 0.1, 8, 8, 8, 4, 4, None) != 0 and b'n_tail' in lib.ojf_last_error()

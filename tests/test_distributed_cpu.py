@@ -174,3 +174,52 @@ def test_flat_clip_equals_clip_grad_norm():
         assert abs(float(n0) - float(n1)) <= 1e-6 * float(n1)
         for p, q in zip(net.parameters(), ref.parameters()):
             assert torch.allclose(p.grad, q.grad, rtol=1e-6, atol=1e-9)
+
+
+# ---- round 6: a process group of ONE rank, ranks pinned to disjoint cores -------------------------------------------------
+def _one_rank_worker(rank, out):
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR'):
+        os.environ.pop(k, None)
+    from online_joint_depthfusion_and_semantic_amd.distributed import init_from_env
+    r, w, l = init_from_env(backend='gloo', force_group=True)  # nobody launched us: a rendezvous with ourselves on 127.0.0.1
+    net = torch.nn.Linear(7, 3)
+    red = FlatGradientAllReduce(net)
+    net(torch.ones(2, 7)).sum().backward()
+    before = red.flat.clone()
+    red.reduce()  # goes through the collective (the identity on one rank) and does NOT divide
+    out[0] = (r, w, l, dist.is_initialized(), dist.get_world_size(), bool(torch.equal(before, red.flat)), float(before.abs().sum()) > 0)
+    dist.destroy_process_group()
+
+
+def test_process_group_of_one_rank():
+    """distributed.init_from_env(force_group=True): the path bench.py --train --force-group takes on the one-GPU box (there on the
+    nccl backend = RCCL) - rendezvous with itself on 127.0.0.1, FlatGradientAllReduce.reduce() through dist.all_reduce."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_one_rank_worker, args=(out,), nprocs=1, join=True)
+    assert out[0] == (0, 1, 0, True, 1, True, True)
+
+
+def _pin_worker(rank, world, out):
+    from online_joint_depthfusion_and_semantic_amd.distributed import pin_rank_to_cores
+    before = sorted(os.sched_getaffinity(0))
+    tag = pin_rank_to_cores(rank, world)
+    out[rank] = (before, sorted(os.sched_getaffinity(0)), tag)
+
+
+def test_ranks_pin_themselves_to_disjoint_core_slices():
+    import pytest
+    cores = sorted(os.sched_getaffinity(0))
+    if len(cores) < 2:
+        pytest.skip('one core')
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_pin_worker, args=(world, out), nprocs=world, join=True)
+    per = len(cores) // world
+    for r in range(world):
+        before, after, tag = out[r]
+        assert before == cores and after == cores[r * per:(r + 1) * per] and tag
+    assert not set(out[0][1]) & set(out[1][1])
+    from online_joint_depthfusion_and_semantic_amd.distributed import pin_rank_to_cores
+    assert pin_rank_to_cores(0, 1) == '' and sorted(os.sched_getaffinity(0)) == cores  # one rank: untouched
