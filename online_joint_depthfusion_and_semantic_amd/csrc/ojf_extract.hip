@@ -30,7 +30,20 @@ struct ExtractArgs {
     int net_cs4;
     int *ovf;  // split-fp16 range flag of the net (or NULL)
     int net_split;  // the net keeps this slot as split planes (split_planes4)
+    int n_tiles = 0;  // extract_tile_kernel: pixel tiles of the frame (the grid is that rounded up to a multiple of 8: XCD bands)
 };
+
+// Pixel tile of a block of extract_tile_kernel: kTileW columns x kTileH rows, the 64 lanes of a wave walk DOWN the columns (lane = column *
+// kTileH + row).  Round 6: with 64 consecutive pixels of an image ROW per wave (rounds 1-5) the lanes of a gather hit ~40-64 different 128-byte
+// lines - an image row runs along the camera's right vector, which for an upright camera lies in the volume's x-y plane, where neighbouring
+// voxels are 512 bytes (one z row) or more apart - and the texture-address path takes one cycle per line.  Image COLUMNS run along the
+// camera's down vector, for an upright camera the volume's contiguous z axis: 16 rows of a column are ~10 voxels of ONE z row = one line.
+#ifndef OJF_EXTRACT_TW
+#define OJF_EXTRACT_TW 4  // (A/B builds: -DOJF_EXTRACT_TW=64 -DOJF_EXTRACT_TH=1 = the row tiles of rounds 1-5; 8 x 8, 2 x 32 measured too)
+#define OJF_EXTRACT_TH 16
+#endif
+constexpr int kTileW = OJF_EXTRACT_TW, kTileH = OJF_EXTRACT_TH;
+static_assert(kTileW * kTileH == 64, "one wave = one pixel tile");
 
 constexpr int kNetPitch = 36;  // floats per pixel of the LDS transpose tile (<= 8 channel groups + padding against bank conflicts)
 
@@ -129,9 +142,14 @@ __device__ __forceinline__ void extract_tile_body(const ExtractArgs &a, const Ca
     __shared__ float pcl[3][64];
     const int N = a.h * a.w;
     const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
-    const int n = banded_block_x() * 64 + lane;  // one band of the image per XCD: neighbouring rays gather the same lines
+    const int ptile = banded_block_x();  // one band of tile rows per XCD: neighbouring rays gather the same lines
+    if (ptile >= a.n_tiles) return;      // (block-uniform: a padding block of the banded grid)
+    const int tiles_x = (a.w + kTileW - 1) / kTileW;
+    const int ty = ptile / tiles_x, tx = ptile - ty * tiles_x;
+    const int r = ty * kTileH + lane % kTileH, c = tx * kTileW + lane / kTileH;
+    const bool valid = r < a.h && c < a.w;
+    const int n = valid ? r * a.w + c : N;  // (n >= N: no pixel)
     if (k == 0 && n < N) {
-        const int r = n / a.w, c = n - r * a.w;
         float pw[3];
         double cv[3], dir[3];
         unproject(r, c, a.depth[n], cam, pw);
@@ -166,13 +184,15 @@ __device__ __forceinline__ void extract_tile_body(const ExtractArgs &a, const Ca
         }
     }
     __syncthreads();
-    const int n0 = n - lane;  // first pixel of the block
     bool bad = false;
     for (int t = threadIdx.x; t < 64 * a.net_cs4; t += blockDim.x) {
+        // stores walk ALONG the rows (the planes are row-major): px -> (row px / kTileW, column px % kTileW) = 64 contiguous bytes per row
         const int cg = t >> 6, px = t & 63;
-        if (n0 + px >= N) continue;
-        const float4 v = *reinterpret_cast<const float4 *>(tile + px * kNetPitch + 4 * cg);
-        a.net_x0[(size_t)cg * N + n0 + px] = a.net_split ? split_planes4(v) : v;
+        const int rl = px / kTileW, cl = px - rl * kTileW;
+        const int rr = ty * kTileH + rl, cc = tx * kTileW + cl;
+        if (rr >= a.h || cc >= a.w) continue;
+        const float4 v = *reinterpret_cast<const float4 *>(tile + (cl * kTileH + rl) * kNetPitch + 4 * cg);
+        a.net_x0[(size_t)cg * N + rr * a.w + cc] = a.net_split ? split_planes4(v) : v;
         bad = bad || fabsf(v.x) > 65504.0f || fabsf(v.y) > 65504.0f || fabsf(v.z) > 65504.0f || fabsf(v.w) > 65504.0f;
     }
     if (bad && a.ovf) guard_raise(a.ovf, 1);  // split-fp16 range guard of the net input (NaN passes, like everywhere else)
@@ -190,6 +210,8 @@ __global__ __launch_bounds__(64 * kMaxTilePoints) void extract_tile_many_kernel(
 {
     extract_tile_body(m.a[blockIdx.y], m.cam[blockIdx.y]);
 }
+
+static inline int extract_tiles(int h, int w) { return ((w + kTileW - 1) / kTileW) * ((h + kTileH - 1) / kTileH); }
 
 // any n_points: one lane per (sample k, pixel n), k-major; every item computes its own ray frame
 __global__ __launch_bounds__(256) void extract_kernel(ExtractArgs a, Camera cam)
@@ -228,9 +250,10 @@ OJF_API int ojf_extract(const float *depth, const float *Ki, const float *E, con
     if (!(res > 0.0)) return fail("ojf_extract: resolution must be > 0");
     ExtractArgs a{depth, tsdf, wgt, out_values, out_weights, dbg_idx, dbg_w, dbg_pts, dbg_pcl,
                   X, Y, Z, h, w, n_points, out_stride, out_layout, pad_value, nullptr, 0, nullptr, 0};
+    a.n_tiles = extract_tiles(h, w);
     const Camera cam = make_camera(Ki, E, origin, res);
     if (n_points <= kMaxTilePoints) {
-        hipLaunchKernelGGL(extract_tile_kernel, dim3((h * w + 63) / 64), dim3(64 * n_points), 0, as_stream(stream), a, cam);
+        hipLaunchKernelGGL(extract_tile_kernel, dim3((a.n_tiles + 7) / 8 * 8), dim3(64 * n_points), 0, as_stream(stream), a, cam);
     } else {
         const int items = h * w * n_points;
         hipLaunchKernelGGL(extract_kernel, dim3((items + 255) / 256), dim3(256), 0, as_stream(stream), a, cam);
@@ -254,8 +277,9 @@ OJF_API int ojf_extract_to_net(const float *depth, const float *Ki, const float 
         return fail("ojf_extract_to_net: unsupported n_points / slot width");
     ExtractArgs a{depth, tsdf, wgt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                   X, Y, Z, h, w, n_points, h * w, 2, pad_value, reinterpret_cast<float4 *>(slot.x0), slot.cs4, slot.ovf, slot.split};
+    a.n_tiles = extract_tiles(h, w);
     const Camera cam = make_camera(Ki, E, origin, res);
-    hipLaunchKernelGGL(extract_tile_kernel, dim3((h * w + 63) / 64), dim3(64 * n_points), 0, as_stream(stream), a, cam);
+    hipLaunchKernelGGL(extract_tile_kernel, dim3((a.n_tiles + 7) / 8 * 8), dim3(64 * n_points), 0, as_stream(stream), a, cam);
     return check_hip(hipGetLastError(), "ojf_extract_to_net launch");
 }
 
@@ -291,8 +315,9 @@ OJF_API int ojf_extract_many(int n, const ojf_extract_job *jobs, int X, int Y, i
             m.a[i] = ExtractArgs{j.depth_dev, j.tsdf_dev, j.weights_dev, j.out_values_dev, j.out_weights_dev, nullptr, nullptr, nullptr, nullptr,
                                  X, Y, Z, h, w, n_points, j.out_stride, j.out_layout, pad_value, nullptr, 0, nullptr, 0};
         }
+        m.a[i].n_tiles = extract_tiles(h, w);
         m.cam[i] = make_camera(j.Kinv_host, j.E_host, j.origin_host, j.resolution);
     }
-    hipLaunchKernelGGL(extract_tile_many_kernel, dim3((h * w + 63) / 64, n), dim3(64 * n_points), 0, as_stream(stream), m);
+    hipLaunchKernelGGL(extract_tile_many_kernel, dim3((extract_tiles(h, w) + 7) / 8 * 8, n), dim3(64 * n_points), 0, as_stream(stream), m);
     return check_hip(hipGetLastError(), "ojf_extract_many launch");
 }

@@ -686,7 +686,14 @@ class Pipeline(torch.nn.Module):
             streams.append(self._side_stream([main] + streams))  # (a stream that runs beside the caller's and the other slots')
         enqueued = 0
         try:
-            if self._integrate_mode == MODE_FAST and self.config.SETTINGS.get('fuse_many_launches', 'joint') == 'joint':
+            import os
+            # 'auto' (default): the joint launches for two scenes, per-slot launches from three on - measured on one box (round 6,
+            # profiles/r06_many_scene_launches.txt): joint 2246 against 2220 frames/s at S = 2, 2650 against 2747 at S = 4 (the two joins -
+            # every net waits for the gather of ALL scenes, the scatter for ALL nets - cost more than the shared launches save)
+            how = os.environ.get('OJF_FUSE_MANY') or self.config.SETTINGS.get('fuse_many_launches', 'auto')  # (env: A/B runs)
+            if how == 'auto':
+                how = 'joint' if len(batches) <= 2 else 'slots'
+            if self._integrate_mode == MODE_FAST and how == 'joint':
                 self._fuse_many_joint(batches, database, sems, fp, main, streams)
                 enqueued = len(batches)
             else:  # PARITY integrate (its sort is per scene) / A-B switch: every slot runs fuse()'s own launches on its stream

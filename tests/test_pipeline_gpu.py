@@ -434,8 +434,9 @@ def test_fuse_training_train_mode_matches_reference_golden(cuda, engine):
 
 
 # ---- several scenes per call ---------------------------------------------------------------------------
+@pytest.mark.parametrize('launches', ['joint', 'slots'])
 @pytest.mark.parametrize('sem', [False, True])
-def test_fuse_many_equals_separate_fuse_calls(cuda, sem):
+def test_fuse_many_equals_separate_fuse_calls(cuda, sem, launches):
     """Pipeline.fuse_many runs one frame of each of S scenes side by side (slot i: own engine, est rows, workspace, stream):
     every volume of every scene must come out bit for bit as from S separate fuse() calls per step - FAST mode is
     deterministic and the scenes share nothing but the read-only weights."""
@@ -446,6 +447,7 @@ def test_fuse_many_equals_separate_fuse_calls(cuda, sem):
     def build():
         cfg = default_config(h, w, semantics=sem, use_semantics=sem, integrate_mode='fast')
         cfg.SETTINGS.device = str(cuda)
+        cfg.SETTINGS.fuse_many_launches = launches  # (default 'auto': joint launches for two scenes, per-slot launches from three on)
         ds = SyntheticDataset(h, w, grid, 8, scenes=scenes)
         db = Database(ds, database_config(cfg))
         torch.manual_seed(3)
@@ -738,7 +740,7 @@ def test_fuse_sequence_prefetch_of_a_dropped_chunk_is_never_taken(cuda):
     assert pre.__dict__['_prefetch']['hits'] == 1
 
 
-@pytest.mark.parametrize('entry', ['fuse_sequence', 'fuse_many'])
+@pytest.mark.parametrize('entry', ['fuse_sequence', 'fuse_many', 'fuse_many_joint'])
 def test_range_guard_policy_f32_covers_fuse_sequence_and_fuse_many(cuda, entry):
     """guard_policy 'f32' through the chunked / multi-scene entry points: the tripped frames are fused again on the fp32-input
     path, in order - volumes bit for bit those of a pipeline that ran arithmetic f32 from the first frame through fuse()."""
@@ -751,6 +753,7 @@ def test_range_guard_policy_f32_covers_fuse_sequence_and_fuse_many(cuda, entry):
         cfg.SETTINGS.device = str(cuda)
         cfg.FUSION_MODEL.guard_policy = policy
         cfg.FUSION_MODEL.arithmetic = arithmetic
+        cfg.SETTINGS.fuse_many_launches = 'joint' if entry == 'fuse_many_joint' else 'slots'
         ds = SyntheticDataset(h, w, grid, 8, scenes=scenes)
         db = Database(ds, database_config(cfg))
         torch.manual_seed(5)
@@ -769,7 +772,7 @@ def test_range_guard_policy_f32_covers_fuse_sequence_and_fuse_many(cuda, entry):
         return {k: (v.to(cuda) if torch.is_tensor(v) else v) for k, v in ds.streams[s].batch(i).items()}
     with torch.no_grad(), pytest.warns(RuntimeWarning, match='switched to f32'):
         for i in range(steps):
-            if entry == 'fuse_many':
+            if entry.startswith('fuse_many'):
                 pipe.fuse_many([batch(ds_a, s, i) for s in scenes], db_a, cuda)
             else:  # a chunk = the step's frames of all scenes in stream order
                 pipe.fuse_sequence([batch(ds_a, s, i) for s in scenes], db_a, cuda)
