@@ -8,6 +8,9 @@
 // root - a third of the per-item instruction count) ONCE and hands them to the other waves through 3 KB of LDS; the
 // kernel is bound by instruction issue of the fp64 index math and the gather latency, not by bytes: the per-frame
 // gather footprint (<= a few MB of 128-B lines) lives in L2/MALL.
+#include <cmath>
+#include <cstdlib>
+
 #include "ojf_common.h"
 
 namespace ojf {
@@ -38,12 +41,8 @@ struct ExtractArgs {
 // lines - an image row runs along the camera's right vector, which for an upright camera lies in the volume's x-y plane, where neighbouring
 // voxels are 512 bytes (one z row) or more apart - and the texture-address path takes one cycle per line.  Image COLUMNS run along the
 // camera's down vector, for an upright camera the volume's contiguous z axis: 16 rows of a column are ~10 voxels of ONE z row = one line.
-#ifndef OJF_EXTRACT_TW
-#define OJF_EXTRACT_TW 4  // (A/B builds: -DOJF_EXTRACT_TW=64 -DOJF_EXTRACT_TH=1 = the row tiles of rounds 1-5; 8 x 8, 2 x 32 measured too)
-#define OJF_EXTRACT_TH 16
-#endif
-constexpr int kTileW = OJF_EXTRACT_TW, kTileH = OJF_EXTRACT_TH;
-static_assert(kTileW * kTileH == 64, "one wave = one pixel tile");
+// Both orientations are built (4 x 16: lanes walk down columns; 16 x 4: along rows) and the host picks per frame the image axis whose
+// world direction has the larger component along the volume's z axis (extract_tile_shape); the same bits either way.
 
 constexpr int kNetPitch = 36;  // floats per pixel of the LDS transpose tile (<= 8 channel groups + padding against bank conflicts)
 
@@ -136,8 +135,10 @@ __device__ __forceinline__ void extract_item(const ExtractArgs &a, int n, int k,
 }
 
 // n_points <= kMaxTilePoints: blockDim.x = 64 * n_points, wave k = sample k of the block's 64 pixels
+template <int kTileW, int kTileH>
 __device__ __forceinline__ void extract_tile_body(const ExtractArgs &a, const Camera &cam)
 {
+    static_assert(kTileW * kTileH == 64, "one wave = one pixel tile");
     __shared__ double frame[6][64];
     __shared__ float pcl[3][64];
     const int N = a.h * a.w;
@@ -198,7 +199,8 @@ __device__ __forceinline__ void extract_tile_body(const ExtractArgs &a, const Ca
     if (bad && a.ovf) guard_raise(a.ovf, 1);  // split-fp16 range guard of the net input (NaN passes, like everywhere else)
 }
 
-__global__ __launch_bounds__(64 * kMaxTilePoints) void extract_tile_kernel(ExtractArgs a, Camera cam) { extract_tile_body(a, cam); }
+template <int TW, int TH>
+__global__ __launch_bounds__(64 * kMaxTilePoints) void extract_tile_kernel(ExtractArgs a, Camera cam) { extract_tile_body<TW, TH>(a, cam); }
 
 // The frames of up to kMaxScenes SCENES in one launch (ojf_extract_many, round 6): blockIdx.y = scene, every scene with its
 // own volumes, camera and outputs.  One frame's launch is one round of 1200 blocks that each walk a chain of dependent steps
@@ -206,12 +208,25 @@ __global__ __launch_bounds__(64 * kMaxTilePoints) void extract_tile_kernel(Extra
 // fill the CUs while other blocks wait - which S launches on S streams do not (they take turns on the queue).  The same
 // blocks, the same code per block: the same bits as S separate calls.
 struct ExtractMany { ExtractArgs a[OJF_MAX_SCENES]; Camera cam[OJF_MAX_SCENES]; };
+template <int TW, int TH>
 __global__ __launch_bounds__(64 * kMaxTilePoints) void extract_tile_many_kernel(ExtractMany m)
 {
-    extract_tile_body(m.a[blockIdx.y], m.cam[blockIdx.y]);
+    extract_tile_body<TW, TH>(m.a[blockIdx.y], m.cam[blockIdx.y]);
 }
 
-static inline int extract_tiles(int h, int w) { return ((w + kTileW - 1) / kTileW) * ((h + kTileH - 1) / kTileH); }
+// true: 4 x 16 tiles (lanes walk down image columns), false: 16 x 4 (along rows).  E = rows of the 3 x 4 camera-to-world matrix: E[8] / E[9] are the
+// volume-z components of the camera's x (image row direction) and y (image column direction) axes.
+static inline bool extract_columns(const float *E)
+{
+    static const int force = getenv("OJF_EXTRACT_TILE") ? atoi(getenv("OJF_EXTRACT_TILE")) : 0;  // A/B: 1 columns, 2 rows
+    if (force) return force == 1;
+    return std::fabs(E[9]) >= std::fabs(E[8]);
+}
+static inline int extract_tiles(int h, int w, bool columns)
+{
+    const int tw = columns ? 4 : 16, th = columns ? 16 : 4;
+    return ((w + tw - 1) / tw) * ((h + th - 1) / th);
+}
 
 // any n_points: one lane per (sample k, pixel n), k-major; every item computes its own ray frame
 __global__ __launch_bounds__(256) void extract_kernel(ExtractArgs a, Camera cam)
@@ -250,10 +265,12 @@ OJF_API int ojf_extract(const float *depth, const float *Ki, const float *E, con
     if (!(res > 0.0)) return fail("ojf_extract: resolution must be > 0");
     ExtractArgs a{depth, tsdf, wgt, out_values, out_weights, dbg_idx, dbg_w, dbg_pts, dbg_pcl,
                   X, Y, Z, h, w, n_points, out_stride, out_layout, pad_value, nullptr, 0, nullptr, 0};
-    a.n_tiles = extract_tiles(h, w);
+    const bool cols = extract_columns(E);
+    a.n_tiles = extract_tiles(h, w, cols);
     const Camera cam = make_camera(Ki, E, origin, res);
     if (n_points <= kMaxTilePoints) {
-        hipLaunchKernelGGL(extract_tile_kernel, dim3((a.n_tiles + 7) / 8 * 8), dim3(64 * n_points), 0, as_stream(stream), a, cam);
+        if (cols) hipLaunchKernelGGL((extract_tile_kernel<4, 16>), dim3((a.n_tiles + 7) / 8 * 8), dim3(64 * n_points), 0, as_stream(stream), a, cam);
+        else hipLaunchKernelGGL((extract_tile_kernel<16, 4>), dim3((a.n_tiles + 7) / 8 * 8), dim3(64 * n_points), 0, as_stream(stream), a, cam);
     } else {
         const int items = h * w * n_points;
         hipLaunchKernelGGL(extract_kernel, dim3((items + 255) / 256), dim3(256), 0, as_stream(stream), a, cam);
@@ -277,9 +294,11 @@ OJF_API int ojf_extract_to_net(const float *depth, const float *Ki, const float 
         return fail("ojf_extract_to_net: unsupported n_points / slot width");
     ExtractArgs a{depth, tsdf, wgt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                   X, Y, Z, h, w, n_points, h * w, 2, pad_value, reinterpret_cast<float4 *>(slot.x0), slot.cs4, slot.ovf, slot.split};
-    a.n_tiles = extract_tiles(h, w);
+    const bool cols = extract_columns(E);
+    a.n_tiles = extract_tiles(h, w, cols);
     const Camera cam = make_camera(Ki, E, origin, res);
-    hipLaunchKernelGGL(extract_tile_kernel, dim3((a.n_tiles + 7) / 8 * 8), dim3(64 * n_points), 0, as_stream(stream), a, cam);
+    if (cols) hipLaunchKernelGGL((extract_tile_kernel<4, 16>), dim3((a.n_tiles + 7) / 8 * 8), dim3(64 * n_points), 0, as_stream(stream), a, cam);
+    else hipLaunchKernelGGL((extract_tile_kernel<16, 4>), dim3((a.n_tiles + 7) / 8 * 8), dim3(64 * n_points), 0, as_stream(stream), a, cam);
     return check_hip(hipGetLastError(), "ojf_extract_to_net launch");
 }
 
@@ -315,9 +334,13 @@ OJF_API int ojf_extract_many(int n, const ojf_extract_job *jobs, int X, int Y, i
             m.a[i] = ExtractArgs{j.depth_dev, j.tsdf_dev, j.weights_dev, j.out_values_dev, j.out_weights_dev, nullptr, nullptr, nullptr, nullptr,
                                  X, Y, Z, h, w, n_points, j.out_stride, j.out_layout, pad_value, nullptr, 0, nullptr, 0};
         }
-        m.a[i].n_tiles = extract_tiles(h, w);
         m.cam[i] = make_camera(j.Kinv_host, j.E_host, j.origin_host, j.resolution);
     }
-    hipLaunchKernelGGL(extract_tile_many_kernel, dim3((extract_tiles(h, w) + 7) / 8 * 8, n), dim3(64 * n_points), 0, as_stream(stream), m);
+    // one tile shape per launch: the first scene's camera decides (any shape computes the same; the scenes of a call are usually filmed alike)
+    const bool cols = extract_columns(jobs[0].E_host);
+    for (int i = 0; i < n; ++i) m.a[i].n_tiles = extract_tiles(h, w, cols);
+    const dim3 grid((extract_tiles(h, w, cols) + 7) / 8 * 8, n);
+    if (cols) hipLaunchKernelGGL((extract_tile_many_kernel<4, 16>), grid, dim3(64 * n_points), 0, as_stream(stream), m);
+    else hipLaunchKernelGGL((extract_tile_many_kernel<16, 4>), grid, dim3(64 * n_points), 0, as_stream(stream), m);
     return check_hip(hipGetLastError(), "ojf_extract_many launch");
 }

@@ -540,3 +540,31 @@ def test_many_scene_launches_refuse_shared_state(cuda):
               out_values=out, out_weights=torch.empty_like(out))
     with pytest.raises(_lib.OjfError, match='same output'):
         ops.extract_many([ej, dict(ej)])
+
+
+@pytest.mark.parametrize('h,w,grid', [(120, 160, 64), (13, 15, 32), (48, 64, 64)])
+def test_extract_bit_exact_for_a_rolled_camera(cuda, h, w, grid):
+    """extract_tile_kernel comes in two tile orientations (lanes down the image columns / along the rows) and the host picks per frame
+    the image axis that runs along the volume's contiguous z axis (csrc/ojf_extract.hip extract_columns).  An upright camera takes the
+    column tiles (every other extract test); the same stream filmed with the camera ROLLED by 90 degrees takes the row tiles: all
+    outputs - indices, corner weights, points, sample rows, sample planes, and the net-input form through Pipeline - bit for bit the oracle's."""
+    st = make_stream(h, w, grid)
+    rng = np.random.default_rng(5)
+    tsdf = rng.uniform(-0.1, 0.1, (grid,) * 3).astype(np.float16)
+    wgt = rng.uniform(0, 6, (grid,) * 3).astype(np.float16)
+    g_tsdf, g_wgt = _t(tsdf, cuda), _t(wgt, cuda)
+    roll = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1]], dtype=np.float32)
+    for i in range(2):
+        fi = frame_inputs(st, i)
+        E = fi['E'].reshape(3, 4).copy()
+        assert abs(E[2, 1]) > abs(E[2, 0])  # upright: the camera's y axis carries the volume's z
+        E[:, :3] = E[:, :3] @ roll
+        assert abs(E[2, 0]) > abs(E[2, 1])  # rolled: now the x axis does
+        E = np.ascontiguousarray(E.reshape(12))
+        ref = oracle.extract(fi['depth'], fi['Ki'], E, st.origin, st.resolution, tsdf, wgt, debug=True)
+        out = ops.extract(_t(fi['depth'], cuda), fi['Ki'], E, st.origin, st.resolution, g_tsdf, g_wgt, debug=True)
+        for key in ref:
+            assert n_mismatch(out[key].cpu().numpy(), ref[key]) == 0, (key, i)
+        planes = ops.extract(_t(fi['depth'], cuda), fi['Ki'], E, st.origin, st.resolution, g_tsdf, g_wgt, planes=True)
+        assert n_mismatch(planes['fusion_values'].t().contiguous().cpu().numpy(), ref['fusion_values']) == 0
+        assert n_mismatch(planes['fusion_weights'].t().contiguous().cpu().numpy(), ref['fusion_weights']) == 0

@@ -269,9 +269,10 @@ def test_nan_inputs_propagate_like_the_reference(cuda, arith):
     eng.close()
 
 
+@pytest.mark.parametrize('rolled', [False, True])
 @pytest.mark.parametrize('version', ['v3', 'v2'])
 @pytest.mark.parametrize('h,w,grid', [(60, 80, 64), (37, 53, 32), (240, 320, 128)])
-def test_extract_to_net_equals_extract_plus_prepare(cuda, version, h, w, grid):
+def test_extract_to_net_equals_extract_plus_prepare(cuda, version, h, w, grid, rolled):
     """ojf_extract_to_net (the extractor writes the net's input planes itself) against ojf_extract + ojf_net_prepare_input on
     a partly filled volume: the net output must be identical bit for bit (ragged frame sizes: the last block of 64
     pixels is partial; rays leaving the volume: pad values)."""
@@ -290,6 +291,11 @@ def test_extract_to_net_equals_extract_plus_prepare(cuda, version, h, w, grid):
     eng = FusionNetEngine(net, h, w, cuda)
     assert eng.fused_input
     Ki, E = fi['Ki'], fi['E']
+    if rolled:  # camera rolled by 90 degrees: the extractor takes its row tiles instead of the column tiles (csrc/ojf_extract.hip)
+        import numpy as np
+        E = E.reshape(3, 4).copy()
+        E[:, :3] = E[:, :3] @ np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1]], dtype=np.float32)
+        E = np.ascontiguousarray(E.reshape(12))
     origin, res = st.origin, st.resolution
     fv = torch.empty((9, h * w), device=cuda)
     fw = torch.empty((9, h * w), device=cuda)
