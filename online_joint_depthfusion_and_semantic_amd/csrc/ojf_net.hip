@@ -2839,11 +2839,8 @@ static int run_vortex(ojf_net *net, Vortex &v, const float *in, int in_g0, float
         ea.split_groups = split ? c4 : 0;
         ea.in_split = in_split ? 1 : 0;
         const dim3 grid(chain_blocks(net)), block(ojf::kChainThreads);
-        static const int entry_mt = getenv("OJF_ENTRY_MT") ? atoi(getenv("OJF_ENTRY_MT")) : 1;  // A/B switch (round 6): pixel tiles per wave
-        if (entry_mt == 2 && v.entry_ntin == 8 && h16) {
-            const int strips = (net->npix + 31) / 32;
-            hipLaunchKernelGGL((entry1x1_kernel<OJF_ARITH_F16X3, 2, 8, 5>), dim3(round_up((strips + ojf::kChainWaves - 1) / ojf::kChainWaves, 8)), block, 0, st, ea);
-        } else
+        // (two pixel tiles per wave - half the blocks, half the weight stream per pixel - measured 22.2 against 23.7 us and changes the
+        // rounding of the channel sums: not kept, profiles/r06_fusion_net_experiments.txt)
         if (v.entry_ntin == 16 && h16) hipLaunchKernelGGL((entry1x1_kernel<OJF_ARITH_F16X3, 1, 16, 5>), grid, block, 0, st, ea);
         else if (v.entry_ntin == 16) hipLaunchKernelGGL((entry1x1_kernel<OJF_ARITH_F32, 1, 16, 5>), grid, block, 0, st, ea);
         else if (h16) hipLaunchKernelGGL((entry1x1_kernel<OJF_ARITH_F16X3, 1, 8, 5>), grid, block, 0, st, ea);
