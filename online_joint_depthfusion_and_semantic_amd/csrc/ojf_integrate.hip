@@ -33,7 +33,21 @@ constexpr unsigned int kEmpty = 0xffffffffu;
 // (host count over the bench streams at 320x240 -> 256^3 and 640x480 -> 512^3; 8 x 8: 730-810), still inside the 2048-slot
 // hash; a voxel now receives 2.1 instead of 2.6-2.9 records per frame, and 600 blocks at 320x240 are ONE round over the
 // 768 block slots of the chip where 1200 were 1.56 (= two) rounds of a latency-bound kernel.
-constexpr int kTileW = 16, kTileH = 8, kTilePix = kTileW * kTileH;
+// Pixel tile of an accumulate block.  OJF_ACC_TILE = 1 (round 6): 8 columns x 16 rows with the tile's pixels numbered DOWN the columns, so
+// that the lanes of a wave (64 consecutive pixel numbers at one ray offset) walk along the image axis that, for an upright camera, is
+// the volume's contiguous z axis (what pays in extract_tile_kernel, profiles/r06_extract_tile_shape.txt): integrate 57.2 -> 56.0 us in a
+// same-box A/B, the semantic form unchanged; 0: 16 x 8, row-major numbering (rounds 3-5).  Any tiling gives the same volumes (integer sums,
+// entry-id maxima).  Measured alongside and NOT kept: the finalize kernel reading the tile's records in order instead of a first-touch list
+// (one dependent hop less per voxel, but every record is read by an otherwise idle lane): +2 us.
+#ifndef OJF_ACC_TILE
+#define OJF_ACC_TILE 1
+#endif
+constexpr int kTileW = OJF_ACC_TILE ? 8 : 16, kTileH = OJF_ACC_TILE ? 16 : 8, kTilePix = kTileW * kTileH;
+__device__ __forceinline__ void tile_pixel(int p, int &rl, int &cl)  // pixel number inside the tile -> (row, column) inside the tile
+{
+    if (OJF_ACC_TILE) { cl = p / kTileH; rl = p - cl * kTileH; }
+    else { rl = p / kTileW; cl = p - rl * kTileW; }
+}
 
 static size_t tile_count(int h, int w) { return (size_t)((h + kTileH - 1) / kTileH) * ((w + kTileW - 1) / kTileW); }
 // records / first touches: a 2048-element slice per tile, then room for every entry that found its tile's hash full
@@ -106,7 +120,9 @@ __device__ __forceinline__ void accumulate_tiled_body(const IntegrateArgs &a, co
     if (blockIdx.x == 0 && threadIdx.x == 0) a.counters[kGuardLatch] = guard_set(a) ? 1u : 0u;
     if (threadIdx.x < kTilePix) {  // once per pixel instead of once per (pixel, sample): three fp64 divisions and a sqrt each
         const int p = threadIdx.x;
-        const int r = ty * kTileH + p / kTileW, c = tx * kTileW + p % kTileW;
+        int rl, cl;
+            tile_pixel(p, rl, cl);
+            const int r = ty * kTileH + rl, c = tx * kTileW + cl;
         if (r < a.h && c < a.w) {
             float pw[3];
             double cv[3], dir[3];
@@ -127,7 +143,9 @@ __device__ __forceinline__ void accumulate_tiled_body(const IntegrateArgs &a, co
     if constexpr (!WCOMB) {
         for (int item = threadIdx.x; item < kTilePix * a.n_tail; item += kAccThreads) {
             const int k = item / kTilePix, p = item % kTilePix;
-            const int r = ty * kTileH + p / kTileW, c = tx * kTileW + p % kTileW;
+            int rl, cl;
+            tile_pixel(p, rl, cl);
+            const int r = ty * kTileH + rl, c = tx * kTileW + cl;
             if (r >= a.h || c >= a.w) continue;
             const int n = r * a.w + c;
             const float z = frame_depth(a, n);
@@ -182,7 +200,9 @@ __device__ __forceinline__ void accumulate_tiled_body(const IntegrateArgs &a, co
         for (int item0 = threadIdx.x - lane; item0 < kTilePix * a.n_tail; item0 += kAccThreads) {
             const int item = item0 + lane;
             const int k = item / kTilePix, p = item % kTilePix;
-            const int r = ty * kTileH + p / kTileW, c = tx * kTileW + p % kTileW;
+            int rl, cl;
+            tile_pixel(p, rl, cl);
+            const int r = ty * kTileH + rl, c = tx * kTileW + cl;
             bool live = item < kTilePix * a.n_tail && r < a.h && c < a.w;
             const int n = live ? r * a.w + c : 0;
             const float z = live ? frame_depth(a, n) : 0.0f;
