@@ -547,6 +547,8 @@ class TrainCase:
         from online_joint_depthfusion_and_semantic_amd.loss import FusionLoss
         cfg = _training_defaults(default_config(h, w))
         cfg.SETTINGS.device = str(dev)
+        if os.environ.get('OJF_BENCH_TRAIN_OVERLAP', '') != '':  # A/B switch
+            cfg.FUSION_MODEL.train_overlap = os.environ['OJF_BENCH_TRAIN_OVERLAP'] not in ('0',)
         self.cfg, self.dev, self.accum = cfg, dev, accum
         n_distinct = min(n_frames, DISTINCT_FRAMES)
         self.st = SyntheticStream(h, w, grid, max(n_distinct, 40), scene='room_%d' % rank, seed=1911 + rank)
@@ -586,16 +588,17 @@ class TrainCase:
             # train_fusion.py:172 adds loss.item() to a window that is read every log_freq frames; summed on the device
             # and read once per timed loop here (the same numbers, without a host round trip per frame)
             self.loss_sum = loss.detach() if self.loss_sum is None else self.loss_sum + loss.detach()
-        if self.cfg.TRAINING.optimization.clipping:  # train_fusion.py:182-183: on the accumulated gradients, every frame
-            self.grads.clip_(1.0)  # (= clip_grad_norm_(parameters, 1., 2): the gradients are views into the flat buffer)
-        if (i + 1) % self.accum == 0:
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            self.grads.reduce()  # the only collective of the training path
-            b.record()
-            self.reduce_events.append((a, b))
-            self.opt.step()
-            self.grads.zero()
+        with self.pipe.gradients():  # (FUSION_MODEL.train_overlap: on the gradient stream, behind this frame's backward pass)
+            if self.cfg.TRAINING.optimization.clipping:  # train_fusion.py:182-183: on the accumulated gradients, every frame
+                self.grads.clip_(1.0)  # (= clip_grad_norm_(parameters, 1., 2): the gradients are views into the flat buffer)
+            if (i + 1) % self.accum == 0:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                self.grads.reduce()  # the only collective of the training path
+                b.record()
+                self.reduce_events.append((a, b))
+                self.opt.step()
+                self.grads.zero()
 
     def run(self, steps, warmup, sync, repeats):
         for i in range(warmup):
@@ -628,7 +631,9 @@ def train_report(case, res, steps, warmup, world, h, w, grid, grouped=False):
     med = times[len(times) // 2] if len(times) % 2 else 0.5 * (times[len(times) // 2 - 1] + times[len(times) // 2])
     return {'workload': 'BASELINE configs[3]: training frame step (fuse_training + FusionLoss + backward per frame; flat-gradient '
                         'all-reduce + RMSprop step every %d frames, clip_grad_norm_ every frame), %dx%d depth into a %d^3 grid, FusionNet_v3 train() mode '
-                        '(batch statistics, dropout), split-fp16 forward / backward-data convolutions and weight gradients, one scene per GPU' % (case.accum, w, h, grid),
+                        '(batch statistics, dropout), split-fp16 forward / backward-data convolutions and weight gradients, one scene per GPU%s' % (
+                            case.accum, w, h, grid, '; a frame\'s backward pass runs on the gradient stream beside the next frame\'s forward stage '
+                            '(FUSION_MODEL.train_overlap, the training driver\'s default: same bits as the serial loop)' if case.cfg.FUSION_MODEL.get('train_overlap', False) else ''),
             'value': world * steps / med, 'unit': 'frames/sec', 'ms_per_step': 1e3 * med / steps, 'steps': steps, 'warmup': warmup,
             'repeats': len(times), 'value_min': world * steps / times[-1], 'value_max': world * steps / times[0],
             'allreduce_us': res['allreduce_us'] if (world > 1 or grouped) else None, 'allreduce_calls_in_timed_region': res['allreduce_calls'],

@@ -362,6 +362,15 @@ int ojf_trainer_set_arithmetic(ojf_trainer *t, int arithmetic);
 int ojf_trainer_set_backward_arithmetic(ojf_trainer *t, int arithmetic);
 int ojf_trainer_layer_count(const ojf_trainer *t);
 int ojf_trainer_launch_count(const ojf_trainer *t);
+/* Optional replay of the passes as device graphs (default off; OJF_TRAIN_GRAPH=1 in the environment turns it on at create):
+ * the launches of a forward / backward pass between the trainer's own buffers and the layer table's tensors are captured once
+ * per (layer table contents, arithmetic) on a stream of the trainer's own and replayed with one hipGraphLaunch on the caller's
+ * stream - same kernels, same arguments, same bits; a pass is captured the second time its key misses in a row, so a table
+ * that changes every frame stays on plain launches.  The launches that touch the per-frame tensors (net input, est, d_est) and
+ * the weight packing (weights_epoch) always run as plain launches around the replay.  ojf_trainer_graph_replays: passes served
+ * by a replay since create (a test hook).  Replaces nothing in the reference. */
+int ojf_trainer_set_graph(ojf_trainer *t, int enable);
+int ojf_trainer_graph_replays(const ojf_trainer *t);
 int ojf_trainer_forward(ojf_trainer *t, const ojf_train_layer *layers, int n_layers, unsigned long long weights_epoch,
                         const float *values_dev, const float *weights_dev, const float *frame_dev, const float *semantic_frame_dev,
                         float *est_dev, ojf_stream_t stream);

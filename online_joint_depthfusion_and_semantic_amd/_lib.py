@@ -126,6 +126,8 @@ SIGNATURES = {
     'ojf_trainer_set_backward_arithmetic': (_i, [_vp, _i]),
     'ojf_trainer_layer_count': (_i, [_vp]),
     'ojf_trainer_launch_count': (_i, [_vp]),
+    'ojf_trainer_set_graph': (_i, [_vp, _i]),
+    'ojf_trainer_graph_replays': (_i, [_vp]),
     'ojf_trainer_forward': (_i, [_vp, _c.POINTER(TrainLayer), _i, _c.c_ulonglong, _vp, _vp, _vp, _vp, _vp, _vp]),
     'ojf_trainer_backward': (_i, [_vp, _c.POINTER(TrainLayer), _i, _vp, _vp]),
     'ojf_train_fuse_output': (_i, [_vp, _vp, _vp, _vp, _i, _i, _c.c_longlong, _f, _vp, _vp]),

@@ -17,6 +17,7 @@
 // them through the pointer table handed over with every call.
 #pragma once
 
+#include <cstring>
 #include <map>
 
 namespace ojf {
@@ -572,6 +573,16 @@ struct ojf_trainer {
     unsigned *bnd_pool = nullptr;  // all units' bound words in one allocation (one memset behind a pass)
     size_t bnd_words = 0;
     int bwd_arith = OJF_ARITH_F16X3;  // OJF_ARITH_F32: backward-data and weight gradients stay on the fp32-input MFMA path
+    // Optional replay (ojf_trainer_set_graph): the launches of a pass captured once per (layer table, tensor addresses,
+    // arithmetic) on a stream of the trainer's own and replayed with ONE hipGraphLaunch on the caller's stream.  A pass
+    // whose key was not seen on the previous miss runs as plain launches (tensors that move every frame never capture).
+    struct Replay { unsigned long long key; hipGraphExec_t exec; int launches; unsigned long long stamp; };
+    bool graph_on = false;
+    hipStream_t cap = nullptr;
+    std::vector<Replay> replays[2];          // [0] forward, [1] backward
+    unsigned long long missed[2] = {0, 0};   // key of the last pass that ran as plain launches
+    unsigned long long graph_clock = 0;
+    int graph_replays = 0, graph_captures = 0;
 };
 
 namespace ojf {
@@ -1205,6 +1216,170 @@ static int t_vortex_backward(TCtx &c, TVortex &v)
     return check_hip(hipGetLastError(), "ojf_trainer VortexPooling backward");
 }
 
+// A pass = the launches that touch the caller's per-frame tensors (net input, est, d_est: plain launches, whatever the addresses)
+// around the launches between the trainer's own buffers and the layer table's tensors (parameters, gradients, BatchNorm
+// statistics, dropout factors: addresses that stay for the life of a training run - what ojf_trainer_set_graph replays).
+
+// net input -> slot 0 of every dense head (modules/model.py:266-270 / :203-207)
+static int t_forward_in(TCtx &c, const float *values, const float *weights, const float *frame, const float *semantic_frame)
+{
+    ojf_trainer *t = c.t;
+    for (size_t hd = 0; hd < t->dbuf.size(); ++hd) {
+        PackInArgs a{};
+        a.src[0] = values; a.nch[0] = t->P; a.src[1] = weights; a.nch[1] = t->P;
+        a.n_src = 3;
+        if (t->version == 3) { a.src[2] = hd == 0 ? frame : semantic_frame; a.nch[2] = 1; }
+        else {
+            a.src[2] = frame; a.nch[2] = 1;
+            if (t->sem) { a.src[3] = semantic_frame; a.nch[3] = 1; a.n_src = 4; }
+        }
+        a.c4 = t->sl4; a.npix = t->npix; a.dst = planes(t->dbuf[hd]);
+        hipLaunchKernelGGL(train_pack_input_kernel, px_grid(t->npix, t->sl4), dim3(256), 0, c.st, a);
+    }
+    return check_hip(hipGetLastError(), "ojf_trainer_forward (net input)");
+}
+
+static int t_forward_net(TCtx &c)
+{
+    ojf_trainer *t = c.t;
+    const size_t heads = t->dbuf.size();
+    for (size_t hd = 0; hd < heads; ++hd) {
+        for (int id : t->dense[hd])
+            if (t_units_forward(c, &id, 1)) return -2;
+        if (t_vortex_forward(c, t->vortex[hd])) return -2;
+    }
+    for (size_t vi = heads; vi < t->vortex.size(); ++vi)
+        if (t_vortex_forward(c, t->vortex[vi])) return -2;
+    for (int id : t->pred)
+        if (t_units_forward(c, &id, 1)) return -2;
+    return check_hip(hipGetLastError(), "ojf_trainer_forward");
+}
+
+static int t_forward_out(TCtx &c, float *est)
+{
+    ojf_trainer *t = c.t;
+    hipLaunchKernelGGL(train_planes_to_nchw_kernel, px_grid(t->npix, (t->P + 3) / 4), dim3(256), 0, c.st, planes(t->est_planes), (t->P + 3) / 4, t->P,
+                       t->npix, est);
+    return check_hip(hipGetLastError(), "ojf_trainer_forward (est)");
+}
+
+static int t_backward_in(TCtx &c, const float *d_est)
+{
+    ojf_trainer *t = c.t;
+    hipLaunchKernelGGL(train_nchw_to_planes_kernel, px_grid(t->npix, (t->P + 3) / 4), dim3(256), 0, c.st, d_est, t->P, t->npix, planes(t->dest_planes));
+    return check_hip(hipGetLastError(), "ojf_trainer_backward (d_est)");
+}
+
+static int t_backward_net(TCtx &c)
+{
+    ojf_trainer *t = c.t;
+    for (auto &kv : t->groups_of) t->written[kv.first].assign(kv.second, 0);
+    for (auto it = t->pred.rbegin(); it != t->pred.rend(); ++it) {
+        const int id = *it;
+        if (t_units_backward(c, &id, 1)) return -2;
+    }
+    const size_t heads = t->dbuf.size();
+    for (size_t vi = t->vortex.size(); vi-- > heads;)
+        if (t_vortex_backward(c, t->vortex[vi])) return -2;
+    for (size_t hd = heads; hd-- > 0;) {
+        if (t_vortex_backward(c, t->vortex[hd])) return -2;
+        for (auto it = t->dense[hd].rbegin(); it != t->dense[hd].rend(); ++it) {
+            const int id = *it;
+            if (t_units_backward(c, &id, 1)) return -2;
+        }
+    }
+    if (t->use_side && t->side) {  // the gradient tensors are complete for whatever the caller enqueues next
+        OJF_HIP(hipEventRecord(t->join_ev, t->side));
+        OJF_HIP(hipStreamWaitEvent(c.st, t->join_ev, 0));
+    }
+    OJF_HIP(hipMemsetAsync(t->bnd_pool, 0, t->bnd_words * 4, c.st));  // (behind every launch that read this pass's bounds)
+    ++t->launches;
+    return check_hip(hipGetLastError(), "ojf_trainer_backward");
+}
+
+// ---- optional hipGraph replay of a pass ---------------------------------------------------------------------------------
+static inline void t_mix(unsigned long long &h, unsigned long long v)
+{
+    for (int i = 0; i < 8; ++i) { h ^= (v >> (8 * i)) & 0xffu; h *= 1099511628211ull; }  // FNV-1a
+}
+static inline unsigned long long t_bits(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline unsigned long long t_addr(const void *p) { return (unsigned long long)(uintptr_t)p; }
+
+// everything the replayed launches of a pass take from the caller: the layer table field by field, the arithmetic
+static unsigned long long t_pass_key(const ojf_trainer *t, const ojf_train_layer *L, int backward)
+{
+    unsigned long long h = 1469598103934665603ull;
+    t_mix(h, (unsigned long long)backward * 4 + (unsigned long long)t->fwd_arith * 2 + (unsigned long long)t->bwd_arith * 16 + (t->use_side ? 1 : 0));
+    for (int i = 0; i < t->n_layers; ++i) {
+        const ojf_train_layer &l = L[i];
+        const void *ptrs[] = {l.weight, l.bias, l.gamma, l.beta, l.running_mean, l.running_var, l.drop_scale};
+        for (const void *q : ptrs) t_mix(h, t_addr(q));
+        if (backward) {  // (a forward pass reads neither the gradient tensors nor the accumulate flag)
+            const void *grads[] = {l.grad_weight, l.grad_bias, l.grad_gamma, l.grad_beta};
+            for (const void *q : grads) t_mix(h, t_addr(q));
+            t_mix(h, (unsigned long long)(unsigned)l.accumulate);
+        }
+        t_mix(h, ((unsigned long long)(unsigned)l.out_channels << 32) | (unsigned)l.in_channels);
+        t_mix(h, ((unsigned long long)(unsigned)l.ksize << 32) | (unsigned)l.dilation);
+        t_mix(h, (unsigned long long)(unsigned)l.bn_training);
+        t_mix(h, (t_bits(l.momentum) << 32) | t_bits(l.eps));
+    }
+    return h ? h : 1;
+}
+
+static void t_drop_replays(ojf_trainer *t)
+{
+    for (auto &v : t->replays) {
+        for (auto &r : v) (void)hipGraphExecDestroy(r.exec);
+        v.clear();
+    }
+    t->missed[0] = t->missed[1] = 0;
+}
+
+// Replays the pass `key` on `st` if a graph of it exists; captures one (and replays it) if the previous miss had the same
+// key.  Returns 1 = the pass is enqueued, 0 = run the plain launches, < 0 = error.  `body(ctx)` enqueues the pass on ctx.st.
+template <class Body>
+static int t_replay(ojf_trainer *t, const ojf_train_layer *L, int which, unsigned long long key, hipStream_t st, Body body)
+{
+    auto &v = t->replays[which];
+    for (auto &r : v)
+        if (r.key == key) {
+            OJF_HIP(hipGraphLaunch(r.exec, st));
+            r.stamp = ++t->graph_clock;
+            t->launches = r.launches;
+            ++t->graph_replays;
+            return 1;
+        }
+    if (t->missed[which] != key) { t->missed[which] = key; return 0; }
+    if (!t->cap && hipStreamCreateWithFlags(&t->cap, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); t->graph_on = false; return 0; }
+    if (hipStreamBeginCapture(t->cap, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); t->graph_on = false; return 0; }
+    TCtx c{t, L, t->cap};
+    t->launches = 0;
+    const int rc = body(c);
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(t->cap, &g);
+    hipGraphExec_t exec = nullptr;
+    if (rc || e != hipSuccess || !g || hipGraphInstantiate(&exec, g, nullptr, nullptr, 0) != hipSuccess) {
+        if (g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        t->graph_on = false;  // (capture is an optimisation only: the plain launches remain)
+        return rc ? rc : 0;
+    }
+    (void)hipGraphDestroy(g);
+    if (v.size() >= 8) {  // tensors that alternate between a few addresses: keep the most recent graphs
+        size_t old = 0;
+        for (size_t i = 1; i < v.size(); ++i)
+            if (v[i].stamp < v[old].stamp) old = i;
+        (void)hipGraphExecDestroy(v[old].exec);
+        v.erase(v.begin() + old);
+    }
+    v.push_back({key, exec, t->launches, ++t->graph_clock});
+    ++t->graph_captures;
+    OJF_HIP(hipGraphLaunch(exec, st));
+    ++t->graph_replays;
+    return 1;
+}
+
 }  // namespace ojf
 
 // ---- C ABI ----------------------------------------------------------------------------------------------------------
@@ -1215,6 +1390,8 @@ OJF_API void ojf_trainer_destroy(ojf_trainer *t)
     for (hipEvent_t e : t->fork_ev) (void)hipEventDestroy(e);
     if (t->join_ev) (void)hipEventDestroy(t->join_ev);
     if (t->side) (void)hipStreamDestroy(t->side);
+    ojf::t_drop_replays(t);
+    if (t->cap) (void)hipStreamDestroy(t->cap);
     delete t;
 }
 
@@ -1309,9 +1486,22 @@ OJF_API int ojf_trainer_create(ojf_trainer **out, int version, int n_points, int
         }
     }
     if (rc) { ojf_trainer_destroy(t); return rc; }
+    static const bool graph_env = getenv("OJF_TRAIN_GRAPH") && atoi(getenv("OJF_TRAIN_GRAPH")) != 0;  // A/B switch
+    t->graph_on = graph_env;
     *out = t;
     return 0;
 }
+
+OJF_API int ojf_trainer_set_graph(ojf_trainer *t, int enable)
+{
+    using namespace ojf;
+    if (!t) return fail("ojf_trainer_set_graph: null trainer");
+    t->graph_on = enable != 0;
+    if (!t->graph_on) t_drop_replays(t);
+    return 0;
+}
+
+OJF_API int ojf_trainer_graph_replays(const ojf_trainer *t) { return t ? t->graph_replays : -1; }
 
 OJF_API int ojf_trainer_set_arithmetic(ojf_trainer *t, int arithmetic)
 {
@@ -1351,36 +1541,19 @@ OJF_API int ojf_trainer_forward(ojf_trainer *t, const ojf_train_layer *layers, i
         if (t_pack_weights(c)) return -2;
         t->epoch = weights_epoch;
     }
-    // net input -> slot 0 of every dense head (modules/model.py:266-270 / :203-207)
-    for (size_t hd = 0; hd < t->dbuf.size(); ++hd) {
-        PackInArgs a{};
-        a.src[0] = values; a.nch[0] = t->P; a.src[1] = weights; a.nch[1] = t->P;
-        a.n_src = 3;
-        if (t->version == 3) { a.src[2] = hd == 0 ? frame : semantic_frame; a.nch[2] = 1; }
-        else {
-            a.src[2] = frame; a.nch[2] = 1;
-            if (t->sem) { a.src[3] = semantic_frame; a.nch[3] = 1; a.n_src = 4; }
-        }
-        a.c4 = t->sl4; a.npix = t->npix; a.dst = planes(t->dbuf[hd]);
-        hipLaunchKernelGGL(train_pack_input_kernel, px_grid(t->npix, t->sl4), dim3(256), 0, c.st, a);
-        ++t->launches;
+    if (t_forward_in(c, values, weights, frame, semantic_frame)) return -2;
+    const int n_in = (int)t->dbuf.size();
+    auto body = [&](TCtx &cc) { return t_forward_net(cc); };
+    int done = 0;
+    if (t->graph_on) {
+        done = t_replay(t, layers, 0, t_pass_key(t, layers, 0), c.st, body);
+        if (done < 0) return done;
     }
-    OJF_HIP(hipGetLastError());
-    const size_t heads = t->dbuf.size();
-    for (size_t hd = 0; hd < heads; ++hd) {
-        for (int id : t->dense[hd])
-            if (t_units_forward(c, &id, 1)) return -2;
-        if (t_vortex_forward(c, t->vortex[hd])) return -2;
-    }
-    for (size_t vi = heads; vi < t->vortex.size(); ++vi)
-        if (t_vortex_forward(c, t->vortex[vi])) return -2;
-    for (int id : t->pred)
-        if (t_units_forward(c, &id, 1)) return -2;
-    hipLaunchKernelGGL(train_planes_to_nchw_kernel, px_grid(t->npix, (t->P + 3) / 4), dim3(256), 0, c.st, planes(t->est_planes), (t->P + 3) / 4, t->P,
-                       t->npix, est);
-    ++t->launches;
+    if (!done && body(c)) return -2;
+    if (t_forward_out(c, est)) return -2;
+    t->launches += n_in + 1;
     t->have_forward = true;
-    return check_hip(hipGetLastError(), "ojf_trainer_forward");
+    return 0;
 }
 
 OJF_API int ojf_trainer_backward(ojf_trainer *t, const ojf_train_layer *layers, int n_layers, const float *d_est, ojf_stream_t stream)
@@ -1391,32 +1564,17 @@ OJF_API int ojf_trainer_backward(ojf_trainer *t, const ojf_train_layer *layers, 
     if (!t->have_forward) return fail("ojf_trainer_backward: no forward pass to differentiate (one backward per forward)");
     TCtx c{t, layers, as_stream(stream)};
     t->launches = 0;
-    for (auto &kv : t->groups_of) t->written[kv.first].assign(kv.second, 0);
-    hipLaunchKernelGGL(train_nchw_to_planes_kernel, px_grid(t->npix, (t->P + 3) / 4), dim3(256), 0, c.st, d_est, t->P, t->npix, planes(t->dest_planes));
-    ++t->launches;
-    OJF_HIP(hipGetLastError());
-    for (auto it = t->pred.rbegin(); it != t->pred.rend(); ++it) {
-        const int id = *it;
-        if (t_units_backward(c, &id, 1)) return -2;
+    if (t_backward_in(c, d_est)) return -2;
+    auto body = [&](TCtx &cc) { return t_backward_net(cc); };
+    int done = 0;
+    if (t->graph_on) {
+        done = t_replay(t, layers, 1, t_pass_key(t, layers, 1), c.st, body);
+        if (done < 0) return done;
     }
-    const size_t heads = t->dbuf.size();
-    for (size_t vi = t->vortex.size(); vi-- > heads;)
-        if (t_vortex_backward(c, t->vortex[vi])) return -2;
-    for (size_t hd = heads; hd-- > 0;) {
-        if (t_vortex_backward(c, t->vortex[hd])) return -2;
-        for (auto it = t->dense[hd].rbegin(); it != t->dense[hd].rend(); ++it) {
-            const int id = *it;
-            if (t_units_backward(c, &id, 1)) return -2;
-        }
-    }
+    if (!done && body(c)) return -2;
+    t->launches += 1;
     t->have_forward = false;
-    if (t->use_side && t->side) {  // the gradient tensors are complete for whatever the caller enqueues next
-        OJF_HIP(hipEventRecord(t->join_ev, t->side));
-        OJF_HIP(hipStreamWaitEvent(c.st, t->join_ev, 0));
-    }
-    OJF_HIP(hipMemsetAsync(t->bnd_pool, 0, t->bnd_words * 4, c.st));  // (behind every launch that read this pass's bounds)
-    ++t->launches;
-    return check_hip(hipGetLastError(), "ojf_trainer_backward");
+    return 0;
 }
 
 OJF_API int ojf_train_fuse_output(const float *est_pn, const float *fv_pn, const float *fw_pn, const long long *valid, int n, int n_points,

@@ -795,9 +795,29 @@ class Pipeline(torch.nn.Module):
                 from .train import HipTrainNet
                 tn = self.__dict__['_hip_train'] = HipTrainNet(self._fusion_network, graph=self.config.FUSION_MODEL.get('train_graph', False),
                                                                inplace_grads=True, arithmetic=self.config.FUSION_MODEL.get('train_arithmetic', 'f16x3'),
-                                                               backward_arithmetic=self.config.FUSION_MODEL.get('train_arithmetic_bwd', None))
+                                                               backward_arithmetic=self.config.FUSION_MODEL.get('train_arithmetic_bwd', None),
+                                                               replay=self.config.FUSION_MODEL.get('train_replay', None),
+                                                               overlap=self.config.FUSION_MODEL.get('train_overlap', False))
             return tn(inputs)
         return self._fusion_network.forward(inputs)
+
+    def gradients(self):
+        """``with pipeline.gradients():`` around everything between ``loss.backward()`` and the next ``fuse_training`` that touches the
+        fusion net's gradients or writes its parameters (train_fusion.py:182-189: clip_grad_norm_, optimizer.step(), zero_grad()).  With
+        ``FUSION_MODEL.train_overlap`` the backward pass of a frame runs on a stream of its own beside the next frame's forward stage and
+        this context puts its body on that stream; without it (the default) the context does nothing."""
+        tn = self.__dict__.get('_hip_train')
+        if tn is not None:
+            return tn.gradients()
+        import contextlib
+        return contextlib.nullcontext()
+
+    def join_gradients(self):
+        """The current stream waits for the gradient stream (before checkpoints, validation, host reads of gradients or freshly stepped
+        weights); a no-op without ``FUSION_MODEL.train_overlap``.  The next ``fuse_training`` joins by itself when a weight changed."""
+        tn = self.__dict__.get('_hip_train')
+        if tn is not None:
+            tn.join_gradients()
 
     def _async_count(self, mask_flat):
         """Number of set elements of a device bool vector, on its way to the host: (pinned int32 buffer, event)."""

@@ -242,7 +242,7 @@ class HipTrainNet:
     """Runs ``net`` (model.FusionNet_v3 / FusionNet_v2) through ``LayerUnit`` nodes.  ``net.training`` selects batch
     statistics + dropout (train) or running statistics, no dropout (eval), exactly like the module's own forward."""
 
-    def __init__(self, net, graph=False, inplace_grads=False, executor=True, arithmetic='f16x3', backward_arithmetic=None):
+    def __init__(self, net, graph=False, inplace_grads=False, executor=True, arithmetic='f16x3', backward_arithmetic=None, replay=None, overlap=False):
         _lib.require_gpu()
         self.net = net
         self.inplace_grads = bool(inplace_grads)  # see _grad_target
@@ -269,7 +269,21 @@ class HipTrainNet:
         self._rand_at = 0
         self._masks = {}
         self.graph = bool(graph)  # capture forward / backward into device graphs (falls back to eager launches if a capture fails)
+        # executor passes replayed as device graphs inside the library (ojf_trainer_set_graph): None = the library's default
+        # (off; OJF_TRAIN_GRAPH=1 in the environment), True / False = set per trainer
+        self.replay = replay
         self._graphs = {}
+        # overlap (FUSION_MODEL.train_overlap; needs executor + inplace_grads): the backward pass of frame k runs on a stream of its
+        # own (``gradient_stream``) beside the forward stage of frame k + 1 on the caller's stream - two executors per frame shape
+        # take turns, so one frame's activations are read while the next frame's are written.  The caller's stream then does NOT
+        # see the gradients: whatever reads or writes them (clipping, all-reduce, optimizer step, zero_grad) belongs inside
+        # ``with net.gradients():``; a forward pass waits for that stream by itself when a weight changed, ``join_gradients()``
+        # makes the caller's stream wait (checkpoints, validation, host reads of a gradient).
+        self.overlap = bool(overlap) and self.executor and self.inplace_grads
+        self._passes = 0
+        self._grad_stream = None
+        self._grad_tail = None
+        self._epoch_joined = None
 
     # ---- one Sequential of conv/BN/act/dropout slots -> units ------------------------------------------------------
     def _unit(self, x, conv, bn, act, dropout, group, slot, scale=1.0):
@@ -430,9 +444,9 @@ class HipTrainNet:
             layers += seq(p.pred)
         return layers
 
-    def _trainer(self, h, w, dev):
+    def _trainer(self, h, w, dev, slot=0):
         from .model import FusionNet_v3
-        key = (h, w, str(dev))
+        key = (h, w, str(dev)) if slot == 0 else (h, w, str(dev), slot)
         tr = self._trainers.get(key)
         if tr is None:
             lib = _lib.load()
@@ -445,7 +459,29 @@ class HipTrainNet:
             _lib.check(lib.ojf_trainer_set_arithmetic(handle, _lib.ARITHMETIC[self.arithmetic]), 'ojf_trainer_set_arithmetic')
             _lib.check(lib.ojf_trainer_set_backward_arithmetic(handle, _lib.ARITHMETIC[self.backward_arithmetic]),
                        'ojf_trainer_set_backward_arithmetic')
+            if self.replay is not None:
+                _lib.check(lib.ojf_trainer_set_graph(handle, int(bool(self.replay))), 'ojf_trainer_set_graph')
         return tr
+
+    # ---- backward passes beside the next forward stage (overlap=True) -------------------------------------------------------
+    def gradient_stream(self, dev):
+        """The stream the executor's backward passes run on under ``overlap`` (None otherwise)."""
+        if not self.overlap:
+            return None
+        if self._grad_stream is None or self._grad_stream.device != torch.device(dev):
+            self._grad_stream = torch.cuda.Stream(device=dev)
+        return self._grad_stream
+
+    def gradients(self):
+        """Context for everything that reads or writes the parameter gradients or writes the parameters (clip_grad_norm_, the
+        flat-gradient all-reduce, optimizer.step(), zero_grad()): under ``overlap`` it runs on the gradient stream, behind the backward
+        passes enqueued so far and behind the caller's stream as of entry; otherwise it is the caller's stream unchanged."""
+        return _GradientContext(self)
+
+    def join_gradients(self, dev=None):
+        """The caller's current stream waits for everything enqueued on the gradient stream so far (no-op without ``overlap``)."""
+        if self._grad_tail is not None:
+            torch.cuda.current_stream(dev if dev is not None else self._grad_stream.device).wait_event(self._grad_tail)
 
     def invalidate(self):
         """Forces the packed weight copies to be rebuilt by the next forward pass.  In-place updates (optimizer steps,
@@ -453,6 +489,12 @@ class HipTrainNet:
         writes through ``p.data`` / ``tensor.data.copy_`` / ``dist.broadcast(p.data)`` bump no counter: call this after
         them."""
         self._weights_sig = None
+
+    @property
+    def replays(self):
+        """Executor passes served by a device-graph replay so far (ojf_trainer_graph_replays), over all frame shapes."""
+        lib = _lib.load()
+        return sum(int(lib.ojf_trainer_graph_replays(t.handle)) for t in self._trainers.values())
 
     @property
     def launches(self):
@@ -485,7 +527,12 @@ class HipTrainNet:
         v = x['tsdf_values']
         dev = v.device
         _, P, h, w = v.shape
-        tr = self._trainer(h, w, dev)
+        slot = self._passes % 2 if (self.overlap and torch.is_grad_enabled()) else 0
+        self._passes += 1
+        tr = self._trainer(h, w, dev, slot)
+        if tr.bwd_done is not None:  # this executor's activations are still being read by its last backward pass on the gradient stream
+            torch.cuda.current_stream(dev).wait_event(tr.bwd_done)
+            tr.bwd_done = None
         mods = self.__dict__.get('_mods')
         if mods is None:
             mods = self._mods = self._layer_modules()
@@ -502,10 +549,11 @@ class HipTrainNet:
         drop_sig = tuple((i, d.p, mods[i][0].out_channels) for i, d in drops)
         scales = {}
         if drops:
-            keep = self.__dict__.get('_keep')
+            keeps = self.__dict__.setdefault('_keeps', {})  # (per executor: a backward pass reads the factors of ITS forward pass)
+            keep = keeps.get(slot)
             if keep is None or keep[0] != drop_sig or keep[1].device != dev:
                 kv = torch.cat([torch.full((mods[i][0].out_channels,), 1.0 - d.p) for i, d in drops]).to(dev)
-                keep = self._keep = (drop_sig, kv, torch.empty_like(kv), torch.empty_like(kv), torch.empty_like(kv, dtype=torch.bool))
+                keep = keeps[slot] = (drop_sig, kv, torch.empty_like(kv), torch.empty_like(kv), torch.empty_like(kv, dtype=torch.bool))
             rand, factors = keep[2], keep[3]
             torch.rand(rand.shape, device=dev, out=rand)
             torch.lt(rand, keep[1], out=keep[4])
@@ -517,6 +565,11 @@ class HipTrainNet:
                 scales[i] = factors[off:off + n]
                 off += n
         epoch = self._epoch(mods)
+        if self._grad_tail is not None and epoch != self._epoch_joined:
+            # a weight changed since the last pass that looked (the optimizer step sits on the gradient stream): this pass - packing included -
+            # goes behind it
+            torch.cuda.current_stream(dev).wait_event(self._grad_tail)
+        self._epoch_joined = epoch
         # The layer table (pointers, geometry, BatchNorm flags) changes only when a tensor moves or a module switches mode: per pass
         # the cached tensors' addresses and the mode flags are compared (~50 us); the walk over the module tree (~60 layers x a
         # dozen nn.Module attribute lookups and ctypes stores: ~0.4 ms of host time per frame, on a step whose host side paces
@@ -632,8 +685,30 @@ class FuseOutput(torch.autograd.Function):
         return d_est, None, None, None, None
 
 
+class _GradientContext:
+    def __init__(self, tn):
+        self.tn, self.ctx = tn, None
+
+    def __enter__(self):
+        tn = self.tn
+        st = tn._grad_stream if tn.overlap else None
+        if st is not None:
+            st.wait_stream(torch.cuda.current_stream(st.device))
+            self.ctx = torch.cuda.stream(st)
+            self.ctx.__enter__()
+        return st
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            st = self.tn._grad_stream
+            self.tn._grad_tail = st.record_event()
+            return self.ctx.__exit__(*exc)
+        return False
+
+
 class _TrainerHandle:
     fwd_launches = bwd_launches = 0
+    bwd_done = None  # overlap: event behind this executor's last backward pass on the gradient stream
 
     def __init__(self, handle):
         self.handle = handle
@@ -680,10 +755,21 @@ class _NetFn(torch.autograd.Function):
         out = [None] * len(tn._params)
         sig = tr.grad_sig
         steady = inplace and sig is not None and all(p.grad is g for p, g in zip(tn._params, sig))
-        if steady:  # every parameter still accumulates into the tensor whose address the table already holds
-            _lib.check(lib.ojf_trainer_backward(tr.handle, table, len(table), dest.contiguous().data_ptr(), _lib.stream_ptr(state['dev'])),
-                       'ojf_trainer_backward')
+        dest = dest.contiguous()
+
+        def run_backward():
+            gs = tn.gradient_stream(state['dev']) if inplace else None
+            if gs is None:
+                _lib.check(lib.ojf_trainer_backward(tr.handle, table, len(table), dest.data_ptr(), _lib.stream_ptr(state['dev'])), 'ojf_trainer_backward')
+            else:  # overlap: behind everything enqueued on this stream so far (d_est, the gradient tensors), beside what comes next on it
+                gs.wait_event(torch.cuda.current_stream(state['dev']).record_event())
+                dest.record_stream(gs)
+                _lib.check(lib.ojf_trainer_backward(tr.handle, table, len(table), dest.data_ptr(), gs.cuda_stream), 'ojf_trainer_backward')
+                tr.bwd_done = tn._grad_tail = gs.record_event()
             tr.bwd_launches = int(lib.ojf_trainer_launch_count(tr.handle))
+
+        if steady:  # every parameter still accumulates into the tensor whose address the table already holds
+            run_backward()
             return (None, None) + (None,) * ctx.n_in + tuple(out)
         all_accumulating = inplace
         for i, (conv, bn, drop) in enumerate(tn._mods):
@@ -714,8 +800,9 @@ class _NetFn(torch.autograd.Function):
                 else:
                     state.setdefault('scratch', []).append(g)
             state.setdefault('scratch', []).extend(o for o in out if o is not None)
-        _lib.check(lib.ojf_trainer_backward(tr.handle, table, len(table), dest.contiguous().data_ptr(), _lib.stream_ptr(state['dev'])),
-                   'ojf_trainer_backward')
+        run_backward()
+        if tr.bwd_done is not None and any(o is not None for o in out):  # gradients handed to autograd: its stream must see them
+            torch.cuda.current_stream(state['dev']).wait_event(tr.bwd_done)
         # steady state from the next pass on: the gradient tensors exist and the table says "accumulate" for every layer
         tr.grad_sig = [p.grad for p in tn._params] if inplace else None
         if tr.grad_sig is not None and not all_accumulating:

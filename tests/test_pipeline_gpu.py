@@ -923,3 +923,56 @@ def test_announced_training_frames_change_no_bit(cuda):
     for x, y in zip(a[3], b[3]):
         assert torch.equal(x.view(torch.int16), y.view(torch.int16))
     assert float((a[3][1].float() > 0).sum()) > 1000
+
+
+@pytest.mark.parametrize('replay', [False, True])
+def test_backward_beside_the_next_forward_stage_changes_no_bit(cuda, replay):
+    """FUSION_MODEL.train_overlap: the backward pass of frame k on the pipeline's gradient stream beside the forward stage of frame
+    k + 1 (two executors take turns; gradient clipping, optimizer step and zero_grad inside ``with pipeline.gradients():``).  The
+    reference's loop order (train_fusion.py:160-189) is kept by stream dependencies instead of by one queue: outputs, losses,
+    parameters, BatchNorm buffers, accumulated gradients and volumes of ten train()-mode frames with Dropout2d and an RMSprop step
+    every third frame are bit for bit those of the serial loop - also with the executor's passes replayed as device graphs."""
+    h, w, grid, frames = 48, 64, 64, 10
+
+    def run(overlap):
+        torch.manual_seed(10)
+        cfg, st, db, pipe = _setup(h, w, grid, False, False, 'fast', cuda)
+        cfg.FUSION_MODEL.train_overlap = overlap
+        cfg.FUSION_MODEL.train_replay = replay and overlap
+        torch.manual_seed(11)
+        for m in pipe._fusion_network.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                torch.nn.init.xavier_normal_(m.weight)
+        pipe.train()
+        net = pipe._fusion_network
+        opt = torch.optim.RMSprop(net.parameters(), lr=1e-3)
+        torch.manual_seed(12)  # the Dropout2d draws
+        batches = [_batch(st, i, cuda) for i in range(frames)]
+        outs = []
+        for i in range(frames):
+            out = pipe.fuse_training(batches[i], db, cuda)
+            loss = (out['tsdf_fused'] - out['tsdf_target']).abs().mean()
+            loss.backward()
+            outs.append((out['tsdf_est'].detach().clone(), out['tsdf_fused'].detach().clone(), loss.detach().clone()))
+            with pipe.gradients():
+                torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
+                if i % 3 == 2:
+                    opt.step()
+                    opt.zero_grad(set_to_none=False)
+        pipe.join_gradients()
+        grads = [p.grad.detach().clone() for p in net.parameters() if p.grad is not None]
+        torch.cuda.synchronize()
+        tn = pipe.__dict__['_hip_train']
+        assert tn.overlap == overlap and (len(tn._trainers) == (2 if overlap else 1))
+        if replay and overlap:
+            assert tn.replays >= 8
+        return (outs, [p.detach().clone() for p in net.parameters()], [b.detach().clone() for b in net.buffers()], grads,
+                [db.scenes_est[st.scene].volume.clone(), db.fusion_weights[st.scene].clone()])
+    a, b = run(True), run(False)
+    for (e1, f1, l1), (e2, f2, l2) in zip(a[0], b[0]):
+        assert torch.equal(e1, e2) and torch.equal(f1, f2) and torch.equal(l1, l2)
+    assert len(a[3]) == len(b[3]) > 100
+    for x, y in zip(a[1] + a[2] + a[3], b[1] + b[2] + b[3]):
+        assert torch.equal(x, y)
+    for x, y in zip(a[4], b[4]):
+        assert torch.equal(x.view(torch.int16), y.view(torch.int16))

@@ -568,3 +568,52 @@ def test_wide_nets_up_to_the_executor_limit(cuda):
                 continue
             assert torch.isfinite(pk).all(), (k, name)
             assert float((p0 - pk).abs().max()) <= 2e-3 * max(float(p0.abs().max()), 1e-3 * gmax), (k, name)
+
+
+def _replay_run(cuda, replay, version, sem, h, w, frames=10):
+    net = _net(version, sem, h, w, seed=11).to(cuda).train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.2
+    g = torch.Generator().manual_seed(7)
+    xs = []
+    for _ in range(3):  # three frames whose tensors stay where they are (a loader's ring of device buffers)
+        x = dict(tsdf_values=((torch.rand(1, 9, h, w, generator=g) - 0.5) * 0.2).to(cuda), tsdf_weights=(torch.rand(1, 9, h, w, generator=g) * 4).to(cuda),
+                 tsdf_frame=(torch.rand(1, 1, h, w, generator=g) * 4).to(cuda))
+        if sem:
+            x['semantic_frame'] = (torch.randint(1, 31, (1, 1, h, w), generator=g).float() / 30).to(cuda)
+        xs.append(x)
+    eng = HipTrainNet(net, inplace_grads=True, replay=replay)
+    opt = torch.optim.RMSprop(net.parameters(), lr=1e-4)
+    torch.manual_seed(123)  # the dropout draws
+    outs = []
+    for i in range(frames):
+        est = eng(xs[i % 3])
+        outs.append(est.detach().clone())
+        est.pow(2).mean().backward()
+        if i % 4 == 3:
+            opt.step()
+            opt.zero_grad(set_to_none=False)
+    torch.cuda.synchronize()
+    state = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    grads = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+    return outs, state, grads, eng.replays
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('version,sem,h,w', [('v3', False, 24, 32), ('v3', True, 23, 37), ('v2', True, 24, 32)])
+def test_executor_passes_replayed_as_device_graphs_change_no_bit(cuda, version, sem, h, w):
+    """ojf_trainer_set_graph: forward / backward passes served by hipGraphLaunch run the same kernels with the same arguments -
+    ten train()-mode frames with Dropout2d, in-place gradient accumulation and an RMSprop step every fourth frame (weights repacked in
+    front of the next replay, `accumulate` toggling between two captured backward passes) leave the same outputs, parameters, BatchNorm
+    statistics and gradients as plain launches, bit for bit; and the replays really ran."""
+    plain = _replay_run(cuda, False, version, sem, h, w)
+    graph = _replay_run(cuda, True, version, sem, h, w)
+    assert plain[3] == 0 and graph[3] >= 8, (plain[3], graph[3])
+    for a, b in zip(plain[0], graph[0]):
+        assert torch.equal(a, b)
+    for k in plain[1]:
+        assert torch.equal(plain[1][k], graph[1][k]), k
+    assert plain[2].keys() == graph[2].keys() and len(plain[2]) > 100
+    for k in plain[2]:
+        assert torch.equal(plain[2][k], graph[2][k]), k
