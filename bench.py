@@ -547,8 +547,9 @@ class TrainCase:
         from online_joint_depthfusion_and_semantic_amd.loss import FusionLoss
         cfg = _training_defaults(default_config(h, w))
         cfg.SETTINGS.device = str(dev)
-        if os.environ.get('OJF_BENCH_TRAIN_OVERLAP', '') != '':  # A/B switch
-            cfg.FUSION_MODEL.train_overlap = os.environ['OJF_BENCH_TRAIN_OVERLAP'] not in ('0',)
+        # like drivers.train_fusion: the backward pass of a frame beside the next frame's forward stage (step() keeps the gradient
+        # work inside pipe.gradients()); OJF_BENCH_TRAIN_OVERLAP=0: the serial loop (A/B switch)
+        cfg.FUSION_MODEL.train_overlap = os.environ.get('OJF_BENCH_TRAIN_OVERLAP', '1') not in ('0',)
         self.cfg, self.dev, self.accum = cfg, dev, accum
         n_distinct = min(n_frames, DISTINCT_FRAMES)
         self.st = SyntheticStream(h, w, grid, max(n_distinct, 40), scene='room_%d' % rank, seed=1911 + rank)

@@ -426,9 +426,6 @@ def _training_defaults(config):
     t.setdefault('loss', {'name': 'fusion', 'w_l1': 1., 'w_l2': 10, 'w_cos': 0.1})
     t.optimization.setdefault('reset_strategy', True)
     t.optimization.setdefault('reset_prob', 0.01)
-    # the training loop below is written for it (gradient work inside ``with pipeline.gradients():``, joins before evaluation and
-    # checkpoints): a frame's backward pass runs beside the next frame's forward stage - same bits, +14 % frames/s
-    config.FUSION_MODEL.setdefault('train_overlap', True)
     from .config import AttrDict
     config.TRAINING = AttrDict(dict(t))
     return config
@@ -482,6 +479,10 @@ def main():
     config = load_config_from_yaml(args.config) if args.config else default_config(args.height, args.width)
     config.SETTINGS.device = str(device)
     config = _training_defaults(config)
+    # this function's loop is written for it (gradient work inside ``with pipeline.gradients():``, joins before evaluation and
+    # checkpoints): a frame's backward pass runs beside the next frame's forward stage - same bits, +14 % frames/s.
+    # (Set here, not in _training_defaults: a loop that clips / steps outside that context must keep the serial contract.)
+    config.FUSION_MODEL.setdefault('train_overlap', True)
     n_scenes = args.scenes or world
     if config.DATA.get('dataset', 'synthetic') in ('Replica', 'ScanNet'):  # real data in the reference's layout
         dataset = get_data(config.DATA.dataset, get_data_config(config, args.mode))

@@ -11,6 +11,7 @@ from online_joint_depthfusion_and_semantic_amd.drivers import _training_defaults
 dev = torch.device('cuda:0')
 h, w, grid, n = 240, 320, 256, 48
 cfg = _training_defaults(default_config(h, w)); cfg.SETTINGS.device = str(dev)
+cfg.FUSION_MODEL.train_overlap = os.environ.get('OJF_TRAIN_OVERLAP', '1') != '0'  # like drivers.train_fusion (0: the serial loop)
 st = SyntheticStream(h, w, grid, n)
 db = Database(st, database_config(cfg))
 pipe = Pipeline(cfg).to(dev).train()
@@ -27,7 +28,8 @@ def step(i):
     loss = crit.forward(out['tsdf_fused'], out['tsdf_target']) if out['tsdf_fused'].shape[1] else None
     if loss is not None: loss.backward()
     if (i + 1) % 8 == 0:
-        opt.step(); opt.zero_grad(set_to_none=False)
+        with pipe.gradients():
+            opt.step(); opt.zero_grad(set_to_none=False)
 for i in range(8): step(i)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for i in range(8, n): step(i)
