@@ -276,6 +276,10 @@ def train_fusion(config, dataset, device, rank=0, world=1, max_steps=None, log=p
         workspace = Workspace(checkpoint_dir)
         workspace.model_path = checkpoint_dir  # checkpoints directly under checkpoint_dir
     chief = workspace is not None and rank == 0  # rank 0 alone writes logs, scalars and model checkpoints
+    # this function's loop is written for it (gradient work inside ``with pipeline.gradients():``, joins before evaluation and
+    # checkpoints): a frame's backward pass runs beside the next frame's forward stage - same bits, +14 % frames/s (DESIGN.md 6.4).
+    # (Set here, not in _training_defaults: a loop that clips / steps outside that context must keep the serial contract.)
+    config.FUSION_MODEL.setdefault('train_overlap', True)
     pipeline = Pipeline(config)
     pipeline.apply(weights_init)
     net = pipeline._fusion_network
@@ -479,10 +483,6 @@ def main():
     config = load_config_from_yaml(args.config) if args.config else default_config(args.height, args.width)
     config.SETTINGS.device = str(device)
     config = _training_defaults(config)
-    # this function's loop is written for it (gradient work inside ``with pipeline.gradients():``, joins before evaluation and
-    # checkpoints): a frame's backward pass runs beside the next frame's forward stage - same bits, +14 % frames/s (DESIGN.md 6.4).
-    # (Set here, not in _training_defaults: a loop that clips / steps outside that context must keep the serial contract.)
-    config.FUSION_MODEL.setdefault('train_overlap', True)
     n_scenes = args.scenes or world
     if config.DATA.get('dataset', 'synthetic') in ('Replica', 'ScanNet'):  # real data in the reference's layout
         dataset = get_data(config.DATA.dataset, get_data_config(config, args.mode))

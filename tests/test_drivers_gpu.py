@@ -188,3 +188,36 @@ def test_test_fusion_lookahead_chunks(cuda):
         assert torch.equal(db.fusion_weights['room_0'].view(torch.int16), db1.fusion_weights['room_0'].view(torch.int16))
         assert r['mse'] == pytest.approx(r1['mse'], rel=1e-12) and r['iou'] == pytest.approx(r1['iou'], rel=1e-12)
         assert int(db.ids_est['room_0'].volume.max()) < n_classes
+
+
+def test_train_fusion_with_the_backward_pass_beside_the_next_frame_is_the_serial_loop(cuda):
+    """drivers.train_fusion runs with FUSION_MODEL.train_overlap by default (a frame's backward pass on the gradient stream beside the next
+    frame's forward stage; clip / all-reduce / optimizer step inside ``pipeline.gradients()``, a join in front of every evaluation):
+    losses, parameters, BatchNorm buffers and the scene volume of eleven frames (accumulation over 3, an evaluation every 5) are bit for
+    bit those of ``train_overlap: False``."""
+    h, w, grid = 48, 64, 32
+
+    def run(overlap):
+        cfg = _training_defaults(default_config(h, w))
+        cfg.SETTINGS.device = str(cuda)
+        cfg.SETTINGS.seed = 5
+        cfg.SETTINGS.eval_freq = 5
+        if overlap is not None:
+            cfg.FUSION_MODEL.train_overlap = overlap
+        cfg.TRAINING.optimization.accumulation_steps = 3
+        cfg.TRAINING.optimization.reset_strategy = False
+        cfg.TRAINING.optimizer.lr = 1e-3
+        ds = SyntheticDataset(h, w, grid, 12, scenes=['room_0'])
+        pipe, db, losses = train_fusion(cfg, ds, cuda, max_steps=11, log=lambda *a: None)
+        torch.cuda.synchronize()
+        tn = pipe.__dict__['_hip_train']
+        assert tn.overlap == (overlap is not False)
+        net = pipe._fusion_network
+        scene = next(iter(db.scenes_est))
+        return (losses, [v.detach().clone() for v in net.state_dict().values()],
+                torch.as_tensor(db.scenes_est[scene].volume).clone(), torch.as_tensor(db.fusion_weights[scene]).clone())
+    a, b = run(None), run(False)
+    assert len(a[0]) == 11 and a[0] == b[0]
+    for x, y in zip(a[1], b[1]):
+        assert torch.equal(x, y)
+    assert torch.equal(a[2].view(torch.int16), b[2].view(torch.int16)) and torch.equal(a[3].view(torch.int16), b[3].view(torch.int16))
