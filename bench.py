@@ -550,6 +550,7 @@ class TrainCase:
         # like drivers.train_fusion: the backward pass of a frame beside the next frame's forward stage (step() keeps the gradient
         # work inside pipe.gradients()); OJF_BENCH_TRAIN_OVERLAP=0: the serial loop (A/B switch)
         cfg.FUSION_MODEL.train_overlap = os.environ.get('OJF_BENCH_TRAIN_OVERLAP', '1') not in ('0',)
+        cfg.FUSION_MODEL.train_overlap_thread = os.environ.get('OJF_BENCH_TRAIN_THREAD', '0') not in ('0',)
         self.cfg, self.dev, self.accum = cfg, dev, accum
         n_distinct = min(n_frames, DISTINCT_FRAMES)
         self.st = SyntheticStream(h, w, grid, max(n_distinct, 40), scene='room_%d' % rank, seed=1911 + rank)
@@ -589,10 +590,12 @@ class TrainCase:
             # train_fusion.py:172 adds loss.item() to a window that is read every log_freq frames; summed on the device
             # and read once per timed loop here (the same numbers, without a host round trip per frame)
             self.loss_sum = loss.detach() if self.loss_sum is None else self.loss_sum + loss.detach()
-        with self.pipe.gradients():  # (FUSION_MODEL.train_overlap: on the gradient stream, behind this frame's backward pass)
+        boundary = (i + 1) % self.accum == 0
+
+        def gradient_step():  # (FUSION_MODEL.train_overlap: on the gradient stream, behind this frame's backward pass)
             if self.cfg.TRAINING.optimization.clipping:  # train_fusion.py:182-183: on the accumulated gradients, every frame
                 self.grads.clip_(1.0)  # (= clip_grad_norm_(parameters, 1., 2): the gradients are views into the flat buffer)
-            if (i + 1) % self.accum == 0:
+            if boundary:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
                 self.grads.reduce()  # the only collective of the training path
@@ -600,10 +603,12 @@ class TrainCase:
                 self.reduce_events.append((a, b))
                 self.opt.step()
                 self.grads.zero()
+        self.pipe.gradient_work(gradient_step, join=boundary)  # like drivers.train_fusion: this thread waits only where the weights change
 
     def run(self, steps, warmup, sync, repeats):
         for i in range(warmup):
             self.step(i)
+        self.pipe.join_gradients()
         self.reduce_events = []
         times, host, at = [], [], warmup
         for _ in range(repeats):
@@ -612,6 +617,7 @@ class TrainCase:
             self.loss_sum = None
             for i in range(at, at + steps):
                 self.step(i)
+            self.pipe.join_gradients()  # (the gradient thread has enqueued everything it was handed: the loop's launches are all in the queues)
             host.append(time.perf_counter() - t0)  # the host's share: Python + enqueue time of the loop (incl. its waits for the valid-ray counts)
             mean_loss = float(self.loss_sum) / steps if self.loss_sum is not None else float('nan')  # the log window's read
             sync()

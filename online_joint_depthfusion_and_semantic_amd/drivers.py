@@ -357,7 +357,9 @@ def train_fusion(config, dataset, device, rank=0, world=1, max_steps=None, log=p
                 window = 0.
             # (FUSION_MODEL.train_overlap: this frame's backward pass runs on the pipeline's gradient stream beside the next frame's
             # forward stage; everything that touches the gradients or steps the weights goes behind it on that stream)
-            with pipeline.gradients() if hasattr(pipeline, 'gradients') else contextlib.nullcontext():
+            # and, with FUSION_MODEL.train_overlap_thread, is enqueued by the pipeline's gradient thread: this thread waits for it only
+            # at the boundaries, where the weights change)
+            def gradient_step(boundary=boundary):
                 if opt.clipping:
                     grads.clip_(1.0)  # clip_grad_norm_(net.parameters(), 1., 2) on the flat buffer the gradients live in
                 if boundary:
@@ -365,6 +367,10 @@ def train_fusion(config, dataset, device, rank=0, world=1, max_steps=None, log=p
                     optimizer.step()
                     grads.zero()    # keeps p.grad aliased to the flat buffer (no set_to_none)
                     scheduler.step()
+            if hasattr(pipeline, 'gradient_work'):
+                pipeline.gradient_work(gradient_step, join=boundary)
+            else:
+                gradient_step()
             step += 1
             done = max_steps is not None and step >= max_steps
             if evaluate_now or done:

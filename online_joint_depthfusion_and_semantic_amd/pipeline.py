@@ -797,7 +797,8 @@ class Pipeline(torch.nn.Module):
                                                                inplace_grads=True, arithmetic=self.config.FUSION_MODEL.get('train_arithmetic', 'f16x3'),
                                                                backward_arithmetic=self.config.FUSION_MODEL.get('train_arithmetic_bwd', None),
                                                                replay=self.config.FUSION_MODEL.get('train_replay', None),
-                                                               overlap=self.config.FUSION_MODEL.get('train_overlap', False))
+                                                               overlap=self.config.FUSION_MODEL.get('train_overlap', False),
+                                                               overlap_thread=self.config.FUSION_MODEL.get('train_overlap_thread', False))
             return tn(inputs)
         return self._fusion_network.forward(inputs)
 
@@ -811,6 +812,15 @@ class Pipeline(torch.nn.Module):
             return tn.gradients()
         import contextlib
         return contextlib.nullcontext()
+
+    def gradient_work(self, fn, join=True):
+        """``fn()`` behind the backward passes enqueued so far - the function form of ``with pipeline.gradients(): ...`` that a host thread
+        of the pipeline's own can run (``FUSION_MODEL.train_overlap_thread``, default off: measured neutral): the caller does not wait
+        for the backward pass's launch loop.  ``join=False`` only for an ``fn`` that writes no parameter (train.HipTrainNet.gradient_work)."""
+        tn = self.__dict__.get('_hip_train')
+        if tn is not None:
+            return tn.gradient_work(fn, join=join)
+        fn()
 
     def join_gradients(self):
         """The current stream waits for the gradient stream (before checkpoints, validation, host reads of gradients or freshly stepped

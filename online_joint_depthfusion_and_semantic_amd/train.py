@@ -242,7 +242,7 @@ class HipTrainNet:
     """Runs ``net`` (model.FusionNet_v3 / FusionNet_v2) through ``LayerUnit`` nodes.  ``net.training`` selects batch
     statistics + dropout (train) or running statistics, no dropout (eval), exactly like the module's own forward."""
 
-    def __init__(self, net, graph=False, inplace_grads=False, executor=True, arithmetic='f16x3', backward_arithmetic=None, replay=None, overlap=False):
+    def __init__(self, net, graph=False, inplace_grads=False, executor=True, arithmetic='f16x3', backward_arithmetic=None, replay=None, overlap=False, overlap_thread=False):
         _lib.require_gpu()
         self.net = net
         self.inplace_grads = bool(inplace_grads)  # see _grad_target
@@ -280,6 +280,15 @@ class HipTrainNet:
         # ``with net.gradients():``; a forward pass waits for that stream by itself when a weight changed, ``join_gradients()``
         # makes the caller's stream wait (checkpoints, validation, host reads of a gradient).
         self.overlap = bool(overlap) and self.executor and self.inplace_grads
+        # overlap_thread (FUSION_MODEL.train_overlap_thread, default OFF): the ~170 launches of a steady-state backward pass - and what
+        # ``gradient_work`` is handed - are ENQUEUED by a host thread of this object's own (ctypes releases the GIL inside the library
+        # call), so the caller's thread goes on to the next frame's forward stage instead of spending that launch loop.  Bit for bit the
+        # same results, and measured to change nothing (228.8 against 227.6 frames/s): the gradient thread does enqueue a backward pass in
+        # 0.8 ms beside the caller, but the caller then waits that much longer for the next frame's valid-ray count - with the device
+        # chains overlapped the step is bound by the kernels' summed time, not by the host.
+        self.overlap_thread = self.overlap and bool(overlap_thread)
+        self._pool = None
+        self._jobs = []
         self._passes = 0
         self._grad_stream = None
         self._grad_tail = None
@@ -472,6 +481,47 @@ class HipTrainNet:
             self._grad_stream = torch.cuda.Stream(device=dev)
         return self._grad_stream
 
+    def _submit(self, fn):
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix='ojf-gradients')  # ONE thread: jobs run in submission order
+        fut = self._pool.submit(fn)
+        self._jobs.append(fut)
+        return fut
+
+    def _drain(self):
+        """The calling host thread waits until the gradient thread has enqueued everything it was handed; a job's exception surfaces here."""
+        jobs, self._jobs = self._jobs, []
+        err = None
+        for f in jobs:
+            try:
+                f.result()
+            except Exception as e:  # (every job is waited for: nothing of an earlier frame is left running behind the error)
+                err = err or e
+        if err is not None:
+            raise err
+
+    def gradient_work(self, fn, join=True):
+        """Runs ``fn()`` - whatever reads or writes the parameter gradients or writes the parameters - behind the backward passes
+        enqueued so far: on the gradient stream, from the gradient thread under ``overlap_thread`` (else like ``with gradients(): fn()``).
+        ``join=False`` lets the caller go on before ``fn`` has been enqueued; it is only valid when ``fn`` writes NO parameter (gradient
+        clipping between optimizer steps): a forward pass decides from the parameters' version counters whether it has to wait."""
+        gs = self._grad_stream if self.overlap else None
+        if gs is None or not self.overlap_thread:
+            with self.gradients():
+                fn()
+            return
+        ev = torch.cuda.current_stream(gs.device).record_event()
+
+        def job():
+            with torch.cuda.stream(gs):
+                gs.wait_event(ev)
+                fn()
+                self._grad_tail = gs.record_event()
+        self._submit(job)
+        if join:
+            self._drain()
+
     def gradients(self):
         """Context for everything that reads or writes the parameter gradients or writes the parameters (clip_grad_norm_, the
         flat-gradient all-reduce, optimizer.step(), zero_grad()): under ``overlap`` it runs on the gradient stream, behind the backward
@@ -480,6 +530,7 @@ class HipTrainNet:
 
     def join_gradients(self, dev=None):
         """The caller's current stream waits for everything enqueued on the gradient stream so far (no-op without ``overlap``)."""
+        self._drain()
         if self._grad_tail is not None:
             torch.cuda.current_stream(dev if dev is not None else self._grad_stream.device).wait_event(self._grad_tail)
 
@@ -530,6 +581,9 @@ class HipTrainNet:
         slot = self._passes % 2 if (self.overlap and torch.is_grad_enabled()) else 0
         self._passes += 1
         tr = self._trainer(h, w, dev, slot)
+        if tr.bwd_job is not None:  # (its launches are being enqueued by the gradient thread: the table and the event below are its)
+            job, tr.bwd_job = tr.bwd_job, None
+            job.result()
         if tr.bwd_done is not None:  # this executor's activations are still being read by its last backward pass on the gradient stream
             torch.cuda.current_stream(dev).wait_event(tr.bwd_done)
             tr.bwd_done = None
@@ -692,6 +746,7 @@ class _GradientContext:
     def __enter__(self):
         tn = self.tn
         st = tn._grad_stream if tn.overlap else None
+        tn._drain()
         if st is not None:
             st.wait_stream(torch.cuda.current_stream(st.device))
             self.ctx = torch.cuda.stream(st)
@@ -709,6 +764,7 @@ class _GradientContext:
 class _TrainerHandle:
     fwd_launches = bwd_launches = 0
     bwd_done = None  # overlap: event behind this executor's last backward pass on the gradient stream
+    bwd_job = None   # overlap_thread: the future of that pass's enqueue job
 
     def __init__(self, handle):
         self.handle = handle
@@ -757,19 +813,30 @@ class _NetFn(torch.autograd.Function):
         steady = inplace and sig is not None and all(p.grad is g for p, g in zip(tn._params, sig))
         dest = dest.contiguous()
 
-        def run_backward():
+        def run_backward(threaded=False):
             gs = tn.gradient_stream(state['dev']) if inplace else None
             if gs is None:
                 _lib.check(lib.ojf_trainer_backward(tr.handle, table, len(table), dest.data_ptr(), _lib.stream_ptr(state['dev'])), 'ojf_trainer_backward')
             else:  # overlap: behind everything enqueued on this stream so far (d_est, the gradient tensors), beside what comes next on it
-                gs.wait_event(torch.cuda.current_stream(state['dev']).record_event())
-                dest.record_stream(gs)
-                _lib.check(lib.ojf_trainer_backward(tr.handle, table, len(table), dest.data_ptr(), gs.cuda_stream), 'ojf_trainer_backward')
-                tr.bwd_done = tn._grad_tail = gs.record_event()
+                ev = torch.cuda.current_stream(state['dev']).record_event()
+
+                def enqueue():
+                    with torch.cuda.device(state['dev']):
+                        gs.wait_event(ev)
+                        dest.record_stream(gs)
+                        _lib.check(lib.ojf_trainer_backward(tr.handle, table, len(table), dest.data_ptr(), gs.cuda_stream), 'ojf_trainer_backward')
+                        tr.bwd_done = tn._grad_tail = gs.record_event()
+                        tr.bwd_launches = int(lib.ojf_trainer_launch_count(tr.handle))
+                if threaded:  # (steady state only: nothing touches this executor's table until its next forward pass has waited for the job)
+                    tr.bwd_job = tn._submit(enqueue)
+                else:
+                    tn._drain()
+                    enqueue()
+                return
             tr.bwd_launches = int(lib.ojf_trainer_launch_count(tr.handle))
 
         if steady:  # every parameter still accumulates into the tensor whose address the table already holds
-            run_backward()
+            run_backward(threaded=tn.overlap_thread)
             return (None, None) + (None,) * ctx.n_in + tuple(out)
         all_accumulating = inplace
         for i, (conv, bn, drop) in enumerate(tn._mods):

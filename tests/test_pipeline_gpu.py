@@ -925,13 +925,14 @@ def test_announced_training_frames_change_no_bit(cuda):
     assert float((a[3][1].float() > 0).sum()) > 1000
 
 
-@pytest.mark.parametrize('replay', [False, True])
-def test_backward_beside_the_next_forward_stage_changes_no_bit(cuda, replay):
+@pytest.mark.parametrize('replay,thread', [(False, False), (True, False), (False, True)])
+def test_backward_beside_the_next_forward_stage_changes_no_bit(cuda, replay, thread):
     """FUSION_MODEL.train_overlap: the backward pass of frame k on the pipeline's gradient stream beside the forward stage of frame
     k + 1 (two executors take turns; gradient clipping, optimizer step and zero_grad inside ``with pipeline.gradients():``).  The
     reference's loop order (train_fusion.py:160-189) is kept by stream dependencies instead of by one queue: outputs, losses,
     parameters, BatchNorm buffers, accumulated gradients and volumes of ten train()-mode frames with Dropout2d and an RMSprop step
-    every third frame are bit for bit those of the serial loop - also with the executor's passes replayed as device graphs."""
+    every third frame are bit for bit those of the serial loop - also with the executor's passes replayed as device graphs, and with the
+    backward pass's launches and the gradient work enqueued by the pipeline's gradient thread (``gradient_work``)."""
     h, w, grid, frames = 48, 64, 64, 10
 
     def run(overlap):
@@ -939,6 +940,7 @@ def test_backward_beside_the_next_forward_stage_changes_no_bit(cuda, replay):
         cfg, st, db, pipe = _setup(h, w, grid, False, False, 'fast', cuda)
         cfg.FUSION_MODEL.train_overlap = overlap
         cfg.FUSION_MODEL.train_replay = replay and overlap
+        cfg.FUSION_MODEL.train_overlap_thread = thread
         torch.manual_seed(11)
         for m in pipe._fusion_network.modules():
             if isinstance(m, torch.nn.Conv2d):
@@ -954,11 +956,16 @@ def test_backward_beside_the_next_forward_stage_changes_no_bit(cuda, replay):
             loss = (out['tsdf_fused'] - out['tsdf_target']).abs().mean()
             loss.backward()
             outs.append((out['tsdf_est'].detach().clone(), out['tsdf_fused'].detach().clone(), loss.detach().clone()))
-            with pipe.gradients():
+            def gradient_step(i=i):
                 torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
                 if i % 3 == 2:
                     opt.step()
                     opt.zero_grad(set_to_none=False)
+            if thread:  # the function form: enqueued by the pipeline's gradient thread, this thread waits only where the weights change
+                pipe.gradient_work(gradient_step, join=i % 3 == 2)
+            else:
+                with pipe.gradients():
+                    gradient_step()
         pipe.join_gradients()
         grads = [p.grad.detach().clone() for p in net.parameters() if p.grad is not None]
         torch.cuda.synchronize()
