@@ -293,6 +293,7 @@ class HipTrainNet:
         self._grad_stream = None
         self._grad_tail = None
         self._epoch_joined = None
+        self._unjoined_backward = False  # a backward pass went to the gradient stream and nothing has ordered the caller behind it yet
 
     # ---- one Sequential of conv/BN/act/dropout slots -> units ------------------------------------------------------
     def _unit(self, x, conv, bn, act, dropout, group, slot, scale=1.0):
@@ -512,6 +513,7 @@ class HipTrainNet:
                 fn()
             return
         ev = torch.cuda.current_stream(gs.device).record_event()
+        self._unjoined_backward = False
 
         def job():
             with torch.cuda.stream(gs):
@@ -531,6 +533,7 @@ class HipTrainNet:
     def join_gradients(self, dev=None):
         """The caller's current stream waits for everything enqueued on the gradient stream so far (no-op without ``overlap``)."""
         self._drain()
+        self._unjoined_backward = False
         if self._grad_tail is not None:
             torch.cuda.current_stream(dev if dev is not None else self._grad_stream.device).wait_event(self._grad_tail)
 
@@ -620,6 +623,13 @@ class HipTrainNet:
                 off += n
         epoch = self._epoch(mods)
         if self._grad_tail is not None and epoch != self._epoch_joined:
+            if self._unjoined_backward:
+                # a parameter was written while a backward pass on the gradient stream had neither been joined nor been followed by a
+                # gradients() / gradient_work() section: that optimizer step ran on the caller's stream BESIDE the backward pass it needed
+                self._epoch_joined = epoch
+                raise _lib.OjfError('HipTrainNet: a parameter changed outside `with pipeline.gradients():` while train_overlap is on - the '
+                                    'optimizer step (and gradient clipping, zero_grad) must run inside that context (or behind '
+                                    'pipeline.join_gradients()): the backward pass runs on the gradient stream, not on the current one')
             # a weight changed since the last pass that looked (the optimizer step sits on the gradient stream): this pass - packing included -
             # goes behind it
             torch.cuda.current_stream(dev).wait_event(self._grad_tail)
@@ -747,6 +757,7 @@ class _GradientContext:
         tn = self.tn
         st = tn._grad_stream if tn.overlap else None
         tn._drain()
+        tn._unjoined_backward = False
         if st is not None:
             st.wait_stream(torch.cuda.current_stream(st.device))
             self.ctx = torch.cuda.stream(st)
@@ -827,6 +838,7 @@ class _NetFn(torch.autograd.Function):
                         _lib.check(lib.ojf_trainer_backward(tr.handle, table, len(table), dest.data_ptr(), gs.cuda_stream), 'ojf_trainer_backward')
                         tr.bwd_done = tn._grad_tail = gs.record_event()
                         tr.bwd_launches = int(lib.ojf_trainer_launch_count(tr.handle))
+                tn._unjoined_backward = True
                 if threaded:  # (steady state only: nothing touches this executor's table until its next forward pass has waited for the job)
                     tr.bwd_job = tn._submit(enqueue)
                 else:

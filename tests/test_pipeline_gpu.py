@@ -983,3 +983,32 @@ def test_backward_beside_the_next_forward_stage_changes_no_bit(cuda, replay, thr
         assert torch.equal(x, y)
     for x, y in zip(a[4], b[4]):
         assert torch.equal(x.view(torch.int16), y.view(torch.int16))
+
+
+def test_optimizer_step_outside_the_gradient_context_is_loud(cuda):
+    """train_overlap moves the backward pass to the gradient stream: an optimizer step on the caller's stream would run beside the
+    backward pass it needs.  The next fuse_training sees the parameters' version counters move without a gradients() section (or a
+    join) since that backward pass and raises instead of training on half-written gradients; behind join_gradients() the plain loop
+    of train_fusion.py:182-189 is fine."""
+    h, w, grid = 48, 64, 64
+    torch.manual_seed(10)
+    cfg, st, db, pipe = _setup(h, w, grid, False, False, 'fast', cuda)
+    cfg.FUSION_MODEL.train_overlap = True
+    pipe.train()
+    net = pipe._fusion_network
+    opt = torch.optim.RMSprop(net.parameters(), lr=1e-4)
+    batches = [_batch(st, i, cuda) for i in range(4)]
+
+    def frame(i):
+        out = pipe.fuse_training(batches[i], db, cuda)
+        (out['tsdf_fused'] - out['tsdf_target']).abs().mean().backward()
+    frame(0)
+    frame(1)  # (steady state: from the second pass on the backward pass runs on the gradient stream)
+    pipe.join_gradients()
+    opt.step()  # behind a join: allowed
+    frame(2)
+    opt.step()  # NOT behind anything
+    with pytest.raises(Exception, match='outside `with pipeline.gradients'):
+        frame(3)
+    pipe.join_gradients()
+    torch.cuda.synchronize()
