@@ -89,6 +89,12 @@ constexpr int kAccThreads = 512;
 // WCOMB (round 4, OJF_INTEGRATE_WAVE_COMBINE=1; off by default): colliding writes INSIDE a wave are combined in registers
 // before they reach the LDS hash - measured 60.2 against 56.8 us per frame for the integrate stage at 320x240 -> 256^3 (the
 // exchanges cost more VALU time than the same-address LDS atomics they spare; results identical bit for bit)
+#ifdef OJF_ACC_STAMPS  // profiling build only (tools/acc_stamps.py): phase stamps of every accumulate block, thread 0
+__device__ unsigned long long g_acc_stamps[4096][8];
+#define ACC_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_acc_stamps[blockIdx.x][i] = (i) >= 6 ? wall_clock64() : clock64(); } while (0)
+#else
+#define ACC_STAMP(i) do { } while (0)
+#endif
 template <bool SEM, bool WCOMB>
 __device__ __forceinline__ void accumulate_tiled_body(const IntegrateArgs &a, const Camera &cam)
 {
@@ -97,17 +103,15 @@ __device__ __forceinline__ void accumulate_tiled_body(const IntegrateArgs &a, co
     __shared__ unsigned long long accu[kSlots];
     __shared__ unsigned int elast[SEM ? kSlots : 1];
     __shared__ unsigned int ediff[SEM ? kSlots : 1];
-    __shared__ unsigned int n_entries, n_new, n_rec, base_rec;
+    __shared__ unsigned int n_entries, n_new;
     __shared__ double frame[6][kTilePix];  // ray frame (voxel-space point, unit direction) of the tile's pixels
-    // slots of the voxels this tile touched first: 4 KB on top of the ray frames, which are dead once the items are done
-    // (46 KB per geometry-only block: three blocks per CU)
-    unsigned short *newlist = reinterpret_cast<unsigned short *>(&frame[0][0]);
-    static_assert(sizeof(frame) >= kSlots * sizeof(unsigned short), "newlist aliases the ray frames");
+    ACC_STAMP(6);
+    ACC_STAMP(0);
     for (int s = threadIdx.x; s < kSlots; s += kAccThreads) {
         keys[s] = kEmpty; accw[s] = 0; accu[s] = 0;
         if constexpr (SEM) { elast[s] = 0; ediff[s] = 0; }
     }
-    if (threadIdx.x == 0) { n_entries = 0; n_new = 0; n_rec = 0; }
+    if (threadIdx.x == 0) { n_entries = 0; n_new = 0; }
     // the counter set of this call (header word kPhaseAcc: flipped by the previous call's finalize kernel, nobody writes it now)
     const unsigned int phase = a.phased ? a.counters[kPhaseAcc] & 1u : 0u;
     unsigned int *const counters = a.counters + 32 * phase;
@@ -115,6 +119,20 @@ __device__ __forceinline__ void accumulate_tiled_body(const IntegrateArgs &a, co
     const int tiles_x = (a.w + kTileW - 1) / kTileW;
     const int tile = banded_block_x();  // one band of the image per XCD: neighbouring tiles hit the same voxels
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    // Record of hash slot s of this tile = element s of the tile's own slice of the record array (round 6: no numbering pass).  The
+    // thread that CLAIMS a slot fires the voxel's list-head exchange at once and files the returned predecessor in the record when the
+    // item's eight corners are through: the ~830 k returning atomics of a frame (10.6 us of a block's 25.9 when they all went out in a
+    // publish phase of their own, profiles/r06_accumulate_stamps.txt) now travel under the items' LDS work.
+    const unsigned int base_rec = (unsigned int)tile * kSlots;
+    auto claim = [&](unsigned int sidx, unsigned int lin) { return atomicExch(&a.head[lin], base_rec + sidx + 1u); };
+    auto file_prev = [&](int sidx, unsigned int prev) {
+        a.recs[base_rec + sidx].next = prev;
+        // first touch of the voxel in this call: into the tile's slice of the first-touch list, in the order the exchanges come back -
+        // the order of the items, i.e. of neighbouring rays: the finalize kernel's lanes then walk neighbouring voxels (a list in hash
+        // order, which rounds 2-5 wrote, costs that kernel 2 us at 320x240 and 12 us at 640x480; an LDS copy of the list beside the live ray
+        // frames costs the third block per CU: profiles/r06_accumulate_stamps.txt)
+        if (prev == 0) a.touched[base_rec + atomicAdd(&n_new, 1u)] = keys[sidx];
+    };
     // the call's range-guard decision (kGuardLatch): this kernel fills the workspace only and never skips; the finalize kernel
     // reads the latch and leaves the volumes alone when the net's range guard had fired
     if (blockIdx.x == 0 && threadIdx.x == 0) a.counters[kGuardLatch] = guard_set(a) ? 1u : 0u;
@@ -136,6 +154,7 @@ __device__ __forceinline__ void accumulate_tiled_body(const IntegrateArgs &a, co
         }
     }
     __syncthreads();
+    ACC_STAMP(1);
 
     constexpr bool sem = SEM;
     const int half = (a.n_points - 1) / 2;
@@ -158,6 +177,10 @@ __device__ __forceinline__ void accumulate_tiled_body(const IntegrateArgs &a, co
             v = v < -a.trunc ? -a.trunc : (v > a.trunc ? a.trunc : v);
             const uint8_t id_e = sem ? a.sem_ids[n] : 0;
             const unsigned int e0 = ((unsigned int)n * a.n_tail + k) * 8u + 1u;
+            int won[8];
+            unsigned int pv[8];
+    #pragma unroll
+            for (int q = 0; q < 8; ++q) won[q] = -1;
     #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 int64_t idx[3];
@@ -177,7 +200,8 @@ __device__ __forceinline__ void accumulate_tiled_body(const IntegrateArgs &a, co
                 for (int probe = 0; probe < 16; ++probe) {
                     const unsigned int sidx = (h0 + probe) & (kSlots - 1);
                     const unsigned int prev = atomicCAS(&keys[sidx], kEmpty, lin);
-                    if (prev == kEmpty || prev == lin) { slot = (int)sidx; break; }
+                    if (prev == kEmpty) { slot = (int)sidx; won[q] = slot; pv[q] = claim(sidx, lin); break; }  // (the exchange is on its way)
+                    if (prev == lin) { slot = (int)sidx; break; }
                 }
                 if (slot >= 0) {
                     atomicAdd(&accw[slot], xw);
@@ -192,6 +216,9 @@ __device__ __forceinline__ void accumulate_tiled_body(const IntegrateArgs &a, co
                     if (a.stats) atomicAdd(&a.stats[2], 1u);
                 }
             }
+    #pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (won[q] >= 0) file_prev(won[q], pv[q]);  // (first use of the exchanges' results: all eight were issued above)
         }
     } else {
         const int lane = threadIdx.x & 63;
@@ -215,6 +242,10 @@ __device__ __forceinline__ void accumulate_tiled_body(const IntegrateArgs &a, co
             v = v < -a.trunc ? -a.trunc : (v > a.trunc ? a.trunc : v);
             const uint8_t id_e = (sem && live) ? a.sem_ids[n] : 0;
             const unsigned int e0 = ((unsigned int)n * a.n_tail + k) * 8u + 1u;
+            int won[8];
+            unsigned int pv[8];
+    #pragma unroll
+            for (int q = 0; q < 8; ++q) won[q] = -1;
     #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 int64_t idx[3];
@@ -262,7 +293,8 @@ __device__ __forceinline__ void accumulate_tiled_body(const IntegrateArgs &a, co
                 for (int probe = 0; probe < 16; ++probe) {
                     const unsigned int sidx = (h0 + probe) & (kSlots - 1);
                     const unsigned int prev = atomicCAS(&keys[sidx], kEmpty, lin);
-                    if (prev == kEmpty || prev == lin) { slot = (int)sidx; break; }
+                    if (prev == kEmpty) { slot = (int)sidx; won[q] = slot; pv[q] = claim(sidx, lin); break; }  // (the exchange is on its way)
+                    if (prev == lin) { slot = (int)sidx; break; }
                 }
                 if (slot >= 0) {
                     atomicAdd(&accw[slot], xw);
@@ -277,49 +309,41 @@ __device__ __forceinline__ void accumulate_tiled_body(const IntegrateArgs &a, co
                     if (a.stats) atomicAdd(&a.stats[2], 1u);
                 }
             }
+    #pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (won[q] >= 0) file_prev(won[q], pv[q]);  // (first use of the exchanges' results: all eight were issued above)
         }
     }
     if (n_in) atomicAdd(&n_entries, n_in);
     __syncthreads();
-    // number this tile's records inside its own slice of the record array, then publish them
-    unsigned int mine[kSlots / kAccThreads];
+    ACC_STAMP(2);
+    // publish the slots' sums (the records' `next` fields and the first-touch list were written while the items ran)
+    unsigned int n_mine = 0;
 #pragma unroll
     for (int j = 0; j < kSlots / kAccThreads; ++j) {
         const int s = threadIdx.x + kAccThreads * j;
-        mine[j] = keys[s] != kEmpty ? atomicAdd(&n_rec, 1u) : kEmpty;
+        if (keys[s] == kEmpty) continue;
+        VoxelRec *r = a.recs + base_rec + s;
+        r->lin = keys[s]; r->w = accw[s]; r->u = accu[s];
+        r->e_last = SEM ? elast[s] : 0u; r->e_diff = SEM ? ediff[s] : 0u;
+        ++n_mine;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        base_rec = tile * kSlots;
-        if (a.stats) {  // test / profiling only: same-line atomics cost 14 us per frame
-            atomicAdd(&a.stats[1], n_entries);
-            atomicAdd(&a.stats[2], n_rec);
-        }
+    if (a.stats) {  // test / profiling only: same-line atomics cost 14 us per frame
+        if (n_mine) atomicAdd(&a.stats[2], n_mine);
+        if (threadIdx.x == 0) atomicAdd(&a.stats[1], n_entries);
     }
+    ACC_STAMP(3);
     __syncthreads();
-    // All of a thread's list-head exchanges are issued before any of their results is used: the returning
-    // atomics' round trips (~1.5 us each) overlap instead of adding up (8 slots per thread).
-    unsigned int prev[kSlots / kAccThreads];
-#pragma unroll
-    for (int j = 0; j < kSlots / kAccThreads; ++j)
-        if (mine[j] != kEmpty) prev[j] = atomicExch(&a.head[keys[threadIdx.x + kAccThreads * j]], base_rec + mine[j] + 1u);
-#pragma unroll
-    for (int j = 0; j < kSlots / kAccThreads; ++j) {
-        if (mine[j] == kEmpty) continue;
-        const int s = threadIdx.x + kAccThreads * j;
-        VoxelRec r;
-        r.lin = keys[s]; r.next = prev[j]; r.w = accw[s]; r.u = accu[s];
-        r.e_last = SEM ? elast[s] : 0u; r.e_diff = SEM ? ediff[s] : 0u;
-        a.recs[base_rec + mine[j]] = r;
-        if (prev[j] == 0) newlist[atomicAdd(&n_new, 1u)] = (unsigned short)s;
-    }
-    __syncthreads();
+    ACC_STAMP(4);
     if (threadIdx.x == 0) a.tile_new[tile] = n_new;
-    for (unsigned int i = threadIdx.x; i < n_new; i += kAccThreads) a.touched[tile * kSlots + i] = keys[newlist[i]];
+    ACC_STAMP(5);
+    ACC_STAMP(7);
 }
 
+// (blocks per CU by LDS: three geometry-only, two with the entry-id tables = six / four waves per SIMD; the second launch-bounds argument holds the register
+// allocation to that - 80 VGPRs for six waves per SIMD - now that a lane keeps eight exchange results in flight)
 template <bool SEM, bool WCOMB>
-__global__ __launch_bounds__(kAccThreads) void integrate_accumulate_tiled_kernel(IntegrateArgs a, Camera cam)
+__global__ __launch_bounds__(kAccThreads, SEM ? 4 : 6) void integrate_accumulate_tiled_kernel(IntegrateArgs a, Camera cam)
 {
     accumulate_tiled_body<SEM, WCOMB>(a, cam);
 }
@@ -328,7 +352,7 @@ __global__ __launch_bounds__(kAccThreads) void integrate_accumulate_tiled_kernel
 // own volumes, camera, est rows and workspace.  The same blocks run the same code per scene: the same bits as separate calls.
 struct IntegrateMany { IntegrateArgs a[OJF_MAX_SCENES]; Camera cam[OJF_MAX_SCENES]; };
 template <bool SEM>
-__global__ __launch_bounds__(kAccThreads) void integrate_accumulate_many_kernel(IntegrateMany m)
+__global__ __launch_bounds__(kAccThreads, SEM ? 4 : 6) void integrate_accumulate_many_kernel(IntegrateMany m)
 {
     accumulate_tiled_body<SEM, false>(m.a[blockIdx.y], m.cam[blockIdx.y]);
 }
@@ -764,3 +788,10 @@ OJF_API int ojf_integrate_entries(const float *values, const int64_t *indices, c
     hipLaunchKernelGGL(integrate_finalize_kernel, dim3(1024), dim3(256), 0, st, a);
     return check_hip(hipGetLastError(), "ojf_integrate_entries launch");
 }
+
+#ifdef OJF_ACC_STAMPS
+extern "C" __attribute__((visibility("default"))) int ojf_debug_acc_stamps(void *host_dst, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(ojf::g_acc_stamps), bytes < sizeof(ojf::g_acc_stamps) ? bytes : sizeof(ojf::g_acc_stamps));
+}
+#endif
