@@ -46,7 +46,18 @@ struct ExtractArgs {
 
 constexpr int kNetPitch = 36;  // floats per pixel of the LDS transpose tile (<= 8 channel groups + padding against bank conflicts)
 
-constexpr int kMaxTilePoints = 16;  // 64 * n_points threads per block
+constexpr int kMaxTilePoints = 16;  // at most 64 * n_points threads per block
+// Waves of an extract_tile_kernel block: every wave takes the samples k = wave, wave + waves, ... of the block's 64 pixels.  Rounds 1-6
+// ran one wave per sample: nine-wave blocks, of which a CU held TWO (nine waves do not spread 7 / 7 / 7 / 6 over the SIMDs that 72 VGPRs
+// allow), so the 1200 blocks of a 320x240 frame ran in three waves of 4.5 us each (profiles/r06_accumulate_stamps.txt).  Three samples per
+// wave: three-wave blocks, eight or nine per CU, the whole frame resident at once.  OJF_EXTRACT_WAVES=n forces n (A/B).
+static int extract_block_waves(int n_points)
+{
+    static const int forced = getenv("OJF_EXTRACT_WAVES") ? atoi(getenv("OJF_EXTRACT_WAVES")) : 0;
+    int waves = forced > 0 ? forced : (n_points + 2) / 3;
+    if (waves > n_points) waves = n_points;
+    return waves < 1 ? 1 : waves;
+}
 
 // body shared by the two mappings: sample k of pixel n on the ray frame (cv, dir)
 __device__ __forceinline__ void extract_item(const ExtractArgs &a, int n, int k, const double cv[3], const double dir[3],
@@ -134,7 +145,13 @@ __device__ __forceinline__ void extract_item(const ExtractArgs &a, int n, int k,
     }
 }
 
-// n_points <= kMaxTilePoints: blockDim.x = 64 * n_points, wave k = sample k of the block's 64 pixels
+#ifdef OJF_EXT_STAMPS  // profiling build only (tools/acc_stamps.py): phase stamps of every extract block, thread 0 and the last wave's lane 0
+__device__ unsigned long long g_ext_stamps[4096][8];
+#define EXT_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_ext_stamps[blockIdx.x][i] = (i) >= 6 ? wall_clock64() : clock64(); } while (0)
+#else
+#define EXT_STAMP(i) do { } while (0)
+#endif
+// n_points <= kMaxTilePoints: blockDim.x = 64 * waves (extract_block_waves), wave v = samples v, v + waves, ... of the block's 64 pixels
 template <int kTileW, int kTileH>
 __device__ __forceinline__ void extract_tile_body(const ExtractArgs &a, const Camera &cam)
 {
@@ -142,15 +159,17 @@ __device__ __forceinline__ void extract_tile_body(const ExtractArgs &a, const Ca
     __shared__ double frame[6][64];
     __shared__ float pcl[3][64];
     const int N = a.h * a.w;
-    const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
     const int ptile = banded_block_x();  // one band of tile rows per XCD: neighbouring rays gather the same lines
     if (ptile >= a.n_tiles) return;      // (block-uniform: a padding block of the banded grid)
+    EXT_STAMP(6);
+    EXT_STAMP(0);
     const int tiles_x = (a.w + kTileW - 1) / kTileW;
     const int ty = ptile / tiles_x, tx = ptile - ty * tiles_x;
     const int r = ty * kTileH + lane % kTileH, c = tx * kTileW + lane / kTileH;
     const bool valid = r < a.h && c < a.w;
     const int n = valid ? r * a.w + c : N;  // (n >= N: no pixel)
-    if (k == 0 && n < N) {
+    if (wave == 0 && n < N) {
         float pw[3];
         double cv[3], dir[3];
         unproject(r, c, a.depth[n], cam, pw);
@@ -163,12 +182,13 @@ __device__ __forceinline__ void extract_tile_body(const ExtractArgs &a, const Ca
         }
     }
     __syncthreads();
+    EXT_STAMP(1);
     if (a.out_layout != 2) {
         if (n >= N) return;
         const double cv[3] = {frame[0][lane], frame[1][lane], frame[2][lane]};
         const double dir[3] = {frame[3][lane], frame[4][lane], frame[5][lane]};
         const float pw[3] = {pcl[0][lane], pcl[1][lane], pcl[2][lane]};
-        extract_item(a, n, k, cv, dir, pw);
+        for (int k = wave; k < a.n_points; k += waves) extract_item(a, n, k, cv, dir, pw);
         return;
     }
     // net-input form: the block's 64 x (2P + 1) results are transposed through LDS into the net's float4 channel planes
@@ -178,13 +198,15 @@ __device__ __forceinline__ void extract_tile_body(const ExtractArgs &a, const Ca
         const double cv[3] = {frame[0][lane], frame[1][lane], frame[2][lane]};
         const double dir[3] = {frame[3][lane], frame[4][lane], frame[5][lane]};
         const float pw[3] = {pcl[0][lane], pcl[1][lane], pcl[2][lane]};
-        extract_item(a, n, k, cv, dir, pw, tile + lane * kNetPitch + k);
-        if (k == 0) {
+        for (int k = wave; k < a.n_points; k += waves) extract_item(a, n, k, cv, dir, pw, tile + lane * kNetPitch + k);
+        if (wave == 0) {
             tile[lane * kNetPitch + 2 * a.n_points] = a.depth[n];
             for (int c = 2 * a.n_points + 1; c < 4 * a.net_cs4; ++c) tile[lane * kNetPitch + c] = 0.0f;
         }
     }
+    EXT_STAMP(2);
     __syncthreads();
+    EXT_STAMP(3);
     bool bad = false;
     for (int t = threadIdx.x; t < 64 * a.net_cs4; t += blockDim.x) {
         // stores walk ALONG the rows (the planes are row-major): px -> (row px / kTileW, column px % kTileW) = 64 contiguous bytes per row
@@ -197,6 +219,8 @@ __device__ __forceinline__ void extract_tile_body(const ExtractArgs &a, const Ca
         bad = bad || fabsf(v.x) > 65504.0f || fabsf(v.y) > 65504.0f || fabsf(v.z) > 65504.0f || fabsf(v.w) > 65504.0f;
     }
     if (bad && a.ovf) guard_raise(a.ovf, 1);  // split-fp16 range guard of the net input (NaN passes, like everywhere else)
+    EXT_STAMP(4);
+    EXT_STAMP(7);
 }
 
 template <int TW, int TH>
@@ -269,8 +293,8 @@ OJF_API int ojf_extract(const float *depth, const float *Ki, const float *E, con
     a.n_tiles = extract_tiles(h, w, cols);
     const Camera cam = make_camera(Ki, E, origin, res);
     if (n_points <= kMaxTilePoints) {
-        if (cols) hipLaunchKernelGGL((extract_tile_kernel<4, 16>), dim3((a.n_tiles + 7) / 8 * 8), dim3(64 * n_points), 0, as_stream(stream), a, cam);
-        else hipLaunchKernelGGL((extract_tile_kernel<16, 4>), dim3((a.n_tiles + 7) / 8 * 8), dim3(64 * n_points), 0, as_stream(stream), a, cam);
+        if (cols) hipLaunchKernelGGL((extract_tile_kernel<4, 16>), dim3((a.n_tiles + 7) / 8 * 8), dim3(64 * extract_block_waves(n_points)), 0, as_stream(stream), a, cam);
+        else hipLaunchKernelGGL((extract_tile_kernel<16, 4>), dim3((a.n_tiles + 7) / 8 * 8), dim3(64 * extract_block_waves(n_points)), 0, as_stream(stream), a, cam);
     } else {
         const int items = h * w * n_points;
         hipLaunchKernelGGL(extract_kernel, dim3((items + 255) / 256), dim3(256), 0, as_stream(stream), a, cam);
@@ -297,8 +321,8 @@ OJF_API int ojf_extract_to_net(const float *depth, const float *Ki, const float 
     const bool cols = extract_columns(E);
     a.n_tiles = extract_tiles(h, w, cols);
     const Camera cam = make_camera(Ki, E, origin, res);
-    if (cols) hipLaunchKernelGGL((extract_tile_kernel<4, 16>), dim3((a.n_tiles + 7) / 8 * 8), dim3(64 * n_points), 0, as_stream(stream), a, cam);
-    else hipLaunchKernelGGL((extract_tile_kernel<16, 4>), dim3((a.n_tiles + 7) / 8 * 8), dim3(64 * n_points), 0, as_stream(stream), a, cam);
+    if (cols) hipLaunchKernelGGL((extract_tile_kernel<4, 16>), dim3((a.n_tiles + 7) / 8 * 8), dim3(64 * extract_block_waves(n_points)), 0, as_stream(stream), a, cam);
+    else hipLaunchKernelGGL((extract_tile_kernel<16, 4>), dim3((a.n_tiles + 7) / 8 * 8), dim3(64 * extract_block_waves(n_points)), 0, as_stream(stream), a, cam);
     return check_hip(hipGetLastError(), "ojf_extract_to_net launch");
 }
 
@@ -340,7 +364,14 @@ OJF_API int ojf_extract_many(int n, const ojf_extract_job *jobs, int X, int Y, i
     const bool cols = extract_columns(jobs[0].E_host);
     for (int i = 0; i < n; ++i) m.a[i].n_tiles = extract_tiles(h, w, cols);
     const dim3 grid((extract_tiles(h, w, cols) + 7) / 8 * 8, n);
-    if (cols) hipLaunchKernelGGL((extract_tile_many_kernel<4, 16>), grid, dim3(64 * n_points), 0, as_stream(stream), m);
-    else hipLaunchKernelGGL((extract_tile_many_kernel<16, 4>), grid, dim3(64 * n_points), 0, as_stream(stream), m);
+    if (cols) hipLaunchKernelGGL((extract_tile_many_kernel<4, 16>), grid, dim3(64 * extract_block_waves(n_points)), 0, as_stream(stream), m);
+    else hipLaunchKernelGGL((extract_tile_many_kernel<16, 4>), grid, dim3(64 * extract_block_waves(n_points)), 0, as_stream(stream), m);
     return check_hip(hipGetLastError(), "ojf_extract_many launch");
 }
+
+#ifdef OJF_EXT_STAMPS
+extern "C" __attribute__((visibility("default"))) int ojf_debug_ext_stamps(void *host_dst, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(ojf::g_ext_stamps), bytes < sizeof(ojf::g_ext_stamps) ? bytes : sizeof(ojf::g_ext_stamps));
+}
+#endif

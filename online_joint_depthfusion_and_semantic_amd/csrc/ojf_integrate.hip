@@ -461,6 +461,12 @@ __device__ __forceinline__ void finalize_voxel(const IntegrateArgs &a, size_t li
 // head -> 2-3 records -> volumes) and a 16x8 tile first-touches ~320 voxels - with one voxel per lane a 256-thread block
 // walked them in two rounds of one chain each and the kernel sat 74 % parked (round 4's counters); two chains per lane
 // are one round with twice the loads in flight.  Same operations per voxel as finalize_voxel: same bits.
+#ifdef OJF_ACC_STAMPS
+__device__ unsigned long long g_fin_stamps[4096][8];
+#define FIN_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_fin_stamps[blockIdx.x][i] = (i) >= 6 ? wall_clock64() : clock64(); } while (0)
+#else
+#define FIN_STAMP(i) do { } while (0)
+#endif
 template <int K>
 __device__ __forceinline__ void finalize_voxels(const IntegrateArgs &a, const unsigned int *list, unsigned int i0, unsigned int stride,
                                                 unsigned int n, unsigned int per_pixel, bool sem, bool skip)
@@ -480,6 +486,7 @@ __device__ __forceinline__ void finalize_voxels(const IntegrateArgs &a, const un
             if (on[k]) a.head[lin[k]] = 0;
         return;
     }
+    FIN_STAMP(1);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         ri[k] = on[k] ? a.head[lin[k]] : 0u;
@@ -496,6 +503,7 @@ __device__ __forceinline__ void finalize_voxels(const IntegrateArgs &a, const un
     bool any = false;
 #pragma unroll
     for (int k = 0; k < K; ++k) any = any || ri[k] != 0;
+    FIN_STAMP(2);
     while (any) {  // 2-3 records per voxel; integer sums: any order gives the same bits
         VoxelRec r[K];
 #pragma unroll
@@ -513,6 +521,7 @@ __device__ __forceinline__ void finalize_voxels(const IntegrateArgs &a, const un
             any = any || ri[k] != 0;
         }
     }
+    FIN_STAMP(3);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         if (!on[k]) continue;
@@ -554,12 +563,16 @@ __device__ __forceinline__ void finalize_body(const IntegrateArgs &a)
     // this kernel runs, the same for every block - all of the call's voxels are updated or none
     const bool skip = a.guard != nullptr && a.counters[kGuardLatch] != 0u;
     constexpr int K = 2;
+    FIN_STAMP(6);
+    FIN_STAMP(0);
     for (int tile = banded_block_x(); tile < a.n_tiles; tile += gridDim.x) {  // (the XCD that accumulated the tile)
         const unsigned int n = a.tile_new[tile];
         const unsigned int *list = a.touched + (size_t)tile * kSlots;
         for (unsigned int i = threadIdx.x; i < n; i += K * blockDim.x) finalize_voxels<K>(a, list, i, blockDim.x, n, per_pixel, sem, skip);
         if (a.stats && threadIdx.x == 0 && n) atomicAdd(&a.stats[0], n);
     }
+    FIN_STAMP(4);
+    FIN_STAMP(7);
     // (header word kPhaseFin: written by this call's accumulate kernel, stable while finalize runs)
     const unsigned int phase = a.phased ? a.counters[kPhaseFin] & 1u : 0u;
     const unsigned int count = a.counters[32 * phase];
@@ -793,5 +806,9 @@ OJF_API int ojf_integrate_entries(const float *values, const int64_t *indices, c
 extern "C" __attribute__((visibility("default"))) int ojf_debug_acc_stamps(void *host_dst, size_t bytes)
 {
     return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(ojf::g_acc_stamps), bytes < sizeof(ojf::g_acc_stamps) ? bytes : sizeof(ojf::g_acc_stamps));
+}
+extern "C" __attribute__((visibility("default"))) int ojf_debug_fin_stamps(void *host_dst, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(ojf::g_fin_stamps), bytes < sizeof(ojf::g_fin_stamps) ? bytes : sizeof(ojf::g_fin_stamps));
 }
 #endif

@@ -1,11 +1,12 @@
-"""Profiling helper (not a test): phase stamps of the accumulate kernel's blocks from a build with -DOJF_ACC_STAMPS
-(OJF_LIB_PATH=.../libojf_stamps.so): where a block of integrate_accumulate_tiled_kernel spends its time."""
+"""Profiling helper (not a test): phase stamps of the extract / accumulate / finalize kernels' blocks from a build with -DOJF_EXT_STAMPS /
+-DOJF_ACC_STAMPS (OJF_LIB_PATH=.../libojf_stamps.so): where a block of those kernels spends its time."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 import bench
 from online_joint_depthfusion_and_semantic_amd import _lib
+
 
 def main():
     dev = torch.device('cuda:0')
@@ -17,21 +18,31 @@ def main():
             case.fuse(i)
     torch.cuda.synchronize()
     lib = ctypes.CDLL(_lib.LIB_PATH)
-    buf = np.zeros((4096, 8), dtype=np.uint64)
-    rc = lib.ojf_debug_acc_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.nbytes))
-    assert rc == 0, rc
-    n = 600
-    b = buf[:n].astype(np.float64)
-    wall = (b[:, 7] - b[:, 6]) * 10e-3  # 100 MHz -> us
-    cyc = b[:, 5] - b[:, 0]
-    rate = np.median(cyc / np.maximum(wall, 1e-9))  # cycles per us
-    names = ['hash clear + ray frames', 'items (corners, hash atomics)', 'number the records', 'head exchanges + record stores', 'first-touch list']
-    print('blocks %d: block life %.2f us median (%.2f mean, %.2f max); clock64 %.0f per us' % (n, np.median(wall), wall.mean(), wall.max(), rate))
-    for i, nm in enumerate(names):
-        d = (b[:, i + 1] - b[:, i]) / rate
-        print('  %-34s median %6.2f us  mean %6.2f  p90 %6.2f' % (nm, np.median(d), d.mean(), np.percentile(d, 90)))
-    start = (b[:, 6] - b[:, 6].min()) * 10e-3
-    end = (b[:, 7] - b[:, 6].min()) * 10e-3
-    print('  block starts: median %.2f us, p90 %.2f, max %.2f after the first; last block ends at %.2f us' % (np.median(start), np.percentile(start, 90), start.max(), end.max()))
+
+    def report(fn, n, title, names):
+        if not hasattr(lib, fn):
+            return
+        buf = np.zeros((4096, 8), dtype=np.uint64)
+        rc = getattr(lib, fn)(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.nbytes))
+        assert rc == 0, rc
+        b = buf[:n].astype(np.float64)
+        b = b[b[:, 6] > 0]
+        wall = (b[:, 7] - b[:, 6]) * 10e-3  # 100 MHz -> us
+        last = len(names)
+        cyc = b[:, last] - b[:, 0]
+        ok = wall > 0.5
+        rate = np.median(cyc[ok] / wall[ok]) if ok.any() else 2400.0  # cycles per us
+        print('%s: blocks %d: block life %.2f us median (%.2f mean, %.2f max); clock64 %.0f per us' % (title, len(b), np.median(wall), wall.mean(), wall.max(), rate))
+        for i, nm in enumerate(names):
+            d = (b[:, i + 1] - b[:, i]) / rate
+            print('  %-48s median %6.2f us  mean %6.2f  p90 %6.2f' % (nm, np.median(d), d.mean(), np.percentile(d, 90)))
+        start = (b[:, 6] - b[:, 6].min()) * 10e-3
+        end = (b[:, 7] - b[:, 6].min()) * 10e-3
+        print('  block starts: median %.2f us, p90 %.2f, max %.2f after the first; last block ends at %.2f us' % (np.median(start), np.percentile(start, 90), start.max(), end.max()))
+
+    report('ojf_debug_ext_stamps', 1200, 'extract_tile_kernel', ['ray frames (wave 0) + barrier', 'items: corners, gathers (thread 0 = sample 0)', 'barrier', 'transposed stores'])
+    report('ojf_debug_acc_stamps', 600, 'integrate_accumulate_tiled_kernel', ['hash clear + ray frames', 'items (corners, hash atomics, head exchanges)', 'barrier', 'record stores', 'tile count'])
+    report('ojf_debug_fin_stamps', 600, 'integrate_finalize_kernel', ['first-touch list load', 'head + old values requested', 'record walk', 'volume stores'])
+
 
 main()
