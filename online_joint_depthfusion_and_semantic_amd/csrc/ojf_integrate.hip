@@ -103,7 +103,8 @@ __device__ __forceinline__ void accumulate_tiled_body(const IntegrateArgs &a, co
     __shared__ unsigned long long accu[kSlots];
     __shared__ unsigned int elast[SEM ? kSlots : 1];
     __shared__ unsigned int ediff[SEM ? kSlots : 1];
-    __shared__ unsigned int n_entries, n_new;
+    __shared__ unsigned int n_entries, n_new, n_rec;
+    __shared__ unsigned short recidx[kSlots];  // record of the slot inside the tile's slice (claim order)
     __shared__ double frame[6][kTilePix];  // ray frame (voxel-space point, unit direction) of the tile's pixels
     ACC_STAMP(6);
     ACC_STAMP(0);
@@ -111,7 +112,7 @@ __device__ __forceinline__ void accumulate_tiled_body(const IntegrateArgs &a, co
         keys[s] = kEmpty; accw[s] = 0; accu[s] = 0;
         if constexpr (SEM) { elast[s] = 0; ediff[s] = 0; }
     }
-    if (threadIdx.x == 0) { n_entries = 0; n_new = 0; }
+    if (threadIdx.x == 0) { n_entries = 0; n_new = 0; n_rec = 0; }
     // the counter set of this call (header word kPhaseAcc: flipped by the previous call's finalize kernel, nobody writes it now)
     const unsigned int phase = a.phased ? a.counters[kPhaseAcc] & 1u : 0u;
     unsigned int *const counters = a.counters + 32 * phase;
@@ -119,18 +120,24 @@ __device__ __forceinline__ void accumulate_tiled_body(const IntegrateArgs &a, co
     const int tiles_x = (a.w + kTileW - 1) / kTileW;
     const int tile = banded_block_x();  // one band of the image per XCD: neighbouring tiles hit the same voxels
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    // Record of hash slot s of this tile = element s of the tile's own slice of the record array (round 6: no numbering pass).  The
-    // thread that CLAIMS a slot fires the voxel's list-head exchange at once and files the returned predecessor in the record when the
+    // Round 6: no numbering pass and no publish round of exchanges.  The thread that CLAIMS a hash slot numbers its record (the tile's own
+    // slice of the record array) and fires the voxel's list-head exchange at once and files the returned predecessor in the record when the
     // item's eight corners are through: the ~830 k returning atomics of a frame (10.6 us of a block's 25.9 when they all went out in a
     // publish phase of their own, profiles/r06_accumulate_stamps.txt) now travel under the items' LDS work.
     const unsigned int base_rec = (unsigned int)tile * kSlots;
-    auto claim = [&](unsigned int sidx, unsigned int lin) { return atomicExch(&a.head[lin], base_rec + sidx + 1u); };
+    // (records numbered densely in claim order - recidx[slot], 4 KB of LDS: 51 KB per geometry-only block, three of which fit a CU's 160 KB,
+    // tools/microbench/lds_occupancy.hip - so that the finalize kernel finds two 32-byte records per line as before; records AT their slot's
+    // position, 68 % of the slice occupied, cost that kernel 24 MB more fetch per frame)
+    auto claim = [&](unsigned int sidx, unsigned int lin) {
+        const unsigned int ri = atomicAdd(&n_rec, 1u);
+        recidx[sidx] = (unsigned short)ri;
+        return atomicExch(&a.head[lin], base_rec + ri + 1u);
+    };
     auto file_prev = [&](int sidx, unsigned int prev) {
-        a.recs[base_rec + sidx].next = prev;
+        a.recs[base_rec + recidx[sidx]].next = prev;
         // first touch of the voxel in this call: into the tile's slice of the first-touch list, in the order the exchanges come back -
         // the order of the items, i.e. of neighbouring rays: the finalize kernel's lanes then walk neighbouring voxels (a list in hash
-        // order, which rounds 2-5 wrote, costs that kernel 2 us at 320x240 and 12 us at 640x480; an LDS copy of the list beside the live ray
-        // frames costs the third block per CU: profiles/r06_accumulate_stamps.txt)
+        // order, which rounds 2-5 wrote, costs that kernel 2 us at 320x240 and 12 us at 640x480: profiles/r06_accumulate_stamps.txt)
         if (prev == 0) a.touched[base_rec + atomicAdd(&n_new, 1u)] = keys[sidx];
     };
     // the call's range-guard decision (kGuardLatch): this kernel fills the workspace only and never skips; the finalize kernel
@@ -323,7 +330,7 @@ __device__ __forceinline__ void accumulate_tiled_body(const IntegrateArgs &a, co
     for (int j = 0; j < kSlots / kAccThreads; ++j) {
         const int s = threadIdx.x + kAccThreads * j;
         if (keys[s] == kEmpty) continue;
-        VoxelRec *r = a.recs + base_rec + s;
+        VoxelRec *r = a.recs + base_rec + recidx[s];
         r->lin = keys[s]; r->w = accw[s]; r->u = accu[s];
         r->e_last = SEM ? elast[s] : 0u; r->e_diff = SEM ? ediff[s] : 0u;
         ++n_mine;
