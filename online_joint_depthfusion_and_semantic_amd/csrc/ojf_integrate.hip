@@ -92,8 +92,11 @@ constexpr int kAccThreads = 512;
 #ifdef OJF_ACC_STAMPS  // profiling build only (tools/acc_stamps.py): phase stamps of every accumulate block, thread 0
 __device__ unsigned long long g_acc_stamps[4096][8];
 #define ACC_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_acc_stamps[blockIdx.x][i] = (i) >= 6 ? wall_clock64() : clock64(); } while (0)
+__device__ unsigned long long g_acc_items[4096][8];
+#define ACC_ITEM_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096 && (i) < 8) g_acc_items[blockIdx.x][i] = clock64(); } while (0)
 #else
 #define ACC_STAMP(i) do { } while (0)
+#define ACC_ITEM_STAMP(i) do { } while (0)
 #endif
 template <bool SEM, bool WCOMB>
 __device__ __forceinline__ void accumulate_tiled_body(const IntegrateArgs &a, const Camera &cam)
@@ -168,6 +171,7 @@ __device__ __forceinline__ void accumulate_tiled_body(const IntegrateArgs &a, co
     unsigned int n_in = 0;
     if constexpr (!WCOMB) {
         for (int item = threadIdx.x; item < kTilePix * a.n_tail; item += kAccThreads) {
+            ACC_ITEM_STAMP(4 * (item / kAccThreads));
             const int k = item / kTilePix, p = item % kTilePix;
             int rl, cl;
             tile_pixel(p, rl, cl);
@@ -184,6 +188,7 @@ __device__ __forceinline__ void accumulate_tiled_body(const IntegrateArgs &a, co
             v = v < -a.trunc ? -a.trunc : (v > a.trunc ? a.trunc : v);
             const uint8_t id_e = sem ? a.sem_ids[n] : 0;
             const unsigned int e0 = ((unsigned int)n * a.n_tail + k) * 8u + 1u;
+            ACC_ITEM_STAMP(4 * (item / kAccThreads) + 1);
             int won[8];
             unsigned int pv[8];
     #pragma unroll
@@ -223,9 +228,11 @@ __device__ __forceinline__ void accumulate_tiled_body(const IntegrateArgs &a, co
                     if (a.stats) atomicAdd(&a.stats[2], 1u);
                 }
             }
+            ACC_ITEM_STAMP(4 * (item / kAccThreads) + 2);
     #pragma unroll
             for (int q = 0; q < 8; ++q)
                 if (won[q] >= 0) file_prev(won[q], pv[q]);  // (first use of the exchanges' results: all eight were issued above)
+            ACC_ITEM_STAMP(4 * (item / kAccThreads) + 3);
         }
     } else {
         const int lane = threadIdx.x & 63;
@@ -813,6 +820,10 @@ OJF_API int ojf_integrate_entries(const float *values, const int64_t *indices, c
 extern "C" __attribute__((visibility("default"))) int ojf_debug_acc_stamps(void *host_dst, size_t bytes)
 {
     return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(ojf::g_acc_stamps), bytes < sizeof(ojf::g_acc_stamps) ? bytes : sizeof(ojf::g_acc_stamps));
+}
+extern "C" __attribute__((visibility("default"))) int ojf_debug_acc_item_stamps(void *host_dst, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(ojf::g_acc_items), bytes < sizeof(ojf::g_acc_items) ? bytes : sizeof(ojf::g_acc_items));
 }
 extern "C" __attribute__((visibility("default"))) int ojf_debug_fin_stamps(void *host_dst, size_t bytes)
 {

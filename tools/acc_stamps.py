@@ -42,6 +42,17 @@ def main():
 
     report('ojf_debug_ext_stamps', 1200, 'extract_tile_kernel', ['ray frames (wave 0) + barrier', 'items: corners, gathers (thread 0 = sample 0)', 'barrier', 'transposed stores'])
     report('ojf_debug_acc_stamps', 600, 'integrate_accumulate_tiled_kernel', ['hash clear + ray frames', 'items (corners, hash atomics, head exchanges)', 'barrier', 'record stores', 'tile count'])
+    if hasattr(lib, 'ojf_debug_acc_item_stamps'):  # thread 0's two items: loads + ray sample | eight corners | exchange results filed
+        buf = np.zeros((4096, 8), dtype=np.uint64)
+        assert lib.ojf_debug_acc_item_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.nbytes)) == 0
+        b = buf[:600].astype(np.float64)
+        b = b[(b[:, 0] > 0) & (b[:, 7] > 0)]
+        rate = 2330.0
+        for it in (0, 1):
+            d = [(b[:, 4 * it + j + 1] - b[:, 4 * it + j]) / rate for j in range(3)]
+            print('  accumulate thread 0, item %d: loads + ray sample %.2f us | eight corners (hash, claims) %.2f us | exchange results filed %.2f us (medians over %d blocks)'
+                  % (it, np.median(d[0]), np.median(d[1]), np.median(d[2]), len(b)))
+        print('  between the items: %.2f us' % np.median((b[:, 4] - b[:, 3]) / rate))
     report('ojf_debug_fin_stamps', 600, 'integrate_finalize_kernel', ['first-touch list load', 'head + old values requested', 'record walk', 'volume stores'])
 
 
