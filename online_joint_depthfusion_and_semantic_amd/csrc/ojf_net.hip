@@ -1453,7 +1453,10 @@ __global__ __launch_bounds__(256) void pool_pyramid_kernel(const PyramidArgs a)
             gave_bias_block(a.gave, reinterpret_cast<float *>(buf), reinterpret_cast<float *>(buf) + 256);
         return;
     }
-    const int lv = blockIdx.y / a.c4 + 1, cg = blockIdx.y - (lv - 1) * a.c4;  // levels of this block's group
+    // levels of this block's group.  The groups are dispatched in blockIdx.y order: the three-level blocks (three cascaded pools from one
+    // window) first, the one-level blocks and the two-head nets' pool-free row last, so that the launch ends on its cheap blocks
+    const int yg = blockIdx.y / a.c4, cg = blockIdx.y - yg * a.c4;
+    const int lv = yg < 3 ? 3 - yg : 4;
     if (lv == 4) {  // two-head nets: branch 0 of the VortexPooling = ReLU(sum of the two heads' partial entry sums + bias), no pooling
         const int tiles_x = (a.w + kPoolTW - 1) / kPoolTW;
         const int tile = banded_block_x();

@@ -24,7 +24,6 @@ cp $(find $O/kp -name '*kernel_stats.csv' | head -1) $O/predict_kernel_stats.csv
 python tools/train_throughput.py > $O/train_throughput.txt 2>&1
 python tools/train_throughput.py >> $O/train_throughput.txt 2>&1
 python bench.py --train --steps 64 --warmup 16 --repeats 5 > $O/bench_train.json 2>/dev/null
-python bench.py --train --force-group --steps 64 --warmup 16 --repeats 3 > $O/bench_train_rccl_one_rank.json 2> $O/bench_train_rccl_one_rank.err
 python tools/train_host_split.py 2>&1 | grep -v amdgpu.ids > $O/train_host_split.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktr -o ktr -- python tools/train_throughput.py > /dev/null 2> $O/ktr.err
 cp $(find $O/ktr -name '*kernel_stats.csv' | head -1) $O/train_kernel_stats.csv
