@@ -98,60 +98,108 @@ __global__ __launch_bounds__(256) void parity_emit_kernel(IntegrateArgs a, Camer
     }
 }
 
+// One WAVE per 64 consecutive slots of the sorted entry list (round 6; rounds 1-5: one lane per slot, the run heads walking their runs
+// alone - 3 busy lanes of 64 on a chain of dependent loads, 1.5 ms per frame).  The wave loads its 64 entries with one coalesced request,
+// every lane forms ITS entry's  ue = we * clamp(est)  (integrator.py:55) in parallel, and each run whose head lies in the chunk is then
+// summed in entry order with wave-uniform fp32 adds over the lanes' values (v_readlane): the same operations in the same order as the
+// reference's sequential index_add_, without a dependent load per entry.  A run that leaves the chunk pulls the next 64 slots.
+__device__ __forceinline__ float lane_f(float x, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), j)); }
+
 __global__ __launch_bounds__(256) void parity_walk_kernel(IntegrateArgs a, const unsigned int *keys, const EntryVal *vals,
                                                            size_t M, unsigned int sentinel)
 {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (a.guard && a.counters[kGuardLatch]) {  // (uniform) the net's range guard had fired when this call began: no volume is touched
-        if (i == 0) atomicAdd(a.guard + 1, 1);
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.guard + 1, 1);
         return;
     }
-    if (i >= M) return;
-    const unsigned int key = keys[i];
-    if (key == sentinel) return;
-    if (i > 0 && keys[i - 1] == key) return;  // not the head of this voxel's run
-    const size_t lin = key;
+    const int lane = threadIdx.x & 63;
+    const size_t base = ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64;
+    if (base >= M) return;  // (wave-uniform)
     const bool sem = a.id_vol != nullptr;
     const unsigned int per_pixel = (unsigned int)a.n_tail * 8u;
-    float Wsum = 0.0f, Usum = 0.0f;  // integrator.py:59-67, sequential fp32 in entry order
-    uint8_t id_old = 0, id_new = 0;
-    float s_old = 0.0f;
-    uint16_t sc_new = 0;
-    if (sem) {
-        id_old = a.id_vol[lin];
-        id_new = id_old;
-        sc_new = a.score_vol[lin];
-        s_old = h2f(sc_new);
-    }
-    unsigned int n_run = 0;
-    for (size_t j = i; j < M && keys[j] == key; ++j) {
-        const EntryVal ev = vals[j];
-        const unsigned int n = ev.e / per_pixel;
-        const unsigned int k = (ev.e / 8u) % (unsigned int)a.n_tail;
-        float v = a.est[(size_t)n * a.est_stride + k];  // pipeline.py:153-156
-        v = v < -a.trunc ? -a.trunc : (v > a.trunc ? a.trunc : v);
-        const float ue = ev.we * v;  // integrator.py:55
-        Wsum += ev.we;
-        Usum += ue;
-        if (sem) {  // integrator.py:93-124, later entries overwrite earlier ones
-            const uint8_t id_e = a.sem_ids[n];
-            const float s_e = a.sem_scores[n];
-            sc_new = f2h(s_e > s_old ? s_e : s_old);
-            if (id_old != id_e) id_new = (s_e > s_old) ? id_e : id_old;
+    // this lane's entry of a chunk: key, weight, update, semantic label / score of its pixel
+    auto load = [&](size_t at, unsigned int &key, float &we, float &ue, unsigned int &id_e, float &s_e) {
+        key = sentinel; we = 0.0f; ue = 0.0f; id_e = 0; s_e = 0.0f;
+        if (at < M) key = keys[at];
+        if (key != sentinel) {
+            const EntryVal ev = vals[at];
+            const unsigned int n = ev.e / per_pixel;
+            const unsigned int k = (ev.e / 8u) % (unsigned int)a.n_tail;
+            float v = a.est[(size_t)n * a.est_stride + k];  // pipeline.py:153-156
+            v = v < -a.trunc ? -a.trunc : (v > a.trunc ? a.trunc : v);
+            we = ev.we;
+            ue = ev.we * v;  // integrator.py:55
+            if (sem) { id_e = a.sem_ids[n]; s_e = a.sem_scores[n]; }
         }
-        ++n_run;
+    };
+    unsigned int key, id_e;
+    float we, ue, s_e;
+    load(base + lane, key, we, ue, id_e, s_e);
+    unsigned int prevkey = (unsigned int)__shfl_up((int)key, 1, 64);
+    if (lane == 0) prevkey = base > 0 ? keys[base - 1] : sentinel;
+    unsigned long long heads = __ballot(key != sentinel && key != prevkey);
+    unsigned int runs = 0, entries = 0;
+    while (heads) {  // (wave-uniform) the runs that begin in this chunk, in order
+        const int h = __builtin_amdgcn_readfirstlane(__builtin_ctzll(heads));
+        heads &= heads - 1;
+        const unsigned int key_h = (unsigned int)__builtin_amdgcn_readlane((int)key, h);
+        const size_t lin = key_h;
+        float Wsum = 0.0f, Usum = 0.0f;  // integrator.py:59-67, sequential fp32 in entry order
+        unsigned int id_old = 0, id_new = 0;
+        float s_old = 0.0f;
+        uint16_t sc_new = 0;
+        if (sem) {
+            id_old = a.id_vol[lin];
+            id_new = id_old;
+            sc_new = a.score_vol[lin];
+            s_old = h2f(sc_new);
+        }
+        unsigned int n_run = 0;
+        // the run's slots inside this chunk are the contiguous lanes h .. end - 1 (sorted keys)
+        int end = h + __builtin_popcountll(__ballot(key == key_h && lane >= h));
+        auto add = [&](float we_c, float ue_c, unsigned int id_c, float s_c, int from, int to) {
+            for (int j = from; j < to; ++j) {  // (wave-uniform: every lane forms the same sums)
+                Wsum += lane_f(we_c, j);
+                Usum += lane_f(ue_c, j);
+                if (sem) {  // integrator.py:93-124, later entries overwrite earlier ones
+                    const unsigned int id_j = (unsigned int)__builtin_amdgcn_readlane((int)id_c, j);
+                    const float s_j = lane_f(s_c, j);
+                    sc_new = f2h(s_j > s_old ? s_j : s_old);
+                    if (id_old != id_j) id_new = (s_j > s_old) ? id_j : id_old;
+                }
+                ++n_run;
+            }
+        };
+        add(we, ue, id_e, s_e, h, end);
+        size_t next = base + 64;
+        while (end == 64 && next < M) {  // the run goes on behind the chunk: pull the next 64 slots (rare: a run is ~22 entries)
+            unsigned int key2, id2;
+            float we2, ue2, s2;
+            load(next + lane, key2, we2, ue2, id2, s2);
+            const int len = __builtin_popcountll(__ballot(key2 == key_h));  // (a prefix of the chunk: sorted keys)
+            add(we2, ue2, id2, s2, 0, len);
+            end = len == 64 ? 64 : 0;
+            next += 64;
+        }
+        if (lane == 0) {
+            const float w_old = h2f(a.wgt[lin]), v_old = h2f(a.tsdf[lin]);
+            const float w_new = w_old + Wsum;
+            const float num = w_old * v_old + Usum;
+            a.wgt[lin] = f2h(w_new);
+            a.tsdf[lin] = f2h(num / w_new);
+            if (sem) {
+                a.score_vol[lin] = sc_new;
+                a.id_vol[lin] = (uint8_t)id_new;
+            }
+        }
+        ++runs;
+        entries += n_run;
     }
-    const float w_old = h2f(a.wgt[lin]), v_old = h2f(a.tsdf[lin]);
-    const float w_new = w_old + Wsum;
-    const float num = w_old * v_old + Usum;
-    a.wgt[lin] = f2h(w_new);
-    a.tsdf[lin] = f2h(num / w_new);
-    if (sem) {
-        a.score_vol[lin] = sc_new;
-        a.id_vol[lin] = id_new;
+    // test / profiling only (ojf_integrate's stats_dev): two same-address atomics per wave - 134 k per frame - were 1.3 ms of this kernel's 1.5
+    if (a.stats && lane == 0 && runs) {
+        atomicAdd(&a.counters[0], runs);
+        atomicAdd(&a.counters[1], entries);
     }
-    atomicAdd(&a.counters[0], 1u);
-    atomicAdd(&a.counters[1], n_run);
 }
 
 __global__ void parity_stats_kernel(IntegrateArgs a)
