@@ -159,6 +159,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise OjfError('libojf.so not found at {}: build it with `python -c "import __graft_entry__ as g; '
                        'g.build()"` or `make -C {}/csrc` (there is no CPU fallback)'.format(LIB_PATH, _HERE))
+    # torch FIRST: it ships its own libamdhip64, and a process that has already loaded the system one through libojf.so ends up with two HIP
+    # runtimes - the second to initialise sees no device ("no ROCm-capable device is detected": __graft_entry__.build() followed by smoke() in
+    # one interpreter, tools/bench_with_lib.py).  With torch's copy loaded, libojf.so's dependency resolves to it by soname.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here == header/library mismatch
